@@ -1,0 +1,814 @@
+/*
+ * fw_oracle.c -- CPU restatement of the fwumious_wabbit LR+FFM hot path (see fw_oracle.h).
+ *
+ * TEST INFRASTRUCTURE ONLY: parity oracle + CPU baseline.  Never linked into the product.
+ *
+ * Compile with -ffp-contract=off (no FMA contraction): the reference's default build
+ * (`cargo build --release`, x86_64 baseline = SSE2) has no `target_feature="fma"`, so
+ * block_ffm.rs:933-944 (mul then add) is the variant restated here.
+ *
+ * Every function cites the reference lines it follows (paths relative to /root/reference/src/).
+ */
+#include "fw_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+/* ------------------------------------------------------------------ bits */
+static inline uint32_t f2u(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+static inline float u2f(uint32_t u) {
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+/* ------------------------------------------------------------------ optimizers */
+
+/* optimizer.rs:121-144 OptimizerAdagradLUT::init */
+void fwo_lut_init(float *lut, float learning_rate, float power_t, float init_acc) {
+    float minus_power_t = -power_t;
+    for (uint32_t x = 0; x < FWO_LUT_SIZE; x++) {
+        float float_x = u2f(x << (31 - FWO_LUT_BITS)) + init_acc;
+        float float_x_plus_one = u2f((x + 1) << (31 - FWO_LUT_BITS)) + init_acc;
+        float val = learning_rate * (powf(float_x, minus_power_t) + powf(float_x_plus_one, minus_power_t)) * 0.5f;
+        if (isnan(val) || isinf(val)) val = learning_rate;
+        lut[x] = val;
+    }
+}
+
+/* optimizer.rs:36-38 */
+float fwo_step_sgd(float lr, float g) { return g * lr; }
+
+/* optimizer.rs:76-88 */
+float fwo_step_flex(float lr, float minus_power_t, float g, float *acc) {
+    float gradient_squared = g * g;
+    float new_acc = *acc + gradient_squared;
+    *acc = new_acc;
+    float update = g * lr * powf(new_acc, minus_power_t);
+    if (isnan(update) || isinf(update)) return 0.0f;
+    return update;
+}
+
+/* optimizer.rs:147-156 */
+float fwo_step_lut(const float *lut, float g, float *acc) {
+    float gradient_squared = g * g;
+    float new_acc = *acc + gradient_squared;
+    *acc = new_acc;
+    uint32_t key = f2u(new_acc) >> (31 - FWO_LUT_BITS);
+    return g * lut[key];
+}
+
+/* ------------------------------------------------------------------ hashing */
+
+/* murmur3 x86_32 (Austin Appleby, public domain algorithm) == fasthash::murmur3::hash32_with_seed,
+ * call sites parser.rs:83, 382-385; pinned by the parser.rs KATs in tests/golden/hash_kat.json. */
+uint32_t fwo_murmur3_32(const uint8_t *data, size_t len, uint32_t seed) {
+    const uint32_t c1 = 0xcc9e2d51u, c2 = 0x1b873593u;
+    uint32_t h1 = seed;
+    size_t nblocks = len / 4;
+    for (size_t i = 0; i < nblocks; i++) {
+        uint32_t k1;
+        memcpy(&k1, data + 4 * i, 4);
+        k1 *= c1;
+        k1 = (k1 << 15) | (k1 >> 17);
+        k1 *= c2;
+        h1 ^= k1;
+        h1 = (h1 << 13) | (h1 >> 19);
+        h1 = h1 * 5 + 0xe6546b64u;
+    }
+    const uint8_t *tail = data + nblocks * 4;
+    uint32_t k1 = 0;
+    switch (len & 3) {
+    case 3: k1 ^= (uint32_t)tail[2] << 16; /* fallthrough */
+    case 2: k1 ^= (uint32_t)tail[1] << 8;  /* fallthrough */
+    case 1:
+        k1 ^= tail[0];
+        k1 *= c1;
+        k1 = (k1 << 15) | (k1 >> 17);
+        k1 *= c2;
+        h1 ^= k1;
+    }
+    h1 ^= (uint32_t)len;
+    h1 ^= h1 >> 16;
+    h1 *= 0x85ebca6bu;
+    h1 ^= h1 >> 13;
+    h1 *= 0xc2b2ae35u;
+    h1 ^= h1 >> 16;
+    return h1;
+}
+
+/* merand48 0.1.0 (= VowpalWabbit rand48.cc merand48): one LCG step from `seed`, 23 mantissa bits
+ * -> [0,1).  Call sites block_ffm.rs:801, 811.  PARITY UNPINNED (no reference test observes it). */
+float fwo_merand48(uint64_t seed) {
+    const uint64_t a = 0xeece66d5deece66dULL, c = 2147483647ULL;
+    seed = a * seed + c;
+    uint32_t temp = (uint32_t)((seed >> 25) & 0x7FFFFF) | (127u << 23);
+    return u2f(temp) - 1.0f;
+}
+
+/* ------------------------------------------------------------------ model */
+
+struct fwo_model {
+    fwo_config cfg;
+    uint64_t lr_len;  /* 1 << bit_precision, block_lr.rs:67 */
+    float *lr;        /* interleaved {weight, acc}, block_helpers.rs:23-28 */
+    uint64_t ffm_len; /* (1<<ffm_bits) + F*k, block_ffm.rs:92-94 */
+    float *ffm_w, *ffm_acc; /* separate arrays, block_ffm.rs:40-41 */
+    float lut_lr[FWO_LUT_SIZE], lut_ffm[FWO_LUT_SIZE];
+    /* per-thread scratch lives on the caller's stack/heap: see fwo_scratch */
+};
+
+typedef struct {
+    float *contra;  /* F*F*k  (FFM_CONTRA_BUF_LEN role, regressor.rs:23) */
+    float *grads;   /* n_ffm*F*k (local_data_ffm_values, block_ffm.rs:294-312) */
+    uint32_t grads_cap;
+    float *ffm_out; /* F*F */
+    float *lr_out;  /* C */
+    float *tri;     /* F(F+1)/2 */
+} fwo_scratch;
+
+static void scratch_init(fwo_scratch *s, const fwo_config *c) {
+    uint32_t F = c->ffm_num_fields, k = c->ffm_k;
+    s->contra = (float *)malloc(sizeof(float) * (size_t)(F * F * k + 16));
+    s->grads = NULL;
+    s->grads_cap = 0;
+    s->ffm_out = (float *)malloc(sizeof(float) * (size_t)(F * F + 1));
+    s->lr_out = (float *)malloc(sizeof(float) * (size_t)(c->num_combos + 1));
+    s->tri = (float *)malloc(sizeof(float) * (size_t)(F * (F + 1) / 2 + 1));
+}
+static void scratch_free(fwo_scratch *s) {
+    free(s->contra);
+    free(s->grads);
+    free(s->ffm_out);
+    free(s->lr_out);
+    free(s->tri);
+}
+
+fwo_model *fwo_create(const fwo_config *cfg) {
+    /* block_ffm.rs:96-101 guard */
+    if ((uint64_t)cfg->ffm_k * cfg->ffm_num_fields * cfg->ffm_num_fields > 41472) return NULL;
+    fwo_model *m = (fwo_model *)calloc(1, sizeof(fwo_model));
+    m->cfg = *cfg;
+    m->lr_len = 1ULL << cfg->bit_precision;
+    m->ffm_len = cfg->ffm_k > 0 ? (1ULL << cfg->ffm_bit_precision) + (uint64_t)cfg->ffm_num_fields * cfg->ffm_k : 0;
+    m->lr = (float *)calloc(m->lr_len * 2, sizeof(float));
+    if (m->ffm_len) {
+        m->ffm_w = (float *)calloc(m->ffm_len, sizeof(float));
+        m->ffm_acc = (float *)calloc(m->ffm_len, sizeof(float));
+    }
+    /* block_lr.rs:63-65, block_ffm.rs:86-91: each block owns its optimizer instance */
+    fwo_lut_init(m->lut_lr, cfg->learning_rate, cfg->power_t, cfg->init_acc_gradient);
+    fwo_lut_init(m->lut_ffm, cfg->ffm_learning_rate, cfg->ffm_power_t, cfg->ffm_init_acc_gradient);
+    return m;
+}
+
+void fwo_free(fwo_model *m) {
+    if (!m) return;
+    free(m->lr);
+    free(m->ffm_w);
+    free(m->ffm_acc);
+    free(m);
+}
+
+/* initial_data(): optimizer.rs:40-42 (SGD: none), 90-92 (Flex: init_acc), 158-161 (LUT: 0.0) */
+static float initial_acc(int optimizer, float init_acc) {
+    return optimizer == FWO_OPT_ADAGRAD_FLEX ? init_acc : 0.0f;
+}
+
+void fwo_init_weights(fwo_model *m) {
+    const fwo_config *c = &m->cfg;
+    /* block_lr.rs:97-105: weight 0.0, acc initial_data() */
+    float a0 = initial_acc(c->optimizer, c->init_acc_gradient);
+    for (uint64_t i = 0; i < m->lr_len; i++) {
+        m->lr[2 * i] = 0.0f;
+        m->lr[2 * i + 1] = a0;
+    }
+    if (!m->ffm_len) return;
+    /* block_ffm.rs:784-829 */
+    float fa0 = initial_acc(c->optimizer, c->ffm_init_acc_gradient);
+    if (c->ffm_init_width == 0.0f) {
+        float ffm_one_over_k_root = 1.0f / sqrtf((float)c->ffm_k) / 50.0f;
+        for (uint64_t i = 0; i < m->ffm_len; i++) {
+            m->ffm_w[i] = (1.0f * fwo_merand48(m->ffm_len + i) - 0.5f) * ffm_one_over_k_root;
+            m->ffm_acc[i] = fa0;
+        }
+    } else {
+        float zero_half_band_width = c->ffm_init_width * c->ffm_init_zero_band * 0.5f;
+        float band_width = c->ffm_init_width * (1.0f - c->ffm_init_zero_band);
+        for (uint64_t i = 0; i < m->ffm_len; i++) {
+            float w = fwo_merand48(i) * band_width - band_width * 0.5f;
+            if (w > 0.0f) w += zero_half_band_width;
+            else w -= zero_half_band_width;
+            w += c->ffm_init_center;
+            m->ffm_w[i] = w;
+            m->ffm_acc[i] = fa0;
+        }
+    }
+}
+
+/* block_ffm.rs:1228-1235 / persistence.rs:315-330 */
+void fwo_ffm_fill(fwo_model *m, float w) {
+    float fa0 = initial_acc(m->cfg.optimizer, m->cfg.ffm_init_acc_gradient);
+    for (uint64_t i = 0; i < m->ffm_len; i++) {
+        m->ffm_w[i] = w;
+        m->ffm_acc[i] = fa0;
+    }
+}
+
+float *fwo_lr_table(fwo_model *m, uint64_t *n) {
+    if (n) *n = m->lr_len;
+    return m->lr;
+}
+float *fwo_ffm_weights(fwo_model *m, uint64_t *n) {
+    if (n) *n = m->ffm_len;
+    return m->ffm_w;
+}
+float *fwo_ffm_acc(fwo_model *m, uint64_t *n) {
+    if (n) *n = m->ffm_len;
+    return m->ffm_acc;
+}
+const float *fwo_lut_lr(fwo_model *m) { return m->lut_lr; }
+const float *fwo_lut_ffm(fwo_model *m) { return m->lut_ffm; }
+
+static inline float opt_step(int optimizer, float lr, float power_t, const float *lut, float g, float *acc) {
+    switch (optimizer) {
+    case FWO_OPT_SGD: return fwo_step_sgd(lr, g);
+    case FWO_OPT_ADAGRAD_FLEX: return fwo_step_flex(lr, -power_t, g, acc);
+    default: return fwo_step_lut(lut, g, acc);
+    }
+}
+
+/* ------------------------------------------------------------------ blocks */
+
+/* block_loss_functions.rs:15-17 */
+static inline float logistic(float t) { return 1.0f / (1.0f + expf(-t)); }
+
+/* block_lr.rs:28-47 */
+static void lr_forward(const fwo_model *m, const fwo_lr_entry *lr, uint32_t n_lr, float *lr_out) {
+    for (uint32_t c = 0; c < m->cfg.num_combos; c++) lr_out[c] = 0.0f;
+    for (uint32_t i = 0; i < n_lr; i++) lr_out[lr[i].combo_index] += m->lr[2 * (uint64_t)lr[i].hash] * lr[i].value;
+}
+
+/* block_lr.rs:135-150 */
+static void lr_update(fwo_model *m, const fwo_lr_entry *lr, uint32_t n_lr, const float *lr_out) {
+    const fwo_config *c = &m->cfg;
+    for (uint32_t i = 0; i < n_lr; i++) {
+        uint64_t h = lr[i].hash;
+        float gradient = lr_out[lr[i].combo_index] * lr[i].value;
+        float update = opt_step(c->optimizer, c->learning_rate, c->power_t, m->lut_lr, gradient, &m->lr[2 * h + 1]);
+        m->lr[2 * h] -= update;
+    }
+}
+
+/* block_misc.rs:864-883 */
+void fwo_triangle_forward(const float *in, uint32_t width, float *out) {
+    uint32_t o = 0;
+    for (uint32_t i = 0; i < width; i++) {
+        for (uint32_t j = 0; j < i; j++) out[o++] = in[i * width + j] * 2.0f;
+        out[o++] = in[i * width + i];
+    }
+}
+
+/* block_misc.rs:822-832 */
+void fwo_triangle_backward(const float *gout, uint32_t width, float *gin) {
+    uint32_t o = 0;
+    for (uint32_t i = 0; i < width; i++)
+        for (uint32_t j = 0; j <= i; j++) {
+            gin[i * width + j] = gout[o];
+            gin[j * width + i] = gout[o];
+            o++;
+        }
+}
+
+/* block_ffm.rs:163-261: pass 1 (contra fields) + pass 2 (gradient cache + outputs) */
+static void ffm_fb_forward(const fwo_model *m, const fwo_ffm_entry *fb, uint32_t n, fwo_scratch *s) {
+    const uint32_t F = m->cfg.ffm_num_fields, k = m->cfg.ffm_k, fc = F * k;
+    const float *W = m->ffm_w;
+    float *contra = s->contra, *out = s->ffm_out, *G = s->grads;
+    for (uint32_t i = 0; i < F * F; i++) out[i] = 0.0f; /* 137-139 */
+
+    uint32_t idx = 0;
+    for (uint32_t field = 0; field < F; field++) { /* 165-217 */
+        uint32_t field_k = field * k;
+        if (idx >= n || fb[idx].contra_field_index > field_k) {
+            uint32_t off = field_k;
+            for (uint32_t z = 0; z < F; z++) {
+                for (uint32_t kk = off; kk < off + k; kk++) contra[kk] = 0.0f;
+                off += fc;
+            }
+            continue;
+        }
+        int first = 1;
+        while (idx < n && fb[idx].contra_field_index == field_k) {
+            float v = fb[idx].value;
+            uint64_t fi = fb[idx].hash;
+            uint32_t off = field_k;
+            if (first) {
+                for (uint32_t z = 0; z < F; z++) {
+                    for (uint32_t kk = 0; kk < k; kk++) contra[off + kk] = W[fi + kk] * v;
+                    off += fc;
+                    fi += k;
+                }
+                first = 0;
+            } else {
+                for (uint32_t z = 0; z < F; z++) {
+                    for (uint32_t kk = 0; kk < k; kk++) contra[off + kk] += W[fi + kk] * v;
+                    off += fc;
+                    fi += k;
+                }
+            }
+            idx++;
+        }
+    }
+
+    uint32_t goff = 0;
+    for (uint32_t i = 0; i < n; i++) { /* 220-261 */
+        float v = fb[i].value;
+        uint64_t fi = fb[i].hash;
+        uint32_t cfi = fb[i].contra_field_index;
+        uint32_t contra_offset = cfi * F;
+        uint32_t contra_offset2 = contra_offset / k;
+        uint32_t vv = 0;
+        for (uint32_t z = 0; z < F; z++) {
+            float correction = 0.0f;
+            uint64_t vfi = fi + vv;
+            uint32_t vco = contra_offset + vv;
+            if (vv == cfi) {
+                for (uint32_t kk = 0; kk < k; kk++) {
+                    float w = W[vfi + kk];
+                    float contra_weight = contra[vco + kk] - w * v;
+                    float gradient = v * contra_weight;
+                    G[goff + kk] = gradient;
+                    correction += w * gradient;
+                }
+            } else {
+                for (uint32_t kk = 0; kk < k; kk++) {
+                    float contra_weight = contra[vco + kk];
+                    float gradient = v * contra_weight;
+                    G[goff + kk] = gradient;
+                    float w = W[vfi + kk];
+                    correction += w * gradient;
+                }
+            }
+            out[contra_offset2 + z] += correction * 0.5f;
+            vv += k;
+            goff += k;
+        }
+    }
+}
+
+/* block_ffm.rs:265-288 */
+static void ffm_fb_update(fwo_model *m, const fwo_ffm_entry *fb, uint32_t n, fwo_scratch *s) {
+    const fwo_config *c = &m->cfg;
+    const uint32_t F = c->ffm_num_fields, k = c->ffm_k;
+    const float *out = s->ffm_out, *G = s->grads;
+    uint32_t local_index = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        uint64_t fi = fb[i].hash;
+        uint32_t contra_offset = (fb[i].contra_field_index * F) / k;
+        for (uint32_t z = 0; z < F; z++) {
+            float general_gradient = out[contra_offset + z];
+            for (uint32_t kk = 0; kk < k; kk++) {
+                float feature_value = G[local_index];
+                float gradient = general_gradient * feature_value;
+                float update = opt_step(c->optimizer, c->ffm_learning_rate, c->ffm_power_t, m->lut_ffm, gradient,
+                                        &m->ffm_acc[fi]);
+                m->ffm_w[fi] -= update;
+                local_index++;
+                fi++;
+            }
+        }
+    }
+}
+
+/* hadd_ps, block_ffm.rs:106-114: (r0+r2)+(r1+r3) */
+static inline float hadd4(const float r[4]) { return (r[0] + r[2]) + (r[1] + r[3]); }
+
+/* 8-wide dot as in calculate_interactions (block_ffm.rs:1132-1139, 1168-1176):
+ * acc_0 = a[0..4]*b[0..4]; acc_1 = a[4..8]*b[4..8]; hadd(acc_0+acc_1) */
+static inline float dot8_sse(const float *a, const float *b) {
+    float s[4];
+    for (int l = 0; l < 4; l++) s[l] = a[l] * b[l] + a[4 + l] * b[4 + l];
+    return hadd4(s);
+}
+
+/* block_ffm.rs:316-440 (forward) with prepare_contra_fields 964-1104 and
+ * calculate_interactions 1107-1201.  Non-FMA variant (933-944). */
+static void ffm_forward(const fwo_model *m, const fwo_ffm_entry *fb, uint32_t n, fwo_scratch *s) {
+    const uint32_t F = m->cfg.ffm_num_fields, k = m->cfg.ffm_k, R = F * k;
+    const float *W = m->ffm_w;
+    float *contra = s->contra, *out = s->ffm_out;
+    for (uint32_t i = 0; i < F * F; i++) out[i] = 0.0f;
+
+    uint32_t idx = 0;
+    for (uint32_t field = 0; field < F; field++) {
+        uint32_t field_k = field * k;
+        uint32_t offset = field_k * F;
+        if (idx >= n || fb[idx].contra_field_index > field_k) { /* 362-383 */
+            for (uint32_t z = 0; z < R; z++) contra[offset + z] = 0.0f;
+            continue;
+        }
+        uint32_t ffm_index = field * (F + 1);
+        int first = 1;
+        while (idx < n && fb[idx].contra_field_index == field_k) {
+            uint64_t fi = fb[idx].hash;
+            float v = fb[idx].value;
+            /* prepare_contra_fields, 964-1104: element-wise, the 16-float unrolling does not
+             * change per-element arithmetic */
+            if (first) {
+                first = 0;
+                if (v == 1.0f) {
+                    for (uint32_t z = 0; z < R; z++) contra[offset + z] = W[fi + z];
+                } else {
+                    for (uint32_t z = 0; z < R; z++) contra[offset + z] = W[fi + z] * v;
+                }
+            } else if (v == 1.0f) {
+                for (uint32_t z = 0; z < R; z++) contra[offset + z] = W[fi + z] + contra[offset + z];
+            } else {
+                for (uint32_t z = 0; z < R; z++) {
+                    float t = W[fi + z] * v; /* _mm_mul_ps then _mm_add_ps (933-944) */
+                    contra[offset + z] = t + contra[offset + z];
+                }
+            }
+            /* 418-426: diagonal pre-correction */
+            float correction = 0.0f;
+            for (uint64_t kk = fi + field_k; kk < fi + field_k + k; kk++) correction += W[kk] * W[kk];
+            out[ffm_index] -= correction * 0.5f * v * v;
+            idx++;
+        }
+    }
+
+    /* calculate_interactions, 1107-1201 */
+    const uint32_t LANES = 8;
+    const uint32_t k_end = k - k % LANES;
+    for (uint32_t f1 = 0; f1 < F; f1++) {
+        uint32_t f1_offset = f1 * R;
+        uint32_t f1_ffmk = f1 * k;
+        uint32_t f1_offset_ffmk = f1_offset + f1_ffmk;
+        float cf = 0.0f;
+        if (k == LANES) {
+            cf = dot8_sse(contra + f1_offset_ffmk, contra + f1_offset_ffmk);
+        } else {
+            for (uint32_t b = 0; b < k_end; b += LANES)
+                cf += dot8_sse(contra + f1_offset_ffmk + b, contra + f1_offset_ffmk + b);
+            for (uint32_t kk = k_end; kk < k; kk++)
+                cf += contra[f1_offset_ffmk + kk] * contra[f1_offset_ffmk + kk];
+        }
+        out[f1 * F + f1] += cf * 0.5f;
+
+        uint32_t f2_offset_ffmk = f1_offset + f1_ffmk;
+        for (uint32_t f2 = f1 + 1; f2 < F; f2++) {
+            f2_offset_ffmk += R;
+            f1_offset_ffmk += k;
+            float c = 0.0f;
+            if (k == LANES) {
+                c = dot8_sse(contra + f1_offset_ffmk, contra + f2_offset_ffmk);
+            } else {
+                for (uint32_t b = 0; b < k_end; b += LANES)
+                    c += dot8_sse(contra + f1_offset_ffmk + b, contra + f2_offset_ffmk + b);
+                for (uint32_t kk = k_end; kk < k; kk++) c += contra[f1_offset_ffmk + kk] * contra[f2_offset_ffmk + kk];
+            }
+            c *= 0.5f;
+            out[f1 * F + f2] += c;
+            out[f2 * F + f1] += c;
+        }
+    }
+}
+
+/* block_loss_functions.rs:105-153; returns p, writes general gradient */
+static float sigmoid_block(const float *a, uint32_t na, const float *b, uint32_t nb, float label, float importance,
+                           float *general_gradient) {
+    float wsum = 0.0f; /* iter().sum(): left fold over the joined span (LR slots, then triangle) */
+    for (uint32_t i = 0; i < na; i++) wsum += a[i];
+    for (uint32_t i = 0; i < nb; i++) wsum += b[i];
+    float p, g;
+    if (isnan(wsum)) {
+        p = logistic(0.0f);
+        g = 0.0f;
+    } else if (wsum < -50.0f) {
+        p = logistic(-50.0f);
+        g = 0.0f;
+    } else if (wsum > 50.0f) {
+        p = logistic(50.0f);
+        g = 0.0f;
+    } else {
+        p = logistic(wsum);
+        g = -(label - p) * importance;
+    }
+    if (general_gradient) *general_gradient = g;
+    return p;
+}
+
+static void ensure_grads(fwo_scratch *s, uint32_t need) {
+    if (need > s->grads_cap) {
+        free(s->grads);
+        s->grads_cap = need + 1024;
+        s->grads = (float *)malloc(sizeof(float) * (size_t)s->grads_cap);
+    }
+}
+
+/* The forward_backward chain (block_helpers.rs:219-228) for [LR, FFM, Triangle, Sigmoid]
+ * (REGRESSOR) or [FFM, Sigmoid] (FFM_ONLY). */
+static float chain_forward_backward(fwo_model *m, fwo_scratch *s, const fwo_lr_entry *lr, uint32_t n_lr,
+                                    const fwo_ffm_entry *ffm, uint32_t n_ffm, float label, float importance,
+                                    int update) {
+    const fwo_config *c = &m->cfg;
+    const uint32_t F = c->ffm_num_fields;
+    const int has_ffm = c->ffm_k > 0;
+    float g, p;
+    if (c->wiring == FWO_WIRING_FFM_ONLY) {
+        ensure_grads(s, n_ffm * F * c->ffm_k);
+        ffm_fb_forward(m, ffm, n_ffm, s);
+        p = sigmoid_block(s->ffm_out, F * F, NULL, 0, label, importance, &g);
+        for (uint32_t i = 0; i < F * F; i++) s->ffm_out[i] = g; /* block_loss_functions.rs:148-151 */
+        if (update) ffm_fb_update(m, ffm, n_ffm, s);
+        return p;
+    }
+    lr_forward(m, lr, n_lr, s->lr_out);
+    uint32_t T = 0;
+    if (has_ffm) {
+        ensure_grads(s, n_ffm * F * c->ffm_k);
+        ffm_fb_forward(m, ffm, n_ffm, s);
+        fwo_triangle_forward(s->ffm_out, F, s->tri);
+        T = F * (F + 1) / 2;
+    }
+    p = sigmoid_block(s->lr_out, c->num_combos, s->tri, T, label, importance, &g);
+    for (uint32_t i = 0; i < c->num_combos; i++) s->lr_out[i] = g;
+    if (has_ffm) {
+        for (uint32_t i = 0; i < T; i++) s->tri[i] = g;
+        /* Triangle mirrors only when update (block_misc.rs:812-833); FFM update reads ffm_out only if update */
+        if (update) {
+            fwo_triangle_backward(s->tri, F, s->ffm_out);
+            ffm_fb_update(m, ffm, n_ffm, s); /* FFM update runs before LR's (block_lr.rs:133-150) */
+        }
+    }
+    if (update) lr_update(m, lr, n_lr, s->lr_out);
+    return p;
+}
+
+static float chain_forward(const fwo_model *m, fwo_scratch *s, const fwo_lr_entry *lr, uint32_t n_lr,
+                           const fwo_ffm_entry *ffm, uint32_t n_ffm) {
+    const fwo_config *c = &m->cfg;
+    const uint32_t F = c->ffm_num_fields;
+    if (c->wiring == FWO_WIRING_FFM_ONLY) {
+        ffm_forward(m, ffm, n_ffm, s);
+        return sigmoid_block(s->ffm_out, F * F, NULL, 0, 0.0f, 0.0f, NULL);
+    }
+    lr_forward(m, lr, n_lr, s->lr_out);
+    uint32_t T = 0;
+    if (c->ffm_k > 0) {
+        ffm_forward(m, ffm, n_ffm, s);
+        fwo_triangle_forward(s->ffm_out, F, s->tri);
+        T = F * (F + 1) / 2;
+    }
+    return sigmoid_block(s->lr_out, c->num_combos, s->tri, T, 0.0f, 0.0f, NULL);
+}
+
+float fwo_forward_backward(fwo_model *m, const fwo_lr_entry *lr, uint32_t n_lr, const fwo_ffm_entry *ffm,
+                           uint32_t n_ffm, float label, float importance, int update) {
+    fwo_scratch s;
+    scratch_init(&s, &m->cfg);
+    float p = chain_forward_backward(m, &s, lr, n_lr, ffm, n_ffm, label, importance, update);
+    scratch_free(&s);
+    return p;
+}
+
+float fwo_predict(fwo_model *m, const fwo_lr_entry *lr, uint32_t n_lr, const fwo_ffm_entry *ffm, uint32_t n_ffm) {
+    fwo_scratch s;
+    scratch_init(&s, &m->cfg);
+    float p = chain_forward(m, &s, lr, n_lr, ffm, n_ffm);
+    scratch_free(&s);
+    return p;
+}
+
+/* regressor.rs:356-379 */
+static float learn_s(fwo_model *m, fwo_scratch *s, const fwo_lr_entry *lr, uint32_t n_lr, const fwo_ffm_entry *ffm,
+                     uint32_t n_ffm, float label, float importance, int update) {
+    update = update && (importance != 0.0f);
+    if (!update) return chain_forward(m, s, lr, n_lr, ffm, n_ffm);
+    return chain_forward_backward(m, s, lr, n_lr, ffm, n_ffm, label, importance, 1);
+}
+
+float fwo_learn(fwo_model *m, const fwo_lr_entry *lr, uint32_t n_lr, const fwo_ffm_entry *ffm, uint32_t n_ffm,
+                float label, float importance, int update) {
+    fwo_scratch s;
+    scratch_init(&s, &m->cfg);
+    float p = learn_s(m, &s, lr, n_lr, ffm, n_ffm, label, importance, update);
+    scratch_free(&s);
+    return p;
+}
+
+/* ------------------------------------------------------------------ translation */
+
+#define FWO_HEADER_LEN 3u               /* parser.rs:13 */
+#define FWO_IS_NOT_SINGLE_MASK (1u << 31) /* parser.rs:17 */
+#define FWO_VOWPAL_FNV_PRIME 16777619u  /* feature_buffer.rs:6 */
+#define FWO_CONSTANT_HASH 11650396u     /* feature_buffer.rs:8 */
+
+uint32_t fwo_lr_hash_mask(uint32_t bit_precision) { return (uint32_t)((1ULL << bit_precision) - 1); }
+
+/* feature_buffer.rs:141-148 */
+uint32_t fwo_ffm_hash_mask(uint32_t ffm_bits, uint32_t ffm_k) {
+    uint32_t bits = 0;
+    while (ffm_k > (1u << bits)) bits++;
+    uint32_t dimensions_mask = (1u << bits) - 1;
+    return ((uint32_t)((1ULL << ffm_bits) - 1)) ^ dimensions_mask;
+}
+
+typedef struct {
+    uint32_t hash;
+    float value;
+} hv;
+
+/* feature_reader! (feature_buffer.rs:47-108), primitive namespaces only.
+ * Appends (hash, value) pairs of namespace `ns` to out; returns count or -1 on overflow. */
+static int read_ns(const uint32_t *rec, uint32_t ns, int is_f32, hv *out, uint32_t cap) {
+    uint32_t first_token = rec[ns + FWO_HEADER_LEN];
+    if ((first_token & FWO_IS_NOT_SINGLE_MASK) == 0) {
+        if (cap < 1) return -1;
+        out[0].hash = first_token;
+        out[0].value = 1.0f;
+        return 1;
+    }
+    uint32_t start = (first_token >> 16) & 0x3fff, end = first_token & 0xffff;
+    int n = 0;
+    for (uint32_t o = start; o < end; o += 2) {
+        if ((uint32_t)n >= cap) return -1;
+        out[n].hash = rec[o];
+        out[n].value = is_f32 ? 1.0f : u2f(rec[o + 1]);
+        n++;
+    }
+    return n;
+}
+
+#define FWO_TMP_CAP 4096
+
+int fwo_translate(const fwo_translator *t, const uint32_t *rec, fwo_lr_entry *lr_out, uint32_t lr_cap, uint32_t *n_lr_out,
+                  fwo_ffm_entry *ffm_out, uint32_t ffm_cap, uint32_t *n_ffm_out, float *label, float *importance) {
+    const uint32_t lr_mask = fwo_lr_hash_mask(t->bit_precision);
+    uint32_t n_lr = 0, n_ffm = 0;
+    *label = (float)rec[1];   /* feature_buffer.rs:187 */
+    *importance = u2f(rec[2]); /* 188-189 */
+    hv a[FWO_TMP_CAP], b[FWO_TMP_CAP], cur[FWO_TMP_CAP];
+    for (uint32_t ci = 0; ci < t->n_combos; ci++) { /* 194-267 */
+        uint32_t s = t->combo_off[ci], e = t->combo_off[ci + 1];
+        float cw = t->combo_weight[ci];
+        int na = read_ns(rec, t->combo_ns[s], t->combo_ns_f32[s], a, FWO_TMP_CAP);
+        if (na < 0) return -1;
+        if (e - s == 1) {
+            for (int i = 0; i < na; i++) {
+                if (n_lr >= lr_cap) return -1;
+                lr_out[n_lr].hash = a[i].hash & lr_mask;
+                lr_out[n_lr].value = a[i].value * cw;
+                lr_out[n_lr].combo_index = ci;
+                n_lr++;
+            }
+            continue;
+        }
+        hv *in = a, *out = b;
+        for (uint32_t mi = s + 1; mi < e; mi++) { /* 235-258 */
+            int nc = read_ns(rec, t->combo_ns[mi], t->combo_ns_f32[mi], cur, FWO_TMP_CAP);
+            if (nc < 0) return -1;
+            int no = 0;
+            for (int i = 0; i < na; i++) {
+                uint32_t half_hash = in[i].hash * FWO_VOWPAL_FNV_PRIME; /* wrapping */
+                for (int j = 0; j < nc; j++) {
+                    if (no >= FWO_TMP_CAP) return -1;
+                    out[no].hash = cur[j].hash ^ half_hash;
+                    out[no].value = in[i].value * cur[j].value;
+                    no++;
+                }
+            }
+            hv *tmp = in;
+            in = out;
+            out = tmp;
+            na = no;
+        }
+        for (int i = 0; i < na; i++) {
+            if (n_lr >= lr_cap) return -1;
+            lr_out[n_lr].hash = in[i].hash & lr_mask;
+            lr_out[n_lr].value = in[i].value * cw;
+            lr_out[n_lr].combo_index = ci;
+            n_lr++;
+        }
+    }
+    if (t->add_constant_feature) { /* 270-276 */
+        if (n_lr >= lr_cap) return -1;
+        lr_out[n_lr].hash = FWO_CONSTANT_HASH & lr_mask;
+        lr_out[n_lr].value = 1.0f;
+        lr_out[n_lr].combo_index = t->n_combos;
+        n_lr++;
+    }
+    if (t->ffm_k > 0) { /* 279-335 */
+        const uint32_t ffm_mask = fwo_ffm_hash_mask(t->ffm_bit_precision, t->ffm_k);
+        for (uint32_t f = 0; f < t->n_fields; f++) {
+            for (uint32_t mi = t->field_off[f]; mi < t->field_off[f + 1]; mi++) {
+                int nc = read_ns(rec, t->field_ns[mi], t->field_ns_f32[mi], cur, FWO_TMP_CAP);
+                if (nc < 0) return -1;
+                for (int j = 0; j < nc; j++) {
+                    if (n_ffm >= ffm_cap) return -1;
+                    ffm_out[n_ffm].hash = cur[j].hash & ffm_mask;
+                    ffm_out[n_ffm].value = cur[j].value;
+                    ffm_out[n_ffm].contra_field_index = f * t->ffm_k;
+                    n_ffm++;
+                }
+            }
+        }
+    }
+    *n_lr_out = n_lr;
+    *n_ffm_out = n_ffm;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ stream runner */
+
+#define FWO_EX_CAP 8192
+
+typedef struct {
+    fwo_model *m;
+    const fwo_translator *t;
+    const uint32_t *records;
+    const uint64_t *rec_off;
+    uint64_t n_train;
+    volatile uint64_t *next; /* shared cursor: stands in for the mpsc queue (hogwild.rs:30-36) */
+} hog_args;
+
+static void *hog_worker(void *p) { /* hogwild.rs:89-103 */
+    hog_args *a = (hog_args *)p;
+    fwo_scratch s;
+    scratch_init(&s, &a->m->cfg);
+    fwo_lr_entry *lr = (fwo_lr_entry *)malloc(sizeof(fwo_lr_entry) * FWO_EX_CAP);
+    fwo_ffm_entry *ffm = (fwo_ffm_entry *)malloc(sizeof(fwo_ffm_entry) * FWO_EX_CAP);
+    for (;;) {
+        uint64_t i = __atomic_fetch_add(a->next, 1, __ATOMIC_RELAXED);
+        if (i >= a->n_train) break;
+        uint32_t n_lr, n_ffm;
+        float label, imp;
+        if (fwo_translate(a->t, a->records + a->rec_off[i], lr, FWO_EX_CAP, &n_lr, ffm, FWO_EX_CAP, &n_ffm, &label, &imp))
+            continue;
+        learn_s(a->m, &s, lr, n_lr, ffm, n_ffm, label, imp, 1);
+    }
+    free(lr);
+    free(ffm);
+    scratch_free(&s);
+    return NULL;
+}
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+double fwo_run_stream(fwo_model *m, const fwo_translator *t, const uint32_t *records, const uint64_t *rec_off,
+                      uint64_t n, uint64_t holdout_after, int nthreads, float *preds) {
+    /* main.rs:236-241: example_num starts at 1; update = example_num < holdout_after */
+    uint64_t n_train = n;
+    if (holdout_after > 0) n_train = holdout_after - 1 < n ? holdout_after - 1 : n;
+    fwo_scratch s;
+    scratch_init(&s, &m->cfg);
+    fwo_lr_entry *lr = (fwo_lr_entry *)malloc(sizeof(fwo_lr_entry) * FWO_EX_CAP);
+    fwo_ffm_entry *ffm = (fwo_ffm_entry *)malloc(sizeof(fwo_ffm_entry) * FWO_EX_CAP);
+    double t0 = now_s(), dt;
+    uint64_t start_seq = 0;
+    if (nthreads > 1) {
+        volatile uint64_t next = 0;
+        hog_args a = {m, t, records, rec_off, n_train, &next};
+        pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+        for (int i = 0; i < nthreads; i++) pthread_create(&th[i], NULL, hog_worker, &a);
+        for (int i = 0; i < nthreads; i++) pthread_join(th[i], NULL);
+        free(th);
+        if (preds)
+            for (uint64_t i = 0; i < n_train; i++) preds[i] = 0.0f; /* main.rs:242-243 */
+        start_seq = n_train;
+        dt = now_s() - t0;
+    } else {
+        for (uint64_t i = 0; i < n_train; i++) {
+            uint32_t n_lr, n_ffm;
+            float label, imp;
+            fwo_translate(t, records + rec_off[i], lr, FWO_EX_CAP, &n_lr, ffm, FWO_EX_CAP, &n_ffm, &label, &imp);
+            float p = learn_s(m, &s, lr, n_lr, ffm, n_ffm, label, imp, 1);
+            if (preds) preds[i] = p;
+        }
+        start_seq = n_train;
+        dt = now_s() - t0;
+    }
+    for (uint64_t i = start_seq; i < n; i++) {
+        uint32_t n_lr, n_ffm;
+        float label, imp;
+        fwo_translate(t, records + rec_off[i], lr, FWO_EX_CAP, &n_lr, ffm, FWO_EX_CAP, &n_ffm, &label, &imp);
+        float p = learn_s(m, &s, lr, n_lr, ffm, n_ffm, label, imp, 0);
+        if (preds) preds[i] = p;
+    }
+    free(lr);
+    free(ffm);
+    scratch_free(&s);
+    return dt;
+}
