@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""Headline benchmark: examples/sec (+ final log-loss) of LR+FFM online training on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N=1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the learn path over one micro-batch of synthetic records (BASELINE.json config C:
+30 fields, k=8, 28-bit hashes, ~200 nnz/example, AdagradLUT) with the translated batch already resident in HBM.
+Rank 0 prints ONE JSON line (see the driver contract in the task description).
+
+N > 1: every rank owns a full replica and trains on its own shard of the stream (weak scaling); replicas are
+kept together by an RCCL all-reduce of the weight/accumulator deltas every --sync-every steps (DESIGN.md,
+"Multi-GPU").  The syncs that fall inside the timed steps are timed.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def build_model_instance(fw, args, device):
+    F = args.fields
+    return fw.ModelInstance(
+        learning_rate=0.1, ffm_learning_rate=0.1, power_t=0.5, ffm_power_t=0.5, init_acc_gradient=1.0,
+        ffm_init_acc_gradient=0.0, bit_precision=args.bits, ffm_bit_precision=args.ffm_bits, ffm_k=args.k,
+        add_constant_feature=True, optimizer=fw.Optimizer.AdagradLUT,
+        feature_combo_descs=[fw.FeatureComboDesc([fw.NamespaceDescriptor(i)]) for i in range(F)],
+        ffm_fields=[[fw.NamespaceDescriptor(i)] for i in range(F)], device=device)
+
+
+def gen_records(fw, args, first, n, threads=8):
+    """Synthetic stream [first, first+n) in chunks on a thread pool (ctypes releases the GIL)."""
+    chunk = 2048
+    jobs = [(first + s, min(chunk, n - s)) for s in range(0, n, chunk)]
+
+    def one(j):
+        return fw.synth_records(args.fields, args.mean_extra, args.zipf, args.ids, args.p_weighted, args.seed, j[0], j[1])
+
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        parts = list(ex.map(one, jobs))
+    recs = np.concatenate([p[0] for p in parts])
+    offs = [np.zeros(1, dtype=np.uint64)]
+    base = 0
+    for r, o in parts:
+        offs.append(o[1:] + np.uint64(base))
+        base += len(r)
+    return recs, np.concatenate(offs)
+
+
+def algorithmic_bytes(args, batch, n_words):
+    """train, AdaGrad: n_ffm*16*R + n_lr*16 + 4*record_len + 4 per example."""
+    R = args.fields * args.k
+    return batch.n_ffm * 16 * R + batch.n_lr * 16 + 4 * n_words + 4 * batch.n
+
+
+def logloss(p, y):
+    p = np.clip(p.astype(np.float64), 1e-15, 1 - 1e-15)  # benchmark/calc_loss.py:5-25
+    return float(np.mean(-np.where(y == 1, np.log(p), np.log(1 - p))))
+
+
+def cpu_baseline(args, n_examples):
+    """The CPU oracle (a C restatement of the reference algorithm; the Rust reference cannot be built here)
+    timed on this box's host cores in hogwild mode on a bounded sample of the same stream."""
+    import fwumious_wabbit_amd as fw
+    from oracle import fwo
+
+    cores = os.cpu_count() or 1
+    F = args.fields
+    ocfg = fwo.make_config(optimizer=fwo.OPT_ADAGRAD_LUT, learning_rate=0.1, ffm_learning_rate=0.1, power_t=0.5,
+                           ffm_power_t=0.5, init_acc_gradient=1.0, bit_precision=args.bits, num_combos=F + 1,
+                           ffm_k=args.k, ffm_bit_precision=args.ffm_bits, ffm_num_fields=F)
+    ots = fwo.TranslatorSpec([([(i, False)], 1.0) for i in range(F)], [[(i, False)] for i in range(F)], True, args.bits,
+                             args.k, args.ffm_bits)
+    try:
+        om = fwo.Model(ocfg, native=True)
+    except Exception:
+        om = fwo.Model(ocfg, native=False)
+    recs, off = gen_records(fw, args, 10_000_000, n_examples)
+    # single thread = the reference's default execution mode (main.rs:213-270); sample sized for ~10 s
+    n1 = max(1000, n_examples // (2 * cores))
+    dt1, _ = om.run_stream(ots, recs[: int(off[n1])], off[: n1 + 1], nthreads=1, want_preds=False)
+    dt, _ = om.run_stream(ots, recs, off, nthreads=cores, want_preds=False)
+    om.close()
+    return {"value": n_examples / dt, "unit": "examples/sec", "cores": cores, "kind": "port",
+            "sample": f"{n_examples} examples of the same synthetic stream, hogwild with {cores} threads "
+                      f"(hogwild.rs semantics) on the C oracle; single thread: {n1 / dt1:.0f} examples/sec on {n1} examples",
+            "single_thread_value": n1 / dt1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16384, help="examples per step per GPU")
+    ap.add_argument("--fields", type=int, default=30)
+    ap.add_argument("--k", type=int, default=8)
+    ap.add_argument("--bits", type=int, default=28)
+    ap.add_argument("--ffm-bits", dest="ffm_bits", type=int, default=28)
+    ap.add_argument("--mean-extra", dest="mean_extra", type=float, default=5.67)
+    ap.add_argument("--zipf", type=float, default=1.05)
+    ap.add_argument("--ids", type=int, default=10_000_000)
+    ap.add_argument("--p-weighted", dest="p_weighted", type=float, default=0.1)
+    ap.add_argument("--seed", type=int, default=20240612)
+    ap.add_argument("--holdout", type=int, default=8192)
+    ap.add_argument("--threads", type=int, default=0, help="workgroup size override")
+    ap.add_argument("--wgs-per-cu", dest="wgs", type=int, default=0)
+    ap.add_argument("--sync-every", dest="sync_every", type=int, default=0, help="N>1: steps between delta all-reduces")
+    ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
+    ap.add_argument("--cpu-examples", dest="cpu_examples", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import fwumious_wabbit_amd as fw
+    from fwumious_wabbit_amd import _capi as capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    mi = build_model_instance(fw, args, local_rank)
+    re = fw.Regressor(mi)
+    if args.threads or args.wgs:
+        re.set_launch(args.threads, args.wgs)
+    fbt = fw.FeatureBufferTranslator(mi)
+
+    K, W, B = args.steps, args.warmup, args.batch
+    # every rank trains on its own shard of the stream: examples [rank*(W+K)*B, ...)
+    t0 = time.time()
+    first = rank * (W + K) * B
+    recs, off = gen_records(fw, args, first, (W + K) * B)
+    batches, words = [], []
+    for s in range(W + K):
+        lo, hi = s * B, (s + 1) * B
+        sub = recs[int(off[lo]):int(off[hi])]
+        batches.append(re.batch_from_records(fbt, sub, off[lo:hi + 1] - off[lo]))
+        words.append(len(sub))
+    hrecs, hoff = gen_records(fw, args, 1_000_000_000, args.holdout)  # same hold-out tail on every rank
+    hbatch = re.batch_from_records(fbt, hrecs, hoff)
+    hy = hrecs[hoff[:-1].astype(np.int64) + 1].astype(np.float32)
+    del recs
+    prep_s = time.time() - t0
+
+    stream = torch.cuda.current_stream()
+    sptr = stream.cuda_stream
+
+    # ---- N>1: replicas + delta all-reduce (local SGD with summed deltas)
+    sync_every = args.sync_every or max(1, K // 2)
+    tabs, snaps = [], []
+    if world > 1:
+        for which in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC):
+            t = re.table_as_torch(which)
+            tabs.append(t)
+            snaps.append(t.clone())
+
+    def sync_replicas():
+        # w <- w0 + sum_r (w_r - w0): every replica ends with the same tables, having applied everyone's updates
+        for t, s0 in zip(tabs, snaps):
+            chunk = 1 << 26  # 256 MiB buckets
+            for a in range(0, t.numel(), chunk):
+                d = t[a:a + chunk] - s0[a:a + chunk]
+                dist.all_reduce(d)
+                s0[a:a + chunk] += d
+                t[a:a + chunk] = s0[a:a + chunk]
+
+    for i in range(W):
+        re.learn_batch(batches[i], capi.MODE_HOGWILD, True, sptr)
+    if world > 1 and W:
+        sync_replicas()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * K)]
+    t_start = time.perf_counter()
+    for i in range(K):
+        ev[2 * i].record(stream)
+        re.learn_batch(batches[W + i], capi.MODE_HOGWILD, True, sptr)
+        ev[2 * i + 1].record(stream)
+        if world > 1 and (i + 1) % sync_every == 0:
+            sync_replicas()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    kernel_ms = [ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(K)]
+    avg_kernel_ms = float(np.mean(kernel_ms))
+    alg_bytes = float(np.mean([algorithmic_bytes(args, batches[W + i], words[W + i]) for i in range(K)]))
+
+    # ---- final hold-out log-loss (main.rs:238-241 --holdout_after semantics: predicted, never learned)
+    re.learn_batch(hbatch, capi.MODE_HOGWILD, False, sptr)
+    final_ll = logloss(hbatch.predictions(sptr), hy)
+
+    if rank == 0:
+        achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "examples/sec + final log-loss, 30-field k=8 FFM, at 1/2/4/8 MI355X",
+            "value": world * K * B / elapsed,
+            "unit": "examples/sec",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": 1e3 * elapsed / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "final_logloss": final_ll,
+            "config": {
+                "workload": f"BASELINE.json configs[2]: synthetic {args.fields}-field k={args.k} FFM + LR, "
+                            f"{args.ffm_bits}-bit FFM hash, {args.bits}-bit LR hash, ~{int(args.fields * (1 + args.mean_extra))} nnz/example, "
+                            f"AdagradLUT, fused learn (forward + sigmoid/log-loss + AdaGrad scatter-update)",
+                "examples_per_step_per_gpu": B,
+                "global_batch": B * world,
+                "mode": "hogwild (device-wide concurrent examples, racy RMW, sc1 accesses)",
+                "parallelism": "1 GPU" if world == 1 else f"dp{world}: replicas, RCCL delta all-reduce every {sync_every} steps",
+                "holdout_examples": args.holdout,
+                "prep_seconds": prep_s,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "fw_example_kernel<4, AdagradLUT, coherent>",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_ms": avg_kernel_ms,
+            },
+        }
+        if args.cpu and world == 1:
+            n_cpu = args.cpu_examples or 20000
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, n_cpu)
+            except Exception as e:  # the baseline is a reported side figure; never lose the GPU line over it
+                out["cpu_baseline"] = {"value": None, "unit": "examples/sec", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {e!r}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,138 @@
+// Internal declarations shared by the host side (regressor.cpp, translate.cpp, trainer.cpp) and the
+// HIP kernels (kernels.hip).  Not part of the C ABI (include/fwgpu.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "fwgpu.h"
+
+namespace fwgpu {
+
+constexpr int kLutBits = 11;  // optimizer.rs:98 FASTMATH_LR_LUT_BITS
+constexpr int kLutSize = 1 << kLutBits;
+constexpr uint32_t kFfmContraBufLen = 41472;  // regressor.rs:23 FFM_CONTRA_BUF_LEN
+
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+#define FWGPU_HIP(call)                                                                                  \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return ::fwgpu::fail(FWGPU_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+// Everything the example kernel needs, passed by value.
+struct KernelParams {
+    // ---- tables (HBM) ----
+    float *ffm_w;          // [2^ffm_bits + F*k]            block_ffm.rs:40
+    float *ffm_acc;        // same length                    block_ffm.rs:41
+    float *lr;             // [2^b] x {w, acc} interleaved   block_lr.rs:20
+    const float *lut_lr;   // [2048]                         optimizer.rs:101-103
+    const float *lut_ffm;  // [2048]
+    // ---- batch (HBM, CSR) ----
+    const uint32_t *ffm_hash;
+    const float *ffm_val;
+    const uint8_t *ffm_fld;  // field index (contra_field_index / k)
+    const uint32_t *ffm_off;  // [n+1]
+    const uint32_t *lr_hash;
+    const float *lr_val;
+    const uint32_t *lr_off;  // [n+1]
+    const float *label;
+    const float *importance;
+    float *pred;
+    uint32_t n_examples;
+    // ---- model ----
+    uint32_t F, k, R;          // fields, ffm_k, R = F*k (row length in floats)
+    uint32_t max_ffm, max_lr;  // LDS capacities for one example's entries
+    int32_t has_lr;            // wiring REGRESSOR: LR block participates
+    int32_t update;
+    int32_t aligned4;          // every FFM row of the batch starts on a 16-byte boundary
+    float lr_rate, lr_minus_power_t;    // SGD / AdagradFlex parameters of the LR block
+    float ffm_rate, ffm_minus_power_t;  // ... of the FFM block
+};
+
+struct LaunchConfig {
+    uint32_t threads = 512;
+    uint32_t workgroups_per_cu = 0;  // 0: as many as LDS allows (capped)
+};
+
+size_t example_kernel_lds_bytes(const KernelParams &p, int optimizer);
+// Enqueue the example kernel.  grid==1 gives the sequential (in-order) semantics.
+hipError_t launch_example_kernel(const KernelParams &p, int optimizer, bool coherent, uint32_t grid,
+                                 uint32_t threads, hipStream_t stream);
+hipError_t launch_ffm_init(float *w, float *acc, uint64_t len, uint32_t k, float init_width, float init_zero_band,
+                           float init_center, float acc0, hipStream_t stream);
+hipError_t launch_fill(float *p, uint64_t n, float v, hipStream_t stream);
+hipError_t launch_fill_lr(float *lr, uint64_t n_entries, float w, float acc, hipStream_t stream);
+hipError_t launch_checksum(const float *p, uint64_t n, unsigned long long *out, hipStream_t stream);
+hipError_t launch_coherence_probe(unsigned *scratch, int use_sc1, unsigned iters, unsigned blocks, hipStream_t stream);
+
+}  // namespace fwgpu
+
+struct fwgpu_batch {
+    fwgpu_regressor *owner = nullptr;
+    uint32_t n = 0;
+    uint64_t n_lr = 0, n_ffm = 0;
+    uint32_t max_lr = 0, max_ffm = 0;
+    bool aligned4 = true;
+    // one device allocation, carved
+    void *dev = nullptr;
+    size_t dev_bytes = 0;
+    uint32_t *ffm_hash = nullptr;
+    float *ffm_val = nullptr;
+    uint8_t *ffm_fld = nullptr;
+    uint32_t *ffm_off = nullptr;
+    uint32_t *lr_hash = nullptr;
+    float *lr_val = nullptr;
+    uint32_t *lr_off = nullptr;
+    float *label = nullptr;
+    float *importance = nullptr;
+    float *pred = nullptr;
+};
+
+struct fwgpu_regressor {
+    fwgpu_config cfg{};
+    int device = 0;
+    int num_cus = 256;
+    size_t lds_per_cu = 160 * 1024;
+    uint64_t lr_len = 0;   // entries
+    uint64_t ffm_len = 0;  // floats
+    float *d_lr = nullptr, *d_ffm_w = nullptr, *d_ffm_acc = nullptr;
+    float *d_lut_lr = nullptr, *d_lut_ffm = nullptr;
+    uint32_t lr_hash_mask = 0, ffm_hash_mask = 0;
+    fwgpu::LaunchConfig launch;
+    // scratch for single-example calls
+    fwgpu_batch *one = nullptr;
+    void *pinned = nullptr;
+    size_t pinned_bytes = 0;
+};
+
+namespace fwgpu {
+// host helpers implemented in regressor.cpp / translate.cpp
+struct HostBatch {  // SoA staging of a CSR batch on the host
+    std::vector<uint32_t> ffm_hash, ffm_off, lr_hash, lr_off;
+    std::vector<float> ffm_val, lr_val, label, importance;
+    std::vector<uint8_t> ffm_fld;
+    uint32_t max_lr = 0, max_ffm = 0;
+    bool aligned4 = true;
+    void clear();
+    uint32_t size() const { return (uint32_t)label.size(); }
+};
+int batch_alloc(fwgpu_regressor *r, uint32_t n, uint64_t n_lr, uint64_t n_ffm, fwgpu_batch **out);
+int batch_upload(fwgpu_batch *b, const HostBatch &hb, hipStream_t stream);
+int append_example(const fwgpu_regressor *r, HostBatch &hb, const fwgpu_lr_entry *lr, uint32_t n_lr,
+                   const fwgpu_ffm_entry *ffm, uint32_t n_ffm, float label, float importance);
+int translate_record(const fwgpu_translator_config *t, const uint32_t *rec, uint32_t rec_len,
+                     std::vector<fwgpu_lr_entry> &lr, std::vector<fwgpu_ffm_entry> &ffm, float *label,
+                     float *importance);
+int check_translator(const fwgpu_regressor *r, const fwgpu_translator_config *t);
+uint32_t lr_hash_mask(uint32_t bit_precision);
+uint32_t ffm_hash_mask(uint32_t ffm_bits, uint32_t ffm_k);
+void lut_init(float *lut, float learning_rate, float power_t, float init_acc);
+KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int update);
+uint32_t pick_grid(const fwgpu_regressor *r, const KernelParams &p, int mode, uint32_t threads);
+}  // namespace fwgpu

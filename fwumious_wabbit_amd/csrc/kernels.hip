@@ -1,0 +1,678 @@
+// HIP kernels (gfx950 / CDNA4) for the LR+FFM learn/predict path.
+//
+// One workgroup owns one example at a time (persistent grid, stride gridDim.x).  Per example:
+//   stage   : the example's FeatureBuffer (feature_buffer.rs:24-31) is copied HBM -> LDS;
+//   gather  : each wave takes whole fields; for every feature of the field it loads the complete weight
+//             row w[hash .. hash+R) (R = F*k floats, one coalesced 16 B/lane buffer load, block_ffm.rs:163-217)
+//             and accumulates the field sum S[f][z][k] in registers, then writes it TRANSPOSED into LDS:
+//             T[z][f][k] = S[f][z][k], so that T[f][.] is exactly the "contra" row a feature of field f
+//             multiplies with (block_ffm.rs:219-261);
+//   dot     : sum_{f,z,k} S[f][z][k]*S[z][f][k] = sum_e T[e]*T[perm(e)] from LDS, minus the self-pair
+//             correction sum_i v_i^2 |w_i[f_i]|^2 (block_ffm.rs:316-440, 1107-1201), wave64 shuffle + LDS
+//             reduction; LR forward = random 8-byte gathers (block_lr.rs:28-47);
+//   sigmoid : block_loss_functions.rs:105-153 (clip +-50, NaN -> 0.5, general gradient);
+//   update  : per feature row, read-modify-write of w and acc with the optimizer step fused
+//             (block_ffm.rs:265-288, optimizer.rs); LR entries likewise (block_lr.rs:135-150).
+//
+// Semantics that are kept exactly as in the reference inside ONE example:
+//   * duplicate LR hashes apply sequentially in buffer order (regressor.rs:629-655 pins this);
+//   * FFM rows of different features may overlap (rows start at hash&mask but are R long,
+//     block_ffm.rs:92-94); overlapping features are applied in buffer order, each seeing the previous
+//     one's accumulator, and all gradients are computed from the pre-update weights.
+// Across examples: grid==1 walks the batch in order (sequential = the reference's single thread); a larger
+// grid runs examples concurrently with unsynchronised read-modify-write (hogwild.rs semantics).
+//
+// Coherence: the per-XCD L2s are not coherent with each other and a CU's L1 is never refreshed by another
+// CU's stores.  All table accesses of an updating launch therefore use device-scope (sc1) loads and stores
+// (buffer_* ... sc1 / agent-scope relaxed atomics for the 8-byte LR entries).  Read-only launches use
+// plain cached loads.
+#include "fwgpu_internal.h"
+
+namespace fwgpu {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+// aux (cache policy) bits of the raw buffer builtins on gfx940+: bit0 sc0, bit1 nt, bit4 sc1.
+constexpr int kAuxPlain = 0;
+constexpr int kAuxSc1 = 16;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, uint32_t bytes) {
+    // raw buffer (stride 0), num_records in bytes; out-of-range lanes load 0 and their stores are dropped.
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<4> {
+    typedef f4 type;
+    template <int AUX>
+    static __device__ __forceinline__ f4 load(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+        u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, AUX);
+        return __builtin_bit_cast(f4, v);
+    }
+    template <int AUX>
+    static __device__ __forceinline__ void store(f4 v, __amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, (int)byte_off, 0, AUX);
+    }
+    static __device__ __forceinline__ f4 lds_load(const float *p) { return *reinterpret_cast<const f4 *>(p); }
+    static __device__ __forceinline__ void lds_store(float *p, f4 v) { *reinterpret_cast<f4 *>(p) = v; }
+    static __device__ __forceinline__ f4 zero() { return f4{0.f, 0.f, 0.f, 0.f}; }
+    static __device__ __forceinline__ float get(const f4 &v, int i) { return v[i]; }
+    static __device__ __forceinline__ void set(f4 &v, int i, float x) { v[i] = x; }
+};
+template <>
+struct Vec<1> {
+    typedef float type;
+    template <int AUX>
+    static __device__ __forceinline__ float load(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+        unsigned v = __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, AUX);
+        return __uint_as_float(v);
+    }
+    template <int AUX>
+    static __device__ __forceinline__ void store(float v, __amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)byte_off, 0, AUX);
+    }
+    static __device__ __forceinline__ float lds_load(const float *p) { return *p; }
+    static __device__ __forceinline__ void lds_store(float *p, float v) { *p = v; }
+    static __device__ __forceinline__ float zero() { return 0.f; }
+    static __device__ __forceinline__ float get(const float &v, int) { return v; }
+    static __device__ __forceinline__ void set(float &v, int, float x) { v = x; }
+};
+
+// ---- optimizer steps (optimizer.rs).  acc chain is kept free of FMA contraction so that, given the same
+// gradient, acc (and hence the integer LUT key) is bit-identical to the reference.
+template <int OPT>
+__device__ __forceinline__ float opt_step(float grad, float &acc, float rate, float minus_power_t, const float *lut) {
+    if (OPT == FWGPU_OPT_SGD) {
+        return grad * rate;  // optimizer.rs:36-38
+    } else if (OPT == FWGPU_OPT_ADAGRAD_FLEX) {  // optimizer.rs:76-88
+        float na = __fadd_rn(acc, __fmul_rn(grad, grad));
+        acc = na;
+        float u = __fmul_rn(__fmul_rn(grad, rate), powf(na, minus_power_t));
+        return (isnan(u) || isinf(u)) ? 0.0f : u;
+    } else {  // optimizer.rs:147-156
+        float na = __fadd_rn(acc, __fmul_rn(grad, grad));
+        acc = na;
+        uint32_t key = __float_as_uint(na) >> (31 - kLutBits);
+        return __fmul_rn(grad, lut[key]);
+    }
+}
+
+__device__ __forceinline__ float logistic(float t) { return 1.0f / (1.0f + expf(-t)); }  // block_loss_functions.rs:15-17
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+template <bool COH>
+__device__ __forceinline__ float2 lr_load(const float *lr, uint32_t h) {
+    const unsigned long long *p = reinterpret_cast<const unsigned long long *>(lr) + h;
+    unsigned long long v;
+    if (COH)
+        v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        v = *p;
+    return float2{__uint_as_float((uint32_t)v), __uint_as_float((uint32_t)(v >> 32))};
+}
+template <bool COH>
+__device__ __forceinline__ void lr_store(float *lr, uint32_t h, float2 wa) {
+    unsigned long long *p = reinterpret_cast<unsigned long long *>(lr) + h;
+    unsigned long long v = (unsigned long long)__float_as_uint(wa.x) | ((unsigned long long)__float_as_uint(wa.y) << 32);
+    if (COH)
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *p = v;
+}
+
+// LDS carve-up (all offsets 16-byte aligned).
+struct Lds {
+    float *T;        // F*R
+    float *selfw;    // max_ffm*k : w_i[f_i*k ..] as read in the gather phase (pre-update)
+    float *lut;      // 2048 (AdagradLUT only)
+    uint32_t *e_hash;  // max_ffm
+    float *e_val;
+    uint32_t *e_fld;  // field | dep<<31
+    uint32_t *l_hash;  // max_lr
+    float *l_val;
+    uint32_t *fstart, *fend;  // F
+    float *red;               // 3*16
+    uint32_t *ctr;            // 4
+};
+
+__host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+__host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t max_ffm, uint32_t max_lr, bool lut,
+                                             size_t *off /*[12]*/) {
+    size_t o = 0;
+    size_t R = (size_t)F * k;
+    off[0] = o; o = align16(o + 4 * F * R);
+    off[1] = o; o = align16(o + 4 * (size_t)max_ffm * k);
+    off[2] = o; o = align16(o + (lut ? 4 * (size_t)kLutSize : 0));
+    off[3] = o; o = align16(o + 4 * (size_t)max_ffm);
+    off[4] = o; o = align16(o + 4 * (size_t)max_ffm);
+    off[5] = o; o = align16(o + 4 * (size_t)max_ffm);
+    off[6] = o; o = align16(o + 4 * (size_t)max_lr);
+    off[7] = o; o = align16(o + 4 * (size_t)max_lr);
+    off[8] = o; o = align16(o + 4 * (size_t)F);
+    off[9] = o; o = align16(o + 4 * (size_t)F);
+    off[10] = o; o = align16(o + 4 * 3 * 16);
+    off[11] = o; o = align16(o + 4 * 4);
+    return o;
+}
+
+size_t example_kernel_lds_bytes(const KernelParams &p, int optimizer) {
+    size_t off[12];
+    return lds_layout(p.F, p.k, p.max_ffm, p.max_lr, optimizer == FWGPU_OPT_ADAGRAD_LUT && p.update, off);
+}
+
+// Update of one FFM feature row by one wave (block_ffm.rs:269-286), U rows at a time for memory-level
+// parallelism.  idx[u] == 0xffffffff marks an unused slot.
+template <int VEC, int OPT, int AUX, int U>
+__device__ __forceinline__ void update_rows(const KernelParams &p, const Lds &s, const uint32_t (&idx)[U], float g,
+                                            int lane) {
+    typedef typename Vec<VEC>::type V;
+    const uint32_t R = p.R, k = p.k;
+    const uint32_t nchunk = (R + 64 * VEC - 1) / (64 * VEC);
+    for (uint32_t c = 0; c < nchunk; ++c) {
+        const uint32_t e0 = (c * 64 + lane) * VEC;
+        const bool inb = e0 < R;
+        const uint32_t z = inb ? e0 / k : 0;
+        V wv[U], av[U];
+        __amdgpu_buffer_rsrc_t rw[U], ra[U];
+        float val[U];
+        uint32_t fld[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            wv[u] = Vec<VEC>::zero();
+            av[u] = Vec<VEC>::zero();
+            if (idx[u] != 0xffffffffu) {
+                const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[idx[u]]);
+                val[u] = s.e_val[idx[u]];
+                fld[u] = s.e_fld[idx[u]] & 0x7fffffffu;
+                rw[u] = make_rsrc(p.ffm_w + h, R * 4);
+                wv[u] = Vec<VEC>::template load<AUX>(rw[u], e0 * 4);
+                if (OPT != FWGPU_OPT_SGD) {
+                    ra[u] = make_rsrc(p.ffm_acc + h, R * 4);
+                    av[u] = Vec<VEC>::template load<AUX>(ra[u], e0 * 4);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (idx[u] == 0xffffffffu) continue;
+            const uint32_t f = fld[u];
+            const float v = val[u];
+            V tv = Vec<VEC>::zero(), sw = Vec<VEC>::zero();
+            const bool self = inb && (z == f);
+            if (inb) tv = Vec<VEC>::lds_load(s.T + f * R + e0);
+            if (self) sw = Vec<VEC>::lds_load(s.selfw + idx[u] * k + (e0 - z * k));
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float t = Vec<VEC>::get(tv, j);
+                if (self) t = t - Vec<VEC>::get(sw, j) * v;  // contra - w*v        block_ffm.rs:238
+                const float G = v * t;                       // gradient cache      block_ffm.rs:239, 249
+                const float grad = g * G;                    // block_ffm.rs:278
+                float acc = Vec<VEC>::get(av[u], j);
+                const float upd = opt_step<OPT>(grad, acc, p.ffm_rate, p.ffm_minus_power_t, s.lut);
+                Vec<VEC>::set(av[u], j, acc);
+                Vec<VEC>::set(wv[u], j, Vec<VEC>::get(wv[u], j) - upd);  // block_ffm.rs:282
+            }
+            Vec<VEC>::template store<AUX>(wv[u], rw[u], e0 * 4);
+            if (OPT != FWGPU_OPT_SGD) Vec<VEC>::template store<AUX>(av[u], ra[u], e0 * 4);
+        }
+    }
+}
+
+template <int VEC, int OPT, bool COH>
+__global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) {
+    typedef typename Vec<VEC>::type V;
+    constexpr int AUX = COH ? kAuxSc1 : kAuxPlain;
+    constexpr int UG = 4;  // feature rows in flight per wave in the gather phase
+    constexpr int UU = 2;  // feature rows in flight per wave in the update phase (x2 tables)
+    extern __shared__ __align__(16) unsigned char smem[];
+    const bool use_lut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update;
+    size_t off[12];
+    lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut, off);
+    Lds s;
+    s.T = reinterpret_cast<float *>(smem + off[0]);
+    s.selfw = reinterpret_cast<float *>(smem + off[1]);
+    s.lut = reinterpret_cast<float *>(smem + off[2]);
+    s.e_hash = reinterpret_cast<uint32_t *>(smem + off[3]);
+    s.e_val = reinterpret_cast<float *>(smem + off[4]);
+    s.e_fld = reinterpret_cast<uint32_t *>(smem + off[5]);
+    s.l_hash = reinterpret_cast<uint32_t *>(smem + off[6]);
+    s.l_val = reinterpret_cast<float *>(smem + off[7]);
+    s.fstart = reinterpret_cast<uint32_t *>(smem + off[8]);
+    s.fend = reinterpret_cast<uint32_t *>(smem + off[9]);
+    s.red = reinterpret_cast<float *>(smem + off[10]);
+    s.ctr = reinterpret_cast<uint32_t *>(smem + off[11]);
+
+    const int tid = threadIdx.x, bd = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nw = bd >> 6;
+    const uint32_t F = p.F, k = p.k, R = p.R;
+    const uint32_t nchunk = R ? (R + 64 * VEC - 1) / (64 * VEC) : 0;
+
+    if (use_lut)
+        for (int i = tid; i < kLutSize; i += bd) s.lut[i] = p.lut_ffm[i];
+
+    for (uint32_t ex = blockIdx.x; ex < p.n_examples; ex += gridDim.x) {
+        // previous example's LDS reads are done and (s_waitcnt vmcnt(0) of the barrier) its stores are complete
+        __syncthreads();
+        const uint32_t fo = p.ffm_off[ex], nf = p.ffm_off[ex + 1] - fo;
+        const uint32_t lo = p.lr_off[ex], nl = p.lr_off[ex + 1] - lo;
+        const float label = p.label[ex], imp = p.importance[ex];
+        const bool do_update = p.update && (imp != 0.0f);  // regressor.rs:366
+
+        // ---------------- stage
+        for (uint32_t i = tid; i < F; i += bd) {
+            s.fstart[i] = 0;
+            s.fend[i] = 0;
+        }
+        if (tid == 0) {
+            s.ctr[0] = 0;  // next field to gather
+            s.ctr[1] = 0;  // any overlapping FFM rows in this example
+        }
+        for (uint32_t i = tid; i < nf; i += bd) {
+            s.e_hash[i] = p.ffm_hash[fo + i];
+            s.e_val[i] = p.ffm_val[fo + i];
+            s.e_fld[i] = p.ffm_fld[fo + i];
+        }
+        for (uint32_t i = tid; i < nl; i += bd) {
+            s.l_hash[i] = p.lr_hash[lo + i];
+            s.l_val[i] = p.lr_val[lo + i];
+        }
+        __syncthreads();
+        uint32_t my_dep[4] = {0, 0, 0, 0};  // supports nf <= 4*bd (checked on the host)
+        {
+            int slot = 0;
+            for (uint32_t i = tid; i < nf; i += bd, ++slot) {
+                const uint32_t f = s.e_fld[i];
+                if (i == 0 || s.e_fld[i - 1] != f) s.fstart[f] = i;
+                if (i == nf - 1 || s.e_fld[i + 1] != f) s.fend[f] = i + 1;
+                if (do_update) {
+                    // does an EARLIER feature's row [h_j, h_j+R) overlap mine?  (rows are R long but
+                    // start on a next_pow2(k) grid: block_ffm.rs:92-94, feature_buffer.rs:141-148)
+                    const uint32_t h = s.e_hash[i];
+                    uint32_t d = 0;
+                    for (uint32_t j = 0; j < i; ++j) {
+                        const uint32_t hj = s.e_hash[j];
+                        const uint32_t diff = h > hj ? h - hj : hj - h;
+                        d |= (diff < R) ? 1u : 0u;
+                    }
+                    my_dep[slot & 3] = d;
+                }
+            }
+        }
+        __syncthreads();
+        if (do_update) {
+            int slot = 0;
+            uint32_t any = 0;
+            for (uint32_t i = tid; i < nf; i += bd, ++slot) {
+                if (my_dep[slot & 3]) {
+                    s.e_fld[i] |= 0x80000000u;
+                    any = 1;
+                }
+            }
+            if (any) s.ctr[1] = 1;
+        }
+
+        // ---------------- gather: field sums, transposed into LDS
+        float dc = 0.0f;  // sum_i v_i^2 |w_i[f_i]|^2 partial (block_ffm.rs:418-426)
+        if (k) {
+            for (;;) {
+                uint32_t f = 0;
+                if (lane == 0) f = atomicAdd(&s.ctr[0], 1u);
+                f = __builtin_amdgcn_readfirstlane(f);
+                if (f >= F) break;
+                const uint32_t fs = s.fstart[f], fe = s.fend[f];
+                for (uint32_t c = 0; c < nchunk; ++c) {
+                    const uint32_t e0 = (c * 64 + lane) * VEC;
+                    const bool inb = e0 < R;
+                    const uint32_t z = inb ? e0 / k : 0;
+                    const bool self = inb && (z == f);
+                    V acc = Vec<VEC>::zero();
+                    for (uint32_t i = fs; i < fe; i += UG) {
+                        V r[UG];
+                        float v[UG];
+#pragma unroll
+                        for (int u = 0; u < UG; ++u) {
+                            r[u] = Vec<VEC>::zero();
+                            v[u] = 0.0f;
+                            if (i + u < fe) {
+                                const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[i + u]);
+                                v[u] = s.e_val[i + u];
+                                r[u] = Vec<VEC>::template load<AUX>(make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < UG; ++u) {
+                            if (i + u < fe) {
+                                float ss = 0.0f;
+#pragma unroll
+                                for (int j = 0; j < VEC; ++j) {
+                                    const float w = Vec<VEC>::get(r[u], j);
+                                    Vec<VEC>::set(acc, j, Vec<VEC>::get(acc, j) + w * v[u]);
+                                    ss += w * w;
+                                }
+                                if (self) {
+                                    dc += ss * v[u] * v[u];
+                                    Vec<VEC>::lds_store(s.selfw + (i + u) * k + (e0 - z * k), r[u]);
+                                }
+                            }
+                        }
+                    }
+                    if (inb) Vec<VEC>::lds_store(s.T + z * R + f * k + (e0 - z * k), acc);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---------------- all-pairs dot from LDS + LR forward
+        float dot = 0.0f;
+        if (k) {
+            const uint32_t nq = F * R / VEC;
+            for (uint32_t q = tid; q < nq; q += bd) {
+                const uint32_t e0 = q * VEC;
+                const uint32_t a = e0 / R, rem = e0 - a * R;
+                const uint32_t b = rem / k, kk = rem - b * k;
+                const V x = Vec<VEC>::lds_load(s.T + e0);
+                const V y = Vec<VEC>::lds_load(s.T + b * R + a * k + kk);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) dot += Vec<VEC>::get(x, j) * Vec<VEC>::get(y, j);
+            }
+        }
+        float lrs = 0.0f;
+        if (p.has_lr)
+            for (uint32_t i = tid; i < nl; i += bd) lrs += lr_load<COH>(p.lr, s.l_hash[i]).x * s.l_val[i];
+        dot = wave_sum(dot);
+        dc = wave_sum(dc);
+        lrs = wave_sum(lrs);
+        if (lane == 0) {
+            s.red[wave] = dot;
+            s.red[16 + wave] = dc;
+            s.red[32 + wave] = lrs;
+        }
+        __syncthreads();
+        float dot_t = 0.0f, dc_t = 0.0f, lr_t = 0.0f;
+        for (int w = 0; w < nw; ++w) {
+            dot_t += s.red[w];
+            dc_t += s.red[16 + w];
+            lr_t += s.red[32 + w];
+        }
+        // sigmoid input: LR slots first, then the FFM pair sum (graph.rs:251-285 tape order)
+        float wsum = 0.0f;
+        if (p.has_lr) wsum += lr_t;
+        if (k) wsum += 0.5f * (dot_t - dc_t);
+
+        // ---------------- sigmoid / log-loss gradient (block_loss_functions.rs:105-153)
+        float pr, g;
+        if (isnan(wsum)) {
+            pr = logistic(0.0f);
+            g = 0.0f;
+        } else if (wsum < -50.0f) {
+            pr = logistic(-50.0f);
+            g = 0.0f;
+        } else if (wsum > 50.0f) {
+            pr = logistic(50.0f);
+            g = 0.0f;
+        } else {
+            pr = logistic(wsum);
+            g = -(label - pr) * imp;
+        }
+        if (tid == 0) p.pred[ex] = pr;
+
+        // ---------------- update.  g == 0 leaves every weight and accumulator unchanged in all three
+        // optimizers (acc += 0, w -= 0), so the whole phase is skipped.
+        if (do_update && g != 0.0f) {
+            // LR (block_lr.rs:135-150): the thread owning the FIRST occurrence of a hash applies all
+            // occurrences in buffer order, so duplicates chain exactly like the reference's loop.
+            if (p.has_lr) {
+                for (uint32_t t = tid; t < nl; t += bd) {
+                    const uint32_t h = s.l_hash[t];
+                    bool first = true;
+                    for (uint32_t j = 0; j < t; ++j) first = first && (s.l_hash[j] != h);
+                    if (first) {
+                        float2 wa = lr_load<COH>(p.lr, h);
+                        for (uint32_t j = t; j < nl; ++j) {
+                            if (s.l_hash[j] == h) {
+                                const float grad = g * s.l_val[j];
+                                const float upd = opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, p.lut_lr);
+                                wa.x -= upd;
+                            }
+                        }
+                        lr_store<COH>(p.lr, h, wa);
+                    }
+                }
+            }
+            if (k) {
+                // phase A: rows with no earlier overlapping row, all waves, UU rows each
+                for (uint32_t i0 = wave * UU; i0 < nf; i0 += nw * UU) {
+                    uint32_t idx[UU];
+#pragma unroll
+                    for (int u = 0; u < UU; ++u) {
+                        const uint32_t i = i0 + u;
+                        idx[u] = (i < nf && !(s.e_fld[i] & 0x80000000u)) ? i : 0xffffffffu;
+                    }
+                    update_rows<VEC, OPT, AUX, UU>(p, s, idx, g, lane);
+                }
+                // phase B: overlapping rows, strictly in buffer order on one wave
+                if (s.ctr[1]) {
+                    __syncthreads();
+                    if (wave == 0) {
+                        for (uint32_t i = 0; i < nf; ++i) {
+                            if (s.e_fld[i] & 0x80000000u) {
+                                uint32_t idx[1] = {i};
+                                update_rows<VEC, OPT, AUX, 1>(p, s, idx, g, lane);
+                                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                                __builtin_amdgcn_s_waitcnt(0);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ launch
+template <int VEC, int OPT, bool COH>
+static hipError_t launch_t(const KernelParams &p, uint32_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
+    auto kern = fw_example_kernel<VEC, OPT, COH>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, p);
+    return hipGetLastError();
+}
+
+template <int VEC>
+static hipError_t launch_v(const KernelParams &p, int optimizer, bool coherent, uint32_t grid, uint32_t threads,
+                           size_t lds, hipStream_t stream) {
+    if (!p.update) return launch_t<VEC, FWGPU_OPT_SGD, false>(p, grid, threads, lds, stream);
+    switch (optimizer) {
+    case FWGPU_OPT_SGD:
+        return coherent ? launch_t<VEC, FWGPU_OPT_SGD, true>(p, grid, threads, lds, stream)
+                        : launch_t<VEC, FWGPU_OPT_SGD, false>(p, grid, threads, lds, stream);
+    case FWGPU_OPT_ADAGRAD_FLEX:
+        return coherent ? launch_t<VEC, FWGPU_OPT_ADAGRAD_FLEX, true>(p, grid, threads, lds, stream)
+                        : launch_t<VEC, FWGPU_OPT_ADAGRAD_FLEX, false>(p, grid, threads, lds, stream);
+    default:
+        return coherent ? launch_t<VEC, FWGPU_OPT_ADAGRAD_LUT, true>(p, grid, threads, lds, stream)
+                        : launch_t<VEC, FWGPU_OPT_ADAGRAD_LUT, false>(p, grid, threads, lds, stream);
+    }
+}
+
+hipError_t launch_example_kernel(const KernelParams &p, int optimizer, bool coherent, uint32_t grid, uint32_t threads,
+                                 hipStream_t stream) {
+    if (p.n_examples == 0) return hipSuccess;
+    const size_t lds = example_kernel_lds_bytes(p, optimizer);
+    // 16-byte row vectors need k % 4 == 0: then R % 4 == 0 and hash & mask is a multiple of next_pow2(k) >= 4
+    // floats (feature_buffer.rs:141-148), so every row starts 16-byte aligned.
+    // Entries that did not come through the translator's mask (raw fwgpu_learn calls) may be unaligned.
+    if (p.k % 4 == 0 && p.aligned4) return launch_v<4>(p, optimizer, coherent, grid, threads, lds, stream);
+    return launch_v<1>(p, optimizer, coherent, grid, threads, lds, stream);
+}
+
+// ------------------------------------------------------------------ init / fill / checksum
+
+// merand48 0.1.0 (VW's LCG), one step from `seed` (block_ffm.rs:801, 811)
+__device__ __forceinline__ float merand48(unsigned long long seed) {
+    seed = 0xeece66d5deece66dULL * seed + 2147483647ULL;
+    const uint32_t t = (uint32_t)((seed >> 25) & 0x7FFFFF) | (127u << 23);
+    return __uint_as_float(t) - 1.0f;
+}
+
+// block_ffm.rs:784-829
+__global__ void ffm_init_kernel(float *w, float *acc, unsigned long long len, float one_over_k_root, float init_width,
+                                float init_zero_band, float init_center, float acc0) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) {
+        float x;
+        if (init_width == 0.0f) {
+            x = __fmul_rn(__fsub_rn(__fmul_rn(1.0f, merand48(len + i)), 0.5f), one_over_k_root);
+        } else {
+            const float zero_half_band_width = __fmul_rn(__fmul_rn(init_width, init_zero_band), 0.5f);
+            const float band_width = __fmul_rn(init_width, __fsub_rn(1.0f, init_zero_band));
+            x = __fsub_rn(__fmul_rn(merand48(i), band_width), __fmul_rn(band_width, 0.5f));
+            if (x > 0.0f)
+                x = __fadd_rn(x, zero_half_band_width);
+            else
+                x = __fsub_rn(x, zero_half_band_width);
+            x = __fadd_rn(x, init_center);
+        }
+        w[i] = x;
+        acc[i] = acc0;
+    }
+}
+
+hipError_t launch_ffm_init(float *w, float *acc, uint64_t len, uint32_t k, float init_width, float init_zero_band,
+                           float init_center, float acc0, hipStream_t stream) {
+    if (!len) return hipSuccess;
+    const float one_over_k_root = 1.0f / sqrtf((float)k) / 50.0f;  // block_ffm.rs:797
+    hipLaunchKernelGGL(ffm_init_kernel, dim3(2048), dim3(256), 0, stream, w, acc, (unsigned long long)len,
+                       one_over_k_root, init_width, init_zero_band, init_center, acc0);
+    return hipGetLastError();
+}
+
+__global__ void fill_kernel(float *p, unsigned long long n, float v) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+hipError_t launch_fill(float *p, uint64_t n, float v, hipStream_t stream) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, stream, p, (unsigned long long)n, v);
+    return hipGetLastError();
+}
+
+__global__ void fill_lr_kernel(float2 *p, unsigned long long n, float w, float acc) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        p[i] = float2{w, acc};
+}
+hipError_t launch_fill_lr(float *lr, uint64_t n_entries, float w, float acc, hipStream_t stream) {
+    if (!n_entries) return hipSuccess;
+    hipLaunchKernelGGL(fill_lr_kernel, dim3(2048), dim3(256), 0, stream, reinterpret_cast<float2 *>(lr),
+                       (unsigned long long)n_entries, w, acc);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {  // splitmix64 finaliser
+    x ^= x >> 30;
+    x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27;
+    x *= 0x94d049bb133111ebULL;
+    x ^= x >> 31;
+    return x;
+}
+__global__ void checksum_kernel(const float *p, unsigned long long n, unsigned long long *out) {
+    unsigned long long acc = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        acc += mix64((i << 32) ^ (unsigned long long)__float_as_uint(p[i]) ^ (i >> 32));
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+hipError_t launch_checksum(const float *p, uint64_t n, unsigned long long *out, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(checksum_kernel, dim3(2048), dim3(256), 0, stream, p, (unsigned long long)n, out);
+    return hipGetLastError();
+}
+
+
+// ------------------------------------------------------------------ cross-XCD visibility probe (debug / tests)
+// Block 0 publishes a 1 KiB payload (value = iteration number) with sc1 or plain stores, drains its stores and
+// bumps a device-scope flag.  Every other block (they land on all 8 XCDs) keeps the payload line warm in its
+// own L1/L2, waits for the flag, re-reads the payload with sc1 or plain loads and counts words older than the
+// flag.  No fences: this is exactly the access pattern of the hogwild-mode table traffic.
+__global__ void coherence_probe_kernel(unsigned *payload, unsigned *flag, unsigned *acks, unsigned *stale,
+                                       unsigned *timeouts, int use_sc1, unsigned iters) {
+    const int lane = threadIdx.x;  // 64 threads
+    const unsigned nblk = gridDim.x;
+    __amdgpu_buffer_rsrc_t rs = make_rsrc(payload, 256 * 4);
+    const unsigned spin_cap = 4000000u;
+    if (blockIdx.x == 0) {
+        for (unsigned it = 1; it <= iters; ++it) {
+            u4 v = {it, it, it, it};
+            if (use_sc1)
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, lane * 16, 0, kAuxSc1);
+            else
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, lane * 16, 0, kAuxPlain);
+            __builtin_amdgcn_s_waitcnt(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                __hip_atomic_store(flag, it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (unsigned b = 1; b < nblk; ++b) {
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(acks + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < it) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > spin_cap) {
+                            atomicAdd(timeouts, 1u);
+                            return;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        unsigned bad = 0;
+        for (unsigned it = 1; it <= iters; ++it) {
+            unsigned spins = 0;
+            for (;;) {
+                // keep the payload line resident in this CU's L1 / this XCD's L2 while waiting
+                u4 w = use_sc1 ? __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, 0, kAuxSc1)
+                               : __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, 0, kAuxPlain);
+                unsigned f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (f >= it) break;
+                if (w.x == 0xdeadbeefu) bad += 1000000u;  // keeps the load alive
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > spin_cap) {
+                    if (lane == 0) atomicAdd(timeouts, 1u);
+                    return;
+                }
+            }
+            u4 v = use_sc1 ? __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, 0, kAuxSc1)
+                           : __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, 0, kAuxPlain);
+            bad += (v.x < it) + (v.y < it) + (v.z < it) + (v.w < it);
+            __builtin_amdgcn_s_waitcnt(0);
+            if (lane == 0) __hip_atomic_store(acks + blockIdx.x, it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+        }
+        if (bad) atomicAdd(stale, bad);
+    }
+}
+
+hipError_t launch_coherence_probe(unsigned *scratch /* >= 256+1+64+2 words, zeroed */, int use_sc1, unsigned iters,
+                                  unsigned blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(coherence_probe_kernel, dim3(blocks), dim3(64), 0, stream, scratch, scratch + 256,
+                       scratch + 320, scratch + 400, scratch + 401, use_sc1, iters);
+    return hipGetLastError();
+}
+
+}  // namespace fwgpu

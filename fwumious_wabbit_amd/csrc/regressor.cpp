@@ -1,0 +1,606 @@
+// Host side of the C ABI: the `Regressor` object (regressor.rs:142-147) that owns the device tables,
+// single-example learn/predict (regressor.rs:356-395), micro-batches, and weight (de)serialisation
+// (regressor.rs:426-469).  There is no CPU compute path: every learn/predict runs the HIP kernel.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <memory>
+
+#include "fwgpu_internal.h"
+
+namespace fwgpu {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string &msg) { g_last_error = msg; }
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+// optimizer.rs:121-144 (host: runs once per block at create time, then lives in HBM)
+void lut_init(float *lut, float learning_rate, float power_t, float init_acc) {
+    const float minus_power_t = -power_t;
+    for (uint32_t x = 0; x < (uint32_t)kLutSize; x++) {
+        uint32_t b0 = x << (31 - kLutBits), b1 = (x + 1) << (31 - kLutBits);
+        float f0, f1;
+        memcpy(&f0, &b0, 4);
+        memcpy(&f1, &b1, 4);
+        const float float_x = f0 + init_acc;
+        const float float_x_plus_one = f1 + init_acc;
+        float val = learning_rate * (powf(float_x, minus_power_t) + powf(float_x_plus_one, minus_power_t)) * 0.5f;
+        if (std::isnan(val) || std::isinf(val)) val = learning_rate;
+        lut[x] = val;
+    }
+}
+
+static float initial_acc(int optimizer, float init_acc) {
+    // optimizer.rs:40-42 (SGD: no state), 90-92 (Flex: init_acc), 158-161 (LUT: 0.0, folded into the table)
+    return optimizer == FWGPU_OPT_ADAGRAD_FLEX ? init_acc : 0.0f;
+}
+
+void HostBatch::clear() {
+    ffm_hash.clear();
+    ffm_val.clear();
+    ffm_fld.clear();
+    lr_hash.clear();
+    lr_val.clear();
+    label.clear();
+    importance.clear();
+    ffm_off.assign(1, 0);
+    lr_off.assign(1, 0);
+    max_lr = max_ffm = 0;
+    aligned4 = true;
+}
+
+int append_example(const fwgpu_regressor *r, HostBatch &hb, const fwgpu_lr_entry *lr, uint32_t n_lr,
+                   const fwgpu_ffm_entry *ffm, uint32_t n_ffm, float label, float importance) {
+    if (hb.ffm_off.empty()) hb.clear();
+    const uint32_t k = r->cfg.ffm_k, F = r->cfg.ffm_num_fields;
+    if (k == 0) n_ffm = 0;  // no FFM block: ffm_buffer is ignored
+    uint32_t prev = 0;
+    for (uint32_t i = 0; i < n_ffm; i++) {
+        const uint32_t cfi = ffm[i].contra_field_index;
+        if (cfi % k != 0 || cfi / k >= F) return fail(FWGPU_ERR_RANGE, "ffm entry: contra_field_index is not field*k of a known field");
+        if (cfi < prev) return fail(FWGPU_ERR_INVALID, "ffm entries must be ordered by field (block_ffm.rs:165-183)");
+        prev = cfi;
+        if ((uint64_t)ffm[i].hash + (uint64_t)F * k > r->ffm_len) return fail(FWGPU_ERR_RANGE, "ffm entry: hash outside the weight table");
+        if (ffm[i].hash & 3u) hb.aligned4 = false;
+        hb.ffm_hash.push_back(ffm[i].hash);
+        hb.ffm_val.push_back(ffm[i].value);
+        hb.ffm_fld.push_back((uint8_t)(cfi / k));
+    }
+    if (r->cfg.wiring == FWGPU_WIRING_FFM_ONLY) n_lr = 0;
+    for (uint32_t i = 0; i < n_lr; i++) {
+        if (lr[i].hash >= r->lr_len) return fail(FWGPU_ERR_RANGE, "lr entry: hash outside the weight table");
+        if (lr[i].combo_index >= r->cfg.num_combos) return fail(FWGPU_ERR_RANGE, "lr entry: combo_index >= num_combos");
+        hb.lr_hash.push_back(lr[i].hash);
+        hb.lr_val.push_back(lr[i].value);
+    }
+    hb.ffm_off.push_back((uint32_t)hb.ffm_hash.size());
+    hb.lr_off.push_back((uint32_t)hb.lr_hash.size());
+    hb.label.push_back(label);
+    hb.importance.push_back(importance);
+    hb.max_lr = std::max(hb.max_lr, n_lr);
+    hb.max_ffm = std::max(hb.max_ffm, n_ffm);
+    return FWGPU_OK;
+}
+
+static size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int batch_alloc(fwgpu_regressor *r, uint32_t n, uint64_t n_lr, uint64_t n_ffm, fwgpu_batch **out) {
+    std::unique_ptr<fwgpu_batch> b(new fwgpu_batch());
+    b->owner = r;
+    b->n = n;
+    b->n_lr = n_lr;
+    b->n_ffm = n_ffm;
+    size_t o = 0, off[10];
+    off[0] = o; o = up256(o + 4 * n_ffm);
+    off[1] = o; o = up256(o + 4 * n_ffm);
+    off[2] = o; o = up256(o + n_ffm);
+    off[3] = o; o = up256(o + 4 * ((size_t)n + 1));
+    off[4] = o; o = up256(o + 4 * n_lr);
+    off[5] = o; o = up256(o + 4 * n_lr);
+    off[6] = o; o = up256(o + 4 * ((size_t)n + 1));
+    off[7] = o; o = up256(o + 4 * (size_t)n);
+    off[8] = o; o = up256(o + 4 * (size_t)n);
+    off[9] = o; o = up256(o + 4 * (size_t)n);
+    b->dev_bytes = std::max<size_t>(o, 256);
+    FWGPU_HIP(hipSetDevice(r->device));
+    FWGPU_HIP(hipMalloc(&b->dev, b->dev_bytes));
+    unsigned char *base = static_cast<unsigned char *>(b->dev);
+    b->ffm_hash = reinterpret_cast<uint32_t *>(base + off[0]);
+    b->ffm_val = reinterpret_cast<float *>(base + off[1]);
+    b->ffm_fld = reinterpret_cast<uint8_t *>(base + off[2]);
+    b->ffm_off = reinterpret_cast<uint32_t *>(base + off[3]);
+    b->lr_hash = reinterpret_cast<uint32_t *>(base + off[4]);
+    b->lr_val = reinterpret_cast<float *>(base + off[5]);
+    b->lr_off = reinterpret_cast<uint32_t *>(base + off[6]);
+    b->label = reinterpret_cast<float *>(base + off[7]);
+    b->importance = reinterpret_cast<float *>(base + off[8]);
+    b->pred = reinterpret_cast<float *>(base + off[9]);
+    *out = b.release();
+    return FWGPU_OK;
+}
+
+int batch_upload(fwgpu_batch *b, const HostBatch &hb, hipStream_t stream) {
+    const uint32_t n = hb.size();
+    if (n > b->n || hb.ffm_hash.size() > b->n_ffm || hb.lr_hash.size() > b->n_lr)
+        return fail(FWGPU_ERR_RANGE, "batch_upload: host batch larger than the device allocation");
+#define UP(dst, vec)                                                                                          \
+    if (!(vec).empty())                                                                                       \
+    FWGPU_HIP(hipMemcpyAsync((dst), (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice, stream))
+    UP(b->ffm_hash, hb.ffm_hash);
+    UP(b->ffm_val, hb.ffm_val);
+    UP(b->ffm_fld, hb.ffm_fld);
+    UP(b->ffm_off, hb.ffm_off);
+    UP(b->lr_hash, hb.lr_hash);
+    UP(b->lr_val, hb.lr_val);
+    UP(b->lr_off, hb.lr_off);
+    UP(b->label, hb.label);
+    UP(b->importance, hb.importance);
+#undef UP
+    b->max_lr = hb.max_lr;
+    b->max_ffm = hb.max_ffm;
+    b->aligned4 = hb.aligned4;
+    return FWGPU_OK;
+}
+
+KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int update) {
+    KernelParams p{};
+    p.ffm_w = r->d_ffm_w;
+    p.ffm_acc = r->d_ffm_acc;
+    p.lr = r->d_lr;
+    p.lut_lr = r->d_lut_lr;
+    p.lut_ffm = r->d_lut_ffm;
+    p.ffm_hash = b->ffm_hash;
+    p.ffm_val = b->ffm_val;
+    p.ffm_fld = b->ffm_fld;
+    p.ffm_off = b->ffm_off;
+    p.lr_hash = b->lr_hash;
+    p.lr_val = b->lr_val;
+    p.lr_off = b->lr_off;
+    p.label = b->label;
+    p.importance = b->importance;
+    p.pred = b->pred;
+    p.n_examples = b->n;
+    p.F = r->cfg.ffm_k ? r->cfg.ffm_num_fields : 0;
+    p.k = r->cfg.ffm_k;
+    p.R = p.F * p.k;
+    p.max_ffm = std::max<uint32_t>(4, (b->max_ffm + 3) & ~3u);
+    p.max_lr = std::max<uint32_t>(4, (b->max_lr + 3) & ~3u);
+    p.has_lr = r->cfg.wiring == FWGPU_WIRING_REGRESSOR;
+    p.update = update ? 1 : 0;
+    p.aligned4 = b->aligned4 ? 1 : 0;
+    p.lr_rate = r->cfg.learning_rate;
+    p.lr_minus_power_t = -r->cfg.power_t;
+    p.ffm_rate = r->cfg.ffm_learning_rate;
+    p.ffm_minus_power_t = -r->cfg.ffm_power_t;
+    return p;
+}
+
+uint32_t pick_grid(const fwgpu_regressor *r, const KernelParams &p, int mode, uint32_t threads) {
+    if (mode == FWGPU_MODE_SEQUENTIAL) return 1;
+    const size_t lds = std::max<size_t>(example_kernel_lds_bytes(p, r->cfg.optimizer), 1024);
+    uint32_t per_cu = (uint32_t)std::max<size_t>(1, r->lds_per_cu / lds);
+    per_cu = std::min<uint32_t>(per_cu, 2048 / threads);  // 32 waves per CU
+    per_cu = std::max<uint32_t>(per_cu, 1);
+    if (r->launch.workgroups_per_cu) per_cu = std::min(per_cu, r->launch.workgroups_per_cu);
+    const uint64_t g = (uint64_t)per_cu * (uint64_t)r->num_cus;
+    return (uint32_t)std::min<uint64_t>(g, p.n_examples);
+}
+
+static int run_batch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, hipStream_t stream) {
+    if (b->n == 0) return FWGPU_OK;
+    KernelParams p = make_params(r, b, update);
+    uint32_t threads = r->launch.threads;
+    if (mode == FWGPU_MODE_SEQUENTIAL) threads = std::max<uint32_t>(threads, 512);
+    if ((uint64_t)p.max_ffm > 4ull * threads) threads = 1024;
+    if ((uint64_t)p.max_ffm > 4ull * threads)
+        return fail(FWGPU_ERR_RANGE, "an example has more than 4096 FFM features");
+    const size_t lds = example_kernel_lds_bytes(p, r->cfg.optimizer);
+    if (lds > r->lds_per_cu)
+        return fail(FWGPU_ERR_RANGE, "example does not fit the 160 KiB LDS (k*F^2 or features per example too large)");
+    const uint32_t grid = pick_grid(r, p, mode, threads);
+    // An updating launch always uses device-scope (sc1) accesses; read-only launches use cached loads.
+    FWGPU_HIP(launch_example_kernel(p, r->cfg.optimizer, update != 0, grid, threads, stream));
+    return FWGPU_OK;
+}
+
+}  // namespace fwgpu
+
+using namespace fwgpu;
+
+extern "C" {
+
+const char *fwgpu_last_error(void) { return g_last_error.c_str(); }
+int fwgpu_abi_version(void) { return FWGPU_ABI_VERSION; }
+
+int fwgpu_create(const fwgpu_config *cfg, fwgpu_regressor **out) {
+    if (!cfg || !out) return fail(FWGPU_ERR_INVALID, "fwgpu_create: NULL argument");
+    *out = nullptr;
+    if (cfg->optimizer != FWGPU_OPT_SGD && cfg->optimizer != FWGPU_OPT_ADAGRAD_FLEX &&
+        cfg->optimizer != FWGPU_OPT_ADAGRAD_LUT)
+        return fail(FWGPU_ERR_INVALID, "fwgpu_create: unknown optimizer");
+    if (cfg->bit_precision < 1 || cfg->bit_precision > 31) return fail(FWGPU_ERR_INVALID, "fwgpu_create: bit_precision out of range");
+    if (cfg->ffm_k > 0) {
+        if (cfg->ffm_bit_precision < 1 || cfg->ffm_bit_precision > 31)
+            return fail(FWGPU_ERR_INVALID, "fwgpu_create: ffm_bit_precision out of range");
+        if (cfg->ffm_num_fields == 0 || cfg->ffm_num_fields > 255)
+            return fail(FWGPU_ERR_INVALID, "fwgpu_create: ffm_num_fields must be in 1..255");
+        // block_ffm.rs:96-101
+        if ((uint64_t)cfg->ffm_k * cfg->ffm_num_fields * cfg->ffm_num_fields > kFfmContraBufLen)
+            return fail(FWGPU_ERR_INVALID, "FFM_CONTRA_BUF_LEN is 41472. It needs to be at least ffm_k * number_of_fields^2");
+    }
+    if (cfg->wiring != FWGPU_WIRING_REGRESSOR && cfg->wiring != FWGPU_WIRING_FFM_ONLY)
+        return fail(FWGPU_ERR_INVALID, "fwgpu_create: unknown wiring");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(FWGPU_ERR_DEVICE, "fwgpu_create: no HIP device available (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(FWGPU_ERR_DEVICE, "fwgpu_create: device ordinal out of range");
+    std::unique_ptr<fwgpu_regressor> r(new fwgpu_regressor());
+    r->cfg = *cfg;
+    r->device = cfg->device;
+    FWGPU_HIP(hipSetDevice(r->device));
+    hipDeviceProp_t prop;
+    FWGPU_HIP(hipGetDeviceProperties(&prop, r->device));
+    r->num_cus = prop.multiProcessorCount;
+    r->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 64 * 1024;
+    r->lr_len = 1ull << cfg->bit_precision;
+    r->ffm_len = cfg->ffm_k ? (1ull << cfg->ffm_bit_precision) + (uint64_t)cfg->ffm_num_fields * cfg->ffm_k : 0;
+    r->lr_hash_mask = lr_hash_mask(cfg->bit_precision);
+    r->ffm_hash_mask = ffm_hash_mask(cfg->ffm_bit_precision, cfg->ffm_k);
+    FWGPU_HIP(hipMalloc((void **)&r->d_lr, r->lr_len * 2 * sizeof(float)));
+    FWGPU_HIP(hipMemset(r->d_lr, 0, r->lr_len * 2 * sizeof(float)));
+    if (r->ffm_len) {
+        // +64 floats of slack so that a 16 B vector at the very end of the spill-over tail stays in the allocation
+        FWGPU_HIP(hipMalloc((void **)&r->d_ffm_w, (r->ffm_len + 64) * sizeof(float)));
+        FWGPU_HIP(hipMalloc((void **)&r->d_ffm_acc, (r->ffm_len + 64) * sizeof(float)));
+        FWGPU_HIP(hipMemset(r->d_ffm_w, 0, (r->ffm_len + 64) * sizeof(float)));
+        FWGPU_HIP(hipMemset(r->d_ffm_acc, 0, (r->ffm_len + 64) * sizeof(float)));
+    }
+    // each block owns its optimizer instance: block_lr.rs:63-65, block_ffm.rs:86-91
+    std::vector<float> lut(kLutSize);
+    FWGPU_HIP(hipMalloc((void **)&r->d_lut_lr, kLutSize * sizeof(float)));
+    FWGPU_HIP(hipMalloc((void **)&r->d_lut_ffm, kLutSize * sizeof(float)));
+    lut_init(lut.data(), cfg->learning_rate, cfg->power_t, cfg->init_acc_gradient);
+    FWGPU_HIP(hipMemcpy(r->d_lut_lr, lut.data(), kLutSize * sizeof(float), hipMemcpyHostToDevice));
+    lut_init(lut.data(), cfg->ffm_learning_rate, cfg->ffm_power_t, cfg->ffm_init_acc_gradient);
+    FWGPU_HIP(hipMemcpy(r->d_lut_ffm, lut.data(), kLutSize * sizeof(float), hipMemcpyHostToDevice));
+    // accumulators start at initial_data() even before init_weights (Vec allocation happens there in the
+    // reference; a zero table with initial accumulators is the natural "new_without_weights" state here)
+    const float a0 = initial_acc(cfg->optimizer, cfg->init_acc_gradient);
+    if (a0 != 0.0f) FWGPU_HIP(launch_fill_lr(r->d_lr, r->lr_len, 0.0f, a0, 0));
+    const float fa0 = initial_acc(cfg->optimizer, cfg->ffm_init_acc_gradient);
+    if (r->ffm_len && fa0 != 0.0f) FWGPU_HIP(launch_fill(r->d_ffm_acc, r->ffm_len, fa0, 0));
+    FWGPU_HIP(hipDeviceSynchronize());
+    *out = r.release();
+    return FWGPU_OK;
+}
+
+int fwgpu_free(fwgpu_regressor *r) {
+    if (!r) return FWGPU_OK;
+    (void)hipSetDevice(r->device);
+    if (r->one) fwgpu_batch_free(r->one);
+    (void)hipFree(r->d_lr);
+    (void)hipFree(r->d_ffm_w);
+    (void)hipFree(r->d_ffm_acc);
+    (void)hipFree(r->d_lut_lr);
+    (void)hipFree(r->d_lut_ffm);
+    if (r->pinned) (void)hipHostFree(r->pinned);
+    delete r;
+    return FWGPU_OK;
+}
+
+int fwgpu_init_weights(fwgpu_regressor *r) {
+    if (!r) return fail(FWGPU_ERR_INVALID, "NULL regressor");
+    FWGPU_HIP(hipSetDevice(r->device));
+    const fwgpu_config &c = r->cfg;
+    // block_lr.rs:97-105
+    FWGPU_HIP(launch_fill_lr(r->d_lr, r->lr_len, 0.0f, initial_acc(c.optimizer, c.init_acc_gradient), 0));
+    // block_ffm.rs:784-829
+    if (r->ffm_len)
+        FWGPU_HIP(launch_ffm_init(r->d_ffm_w, r->d_ffm_acc, r->ffm_len, c.ffm_k, c.ffm_init_width, c.ffm_init_zero_band,
+                                  c.ffm_init_center, initial_acc(c.optimizer, c.ffm_init_acc_gradient), 0));
+    FWGPU_HIP(hipDeviceSynchronize());
+    return FWGPU_OK;
+}
+
+int fwgpu_set_launch(fwgpu_regressor *r, uint32_t threads, uint32_t workgroups_per_cu) {
+    if (!r) return fail(FWGPU_ERR_INVALID, "NULL regressor");
+    if (threads) {
+        if (threads % 64 || threads > 1024) return fail(FWGPU_ERR_INVALID, "threads must be a multiple of 64, <= 1024");
+        r->launch.threads = threads;
+    }
+    r->launch.workgroups_per_cu = workgroups_per_cu;
+    return FWGPU_OK;
+}
+
+// ------------------------------------------------------------------ single example
+
+static int ensure_one(fwgpu_regressor *r, uint32_t n_lr, uint32_t n_ffm) {
+    if (r->one && r->one->n_lr >= n_lr && r->one->n_ffm >= n_ffm) return FWGPU_OK;
+    if (r->one) {
+        fwgpu_batch_free(r->one);
+        r->one = nullptr;
+    }
+    return batch_alloc(r, 1, std::max<uint32_t>(n_lr * 2, 256), std::max<uint32_t>(n_ffm * 2, 256), &r->one);
+}
+
+static int learn_one(fwgpu_regressor *r, const fwgpu_lr_entry *lr, uint32_t n_lr, const fwgpu_ffm_entry *ffm,
+                     uint32_t n_ffm, float label, float importance, int update, float *prediction) {
+    if (!r || !prediction) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    if ((n_lr && !lr) || (n_ffm && !ffm)) return fail(FWGPU_ERR_INVALID, "NULL entry buffer");
+    FWGPU_HIP(hipSetDevice(r->device));
+    HostBatch hb;
+    hb.clear();
+    int rc = append_example(r, hb, lr, n_lr, ffm, n_ffm, label, importance);
+    if (rc) return rc;
+    rc = ensure_one(r, (uint32_t)hb.lr_hash.size(), (uint32_t)hb.ffm_hash.size());
+    if (rc) return rc;
+    rc = batch_upload(r->one, hb, 0);
+    if (rc) return rc;
+    rc = run_batch(r, r->one, FWGPU_MODE_SEQUENTIAL, update, 0);
+    if (rc) return rc;
+    FWGPU_HIP(hipMemcpy(prediction, r->one->pred, sizeof(float), hipMemcpyDeviceToHost));
+    return FWGPU_OK;
+}
+
+int fwgpu_learn(fwgpu_regressor *r, const fwgpu_lr_entry *lr, uint32_t n_lr, const fwgpu_ffm_entry *ffm, uint32_t n_ffm,
+                float label, float importance, int update, float *prediction) {
+    return learn_one(r, lr, n_lr, ffm, n_ffm, label, importance, update, prediction);
+}
+
+int fwgpu_predict(fwgpu_regressor *r, const fwgpu_lr_entry *lr, uint32_t n_lr, const fwgpu_ffm_entry *ffm,
+                  uint32_t n_ffm, float *prediction) {
+    return learn_one(r, lr, n_lr, ffm, n_ffm, 0.0f, 1.0f, 0, prediction);
+}
+
+// ------------------------------------------------------------------ batches
+
+int fwgpu_batch_create(fwgpu_regressor *r, const fwgpu_lr_entry *lr, const uint32_t *lr_off, const fwgpu_ffm_entry *ffm,
+                       const uint32_t *ffm_off, const float *label, const float *importance, uint32_t n,
+                       fwgpu_batch **out) {
+    if (!r || !out || !lr_off || !ffm_off || (n && (!label || !importance)))
+        return fail(FWGPU_ERR_INVALID, "fwgpu_batch_create: NULL argument");
+    *out = nullptr;
+    HostBatch hb;
+    hb.clear();
+    for (uint32_t i = 0; i < n; i++) {
+        if (lr_off[i + 1] < lr_off[i] || ffm_off[i + 1] < ffm_off[i]) return fail(FWGPU_ERR_INVALID, "offsets must be non-decreasing");
+        int rc = append_example(r, hb, lr ? lr + lr_off[i] : nullptr, lr_off[i + 1] - lr_off[i],
+                                ffm ? ffm + ffm_off[i] : nullptr, ffm_off[i + 1] - ffm_off[i], label[i], importance[i]);
+        if (rc) return rc;
+    }
+    fwgpu_batch *b = nullptr;
+    int rc = batch_alloc(r, n, hb.lr_hash.size(), hb.ffm_hash.size(), &b);
+    if (rc) return rc;
+    rc = batch_upload(b, hb, 0);
+    if (rc == FWGPU_OK && hipStreamSynchronize(0) != hipSuccess) rc = fail(FWGPU_ERR_DEVICE, "upload failed");
+    if (rc) {
+        fwgpu_batch_free(b);
+        return rc;
+    }
+    *out = b;
+    return FWGPU_OK;
+}
+
+int fwgpu_batch_free(fwgpu_batch *b) {
+    if (!b) return FWGPU_OK;
+    if (b->dev) (void)hipFree(b->dev);
+    delete b;
+    return FWGPU_OK;
+}
+
+int fwgpu_batch_size(const fwgpu_batch *b, uint32_t *n, uint64_t *n_lr, uint64_t *n_ffm) {
+    if (!b) return fail(FWGPU_ERR_INVALID, "NULL batch");
+    if (n) *n = b->n;
+    if (n_lr) *n_lr = b->n_lr;
+    if (n_ffm) *n_ffm = b->n_ffm;
+    return FWGPU_OK;
+}
+
+int fwgpu_learn_batch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, void *stream) {
+    if (!r || !b) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    if (b->owner != r) return fail(FWGPU_ERR_INVALID, "batch belongs to another regressor");
+    if (mode != FWGPU_MODE_SEQUENTIAL && mode != FWGPU_MODE_HOGWILD) return fail(FWGPU_ERR_INVALID, "unknown mode");
+    return run_batch(r, b, mode, update, static_cast<hipStream_t>(stream));
+}
+
+int fwgpu_batch_predictions(fwgpu_batch *b, float *host_out, uint32_t n, void *stream) {
+    if (!b || !host_out) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    if (n > b->n) return fail(FWGPU_ERR_RANGE, "n > batch size");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    FWGPU_HIP(hipMemcpyAsync(host_out, b->pred, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    FWGPU_HIP(hipStreamSynchronize(s));
+    return FWGPU_OK;
+}
+
+int fwgpu_batch_predictions_device(fwgpu_batch *b, void **dev_ptr) {
+    if (!b || !dev_ptr) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    *dev_ptr = b->pred;
+    return FWGPU_OK;
+}
+
+// ------------------------------------------------------------------ tables
+
+static int table_ptr(fwgpu_regressor *r, int which, float **p, uint64_t *n) {
+    if (!r) return fail(FWGPU_ERR_INVALID, "NULL regressor");
+    switch (which) {
+    case FWGPU_TABLE_LR: *p = r->d_lr; *n = r->lr_len * 2; return FWGPU_OK;
+    case FWGPU_TABLE_FFM_W: *p = r->d_ffm_w; *n = r->ffm_len; return FWGPU_OK;
+    case FWGPU_TABLE_FFM_ACC: *p = r->d_ffm_acc; *n = r->ffm_len; return FWGPU_OK;
+    }
+    return fail(FWGPU_ERR_INVALID, "unknown table");
+}
+
+int fwgpu_table_len(fwgpu_regressor *r, int which, uint64_t *n_floats) {
+    float *p;
+    uint64_t n;
+    int rc = table_ptr(r, which, &p, &n);
+    if (rc) return rc;
+    *n_floats = n;
+    return FWGPU_OK;
+}
+
+int fwgpu_table_device_ptr(fwgpu_regressor *r, int which, void **dev_ptr) {
+    float *p;
+    uint64_t n;
+    int rc = table_ptr(r, which, &p, &n);
+    if (rc) return rc;
+    if (!dev_ptr) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    *dev_ptr = p;
+    return FWGPU_OK;
+}
+
+int fwgpu_table_read(fwgpu_regressor *r, int which, uint64_t offset, uint64_t count, float *host_out) {
+    float *p;
+    uint64_t n;
+    int rc = table_ptr(r, which, &p, &n);
+    if (rc) return rc;
+    if (offset > n || count > n - offset) return fail(FWGPU_ERR_RANGE, "table_read out of range");
+    FWGPU_HIP(hipSetDevice(r->device));
+    FWGPU_HIP(hipDeviceSynchronize());
+    if (count) FWGPU_HIP(hipMemcpy(host_out, p + offset, count * sizeof(float), hipMemcpyDeviceToHost));
+    return FWGPU_OK;
+}
+
+int fwgpu_table_write(fwgpu_regressor *r, int which, uint64_t offset, uint64_t count, const float *host_in) {
+    float *p;
+    uint64_t n;
+    int rc = table_ptr(r, which, &p, &n);
+    if (rc) return rc;
+    if (offset > n || count > n - offset) return fail(FWGPU_ERR_RANGE, "table_write out of range");
+    FWGPU_HIP(hipSetDevice(r->device));
+    FWGPU_HIP(hipDeviceSynchronize());
+    if (count) FWGPU_HIP(hipMemcpy(p + offset, host_in, count * sizeof(float), hipMemcpyHostToDevice));
+    return FWGPU_OK;
+}
+
+int fwgpu_table_fill(fwgpu_regressor *r, int which, float value) {
+    float *p;
+    uint64_t n;
+    int rc = table_ptr(r, which, &p, &n);
+    if (rc) return rc;
+    FWGPU_HIP(hipSetDevice(r->device));
+    FWGPU_HIP(launch_fill(p, n, value, 0));
+    FWGPU_HIP(hipDeviceSynchronize());
+    return FWGPU_OK;
+}
+
+int fwgpu_table_checksum(fwgpu_regressor *r, int which, uint64_t *checksum) {
+    float *p;
+    uint64_t n;
+    int rc = table_ptr(r, which, &p, &n);
+    if (rc) return rc;
+    FWGPU_HIP(hipSetDevice(r->device));
+    unsigned long long *d = nullptr;
+    FWGPU_HIP(hipMalloc((void **)&d, sizeof(unsigned long long)));
+    hipError_t e = launch_checksum(p, n, d, 0);
+    unsigned long long h = 0;
+    if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(FWGPU_ERR_DEVICE, std::string("checksum: ") + hipGetErrorString(e));
+    *checksum = h;
+    return FWGPU_OK;
+}
+
+int fwgpu_debug_coherence_probe(int device, int use_sc1, uint32_t iters, uint32_t *stale_words, uint32_t *timeouts) {
+    if (!stale_words || !timeouts) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    FWGPU_HIP(hipSetDevice(device));
+    unsigned *d = nullptr;
+    FWGPU_HIP(hipMalloc((void **)&d, 512 * sizeof(unsigned)));
+    hipError_t e = hipMemset(d, 0, 512 * sizeof(unsigned));
+    if (e == hipSuccess) e = launch_coherence_probe(d, use_sc1, iters, 16, 0);
+    unsigned out[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpy(out, d + 400, sizeof(out), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(FWGPU_ERR_DEVICE, std::string("coherence probe: ") + hipGetErrorString(e));
+    *stale_words = out[0];
+    *timeouts = out[1];
+    return FWGPU_OK;
+}
+
+// ------------------------------------------------------------------ weight blob (regressor.rs:426-469)
+
+static uint64_t serialized_elems(const fwgpu_regressor *r) {
+    // sum of get_serialized_len(): block_lr.rs:253-255 (weights_len), block_ffm.rs:831-833 (ffm_weights_len)
+    return r->lr_len + r->ffm_len;
+}
+
+int fwgpu_serialized_len(fwgpu_regressor *r, uint64_t *n_bytes) {
+    if (!r || !n_bytes) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    const bool sgd = r->cfg.optimizer == FWGPU_OPT_SGD;
+    // SGD's PerWeightStore is PhantomData (0 bytes): optimizer.rs:20
+    *n_bytes = 8 + r->lr_len * (sgd ? 4 : 8) + r->ffm_len * (sgd ? 4 : 8);
+    return FWGPU_OK;
+}
+
+int fwgpu_write_weights(fwgpu_regressor *r, uint8_t *buf, uint64_t cap, uint64_t *written) {
+    uint64_t need = 0;
+    int rc = fwgpu_serialized_len(r, &need);
+    if (rc) return rc;
+    if (!buf || cap < need) return fail(FWGPU_ERR_RANGE, "write_weights: buffer too small");
+    FWGPU_HIP(hipSetDevice(r->device));
+    FWGPU_HIP(hipDeviceSynchronize());
+    const bool sgd = r->cfg.optimizer == FWGPU_OPT_SGD;
+    const uint64_t total = serialized_elems(r);
+    memcpy(buf, &total, 8);  // little-endian host
+    uint8_t *o = buf + 8;
+    if (!sgd) {
+        FWGPU_HIP(hipMemcpy(o, r->d_lr, r->lr_len * 8, hipMemcpyDeviceToHost));
+        o += r->lr_len * 8;
+    } else {
+        std::vector<float> tmp(r->lr_len * 2);
+        FWGPU_HIP(hipMemcpy(tmp.data(), r->d_lr, r->lr_len * 8, hipMemcpyDeviceToHost));
+        float *dst = reinterpret_cast<float *>(o);
+        for (uint64_t i = 0; i < r->lr_len; i++) dst[i] = tmp[2 * i];
+        o += r->lr_len * 4;
+    }
+    if (r->ffm_len) {
+        FWGPU_HIP(hipMemcpy(o, r->d_ffm_w, r->ffm_len * 4, hipMemcpyDeviceToHost));
+        o += r->ffm_len * 4;
+        if (!sgd) {
+            FWGPU_HIP(hipMemcpy(o, r->d_ffm_acc, r->ffm_len * 4, hipMemcpyDeviceToHost));
+            o += r->ffm_len * 4;
+        }
+    }
+    if (written) *written = (uint64_t)(o - buf);
+    return FWGPU_OK;
+}
+
+int fwgpu_read_weights(fwgpu_regressor *r, const uint8_t *buf, uint64_t len) {
+    uint64_t need = 0;
+    int rc = fwgpu_serialized_len(r, &need);
+    if (rc) return rc;
+    if (!buf || len < need) return fail(FWGPU_ERR_FORMAT, "read_weights: blob shorter than the model");
+    uint64_t total = 0;
+    memcpy(&total, buf, 8);
+    // regressor.rs:452-457: "Lenghts of weights array in regressor file differ"
+    if (total != serialized_elems(r)) return fail(FWGPU_ERR_FORMAT, "read_weights: weight count differs from the model's");
+    FWGPU_HIP(hipSetDevice(r->device));
+    FWGPU_HIP(hipDeviceSynchronize());
+    const bool sgd = r->cfg.optimizer == FWGPU_OPT_SGD;
+    const uint8_t *o = buf + 8;
+    if (!sgd) {
+        FWGPU_HIP(hipMemcpy(r->d_lr, o, r->lr_len * 8, hipMemcpyHostToDevice));
+        o += r->lr_len * 8;
+    } else {
+        std::vector<float> tmp(r->lr_len * 2, 0.0f);
+        const float *src = reinterpret_cast<const float *>(o);
+        for (uint64_t i = 0; i < r->lr_len; i++) tmp[2 * i] = src[i];
+        FWGPU_HIP(hipMemcpy(r->d_lr, tmp.data(), r->lr_len * 8, hipMemcpyHostToDevice));
+        o += r->lr_len * 4;
+    }
+    if (r->ffm_len) {
+        FWGPU_HIP(hipMemcpy(r->d_ffm_w, o, r->ffm_len * 4, hipMemcpyHostToDevice));
+        o += r->ffm_len * 4;
+        if (!sgd) {
+            FWGPU_HIP(hipMemcpy(r->d_ffm_acc, o, r->ffm_len * 4, hipMemcpyHostToDevice));
+            o += r->ffm_len * 4;
+        }
+    }
+    return FWGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,388 @@
+"""Host-side mirror of the reference interface for the LR+FFM path, over the C ABI (include/fwgpu.h).
+
+Names, argument meaning and error behaviour follow the reference so that the parity tests read like
+the reference's own tests:
+
+  ModelInstance            model_instance.rs:47-97 (only the fields this path reads)
+  FeatureBuffer            feature_buffer.rs:24-31
+  FeatureBufferTranslator  feature_buffer.rs:33-44, 138-338
+  Regressor                regressor.rs:142-147, 356-395, 426-469
+  HogwildTrainer           hogwild.rs:13-61
+
+All compute happens in libfwgpu.so on the GPU; nothing here falls back to the CPU.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _capi as capi
+from ._capi import FFM_ENTRY, LR_ENTRY, check, ptr
+
+
+class Optimizer:
+    """model_instance.rs:24-28"""
+    SGD = capi.OPT_SGD
+    AdagradFlex = capi.OPT_ADAGRAD_FLEX
+    AdagradLUT = capi.OPT_ADAGRAD_LUT
+
+
+@dataclass
+class NamespaceDescriptor:
+    """vwmap.rs:23-27 (primitive namespaces only)."""
+    namespace_index: int
+    namespace_format_f32: bool = False
+
+
+@dataclass
+class FeatureComboDesc:
+    """model_instance.rs FeatureComboDesc {namespace_descriptors, weight}."""
+    namespace_descriptors: List[NamespaceDescriptor]
+    weight: float = 1.0
+
+
+@dataclass
+class ModelInstance:
+    """Defaults = ModelInstance::new_empty() (model_instance.rs:120-150)."""
+    learning_rate: float = 0.5
+    ffm_learning_rate: float = 0.5
+    bit_precision: int = 18
+    power_t: float = 0.5
+    ffm_power_t: float = 0.5
+    add_constant_feature: bool = True
+    feature_combo_descs: List[FeatureComboDesc] = field(default_factory=list)
+    ffm_fields: List[List[NamespaceDescriptor]] = field(default_factory=list)
+    ffm_k: int = 0
+    ffm_bit_precision: int = 18
+    ffm_init_center: float = 0.0
+    ffm_init_width: float = 0.0
+    ffm_init_zero_band: float = 0.0
+    ffm_init_acc_gradient: float = 0.0
+    init_acc_gradient: float = 1.0
+    optimizer: int = Optimizer.SGD
+    # not in the reference: which graph the regressor is wired as (tests of the bare FFM block) and the device
+    wiring: int = capi.WIRING_REGRESSOR
+    device: int = 0
+
+    @property
+    def num_combos(self):  # block_lr.rs:53-56
+        return len(self.feature_combo_descs) + (1 if self.add_constant_feature else 0)
+
+    def to_config(self):
+        return capi.Config(self.optimizer, self.learning_rate, self.power_t, self.init_acc_gradient, self.bit_precision,
+                           self.num_combos, self.ffm_k, self.ffm_bit_precision, len(self.ffm_fields),
+                           self.ffm_learning_rate, self.ffm_power_t, self.ffm_init_acc_gradient, self.ffm_init_center,
+                           self.ffm_init_width, self.ffm_init_zero_band, self.wiring, self.device)
+
+
+@dataclass
+class FeatureBuffer:
+    """feature_buffer.rs:24-31.  lr_buffer rows (hash, value, combo_index); ffm_buffer rows
+    (hash, value, contra_field_index)."""
+    label: float = 0.0
+    example_importance: float = 1.0
+    example_number: int = 0
+    lr_buffer: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=LR_ENTRY))
+    ffm_buffer: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=FFM_ENTRY))
+
+
+def lr_vec(rows, label=0.0, importance=1.0):
+    """regressor.rs:544-552 test helper."""
+    return FeatureBuffer(label, importance, 0, np.array([tuple(r) for r in rows], dtype=LR_ENTRY).reshape(-1))
+
+
+def ffm_vec(rows, label=0.0, importance=1.0):
+    """block_ffm.rs:1219-1227 test helper."""
+    return FeatureBuffer(label, importance, 0, np.zeros(0, dtype=LR_ENTRY),
+                         np.array([tuple(r) for r in rows], dtype=FFM_ENTRY).reshape(-1))
+
+
+def lr_and_ffm_vec(lr_rows, ffm_rows, label=0.0, importance=1.0):
+    """persistence.rs:420-433 test helper."""
+    return FeatureBuffer(label, importance, 0, np.array([tuple(r) for r in lr_rows], dtype=LR_ENTRY).reshape(-1),
+                         np.array([tuple(r) for r in ffm_rows], dtype=FFM_ENTRY).reshape(-1))
+
+
+class FeatureBufferTranslator:
+    """feature_buffer.rs:33-44: record (&[u32]) -> FeatureBuffer.  Pure host code inside libfwgpu."""
+
+    def __init__(self, mi: ModelInstance):
+        self.mi = mi
+        co, cn, cf, cw = [0], [], [], []
+        for cd in mi.feature_combo_descs:
+            for nd in cd.namespace_descriptors:
+                cn.append(nd.namespace_index)
+                cf.append(int(nd.namespace_format_f32))
+            co.append(len(cn))
+            cw.append(cd.weight)
+        fo, fn, ff = [0], [], []
+        for fld in mi.ffm_fields:
+            for nd in fld:
+                fn.append(nd.namespace_index)
+                ff.append(int(nd.namespace_format_f32))
+            fo.append(len(fn))
+        self._keep = [np.array(co, np.uint32), np.array(cn, np.uint32), np.array(cf, np.uint8),
+                      np.array(cw, np.float32), np.array(fo, np.uint32), np.array(fn, np.uint32),
+                      np.array(ff, np.uint8)]
+        k = self._keep
+        self.c = capi.TranslatorConfig(len(mi.feature_combo_descs), ptr(k[0]), ptr(k[1]), ptr(k[2]), ptr(k[3]),
+                                       int(mi.add_constant_feature), len(mi.ffm_fields), ptr(k[4]), ptr(k[5]),
+                                       ptr(k[6]), mi.bit_precision, mi.ffm_k, mi.ffm_bit_precision)
+        L = capi.lib()
+        self.lr_hash_mask = L.fwgpu_lr_hash_mask(mi.bit_precision)
+        self.ffm_hash_mask = L.fwgpu_ffm_hash_mask(mi.ffm_bit_precision, mi.ffm_k)
+        self.feature_buffer = FeatureBuffer()
+
+    def translate(self, record_buffer, example_number=0, cap=8192):
+        """feature_buffer.rs:174-176"""
+        L = capi.lib()
+        rec = np.ascontiguousarray(record_buffer, dtype=np.uint32)
+        lr = np.zeros(cap, dtype=LR_ENTRY)
+        ffm = np.zeros(cap, dtype=FFM_ENTRY)
+        n_lr, n_ffm = C.c_uint32(0), C.c_uint32(0)
+        label, imp = C.c_float(0), C.c_float(0)
+        check(L.fwgpu_translate(C.byref(self.c), ptr(rec), len(rec), ptr(lr), cap, C.byref(n_lr), ptr(ffm), cap,
+                                C.byref(n_ffm), C.byref(label), C.byref(imp)))
+        self.feature_buffer = FeatureBuffer(label.value, imp.value, example_number, lr[: n_lr.value].copy(),
+                                            ffm[: n_ffm.value].copy())
+        return self.feature_buffer
+
+
+class Batch:
+    """A device-resident micro-batch of FeatureBuffers (CSR)."""
+
+    def __init__(self, regressor, handle):
+        self.regressor, self.h = regressor, handle
+        n, n_lr, n_ffm = C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
+        check(capi.lib().fwgpu_batch_size(self.h, C.byref(n), C.byref(n_lr), C.byref(n_ffm)))
+        self.n, self.n_lr, self.n_ffm = n.value, n_lr.value, n_ffm.value
+
+    def predictions(self, stream=None):
+        out = np.zeros(self.n, dtype=np.float32)
+        check(capi.lib().fwgpu_batch_predictions(self.h, ptr(out), self.n, stream))
+        return out
+
+    def close(self):
+        if self.h:
+            capi.lib().fwgpu_batch_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Regressor:
+    """regressor.rs:142-147.  `Regressor(mi)` == Regressor::new(&mi): builds the graph and initialises weights."""
+
+    def __init__(self, mi: ModelInstance, init_weights: bool = True):
+        self.mi = mi
+        self.L = capi.lib()
+        self.h = C.c_void_p()
+        cfg = mi.to_config()
+        check(self.L.fwgpu_create(C.byref(cfg), C.byref(self.h)))
+        if init_weights:
+            self.allocate_and_init_weights()
+
+    @classmethod
+    def new_without_weights(cls, mi):  # regressor.rs:173
+        return cls(mi, init_weights=False)
+
+    def allocate_and_init_weights(self, mi=None):  # regressor.rs:352-354
+        check(self.L.fwgpu_init_weights(self.h))
+
+    def get_name(self):  # regressor.rs:177
+        names = {Optimizer.SGD: "SGD", Optimizer.AdagradFlex: "AdagradFlex", Optimizer.AdagradLUT: "AdagradLUT"}
+        return f'Regressor with optimizer "{names[self.mi.optimizer]}"'
+
+    def new_portbuffer(self):  # regressor.rs:348-350: the tape lives in LDS on the device
+        return None
+
+    def close(self):
+        if self.h:
+            self.L.fwgpu_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- regressor.rs:356-395
+    def learn(self, fb: FeatureBuffer, pb=None, update: bool = True) -> float:
+        lr = np.ascontiguousarray(fb.lr_buffer, dtype=LR_ENTRY)
+        ffm = np.ascontiguousarray(fb.ffm_buffer, dtype=FFM_ENTRY)
+        out = C.c_float(0)
+        check(self.L.fwgpu_learn(self.h, ptr(lr), len(lr), ptr(ffm), len(ffm), fb.label, fb.example_importance,
+                                 int(update), C.byref(out)))
+        return out.value
+
+    def predict(self, fb: FeatureBuffer, pb=None) -> float:
+        lr = np.ascontiguousarray(fb.lr_buffer, dtype=LR_ENTRY)
+        ffm = np.ascontiguousarray(fb.ffm_buffer, dtype=FFM_ENTRY)
+        out = C.c_float(0)
+        check(self.L.fwgpu_predict(self.h, ptr(lr), len(lr), ptr(ffm), len(ffm), C.byref(out)))
+        return out.value
+
+    # ---- micro-batches
+    def batch(self, fbs: List[FeatureBuffer]) -> Batch:
+        lr = np.concatenate([np.ascontiguousarray(f.lr_buffer, dtype=LR_ENTRY) for f in fbs]) if fbs else np.zeros(0, LR_ENTRY)
+        ffm = np.concatenate([np.ascontiguousarray(f.ffm_buffer, dtype=FFM_ENTRY) for f in fbs]) if fbs else np.zeros(0, FFM_ENTRY)
+        lr_off = np.zeros(len(fbs) + 1, dtype=np.uint32)
+        ffm_off = np.zeros(len(fbs) + 1, dtype=np.uint32)
+        lr_off[1:] = np.cumsum([len(f.lr_buffer) for f in fbs])
+        ffm_off[1:] = np.cumsum([len(f.ffm_buffer) for f in fbs])
+        label = np.array([f.label for f in fbs], dtype=np.float32)
+        imp = np.array([f.example_importance for f in fbs], dtype=np.float32)
+        return self.batch_from_arrays(lr, lr_off, ffm, ffm_off, label, imp)
+
+    def batch_from_arrays(self, lr, lr_off, ffm, ffm_off, label, importance) -> Batch:
+        h = C.c_void_p()
+        lr = np.ascontiguousarray(lr, dtype=LR_ENTRY)
+        ffm = np.ascontiguousarray(ffm, dtype=FFM_ENTRY)
+        lr_off = np.ascontiguousarray(lr_off, dtype=np.uint32)
+        ffm_off = np.ascontiguousarray(ffm_off, dtype=np.uint32)
+        label = np.ascontiguousarray(label, dtype=np.float32)
+        importance = np.ascontiguousarray(importance, dtype=np.float32)
+        # zero-length arrays still need a valid offsets pointer
+        check(self.L.fwgpu_batch_create(self.h, ptr(lr), lr_off.ctypes.data_as(C.c_void_p), ptr(ffm),
+                                        ffm_off.ctypes.data_as(C.c_void_p), ptr(label), ptr(importance), len(label),
+                                        C.byref(h)))
+        return Batch(self, h)
+
+    def batch_from_records(self, translator: FeatureBufferTranslator, records, rec_off) -> Batch:
+        records = np.ascontiguousarray(records, dtype=np.uint32)
+        rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
+        h = C.c_void_p()
+        check(self.L.fwgpu_batch_from_records(self.h, C.byref(translator.c), ptr(records),
+                                              rec_off.ctypes.data_as(C.c_void_p), len(rec_off) - 1, C.byref(h)))
+        return Batch(self, h)
+
+    def learn_batch(self, batch: Batch, mode=capi.MODE_SEQUENTIAL, update=True, stream=None):
+        check(self.L.fwgpu_learn_batch(self.h, batch.h, mode, int(update), stream))
+
+    def set_launch(self, threads=0, workgroups_per_cu=0):
+        check(self.L.fwgpu_set_launch(self.h, threads, workgroups_per_cu))
+
+    # ---- tables
+    def table_len(self, which):
+        n = C.c_uint64(0)
+        check(self.L.fwgpu_table_len(self.h, which, C.byref(n)))
+        return n.value
+
+    def table_read(self, which, offset=0, count=None):
+        count = self.table_len(which) - offset if count is None else count
+        out = np.zeros(count, dtype=np.float32)
+        check(self.L.fwgpu_table_read(self.h, which, offset, count, ptr(out)))
+        return out
+
+    def table_write(self, which, values, offset=0):
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        check(self.L.fwgpu_table_write(self.h, which, offset, len(v), ptr(v)))
+
+    def table_fill(self, which, value):
+        check(self.L.fwgpu_table_fill(self.h, which, value))
+
+    def table_checksum(self, which):
+        c = C.c_uint64(0)
+        check(self.L.fwgpu_table_checksum(self.h, which, C.byref(c)))
+        return c.value
+
+    def table_device_ptr(self, which):
+        p = C.c_void_p()
+        check(self.L.fwgpu_table_device_ptr(self.h, which, C.byref(p)))
+        return p.value
+
+    def table_as_torch(self, which):
+        """Zero-copy torch view of a table (device memory stays owned by the library)."""
+        import torch
+
+        n = self.table_len(which)
+
+        class _View:
+            pass
+
+        v = _View()
+        v.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (self.table_device_ptr(which), False),
+                                      "version": 2}
+        t = torch.as_tensor(v, device=f"cuda:{self.mi.device}")
+        t._fwgpu_owner = self  # keep the regressor alive as long as the view
+        return t
+
+    def ffm_fill(self, w):
+        """The reference tests' ffm_init (block_ffm.rs:1228-1235): weights = w, accumulators = initial_data()."""
+        self.table_fill(capi.TABLE_FFM_W, w)
+        a0 = self.mi.ffm_init_acc_gradient if self.mi.optimizer == Optimizer.AdagradFlex else 0.0
+        self.table_fill(capi.TABLE_FFM_ACC, a0)
+
+    # ---- regressor.rs:426-469
+    def write_weights_to_buf(self) -> bytes:
+        n = C.c_uint64(0)
+        check(self.L.fwgpu_serialized_len(self.h, C.byref(n)))
+        buf = np.zeros(n.value, dtype=np.uint8)
+        w = C.c_uint64(0)
+        check(self.L.fwgpu_write_weights(self.h, ptr(buf), n.value, C.byref(w)))
+        return buf[: w.value].tobytes()
+
+    def overwrite_weights_from_buf(self, blob: bytes):
+        b = np.frombuffer(blob, dtype=np.uint8)
+        check(self.L.fwgpu_read_weights(self.h, ptr(b), len(b)))
+
+
+class HogwildTrainer:
+    """hogwild.rs:13-61.  num_workers has no meaning on the device; micro_batch replaces it."""
+
+    def __init__(self, regressor: Regressor, model_instance: ModelInstance, num_workers: int = 16,
+                 micro_batch: int = 4096):
+        self.regressor = regressor
+        self.translator = FeatureBufferTranslator(model_instance)
+        self.h = C.c_void_p()
+        check(capi.lib().fwgpu_trainer_create(regressor.h, C.byref(self.translator.c), micro_batch, C.byref(self.h)))
+
+    def digest_example(self, feature_buffer):
+        """hogwild.rs:51-53: one record (Vec<u32>)."""
+        rec = np.ascontiguousarray(feature_buffer, dtype=np.uint32)
+        off = np.array([0, len(rec)], dtype=np.uint64)
+        check(capi.lib().fwgpu_digest_records(self.h, ptr(rec), ptr(off), 1))
+
+    def digest_records(self, records, rec_off):
+        records = np.ascontiguousarray(records, dtype=np.uint32)
+        rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
+        check(capi.lib().fwgpu_digest_records(self.h, ptr(records), ptr(rec_off), len(rec_off) - 1))
+
+    def block_until_workers_finished(self):
+        """hogwild.rs:55-60"""
+        check(capi.lib().fwgpu_finish(self.h))
+
+    def examples_seen(self):
+        n = C.c_uint64(0)
+        check(capi.lib().fwgpu_trainer_examples_seen(self.h, C.byref(n)))
+        return n.value
+
+    def close(self):
+        if self.h:
+            capi.lib().fwgpu_trainer_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def synth_records(n_namespaces, mean_extra, zipf_s, ids_per_ns, p_weighted, seed, first_example, n):
+    """Synthetic record stream of the BASELINE.json configs (see fwgpu_synth_records in include/fwgpu.h).
+    Returns (records u32[], rec_off u64[n+1])."""
+    L = capi.lib()
+    cfg = capi.SynthConfig(n_namespaces, mean_extra, zipf_s, ids_per_ns, p_weighted, seed)
+    nw = C.c_uint64(0)
+    rec_off = np.zeros(n + 1, dtype=np.uint64)
+    check(L.fwgpu_synth_records(C.byref(cfg), first_example, n, None, 0, ptr(rec_off), C.byref(nw)))
+    records = np.zeros(nw.value, dtype=np.uint32)
+    check(L.fwgpu_synth_records(C.byref(cfg), first_example, n, ptr(records), nw.value, ptr(rec_off), C.byref(nw)))
+    return records, rec_off

@@ -1,0 +1,239 @@
+/*
+ * fwgpu.h -- C ABI of the MI355X-native LR+FFM online learner.
+ *
+ * This library is a drop-in for ONE path of outbrain-inc/fwumious_wabbit: what sits behind
+ * `Regressor` (src/regressor.rs:142-147) and `HogwildTrainer` (src/hogwild.rs:13-61), i.e.
+ * block_lr / block_ffm / block_misc::Triangle / block_loss_functions / optimizer / hogwild.
+ * Everything is plain pointers and sizes; no C++/torch types cross this boundary.
+ *
+ * Conventions (cf. the reference's existing predict-only C ABI, src/lib.rs:151-243):
+ *  - every call returns an int status (FWGPU_OK == 0); fwgpu_last_error() gives the message of the
+ *    last failure on the calling thread.  Nothing unwinds across the boundary.
+ *  - the caller owns every input buffer; buffers are borrowed for the duration of the call only
+ *    (fwgpu_digest_records copies the records, like main.rs:243 `Vec::from(buffer)`).
+ *  - the library owns weights, optimizer state and all device scratch.
+ *  - one handle == one device context.  learn/update calls on one handle are single-producer
+ *    (regressor.rs:362-365: learn() is not thread-safe).
+ *  - `stream` arguments are `hipStream_t` passed as void* (NULL = the null stream), so a caller that
+ *    already runs on a stream (e.g. torch.cuda.current_stream().cuda_stream) can time and order the
+ *    work with its own events.
+ *  - there is NO CPU fallback: if no HIP device is usable fwgpu_create fails with FWGPU_ERR_DEVICE.
+ */
+#ifndef FWGPU_H
+#define FWGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FWGPU_ABI_VERSION 1
+
+enum {
+    FWGPU_OK = 0,
+    FWGPU_ERR_INVALID = 1, /* bad argument / config (the reference exits 1: main.rs:44-47) */
+    FWGPU_ERR_DEVICE = 2,  /* HIP error or no device */
+    FWGPU_ERR_OOM = 3,
+    FWGPU_ERR_RANGE = 4,   /* buffer too small / index out of range */
+    FWGPU_ERR_FORMAT = 5   /* malformed record or weight blob */
+};
+
+/* model_instance.rs:24-28 `enum Optimizer` */
+enum { FWGPU_OPT_SGD = 100, FWGPU_OPT_ADAGRAD_FLEX = 200, FWGPU_OPT_ADAGRAD_LUT = 300 };
+
+/* Graph wiring.  REGRESSOR: regressor.rs:173-330 LR -> [FFM -> Triangle -> Join] -> Sigmoid.
+ * FFM_ONLY: the wiring of the reference's FFM block tests (block_ffm.rs:1253-1254: FFM -> Sigmoid). */
+enum { FWGPU_WIRING_REGRESSOR = 0, FWGPU_WIRING_FFM_ONLY = 1 };
+
+/* How a batch is executed on the device.
+ * SEQUENTIAL: one workgroup walks the batch in order; example i sees every update of examples <i.
+ *             This is the reference's single-thread semantics (main.rs:213-270) and the parity mode.
+ * HOGWILD:    all workgroups run examples concurrently against the shared tables with unsynchronised
+ *             read-modify-write, the device analogue of hogwild.rs:24-103 (non-deterministic). */
+enum { FWGPU_MODE_SEQUENTIAL = 0, FWGPU_MODE_HOGWILD = 1 };
+
+/* feature_buffer.rs:10-15 `HashAndValue` */
+typedef struct fwgpu_lr_entry {
+    uint32_t hash;
+    float value;
+    uint32_t combo_index;
+} fwgpu_lr_entry;
+
+/* feature_buffer.rs:17-22 `HashAndValueAndSeq` */
+typedef struct fwgpu_ffm_entry {
+    uint32_t hash;
+    float value;
+    uint32_t contra_field_index; /* field * ffm_k */
+} fwgpu_ffm_entry;
+
+/* The ModelInstance fields the blocks on this path read (model_instance.rs:47-97;
+ * block_lr.rs:53-67, block_ffm.rs:70-94, 793-822). */
+typedef struct fwgpu_config {
+    int32_t optimizer;        /* FWGPU_OPT_* */
+    float learning_rate;      /* -l */
+    float power_t;            /* --power_t */
+    float init_acc_gradient;  /* --init_acc_gradient */
+    uint32_t bit_precision;   /* -b : LR table has 2^b entries (block_lr.rs:67) */
+    uint32_t num_combos;      /* feature_combo_descs.len() + (add_constant_feature ? 1 : 0) (block_lr.rs:53-56) */
+    uint32_t ffm_k;           /* --ffm_k, 0 = no FFM block */
+    uint32_t ffm_bit_precision;
+    uint32_t ffm_num_fields;  /* ffm_fields.len() */
+    float ffm_learning_rate, ffm_power_t, ffm_init_acc_gradient;
+    float ffm_init_center, ffm_init_width, ffm_init_zero_band;
+    int32_t wiring;           /* FWGPU_WIRING_* */
+    int32_t device;           /* HIP device ordinal */
+} fwgpu_config;
+
+typedef struct fwgpu_regressor fwgpu_regressor; /* opaque, like lib.rs:50-53 FfiPredictor */
+typedef struct fwgpu_batch fwgpu_batch;         /* opaque device-resident micro-batch */
+typedef struct fwgpu_trainer fwgpu_trainer;     /* opaque record-stream trainer (HogwildTrainer role) */
+
+const char *fwgpu_last_error(void);
+int fwgpu_abi_version(void);
+
+/* ---------------------------------------------------------------- Regressor
+ * fwgpu_create        <= Regressor::new_without_weights(&ModelInstance)   regressor.rs:173-330
+ *                        (tables are allocated here, zero-filled)
+ * fwgpu_init_weights  <= Regressor::allocate_and_init_weights             regressor.rs:352-354
+ * fwgpu_learn         <= Regressor::learn(&FeatureBuffer,&mut PortBuffer,update) -> f32   regressor.rs:356-379
+ * fwgpu_predict       <= Regressor::predict(&FeatureBuffer,&mut PortBuffer) -> f32        regressor.rs:381-395
+ * fwgpu_free          <= drop(Regressor)
+ * The FeatureBuffer (feature_buffer.rs:24-31) is passed as its four members. ffm entries must be
+ * ordered by field, as FeatureBufferTranslator produces them (block_ffm.rs:165-183 relies on it). */
+int fwgpu_create(const fwgpu_config *cfg, fwgpu_regressor **out);
+int fwgpu_free(fwgpu_regressor *r);
+int fwgpu_init_weights(fwgpu_regressor *r);
+int fwgpu_learn(fwgpu_regressor *r, const fwgpu_lr_entry *lr, uint32_t n_lr, const fwgpu_ffm_entry *ffm,
+                uint32_t n_ffm, float label, float importance, int update, float *prediction);
+int fwgpu_predict(fwgpu_regressor *r, const fwgpu_lr_entry *lr, uint32_t n_lr, const fwgpu_ffm_entry *ffm,
+                  uint32_t n_ffm, float *prediction);
+
+/* ---------------------------------------------------------------- weight (de)serialisation
+ * fwgpu_serialized_len / fwgpu_write_weights / fwgpu_read_weights
+ *      <= Regressor::write_weights_to_buf / overwrite_weights_from_buf    regressor.rs:426-469
+ * Blob = u64 LE total element count (sum of get_serialized_len), then per block, in order:
+ *   LR : 2^b x {f32 w, f32 acc}   (SGD: {f32 w})              block_lr.rs:257-275, block_helpers.rs:17-28
+ *   FFM: len x f32 w, then len x f32 acc (SGD: no acc part)   block_ffm.rs:835-863
+ * fwgpu_serialized_len returns the byte size of that blob. */
+int fwgpu_serialized_len(fwgpu_regressor *r, uint64_t *n_bytes);
+int fwgpu_write_weights(fwgpu_regressor *r, uint8_t *buf, uint64_t cap, uint64_t *written);
+int fwgpu_read_weights(fwgpu_regressor *r, const uint8_t *buf, uint64_t len);
+
+/* Raw table access (tests, weight patching).  which: 0 = LR table as interleaved {w,acc} floats
+ * (2*2^b floats), 1 = FFM weights, 2 = FFM optimizer state (each 2^ffm_bits + F*k floats,
+ * block_ffm.rs:92-94).  Offsets and counts are in floats. */
+enum { FWGPU_TABLE_LR = 0, FWGPU_TABLE_FFM_W = 1, FWGPU_TABLE_FFM_ACC = 2 };
+int fwgpu_table_len(fwgpu_regressor *r, int which, uint64_t *n_floats);
+int fwgpu_table_read(fwgpu_regressor *r, int which, uint64_t offset, uint64_t count, float *host_out);
+int fwgpu_table_write(fwgpu_regressor *r, int which, uint64_t offset, uint64_t count, const float *host_in);
+int fwgpu_table_fill(fwgpu_regressor *r, int which, float value);
+/* Order-independent checksum of a table computed on the device: sum over i of
+ * mix64(i ^ bits(table[i])) (wrapping u64). */
+int fwgpu_table_checksum(fwgpu_regressor *r, int which, uint64_t *checksum);
+/* Device address of a table (for zero-copy interop, e.g. wrapping it for an RCCL all-reduce). */
+int fwgpu_table_device_ptr(fwgpu_regressor *r, int which, void **dev_ptr);
+
+/* ---------------------------------------------------------------- micro-batches
+ * A batch is a CSR of FeatureBuffers resident in HBM: example i owns lr[lr_off[i]..lr_off[i+1]) and
+ * ffm[ffm_off[i]..ffm_off[i+1]).  label/importance per example (feature_buffer.rs:187-189).
+ * fwgpu_batch_create copies host arrays to the device (synchronously, on the null stream). */
+int fwgpu_batch_create(fwgpu_regressor *r, const fwgpu_lr_entry *lr, const uint32_t *lr_off,
+                       const fwgpu_ffm_entry *ffm, const uint32_t *ffm_off, const float *label,
+                       const float *importance, uint32_t n_examples, fwgpu_batch **out);
+int fwgpu_batch_free(fwgpu_batch *b);
+int fwgpu_batch_size(const fwgpu_batch *b, uint32_t *n_examples, uint64_t *n_lr, uint64_t *n_ffm);
+/* Enqueue one pass over the batch on `stream`: for every example, Regressor::learn(fb, update)
+ * (update=0: Regressor::predict).  Predictions land in the batch's device buffer. Asynchronous. */
+int fwgpu_learn_batch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, void *stream);
+/* Copy the batch's predictions to the host (synchronises `stream`). */
+int fwgpu_batch_predictions(fwgpu_batch *b, float *host_out, uint32_t n, void *stream);
+/* Device pointer of the batch's prediction buffer (n_examples floats). */
+int fwgpu_batch_predictions_device(fwgpu_batch *b, void **dev_ptr);
+
+/* ---------------------------------------------------------------- record translation
+ * FeatureBufferTranslator (feature_buffer.rs:33-44, 138-338) for primitive namespaces.
+ * A translator describes which namespaces feed which LR combo / FFM field; namespaces are
+ * identified by their index in the record (vwmap.rs:115-147). */
+typedef struct fwgpu_translator_config {
+    uint32_t n_combos;           /* feature_combo_descs.len() */
+    const uint32_t *combo_off;   /* n_combos+1 offsets into combo_ns */
+    const uint32_t *combo_ns;    /* namespace_index of each combo member */
+    const uint8_t *combo_ns_f32; /* 1 if the namespace is NamespaceFormat::F32 */
+    const float *combo_weight;   /* per combo */
+    int32_t add_constant_feature;
+    uint32_t n_fields;           /* ffm_fields.len() */
+    const uint32_t *field_off;   /* n_fields+1 offsets into field_ns */
+    const uint32_t *field_ns;
+    const uint8_t *field_ns_f32;
+    /* the ModelInstance fields FeatureBufferTranslator::new reads for its masks (feature_buffer.rs:138-148) */
+    uint32_t bit_precision;
+    uint32_t ffm_k;              /* 0: no ffm_buffer is produced */
+    uint32_t ffm_bit_precision;
+} fwgpu_translator_config;
+
+/* lr_hash_mask / ffm_hash_mask as FeatureBufferTranslator::new computes them (feature_buffer.rs:138-148) */
+uint32_t fwgpu_lr_hash_mask(uint32_t bit_precision);
+uint32_t fwgpu_ffm_hash_mask(uint32_t ffm_bit_precision, uint32_t ffm_k);
+
+/* Translate one record (parser.rs:57-74 layout) into caller-provided entry buffers (pure host code).
+ * <= FeatureBufferTranslator::translate(record, example_number)   feature_buffer.rs:174-338 */
+int fwgpu_translate(const fwgpu_translator_config *t, const uint32_t *record, uint32_t record_len, fwgpu_lr_entry *lr_out, uint32_t lr_cap, uint32_t *n_lr,
+                    fwgpu_ffm_entry *ffm_out, uint32_t ffm_cap, uint32_t *n_ffm, float *label, float *importance);
+/* Translate n back-to-back records (rec_off[i] = u32 offset of record i, n+1 entries) into a
+ * device-resident batch. */
+int fwgpu_batch_from_records(fwgpu_regressor *r, const fwgpu_translator_config *t, const uint32_t *records,
+                             const uint64_t *rec_off, uint32_t n, fwgpu_batch **out);
+
+/* ---------------------------------------------------------------- HogwildTrainer replacement
+ * fwgpu_trainer_create  <= HogwildTrainer::new(regressor, &model_instance, num_workers)  hogwild.rs:24-49
+ * fwgpu_digest_records  <= HogwildTrainer::digest_example(Vec<u32>)                      hogwild.rs:51-53
+ *                          (n records per call; records are copied)
+ * fwgpu_finish          <= HogwildTrainer::block_until_workers_finished                  hogwild.rs:55-60
+ *                          (flushes the partial micro-batch and waits; the trainer stays usable)
+ * Records are translated on the host, packed into micro-batches of `micro_batch` examples and run in
+ * HOGWILD mode on an internal stream, double-buffered.  Like the reference, no predictions are
+ * produced for hogwild-trained examples (main.rs:242-243). */
+int fwgpu_trainer_create(fwgpu_regressor *r, const fwgpu_translator_config *t, uint32_t micro_batch,
+                         fwgpu_trainer **out);
+int fwgpu_digest_records(fwgpu_trainer *tr, const uint32_t *records, const uint64_t *rec_off, uint32_t n);
+int fwgpu_finish(fwgpu_trainer *tr);
+int fwgpu_trainer_free(fwgpu_trainer *tr);
+int fwgpu_trainer_examples_seen(const fwgpu_trainer *tr, uint64_t *n);
+
+/* ---------------------------------------------------------------- launch tuning (optional)
+ * threads: workgroup size (multiple of 64, <=1024); workgroups_per_cu: persistent grid = CUs*this.
+ * 0 keeps the default.  Does not change results in SEQUENTIAL mode. */
+int fwgpu_set_launch(fwgpu_regressor *r, uint32_t threads, uint32_t workgroups_per_cu);
+
+/* ---------------------------------------------------------------- diagnostics
+ * Cross-XCD visibility probe for the access pattern the HOGWILD mode relies on: one workgroup publishes a
+ * 1 KiB payload `iters` times (sc1 or plain stores), 15 workgroups spread over the XCDs re-read it (sc1 or
+ * plain loads) after a device-scope flag and count words older than the flag.  With use_sc1=1 the count must
+ * be 0; with use_sc1=0 it shows the hazard the kernels avoid. */
+int fwgpu_debug_coherence_probe(int device, int use_sc1, uint32_t iters, uint32_t *stale_words, uint32_t *timeouts);
+
+/* ---------------------------------------------------------------- synthetic record streams
+ * Generates records in the parser's output format (parser.rs:57-74) for the BASELINE.json configs:
+ * n_namespaces namespaces == fields; per namespace 1+Poisson(mean_extra) features (exactly 1 when
+ * mean_extra==0); ids ~ Zipf(zipf_s) over ids_per_ns; feature hash = murmur3(decimal id,
+ * seed=murmur3(namespace name)) & MASK31 as the parser does (parser.rs:82-87, 382-385); a feature has
+ * value 1.0 with probability 1-p_weighted else U(0.5,2); label from a fixed random teacher.
+ * Two-call protocol: call with records==NULL to get the sizes, then with buffers. */
+typedef struct fwgpu_synth_config {
+    uint32_t n_namespaces;
+    float mean_extra;
+    double zipf_s;
+    uint32_t ids_per_ns;
+    float p_weighted;
+    uint64_t seed;
+} fwgpu_synth_config;
+int fwgpu_synth_records(const fwgpu_synth_config *cfg, uint64_t first_example, uint32_t n, uint32_t *records,
+                        uint64_t records_cap, uint64_t *rec_off, uint64_t *n_words);
+uint32_t fwgpu_murmur3_32(const uint8_t *data, size_t len, uint32_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,389 @@
+"""GPU parity tests (run with -m gpu on the MI355X box).  Everything goes through the C ABI (libfwgpu.so);
+the CPU oracle is only the checker.
+
+Parity bar (BASELINE.json north_star): hash indices bit-exact; per-example log-loss within 1e-4 of the
+reference CPU path on identical input.  Tolerances used here are written next to each assert.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import fwumious_wabbit_amd as fw
+from fwumious_wabbit_amd import _capi as capi
+from helpers import logloss, make_pair, mi_from_cfg, record_labels
+from oracle import fwo
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+with open(os.path.join(ROOT, "tests", "golden", "reference_kats.json")) as f:
+    KATS = json.load(f)
+
+PRED_TOL = 1e-5      # |p_gpu - p_ref| on a single prediction (f32 summation-order noise is ~1e-7)
+LOGLOSS_TOL = 1e-4   # north_star: per-example log-loss tolerance
+
+
+# ------------------------------------------------------------------ the reference's own KATs, on the GPU
+@pytest.mark.parametrize("sc", KATS["scenarios"], ids=[s["name"] for s in KATS["scenarios"]])
+def test_reference_kat_scenarios_on_gpu(sc):
+    mi = mi_from_cfg(sc["config"], sc["wiring"])
+    re = fw.Regressor(mi)
+    if "ffm_fill" in sc:
+        re.ffm_fill(sc["ffm_fill"])
+    for i, st in enumerate(sc["steps"]):
+        fb = fw.lr_and_ffm_vec(st["lr"], st["ffm"], st["label"], st["importance"])
+        if st["op"] == "predict" or not st["update"]:
+            got = re.predict(fb) if st["op"] == "predict" else re.learn(fb, None, False)
+        else:
+            got = re.learn(fb, None, True)
+        want = st.get("current_code", st["expect"]) if st.get("stale") else st["expect"]
+        assert abs(got - want) < PRED_TOL, f"{sc['name']} step {i} ({st['op']}): got {got!r} want {want!r}"
+    re.close()
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+
+    g.smoke()
+
+
+# ------------------------------------------------------------------ streams: sequential mode == reference single thread
+def _stream_parity(n_ns, k, bits, ffm_bits, optimizer, n, mean_extra, p_weighted, ids, seed, interactions=(),
+                   weight_tol=2e-5, **kw):
+    mi, ocfg, ots = make_pair(n_ns, k, bits, ffm_bits, optimizer, interactions=interactions, **kw)
+    recs, off = fw.synth_records(n_ns, mean_extra, 1.1, ids, p_weighted, seed, 0, n)
+    y = record_labels(recs, off)
+    om = fwo.Model(ocfg)
+    _, p_ref = om.run_stream(ots, recs, off, holdout_after=0, nthreads=1)
+    re = fw.Regressor(mi)
+    fbt = fw.FeatureBufferTranslator(mi)
+    b = re.batch_from_records(fbt, recs, off)
+    re.learn_batch(b, capi.MODE_SEQUENTIAL, True)
+    p_gpu = b.predictions()
+    d_ll = np.abs(logloss(p_gpu, y) - logloss(p_ref, y))
+    assert d_ll.max() < LOGLOSS_TOL, f"max per-example |d logloss| = {d_ll.max()} at {d_ll.argmax()}"
+    assert np.abs(p_gpu - p_ref).max() < 5e-5
+    # final tables: same state as the reference after the whole stream
+    lr_gpu = re.table_read(capi.TABLE_LR)
+    assert np.abs(lr_gpu - om.lr_table).max() < weight_tol
+    if k:
+        assert np.abs(re.table_read(capi.TABLE_FFM_W) - om.ffm_weights).max() < weight_tol
+        acc_g, acc_o = re.table_read(capi.TABLE_FFM_ACC), om.ffm_acc
+        assert np.abs(acc_g - acc_o).max() < 1e-4 * max(1.0, float(np.abs(acc_o).max()))
+        # exactly the same set of accumulators was touched
+        a0 = np.float32(kw.get("ffm_init_acc", 0.0) if optimizer == fw.Optimizer.AdagradFlex else 0.0)
+        assert np.array_equal(acc_g != a0, acc_o != a0)
+    b.close()
+    re.close()
+    return p_gpu, p_ref
+
+
+def test_sequential_stream_config_b_like_with_collisions():
+    # 10 fields, k=4 (16-byte vector path), tiny tables: heavy hash collisions and overlapping FFM rows
+    _stream_parity(10, 4, 12, 12, fw.Optimizer.AdagradLUT, n=1500, mean_extra=0.0, p_weighted=0.0, ids=3000, seed=1)
+
+
+def test_sequential_stream_config_c_like():
+    # 30 fields, k=8, ~200 nnz per example, weighted features, LR interactions
+    _stream_parity(30, 8, 18, 18, fw.Optimizer.AdagradLUT, n=300, mean_extra=5.67, p_weighted=0.1, ids=100000, seed=2,
+                   interactions=[(0, 1), (3, 7)])
+
+
+def test_sequential_stream_config_a_like_scalar_path():
+    # examples/ffm: 2 fields, k=10 (scalar path: k % 4 != 0), interaction AB, tiny tables
+    _stream_parity(2, 10, 13, 13, fw.Optimizer.AdagradLUT, n=2000, mean_extra=0.0, p_weighted=0.0, ids=300, seed=3,
+                   interactions=[(0, 1)], power_t=0.0, ffm_power_t=0.0)
+
+
+def test_sequential_stream_sgd_and_flex():
+    _stream_parity(6, 4, 12, 12, fw.Optimizer.SGD, n=800, mean_extra=1.0, p_weighted=0.2, ids=500, seed=4, lr=0.05,
+                   ffm_lr=0.05)
+    _stream_parity(6, 8, 12, 12, fw.Optimizer.AdagradFlex, n=800, mean_extra=1.0, p_weighted=0.2, ids=500, seed=5,
+                   init_acc=1.0, ffm_init_acc=1.0, weight_tol=5e-5)
+
+
+def test_sequential_stream_k16_two_chunk_rows():
+    # R = 30*16 = 480 floats: two 64-lane chunks per row
+    _stream_parity(30, 16, 16, 18, fw.Optimizer.AdagradLUT, n=120, mean_extra=1.0, p_weighted=0.1, ids=20000, seed=6)
+
+
+def test_lr_only_model():
+    _stream_parity(8, 0, 14, 14, fw.Optimizer.AdagradLUT, n=1500, mean_extra=1.0, p_weighted=0.2, ids=2000, seed=7,
+                   interactions=[(0, 1)])
+
+
+def test_sequential_mode_is_deterministic():
+    mi, _, _ = make_pair(10, 4, 12, 12, fw.Optimizer.AdagradLUT)
+    recs, off = fw.synth_records(10, 1.0, 1.1, 3000, 0.1, 9, 0, 600)
+    outs = []
+    for _ in range(2):
+        re = fw.Regressor(mi)
+        b = re.batch_from_records(fw.FeatureBufferTranslator(mi), recs, off)
+        re.learn_batch(b, capi.MODE_SEQUENTIAL, True)
+        outs.append((b.predictions(), re.table_checksum(capi.TABLE_FFM_W), re.table_checksum(capi.TABLE_FFM_ACC),
+                     re.table_checksum(capi.TABLE_LR)))
+        re.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1:] == outs[1][1:]
+
+
+# ------------------------------------------------------------------ inference on identical weights
+def test_batch_inference_matches_reference_predict():
+    mi, ocfg, ots = make_pair(30, 8, 18, 18, fw.Optimizer.AdagradLUT)
+    recs, off = fw.synth_records(30, 5.67, 1.05, 100000, 0.1, 21, 0, 600)
+    y = record_labels(recs, off)
+    om = fwo.Model(ocfg)
+    om.run_stream(ots, recs[: int(off[300])], off[:301], nthreads=1)  # train the oracle on the first half
+    re = fw.Regressor(mi)
+    re.table_write(capi.TABLE_LR, om.lr_table)                       # identical weights on the device
+    re.table_write(capi.TABLE_FFM_W, om.ffm_weights)
+    re.table_write(capi.TABLE_FFM_ACC, om.ffm_acc)
+    fbt = fw.FeatureBufferTranslator(mi)
+    b = re.batch_from_records(fbt, recs, off)
+    before = [re.table_checksum(t) for t in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)]
+    re.learn_batch(b, capi.MODE_HOGWILD, False)  # predict-only: all workgroups, cached loads
+    p_gpu = b.predictions()
+    after = [re.table_checksum(t) for t in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)]
+    assert before == after  # inference never writes
+    p_ref = np.zeros(600, dtype=np.float32)
+    for i in range(600):
+        lr, ffm, _, _ = ots.translate(recs[int(off[i]):int(off[i + 1])])
+        p_ref[i] = om.predict(lr, ffm)
+    assert np.abs(logloss(p_gpu, y) - logloss(p_ref, y)).max() < LOGLOSS_TOL
+    assert np.abs(p_gpu - p_ref).max() < PRED_TOL
+    # idempotence
+    re.learn_batch(b, capi.MODE_SEQUENTIAL, False)
+    assert np.abs(b.predictions() - p_gpu).max() < 1e-6
+    re.close()
+
+
+# ------------------------------------------------------------------ hogwild mode and the record-stream trainer
+def _holdout_loss_oracle(ocfg, ots, recs, off, n_train):
+    om = fwo.Model(ocfg)
+    _, p = om.run_stream(ots, recs, off, holdout_after=n_train + 1, nthreads=1)
+    y = record_labels(recs, off)
+    return float(logloss(p[n_train:], y[n_train:]).mean()), float(logloss(p[:n_train], y[:n_train]).mean())
+
+
+def test_hogwild_mode_reaches_reference_holdout_loss():
+    n_train, n_hold = 24000, 4000
+    mi, ocfg, ots = make_pair(10, 4, 18, 18, fw.Optimizer.AdagradLUT)
+    recs, off = fw.synth_records(10, 0.0, 1.1, 100000, 0.0, 20240611, 0, n_train + n_hold)
+    y = record_labels(recs, off)
+    ref_hold, _ = _holdout_loss_oracle(ocfg, ots, recs, off, n_train)
+    re = fw.Regressor(mi)
+    fbt = fw.FeatureBufferTranslator(mi)
+    mb = 2048
+    for s in range(0, n_train, mb):
+        e = min(n_train, s + mb)
+        b = re.batch_from_records(fbt, recs[int(off[s]):int(off[e])], off[s:e + 1] - off[s])
+        re.learn_batch(b, capi.MODE_HOGWILD, True)
+        b.close()
+    hb = re.batch_from_records(fbt, recs[int(off[n_train]):], off[n_train:] - off[n_train])
+    re.learn_batch(hb, capi.MODE_HOGWILD, False)
+    gpu_hold = float(logloss(hb.predictions(), y[n_train:]).mean())
+    # micro-batched (stale-gradient) training is a different algorithm from the sequential reference, like the
+    # reference's own hogwild mode; the bar is the final hold-out loss
+    assert abs(gpu_hold - ref_hold) < 0.01, (gpu_hold, ref_hold)
+    assert gpu_hold < 0.6931  # it learned something
+    re.close()
+
+
+def test_trainer_digest_records_matches_manual_batches():
+    n_train, n_hold = 12000, 2000
+    mi, ocfg, ots = make_pair(10, 4, 18, 18, fw.Optimizer.AdagradLUT)
+    recs, off = fw.synth_records(10, 0.0, 1.1, 100000, 0.0, 77, 0, n_train + n_hold)
+    y = record_labels(recs, off)
+    ref_hold, _ = _holdout_loss_oracle(ocfg, ots, recs, off, n_train)
+    re = fw.Regressor(mi)
+    tr = fw.HogwildTrainer(re, mi, micro_batch=1024)
+    # mix of the single-record and the bulk entry points
+    for i in range(10):
+        tr.digest_example(recs[int(off[i]):int(off[i + 1])])
+    tr.digest_records(recs[int(off[10]):int(off[n_train])], off[10:n_train + 1] - off[10])
+    tr.block_until_workers_finished()
+    assert tr.examples_seen() == n_train
+    hb = re.batch_from_records(fw.FeatureBufferTranslator(mi), recs[int(off[n_train]):], off[n_train:] - off[n_train])
+    re.learn_batch(hb, capi.MODE_HOGWILD, False)
+    gpu_hold = float(logloss(hb.predictions(), y[n_train:]).mean())
+    assert abs(gpu_hold - ref_hold) < 0.01, (gpu_hold, ref_hold)
+    tr.close()
+    re.close()
+
+
+def test_cross_xcd_visibility_of_sc1_accesses():
+    L = capi.lib()
+    stale, tmo = C.c_uint32(0), C.c_uint32(0)
+    capi.check(L.fwgpu_debug_coherence_probe(0, 1, 2000, C.byref(stale), C.byref(tmo)))
+    assert tmo.value == 0
+    assert stale.value == 0, f"sc1 store -> sc1 load saw {stale.value} stale words"
+    stale2, tmo2 = C.c_uint32(0), C.c_uint32(0)
+    capi.check(L.fwgpu_debug_coherence_probe(0, 0, 2000, C.byref(stale2), C.byref(tmo2)))
+    print(f"plain store/load variant: {stale2.value} stale words (informational), timeouts {tmo2.value}")
+
+
+# ------------------------------------------------------------------ weight init, tables, serialisation
+def _np_checksum(a):
+    i = np.arange(a.size, dtype=np.uint64)
+    x = (i << np.uint64(32)) ^ a.view(np.uint32).astype(np.uint64) ^ (i >> np.uint64(32))
+    with np.errstate(over="ignore"):
+        x ^= x >> np.uint64(30)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27)
+        x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+        return int(x.sum(dtype=np.uint64))
+
+
+@pytest.mark.parametrize("k,bits,opt,width", [(8, 16, fw.Optimizer.AdagradLUT, 0.0), (4, 14, fw.Optimizer.AdagradFlex, 0.0),
+                                              (10, 15, fw.Optimizer.SGD, 0.0), (8, 14, fw.Optimizer.AdagradLUT, 0.2)])
+def test_weight_init_is_bit_exact_vs_oracle(k, bits, opt, width):
+    mi, ocfg, _ = make_pair(5, k, 14, bits, opt, ffm_init_acc=0.5)
+    mi.ffm_init_width, mi.ffm_init_zero_band, mi.ffm_init_center = width, 0.25, 0.01
+    ocfg.ffm_init_width, ocfg.ffm_init_zero_band, ocfg.ffm_init_center = width, 0.25, 0.01
+    om = fwo.Model(ocfg)
+    re = fw.Regressor(mi)
+    assert re.table_len(capi.TABLE_FFM_W) == (1 << bits) + 5 * k  # block_ffm.rs:92-94
+    assert np.array_equal(re.table_read(capi.TABLE_FFM_W).view(np.uint32), om.ffm_weights.view(np.uint32))
+    assert np.array_equal(re.table_read(capi.TABLE_FFM_ACC), om.ffm_acc)
+    assert np.array_equal(re.table_read(capi.TABLE_LR), om.lr_table)
+    assert re.table_checksum(capi.TABLE_FFM_W) == _np_checksum(om.ffm_weights)
+    re.close()
+
+
+def test_serialised_weights_follow_the_reference_layout():
+    for opt in (fw.Optimizer.AdagradLUT, fw.Optimizer.SGD):
+        mi, ocfg, ots = make_pair(4, 4, 10, 10, opt)
+        recs, off = fw.synth_records(4, 1.0, 1.1, 200, 0.1, 5, 0, 200)
+        re = fw.Regressor(mi)
+        b = re.batch_from_records(fw.FeatureBufferTranslator(mi), recs, off)
+        re.learn_batch(b, capi.MODE_SEQUENTIAL, True)
+        blob = re.write_weights_to_buf()
+        lr, w, acc = re.table_read(capi.TABLE_LR), re.table_read(capi.TABLE_FFM_W), re.table_read(capi.TABLE_FFM_ACC)
+        n_lr, n_ffm = 1 << 10, (1 << 10) + 16
+        # regressor.rs:426-442: u64 total = sum of get_serialized_len, then LR block, FFM weights, FFM optimizer
+        assert int(np.frombuffer(blob[:8], dtype="<u8")[0]) == n_lr + n_ffm
+        body = np.frombuffer(blob[8:], dtype="<f4")
+        if opt == fw.Optimizer.SGD:  # 4-byte LR entries, no optimizer part (optimizer.rs:20)
+            assert len(body) == n_lr + n_ffm
+            assert np.array_equal(body[:n_lr], lr[0::2]) and np.array_equal(body[n_lr:], w)
+        else:
+            assert len(body) == 2 * n_lr + 2 * n_ffm
+            assert np.array_equal(body[: 2 * n_lr], lr)
+            assert np.array_equal(body[2 * n_lr: 2 * n_lr + n_ffm], w) and np.array_equal(body[2 * n_lr + n_ffm:], acc)
+        re2 = fw.Regressor(mi)
+        re2.overwrite_weights_from_buf(blob)
+        for t in (capi.TABLE_LR, capi.TABLE_FFM_W) + ((capi.TABLE_FFM_ACC,) if opt != fw.Optimizer.SGD else ()):
+            assert re2.table_checksum(t) == re.table_checksum(t)
+        with pytest.raises(capi.FwgpuError):
+            re2.overwrite_weights_from_buf(blob[:-4])
+        re.close()
+        re2.close()
+
+
+# ------------------------------------------------------------------ edge cases the reference tests
+def test_edge_cases_against_oracle():
+    k, F = 4, 5
+    mi, ocfg, _ = make_pair(F, k, 10, 10, fw.Optimizer.AdagradLUT)
+    om = fwo.Model(ocfg)
+    re = fw.Regressor(mi)
+    R = F * k
+    cases = [
+        ([], []),                                                   # no features at all
+        ([(3, 1.0, 0)], []),                                        # LR only
+        ([], [(8, 1.0, 2 * k)]),                                    # a single FFM feature: only self-pairs -> 0
+        ([(7, 1.0, 0), (7, 2.0, 0), (7, -1.5, 1)], []),             # duplicate LR hash (regressor.rs:629-655)
+        ([], [(16, 1.0, 0), (16, 2.0, 1 * k), (200, 1.0, 4 * k)]),  # same row in two fields
+        ([], [(16, 1.0, 0), (16 + 4, 2.0, 1 * k), (16 + 8, 0.5, 3 * k)]),  # overlapping rows (stride 4 < R)
+        ([(5, 1.0, 0)], [(40, 1.0, 1 * k), (44, 1.0, 1 * k), (40, 3.0, 1 * k), (400, 1.0, 3 * k)]),  # dup inside a field
+        ([(9, 1.0, 5)], [(1020, 1.0, 0), (1020, 1.0, 4 * k)]),      # row reaching into the spill-over tail
+    ]
+    for rep in range(3):
+        for ci, (lr, ffm) in enumerate(cases):
+            for label, imp in ((1.0, 1.0), (0.0, 0.5), (1.0, 0.0)):
+                fb = fw.lr_and_ffm_vec(lr, ffm, label, imp)
+                pg = re.learn(fb, None, True)
+                po = om.learn(fwo.lr_entries(lr), fwo.ffm_entries(ffm), label, imp, True)
+                assert abs(pg - po) < PRED_TOL, (rep, ci, label, imp, pg, po)
+    assert np.abs(re.table_read(capi.TABLE_FFM_W) - om.ffm_weights).max() < 1e-5
+    assert np.abs(re.table_read(capi.TABLE_FFM_ACC) - om.ffm_acc).max() < 1e-5
+    assert np.abs(re.table_read(capi.TABLE_LR) - om.lr_table).max() < 1e-5
+    # unordered FFM entries / out-of-range hashes are rejected, not mis-trained
+    with pytest.raises(capi.FwgpuError):
+        re.learn(fw.ffm_vec([(8, 1.0, 2 * k), (8, 1.0, 0)]), None, True)
+    with pytest.raises(capi.FwgpuError):
+        re.learn(fw.ffm_vec([(1 << 10 + 1, 1.0, 0)]), None, True)
+    with pytest.raises(capi.FwgpuError):
+        re.learn(fw.lr_vec([(1 << 10, 1.0, 0)]), None, True)
+    # empty batch
+    b = re.batch([])
+    re.learn_batch(b, capi.MODE_HOGWILD, True)
+    assert len(b.predictions()) == 0
+    re.close()
+
+
+def test_saturated_and_nan_logits_follow_the_sigmoid_rules():
+    # block_loss_functions.rs:125-141: |wsum| > 50 -> p = sigma(+-50), no update; NaN -> 0.5, no update
+    mi = fw.ModelInstance(optimizer=fw.Optimizer.SGD, learning_rate=0.1, bit_precision=10)
+    re = fw.Regressor(mi)
+    om = fwo.Model(fwo.make_config(optimizer=fwo.OPT_SGD, learning_rate=0.1, bit_precision=10))
+    for wv, want in ((100.0, 1.0), (-100.0, 1.9287e-22), (float("nan"), 0.5)):
+        t = np.zeros(2 << 10, dtype=np.float32)
+        t[2 * 5] = wv
+        re.table_write(capi.TABLE_LR, t)
+        om.lr_table[:] = t
+        fb = fw.lr_vec([(5, 1.0, 0)], label=0.0)
+        pg, po = re.learn(fb, None, True), om.learn(fwo.lr_entries([(5, 1.0, 0)]), None, 0.0, 1.0, True)
+        assert (np.isnan(pg) and np.isnan(po)) or abs(pg - po) < 1e-7
+        assert abs(pg - want) < 1e-6
+        got = re.table_read(capi.TABLE_LR, 10, 1)[0]
+        assert (np.isnan(got) and np.isnan(wv)) or got == np.float32(wv)  # general gradient 0: weight untouched
+    re.close()
+
+
+# ------------------------------------------------------------------ BASELINE.json full sizes: size-independent properties
+def test_full_size_config_c_properties():
+    # 30 fields, k=8, 28-bit hash: 2 x 1.07 GB FFM tables + 2.1 GB LR table.  The oracle cannot follow at this
+    # size in seconds, so check properties: init checksum == closed form on a slice, inference is read-only and
+    # idempotent, a training pass changes exactly the touched rows, sequential == oracle on the touched rows.
+    mi, ocfg, ots = make_pair(30, 8, 28, 28, fw.Optimizer.AdagradLUT)
+    re = fw.Regressor(mi)
+    L = fwo.lib()
+    n = (1 << 28) + 240
+    # spot-check the init against the published LCG on slices across the table, including the tail
+    for start in (0, 123456789, n - 4096):
+        got = re.table_read(capi.TABLE_FFM_W, start, 4096)
+        want = np.array([(1.0 * L.fwo_merand48(n + start + i) - 0.5) for i in range(4096)], dtype=np.float32)
+        want = (want * np.float32(1.0 / np.sqrt(np.float32(8.0)) / np.float32(50.0))).astype(np.float32)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    recs, off = fw.synth_records(30, 5.67, 1.05, 10_000_000, 0.1, 20240612, 0, 2048)
+    fbt = fw.FeatureBufferTranslator(mi)
+    b = re.batch_from_records(fbt, recs, off)
+    c0 = [re.table_checksum(t) for t in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)]
+    re.learn_batch(b, capi.MODE_HOGWILD, False)
+    p1 = b.predictions()
+    re.learn_batch(b, capi.MODE_HOGWILD, False)
+    p2 = b.predictions()
+    assert np.array_equal(p1, p2) and np.all((p1 > 0) & (p1 < 1))
+    assert c0 == [re.table_checksum(t) for t in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)]
+    # sequential training of the first 64 examples vs the oracle restricted to the touched rows
+    nseq = 64
+    bs = re.batch_from_records(fbt, recs[: int(off[nseq])], off[: nseq + 1])
+    re.learn_batch(bs, capi.MODE_SEQUENTIAL, True)
+    p_gpu = bs.predictions()
+    c1 = [re.table_checksum(t) for t in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)]
+    assert all(a != b_ for a, b_ in zip(c0, c1))
+    om = fwo.Model(ocfg)  # 4.3 GB on the host; init takes a few seconds
+    _, p_ref = om.run_stream(ots, recs[: int(off[nseq])], off[: nseq + 1], nthreads=1)
+    y = record_labels(recs, off)[:nseq]
+    assert np.abs(logloss(p_gpu, y) - logloss(p_ref, y)).max() < LOGLOSS_TOL
+    for i in range(0, nseq, 7):
+        lr, ffm, _, _ = ots.translate(recs[int(off[i]):int(off[i + 1])])
+        for e in ffm[::17]:
+            h = int(e["hash"])
+            assert np.abs(re.table_read(capi.TABLE_FFM_W, h, 240) - om.ffm_weights[h:h + 240]).max() < 2e-5
+            assert np.abs(re.table_read(capi.TABLE_FFM_ACC, h, 240) - om.ffm_acc[h:h + 240]).max() < 1e-4
+    om.close()
+    re.close()
