@@ -140,13 +140,14 @@ struct Lds {
     float *l_val;
     uint32_t *fstart, *fend;  // F
     float *red;               // 3*16
+    float *dcf;               // F: per-field self-pair correction
     uint32_t *ctr;            // 4
 };
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t max_ffm, uint32_t max_lr, bool lut,
-                                             size_t *off /*[12]*/) {
+                                             size_t *off /*[13]*/) {
     size_t o = 0;
     size_t R = (size_t)F * k;
     off[0] = o; o = align16(o + 4 * F * R);
@@ -161,11 +162,12 @@ __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t ma
     off[9] = o; o = align16(o + 4 * (size_t)F);
     off[10] = o; o = align16(o + 4 * 3 * 16);
     off[11] = o; o = align16(o + 4 * 4);
+    off[12] = o; o = align16(o + 4 * (size_t)F);
     return o;
 }
 
 size_t example_kernel_lds_bytes(const KernelParams &p, int optimizer) {
-    size_t off[12];
+    size_t off[13];
     return lds_layout(p.F, p.k, p.max_ffm, p.max_lr, optimizer == FWGPU_OPT_ADAGRAD_LUT && p.update, off);
 }
 
@@ -213,9 +215,9 @@ __device__ __forceinline__ void update_rows(const KernelParams &p, const Lds &s,
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 float t = Vec<VEC>::get(tv, j);
-                if (self) t = t - Vec<VEC>::get(sw, j) * v;  // contra - w*v        block_ffm.rs:238
-                const float G = v * t;                       // gradient cache      block_ffm.rs:239, 249
-                const float grad = g * G;                    // block_ffm.rs:278
+                if (self) t = __fsub_rn(t, __fmul_rn(Vec<VEC>::get(sw, j), v));  // contra - w*v  block_ffm.rs:238
+                const float G = __fmul_rn(v, t);             // gradient cache      block_ffm.rs:239, 249
+                const float grad = __fmul_rn(g, G);           // block_ffm.rs:278
                 float acc = Vec<VEC>::get(av[u], j);
                 const float upd = opt_step<OPT>(grad, acc, p.ffm_rate, p.ffm_minus_power_t, s.lut);
                 Vec<VEC>::set(av[u], j, acc);
@@ -235,7 +237,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
     constexpr int UU = 2;  // feature rows in flight per wave in the update phase (x2 tables)
     extern __shared__ __align__(16) unsigned char smem[];
     const bool use_lut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update;
-    size_t off[12];
+    size_t off[13];
     lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut, off);
     Lds s;
     s.T = reinterpret_cast<float *>(smem + off[0]);
@@ -250,6 +252,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
     s.fend = reinterpret_cast<uint32_t *>(smem + off[9]);
     s.red = reinterpret_cast<float *>(smem + off[10]);
     s.ctr = reinterpret_cast<uint32_t *>(smem + off[11]);
+    s.dcf = reinterpret_cast<float *>(smem + off[12]);
 
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = bd >> 6;
@@ -260,7 +263,11 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         for (int i = tid; i < kLutSize; i += bd) s.lut[i] = p.lut_ffm[i];
 
     for (uint32_t ex = blockIdx.x; ex < p.n_examples; ex += gridDim.x) {
-        // previous example's LDS reads are done and (s_waitcnt vmcnt(0) of the barrier) its stores are complete
+        // Previous example's LDS reads are done.  A workgroup-scope barrier does not drain vmcnt on this target,
+        // so in the in-order (single workgroup) mode every wave first waits for its own table stores to be
+        // acknowledged: the next example must read what this one wrote.  Concurrent (hogwild) grids skip the
+        // wait and let the stores drain under the next example's gather.
+        if (gridDim.x == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const uint32_t fo = p.ffm_off[ex], nf = p.ffm_off[ex + 1] - fo;
         const uint32_t lo = p.lr_off[ex], nl = p.lr_off[ex + 1] - lo;
@@ -321,14 +328,19 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         }
 
         // ---------------- gather: field sums, transposed into LDS
-        float dc = 0.0f;  // sum_i v_i^2 |w_i[f_i]|^2 partial (block_ffm.rs:418-426)
         if (k) {
             for (;;) {
-                uint32_t f = 0;
-                if (lane == 0) f = atomicAdd(&s.ctr[0], 1u);
-                f = __builtin_amdgcn_readfirstlane(f);
+                // Dynamic field -> wave assignment.  Every lane takes part in the atomic (lane 0 adds 1, the others
+                // add 0, so lane 0 always gets the old counter) and NO lane-conditional BRANCH may sit in this
+                // loop: a lane-0-only statement here gets jump-threaded into the next iteration's increment and
+                // readfirstlane then runs under a divergent mask (lanes 1..63 spin on field 0 forever).
+                const uint32_t ticket = atomicAdd(&s.ctr[0], lane == 0 ? 1u : 0u);
+                const uint32_t f = __builtin_amdgcn_readfirstlane(ticket);
                 if (f >= F) break;
                 const uint32_t fs = s.fstart[f], fe = s.fend[f];
+                // sum_{i in field f} v_i^2 |w_i[f*k..]|^2 (block_ffm.rs:418-426).  Reduced per field so that the
+                // result does not depend on which wave happened to take the field.
+                float dc = 0.0f;
                 for (uint32_t c = 0; c < nchunk; ++c) {
                     const uint32_t e0 = (c * 64 + lane) * VEC;
                     const bool inb = e0 < R;
@@ -355,7 +367,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
 #pragma unroll
                                 for (int j = 0; j < VEC; ++j) {
                                     const float w = Vec<VEC>::get(r[u], j);
-                                    Vec<VEC>::set(acc, j, Vec<VEC>::get(acc, j) + w * v[u]);
+                                    Vec<VEC>::set(acc, j, __fadd_rn(Vec<VEC>::get(acc, j), __fmul_rn(w, v[u])));  // block_ffm.rs:205
                                     ss += w * w;
                                 }
                                 if (self) {
@@ -367,6 +379,8 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                     }
                     if (inb) Vec<VEC>::lds_store(s.T + z * R + f * k + (e0 - z * k), acc);
                 }
+                dc = wave_sum(dc);
+                s.dcf[f] = dc;  // same value from all 64 lanes
             }
         }
         __syncthreads();
@@ -389,20 +403,18 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         if (p.has_lr)
             for (uint32_t i = tid; i < nl; i += bd) lrs += lr_load<COH>(p.lr, s.l_hash[i]).x * s.l_val[i];
         dot = wave_sum(dot);
-        dc = wave_sum(dc);
         lrs = wave_sum(lrs);
         if (lane == 0) {
             s.red[wave] = dot;
-            s.red[16 + wave] = dc;
             s.red[32 + wave] = lrs;
         }
         __syncthreads();
         float dot_t = 0.0f, dc_t = 0.0f, lr_t = 0.0f;
         for (int w = 0; w < nw; ++w) {
             dot_t += s.red[w];
-            dc_t += s.red[16 + w];
             lr_t += s.red[32 + w];
         }
+        for (uint32_t f = 0; f < F; ++f) dc_t += s.dcf[f];
         // sigmoid input: LR slots first, then the FFM pair sum (graph.rs:251-285 tape order)
         float wsum = 0.0f;
         if (p.has_lr) wsum += lr_t;
@@ -461,6 +473,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                 }
                 // phase B: overlapping rows, strictly in buffer order on one wave
                 if (s.ctr[1]) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // phase A stores acknowledged
                     __syncthreads();
                     if (wave == 0) {
                         for (uint32_t i = 0; i < nf; ++i) {

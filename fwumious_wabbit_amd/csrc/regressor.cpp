@@ -408,8 +408,10 @@ int fwgpu_learn_batch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, 
 }
 
 int fwgpu_batch_predictions(fwgpu_batch *b, float *host_out, uint32_t n, void *stream) {
-    if (!b || !host_out) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    if (!b) return fail(FWGPU_ERR_INVALID, "NULL argument");
     if (n > b->n) return fail(FWGPU_ERR_RANGE, "n > batch size");
+    if (n == 0) return FWGPU_OK;
+    if (!host_out) return fail(FWGPU_ERR_INVALID, "NULL argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     FWGPU_HIP(hipMemcpyAsync(host_out, b->pred, n * sizeof(float), hipMemcpyDeviceToHost, s));
     FWGPU_HIP(hipStreamSynchronize(s));
