@@ -28,11 +28,19 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+# Hyper-parameters: the reference's production-like command line (run_one.sh: `-l 0.025 --adaptive --power_t 0.38`,
+# k=8, FFM inheriting lr / power_t / init_acc_gradient=1.0 from the LR block: model_instance.rs:418-428).
+# `-l 0.1` (the benchmark/ LR setting, ~13 nnz/example) DIVERGES on this ~200-nnz stream even in the sequential
+# reference algorithm (scripts/oracle_convergence.py: hold-out log-loss 2.12 vs 0.659 at 0.025), and a diverged run
+# saturates the sigmoid, which skips updates and inflates examples/sec.
+LR, POWER_T, INIT_ACC = 0.025, 0.38, 1.0
+
+
 def build_model_instance(fw, args, device):
     F = args.fields
     return fw.ModelInstance(
-        learning_rate=0.1, ffm_learning_rate=0.1, power_t=0.5, ffm_power_t=0.5, init_acc_gradient=1.0,
-        ffm_init_acc_gradient=0.0, bit_precision=args.bits, ffm_bit_precision=args.ffm_bits, ffm_k=args.k,
+        learning_rate=LR, ffm_learning_rate=LR, power_t=POWER_T, ffm_power_t=POWER_T, init_acc_gradient=INIT_ACC,
+        ffm_init_acc_gradient=INIT_ACC, bit_precision=args.bits, ffm_bit_precision=args.ffm_bits, ffm_k=args.k,
         add_constant_feature=True, optimizer=fw.Optimizer.AdagradLUT,
         feature_combo_descs=[fw.FeatureComboDesc([fw.NamespaceDescriptor(i)]) for i in range(F)],
         ffm_fields=[[fw.NamespaceDescriptor(i)] for i in range(F)], device=device)
@@ -76,9 +84,10 @@ def cpu_baseline(args, n_examples):
 
     cores = os.cpu_count() or 1
     F = args.fields
-    ocfg = fwo.make_config(optimizer=fwo.OPT_ADAGRAD_LUT, learning_rate=0.1, ffm_learning_rate=0.1, power_t=0.5,
-                           ffm_power_t=0.5, init_acc_gradient=1.0, bit_precision=args.bits, num_combos=F + 1,
-                           ffm_k=args.k, ffm_bit_precision=args.ffm_bits, ffm_num_fields=F)
+    ocfg = fwo.make_config(optimizer=fwo.OPT_ADAGRAD_LUT, learning_rate=LR, ffm_learning_rate=LR, power_t=POWER_T,
+                           ffm_power_t=POWER_T, init_acc_gradient=INIT_ACC, ffm_init_acc_gradient=INIT_ACC,
+                           bit_precision=args.bits, num_combos=F + 1, ffm_k=args.k, ffm_bit_precision=args.ffm_bits,
+                           ffm_num_fields=F)
     ots = fwo.TranslatorSpec([([(i, False)], 1.0) for i in range(F)], [[(i, False)] for i in range(F)], True, args.bits,
                              args.k, args.ffm_bits)
     try:
@@ -86,14 +95,21 @@ def cpu_baseline(args, n_examples):
     except Exception:
         om = fwo.Model(ocfg, native=False)
     recs, off = gen_records(fw, args, 10_000_000, n_examples)
-    # single thread = the reference's default execution mode (main.rs:213-270); sample sized for ~10 s
-    n1 = max(1000, n_examples // (2 * cores))
+    # single thread = the reference's default execution mode (main.rs:213-270)
+    n1 = min(n_examples, 4000)
     dt1, _ = om.run_stream(ots, recs[: int(off[n1])], off[: n1 + 1], nthreads=1, want_preds=False)
-    dt, _ = om.run_stream(ots, recs, off, nthreads=cores, want_preds=False)
+    # hogwild: the reference's default is 16 threads (main.rs:189-194); also try more of the box and keep the best
+    tried = {}
+    for t in sorted({min(16, cores), min(64, cores), cores}):
+        dt, _ = om.run_stream(ots, recs, off, nthreads=t, want_preds=False)
+        tried[t] = n_examples / dt
+    best = max(tried, key=tried.get)
     om.close()
-    return {"value": n_examples / dt, "unit": "examples/sec", "cores": cores, "kind": "port",
-            "sample": f"{n_examples} examples of the same synthetic stream, hogwild with {cores} threads "
-                      f"(hogwild.rs semantics) on the C oracle; single thread: {n1 / dt1:.0f} examples/sec on {n1} examples",
+    return {"value": tried[best], "unit": "examples/sec", "cores": best, "kind": "port",
+            "sample": f"{n_examples} examples of the same synthetic stream per run, C oracle in hogwild mode "
+                      f"(hogwild.rs semantics); threads -> examples/sec: "
+                      + ", ".join(f"{t}: {v:.0f}" for t, v in sorted(tried.items()))
+                      + f"; single thread (reference default mode): {n1 / dt1:.0f} on {n1} examples; host has {cores} cores",
             "single_thread_value": n1 / dt1}
 
 
@@ -215,6 +231,10 @@ def main():
     # ---- final hold-out log-loss (main.rs:238-241 --holdout_after semantics: predicted, never learned)
     re.learn_batch(hbatch, capi.MODE_HOGWILD, False, sptr)
     final_ll = logloss(hbatch.predictions(sptr), hy)
+    # guard: a saturated sigmoid (|logit| > 50, block_loss_functions.rs:125-133) skips the update; report how many of
+    # the last timed step's examples were in that state (healthy training: 0)
+    p_last = batches[W + K - 1].predictions(sptr)
+    saturated = float(np.mean((p_last < 1e-20) | (p_last > 1.0 - 1e-7)))
 
     if rank == 0:
         achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
@@ -232,7 +252,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "final_logloss": final_ll,
+            "saturated_fraction_last_step": saturated,
             "config": {
+                "hyperparameters": f"AdagradLUT lr={LR} power_t={POWER_T} init_acc_gradient={INIT_ACC} (run_one.sh)",
                 "workload": f"BASELINE.json configs[2]: synthetic {args.fields}-field k={args.k} FFM + LR, "
                             f"{args.ffm_bits}-bit FFM hash, {args.bits}-bit LR hash, ~{int(args.fields * (1 + args.mean_extra))} nnz/example, "
                             f"AdagradLUT, fused learn (forward + sigmoid/log-loss + AdaGrad scatter-update)",

@@ -53,6 +53,7 @@ struct KernelParams {
     int32_t aligned4;          // every FFM row of the batch starts on a 16-byte boundary
     float lr_rate, lr_minus_power_t;    // SGD / AdagradFlex parameters of the LR block
     float ffm_rate, ffm_minus_power_t;  // ... of the FFM block
+    unsigned long long *ticks;          // optional [8] per-phase shader-clock accumulators (debug), else NULL
 };
 
 struct LaunchConfig {
@@ -105,6 +106,7 @@ struct fwgpu_regressor {
     float *d_lut_lr = nullptr, *d_lut_ffm = nullptr;
     uint32_t lr_hash_mask = 0, ffm_hash_mask = 0;
     fwgpu::LaunchConfig launch;
+    unsigned long long *d_ticks = nullptr;  // debug phase timing, see fwgpu_debug_phase_ticks
     // scratch for single-example calls
     fwgpu_batch *one = nullptr;
     void *pinned = nullptr;

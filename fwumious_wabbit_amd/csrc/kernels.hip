@@ -141,13 +141,47 @@ struct Lds {
     uint32_t *fstart, *fend;  // F
     float *red;               // 3*16
     float *dcf;               // F: per-field self-pair correction
+    uint32_t *set_ffm;        // open-addressing set of FFM row block keys (overlap pre-filter)
+    uint32_t *set_lr;         // open-addressing set of LR hashes (duplicate pre-filter)
     uint32_t *ctr;            // 4
 };
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
+// size of the open-addressing sets: power of two >= 2*n (load factor <= 0.5)
+__host__ __device__ inline uint32_t set_size(uint32_t n) {
+    uint32_t s = 16;
+    while (s < 2 * n) s <<= 1;
+    return s;
+}
+__host__ __device__ inline uint32_t log2u(uint32_t pow2) {
+    uint32_t l = 0;
+    while ((1u << l) < pow2) l++;
+    return l;
+}
+constexpr uint32_t kSetEmpty = 0xffffffffu;
+// returns true if `key` was already present
+__device__ __forceinline__ bool set_insert(uint32_t *tab, uint32_t mask, uint32_t shift, uint32_t key) {
+    uint32_t slot = (key * 2654435761u) >> shift;
+    for (;;) {
+        const uint32_t old = atomicCAS(&tab[slot], kSetEmpty, key);
+        if (old == kSetEmpty) return false;
+        if (old == key) return true;
+        slot = (slot + 1) & mask;
+    }
+}
+__device__ __forceinline__ bool set_contains(const uint32_t *tab, uint32_t mask, uint32_t shift, uint32_t key) {
+    uint32_t slot = (key * 2654435761u) >> shift;
+    for (;;) {
+        const uint32_t v = tab[slot];
+        if (v == kSetEmpty) return false;
+        if (v == key) return true;
+        slot = (slot + 1) & mask;
+    }
+}
+
 __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t max_ffm, uint32_t max_lr, bool lut,
-                                             size_t *off /*[13]*/) {
+                                             size_t *off /*[15]*/) {
     size_t o = 0;
     size_t R = (size_t)F * k;
     off[0] = o; o = align16(o + 4 * F * R);
@@ -163,11 +197,13 @@ __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t ma
     off[10] = o; o = align16(o + 4 * 3 * 16);
     off[11] = o; o = align16(o + 4 * 4);
     off[12] = o; o = align16(o + 4 * (size_t)F);
+    off[13] = o; o = align16(o + 4 * (size_t)set_size(max_ffm));
+    off[14] = o; o = align16(o + 4 * (size_t)set_size(max_lr));
     return o;
 }
 
 size_t example_kernel_lds_bytes(const KernelParams &p, int optimizer) {
-    size_t off[13];
+    size_t off[15];
     return lds_layout(p.F, p.k, p.max_ffm, p.max_lr, optimizer == FWGPU_OPT_ADAGRAD_LUT && p.update, off);
 }
 
@@ -233,11 +269,11 @@ template <int VEC, int OPT, bool COH>
 __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) {
     typedef typename Vec<VEC>::type V;
     constexpr int AUX = COH ? kAuxSc1 : kAuxPlain;
-    constexpr int UG = 4;  // feature rows in flight per wave in the gather phase
-    constexpr int UU = 2;  // feature rows in flight per wave in the update phase (x2 tables)
+    constexpr int UG = 8;  // feature rows in flight per wave in the gather phase
+    constexpr int UU = 4;  // feature rows in flight per wave in the update phase (x2 tables)
     extern __shared__ __align__(16) unsigned char smem[];
     const bool use_lut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update;
-    size_t off[13];
+    size_t off[15];
     lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut, off);
     Lds s;
     s.T = reinterpret_cast<float *>(smem + off[0]);
@@ -253,6 +289,12 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
     s.red = reinterpret_cast<float *>(smem + off[10]);
     s.ctr = reinterpret_cast<uint32_t *>(smem + off[11]);
     s.dcf = reinterpret_cast<float *>(smem + off[12]);
+    s.set_ffm = reinterpret_cast<uint32_t *>(smem + off[13]);
+    s.set_lr = reinterpret_cast<uint32_t *>(smem + off[14]);
+    const uint32_t setf_n = set_size(p.max_ffm), setl_n = set_size(p.max_lr);
+    const uint32_t setf_shift = 32 - log2u(setf_n), setl_shift = 32 - log2u(setl_n);
+    uint32_t blk_shift = 0;  // 2^blk_shift >= R: rows that overlap have block keys (hash >> blk_shift) differing by <= 1
+    while ((1u << blk_shift) < p.R) blk_shift++;
 
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = bd >> 6;
@@ -262,6 +304,17 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
     if (use_lut)
         for (int i = tid; i < kLutSize; i += bd) s.lut[i] = p.lut_ffm[i];
 
+    // debug phase timing (thread 0 of every workgroup; all stamps sit right after a barrier or at a phase end)
+    unsigned long long tk_last = 0, tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool timing = p.ticks != nullptr && tid == 0;
+#define FW_TICK(slot)                                           \
+    if (timing) {                                               \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        tk[slot] += now_ - tk_last;                             \
+        tk_last = now_;                                         \
+    }
+    if (timing) tk_last = __builtin_amdgcn_s_memtime();
+
     for (uint32_t ex = blockIdx.x; ex < p.n_examples; ex += gridDim.x) {
         // Previous example's LDS reads are done.  A workgroup-scope barrier does not drain vmcnt on this target,
         // so in the in-order (single workgroup) mode every wave first waits for its own table stores to be
@@ -269,6 +322,8 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         // wait and let the stores drain under the next example's gather.
         if (gridDim.x == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        FW_TICK(6);
+        if (timing) tk[7] += 1;
         const uint32_t fo = p.ffm_off[ex], nf = p.ffm_off[ex + 1] - fo;
         const uint32_t lo = p.lr_off[ex], nl = p.lr_off[ex + 1] - lo;
         const float label = p.label[ex], imp = p.importance[ex];
@@ -281,7 +336,13 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         }
         if (tid == 0) {
             s.ctr[0] = 0;  // next field to gather
-            s.ctr[1] = 0;  // any overlapping FFM rows in this example
+            s.ctr[1] = 0;  // some FFM rows of this example overlap an earlier row (exact)
+            s.ctr[2] = 0;  // pre-filter: rows MAY overlap
+            s.ctr[3] = 0;  // duplicate LR hashes in this example
+        }
+        if (do_update) {
+            for (uint32_t i = tid; i < setf_n; i += bd) s.set_ffm[i] = kSetEmpty;
+            for (uint32_t i = tid; i < setl_n; i += bd) s.set_lr[i] = kSetEmpty;
         }
         for (uint32_t i = tid; i < nf; i += bd) {
             s.e_hash[i] = p.ffm_hash[fo + i];
@@ -293,30 +354,40 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
             s.l_val[i] = p.lr_val[lo + i];
         }
         __syncthreads();
-        uint32_t my_dep[4] = {0, 0, 0, 0};  // supports nf <= 4*bd (checked on the host)
-        {
+        FW_TICK(0);
+        // field boundaries; and O(1) pre-filters for the two cases that need in-order treatment inside one example:
+        // FFM rows that may overlap (block keys equal or adjacent) and duplicate LR hashes.  ctr[2]/ctr[3] flag them.
+        for (uint32_t i = tid; i < nf; i += bd) {
+            const uint32_t f = s.e_fld[i];
+            if (i == 0 || s.e_fld[i - 1] != f) s.fstart[f] = i;
+            if (i == nf - 1 || s.e_fld[i + 1] != f) s.fend[f] = i + 1;
+            if (do_update && set_insert(s.set_ffm, setf_n - 1, setf_shift, s.e_hash[i] >> blk_shift)) s.ctr[2] = 1;
+        }
+        if (do_update && p.has_lr)
+            for (uint32_t i = tid; i < nl; i += bd)
+                if (set_insert(s.set_lr, setl_n - 1, setl_shift, s.l_hash[i])) s.ctr[3] = 1;
+        __syncthreads();
+        if (do_update)
+            for (uint32_t i = tid; i < nf; i += bd)
+                if (set_contains(s.set_ffm, setf_n - 1, setf_shift, (s.e_hash[i] >> blk_shift) + 1)) s.ctr[2] = 1;
+        __syncthreads();
+        if (do_update && s.ctr[2]) {
+            // Rare: some rows may overlap.  Exact scan: does an EARLIER feature's row [h_j, h_j+R) overlap mine?
+            // (rows are R long but start on a next_pow2(k) grid: block_ffm.rs:92-94, feature_buffer.rs:141-148)
+            uint32_t my_dep[4] = {0, 0, 0, 0};  // supports nf <= 4*bd (checked on the host)
             int slot = 0;
             for (uint32_t i = tid; i < nf; i += bd, ++slot) {
-                const uint32_t f = s.e_fld[i];
-                if (i == 0 || s.e_fld[i - 1] != f) s.fstart[f] = i;
-                if (i == nf - 1 || s.e_fld[i + 1] != f) s.fend[f] = i + 1;
-                if (do_update) {
-                    // does an EARLIER feature's row [h_j, h_j+R) overlap mine?  (rows are R long but
-                    // start on a next_pow2(k) grid: block_ffm.rs:92-94, feature_buffer.rs:141-148)
-                    const uint32_t h = s.e_hash[i];
-                    uint32_t d = 0;
-                    for (uint32_t j = 0; j < i; ++j) {
-                        const uint32_t hj = s.e_hash[j];
-                        const uint32_t diff = h > hj ? h - hj : hj - h;
-                        d |= (diff < R) ? 1u : 0u;
-                    }
-                    my_dep[slot & 3] = d;
+                const uint32_t h = s.e_hash[i];
+                uint32_t d = 0;
+                for (uint32_t j = 0; j < i; ++j) {
+                    const uint32_t hj = s.e_hash[j];
+                    const uint32_t diff = h > hj ? h - hj : hj - h;
+                    d |= (diff < R) ? 1u : 0u;
                 }
+                my_dep[slot & 3] = d;
             }
-        }
-        __syncthreads();
-        if (do_update) {
-            int slot = 0;
+            __syncthreads();
+            slot = 0;
             uint32_t any = 0;
             for (uint32_t i = tid; i < nf; i += bd, ++slot) {
                 if (my_dep[slot & 3]) {
@@ -327,6 +398,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
             if (any) s.ctr[1] = 1;
         }
 
+        FW_TICK(1);
         // ---------------- gather: field sums, transposed into LDS
         if (k) {
             for (;;) {
@@ -384,6 +456,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
             }
         }
         __syncthreads();
+        FW_TICK(2);
 
         // ---------------- all-pairs dot from LDS + LR forward
         float dot = 0.0f;
@@ -436,13 +509,23 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
             g = -(label - pr) * imp;
         }
         if (tid == 0) p.pred[ex] = pr;
+        FW_TICK(3);
 
         // ---------------- update.  g == 0 leaves every weight and accumulator unchanged in all three
         // optimizers (acc += 0, w -= 0), so the whole phase is skipped.
         if (do_update && g != 0.0f) {
             // LR (block_lr.rs:135-150): the thread owning the FIRST occurrence of a hash applies all
             // occurrences in buffer order, so duplicates chain exactly like the reference's loop.
-            if (p.has_lr) {
+            if (p.has_lr && !s.ctr[3]) {
+                for (uint32_t t = tid; t < nl; t += bd) {
+                    const uint32_t h = s.l_hash[t];
+                    float2 wa = lr_load<COH>(p.lr, h);
+                    const float grad = g * s.l_val[t];
+                    const float upd = opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, p.lut_lr);
+                    wa.x -= upd;
+                    lr_store<COH>(p.lr, h, wa);
+                }
+            } else if (p.has_lr) {
                 for (uint32_t t = tid; t < nl; t += bd) {
                     const uint32_t h = s.l_hash[t];
                     bool first = true;
@@ -460,6 +543,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                     }
                 }
             }
+            FW_TICK(4);
             if (k) {
                 // phase A: rows with no earlier overlapping row, all waves, UU rows each
                 for (uint32_t i0 = wave * UU; i0 < nf; i0 += nw * UU) {
@@ -487,8 +571,12 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                     }
                 }
             }
+            FW_TICK(5);
         }
     }
+    if (timing)
+        for (int i = 0; i < 8; ++i) atomicAdd(p.ticks + i, tk[i]);
+#undef FW_TICK
 }
 
 // ------------------------------------------------------------------ launch

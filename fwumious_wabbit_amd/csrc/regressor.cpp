@@ -176,6 +176,7 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
     p.lr_minus_power_t = -r->cfg.power_t;
     p.ffm_rate = r->cfg.ffm_learning_rate;
     p.ffm_minus_power_t = -r->cfg.ffm_power_t;
+    p.ticks = r->d_ticks;
     return p;
 }
 
@@ -504,6 +505,26 @@ int fwgpu_table_checksum(fwgpu_regressor *r, int which, uint64_t *checksum) {
     (void)hipFree(d);
     if (e != hipSuccess) return fail(FWGPU_ERR_DEVICE, std::string("checksum: ") + hipGetErrorString(e));
     *checksum = h;
+    return FWGPU_OK;
+}
+
+int fwgpu_debug_phase_ticks(fwgpu_regressor *r, int enable, uint64_t *out8) {
+    if (!r) return fail(FWGPU_ERR_INVALID, "NULL regressor");
+    FWGPU_HIP(hipSetDevice(r->device));
+    FWGPU_HIP(hipDeviceSynchronize());
+    if (out8) {
+        if (r->d_ticks)
+            FWGPU_HIP(hipMemcpy(out8, r->d_ticks, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        else
+            memset(out8, 0, 8 * sizeof(uint64_t));
+    }
+    if (enable) {
+        if (!r->d_ticks) FWGPU_HIP(hipMalloc((void **)&r->d_ticks, 8 * sizeof(uint64_t)));
+        FWGPU_HIP(hipMemset(r->d_ticks, 0, 8 * sizeof(uint64_t)));
+    } else if (r->d_ticks) {
+        (void)hipFree(r->d_ticks);
+        r->d_ticks = nullptr;
+    }
     return FWGPU_OK;
 }
 

@@ -212,6 +212,11 @@ int fwgpu_set_launch(fwgpu_regressor *r, uint32_t threads, uint32_t workgroups_p
  * 1 KiB payload `iters` times (sc1 or plain stores), 15 workgroups spread over the XCDs re-read it (sc1 or
  * plain loads) after a device-scope flag and count words older than the flag.  With use_sc1=1 the count must
  * be 0; with use_sc1=0 it shows the hazard the kernels avoid. */
+/* Per-phase shader-clock accounting of the example kernel (debug): enable=1 allocates/zeroes 8 device counters that
+ * every workgroup's thread 0 adds to: [0] stage entries, [1] field boundaries + overlap scan, [2] row gather,
+ * [3] dot + LR forward + sigmoid, [4] LR update, [5] FFM update, [6] wait for the slowest wave, [7] examples.
+ * out8 (may be NULL) receives the counters accumulated so far. */
+int fwgpu_debug_phase_ticks(fwgpu_regressor *r, int enable, uint64_t *out8);
 int fwgpu_debug_coherence_probe(int device, int use_sc1, uint32_t iters, uint32_t *stale_words, uint32_t *timeouts);
 
 /* ---------------------------------------------------------------- synthetic record streams
