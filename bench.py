@@ -236,6 +236,19 @@ def main():
     p_last = batches[W + K - 1].predictions(sptr)
     saturated = float(np.mean((p_last < 1e-20) | (p_last > 1.0 - 1e-7)))
 
+    # HBM traffic per launch: PMC counters cannot be read from inside this process; the figure is the rocprofv3
+    # measurement of this very command (separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 correction on the
+    # read side) committed under profiles/, reported only when the run uses the profiled configuration.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_v2_pmc.json")) as f:
+            pmc = json.load(f)
+        if (B == pmc["examples_per_launch"] and args.fields == 30 and args.k == 8 and args.ffm_bits == 28
+                and not args.threads and not args.wgs):
+            traffic = pmc["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+
     if rank == 0:
         achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
         out = {
@@ -267,12 +280,14 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "fw_example_kernel<4, AdagradLUT, coherent>",
+                "kernel": "fw_example_kernel_r<AdagradLUT, coherent, MAXR=12> (register-resident rows)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": "profiles/r01_v2_pmc.json (rocprofv3 PMC, separate passes)" if traffic else None,
+                "pattern_ceiling_note": "tools/rowbw.hip: random 960 B rows read 6.4 TB/s, written 3.2 TB/s; read w+acc, write w+acc = 4.2 TB/s",
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": avg_kernel_ms,
             },

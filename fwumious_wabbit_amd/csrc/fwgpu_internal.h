@@ -53,12 +53,14 @@ struct KernelParams {
     int32_t aligned4;          // every FFM row of the batch starts on a 16-byte boundary
     float lr_rate, lr_minus_power_t;    // SGD / AdagradFlex parameters of the LR block
     float ffm_rate, ffm_minus_power_t;  // ... of the FFM block
+    int32_t kernel_version;             // 0 = auto, 1 = force the v1 kernel, 2 = v2 where applicable
     unsigned long long *ticks;          // optional [8] per-phase shader-clock accumulators (debug), else NULL
 };
 
 struct LaunchConfig {
     uint32_t threads = 512;
     uint32_t workgroups_per_cu = 0;  // 0: as many as LDS allows (capped)
+    int32_t kernel_version = 0;      // 0 = auto
 };
 
 size_t example_kernel_lds_bytes(const KernelParams &p, int optimizer);

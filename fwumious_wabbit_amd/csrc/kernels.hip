@@ -607,6 +607,446 @@ static hipError_t launch_v(const KernelParams &p, int optimizer, bool coherent, 
     }
 }
 
+// ------------------------------------------------------------------ v2: register-resident rows
+//
+// Same math and same LDS stage / dot / sigmoid / LR code as fw_example_kernel, but the FFM row traffic is organised
+// for memory-level parallelism and to read every weight row from HBM exactly once:
+//   * every wave owns a CONTIGUOUS range of the example's features, cut at field boundaries and balanced by the rule
+//     owner(field) = floor(first_feature_index * n_waves / n_features)  (monotone, so ranges are contiguous);
+//   * the wave issues ALL its row loads up front (up to MAXR rows of 16 B/lane in flight per wave) into a statically
+//     indexed register array and consumes them in buffer order (field sums stay bit-identical to the reference);
+//   * the rows STAY in registers through dot/sigmoid, so the update phase loads only the accumulator rows
+//     (UA at a time) and writes w and acc: HBM traffic per row = read w, read acc, write w, write acc = the
+//     algorithmic 16 B/float;
+//   * rows beyond MAXR of a wave's range, and rows that overlap an earlier row of the same example (rare), take the
+//     v1 route (transient load in the gather, update_rows with a fresh read of w).
+// Only for 16 B-aligned single-chunk rows (k % 4 == 0, R <= 256 floats): BASELINE configs B and C.
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+template <int OPT, bool COH, int MAXR>
+__global__ void __launch_bounds__(1024) fw_example_kernel_r(const KernelParams p) {
+    typedef f4 V;
+    constexpr int VEC = 4;
+    constexpr int AUX = COH ? kAuxSc1 : kAuxPlain;
+    constexpr int UA = 4;  // accumulator rows in flight per wave in the update phase
+    extern __shared__ __align__(16) unsigned char smem[];
+    const bool use_lut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update;
+    size_t off[15];
+    lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut, off);
+    Lds s;
+    s.T = reinterpret_cast<float *>(smem + off[0]);
+    s.selfw = reinterpret_cast<float *>(smem + off[1]);
+    s.lut = reinterpret_cast<float *>(smem + off[2]);
+    s.e_hash = reinterpret_cast<uint32_t *>(smem + off[3]);
+    s.e_val = reinterpret_cast<float *>(smem + off[4]);
+    s.e_fld = reinterpret_cast<uint32_t *>(smem + off[5]);
+    s.l_hash = reinterpret_cast<uint32_t *>(smem + off[6]);
+    s.l_val = reinterpret_cast<float *>(smem + off[7]);
+    s.fstart = reinterpret_cast<uint32_t *>(smem + off[8]);
+    s.fend = reinterpret_cast<uint32_t *>(smem + off[9]);
+    s.red = reinterpret_cast<float *>(smem + off[10]);
+    s.ctr = reinterpret_cast<uint32_t *>(smem + off[11]);
+    s.dcf = reinterpret_cast<float *>(smem + off[12]);
+    s.set_ffm = reinterpret_cast<uint32_t *>(smem + off[13]);
+    s.set_lr = reinterpret_cast<uint32_t *>(smem + off[14]);
+    const uint32_t setf_n = set_size(p.max_ffm), setl_n = set_size(p.max_lr);
+    const uint32_t setf_shift = 32 - log2u(setf_n), setl_shift = 32 - log2u(setl_n);
+    uint32_t blk_shift = 0;
+    while ((1u << blk_shift) < p.R) blk_shift++;
+
+    const int tid = threadIdx.x, bd = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nw = bd >> 6;
+    const uint32_t F = p.F, k = p.k, R = p.R;
+    // this lane's 4 floats of a row: elements [e0, e0+4) = slot z, offset kk0
+    const uint32_t e0 = lane * VEC;
+    const bool inb = e0 < R;
+    const uint32_t z = inb ? e0 / k : 0xfffffffeu;
+    const uint32_t kk0 = inb ? e0 - z * k : 0;
+
+    if (use_lut)
+        for (int i = tid; i < kLutSize; i += bd) s.lut[i] = p.lut_ffm[i];
+
+    unsigned long long tk_last = 0;
+    const bool timing = p.ticks != nullptr && tid == 0;
+#define FW_TICK(slot)                                                 \
+    if (timing) {                                                     \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        atomicAdd(p.ticks + (slot), now_ - tk_last);                  \
+        tk_last = now_;                                               \
+    }
+    if (timing) tk_last = __builtin_amdgcn_s_memtime();
+
+    for (uint32_t ex = blockIdx.x; ex < p.n_examples; ex += gridDim.x) {
+        if (gridDim.x == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in-order mode: see fw_example_kernel
+        __syncthreads();
+        FW_TICK(6);
+        if (timing) atomicAdd(p.ticks + 7, 1ull);
+        const uint32_t fo = p.ffm_off[ex], nf = p.ffm_off[ex + 1] - fo;
+        const uint32_t lo_lr = p.lr_off[ex], nl = p.lr_off[ex + 1] - lo_lr;
+        const float label = p.label[ex], imp = p.importance[ex];
+        const bool do_update = p.update && (imp != 0.0f);
+
+        // ---------------- stage (identical to fw_example_kernel)
+        for (uint32_t i = tid; i < F; i += bd) {
+            s.fstart[i] = 0;
+            s.fend[i] = 0;
+        }
+        if (tid == 0) {
+            s.ctr[1] = 0;
+            s.ctr[2] = 0;
+            s.ctr[3] = 0;
+        }
+        if (do_update) {
+            for (uint32_t i = tid; i < setf_n; i += bd) s.set_ffm[i] = kSetEmpty;
+            for (uint32_t i = tid; i < setl_n; i += bd) s.set_lr[i] = kSetEmpty;
+        }
+        for (uint32_t i = tid; i < nf; i += bd) {
+            s.e_hash[i] = p.ffm_hash[fo + i];
+            s.e_val[i] = p.ffm_val[fo + i];
+            s.e_fld[i] = p.ffm_fld[fo + i];
+        }
+        for (uint32_t i = tid; i < nl; i += bd) {
+            s.l_hash[i] = p.lr_hash[lo_lr + i];
+            s.l_val[i] = p.lr_val[lo_lr + i];
+        }
+        __syncthreads();
+        FW_TICK(0);
+        for (uint32_t i = tid; i < nf; i += bd) {
+            const uint32_t f = s.e_fld[i];
+            if (i == 0 || s.e_fld[i - 1] != f) s.fstart[f] = i;
+            if (i == nf - 1 || s.e_fld[i + 1] != f) s.fend[f] = i + 1;
+            if (do_update && set_insert(s.set_ffm, setf_n - 1, setf_shift, s.e_hash[i] >> blk_shift)) s.ctr[2] = 1;
+        }
+        if (do_update && p.has_lr)
+            for (uint32_t i = tid; i < nl; i += bd)
+                if (set_insert(s.set_lr, setl_n - 1, setl_shift, s.l_hash[i])) s.ctr[3] = 1;
+        __syncthreads();
+        if (do_update)
+            for (uint32_t i = tid; i < nf; i += bd)
+                if (set_contains(s.set_ffm, setf_n - 1, setf_shift, (s.e_hash[i] >> blk_shift) + 1)) s.ctr[2] = 1;
+        // T columns of empty fields are zero (block_ffm.rs:168-180)
+        for (uint32_t idx = tid; idx < F * (R / VEC); idx += bd) {
+            const uint32_t f = idx / (R / VEC), q = idx - f * (R / VEC);
+            if (s.fstart[f] == s.fend[f]) {
+                const uint32_t ee = q * VEC, zz = ee / k;
+                Vec<VEC>::lds_store(s.T + zz * R + f * k + (ee - zz * k), Vec<VEC>::zero());
+            }
+        }
+        for (uint32_t f = tid; f < F; f += bd)
+            if (s.fstart[f] == s.fend[f]) s.dcf[f] = 0.0f;
+        __syncthreads();
+        if (do_update && s.ctr[2]) {
+            uint32_t my_dep[4] = {0, 0, 0, 0};
+            int slot = 0;
+            for (uint32_t i = tid; i < nf; i += bd, ++slot) {
+                const uint32_t h = s.e_hash[i];
+                uint32_t d = 0;
+                for (uint32_t j = 0; j < i; ++j) {
+                    const uint32_t hj = s.e_hash[j];
+                    const uint32_t diff = h > hj ? h - hj : hj - h;
+                    d |= (diff < R) ? 1u : 0u;
+                }
+                my_dep[slot & 3] = d;
+            }
+            __syncthreads();
+            slot = 0;
+            uint32_t any = 0;
+            for (uint32_t i = tid; i < nf; i += bd, ++slot) {
+                if (my_dep[slot & 3]) {
+                    s.e_fld[i] |= 0x80000000u;
+                    any = 1;
+                }
+            }
+            if (any) s.ctr[1] = 1;
+            __syncthreads();
+        }
+        FW_TICK(1);
+
+        // ---------------- this wave's feature range [lo, hi): the fields f with floor(fstart[f]*nw/nf) == wave
+        uint32_t lo = 0xffffffffu, hi = 0;
+        for (uint32_t f = lane; f < F; f += 64) {
+            const uint32_t a = s.fstart[f], b = s.fend[f];
+            if (b > a && (a * (uint32_t)nw) / nf == (uint32_t)wave) {
+                lo = a < lo ? a : lo;
+                hi = b > hi ? b : hi;
+            }
+        }
+        lo = wave_min_u32(lo);
+        hi = wave_max_u32(hi);
+        const uint32_t cnt = hi > lo ? hi - lo : 0;
+        if (cnt == 0) lo = 0;
+
+        // ---------------- gather: all row loads up front, rows stay resident
+        V rows[MAXR];
+#pragma unroll
+        for (int sl = 0; sl < MAXR; ++sl) {
+            rows[sl] = Vec<VEC>::zero();
+            if ((uint32_t)sl < cnt) {
+                const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[lo + sl]);
+                rows[sl] = Vec<VEC>::template load<AUX>(make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
+            }
+        }
+        {
+            V acc = Vec<VEC>::zero();
+            float dc = 0.0f;
+            uint32_t cur = 0xffffffffu;
+            // consume one row (buffer order): field switch -> flush the finished field's sum, transposed, into T
+#define FW_CONSUME(ROW, IDX)                                                                                  \
+    {                                                                                                         \
+        const uint32_t f_ = __builtin_amdgcn_readfirstlane(s.e_fld[(IDX)] & 0x7fffffffu);                      \
+        const float v_ = s.e_val[(IDX)];                                                                      \
+        if (f_ != cur) {                                                                                      \
+            if (cur != 0xffffffffu) {                                                                         \
+                if (inb) Vec<VEC>::lds_store(s.T + z * R + cur * k + kk0, acc);                                \
+                dc = wave_sum(dc);                                                                            \
+                s.dcf[cur] = dc;                                                                              \
+            }                                                                                                 \
+            acc = Vec<VEC>::zero();                                                                           \
+            dc = 0.0f;                                                                                        \
+            cur = f_;                                                                                         \
+        }                                                                                                     \
+        float ss_ = 0.0f;                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < VEC; ++j) {                                                     \
+            const float w_ = (ROW)[j];                                                                        \
+            acc[j] = __fadd_rn(acc[j], __fmul_rn(w_, v_)); /* block_ffm.rs:205 */                             \
+            ss_ += w_ * w_;                                                                                   \
+        }                                                                                                     \
+        if (z == f_) {                                                                                        \
+            dc += ss_ * v_ * v_;                                                                              \
+            Vec<VEC>::lds_store(s.selfw + (IDX)*k + kk0, (ROW));                                               \
+        }                                                                                                     \
+    }
+#pragma unroll
+            for (int sl = 0; sl < MAXR; ++sl)
+                if ((uint32_t)sl < cnt) FW_CONSUME(rows[sl], lo + sl)
+            // overflow rows of this range: transient (they are re-read in the update phase)
+            for (uint32_t i = lo + MAXR; i < hi; i += 4) {
+                V r[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    r[u] = Vec<VEC>::zero();
+                    if (i + u < hi) {
+                        const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[i + u]);
+                        r[u] = Vec<VEC>::template load<AUX>(make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i + u < hi) FW_CONSUME(r[u], i + u)
+            }
+            if (cur != 0xffffffffu) {
+                if (inb) Vec<VEC>::lds_store(s.T + z * R + cur * k + kk0, acc);
+                dc = wave_sum(dc);
+                s.dcf[cur] = dc;
+            }
+#undef FW_CONSUME
+        }
+        __syncthreads();
+        FW_TICK(2);
+
+        // ---------------- all-pairs dot from LDS + LR forward (identical to fw_example_kernel)
+        float dot = 0.0f;
+        {
+            const uint32_t nq = F * R / VEC;
+            for (uint32_t q = tid; q < nq; q += bd) {
+                const uint32_t ee = q * VEC;
+                const uint32_t a = ee / R, rem = ee - a * R;
+                const uint32_t b = rem / k, kk = rem - b * k;
+                const V x = Vec<VEC>::lds_load(s.T + ee);
+                const V y = Vec<VEC>::lds_load(s.T + b * R + a * k + kk);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) dot += x[j] * y[j];
+            }
+        }
+        float lrs = 0.0f;
+        if (p.has_lr)
+            for (uint32_t i = tid; i < nl; i += bd) lrs += lr_load<COH>(p.lr, s.l_hash[i]).x * s.l_val[i];
+        dot = wave_sum(dot);
+        lrs = wave_sum(lrs);
+        if (lane == 0) {
+            s.red[wave] = dot;
+            s.red[32 + wave] = lrs;
+        }
+        __syncthreads();
+        float dot_t = 0.0f, dc_t = 0.0f, lr_t = 0.0f;
+        for (int w = 0; w < nw; ++w) {
+            dot_t += s.red[w];
+            lr_t += s.red[32 + w];
+        }
+        for (uint32_t f = 0; f < F; ++f) dc_t += s.dcf[f];
+        float wsum = 0.0f;
+        if (p.has_lr) wsum += lr_t;
+        wsum += 0.5f * (dot_t - dc_t);
+
+        float pr, g;
+        if (isnan(wsum)) {
+            pr = logistic(0.0f);
+            g = 0.0f;
+        } else if (wsum < -50.0f) {
+            pr = logistic(-50.0f);
+            g = 0.0f;
+        } else if (wsum > 50.0f) {
+            pr = logistic(50.0f);
+            g = 0.0f;
+        } else {
+            pr = logistic(wsum);
+            g = -(label - pr) * imp;
+        }
+        if (tid == 0) p.pred[ex] = pr;
+        FW_TICK(3);
+
+        if (do_update && g != 0.0f) {
+            if (p.has_lr && !s.ctr[3]) {
+                for (uint32_t t = tid; t < nl; t += bd) {
+                    const uint32_t h = s.l_hash[t];
+                    float2 wa = lr_load<COH>(p.lr, h);
+                    const float grad = g * s.l_val[t];
+                    const float upd = opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, p.lut_lr);
+                    wa.x -= upd;
+                    lr_store<COH>(p.lr, h, wa);
+                }
+            } else if (p.has_lr) {
+                for (uint32_t t = tid; t < nl; t += bd) {
+                    const uint32_t h = s.l_hash[t];
+                    bool first = true;
+                    for (uint32_t j = 0; j < t; ++j) first = first && (s.l_hash[j] != h);
+                    if (first) {
+                        float2 wa = lr_load<COH>(p.lr, h);
+                        for (uint32_t j = t; j < nl; ++j) {
+                            if (s.l_hash[j] == h) {
+                                const float grad = g * s.l_val[j];
+                                const float upd = opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, p.lut_lr);
+                                wa.x -= upd;
+                            }
+                        }
+                        lr_store<COH>(p.lr, h, wa);
+                    }
+                }
+            }
+            FW_TICK(4);
+            // phase A, resident rows: w comes from registers (read once, in the gather); only acc is loaded
+#pragma unroll
+            for (int g0 = 0; g0 < MAXR; g0 += UA) {
+                if ((uint32_t)g0 < cnt) {
+                    V av[UA];
+#pragma unroll
+                    for (int u = 0; u < UA; ++u) {
+                        av[u] = Vec<VEC>::zero();
+                        if (OPT != FWGPU_OPT_SGD && (uint32_t)(g0 + u) < cnt) {
+                            const uint32_t i = lo + g0 + u;
+                            if (!(s.e_fld[i] & 0x80000000u)) {
+                                const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[i]);
+                                av[u] = Vec<VEC>::template load<AUX>(make_rsrc(p.ffm_acc + h, R * 4), e0 * 4);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < UA; ++u) {
+                        if (g0 + u < MAXR && (uint32_t)(g0 + u) < cnt) {
+                            const uint32_t i = lo + g0 + u;
+                            const uint32_t fb = s.e_fld[i];
+                            if (!(fb & 0x80000000u)) {
+                                const uint32_t f = __builtin_amdgcn_readfirstlane(fb);
+                                const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[i]);
+                                const float v = s.e_val[i];
+                                V wv = rows[(g0 + u) < MAXR ? (g0 + u) : 0];
+                                V tv = Vec<VEC>::zero();
+                                if (inb) tv = Vec<VEC>::lds_load(s.T + f * R + e0);
+                                const bool self = (z == f);
+#pragma unroll
+                                for (int j = 0; j < VEC; ++j) {
+                                    float t = tv[j];
+                                    if (self) t = __fsub_rn(t, __fmul_rn(wv[j], v));  // contra - w*v  block_ffm.rs:238
+                                    const float G = __fmul_rn(v, t);
+                                    const float grad = __fmul_rn(g, G);
+                                    float acc = av[u][j];
+                                    const float upd = opt_step<OPT>(grad, acc, p.ffm_rate, p.ffm_minus_power_t, s.lut);
+                                    av[u][j] = acc;
+                                    wv[j] = wv[j] - upd;  // block_ffm.rs:282
+                                }
+                                Vec<VEC>::template store<AUX>(wv, make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
+                                if (OPT != FWGPU_OPT_SGD)
+                                    Vec<VEC>::template store<AUX>(av[u], make_rsrc(p.ffm_acc + h, R * 4), e0 * 4);
+                            }
+                        }
+                    }
+                }
+            }
+            // phase A, overflow rows of this range: the v1 route (fresh read of w)
+            for (uint32_t i0 = lo + MAXR; i0 < hi; i0 += 2) {
+                uint32_t idx[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const uint32_t i = i0 + u;
+                    idx[u] = (i < hi && !(s.e_fld[i] & 0x80000000u)) ? i : 0xffffffffu;
+                }
+                update_rows<VEC, OPT, AUX, 2>(p, s, idx, g, lane);
+            }
+            // phase B: rows overlapping an earlier row of this example, strictly in buffer order on one wave
+            if (s.ctr[1]) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (wave == 0) {
+                    for (uint32_t i = 0; i < nf; ++i) {
+                        if (s.e_fld[i] & 0x80000000u) {
+                            uint32_t idx[1] = {i};
+                            update_rows<VEC, OPT, AUX, 1>(p, s, idx, g, lane);
+                            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                            __builtin_amdgcn_s_waitcnt(0);
+                        }
+                    }
+                }
+            }
+            FW_TICK(5);
+        }
+    }
+#undef FW_TICK
+}
+
+#ifndef FW_MAXR
+#define FW_MAXR 12
+#endif
+template <int OPT, bool COH>
+static hipError_t launch_r(const KernelParams &p, uint32_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
+    auto kern = fw_example_kernel_r<OPT, COH, FW_MAXR>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, p);
+    return hipGetLastError();
+}
+
+static hipError_t launch_resident(const KernelParams &p, int optimizer, bool coherent, uint32_t grid, uint32_t threads,
+                                  size_t lds, hipStream_t stream) {
+    if (!p.update) return launch_r<FWGPU_OPT_SGD, false>(p, grid, threads, lds, stream);
+    switch (optimizer) {
+    case FWGPU_OPT_SGD:
+        return coherent ? launch_r<FWGPU_OPT_SGD, true>(p, grid, threads, lds, stream)
+                        : launch_r<FWGPU_OPT_SGD, false>(p, grid, threads, lds, stream);
+    case FWGPU_OPT_ADAGRAD_FLEX:
+        return coherent ? launch_r<FWGPU_OPT_ADAGRAD_FLEX, true>(p, grid, threads, lds, stream)
+                        : launch_r<FWGPU_OPT_ADAGRAD_FLEX, false>(p, grid, threads, lds, stream);
+    default:
+        return coherent ? launch_r<FWGPU_OPT_ADAGRAD_LUT, true>(p, grid, threads, lds, stream)
+                        : launch_r<FWGPU_OPT_ADAGRAD_LUT, false>(p, grid, threads, lds, stream);
+    }
+}
+
 hipError_t launch_example_kernel(const KernelParams &p, int optimizer, bool coherent, uint32_t grid, uint32_t threads,
                                  hipStream_t stream) {
     if (p.n_examples == 0) return hipSuccess;
@@ -614,7 +1054,11 @@ hipError_t launch_example_kernel(const KernelParams &p, int optimizer, bool cohe
     // 16-byte row vectors need k % 4 == 0: then R % 4 == 0 and hash & mask is a multiple of next_pow2(k) >= 4
     // floats (feature_buffer.rs:141-148), so every row starts 16-byte aligned.
     // Entries that did not come through the translator's mask (raw fwgpu_learn calls) may be unaligned.
-    if (p.k % 4 == 0 && p.aligned4) return launch_v<4>(p, optimizer, coherent, grid, threads, lds, stream);
+    if (p.k % 4 == 0 && p.aligned4) {
+        // single-chunk rows: the register-resident kernel (v2); p.kernel_version == 1 forces v1 (tests, A/B runs)
+        if (p.R <= 64 * 4 && p.kernel_version != 1) return launch_resident(p, optimizer, coherent, grid, threads, lds, stream);
+        return launch_v<4>(p, optimizer, coherent, grid, threads, lds, stream);
+    }
     return launch_v<1>(p, optimizer, coherent, grid, threads, lds, stream);
 }
 

@@ -177,6 +177,7 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
     p.ffm_rate = r->cfg.ffm_learning_rate;
     p.ffm_minus_power_t = -r->cfg.ffm_power_t;
     p.ticks = r->d_ticks;
+    p.kernel_version = r->launch.kernel_version;
     return p;
 }
 
@@ -314,6 +315,13 @@ int fwgpu_set_launch(fwgpu_regressor *r, uint32_t threads, uint32_t workgroups_p
         r->launch.threads = threads;
     }
     r->launch.workgroups_per_cu = workgroups_per_cu;
+    return FWGPU_OK;
+}
+
+int fwgpu_debug_set_kernel_version(fwgpu_regressor *r, int version) {
+    if (!r) return fail(FWGPU_ERR_INVALID, "NULL regressor");
+    if (version < 0 || version > 2) return fail(FWGPU_ERR_INVALID, "kernel version must be 0 (auto), 1 or 2");
+    r->launch.kernel_version = version;
     return FWGPU_OK;
 }
 

@@ -217,6 +217,8 @@ int fwgpu_set_launch(fwgpu_regressor *r, uint32_t threads, uint32_t workgroups_p
  * [3] dot + LR forward + sigmoid, [4] LR update, [5] FFM update, [6] wait for the slowest wave, [7] examples.
  * out8 (may be NULL) receives the counters accumulated so far. */
 int fwgpu_debug_phase_ticks(fwgpu_regressor *r, int enable, uint64_t *out8);
+/* 0 = automatic kernel choice, 1 = force the generic kernel (v1), 2 = register-resident rows (v2) where applicable. */
+int fwgpu_debug_set_kernel_version(fwgpu_regressor *r, int version);
 int fwgpu_debug_coherence_probe(int device, int use_sc1, uint32_t iters, uint32_t *stale_words, uint32_t *timeouts);
 
 /* ---------------------------------------------------------------- synthetic record streams

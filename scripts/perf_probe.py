@@ -17,15 +17,20 @@ recs, off = bench.gen_records(fw, args, 0, NB * B)
 batches = [re.batch_from_records(fbt, recs[int(off[s*B]):int(off[(s+1)*B])], off[s*B:(s+1)*B+1] - off[s*B]) for s in range(NB)]
 names = ["stage", "scan", "gather", "dot+lrfwd+sigm", "lr_update", "ffm_update", "wait_slowest", "examples"]
 
-def run(threads, wgs, update=True, reps=4, label=""):
+def run(threads, wgs, update=True, reps=6, label=""):
     re.set_launch(threads, wgs)
     re.learn_batch(batches[0], capi.MODE_HOGWILD, update); batches[0].predictions()
-    capi.check(L.fwgpu_debug_phase_ticks(re.h, 1, None))
+    # 1) wall time without instrumentation
     t0 = time.perf_counter()
     for i in range(reps):
         re.learn_batch(batches[i % NB], capi.MODE_HOGWILD, update)
     batches[(reps - 1) % NB].predictions()
     dt = (time.perf_counter() - t0) / reps
+    # 2) phase breakdown (instrumented run)
+    capi.check(L.fwgpu_debug_phase_ticks(re.h, 1, None))
+    for i in range(2):
+        re.learn_batch(batches[i % NB], capi.MODE_HOGWILD, update)
+    batches[1].predictions()
     out = (C.c_uint64 * 8)()
     capi.check(L.fwgpu_debug_phase_ticks(re.h, 0, out))
     t = np.array(list(out), dtype=np.float64)
@@ -34,20 +39,16 @@ def run(threads, wgs, update=True, reps=4, label=""):
     br = " ".join(f"{n}={100*v/tot:.0f}%" for n, v in zip(names[:7], t[:7]))
     print(f"{label} threads={threads} wgs/cu={wgs or 'auto'} update={update}: {dt*1e3:.3f} ms/launch {B/dt/1e6:.2f} Mex/s | ticks/example={per_ex:.0f} | {br}", flush=True)
 
-run(512, 0, label="base")
-run(512, 0, update=False, label="predict")
-for th, w in ((256, 0), (1024, 0), (512, 2), (512, 1), (1024, 1), (256, 4)):
-    run(th, w)
+for ver in (2, 1):
+    capi.check(L.fwgpu_debug_set_kernel_version(re.h, ver))
+    print(f"--- kernel v{ver}")
+    for th, w in ((1024, 1), (512, 2), (512, 1), (768, 1), (256, 4)):
+        run(th, w)
+    run(1024, 1, update=False, label="predict"); run(512, 2, update=False, label="predict")
 
-# ---- isolate the LR block's cost
-print("--- FFM only (LR block off)")
+
+print("--- v2, FFM only (LR block off)")
 mi2 = bench.build_model_instance(fw, args, 0); mi2.wiring = capi.WIRING_FFM_ONLY
-re_full, batches_full = re, batches
 re = fw.Regressor(mi2); fbt2 = fw.FeatureBufferTranslator(mi2)
 batches = [re.batch_from_records(fbt2, recs[int(off[s*B]):int(off[(s+1)*B])], off[s*B:(s+1)*B+1] - off[s*B]) for s in range(NB)]
-run(512, 0, label="ffm_only"); run(512, 0, update=False, label="ffm_only predict")
-print("--- LR only (no FFM block)")
-mi3 = bench.build_model_instance(fw, args, 0); mi3.ffm_k = 0; mi3.ffm_fields = []
-re = fw.Regressor(mi3); fbt3 = fw.FeatureBufferTranslator(mi3)
-batches = [re.batch_from_records(fbt3, recs[int(off[s*B]):int(off[(s+1)*B])], off[s*B:(s+1)*B+1] - off[s*B]) for s in range(NB)]
-run(512, 0, label="lr_only"); run(256, 8, label="lr_only"); run(512, 0, update=False, label="lr_only predict")
+run(512, 2, label="ffm_only"); run(1024, 1, label="ffm_only"); run(512, 2, update=False, label="ffm_only predict")

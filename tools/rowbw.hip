@@ -46,7 +46,7 @@ __global__ void read_rows(const float *tab, const uint32_t *rows, uint32_t nrows
     if (acc.x + acc.y + acc.z + acc.w == 123.456f) sink[0] = acc.x;
 }
 
-template <int U>
+template <int U, int LAUX = 16, int SAUX = 16, bool DO_LOAD = true, bool DO_STORE = true>
 __global__ void rmw_rows(float *w, float *a, const uint32_t *rows, uint32_t nrows, uint32_t R) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -57,16 +57,23 @@ __global__ void rmw_rows(float *w, float *a, const uint32_t *rows, uint32_t nrow
         for (int u = 0; u < U; ++u) {
             const uint32_t r = i + u < nrows ? i + u : i;
             h[u] = __builtin_amdgcn_readfirstlane(rows[r]);
-            vw[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc(w + h[u], R * 4), lane * 16, 0, 16);
-            va[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc(a + h[u], R * 4), lane * 16, 0, 16);
+            vw[u] = va[u] = u4{1, 2, 3, (unsigned)i};
+            if (DO_LOAD) {
+                vw[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc(w + h[u], R * 4), lane * 16, 0, LAUX);
+                va[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc(a + h[u], R * 4), lane * 16, 0, LAUX);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             f4 x = __builtin_bit_cast(f4, vw[u]), y = __builtin_bit_cast(f4, va[u]);
             y += x * x;
             x -= y * 1e-9f;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, x), rsrc(w + h[u], R * 4), lane * 16, 0, 16);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, y), rsrc(a + h[u], R * 4), lane * 16, 0, 16);
+            if (DO_STORE) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, x), rsrc(w + h[u], R * 4), lane * 16, 0, SAUX);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, y), rsrc(a + h[u], R * 4), lane * 16, 0, SAUX);
+            } else if (x.x == 123.456f) {
+                a[0] = y.x;
+            }
         }
     }
 }
@@ -160,6 +167,20 @@ int main(int argc, char **argv) {
         {
             float ms = time_ms([&] { hipLaunchKernelGGL((atomic_rows<2>), dim3(blocks), dim3(256), 0, 0, w, a, rows, nrows, R); });
             printf("%-22s waves/CU=%2d U=2     : %7.3f ms  %7.1f GB/s (4 x row bytes)\n", "atomic acc+w", wpc, ms, 4 * row_bytes / ms / 1e6);
+        }
+#define RUN_VAR(LA, SA, DL, DS, name, mult)                                                                           \
+    {                                                                                                                 \
+        float ms = time_ms([&] { hipLaunchKernelGGL((rmw_rows<2, LA, SA, DL, DS>), dim3(blocks), dim3(256), 0, 0, w, a, rows, nrows, R); }); \
+        printf("%-22s waves/CU=%2d U=2     : %7.3f ms  %7.1f GB/s (%d x row bytes)\n", name, wpc, ms, mult * row_bytes / ms / 1e6, mult); \
+    }
+        if (wpc == 16) {
+            RUN_VAR(16, 0, true, true, "rmw ld sc1 st plain", 4);
+            RUN_VAR(16, 2, true, true, "rmw ld sc1 st nt", 4);
+            RUN_VAR(16, 17, true, true, "rmw ld sc1 st sc0sc1", 4);
+            RUN_VAR(0, 0, true, true, "rmw ld plain st plain", 4);
+            RUN_VAR(16, 16, true, false, "load w+acc only sc1", 2);
+            RUN_VAR(16, 16, false, true, "store w+acc only sc1", 2);
+            RUN_VAR(16, 0, false, true, "store w+acc only plain", 2);
         }
         RUN_RMW(1);
         RUN_RMW(2);
