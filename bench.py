@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--threads", type=int, default=0, help="workgroup size override")
     ap.add_argument("--wgs-per-cu", dest="wgs", type=int, default=0)
     ap.add_argument("--sync-every", dest="sync_every", type=int, default=0, help="N>1: steps between delta all-reduces")
+    ap.add_argument("--force-dist", dest="force_dist", action="store_true",
+                    help="run the RCCL replica-sync path even with one rank (smoke test of the N>1 code on one GPU)")
     ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
     ap.add_argument("--cpu-examples", dest="cpu_examples", type=int, default=0)
     args = ap.parse_args()
@@ -148,8 +150,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     mi = build_model_instance(fw, args, local_rank)
@@ -180,29 +185,24 @@ def main():
 
     # ---- N>1: replicas + delta all-reduce (local SGD with summed deltas)
     sync_every = args.sync_every or max(1, K // 2)
-    tabs, snaps = [], []
-    if world > 1:
-        for which in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC):
-            t = re.table_as_torch(which)
-            tabs.append(t)
-            snaps.append(t.clone())
+    syncer = None
+    if use_dist:
+        from fwumious_wabbit_amd.dist_sync import DeltaAllReduce
+
+        # zero-copy torch views of the library's tables; torch.distributed (RCCL) does the exchange
+        syncer = DeltaAllReduce([re.table_as_torch(w) for w in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)])
 
     def sync_replicas():
-        # w <- w0 + sum_r (w_r - w0): every replica ends with the same tables, having applied everyone's updates
-        for t, s0 in zip(tabs, snaps):
-            chunk = 1 << 26  # 256 MiB buckets
-            for a in range(0, t.numel(), chunk):
-                d = t[a:a + chunk] - s0[a:a + chunk]
-                dist.all_reduce(d)
-                s0[a:a + chunk] += d
-                t[a:a + chunk] = s0[a:a + chunk]
+        # table <- snapshot + sum_r (table_r - snapshot): every replica ends with the same tables, having applied
+        # everyone's updates (runs on the same stream as the kernels)
+        syncer.sync()
 
     for i in range(W):
         re.learn_batch(batches[i], capi.MODE_HOGWILD, True, sptr)
-    if world > 1 and W:
+    if use_dist and W:
         sync_replicas()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
 
@@ -212,14 +212,14 @@ def main():
         ev[2 * i].record(stream)
         re.learn_batch(batches[W + i], capi.MODE_HOGWILD, True, sptr)
         ev[2 * i + 1].record(stream)
-        if world > 1 and (i + 1) % sync_every == 0:
+        if use_dist and (i + 1) % sync_every == 0:
             sync_replicas()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -274,7 +274,9 @@ def main():
                 "examples_per_step_per_gpu": B,
                 "global_batch": B * world,
                 "mode": "hogwild (device-wide concurrent examples, racy RMW, sc1 accesses)",
-                "parallelism": "1 GPU" if world == 1 else f"dp{world}: replicas, RCCL delta all-reduce every {sync_every} steps",
+                "parallelism": ("1 GPU" if not use_dist else
+                                f"dp{world}: replicas, RCCL delta all-reduce of {syncer.bytes_per_sync() / 1e9:.2f} GB every "
+                                f"{sync_every} steps ({syncer.n_syncs} syncs incl. warmup)"),
                 "holdout_examples": args.holdout,
                 "prep_seconds": prep_s,
             },
@@ -299,10 +301,22 @@ def main():
             except Exception as e:  # the baseline is a reported side figure; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "examples/sec", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        result_line = json.dumps(out)
+    else:
+        result_line = None
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    # RCCL prints a version banner through C stdio; flush it first so that the JSON line is the LAST line on stdout
+    try:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    if result_line is not None:
+        print(result_line, flush=True)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,77 @@
+"""world_size-2 gloo test of the replica delta all-reduce (CPU tensors; the GPU path uses the same code over RCCL)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from fwumious_wabbit_amd.dist_sync import DeltaAllReduce
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(1234)
+    base_w = torch.randn(1000, generator=g)          # identical initial tables on every rank
+    base_a = torch.rand(777, generator=g)
+    w, a = base_w.clone(), base_a.clone()
+    sync = DeltaAllReduce([w, a], bucket_elems=256)  # several buckets, last one ragged
+    expect_w, expect_a = base_w.clone(), base_a.clone()
+    for step in range(3):
+        # each rank applies its own sparse "training" updates
+        gr = torch.Generator().manual_seed(100 * step + rank)
+        idx = torch.randint(0, 1000, (50,), generator=gr)
+        w[idx] -= 0.01 * (rank + 1)
+        a[idx % 777] += 0.5
+        # what the union of all ranks' updates amounts to
+        for r in range(world):
+            g2 = torch.Generator().manual_seed(100 * step + r)
+            i2 = torch.randint(0, 1000, (50,), generator=g2)
+            dw = torch.zeros(1000)
+            dw[i2] -= 0.01 * (r + 1)          # same semantics as the in-place op above (last write per index)
+            da = torch.zeros(777)
+            da[i2 % 777] += 0.5
+            expect_w += dw
+            expect_a += da
+        sync.sync()
+        assert torch.allclose(w, expect_w, atol=1e-6) and torch.allclose(a, expect_a, atol=1e-6)
+        assert torch.equal(w, sync.snapshots[0]) and torch.equal(a, sync.snapshots[1])
+    # replicas are bit-identical after a sync
+    gathered = [torch.zeros_like(w) for _ in range(world)]
+    dist.all_gather(gathered, w)
+    assert all(torch.equal(gathered[0], x) for x in gathered)
+    out[rank] = float(w.sum())
+    dist.destroy_process_group()
+
+
+def test_delta_allreduce_world2_gloo():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+        assert len(out) == world and abs(out[0] - out[1]) == 0.0
+
+
+def test_delta_allreduce_single_rank_is_identity():
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        t = torch.arange(10, dtype=torch.float32)
+        s = DeltaAllReduce([t], bucket_elems=4)
+        t += 1.5
+        want = t.clone()
+        s.sync()
+        assert torch.equal(t, want) and s.n_syncs == 1 and s.bytes_per_sync() == 40
+    finally:
+        dist.destroy_process_group()
