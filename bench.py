@@ -172,10 +172,11 @@ def main():
     for s in range(W + K):
         lo, hi = s * B, (s + 1) * B
         sub = recs[int(off[lo]):int(off[hi])]
-        batches.append(re.batch_from_records(fbt, sub, off[lo:hi + 1] - off[lo]))
+        # raw records in HBM; FeatureBufferTranslator::translate (a2) runs inside the kernel's stage phase
+        batches.append(re.record_batch(fbt, sub, off[lo:hi + 1] - off[lo]))
         words.append(len(sub))
     hrecs, hoff = gen_records(fw, args, 1_000_000_000, args.holdout)  # same hold-out tail on every rank
-    hbatch = re.batch_from_records(fbt, hrecs, hoff)
+    hbatch = re.record_batch(fbt, hrecs, hoff)
     hy = hrecs[hoff[:-1].astype(np.int64) + 1].astype(np.float32)
     del recs
     prep_s = time.time() - t0
@@ -270,7 +271,7 @@ def main():
                 "hyperparameters": f"AdagradLUT lr={LR} power_t={POWER_T} init_acc_gradient={INIT_ACC} (run_one.sh)",
                 "workload": f"BASELINE.json configs[2]: synthetic {args.fields}-field k={args.k} FFM + LR, "
                             f"{args.ffm_bits}-bit FFM hash, {args.bits}-bit LR hash, ~{int(args.fields * (1 + args.mean_extra))} nnz/example, "
-                            f"AdagradLUT, fused learn (forward + sigmoid/log-loss + AdaGrad scatter-update)",
+                            f"AdagradLUT, fused learn (record translation + forward + sigmoid/log-loss + AdaGrad scatter-update)",
                 "examples_per_step_per_gpu": B,
                 "global_batch": B * world,
                 "mode": "hogwild (device-wide concurrent examples, racy RMW, sc1 accesses)",

@@ -118,6 +118,7 @@ def lib():
         "fwgpu_batch_predictions_device": [vp, P(vp)],
         "fwgpu_translate": [P(TranslatorConfig), vp, u32, vp, u32, P(u32), vp, u32, P(u32), P(f32), P(f32)],
         "fwgpu_batch_from_records": [vp, P(TranslatorConfig), vp, vp, u32, P(vp)],
+        "fwgpu_record_batch_create": [vp, P(TranslatorConfig), vp, vp, u32, P(vp)],
         "fwgpu_trainer_create": [vp, P(TranslatorConfig), u32, P(vp)],
         "fwgpu_digest_records": [vp, vp, vp, u32],
         "fwgpu_finish": [vp],

@@ -25,6 +25,18 @@ int fail(int code, const std::string &msg);
             return ::fwgpu::fail(FWGPU_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_));   \
     } while (0)
 
+// Device copy of a FeatureBufferTranslator (feature_buffer.rs:33-44): which namespaces feed which LR combo / FFM field.
+struct DevTranslator {
+    const uint32_t *combo_off;   // [n_combos+1] into combo_ns
+    const uint32_t *combo_ns;    // namespace index of each combo member
+    const uint8_t *combo_f32;    // member namespace is NamespaceFormat::F32
+    const float *combo_w;        // [n_combos] combo weight
+    const uint32_t *pair_ns;     // flattened (field, namespace) pairs in field order
+    const uint8_t *pair_f32;
+    const uint8_t *pair_field;   // field index of each pair
+    uint32_t n_combos, n_pairs, add_const, lr_mask, ffm_mask;
+};
+
 // Everything the example kernel needs, passed by value.
 struct KernelParams {
     // ---- tables (HBM) ----
@@ -45,6 +57,11 @@ struct KernelParams {
     const float *importance;
     float *pred;
     uint32_t n_examples;
+    // ---- or: raw records (parser.rs:57-74), translated on the device in the stage phase (records != NULL)
+    const uint32_t *records;
+    const uint64_t *rec_off;  // [n+1] u32-word offsets
+    uint32_t max_rec;         // longest record of the batch, in words (LDS capacity)
+    DevTranslator tr;
     // ---- model ----
     uint32_t F, k, R;          // fields, ffm_k, R = F*k (row length in floats)
     uint32_t max_ffm, max_lr;  // LDS capacities for one example's entries
@@ -95,6 +112,15 @@ struct fwgpu_batch {
     float *label = nullptr;
     float *importance = nullptr;
     float *pred = nullptr;
+    // raw-record batches (device-side translation)
+    uint32_t *records = nullptr;
+    uint64_t *rec_off = nullptr;
+    uint32_t max_rec = 0;
+    uint64_t n_words = 0;
+    uint64_t words_cap = 0;
+    uint32_t n_cap = 0;
+    void *tr_dev = nullptr;  // device blob holding the DevTranslator arrays
+    fwgpu::DevTranslator tr{};
 };
 
 struct fwgpu_regressor {
@@ -134,6 +160,27 @@ int translate_record(const fwgpu_translator_config *t, const uint32_t *rec, uint
                      std::vector<fwgpu_lr_entry> &lr, std::vector<fwgpu_ffm_entry> &ffm, float *label,
                      float *importance);
 int check_translator(const fwgpu_regressor *r, const fwgpu_translator_config *t);
+// validates one record against the translator and counts the entries its translation produces
+int count_record(const fwgpu_translator_config *t, const uint32_t *rec, uint32_t rec_len, uint32_t *n_lr, uint32_t *n_ffm);
+// device-resident raw-record batch (translation happens inside the example kernel)
+int record_batch_alloc(fwgpu_regressor *r, const fwgpu_translator_config *t, uint32_t n_cap, uint64_t words_cap,
+                       fwgpu_batch **out);
+struct RecordStats {  // what the host learns about a slice of records without translating them
+    uint32_t max_lr = 0, max_ffm = 0, max_rec = 0;
+    uint64_t tot_lr = 0, tot_ffm = 0;
+    void merge(const RecordStats &o) {
+        max_lr = max_lr > o.max_lr ? max_lr : o.max_lr;
+        max_ffm = max_ffm > o.max_ffm ? max_ffm : o.max_ffm;
+        max_rec = max_rec > o.max_rec ? max_rec : o.max_rec;
+        tot_lr += o.tot_lr;
+        tot_ffm += o.tot_ffm;
+    }
+};
+int count_records(const fwgpu_translator_config *t, const uint32_t *records, const uint64_t *rec_off, uint32_t n,
+                  RecordStats *st);
+// stats == NULL: validate and count here
+int record_batch_upload(fwgpu_batch *b, const fwgpu_translator_config *t, const uint32_t *records,
+                        const uint64_t *rec_off, uint32_t n, hipStream_t stream, const RecordStats *stats = nullptr);
 uint32_t lr_hash_mask(uint32_t bit_precision);
 uint32_t ffm_hash_mask(uint32_t ffm_bits, uint32_t ffm_k);
 void lut_init(float *lut, float learning_rate, float power_t, float init_acc);

@@ -143,7 +143,9 @@ struct Lds {
     float *dcf;               // F: per-field self-pair correction
     uint32_t *set_ffm;        // open-addressing set of FFM row block keys (overlap pre-filter)
     uint32_t *set_lr;         // open-addressing set of LR hashes (duplicate pre-filter)
-    uint32_t *ctr;            // 4
+    uint32_t *rec;            // raw record staged for device-side translation (max_rec words)
+    uint32_t *tcnt;           // per (field,namespace) pair and per combo: entry count, then exclusive offset
+    uint32_t *ctr;            // 8
 };
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -181,7 +183,7 @@ __device__ __forceinline__ bool set_contains(const uint32_t *tab, uint32_t mask,
 }
 
 __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t max_ffm, uint32_t max_lr, bool lut,
-                                             size_t *off /*[15]*/) {
+                                             uint32_t max_rec, uint32_t tr_items, size_t *off /*[17]*/) {
     size_t o = 0;
     size_t R = (size_t)F * k;
     off[0] = o; o = align16(o + 4 * F * R);
@@ -195,16 +197,257 @@ __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t ma
     off[8] = o; o = align16(o + 4 * (size_t)F);
     off[9] = o; o = align16(o + 4 * (size_t)F);
     off[10] = o; o = align16(o + 4 * 3 * 16);
-    off[11] = o; o = align16(o + 4 * 4);
+    off[11] = o; o = align16(o + 4 * 8);
     off[12] = o; o = align16(o + 4 * (size_t)F);
     off[13] = o; o = align16(o + 4 * (size_t)set_size(max_ffm));
     off[14] = o; o = align16(o + 4 * (size_t)set_size(max_lr));
+    off[15] = o; o = align16(o + 4 * (size_t)max_rec);
+    off[16] = o; o = align16(o + 4 * (size_t)tr_items);
+    return o;
+}
+
+__device__ __forceinline__ bool k_nonzero(uint32_t k) { return k != 0; }
+
+// ------------------------------------------------------------------ stage phase (shared by both example kernels)
+struct SetGeom {
+    uint32_t setf_n, setl_n, setf_shift, setl_shift, blk_shift;
+};
+struct StageOut {
+    uint32_t nf, nl;
+    float label, imp;
+    bool do_update;
+};
+
+// record slot decoding, feature_reader! (feature_buffer.rs:47-108) on the LDS copy of the record
+__device__ __forceinline__ uint32_t slot_count(const uint32_t *rec, uint32_t ns) {
+    const uint32_t w = rec[3 + ns];
+    if (!(w & 0x80000000u)) return 1;                      // single feature, value 1.0 (parser.rs:62-66)
+    return ((w & 0xffffu) - ((w >> 16) & 0x3fffu)) >> 1;   // NO_FEATURES = 0x80000000 -> 0
+}
+__device__ __forceinline__ void slot_get(const uint32_t *rec, uint32_t ns, bool is_f32, uint32_t q, uint32_t &hash,
+                                         float &val) {
+    const uint32_t w = rec[3 + ns];
+    if (!(w & 0x80000000u)) {
+        hash = w;
+        val = 1.0f;
+    } else {
+        const uint32_t st = (w >> 16) & 0x3fffu;
+        hash = rec[st + 2 * q];
+        val = is_f32 ? 1.0f : __uint_as_float(rec[st + 2 * q + 1]);  // feature_buffer.rs:88-104
+    }
+}
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// Brings example `ex` into LDS: either copies its pre-translated entries, or translates its raw record
+// (FeatureBufferTranslator::translate, feature_buffer.rs:178-338, bit-exact hashing) on the spot; then finds the field
+// boundaries and runs the O(1) pre-filters for overlapping FFM rows / duplicate LR hashes (exact scan only if they hit).
+// Must be called by every thread of the workgroup (it contains barriers).
+__device__ __forceinline__ StageOut stage_example(const KernelParams &p, const Lds &s, const SetGeom &g, uint32_t ex,
+                                                  int tid, int bd) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t F = p.F, R = p.R;
+    StageOut o;
+    const uint32_t *grec = nullptr;
+    uint32_t rec_len = 0, fo = 0, lo = 0;
+    if (p.records) {
+        const uint64_t r0 = p.rec_off[ex];
+        grec = p.records + r0;
+        rec_len = (uint32_t)(p.rec_off[ex + 1] - r0);
+        o.label = (float)grec[1];              // feature_buffer.rs:187
+        o.imp = __uint_as_float(grec[2]);      // feature_buffer.rs:188-189
+        o.nf = o.nl = 0;
+    } else {
+        fo = p.ffm_off[ex];
+        o.nf = p.ffm_off[ex + 1] - fo;
+        lo = p.lr_off[ex];
+        o.nl = p.lr_off[ex + 1] - lo;
+        o.label = p.label[ex];
+        o.imp = p.importance[ex];
+    }
+    o.do_update = p.update && (o.imp != 0.0f);  // regressor.rs:366
+    const bool do_update = o.do_update;
+
+    for (uint32_t i = tid; i < F; i += bd) {
+        s.fstart[i] = 0;
+        s.fend[i] = 0;
+    }
+    if (tid == 0) {
+        s.ctr[0] = 0;  // next field to gather (v1)
+        s.ctr[1] = 0;  // some FFM rows of this example overlap an earlier row (exact)
+        s.ctr[2] = 0;  // pre-filter: rows MAY overlap
+        s.ctr[3] = 0;  // duplicate LR hashes in this example
+    }
+    if (do_update) {
+        for (uint32_t i = tid; i < g.setf_n; i += bd) s.set_ffm[i] = kSetEmpty;
+        for (uint32_t i = tid; i < g.setl_n; i += bd) s.set_lr[i] = kSetEmpty;
+    }
+    if (!p.records) {
+        for (uint32_t i = tid; i < o.nf; i += bd) {
+            s.e_hash[i] = p.ffm_hash[fo + i];
+            s.e_val[i] = p.ffm_val[fo + i];
+            s.e_fld[i] = p.ffm_fld[fo + i];
+        }
+        for (uint32_t i = tid; i < o.nl; i += bd) {
+            s.l_hash[i] = p.lr_hash[lo + i];
+            s.l_val[i] = p.lr_val[lo + i];
+        }
+        __syncthreads();
+    } else {
+        const DevTranslator &t = p.tr;
+        const uint32_t NP = t.n_pairs, NC = t.n_combos;
+        for (uint32_t i = tid; i < rec_len; i += bd) s.rec[i] = grec[i];
+        __syncthreads();
+        // Wave 0 builds the ffm_buffer, wave 1 the lr_buffer: per 64 items count -> wave scan -> emit, all inside one
+        // wave, so no workgroup barrier is needed between the steps.
+        if (wave == 0) {
+            // ffm_buffer, ordered by field (feature_buffer.rs:314-335)
+            uint32_t carry = 0;
+            for (uint32_t b0 = 0; b0 < NP; b0 += 64) {
+                const uint32_t j = b0 + lane;
+                const bool on = j < NP && k_nonzero(p.k);
+                const uint32_t ns = on ? t.pair_ns[j] : 0;
+                const uint32_t cnt = on ? slot_count(s.rec, ns) : 0;
+                const uint32_t inc = wave_scan_incl(cnt, lane);
+                const uint32_t base = carry + inc - cnt;
+                if (on) {
+                    const bool f32 = t.pair_f32[j] != 0;
+                    const uint32_t fld = t.pair_field[j];
+                    for (uint32_t q = 0; q < cnt; ++q) {
+                        uint32_t h;
+                        float v;
+                        slot_get(s.rec, ns, f32, q, h, v);
+                        s.e_hash[base + q] = h & t.ffm_mask;
+                        s.e_val[base + q] = v;
+                        s.e_fld[base + q] = fld;
+                    }
+                }
+                carry += (uint32_t)__shfl((int)inc, 63, 64);
+            }
+            if (lane == 0) s.ctr[4] = carry;
+        }
+        if (wave == (bd > 64 ? 1 : 0)) {
+            // lr_buffer (feature_buffer.rs:194-276): hash = (h_prev * 16777619) ^ h_next, values multiply
+            uint32_t carry = 0;
+            for (uint32_t b0 = 0; b0 < NC; b0 += 64) {
+                const uint32_t c = b0 + lane;
+                const bool on = c < NC && p.has_lr;
+                const uint32_t m0 = on ? t.combo_off[c] : 0, m1 = on ? t.combo_off[c + 1] : 0;
+                uint32_t total = on ? 1 : 0;
+                for (uint32_t m = m0; m < m1; ++m) total *= slot_count(s.rec, t.combo_ns[m]);
+                const uint32_t inc = wave_scan_incl(total, lane);
+                const uint32_t base = carry + inc - total;
+                if (on) {
+                    const float cw = t.combo_w[c];
+                    for (uint32_t idx = 0; idx < total; ++idx) {
+                        // digits of idx, first namespace most significant (the reference's loop nesting)
+                        uint32_t rem = idx, div = total;
+                        uint32_t hash = 0;
+                        float val = 1.0f;
+                        for (uint32_t m = m0; m < m1; ++m) {
+                            const uint32_t cm = slot_count(s.rec, t.combo_ns[m]);
+                            div /= cm;
+                            const uint32_t q = rem / div;
+                            rem -= q * div;
+                            uint32_t h;
+                            float v;
+                            slot_get(s.rec, t.combo_ns[m], t.combo_f32[m] != 0, q, h, v);
+                            if (m == m0) {
+                                hash = h;
+                                val = v;
+                            } else {
+                                hash = (hash * 16777619u) ^ h;  // feature_buffer.rs:242-251 (wrapping)
+                                val = val * v;
+                            }
+                        }
+                        s.l_hash[base + idx] = hash & t.lr_mask;
+                        s.l_val[base + idx] = val * cw;
+                    }
+                }
+                carry += (uint32_t)__shfl((int)inc, 63, 64);
+            }
+            if (p.has_lr && t.add_const) {  // feature_buffer.rs:270-276
+                if (lane == 0) {
+                    s.l_hash[carry] = 11650396u & t.lr_mask;
+                    s.l_val[carry] = 1.0f;
+                }
+                carry += 1;
+            }
+            if (lane == 0) s.ctr[5] = carry;
+        }
+        __syncthreads();
+        o.nf = s.ctr[4];
+        o.nl = s.ctr[5];
+    }
+    const uint32_t nf = o.nf, nl = o.nl;
+    // field boundaries; O(1) pre-filters: FFM rows that may overlap (block keys equal or adjacent), duplicate LR hashes
+    for (uint32_t i = tid; i < nf; i += bd) {
+        const uint32_t f = s.e_fld[i];
+        if (i == 0 || s.e_fld[i - 1] != f) s.fstart[f] = i;
+        if (i == nf - 1 || s.e_fld[i + 1] != f) s.fend[f] = i + 1;
+        if (do_update && set_insert(s.set_ffm, g.setf_n - 1, g.setf_shift, s.e_hash[i] >> g.blk_shift)) s.ctr[2] = 1;
+    }
+    if (do_update && p.has_lr)
+        for (uint32_t i = tid; i < nl; i += bd)
+            if (set_insert(s.set_lr, g.setl_n - 1, g.setl_shift, s.l_hash[i])) s.ctr[3] = 1;
+    __syncthreads();
+    if (do_update)
+        for (uint32_t i = tid; i < nf; i += bd)
+            if (set_contains(s.set_ffm, g.setf_n - 1, g.setf_shift, (s.e_hash[i] >> g.blk_shift) + 1)) s.ctr[2] = 1;
+    // T columns and self-pair corrections of empty fields are zero (block_ffm.rs:168-180)
+    if (p.k) {
+        const uint32_t per = R / (p.k % 4 == 0 ? 4 : 1), vecw = p.k % 4 == 0 ? 4 : 1;
+        for (uint32_t idx = tid; idx < F * per; idx += bd) {
+            const uint32_t f = idx / per, q = idx - f * per;
+            if (s.fstart[f] == s.fend[f]) {
+                const uint32_t ee = q * vecw, zz = ee / p.k;
+                for (uint32_t j = 0; j < vecw; ++j) s.T[zz * R + f * p.k + (ee - zz * p.k) + j] = 0.0f;
+            }
+        }
+        for (uint32_t f = tid; f < F; f += bd)
+            if (s.fstart[f] == s.fend[f]) s.dcf[f] = 0.0f;
+    }
+    __syncthreads();
+    if (do_update && s.ctr[2]) {
+        // Rare: some rows may overlap.  Exact scan: does an EARLIER feature's row [h_j, h_j+R) overlap mine?
+        // (rows are R long but start on a next_pow2(k) grid: block_ffm.rs:92-94, feature_buffer.rs:141-148)
+        uint32_t my_dep[4] = {0, 0, 0, 0};  // supports nf <= 4*bd (checked on the host)
+        int slot = 0;
+        for (uint32_t i = tid; i < nf; i += bd, ++slot) {
+            const uint32_t h = s.e_hash[i];
+            uint32_t d = 0;
+            for (uint32_t j = 0; j < i; ++j) {
+                const uint32_t hj = s.e_hash[j];
+                const uint32_t diff = h > hj ? h - hj : hj - h;
+                d |= (diff < R) ? 1u : 0u;
+            }
+            my_dep[slot & 3] = d;
+        }
+        __syncthreads();
+        slot = 0;
+        uint32_t any = 0;
+        for (uint32_t i = tid; i < nf; i += bd, ++slot) {
+            if (my_dep[slot & 3]) {
+                s.e_fld[i] |= 0x80000000u;
+                any = 1;
+            }
+        }
+        if (any) s.ctr[1] = 1;
+        __syncthreads();
+    }
     return o;
 }
 
 size_t example_kernel_lds_bytes(const KernelParams &p, int optimizer) {
-    size_t off[15];
-    return lds_layout(p.F, p.k, p.max_ffm, p.max_lr, optimizer == FWGPU_OPT_ADAGRAD_LUT && p.update, off);
+    size_t off[17];
+    return lds_layout(p.F, p.k, p.max_ffm, p.max_lr, optimizer == FWGPU_OPT_ADAGRAD_LUT && p.update,
+                      p.records ? p.max_rec : 0, p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, off);
 }
 
 // Update of one FFM feature row by one wave (block_ffm.rs:269-286), U rows at a time for memory-level
@@ -273,8 +516,9 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
     constexpr int UU = 4;  // feature rows in flight per wave in the update phase (x2 tables)
     extern __shared__ __align__(16) unsigned char smem[];
     const bool use_lut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update;
-    size_t off[15];
-    lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut, off);
+    size_t off[17];
+    lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut, p.records ? p.max_rec : 0,
+               p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, off);
     Lds s;
     s.T = reinterpret_cast<float *>(smem + off[0]);
     s.selfw = reinterpret_cast<float *>(smem + off[1]);
@@ -291,10 +535,15 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
     s.dcf = reinterpret_cast<float *>(smem + off[12]);
     s.set_ffm = reinterpret_cast<uint32_t *>(smem + off[13]);
     s.set_lr = reinterpret_cast<uint32_t *>(smem + off[14]);
-    const uint32_t setf_n = set_size(p.max_ffm), setl_n = set_size(p.max_lr);
-    const uint32_t setf_shift = 32 - log2u(setf_n), setl_shift = 32 - log2u(setl_n);
-    uint32_t blk_shift = 0;  // 2^blk_shift >= R: rows that overlap have block keys (hash >> blk_shift) differing by <= 1
-    while ((1u << blk_shift) < p.R) blk_shift++;
+    s.rec = reinterpret_cast<uint32_t *>(smem + off[15]);
+    s.tcnt = reinterpret_cast<uint32_t *>(smem + off[16]);
+    SetGeom geom;
+    geom.setf_n = set_size(p.max_ffm);
+    geom.setl_n = set_size(p.max_lr);
+    geom.setf_shift = 32 - log2u(geom.setf_n);
+    geom.setl_shift = 32 - log2u(geom.setl_n);
+    geom.blk_shift = 0;  // 2^blk_shift >= R: rows that overlap have block keys (hash >> blk_shift) differing by <= 1
+    while ((1u << geom.blk_shift) < p.R) geom.blk_shift++;
 
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = bd >> 6;
@@ -324,80 +573,10 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         __syncthreads();
         FW_TICK(6);
         if (timing) tk[7] += 1;
-        const uint32_t fo = p.ffm_off[ex], nf = p.ffm_off[ex + 1] - fo;
-        const uint32_t lo = p.lr_off[ex], nl = p.lr_off[ex + 1] - lo;
-        const float label = p.label[ex], imp = p.importance[ex];
-        const bool do_update = p.update && (imp != 0.0f);  // regressor.rs:366
-
-        // ---------------- stage
-        for (uint32_t i = tid; i < F; i += bd) {
-            s.fstart[i] = 0;
-            s.fend[i] = 0;
-        }
-        if (tid == 0) {
-            s.ctr[0] = 0;  // next field to gather
-            s.ctr[1] = 0;  // some FFM rows of this example overlap an earlier row (exact)
-            s.ctr[2] = 0;  // pre-filter: rows MAY overlap
-            s.ctr[3] = 0;  // duplicate LR hashes in this example
-        }
-        if (do_update) {
-            for (uint32_t i = tid; i < setf_n; i += bd) s.set_ffm[i] = kSetEmpty;
-            for (uint32_t i = tid; i < setl_n; i += bd) s.set_lr[i] = kSetEmpty;
-        }
-        for (uint32_t i = tid; i < nf; i += bd) {
-            s.e_hash[i] = p.ffm_hash[fo + i];
-            s.e_val[i] = p.ffm_val[fo + i];
-            s.e_fld[i] = p.ffm_fld[fo + i];
-        }
-        for (uint32_t i = tid; i < nl; i += bd) {
-            s.l_hash[i] = p.lr_hash[lo + i];
-            s.l_val[i] = p.lr_val[lo + i];
-        }
-        __syncthreads();
-        FW_TICK(0);
-        // field boundaries; and O(1) pre-filters for the two cases that need in-order treatment inside one example:
-        // FFM rows that may overlap (block keys equal or adjacent) and duplicate LR hashes.  ctr[2]/ctr[3] flag them.
-        for (uint32_t i = tid; i < nf; i += bd) {
-            const uint32_t f = s.e_fld[i];
-            if (i == 0 || s.e_fld[i - 1] != f) s.fstart[f] = i;
-            if (i == nf - 1 || s.e_fld[i + 1] != f) s.fend[f] = i + 1;
-            if (do_update && set_insert(s.set_ffm, setf_n - 1, setf_shift, s.e_hash[i] >> blk_shift)) s.ctr[2] = 1;
-        }
-        if (do_update && p.has_lr)
-            for (uint32_t i = tid; i < nl; i += bd)
-                if (set_insert(s.set_lr, setl_n - 1, setl_shift, s.l_hash[i])) s.ctr[3] = 1;
-        __syncthreads();
-        if (do_update)
-            for (uint32_t i = tid; i < nf; i += bd)
-                if (set_contains(s.set_ffm, setf_n - 1, setf_shift, (s.e_hash[i] >> blk_shift) + 1)) s.ctr[2] = 1;
-        __syncthreads();
-        if (do_update && s.ctr[2]) {
-            // Rare: some rows may overlap.  Exact scan: does an EARLIER feature's row [h_j, h_j+R) overlap mine?
-            // (rows are R long but start on a next_pow2(k) grid: block_ffm.rs:92-94, feature_buffer.rs:141-148)
-            uint32_t my_dep[4] = {0, 0, 0, 0};  // supports nf <= 4*bd (checked on the host)
-            int slot = 0;
-            for (uint32_t i = tid; i < nf; i += bd, ++slot) {
-                const uint32_t h = s.e_hash[i];
-                uint32_t d = 0;
-                for (uint32_t j = 0; j < i; ++j) {
-                    const uint32_t hj = s.e_hash[j];
-                    const uint32_t diff = h > hj ? h - hj : hj - h;
-                    d |= (diff < R) ? 1u : 0u;
-                }
-                my_dep[slot & 3] = d;
-            }
-            __syncthreads();
-            slot = 0;
-            uint32_t any = 0;
-            for (uint32_t i = tid; i < nf; i += bd, ++slot) {
-                if (my_dep[slot & 3]) {
-                    s.e_fld[i] |= 0x80000000u;
-                    any = 1;
-                }
-            }
-            if (any) s.ctr[1] = 1;
-        }
-
+        const StageOut so = stage_example(p, s, geom, ex, tid, bd);
+        const uint32_t nf = so.nf, nl = so.nl;
+        const float label = so.label, imp = so.imp;
+        const bool do_update = so.do_update;
         FW_TICK(1);
         // ---------------- gather: field sums, transposed into LDS
         if (k) {
@@ -646,8 +825,9 @@ __global__ void __launch_bounds__(1024) fw_example_kernel_r(const KernelParams p
     constexpr int UA = 4;  // accumulator rows in flight per wave in the update phase
     extern __shared__ __align__(16) unsigned char smem[];
     const bool use_lut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update;
-    size_t off[15];
-    lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut, off);
+    size_t off[17];
+    lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut, p.records ? p.max_rec : 0,
+               p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, off);
     Lds s;
     s.T = reinterpret_cast<float *>(smem + off[0]);
     s.selfw = reinterpret_cast<float *>(smem + off[1]);
@@ -664,10 +844,15 @@ __global__ void __launch_bounds__(1024) fw_example_kernel_r(const KernelParams p
     s.dcf = reinterpret_cast<float *>(smem + off[12]);
     s.set_ffm = reinterpret_cast<uint32_t *>(smem + off[13]);
     s.set_lr = reinterpret_cast<uint32_t *>(smem + off[14]);
-    const uint32_t setf_n = set_size(p.max_ffm), setl_n = set_size(p.max_lr);
-    const uint32_t setf_shift = 32 - log2u(setf_n), setl_shift = 32 - log2u(setl_n);
-    uint32_t blk_shift = 0;
-    while ((1u << blk_shift) < p.R) blk_shift++;
+    s.rec = reinterpret_cast<uint32_t *>(smem + off[15]);
+    s.tcnt = reinterpret_cast<uint32_t *>(smem + off[16]);
+    SetGeom geom;
+    geom.setf_n = set_size(p.max_ffm);
+    geom.setl_n = set_size(p.max_lr);
+    geom.setf_shift = 32 - log2u(geom.setf_n);
+    geom.setl_shift = 32 - log2u(geom.setl_n);
+    geom.blk_shift = 0;  // 2^blk_shift >= R: rows that overlap have block keys (hash >> blk_shift) differing by <= 1
+    while ((1u << geom.blk_shift) < p.R) geom.blk_shift++;
 
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = bd >> 6;
@@ -696,85 +881,10 @@ __global__ void __launch_bounds__(1024) fw_example_kernel_r(const KernelParams p
         __syncthreads();
         FW_TICK(6);
         if (timing) atomicAdd(p.ticks + 7, 1ull);
-        const uint32_t fo = p.ffm_off[ex], nf = p.ffm_off[ex + 1] - fo;
-        const uint32_t lo_lr = p.lr_off[ex], nl = p.lr_off[ex + 1] - lo_lr;
-        const float label = p.label[ex], imp = p.importance[ex];
-        const bool do_update = p.update && (imp != 0.0f);
-
-        // ---------------- stage (identical to fw_example_kernel)
-        for (uint32_t i = tid; i < F; i += bd) {
-            s.fstart[i] = 0;
-            s.fend[i] = 0;
-        }
-        if (tid == 0) {
-            s.ctr[1] = 0;
-            s.ctr[2] = 0;
-            s.ctr[3] = 0;
-        }
-        if (do_update) {
-            for (uint32_t i = tid; i < setf_n; i += bd) s.set_ffm[i] = kSetEmpty;
-            for (uint32_t i = tid; i < setl_n; i += bd) s.set_lr[i] = kSetEmpty;
-        }
-        for (uint32_t i = tid; i < nf; i += bd) {
-            s.e_hash[i] = p.ffm_hash[fo + i];
-            s.e_val[i] = p.ffm_val[fo + i];
-            s.e_fld[i] = p.ffm_fld[fo + i];
-        }
-        for (uint32_t i = tid; i < nl; i += bd) {
-            s.l_hash[i] = p.lr_hash[lo_lr + i];
-            s.l_val[i] = p.lr_val[lo_lr + i];
-        }
-        __syncthreads();
-        FW_TICK(0);
-        for (uint32_t i = tid; i < nf; i += bd) {
-            const uint32_t f = s.e_fld[i];
-            if (i == 0 || s.e_fld[i - 1] != f) s.fstart[f] = i;
-            if (i == nf - 1 || s.e_fld[i + 1] != f) s.fend[f] = i + 1;
-            if (do_update && set_insert(s.set_ffm, setf_n - 1, setf_shift, s.e_hash[i] >> blk_shift)) s.ctr[2] = 1;
-        }
-        if (do_update && p.has_lr)
-            for (uint32_t i = tid; i < nl; i += bd)
-                if (set_insert(s.set_lr, setl_n - 1, setl_shift, s.l_hash[i])) s.ctr[3] = 1;
-        __syncthreads();
-        if (do_update)
-            for (uint32_t i = tid; i < nf; i += bd)
-                if (set_contains(s.set_ffm, setf_n - 1, setf_shift, (s.e_hash[i] >> blk_shift) + 1)) s.ctr[2] = 1;
-        // T columns of empty fields are zero (block_ffm.rs:168-180)
-        for (uint32_t idx = tid; idx < F * (R / VEC); idx += bd) {
-            const uint32_t f = idx / (R / VEC), q = idx - f * (R / VEC);
-            if (s.fstart[f] == s.fend[f]) {
-                const uint32_t ee = q * VEC, zz = ee / k;
-                Vec<VEC>::lds_store(s.T + zz * R + f * k + (ee - zz * k), Vec<VEC>::zero());
-            }
-        }
-        for (uint32_t f = tid; f < F; f += bd)
-            if (s.fstart[f] == s.fend[f]) s.dcf[f] = 0.0f;
-        __syncthreads();
-        if (do_update && s.ctr[2]) {
-            uint32_t my_dep[4] = {0, 0, 0, 0};
-            int slot = 0;
-            for (uint32_t i = tid; i < nf; i += bd, ++slot) {
-                const uint32_t h = s.e_hash[i];
-                uint32_t d = 0;
-                for (uint32_t j = 0; j < i; ++j) {
-                    const uint32_t hj = s.e_hash[j];
-                    const uint32_t diff = h > hj ? h - hj : hj - h;
-                    d |= (diff < R) ? 1u : 0u;
-                }
-                my_dep[slot & 3] = d;
-            }
-            __syncthreads();
-            slot = 0;
-            uint32_t any = 0;
-            for (uint32_t i = tid; i < nf; i += bd, ++slot) {
-                if (my_dep[slot & 3]) {
-                    s.e_fld[i] |= 0x80000000u;
-                    any = 1;
-                }
-            }
-            if (any) s.ctr[1] = 1;
-            __syncthreads();
-        }
+        const StageOut so = stage_example(p, s, geom, ex, tid, bd);
+        const uint32_t nf = so.nf, nl = so.nl;
+        const float label = so.label, imp = so.imp;
+        const bool do_update = so.do_update;
         FW_TICK(1);
 
         // ---------------- this wave's feature range [lo, hi): the fields f with floor(fstart[f]*nw/nf) == wave

@@ -123,6 +123,127 @@ int batch_alloc(fwgpu_regressor *r, uint32_t n, uint64_t n_lr, uint64_t n_ffm, f
     return FWGPU_OK;
 }
 
+static size_t up256b(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int record_batch_alloc(fwgpu_regressor *r, const fwgpu_translator_config *t, uint32_t n_cap, uint64_t words_cap,
+                       fwgpu_batch **out) {
+    int rc = check_translator(r, t);
+    if (rc) return rc;
+    if (t->n_fields > 255) return fail(FWGPU_ERR_INVALID, "translator: more than 255 fields");
+    std::unique_ptr<fwgpu_batch> b(new fwgpu_batch());
+    b->owner = r;
+    b->n = 0;
+    b->n_cap = n_cap;
+    b->words_cap = words_cap;
+    FWGPU_HIP(hipSetDevice(r->device));
+    size_t o = 0;
+    const size_t o_rec = o; o = up256b(o + 4 * words_cap);
+    const size_t o_off = o; o = up256b(o + 8 * ((size_t)n_cap + 1));
+    const size_t o_pred = o; o = up256b(o + 4 * (size_t)n_cap);
+    b->dev_bytes = std::max<size_t>(o, 256);
+    FWGPU_HIP(hipMalloc(&b->dev, b->dev_bytes));
+    unsigned char *base = static_cast<unsigned char *>(b->dev);
+    b->records = reinterpret_cast<uint32_t *>(base + o_rec);
+    b->rec_off = reinterpret_cast<uint64_t *>(base + o_off);
+    b->pred = reinterpret_cast<float *>(base + o_pred);
+    // translator blob: the (field, namespace) pairs are flattened in field order
+    const uint32_t ncm = t->n_combos ? t->combo_off[t->n_combos] : 0;
+    const uint32_t npr = (t->ffm_k && t->n_fields) ? t->field_off[t->n_fields] : 0;
+    std::vector<uint8_t> pair_field(npr);
+    for (uint32_t f = 0; f < t->n_fields && t->ffm_k; f++)
+        for (uint32_t m = t->field_off[f]; m < t->field_off[f + 1]; m++) pair_field[m] = (uint8_t)f;
+    size_t q = 0;
+    const size_t q_coff = q; q = up256b(q + 4 * ((size_t)t->n_combos + 1));
+    const size_t q_cns = q; q = up256b(q + 4 * (size_t)ncm);
+    const size_t q_cf32 = q; q = up256b(q + ncm);
+    const size_t q_cw = q; q = up256b(q + 4 * (size_t)t->n_combos);
+    const size_t q_pns = q; q = up256b(q + 4 * (size_t)npr);
+    const size_t q_pf32 = q; q = up256b(q + npr);
+    const size_t q_pfld = q; q = up256b(q + npr);
+    std::vector<unsigned char> blob(std::max<size_t>(q, 256), 0);
+    memcpy(blob.data() + q_coff, t->combo_off, 4 * ((size_t)t->n_combos + 1));
+    if (ncm) {
+        memcpy(blob.data() + q_cns, t->combo_ns, 4 * (size_t)ncm);
+        memcpy(blob.data() + q_cf32, t->combo_ns_f32, ncm);
+    }
+    if (t->n_combos) memcpy(blob.data() + q_cw, t->combo_weight, 4 * (size_t)t->n_combos);
+    if (npr) {
+        memcpy(blob.data() + q_pns, t->field_ns, 4 * (size_t)npr);
+        memcpy(blob.data() + q_pf32, t->field_ns_f32, npr);
+        memcpy(blob.data() + q_pfld, pair_field.data(), npr);
+    }
+    FWGPU_HIP(hipMalloc(&b->tr_dev, blob.size()));
+    FWGPU_HIP(hipMemcpy(b->tr_dev, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    unsigned char *tb = static_cast<unsigned char *>(b->tr_dev);
+    b->tr.combo_off = reinterpret_cast<const uint32_t *>(tb + q_coff);
+    b->tr.combo_ns = reinterpret_cast<const uint32_t *>(tb + q_cns);
+    b->tr.combo_f32 = reinterpret_cast<const uint8_t *>(tb + q_cf32);
+    b->tr.combo_w = reinterpret_cast<const float *>(tb + q_cw);
+    b->tr.pair_ns = reinterpret_cast<const uint32_t *>(tb + q_pns);
+    b->tr.pair_f32 = reinterpret_cast<const uint8_t *>(tb + q_pf32);
+    b->tr.pair_field = reinterpret_cast<const uint8_t *>(tb + q_pfld);
+    b->tr.n_combos = t->n_combos;
+    b->tr.n_pairs = npr;
+    b->tr.add_const = t->add_constant_feature ? 1 : 0;
+    b->tr.lr_mask = r->lr_hash_mask;
+    b->tr.ffm_mask = r->ffm_hash_mask;
+    *out = b.release();
+    return FWGPU_OK;
+}
+
+int count_records(const fwgpu_translator_config *t, const uint32_t *records, const uint64_t *rec_off, uint32_t n,
+                  RecordStats *st) {
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t len = (uint32_t)(rec_off[i + 1] - rec_off[i]);
+        uint32_t nl, nf;
+        int rc = count_record(t, records + rec_off[i], len, &nl, &nf);
+        if (rc) return rc;
+        st->max_lr = std::max(st->max_lr, nl);
+        st->max_ffm = std::max(st->max_ffm, nf);
+        st->max_rec = std::max(st->max_rec, len);
+        st->tot_lr += nl;
+        st->tot_ffm += nf;
+    }
+    return FWGPU_OK;
+}
+
+int record_batch_upload(fwgpu_batch *b, const fwgpu_translator_config *t, const uint32_t *records, const uint64_t *rec_off,
+                        uint32_t n, hipStream_t stream, const RecordStats *stats) {
+    if (!b->records) return fail(FWGPU_ERR_INVALID, "not a record batch");
+    const uint64_t words = n ? rec_off[n] - rec_off[0] : 0;
+    if (n > b->n_cap || words > b->words_cap) return fail(FWGPU_ERR_RANGE, "record batch larger than its allocation");
+    // validate + count on the host (slot words only, no hashing): sizes the kernel's LDS arrays
+    RecordStats st;
+    if (stats) {
+        st = *stats;
+    } else {
+        int rc = count_records(t, records, rec_off, n, &st);
+        if (rc) return rc;
+    }
+    const uint32_t max_lr = st.max_lr, max_ffm = st.max_ffm, max_rec = st.max_rec;
+    const uint64_t tot_lr = st.tot_lr, tot_ffm = st.tot_ffm;
+    if (n) {
+        FWGPU_HIP(hipMemcpyAsync(b->records, records + rec_off[0], words * 4, hipMemcpyHostToDevice, stream));
+        if (rec_off[0] == 0) {
+            FWGPU_HIP(hipMemcpyAsync(b->rec_off, rec_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, stream));
+        } else {
+            std::vector<uint64_t> rel((size_t)n + 1);
+            for (uint32_t i = 0; i <= n; i++) rel[i] = rec_off[i] - rec_off[0];
+            FWGPU_HIP(hipMemcpyAsync(b->rec_off, rel.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, stream));
+            FWGPU_HIP(hipStreamSynchronize(stream));
+        }
+    }
+    b->n = n;
+    b->n_lr = tot_lr;
+    b->n_ffm = tot_ffm;
+    b->n_words = words;
+    b->max_lr = b->owner->cfg.wiring == FWGPU_WIRING_FFM_ONLY ? 0 : max_lr;
+    b->max_ffm = max_ffm;
+    b->max_rec = max_rec;
+    b->aligned4 = true;  // hash & ffm_mask clears the low log2(next_pow2(k)) bits (feature_buffer.rs:141-148)
+    return FWGPU_OK;
+}
+
 int batch_upload(fwgpu_batch *b, const HostBatch &hb, hipStream_t stream) {
     const uint32_t n = hb.size();
     if (n > b->n || hb.ffm_hash.size() > b->n_ffm || hb.lr_hash.size() > b->n_lr)
@@ -177,6 +298,10 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
     p.ffm_rate = r->cfg.ffm_learning_rate;
     p.ffm_minus_power_t = -r->cfg.ffm_power_t;
     p.ticks = r->d_ticks;
+    p.records = b->records;
+    p.rec_off = b->rec_off;
+    p.max_rec = (b->max_rec + 3) & ~3u;
+    p.tr = b->tr;
     p.kernel_version = r->launch.kernel_version;
     return p;
 }
@@ -394,9 +519,28 @@ int fwgpu_batch_create(fwgpu_regressor *r, const fwgpu_lr_entry *lr, const uint3
     return FWGPU_OK;
 }
 
+int fwgpu_record_batch_create(fwgpu_regressor *r, const fwgpu_translator_config *t, const uint32_t *records,
+                              const uint64_t *rec_off, uint32_t n, fwgpu_batch **out) {
+    if (!r || !t || !out || (n && (!records || !rec_off))) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    fwgpu_batch *b = nullptr;
+    const uint64_t words = n ? rec_off[n] - rec_off[0] : 0;
+    int rc = record_batch_alloc(r, t, std::max<uint32_t>(n, 1), std::max<uint64_t>(words, 1), &b);
+    if (rc) return rc;
+    rc = record_batch_upload(b, t, records, rec_off, n, 0);
+    if (rc == FWGPU_OK && hipStreamSynchronize(0) != hipSuccess) rc = fail(FWGPU_ERR_DEVICE, "upload failed");
+    if (rc) {
+        fwgpu_batch_free(b);
+        return rc;
+    }
+    *out = b;
+    return FWGPU_OK;
+}
+
 int fwgpu_batch_free(fwgpu_batch *b) {
     if (!b) return FWGPU_OK;
     if (b->dev) (void)hipFree(b->dev);
+    if (b->tr_dev) (void)hipFree(b->tr_dev);
     delete b;
     return FWGPU_OK;
 }

@@ -1,10 +1,12 @@
-// HogwildTrainer replacement (hogwild.rs:13-103): records are translated on the host, packed into
-// micro-batches and run on the device in HOGWILD mode on an internal stream.  Two device batches are
-// used alternately so that translating/uploading micro-batch i+1 overlaps the kernel of micro-batch i.
+// HogwildTrainer replacement (hogwild.rs:13-103).  Records are copied as they are into a host staging buffer,
+// shipped to HBM in micro-batches and translated + learned on the device (the stage phase of the example kernel is
+// FeatureBufferTranslator::translate).  Two staging/device buffers alternate so that filling and uploading
+// micro-batch i+1 overlaps the kernel of micro-batch i.  The host only validates slot words (count_record).
 #include <string.h>
 
 #include <algorithm>
 #include <memory>
+#include <thread>
 
 #include "fwgpu_internal.h"
 
@@ -18,50 +20,57 @@ struct fwgpu_trainer {
     std::vector<uint8_t> combo_f32, field_f32;
     std::vector<float> combo_weight;
     fwgpu_translator_config t{};
-    HostBatch hb[2];
+    // raw record words of the micro-batch being filled, in PINNED host memory (H2D at PCIe rate, truly asynchronous)
+    uint32_t *rec[2] = {nullptr, nullptr};
+    uint64_t rec_used[2] = {0, 0}, rec_cap[2] = {0, 0};
+    std::vector<uint64_t> off[2];   // [n+1] word offsets
+    RecordStats stats[2];           // accumulated while the records are copied in
+    unsigned host_threads = 1;
     fwgpu_batch *dev[2] = {nullptr, nullptr};
     hipEvent_t done[2] = {nullptr, nullptr};
     bool in_flight[2] = {false, false};
     int cur = 0;
     hipStream_t stream = nullptr;
     uint64_t seen = 0;
-    std::vector<fwgpu_lr_entry> lr;
-    std::vector<fwgpu_ffm_entry> ffm;
 };
 
 static int flush(fwgpu_trainer *tr) {
     const int c = tr->cur;
-    HostBatch &hb = tr->hb[c];
-    const uint32_t n = hb.size();
+    const uint32_t n = (uint32_t)(tr->off[c].size() - 1);
     if (n == 0) return FWGPU_OK;
     fwgpu_regressor *r = tr->r;
     FWGPU_HIP(hipSetDevice(r->device));
-    // device batch c may still be read by its previous kernel
+    // device buffer c may still be read by its previous kernel
     if (tr->in_flight[c]) {
         FWGPU_HIP(hipEventSynchronize(tr->done[c]));
         tr->in_flight[c] = false;
     }
+    const uint64_t words = tr->rec_used[c];
     fwgpu_batch *b = tr->dev[c];
-    if (!b || b->n < n || b->n_lr < hb.lr_hash.size() || b->n_ffm < hb.ffm_hash.size()) {
+    if (!b || b->n_cap < n || b->words_cap < words) {
         if (b) fwgpu_batch_free(b);
         tr->dev[c] = nullptr;
-        int rc = batch_alloc(r, std::max(n, tr->micro_batch), hb.lr_hash.size() * 5 / 4 + 1024,
-                             hb.ffm_hash.size() * 5 / 4 + 1024, &tr->dev[c]);
+        int rc = record_batch_alloc(r, &tr->t, std::max(n, tr->micro_batch), words * 5 / 4 + 4096, &tr->dev[c]);
         if (rc) return rc;
         b = tr->dev[c];
     }
-    int rc = batch_upload(b, hb, tr->stream);
+    int rc = record_batch_upload(b, &tr->t, tr->rec[c], tr->off[c].data(), n, tr->stream, &tr->stats[c]);
     if (rc) return rc;
-    const uint32_t cap = b->n;
-    b->n = n;  // run only the filled part
     rc = fwgpu_learn_batch(r, b, FWGPU_MODE_HOGWILD, 1, tr->stream);
-    b->n = cap;
     if (rc) return rc;
     FWGPU_HIP(hipEventRecord(tr->done[c], tr->stream));
     tr->in_flight[c] = true;
-    // hipMemcpyAsync from pageable vectors has returned => the host staging can be reused
-    hb.clear();
+    // Staging buffer c stays untouched until its copies and kernel are done; switch to the other buffer, which may be
+    // refilled once ITS previous micro-batch has completed.
     tr->cur ^= 1;
+    const int c2 = tr->cur;
+    if (tr->in_flight[c2]) {
+        FWGPU_HIP(hipEventSynchronize(tr->done[c2]));
+        tr->in_flight[c2] = false;
+    }
+    tr->rec_used[c2] = 0;
+    tr->off[c2].assign(1, 0);
+    tr->stats[c2] = RecordStats();
     return FWGPU_OK;
 }
 
@@ -92,8 +101,9 @@ int fwgpu_trainer_create(fwgpu_regressor *r, const fwgpu_translator_config *t, u
     tr->t.field_off = tr->field_off.data();
     tr->t.field_ns = tr->field_ns.data();
     tr->t.field_ns_f32 = tr->field_f32.data();
-    tr->hb[0].clear();
-    tr->hb[1].clear();
+    tr->off[0].assign(1, 0);
+    tr->off[1].assign(1, 0);
+    tr->host_threads = std::max(1u, std::thread::hardware_concurrency());
     FWGPU_HIP(hipSetDevice(r->device));
     FWGPU_HIP(hipStreamCreateWithFlags(&tr->stream, hipStreamNonBlocking));
     FWGPU_HIP(hipEventCreateWithFlags(&tr->done[0], hipEventDisableTiming));
@@ -104,18 +114,51 @@ int fwgpu_trainer_create(fwgpu_regressor *r, const fwgpu_translator_config *t, u
 
 int fwgpu_digest_records(fwgpu_trainer *tr, const uint32_t *records, const uint64_t *rec_off, uint32_t n) {
     if (!tr || (n && (!records || !rec_off))) return fail(FWGPU_ERR_INVALID, "NULL argument");
-    for (uint32_t i = 0; i < n; i++) {
-        float label, imp;
-        const uint32_t len = (uint32_t)(rec_off[i + 1] - rec_off[i]);
-        int rc = translate_record(&tr->t, records + rec_off[i], len, tr->lr, tr->ffm, &label, &imp);
-        if (rc) return rc;
-        HostBatch &hb = tr->hb[tr->cur];
-        rc = append_example(tr->r, hb, tr->lr.data(), (uint32_t)tr->lr.size(), tr->ffm.data(), (uint32_t)tr->ffm.size(),
-                            label, imp);
-        if (rc) return rc;
-        tr->seen++;
-        if (hb.size() >= tr->micro_batch) {
-            rc = flush(tr);
+    uint32_t i = 0;
+    while (i < n) {
+        const int c = tr->cur;
+        const uint32_t have = (uint32_t)(tr->off[c].size() - 1);
+        const uint32_t take = std::min<uint32_t>(n - i, tr->micro_batch - have);
+        // the records are copied (main.rs:243 `Vec::from(buffer)`)
+        const uint64_t w0 = rec_off[i], w1 = rec_off[i + take];
+        const uint64_t base = tr->rec_used[c];
+        if (base + (w1 - w0) > tr->rec_cap[c]) {
+            const uint64_t ncap = std::max<uint64_t>((base + (w1 - w0)) * 3 / 2, 1u << 20);
+            uint32_t *nbuf = nullptr;
+            FWGPU_HIP(hipSetDevice(tr->r->device));
+            FWGPU_HIP(hipHostMalloc((void **)&nbuf, ncap * 4, hipHostMallocDefault));
+            if (base) memcpy(nbuf, tr->rec[c], base * 4);
+            if (tr->rec[c]) (void)hipHostFree(tr->rec[c]);
+            tr->rec[c] = nbuf;
+            tr->rec_cap[c] = ncap;
+        }
+        // copy into the pinned staging buffer and validate/count, on a few host threads for large slices
+        {
+            const unsigned T = take >= 4096 ? std::min<unsigned>(tr->host_threads, 8) : 1;
+            std::vector<RecordStats> st(T);
+            std::vector<int> rcs(T, FWGPU_OK);
+            std::vector<std::string> msgs(T);
+            auto work = [&](unsigned k) {
+                const uint32_t a = i + (uint32_t)((uint64_t)take * k / T), e = i + (uint32_t)((uint64_t)take * (k + 1) / T);
+                memcpy(tr->rec[c] + base + (rec_off[a] - w0), records + rec_off[a], (rec_off[e] - rec_off[a]) * 4);
+                rcs[k] = count_records(&tr->t, records, rec_off + a, e - a, &st[k]);
+                if (rcs[k]) msgs[k] = fwgpu_last_error();
+            };
+            std::vector<std::thread> th;
+            for (unsigned k = 1; k < T; k++) th.emplace_back(work, k);
+            work(0);
+            for (auto &x : th) x.join();
+            for (unsigned k = 0; k < T; k++) {
+                if (rcs[k]) return fail(rcs[k], msgs[k]);
+                tr->stats[c].merge(st[k]);
+            }
+        }
+        tr->rec_used[c] = base + (w1 - w0);
+        for (uint32_t j = 1; j <= take; j++) tr->off[c].push_back(base + (rec_off[i + j] - w0));
+        tr->seen += take;
+        i += take;
+        if (tr->off[c].size() - 1 >= tr->micro_batch) {
+            int rc = flush(tr);
             if (rc) return rc;
         }
     }
@@ -138,6 +181,7 @@ int fwgpu_trainer_free(fwgpu_trainer *tr) {
     if (tr->stream) (void)hipStreamSynchronize(tr->stream);
     for (int i = 0; i < 2; i++) {
         if (tr->dev[i]) fwgpu_batch_free(tr->dev[i]);
+        if (tr->rec[i]) (void)hipHostFree(tr->rec[i]);
         if (tr->done[i]) (void)hipEventDestroy(tr->done[i]);
     }
     if (tr->stream) (void)hipStreamDestroy(tr->stream);

@@ -95,6 +95,46 @@ int translate_record(const fwgpu_translator_config *t, const uint32_t *rec, uint
     return FWGPU_OK;
 }
 
+int count_record(const fwgpu_translator_config *t, const uint32_t *rec, uint32_t rec_len, uint32_t *n_lr, uint32_t *n_ffm) {
+    if (rec_len < kHeaderLen) return fail(FWGPU_ERR_FORMAT, "record shorter than its header");
+    auto cnt = [&](uint32_t ns, uint32_t *c) -> int {
+        if (ns + kHeaderLen >= rec_len) return fail(FWGPU_ERR_FORMAT, "record: namespace slot beyond the record");
+        const uint32_t w = rec[ns + kHeaderLen];
+        if ((w & kIsNotSingleMask) == 0) {
+            *c = 1;
+            return FWGPU_OK;
+        }
+        const uint32_t start = (w >> 16) & 0x3fff, end = w & 0xffff;
+        if (end < start || end > rec_len || ((end - start) & 1) || (end > start && start < kHeaderLen))
+            return fail(FWGPU_ERR_FORMAT, "record: malformed feature range");
+        *c = (end - start) / 2;
+        return FWGPU_OK;
+    };
+    uint64_t nl = 0, nf = 0;
+    for (uint32_t ci = 0; ci < t->n_combos; ci++) {
+        uint64_t prod = 1;
+        for (uint32_t m = t->combo_off[ci]; m < t->combo_off[ci + 1]; m++) {
+            uint32_t c;
+            int rc = cnt(t->combo_ns[m], &c);
+            if (rc) return rc;
+            prod *= c;
+        }
+        nl += prod;
+    }
+    if (t->add_constant_feature) nl++;
+    if (t->ffm_k > 0)
+        for (uint32_t m = 0; m < t->field_off[t->n_fields]; m++) {
+            uint32_t c;
+            int rc = cnt(t->field_ns[m], &c);
+            if (rc) return rc;
+            nf += c;
+        }
+    if (nl > 1000000 || nf > 1000000) return fail(FWGPU_ERR_RANGE, "record translates to too many entries");
+    *n_lr = (uint32_t)nl;
+    *n_ffm = (uint32_t)nf;
+    return FWGPU_OK;
+}
+
 int check_translator(const fwgpu_regressor *r, const fwgpu_translator_config *t) {
     if (!r || !t) return fail(FWGPU_ERR_INVALID, "NULL argument");
     if (t->bit_precision != r->cfg.bit_precision || t->ffm_k != r->cfg.ffm_k ||

@@ -262,6 +262,15 @@ class Regressor:
                                               rec_off.ctypes.data_as(C.c_void_p), len(rec_off) - 1, C.byref(h)))
         return Batch(self, h)
 
+    def record_batch(self, translator: FeatureBufferTranslator, records, rec_off) -> Batch:
+        """Raw records to HBM; translation happens on the device inside the example kernel."""
+        records = np.ascontiguousarray(records, dtype=np.uint32)
+        rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
+        h = C.c_void_p()
+        check(self.L.fwgpu_record_batch_create(self.h, C.byref(translator.c), ptr(records),
+                                               rec_off.ctypes.data_as(C.c_void_p), len(rec_off) - 1, C.byref(h)))
+        return Batch(self, h)
+
     def learn_batch(self, batch: Batch, mode=capi.MODE_SEQUENTIAL, update=True, stream=None):
         check(self.L.fwgpu_learn_batch(self.h, batch.h, mode, int(update), stream))
 

@@ -186,6 +186,12 @@ int fwgpu_translate(const fwgpu_translator_config *t, const uint32_t *record, ui
 int fwgpu_batch_from_records(fwgpu_regressor *r, const fwgpu_translator_config *t, const uint32_t *records,
                              const uint64_t *rec_off, uint32_t n, fwgpu_batch **out);
 
+/* Raw-record batch: the n records are copied to HBM as they are (4 x record_len bytes per example) and
+ * FeatureBufferTranslator::translate (feature_buffer.rs:174-338) runs INSIDE the example kernel's stage phase, so the host
+ * only validates the slot words.  Same results as fwgpu_batch_from_records, bit for bit. */
+int fwgpu_record_batch_create(fwgpu_regressor *r, const fwgpu_translator_config *t, const uint32_t *records,
+                              const uint64_t *rec_off, uint32_t n, fwgpu_batch **out);
+
 /* ---------------------------------------------------------------- HogwildTrainer replacement
  * fwgpu_trainer_create  <= HogwildTrainer::new(regressor, &model_instance, num_workers)  hogwild.rs:24-49
  * fwgpu_digest_records  <= HogwildTrainer::digest_example(Vec<u32>)                      hogwild.rs:51-53

@@ -61,30 +61,36 @@ def _stream_parity(n_ns, k, bits, ffm_bits, optimizer, n, mean_extra, p_weighted
     y = record_labels(recs, off)
     om = fwo.Model(ocfg)
     _, p_ref = om.run_stream(ots, recs, off, holdout_after=0, nthreads=1)
-    re = fw.Regressor(mi)
-    fbt = fw.FeatureBufferTranslator(mi)
-    b = re.batch_from_records(fbt, recs, off)
-    re.learn_batch(b, capi.MODE_SEQUENTIAL, True)
-    p_gpu = b.predictions()
-    d_ll = np.abs(logloss(p_gpu, y) - logloss(p_ref, y))
-    assert d_ll.max() < LOGLOSS_TOL, f"max per-example |d logloss| = {d_ll.max()} at {d_ll.argmax()}"
-    assert np.abs(p_gpu - p_ref).max() < 5e-5
-    # final tables: same state as the reference after the whole stream
-    # (weights are O(0.1); accumulators grow to O(100), hence the relative term)
-    def close(a, b):
-        return bool(np.all(np.abs(a - b) <= weight_tol + 1e-5 * np.abs(b)))
+    results = []
+    # both ways of feeding the device: entries translated on the host, and raw records translated inside the kernel
+    for kind in ("entries", "records"):
+        re = fw.Regressor(mi)
+        fbt = fw.FeatureBufferTranslator(mi)
+        b = re.batch_from_records(fbt, recs, off) if kind == "entries" else re.record_batch(fbt, recs, off)
+        re.learn_batch(b, capi.MODE_SEQUENTIAL, True)
+        p_gpu = b.predictions()
+        d_ll = np.abs(logloss(p_gpu, y) - logloss(p_ref, y))
+        assert d_ll.max() < LOGLOSS_TOL, f"{kind}: max per-example |d logloss| = {d_ll.max()} at {d_ll.argmax()}"
+        assert np.abs(p_gpu - p_ref).max() < 5e-5
+        # final tables: same state as the reference after the whole stream
+        # (weights are O(0.1); accumulators grow to O(100), hence the relative term)
+        def close(a, b_):
+            return bool(np.all(np.abs(a - b_) <= weight_tol + 1e-5 * np.abs(b_)))
 
-    assert close(re.table_read(capi.TABLE_LR), om.lr_table)
-    if k:
-        assert close(re.table_read(capi.TABLE_FFM_W), om.ffm_weights)
-        acc_g, acc_o = re.table_read(capi.TABLE_FFM_ACC), om.ffm_acc
-        assert close(acc_g, acc_o)
-        # exactly the same set of accumulators was touched
-        a0 = np.float32(mi.ffm_init_acc_gradient if optimizer == fw.Optimizer.AdagradFlex else 0.0)
-        assert np.array_equal(acc_g != a0, acc_o != a0)
-    b.close()
-    re.close()
-    return p_gpu, p_ref
+        assert close(re.table_read(capi.TABLE_LR), om.lr_table)
+        if k:
+            assert close(re.table_read(capi.TABLE_FFM_W), om.ffm_weights)
+            acc_g, acc_o = re.table_read(capi.TABLE_FFM_ACC), om.ffm_acc
+            assert close(acc_g, acc_o)
+            # exactly the same set of accumulators was touched
+            a0 = np.float32(mi.ffm_init_acc_gradient if optimizer == fw.Optimizer.AdagradFlex else 0.0)
+            assert np.array_equal(acc_g != a0, acc_o != a0)
+        results.append((p_gpu, [re.table_checksum(t) for t in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)]))
+        b.close()
+        re.close()
+    # device-side translation == host translation, bit for bit (hash indices and everything downstream)
+    assert np.array_equal(results[0][0], results[1][0]) and results[0][1] == results[1][1]
+    return results[0][0], p_ref
 
 
 def test_sequential_stream_config_b_like_with_collisions():
@@ -164,6 +170,52 @@ def test_batch_inference_matches_reference_predict():
     assert np.abs(b.predictions() - p_gpu).max() < PRED_TOL
     re.learn_batch(b, capi.MODE_HOGWILD, False)
     assert np.array_equal(b.predictions(), p_gpu)
+    re.close()
+
+
+def test_device_translation_of_crafted_records_matches_host_translation():
+    import struct
+
+    def f32b(x):
+        return struct.unpack("<I", struct.pack("<f", x))[0]
+
+    NS, NOF = 0x80000000, 0x80000000
+    ND = fw.NamespaceDescriptor
+    mi = fw.ModelInstance(
+        learning_rate=0.05, ffm_learning_rate=0.05, bit_precision=12, ffm_bit_precision=12, ffm_k=4,
+        optimizer=fw.Optimizer.AdagradLUT, ffm_init_acc_gradient=1.0, add_constant_feature=True,
+        feature_combo_descs=[fw.FeatureComboDesc([ND(0)]), fw.FeatureComboDesc([ND(0), ND(1)], 2.0),
+                             fw.FeatureComboDesc([ND(2, True)]), fw.FeatureComboDesc([ND(0), ND(1), ND(3)], 0.5)],
+        ffm_fields=[[ND(0)], [ND(0), ND(1)], [ND(3)], [ND(2, True)]])
+    recs = []
+    def rec(label, words):
+        r = [3 + 4 + 0, label, f32b(1.0)] + words
+        r[0] = len(r)
+        return r
+    # ns0: two weighted features, ns1: single, ns2 (f32): two, ns3: none
+    recs.append(rec(1, [NS | (7 << 16) | 11, 0x123, NS | (11 << 16) | 15, NOF, 0xfea, f32b(2.0), 0xfeb, f32b(3.0), 0x77, f32b(5.0), 0x78, f32b(7.0)]))
+    # everything single
+    recs.append(rec(0, [0x10, 0x20, 0x30, 0x40]))
+    # ns0 empty -> combos with ns0 vanish; ns3 three features
+    recs.append(rec(1, [NOF, 0x21, NOF, NS | (7 << 16) | 13, 0x1, f32b(1.0), 0x2, f32b(0.5), 0x3, f32b(0.25)]))
+    recs.append(rec(0, [NOF, NOF, NOF, NOF]))
+    flat = np.array([w for r in recs for w in r], dtype=np.uint32)
+    off = np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64)
+    fbt = fw.FeatureBufferTranslator(mi)
+    outs = []
+    for kind in ("entries", "records"):
+        re = fw.Regressor(mi)
+        b = re.batch_from_records(fbt, flat, off) if kind == "entries" else re.record_batch(fbt, flat, off)
+        for _ in range(3):
+            re.learn_batch(b, capi.MODE_SEQUENTIAL, True)
+        outs.append((b.predictions(), [re.table_checksum(t) for t in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)]))
+        re.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+    # malformed records are rejected on the host before anything reaches the device
+    re = fw.Regressor(mi)
+    bad = np.array(rec(1, [NS | (7 << 16) | 400, 0x1, 0x2, 0x3]), dtype=np.uint32)
+    with pytest.raises(capi.FwgpuError):
+        re.record_batch(fbt, bad, np.array([0, len(bad)], dtype=np.uint64))
     re.close()
 
 
