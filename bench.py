@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--threads", type=int, default=0, help="workgroup size override")
     ap.add_argument("--wgs-per-cu", dest="wgs", type=int, default=0)
     ap.add_argument("--sync-every", dest="sync_every", type=int, default=0, help="N>1: steps between delta all-reduces")
+    ap.add_argument("--blocking-sync", dest="blocking_sync", action="store_true",
+                    help="N>1: blocking delta all-reduce instead of the overlapped one")
     ap.add_argument("--force-dist", dest="force_dist", action="store_true",
                     help="run the RCCL replica-sync path even with one rank (smoke test of the N>1 code on one GPU)")
     ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
@@ -191,17 +193,20 @@ def main():
         from fwumious_wabbit_amd.dist_sync import DeltaAllReduce
 
         # zero-copy torch views of the library's tables; torch.distributed (RCCL) does the exchange
-        syncer = DeltaAllReduce([re.table_as_torch(w) for w in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)])
+        syncer = DeltaAllReduce([re.table_as_torch(w) for w in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)],
+                                overlap=not args.blocking_sync)
 
     def sync_replicas():
         # table <- snapshot + sum_r (table_r - snapshot): every replica ends with the same tables, having applied
-        # everyone's updates (runs on the same stream as the kernels)
-        syncer.sync()
+        # everyone's updates.  Overlapped mode: land the previous exchange, start the next; RCCL runs in the background
+        # while the following steps train.
+        syncer.step()
 
     for i in range(W):
         re.learn_batch(batches[i], capi.MODE_HOGWILD, True, sptr)
     if use_dist and W:
         sync_replicas()
+        syncer.finish()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -215,6 +220,8 @@ def main():
         ev[2 * i + 1].record(stream)
         if use_dist and (i + 1) % sync_every == 0:
             sync_replicas()
+    if use_dist:
+        syncer.finish()  # the exchange still in flight lands INSIDE the timed region
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -276,7 +283,7 @@ def main():
                 "global_batch": B * world,
                 "mode": "hogwild (device-wide concurrent examples, racy RMW, sc1 accesses)",
                 "parallelism": ("1 GPU" if not use_dist else
-                                f"dp{world}: replicas, RCCL delta all-reduce of {syncer.bytes_per_sync() / 1e9:.2f} GB every "
+                                f"dp{world}: replicas, {'blocking' if args.blocking_sync else 'overlapped'} RCCL delta all-reduce of {syncer.bytes_per_sync() / 1e9:.2f} GB every "
                                 f"{sync_every} steps ({syncer.n_syncs} syncs incl. warmup)"),
                 "holdout_examples": args.holdout,
                 "prep_seconds": prep_s,

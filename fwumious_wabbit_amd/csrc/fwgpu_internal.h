@@ -70,6 +70,7 @@ struct KernelParams {
     int32_t aligned4;          // every FFM row of the batch starts on a 16-byte boundary
     float lr_rate, lr_minus_power_t;    // SGD / AdagradFlex parameters of the LR block
     float ffm_rate, ffm_minus_power_t;  // ... of the FFM block
+    int32_t lut_global;                 // 1: AdaGrad LUT read from global memory (through L1) instead of an LDS copy
     int32_t kernel_version;             // 0 = auto, 1 = force the v1 kernel, 2 = v2 where applicable
     unsigned long long *ticks;          // optional [8] per-phase shader-clock accumulators (debug), else NULL
 };
@@ -78,6 +79,7 @@ struct LaunchConfig {
     uint32_t threads = 512;
     uint32_t workgroups_per_cu = 0;  // 0: as many as LDS allows (capped)
     int32_t kernel_version = 0;      // 0 = auto
+    int32_t lut_global = 0;
 };
 
 size_t example_kernel_lds_bytes(const KernelParams &p, int optimizer);
@@ -89,6 +91,8 @@ hipError_t launch_ffm_init(float *w, float *acc, uint64_t len, uint32_t k, float
 hipError_t launch_fill(float *p, uint64_t n, float v, hipStream_t stream);
 hipError_t launch_fill_lr(float *lr, uint64_t n_entries, float w, float acc, hipStream_t stream);
 hipError_t launch_checksum(const float *p, uint64_t n, unsigned long long *out, hipStream_t stream);
+hipError_t launch_delta_start(const float *t, const float *s0, float *d, float *D, uint64_t n, hipStream_t stream);
+hipError_t launch_delta_finish(float *t, float *s0, const float *d, const float *D, uint64_t n, hipStream_t stream);
 hipError_t launch_coherence_probe(unsigned *scratch, int use_sc1, unsigned iters, unsigned blocks, hipStream_t stream);
 
 }  // namespace fwgpu

@@ -446,7 +446,7 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
 
 size_t example_kernel_lds_bytes(const KernelParams &p, int optimizer) {
     size_t off[17];
-    return lds_layout(p.F, p.k, p.max_ffm, p.max_lr, optimizer == FWGPU_OPT_ADAGRAD_LUT && p.update,
+    return lds_layout(p.F, p.k, p.max_ffm, p.max_lr, optimizer == FWGPU_OPT_ADAGRAD_LUT && p.update && !p.lut_global,
                       p.records ? p.max_rec : 0, p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, off);
 }
 
@@ -515,7 +515,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
     constexpr int UG = 8;  // feature rows in flight per wave in the gather phase
     constexpr int UU = 4;  // feature rows in flight per wave in the update phase (x2 tables)
     extern __shared__ __align__(16) unsigned char smem[];
-    const bool use_lut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update;
+    const bool use_lut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global;
     size_t off[17];
     lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut, p.records ? p.max_rec : 0,
                p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, off);
@@ -552,6 +552,8 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
 
     if (use_lut)
         for (int i = tid; i < kLutSize; i += bd) s.lut[i] = p.lut_ffm[i];
+    else
+        s.lut = const_cast<float *>(p.lut_ffm);  // LUT read through L1 (the sc1 row traffic bypasses L1)
 
     // debug phase timing (thread 0 of every workgroup; all stamps sit right after a barrier or at a phase end)
     unsigned long long tk_last = 0, tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -824,7 +826,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel_r(const KernelParams p
     constexpr int AUX = COH ? kAuxSc1 : kAuxPlain;
     constexpr int UA = 4;  // accumulator rows in flight per wave in the update phase
     extern __shared__ __align__(16) unsigned char smem[];
-    const bool use_lut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update;
+    const bool use_lut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global;
     size_t off[17];
     lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut, p.records ? p.max_rec : 0,
                p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, off);
@@ -865,6 +867,8 @@ __global__ void __launch_bounds__(1024) fw_example_kernel_r(const KernelParams p
 
     if (use_lut)
         for (int i = tid; i < kLutSize; i += bd) s.lut[i] = p.lut_ffm[i];
+    else
+        s.lut = const_cast<float *>(p.lut_ffm);  // LUT read through L1 (the sc1 row traffic bypasses L1)
 
     unsigned long long tk_last = 0;
     const bool timing = p.ticks != nullptr && tid == 0;
@@ -1259,6 +1263,48 @@ hipError_t launch_checksum(const float *p, uint64_t n, unsigned long long *out, 
     return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------ replica delta bookkeeping (multi-GPU sync)
+// start : d = D = t - s0                    (D is then all-reduced in place over RCCL)
+// finish: s0 += D ; t += D - d              (others' updates land; local updates made meanwhile stay in t)
+__global__ void delta_start_kernel(const float *t, const float *s0, float *d, float *D, unsigned long long n) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i * 4 < n; i += stride) {
+        if (i * 4 + 4 <= n) {
+            const f4 x = reinterpret_cast<const f4 *>(t)[i] - reinterpret_cast<const f4 *>(s0)[i];
+            reinterpret_cast<f4 *>(d)[i] = x;
+            reinterpret_cast<f4 *>(D)[i] = x;
+        } else {
+            for (unsigned long long j = i * 4; j < n; ++j) d[j] = D[j] = t[j] - s0[j];
+        }
+    }
+}
+__global__ void delta_finish_kernel(float *t, float *s0, const float *d, const float *D, unsigned long long n) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i * 4 < n; i += stride) {
+        if (i * 4 + 4 <= n) {
+            const f4 Dv = reinterpret_cast<const f4 *>(D)[i];
+            const f4 others = Dv - reinterpret_cast<const f4 *>(d)[i];
+            reinterpret_cast<f4 *>(s0)[i] += Dv;
+            reinterpret_cast<f4 *>(t)[i] += others;
+        } else {
+            for (unsigned long long j = i * 4; j < n; ++j) {
+                s0[j] += D[j];
+                t[j] += D[j] - d[j];
+            }
+        }
+    }
+}
+hipError_t launch_delta_start(const float *t, const float *s0, float *d, float *D, uint64_t n, hipStream_t stream) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(delta_start_kernel, dim3(2048), dim3(256), 0, stream, t, s0, d, D, (unsigned long long)n);
+    return hipGetLastError();
+}
+hipError_t launch_delta_finish(float *t, float *s0, const float *d, const float *D, uint64_t n, hipStream_t stream) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(delta_finish_kernel, dim3(2048), dim3(256), 0, stream, t, s0, d, D, (unsigned long long)n);
+    return hipGetLastError();
+}
 
 // ------------------------------------------------------------------ cross-XCD visibility probe (debug / tests)
 // Block 0 publishes a 1 KiB payload (value = iteration number) with sc1 or plain stores, drains its stores and

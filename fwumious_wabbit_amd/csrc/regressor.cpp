@@ -303,6 +303,7 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
     p.max_rec = (b->max_rec + 3) & ~3u;
     p.tr = b->tr;
     p.kernel_version = r->launch.kernel_version;
+    p.lut_global = r->launch.lut_global;
     return p;
 }
 
@@ -441,6 +442,14 @@ int fwgpu_set_launch(fwgpu_regressor *r, uint32_t threads, uint32_t workgroups_p
     }
     r->launch.workgroups_per_cu = workgroups_per_cu;
     return FWGPU_OK;
+}
+
+int fwgpu_debug_set_option(fwgpu_regressor *r, int option, int value) {
+    if (!r) return fail(FWGPU_ERR_INVALID, "NULL regressor");
+    switch (option) {
+    case 1: r->launch.lut_global = value ? 1 : 0; return FWGPU_OK;
+    }
+    return fail(FWGPU_ERR_INVALID, "unknown debug option");
 }
 
 int fwgpu_debug_set_kernel_version(fwgpu_regressor *r, int version) {
@@ -657,6 +666,24 @@ int fwgpu_table_checksum(fwgpu_regressor *r, int which, uint64_t *checksum) {
     (void)hipFree(d);
     if (e != hipSuccess) return fail(FWGPU_ERR_DEVICE, std::string("checksum: ") + hipGetErrorString(e));
     *checksum = h;
+    return FWGPU_OK;
+}
+
+int fwgpu_delta_start(const void *table, const void *snapshot, void *local_delta, void *summed_delta, uint64_t n_floats,
+                      void *stream) {
+    if (!table || !snapshot || !local_delta || !summed_delta) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    FWGPU_HIP(launch_delta_start(static_cast<const float *>(table), static_cast<const float *>(snapshot),
+                                 static_cast<float *>(local_delta), static_cast<float *>(summed_delta), n_floats,
+                                 static_cast<hipStream_t>(stream)));
+    return FWGPU_OK;
+}
+
+int fwgpu_delta_finish(void *table, void *snapshot, const void *local_delta, const void *summed_delta, uint64_t n_floats,
+                       void *stream) {
+    if (!table || !snapshot || !local_delta || !summed_delta) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    FWGPU_HIP(launch_delta_finish(static_cast<float *>(table), static_cast<float *>(snapshot),
+                                  static_cast<const float *>(local_delta), static_cast<const float *>(summed_delta),
+                                  n_floats, static_cast<hipStream_t>(stream)));
     return FWGPU_OK;
 }
 

@@ -1,29 +1,42 @@
 """Data-parallel replica synchronisation over torch.distributed (RCCL on MI355X, gloo in the CPU tests).
 
-Every rank trains its own replica on its own shard of the stream.  `DeltaAllReduce.sync()` makes all replicas
-identical again by summing what each one changed since the last sync:
+Every rank trains its own replica on its own shard of the stream.  A sync makes every replica apply what the OTHER
+ranks changed since the last agreed snapshot `s0`:
 
-    table <- snapshot + sum_over_ranks(table_r - snapshot)
+    blocking :  d = t - s0 ; D = all_reduce(d) ; s0 <- s0 + D ; t <- s0
+    overlapped: start():  d = t - s0 ; launch all_reduce(D <- d) asynchronously; training continues on t
+                finish(): wait ; t <- t + (D - d) ; s0 <- s0 + D
 
-i.e. every replica ends up having applied every rank's updates (weights AND AdaGrad accumulators), with a staleness
-of `steps_between_syncs x batch x world_size` examples -- the multi-GPU analogue of hogwild.rs.  The tensors are
-zero-copy views of the library's tables (Regressor.table_as_torch); torch is only the plumbing here.
+With `u` = the local updates made while the all-reduce was in flight, `t = s0 + d + u` before finish() and
+`t = (s0 + D) + u` after it, so the next delta is exactly `u`: nothing is lost or applied twice.  Replicas agree up to their
+not-yet-synchronised local updates -- the multi-GPU analogue of hogwild.rs staleness (weights AND AdaGrad accumulators
+are summed).  The tensors are zero-copy views of the library's tables (Regressor.table_as_torch); torch is only plumbing.
+
+xGMI note: a ring all-reduce of the 4.3 GB of tables is bound by one link per hop; large buckets (256 MiB) amortise
+launch and ring latency, and the overlapped mode hides the transfer behind `sync_every` steps of training.
 """
 import torch
 import torch.distributed as dist
 
 
 class DeltaAllReduce:
-    def __init__(self, tables, bucket_elems=1 << 26, group=None):
-        """tables: list of 1-D float32 tensors (views of the regressor's tables); bucket_elems: all-reduce bucket
-        size in elements (2^26 floats = 256 MiB: large buckets amortise RCCL launch/ring latency over xGMI)."""
+    def __init__(self, tables, bucket_elems=1 << 26, group=None, overlap=False):
+        """tables: list of 1-D float32 tensors (views of the regressor's tables); bucket_elems: all-reduce bucket size in
+        elements (2^26 floats = 256 MiB); overlap: keep a delta buffer per table and run the all-reduce asynchronously."""
         self.tables = list(tables)
         self.snapshots = [t.clone() for t in self.tables]
         self.bucket = int(bucket_elems)
         self.group = group
+        self.overlap = bool(overlap)
         self.n_syncs = 0
+        self._local = [torch.empty_like(t) for t in self.tables] if overlap else None   # d (kept)
+        self._summed = [torch.empty_like(t) for t in self.tables] if overlap else None  # D (all-reduced in place)
+        self._works = None
 
+    # ---- blocking
     def sync(self):
+        if self._works is not None:
+            self.finish()
         for t, s0 in zip(self.tables, self.snapshots):
             for a in range(0, t.numel(), self.bucket):
                 b = min(a + self.bucket, t.numel())
@@ -32,6 +45,55 @@ class DeltaAllReduce:
                 s0[a:b] += d
                 t[a:b] = s0[a:b]
         self.n_syncs += 1
+
+    # ---- overlapped
+    def start(self):
+        assert self.overlap, "construct with overlap=True"
+        if self._works is not None:
+            self.finish()
+        works = []
+        for t, s0, d, D in zip(self.tables, self.snapshots, self._local, self._summed):
+            if t.is_cuda:  # one fused pass in the library instead of two torch passes
+                from . import _capi as capi
+
+                capi.check(capi.lib().fwgpu_delta_start(t.data_ptr(), s0.data_ptr(), d.data_ptr(), D.data_ptr(), t.numel(),
+                                                        torch.cuda.current_stream(t.device).cuda_stream))
+            else:
+                torch.sub(t, s0, out=d)
+                D.copy_(d)
+            for a in range(0, t.numel(), self.bucket):
+                b = min(a + self.bucket, t.numel())
+                works.append(dist.all_reduce(D[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._works = works
+
+    def in_flight(self):
+        return self._works is not None
+
+    def finish(self):
+        if self._works is None:
+            return
+        for w in self._works:
+            w.wait()
+        self._works = None
+        for t, s0, d, D in zip(self.tables, self.snapshots, self._local, self._summed):
+            if t.is_cuda:
+                from . import _capi as capi
+
+                capi.check(capi.lib().fwgpu_delta_finish(t.data_ptr(), s0.data_ptr(), d.data_ptr(), D.data_ptr(), t.numel(),
+                                                         torch.cuda.current_stream(t.device).cuda_stream))
+            else:
+                s0 += D          # new agreed snapshot
+                D -= d           # what the other ranks did
+                t += D           # local table keeps its own newer updates
+        self.n_syncs += 1
+
+    def step(self):
+        """One call per sync point: land the previous exchange (if any) and start the next one."""
+        if self.overlap:
+            self.finish()
+            self.start()
+        else:
+            self.sync()
 
     def bytes_per_sync(self):
         return sum(4 * t.numel() for t in self.tables)

@@ -213,6 +213,17 @@ int fwgpu_trainer_examples_seen(const fwgpu_trainer *tr, uint64_t *n);
  * 0 keeps the default.  Does not change results in SEQUENTIAL mode. */
 int fwgpu_set_launch(fwgpu_regressor *r, uint32_t threads, uint32_t workgroups_per_cu);
 
+/* ---------------------------------------------------------------- multi-GPU replica bookkeeping (device pointers)
+ * Data-parallel replicas exchange what each changed since the last agreed snapshot (replaces hogwild.rs's shared
+ * memory across GPUs; the all-reduce itself is RCCL via torch.distributed, see fwumious_wabbit_amd/dist_sync.py):
+ *   fwgpu_delta_start : local_delta = summed_delta = table - snapshot   (summed_delta is then all-reduced in place)
+ *   fwgpu_delta_finish: snapshot += summed_delta ; table += summed_delta - local_delta
+ * One fused pass each over n_floats elements, enqueued on `stream`. */
+int fwgpu_delta_start(const void *table, const void *snapshot, void *local_delta, void *summed_delta, uint64_t n_floats,
+                      void *stream);
+int fwgpu_delta_finish(void *table, void *snapshot, const void *local_delta, const void *summed_delta, uint64_t n_floats,
+                       void *stream);
+
 /* ---------------------------------------------------------------- diagnostics
  * Cross-XCD visibility probe for the access pattern the HOGWILD mode relies on: one workgroup publishes a
  * 1 KiB payload `iters` times (sc1 or plain stores), 15 workgroups spread over the XCDs re-read it (sc1 or
@@ -225,6 +236,8 @@ int fwgpu_set_launch(fwgpu_regressor *r, uint32_t threads, uint32_t workgroups_p
 int fwgpu_debug_phase_ticks(fwgpu_regressor *r, int enable, uint64_t *out8);
 /* 0 = automatic kernel choice, 1 = force the generic kernel (v1), 2 = register-resident rows (v2) where applicable. */
 int fwgpu_debug_set_kernel_version(fwgpu_regressor *r, int version);
+/* Tuning switches for experiments. option 1: value 1 = read the AdaGrad LUT from global memory instead of an LDS copy. */
+int fwgpu_debug_set_option(fwgpu_regressor *r, int option, int value);
 int fwgpu_debug_coherence_probe(int device, int use_sc1, uint32_t iters, uint32_t *stale_words, uint32_t *timeouts);
 
 /* ---------------------------------------------------------------- synthetic record streams

@@ -39,16 +39,11 @@ def run(threads, wgs, update=True, reps=6, label=""):
     br = " ".join(f"{n}={100*v/tot:.0f}%" for n, v in zip(names[:7], t[:7]))
     print(f"{label} threads={threads} wgs/cu={wgs or 'auto'} update={update}: {dt*1e3:.3f} ms/launch {B/dt/1e6:.2f} Mex/s | ticks/example={per_ex:.0f} | {br}", flush=True)
 
-for ver in (2, 1):
-    capi.check(L.fwgpu_debug_set_kernel_version(re.h, ver))
-    print(f"--- kernel v{ver}")
-    for th, w in ((1024, 1), (512, 2), (512, 1), (768, 1), (256, 4)):
+use_records = os.environ.get("RECORDS", "1") == "1"
+if use_records:
+    batches = [re.record_batch(fbt, recs[int(off[s*B]):int(off[(s+1)*B])], off[s*B:(s+1)*B+1] - off[s*B]) for s in range(NB)]
+for lutg in (0, 1):
+    capi.check(L.fwgpu_debug_set_option(re.h, 1, lutg))
+    print(f"--- kernel v2, lut_global={lutg}, records={use_records}")
+    for th, w in ((512, 2), (384, 2), (320, 3), (384, 3), (256, 4), (448, 2)):
         run(th, w)
-    run(1024, 1, update=False, label="predict"); run(512, 2, update=False, label="predict")
-
-
-print("--- v2, FFM only (LR block off)")
-mi2 = bench.build_model_instance(fw, args, 0); mi2.wiring = capi.WIRING_FFM_ONLY
-re = fw.Regressor(mi2); fbt2 = fw.FeatureBufferTranslator(mi2)
-batches = [re.batch_from_records(fbt2, recs[int(off[s*B]):int(off[(s+1)*B])], off[s*B:(s+1)*B+1] - off[s*B]) for s in range(NB)]
-run(512, 2, label="ffm_only"); run(1024, 1, label="ffm_only"); run(512, 2, update=False, label="ffm_only predict")

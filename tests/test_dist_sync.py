@@ -53,6 +53,54 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _worker_overlap(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    base = torch.linspace(-1, 1, 900)
+    t = base.clone()
+    sync = DeltaAllReduce([t], bucket_elems=256, overlap=True)
+    # the bookkeeping invariant: table == agreed snapshot + (all landed deltas of others already inside it) + local tail
+    total = base.clone()          # what a single sequential learner applying everyone's updates would hold
+    local_unsynced = torch.zeros(900)
+    landed_own = torch.zeros(900)
+    for step in range(4):
+        upd = torch.zeros(900)
+        upd[(step * 37 + rank * 101) % 900] = 0.25 * (rank + 1)
+        upd[(step * 11 + 5) % 900] += -0.5            # an index BOTH ranks touch
+        t += upd                                      # "training" between sync points
+        sync.step()                                   # lands the previous exchange, starts the next one
+        more = torch.zeros(900)
+        more[(step * 7 + rank) % 900] = 0.125         # updates made while the all-reduce is in flight
+        t += more
+        for r in range(world):
+            u2 = torch.zeros(900)
+            u2[(step * 37 + r * 101) % 900] = 0.25 * (r + 1)
+            u2[(step * 11 + 5) % 900] += -0.5
+            m2 = torch.zeros(900)
+            m2[(step * 7 + r) % 900] = 0.125
+            total += u2 + m2
+    sync.finish()      # land the last exchange
+    sync.step()        # exchange the remaining local tails ...
+    sync.finish()      # ... and land them: now every replica holds everything
+    assert torch.allclose(t, total, atol=1e-5), float((t - total).abs().max())
+    gathered = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t)
+    assert all(torch.allclose(gathered[0], x, atol=1e-6) for x in gathered)
+    assert torch.allclose(t, sync.snapshots[0], atol=1e-6)
+    out[rank] = sync.n_syncs
+    dist.destroy_process_group()
+
+
+def test_overlapped_delta_allreduce_world2_gloo():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_worker_overlap, args=(world, port, out), nprocs=world, join=True)
+        assert out[0] == out[1] == 5
+
+
 def test_delta_allreduce_world2_gloo():
     world = 2
     port = _free_port()

@@ -447,3 +447,40 @@ def test_full_size_config_c_properties():
             assert np.abs(re.table_read(capi.TABLE_FFM_ACC, h, 240) - om.ffm_acc[h:h + 240]).max() < 1e-4
     om.close()
     re.close()
+
+
+# ------------------------------------------------------------------ multi-GPU bookkeeping kernels
+def test_delta_kernels_match_torch_reference():
+    import torch
+
+    L = capi.lib()
+    for n in (1, 3, 4, 1027, 1 << 20):
+        g = torch.Generator(device="cpu").manual_seed(n)
+        t = torch.randn(n, generator=g).cuda()
+        s0 = torch.randn(n, generator=g).cuda()
+        d = torch.empty(n, device="cuda")
+        D = torch.empty(n, device="cuda")
+        t0, s00 = t.clone(), s0.clone()
+        st = torch.cuda.current_stream().cuda_stream
+        capi.check(L.fwgpu_delta_start(t.data_ptr(), s0.data_ptr(), d.data_ptr(), D.data_ptr(), n, st))
+        assert torch.equal(d, t0 - s00) and torch.equal(D, d)
+        D += 0.5  # "others" contributed 0.5 everywhere
+        t += 0.25  # local updates while the exchange was in flight
+        capi.check(L.fwgpu_delta_finish(t.data_ptr(), s0.data_ptr(), d.data_ptr(), D.data_ptr(), n, st))
+        torch.cuda.synchronize()
+        assert torch.allclose(s0, s00 + (t0 - s00) + 0.5, atol=1e-6)
+        assert torch.allclose(t, t0 + 0.25 + 0.5, atol=1e-6)
+
+
+def test_table_torch_view_is_zero_copy():
+    import torch
+
+    mi, _, _ = make_pair(4, 4, 10, 10, fw.Optimizer.AdagradLUT)
+    re = fw.Regressor(mi)
+    v = re.table_as_torch(capi.TABLE_FFM_W)
+    assert v.is_cuda and v.dtype == torch.float32 and v.numel() == re.table_len(capi.TABLE_FFM_W)
+    assert np.array_equal(v.cpu().numpy(), re.table_read(capi.TABLE_FFM_W))
+    v[5] = 42.0
+    torch.cuda.synchronize()
+    assert re.table_read(capi.TABLE_FFM_W, 5, 1)[0] == np.float32(42.0)
+    re.close()
