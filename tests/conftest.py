@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built artefacts: build them once (hipcc cross-compiles gfx950 without a GPU)
+    lib = os.path.join(ROOT, "fwumious_wabbit_amd", "lib", "libfwgpu.so")
+    if not os.path.exists(lib):
+        import __graft_entry__
+
+        __graft_entry__.build()
 
 
 def _have_gpu():

@@ -484,3 +484,15 @@ def test_table_torch_view_is_zero_copy():
     torch.cuda.synchronize()
     assert re.table_read(capi.TABLE_FFM_W, 5, 1)[0] == np.float32(42.0)
     re.close()
+
+
+# ------------------------------------------------------------------ the C++ host mirror, reference-style tests
+def test_cpp_host_mirror_reference_tests():
+    import subprocess
+
+    exe = os.path.join(ROOT, "host", "test_reference_kats")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "host")], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all 14 tests passed" in r.stdout
