@@ -122,6 +122,11 @@ struct fwo_model {
     uint64_t ffm_len; /* (1<<ffm_bits) + F*k, block_ffm.rs:92-94 */
     float *ffm_w, *ffm_acc; /* separate arrays, block_ffm.rs:40-41 */
     float lut_lr[FWO_LUT_SIZE], lut_ffm[FWO_LUT_SIZE];
+    /* deep head */
+    fwo_nn_config nn;
+    uint32_t nn_in[FWO_NN_MAX_LAYERS + 1], nn_out[FWO_NN_MAX_LAYERS + 1]; /* per layer incl. the final neuron */
+    float *nn_w[FWO_NN_MAX_LAYERS + 1], *nn_acc[FWO_NN_MAX_LAYERS + 1];
+    float lut_nn[FWO_LUT_SIZE];
     /* per-thread scratch lives on the caller's stack/heap: see fwo_scratch */
 };
 
@@ -174,6 +179,10 @@ void fwo_free(fwo_model *m) {
     free(m->lr);
     free(m->ffm_w);
     free(m->ffm_acc);
+    for (int l = 0; l <= FWO_NN_MAX_LAYERS; l++) {
+        free(m->nn_w[l]);
+        free(m->nn_acc[l]);
+    }
     free(m);
 }
 
@@ -181,6 +190,10 @@ void fwo_free(fwo_model *m) {
 static float initial_acc(int optimizer, float init_acc) {
     return optimizer == FWO_OPT_ADAGRAD_FLEX ? init_acc : 0.0f;
 }
+
+static void nn_init_weights(fwo_model *m);
+static float chain_nn(fwo_model *m, fwo_scratch *s, const fwo_lr_entry *lr, uint32_t n_lr, const fwo_ffm_entry *ffm,
+                      uint32_t n_ffm, float label, float importance, int update, int training_numerics);
 
 void fwo_init_weights(fwo_model *m) {
     const fwo_config *c = &m->cfg;
@@ -190,6 +203,7 @@ void fwo_init_weights(fwo_model *m) {
         m->lr[2 * i] = 0.0f;
         m->lr[2 * i + 1] = a0;
     }
+    if (m->nn.n_layers) nn_init_weights(m);
     if (!m->ffm_len) return;
     /* block_ffm.rs:784-829 */
     float fa0 = initial_acc(c->optimizer, c->ffm_init_acc_gradient);
@@ -523,6 +537,8 @@ static float chain_forward_backward(fwo_model *m, fwo_scratch *s, const fwo_lr_e
     const uint32_t F = c->ffm_num_fields;
     const int has_ffm = c->ffm_k > 0;
     float g, p;
+    if (m->nn.n_layers && c->wiring == FWO_WIRING_REGRESSOR)
+        return chain_nn(m, s, lr, n_lr, ffm, n_ffm, label, importance, update, 1);
     if (c->wiring == FWO_WIRING_FFM_ONLY) {
         ensure_grads(s, n_ffm * F * c->ffm_k);
         ffm_fb_forward(m, ffm, n_ffm, s);
@@ -557,6 +573,8 @@ static float chain_forward(const fwo_model *m, fwo_scratch *s, const fwo_lr_entr
                            const fwo_ffm_entry *ffm, uint32_t n_ffm) {
     const fwo_config *c = &m->cfg;
     const uint32_t F = c->ffm_num_fields;
+    if (m->nn.n_layers && c->wiring == FWO_WIRING_REGRESSOR)
+        return chain_nn((fwo_model *)m, s, lr, n_lr, ffm, n_ffm, 0.0f, 0.0f, 0, 0);
     if (c->wiring == FWO_WIRING_FFM_ONLY) {
         ffm_forward(m, ffm, n_ffm, s);
         return sigmoid_block(s->ffm_out, F * F, NULL, 0, 0.0f, 0.0f, NULL);
@@ -725,6 +743,208 @@ int fwo_translate(const fwo_translator *t, const uint32_t *rec, fwo_lr_entry *lr
     *n_lr_out = n_lr;
     *n_ffm_out = n_ffm;
     return 0;
+}
+
+
+/* ------------------------------------------------------------------ deep head (a18) */
+
+static uint32_t nn_x_len(const fwo_model *m) { /* the Join span: LR slots + triangle */
+    const uint32_t F = m->cfg.ffm_k ? m->cfg.ffm_num_fields : 0;
+    return m->cfg.num_combos + F * (F + 1) / 2;
+}
+
+int fwo_set_nn(fwo_model *m, const fwo_nn_config *nn) {
+    if (nn->n_layers == 0 || nn->n_layers > FWO_NN_MAX_LAYERS || (nn->topology != 1 && nn->topology != 2)) return -1;
+    m->nn = *nn;
+    uint32_t in = nn_x_len(m);
+    for (uint32_t l = 0; l < nn->n_layers; l++) {
+        m->nn_in[l] = in;
+        m->nn_out[l] = nn->width[l];
+        in = nn->width[l];
+    }
+    m->nn_in[nn->n_layers] = in + (nn->topology == 1 ? nn_x_len(m) : 0); /* Join(h_last, x copy), regressor.rs:307-311 */
+    m->nn_out[nn->n_layers] = 1;
+    for (uint32_t l = 0; l <= nn->n_layers; l++) {
+        const size_t len = ((size_t)m->nn_in[l] + 1) * m->nn_out[l];
+        free(m->nn_w[l]);
+        free(m->nn_acc[l]);
+        m->nn_w[l] = (float *)calloc(len, sizeof(float));
+        m->nn_acc[l] = (float *)calloc(len, sizeof(float));
+    }
+    fwo_lut_init(m->lut_nn, nn->nn_learning_rate, nn->nn_power_t, nn->nn_init_acc_gradient); /* block_neural.rs:111-112 */
+    return 0;
+}
+
+float *fwo_nn_weights(fwo_model *m, uint32_t layer, uint64_t *len) {
+    if (len) *len = ((uint64_t)m->nn_in[layer] + 1) * m->nn_out[layer];
+    return m->nn_w[layer];
+}
+float *fwo_nn_acc(fwo_model *m, uint32_t layer, uint64_t *len) {
+    if (len) *len = ((uint64_t)m->nn_in[layer] + 1) * m->nn_out[layer];
+    return m->nn_acc[layer];
+}
+
+static uint64_t nn_rng(uint64_t *s) { /* splitmix64 */
+    uint64_t z = (*s += 0x9e3779b97f4a7c15ULL);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+static double nn_u01(uint64_t *s) { return ((double)(nn_rng(s) >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+
+static void nn_init_weights(fwo_model *m) { /* block_neural.rs:367-424 (RNG stream: stand-in, see header) */
+    const float a0 = initial_acc(m->cfg.optimizer, m->nn.nn_init_acc_gradient);
+    for (uint32_t l = 0; l <= m->nn.n_layers; l++) {
+        const uint32_t in = m->nn_in[l], out = m->nn_out[l];
+        const size_t bias = (size_t)in * out, len = bias + out;
+        const uint32_t init = l == m->nn.n_layers ? FWO_NN_INIT_ONE : m->nn.init[l];
+        uint64_t st = 0x5eed0000ULL + 7919ULL * l + in + len;
+        for (size_t i = 0; i < bias; i++) {
+            float w;
+            switch (init) {
+            case FWO_NN_INIT_XAVIER: {
+                const double bound = sqrt(6.0) / sqrt((double)bias);
+                w = (float)((2.0 * nn_u01(&st) - 1.0) * bound);
+                break;
+            }
+            case FWO_NN_INIT_HU: {
+                const double u1 = nn_u01(&st), u2 = nn_u01(&st);
+                w = (float)(sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2) * sqrt(2.0 / (double)in));
+                break;
+            }
+            case FWO_NN_INIT_ONE: w = 1.0f; break;
+            default: w = 0.0f;
+            }
+            m->nn_w[l][i] = w;
+        }
+        for (size_t i = bias; i < len; i++) m->nn_w[l][i] = 0.0f; /* biases always zero, 419-422 */
+        for (size_t i = 0; i < len; i++) m->nn_acc[l][i] = a0;
+    }
+}
+
+/* block_neural.rs:196-222: y = bias; y += W x (sgemv 'T'); MKL's summation order is not observable, plain order here */
+static void nn_layer_forward(const float *w, uint32_t in, uint32_t out, const float *x, float *y) {
+    const float *bias = w + (size_t)in * out;
+    for (uint32_t j = 0; j < out; j++) {
+        float dot = 0.0f;
+        const float *wj = w + (size_t)j * in;
+        for (uint32_t i = 0; i < in; i++) dot += wj[i] * x[i];
+        y[j] = bias[j] + dot;
+    }
+}
+
+/* block_neural.rs:252-340 without dropout / max-norm / layer-norm (all off by default): per neuron j in order, per
+ * input i in order: AdaGrad step on W[j][i]; output_errors[i] += W_old[j][i] * gg; then the bias; finally the input
+ * tape is replaced by output_errors. */
+static void nn_layer_backward(int optimizer, float lr, float power_t, const float *lut, float *w, float *acc, uint32_t in,
+                              uint32_t out, float *x, const float *out_grad) {
+    float *oe = (float *)calloc(in ? in : 1, sizeof(float));
+    const size_t bias = (size_t)in * out;
+    for (uint32_t j = 0; j < out; j++) {
+        const float gg = out_grad[j] * 1.0f; /* dropout_inv == 1 */
+        if (gg == 0.0f) continue;
+        const size_t jo = (size_t)j * in;
+        for (uint32_t i = 0; i < in; i++) {
+            const float gradient = gg * x[i];
+            const float update = opt_step(optimizer, lr, power_t, lut, gradient, &acc[jo + i]);
+            oe[i] += w[jo + i] * gg;
+            w[jo + i] -= update;
+        }
+        const float update = opt_step(optimizer, lr, power_t, lut, gg * 1.0f, &acc[bias + j]);
+        w[bias + j] -= update;
+    }
+    memcpy(x, oe, sizeof(float) * in);
+    free(oe);
+}
+
+void fwo_neuron_layer_fb(int optimizer, float lr, float power_t, float init_acc, float *w, float *acc, uint32_t n_in,
+                         uint32_t n_out, float *x, float *y, const float *out_grad, int update) {
+    float lut[FWO_LUT_SIZE];
+    fwo_lut_init(lut, lr, power_t, init_acc);
+    nn_layer_forward(w, n_in, n_out, x, y);
+    if (update) nn_layer_backward(optimizer, lr, power_t, lut, w, acc, n_in, n_out, x, out_grad);
+}
+
+/* Whole chain with the deep head.  Tape order follows graph.rs:251-285; gradients flow as the recursion unwinds:
+ * sigmoid -> final neuron -> [ReLU -> layer]* -> Copy (sums both branches) -> Triangle mirror -> FFM update, LR update. */
+static float chain_nn(fwo_model *m, fwo_scratch *s, const fwo_lr_entry *lr, uint32_t n_lr, const fwo_ffm_entry *ffm,
+                      uint32_t n_ffm, float label, float importance, int update, int training_numerics) {
+    const fwo_config *c = &m->cfg;
+    const uint32_t F = c->ffm_k ? c->ffm_num_fields : 0, C = c->num_combos, T = F * (F + 1) / 2, X = C + T;
+    const uint32_t L = m->nn.n_layers;
+    float *x = (float *)malloc(sizeof(float) * (X + 1));
+    float *xc = (float *)malloc(sizeof(float) * (X + 1)); /* BlockCopy output 1 */
+    float *pre[FWO_NN_MAX_LAYERS], *post[FWO_NN_MAX_LAYERS];
+    lr_forward(m, lr, n_lr, s->lr_out);
+    if (F) {
+        if (training_numerics) {
+            ensure_grads(s, n_ffm * F * c->ffm_k);
+            ffm_fb_forward(m, ffm, n_ffm, s);
+        } else {
+            ffm_forward(m, ffm, n_ffm, s);
+        }
+        fwo_triangle_forward(s->ffm_out, F, s->tri);
+    }
+    memcpy(x, s->lr_out, sizeof(float) * C);
+    if (T) memcpy(x + C, s->tri, sizeof(float) * T);
+    memcpy(xc, x, sizeof(float) * X);
+    const float *h = x;
+    for (uint32_t l = 0; l < L; l++) {
+        pre[l] = (float *)malloc(sizeof(float) * m->nn_out[l]);
+        post[l] = (float *)malloc(sizeof(float) * m->nn_out[l]);
+        nn_layer_forward(m->nn_w[l], m->nn_in[l], m->nn_out[l], h, pre[l]);
+        for (uint32_t j = 0; j < m->nn_out[l]; j++) { /* block_relu.rs:38-54, 93-101 */
+            const float wv = pre[l][j];
+            if (m->nn.relu[l]) {
+                post[l][j] = wv < 0.0f ? 0.0f : wv;
+                pre[l][j] = wv < 0.0f ? 0.0f : 1.0f; /* the input slot now holds the 0/1 mask */
+            } else {
+                post[l][j] = wv;
+            }
+        }
+        h = post[l];
+    }
+    const uint32_t fin = m->nn_in[L];
+    float *fx = (float *)malloc(sizeof(float) * (fin + 1));
+    memcpy(fx, h, sizeof(float) * m->nn_out[L - 1]);
+    if (m->nn.topology == 1) memcpy(fx + m->nn_out[L - 1], xc, sizeof(float) * X);
+    float z;
+    nn_layer_forward(m->nn_w[L], fin, 1, fx, &z);
+    float g;
+    const float p = sigmoid_block(&z, 1, NULL, 0, label, importance, &g);
+    if (update) {
+        const int o = c->optimizer;
+        const float nlr = m->nn.nn_learning_rate, npt = m->nn.nn_power_t;
+        nn_layer_backward(o, nlr, npt, m->lut_nn, m->nn_w[L], m->nn_acc[L], fin, 1, fx, &g);
+        float *grad_h = fx; /* first width_last entries: gradient w.r.t. h_last */
+        for (int l = (int)L - 1; l >= 0; l--) {
+            float *og = (float *)malloc(sizeof(float) * m->nn_out[l]);
+            for (uint32_t j = 0; j < m->nn_out[l]; j++)
+                og[j] = m->nn.relu[l] ? pre[l][j] * grad_h[j] : grad_h[j]; /* block_relu.rs:105-110 */
+            float *in_vec = l == 0 ? x : post[l - 1];
+            nn_layer_backward(o, nlr, npt, m->lut_nn, m->nn_w[l], m->nn_acc[l], m->nn_in[l], m->nn_out[l], in_vec, og);
+            free(og);
+            grad_h = in_vec;
+        }
+        /* x now holds d/dx through the layers; BlockCopy sums the second branch (block_misc.rs:456-475) */
+        if (m->nn.topology == 1)
+            for (uint32_t i = 0; i < X; i++) x[i] += fx[m->nn_out[L - 1] + i];
+        for (uint32_t i = 0; i < C; i++) s->lr_out[i] = x[i];
+        if (F) {
+            for (uint32_t i = 0; i < T; i++) s->tri[i] = x[C + i];
+            fwo_triangle_backward(s->tri, F, s->ffm_out);
+            ffm_fb_update(m, ffm, n_ffm, s);
+        }
+        lr_update(m, lr, n_lr, s->lr_out);
+    }
+    for (uint32_t l = 0; l < L; l++) {
+        free(pre[l]);
+        free(post[l]);
+    }
+    free(fx);
+    free(x);
+    free(xc);
+    return p;
 }
 
 /* ------------------------------------------------------------------ stream runner */

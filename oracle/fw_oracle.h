@@ -98,6 +98,32 @@ float fwo_predict(fwo_model *m, const fwo_lr_entry *lr, uint32_t n_lr, const fwo
 float fwo_forward_backward(fwo_model *m, const fwo_lr_entry *lr, uint32_t n_lr, const fwo_ffm_entry *ffm,
                            uint32_t n_ffm, float label, float importance, int update);
 
+/* ---- deep head: BlockCopy (block_misc.rs:435-519), BlockNeuronLayer (block_neural.rs:196-340),
+ * BlockRELU (block_relu.rs:79-112), final single neuron InitType::One (regressor.rs:312-319).
+ * topology 1 = "one" (default, model_instance.rs:42): x = [LR slots, triangle]; h = relu(W x + b) ... ;
+ *                logit = w_f . [h_last, x] + b_f ;  topology 2 = "two": logit = w_f . h_last + b_f (no copy/join).
+ * Hidden-layer init Hu / Xavier draws from rand_xoshiro + rand_distr in the reference (block_neural.rs:385-406):
+ * PARITY UNPINNED (third-party RNG/ziggurat, no reference test observes a value); the oracle uses its own
+ * deterministic N(0, sqrt(2/in)) / U(+-sqrt(6/(in*out))) stand-in and tests load identical weights on both sides. */
+#define FWO_NN_MAX_LAYERS 8
+enum { FWO_NN_INIT_XAVIER = 0, FWO_NN_INIT_HU = 1, FWO_NN_INIT_ONE = 2, FWO_NN_INIT_ZERO = 3 };
+typedef struct {
+    uint32_t n_layers;                  /* hidden layers (the final 1-neuron layer is implied) */
+    uint32_t width[FWO_NN_MAX_LAYERS];
+    uint32_t relu[FWO_NN_MAX_LAYERS];   /* activation: 1 relu, 0 none */
+    uint32_t init[FWO_NN_MAX_LAYERS];
+    uint32_t topology;                  /* 1 = "one", 2 = "two" */
+    float nn_learning_rate, nn_power_t, nn_init_acc_gradient;
+} fwo_nn_config;
+int fwo_set_nn(fwo_model *m, const fwo_nn_config *nn);  /* call before fwo_init_weights */
+/* layer 0..n_layers-1 = hidden, n_layers = final neuron; weights are [(in+1)*out]: W[j*in+i], biases at in*out+j */
+float *fwo_nn_weights(fwo_model *m, uint32_t layer, uint64_t *len);
+float *fwo_nn_acc(fwo_model *m, uint32_t layer, uint64_t *len);
+/* one BlockNeuronLayer forward_backward with upstream gradient `out_grad` (block_neural.rs:252-340), for its KATs:
+ * writes outputs to y, replaces x by the input gradients when update != 0 */
+void fwo_neuron_layer_fb(int optimizer, float lr, float power_t, float init_acc, float *w, float *acc, uint32_t n_in,
+                         uint32_t n_out, float *x, float *y, const float *out_grad, int update);
+
 /* ---- block_misc.rs:742-884 Triangle (exposed for its KAT) ---- */
 void fwo_triangle_forward(const float *in, uint32_t width, float *out);
 void fwo_triangle_backward(const float *gout, uint32_t width, float *gin);

@@ -39,6 +39,33 @@ class Config(C.Structure):
     ]
 
 
+NN_INIT = {"xavier": 0, "hu": 1, "one": 2, "zero": 3}
+
+
+class NNConfig(C.Structure):
+    _fields_ = [
+        ("n_layers", C.c_uint32),
+        ("width", C.c_uint32 * 8),
+        ("relu", C.c_uint32 * 8),
+        ("init", C.c_uint32 * 8),
+        ("topology", C.c_uint32),
+        ("nn_learning_rate", C.c_float),
+        ("nn_power_t", C.c_float),
+        ("nn_init_acc_gradient", C.c_float),
+    ]
+
+
+def make_nn_config(layers, topology="one", nn_learning_rate=0.02, nn_power_t=0.45, nn_init_acc_gradient=0.0):
+    """layers: list of (width, activation 'relu'|'none', init 'hu'|'xavier'|'one'|'zero')."""
+    c = NNConfig()
+    c.n_layers = len(layers)
+    for i, (w, act, init) in enumerate(layers):
+        c.width[i], c.relu[i], c.init[i] = w, int(act == "relu"), NN_INIT[init]
+    c.topology = {"one": 1, "two": 2}[topology]
+    c.nn_learning_rate, c.nn_power_t, c.nn_init_acc_gradient = nn_learning_rate, nn_power_t, nn_init_acc_gradient
+    return c
+
+
 class Translator(C.Structure):
     _fields_ = [
         ("n_combos", C.c_uint32),
@@ -105,6 +132,13 @@ def lib(native=False):
     L.fwo_forward_backward.argtypes = ex + [C.c_float, C.c_float, C.c_int]
     L.fwo_predict.restype = C.c_float
     L.fwo_predict.argtypes = ex
+    L.fwo_set_nn.restype = C.c_int
+    L.fwo_set_nn.argtypes = [vp, C.POINTER(NNConfig)]
+    for fn in ("fwo_nn_weights", "fwo_nn_acc"):
+        getattr(L, fn).restype = f32p
+        getattr(L, fn).argtypes = [vp, C.c_uint32, u64p]
+    L.fwo_neuron_layer_fb.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, f32p, f32p, C.c_uint32, C.c_uint32, f32p,
+                                      f32p, f32p, C.c_int]
     L.fwo_triangle_forward.argtypes = [f32p, C.c_uint32, f32p]
     L.fwo_triangle_backward.argtypes = [f32p, C.c_uint32, f32p]
     L.fwo_lr_hash_mask.restype = C.c_uint32
@@ -193,12 +227,15 @@ class TranslatorSpec:
 
 
 class Model:
-    def __init__(self, cfg, init=True, native=False):
+    def __init__(self, cfg, init=True, native=False, nn=None):
         self.L = lib(native)
         self.cfg = cfg
         self.h = self.L.fwo_create(C.byref(cfg))
         if not self.h:
             raise ValueError("fwo_create failed (k*F^2 > 41472?)")
+        self.nn = nn
+        if nn is not None and self.L.fwo_set_nn(self.h, C.byref(nn)) != 0:
+            raise ValueError("fwo_set_nn failed")
         if init:
             self.L.fwo_init_weights(self.h)
 
@@ -232,6 +269,16 @@ class Model:
     @property
     def ffm_acc(self):
         return self._view("fwo_ffm_acc")
+
+    def nn_weights(self, layer):
+        n = C.c_uint64(0)
+        p = self.L.fwo_nn_weights(self.h, layer, C.byref(n))
+        return np.ctypeslib.as_array(p, shape=(n.value,))
+
+    def nn_acc(self, layer):
+        n = C.c_uint64(0)
+        p = self.L.fwo_nn_acc(self.h, layer, C.byref(n))
+        return np.ctypeslib.as_array(p, shape=(n.value,))
 
     def lut(self, which="lr"):
         p = (self.L.fwo_lut_lr if which == "lr" else self.L.fwo_lut_ffm)(self.h)

@@ -154,3 +154,54 @@ def test_merand48_properties():
     bound = 0.5 / np.sqrt(4.0) / 50.0
     assert np.abs(w).max() <= bound + 1e-9 and np.abs(w).max() > 0.5 * bound
     assert np.all(m.ffm_acc == 0.0)
+
+
+# ------------------------------------------------------------------ deep head (a18)
+def _layer_fb(opt, lr, w, acc, x, out_grad, n_in, n_out, update=True):
+    L = fwo.lib()
+    fp = C.POINTER(C.c_float)
+    y = np.zeros(n_out, dtype=np.float32)
+    L.fwo_neuron_layer_fb(opt, lr, 0.0, 0.0, w.ctypes.data_as(fp), acc.ctypes.data_as(fp), n_in, n_out,
+                          x.ctypes.data_as(fp), y.ctypes.data_as(fp), out_grad.ctypes.data_as(fp), int(update))
+    return y
+
+
+def test_neuron_layer_kats():
+    # block_neural.rs:507-537 test_simple: SGD lr 0.1, One-init (w=1, bias=0), input 2.0, upstream gradient 1.0
+    w, acc = np.array([1.0, 0.0], dtype=np.float32), np.zeros(2, dtype=np.float32)
+    x = np.array([2.0], dtype=np.float32)
+    assert abs(_layer_fb(fwo.OPT_SGD, 0.1, w, acc, x, np.ones(1, np.float32), 1, 1)[0] - 2.0) < 5e-6
+    x = np.array([2.0], dtype=np.float32)
+    assert abs(_layer_fb(fwo.OPT_SGD, 0.1, w, acc, x, np.ones(1, np.float32), 1, 1)[0] - 1.5) < 5e-6
+    # block_neural.rs:539-581 test_two_neurons: both neurons output 2.0, then 1.5 with update=false
+    w, acc = np.array([1.0, 1.0, 0.0, 0.0], dtype=np.float32), np.zeros(4, dtype=np.float32)
+    x = np.array([2.0], dtype=np.float32)
+    y = _layer_fb(fwo.OPT_SGD, 0.1, w, acc, x, np.ones(2, np.float32), 1, 2)
+    assert y.tolist() == [2.0, 2.0]
+    assert x[0] == 2.0  # "on tape 0 input of 2.0 will be replaced with the gradient of 2.0" (1*1 + 1*1)
+    x = np.array([2.0], dtype=np.float32)
+    y = _layer_fb(fwo.OPT_SGD, 0.1, w, acc, x, np.ones(2, np.float32), 1, 2, update=False)
+    assert abs(y[0] - 1.5) < 5e-6 and abs(y[1] - 1.5) < 5e-6
+
+
+def test_deep_head_reduces_to_plain_regressor_when_transparent():
+    """Structural check of the a18 wiring: with topology 'one', a hidden layer of zero weights and the final neuron's
+    One-init (regressor.rs:312-319), the logit is 0*h + 1*x summed = the plain LR+FFM logit, so the first prediction
+    equals the plain regressor's; and learning then changes the head's weights."""
+    cfgk = dict(optimizer=fwo.OPT_ADAGRAD_LUT, learning_rate=0.1, ffm_learning_rate=0.1, bit_precision=10,
+                num_combos=3, ffm_k=4, ffm_bit_precision=10, ffm_num_fields=3, ffm_init_acc_gradient=1.0)
+    lr = fwo.lr_entries([(5, 1.0, 0), (9, 2.0, 1), (11650396 & 1023, 1.0, 2)])
+    ffm = fwo.ffm_entries([(8, 1.0, 0), (40, 2.0, 4), (100, 1.0, 8)])
+    plain = fwo.Model(fwo.make_config(**cfgk))
+    plain.lr_table[:] = np.linspace(-0.3, 0.3, plain.lr_table.size, dtype=np.float32)
+    nn = fwo.make_nn_config([(6, "relu", "zero")], topology="one", nn_learning_rate=0.05, nn_power_t=0.0)
+    deep = fwo.Model(fwo.make_config(**cfgk), nn=nn)
+    deep.lr_table[:] = plain.lr_table
+    assert np.array_equal(deep.ffm_weights, plain.ffm_weights)
+    p0 = plain.predict(lr, ffm)
+    assert abs(deep.predict(lr, ffm) - p0) < 1e-6
+    assert abs(deep.learn(lr, ffm, 1.0, 1.0, True) - p0) < 1e-6
+    assert deep.nn_weights(1).size == 6 + (3 + 6) + 1  # final neuron: h(6) + x(3 combos + 6 triangle) + bias
+    assert not np.all(deep.nn_weights(1)[:-1] == 1.0)   # the One-initialised final neuron has learned
+    p1 = deep.predict(lr, ffm)
+    assert p1 > p0                                       # label 1: the prediction moved up
