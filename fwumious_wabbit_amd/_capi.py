@@ -16,7 +16,8 @@ OK = 0
 OPT_SGD, OPT_ADAGRAD_FLEX, OPT_ADAGRAD_LUT = 100, 200, 300
 WIRING_REGRESSOR, WIRING_FFM_ONLY = 0, 1
 MODE_SEQUENTIAL, MODE_HOGWILD = 0, 1
-TABLE_LR, TABLE_FFM_W, TABLE_FFM_ACC = 0, 1, 2
+TABLE_LR, TABLE_FFM_W, TABLE_FFM_ACC, TABLE_NN_W, TABLE_NN_ACC = 0, 1, 2, 3, 4
+NN_INIT = {"xavier": 0, "hu": 1, "one": 2, "zero": 3}
 
 LR_ENTRY = np.dtype([("hash", "<u4"), ("value", "<f4"), ("combo_index", "<u4")])
 FFM_ENTRY = np.dtype([("hash", "<u4"), ("value", "<f4"), ("contra_field_index", "<u4")])
@@ -41,6 +42,19 @@ class Config(C.Structure):
         ("ffm_init_zero_band", C.c_float),
         ("wiring", C.c_int32),
         ("device", C.c_int32),
+    ]
+
+
+class NNConfig(C.Structure):
+    _fields_ = [
+        ("n_layers", C.c_uint32),
+        ("width", C.c_uint32 * 8),
+        ("relu", C.c_uint32 * 8),
+        ("init", C.c_uint32 * 8),
+        ("topology", C.c_uint32),
+        ("nn_learning_rate", C.c_float),
+        ("nn_power_t", C.c_float),
+        ("nn_init_acc_gradient", C.c_float),
     ]
 
 
@@ -99,6 +113,7 @@ def lib():
         "fwgpu_create": [P(Config), P(vp)],
         "fwgpu_free": [vp],
         "fwgpu_init_weights": [vp],
+        "fwgpu_set_nn": [vp, P(NNConfig)],
         "fwgpu_learn": [vp, vp, u32, vp, u32, f32, f32, i32, P(f32)],
         "fwgpu_predict": [vp, vp, u32, vp, u32, P(f32)],
         "fwgpu_serialized_len": [vp, P(u64)],

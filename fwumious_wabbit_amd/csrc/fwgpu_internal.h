@@ -37,6 +37,22 @@ struct DevTranslator {
     uint32_t n_combos, n_pairs, add_const, lr_mask, ffm_mask;
 };
 
+// Deep head: BlockCopy -> [BlockNeuronLayer -> BlockRELU]* -> Join -> single neuron (regressor.rs:191-320)
+constexpr int kNnMaxLayers = 8;
+struct DevNN {
+    uint32_t n_layers;  // hidden layers; 0 = no deep head
+    uint32_t topology;  // 1 = "one" (final neuron sees [h_last, x]), 2 = "two" (h_last only)
+    uint32_t in[kNnMaxLayers + 1], out[kNnMaxLayers + 1], off[kNnMaxLayers + 1];  // per layer incl. the final neuron;
+                                                                                   // off = float offset into w / acc
+    uint32_t relu[kNnMaxLayers];
+    uint32_t X;          // length of x = LR slots + triangle
+    uint32_t sum_width;  // sum of the hidden widths
+    uint32_t max_in;     // largest layer input (LDS scratch)
+    float rate, minus_power_t;
+    float *w, *acc;      // all layers back to back: per layer W[j*in+i] then the biases (block_neural.rs:86-88)
+    const float *lut;
+};
+
 // Everything the example kernel needs, passed by value.
 struct KernelParams {
     // ---- tables (HBM) ----
@@ -53,6 +69,7 @@ struct KernelParams {
     const uint32_t *lr_hash;
     const float *lr_val;
     const uint32_t *lr_off;  // [n+1]
+    const uint16_t *lr_combo;  // combo slot of each LR entry (only read when the deep head is on)
     const float *label;
     const float *importance;
     float *pred;
@@ -62,6 +79,8 @@ struct KernelParams {
     const uint64_t *rec_off;  // [n+1] u32-word offsets
     uint32_t max_rec;         // longest record of the batch, in words (LDS capacity)
     DevTranslator tr;
+    DevNN nn;
+    uint32_t num_combos;
     // ---- model ----
     uint32_t F, k, R;          // fields, ffm_k, R = F*k (row length in floats)
     uint32_t max_ffm, max_lr;  // LDS capacities for one example's entries
@@ -113,6 +132,7 @@ struct fwgpu_batch {
     uint32_t *lr_hash = nullptr;
     float *lr_val = nullptr;
     uint32_t *lr_off = nullptr;
+    uint16_t *lr_combo = nullptr;
     float *label = nullptr;
     float *importance = nullptr;
     float *pred = nullptr;
@@ -139,6 +159,11 @@ struct fwgpu_regressor {
     uint32_t lr_hash_mask = 0, ffm_hash_mask = 0;
     fwgpu::LaunchConfig launch;
     unsigned long long *d_ticks = nullptr;  // debug phase timing, see fwgpu_debug_phase_ticks
+    // deep head
+    fwgpu::DevNN nn{};
+    fwgpu_nn_config nn_cfg{};
+    float *d_nn_w = nullptr, *d_nn_acc = nullptr, *d_lut_nn = nullptr;
+    uint64_t nn_len = 0;
     // scratch for single-example calls
     fwgpu_batch *one = nullptr;
     void *pinned = nullptr;
@@ -151,6 +176,7 @@ struct HostBatch {  // SoA staging of a CSR batch on the host
     std::vector<uint32_t> ffm_hash, ffm_off, lr_hash, lr_off;
     std::vector<float> ffm_val, lr_val, label, importance;
     std::vector<uint8_t> ffm_fld;
+    std::vector<uint16_t> lr_combo;
     uint32_t max_lr = 0, max_ffm = 0;
     bool aligned4 = true;
     void clear();

@@ -145,10 +145,19 @@ struct Lds {
     uint32_t *set_lr;         // open-addressing set of LR hashes (duplicate pre-filter)
     uint32_t *rec;            // raw record staged for device-side translation (max_rec words)
     uint32_t *tcnt;           // per (field,namespace) pair and per combo: entry count, then exclusive offset
+    uint32_t *l_combo;        // combo slot of each LR entry (deep head only)
+    float *nn;                // deep-head scratch: x[X], xg[X], h[sum_width], m[sum_width], l_prod[max_lr]
     uint32_t *ctr;            // 8
 };
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// LDS floats the deep head needs: x and its gradient, activations and masks of every hidden layer, the final neuron's
+// input gradient, and one product per LR entry
+__host__ __device__ inline uint32_t nn_lds_floats(const KernelParams &p) {
+    if (!p.nn.n_layers) return 0;
+    return 2 * p.nn.X + 2 * p.nn.sum_width + p.nn.max_in + p.max_lr + 16;
+}
 
 // size of the open-addressing sets: power of two >= 2*n (load factor <= 0.5)
 __host__ __device__ inline uint32_t set_size(uint32_t n) {
@@ -183,7 +192,7 @@ __device__ __forceinline__ bool set_contains(const uint32_t *tab, uint32_t mask,
 }
 
 __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t max_ffm, uint32_t max_lr, bool lut,
-                                             uint32_t max_rec, uint32_t tr_items, size_t *off /*[17]*/) {
+                                             uint32_t max_rec, uint32_t tr_items, uint32_t nn_floats, size_t *off /*[19]*/) {
     size_t o = 0;
     size_t R = (size_t)F * k;
     off[0] = o; o = align16(o + 4 * F * R);
@@ -203,6 +212,8 @@ __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t ma
     off[14] = o; o = align16(o + 4 * (size_t)set_size(max_lr));
     off[15] = o; o = align16(o + 4 * (size_t)max_rec);
     off[16] = o; o = align16(o + 4 * (size_t)tr_items);
+    off[17] = o; o = align16(o + (nn_floats ? 4 * (size_t)max_lr : 0));
+    off[18] = o; o = align16(o + 4 * (size_t)nn_floats);
     return o;
 }
 
@@ -297,6 +308,7 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
         for (uint32_t i = tid; i < o.nl; i += bd) {
             s.l_hash[i] = p.lr_hash[lo + i];
             s.l_val[i] = p.lr_val[lo + i];
+            if (p.nn.n_layers) s.l_combo[i] = p.lr_combo[lo + i];
         }
         __syncthreads();
     } else {
@@ -368,6 +380,7 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
                         }
                         s.l_hash[base + idx] = hash & t.lr_mask;
                         s.l_val[base + idx] = val * cw;
+                        if (p.nn.n_layers) s.l_combo[base + idx] = c;
                     }
                 }
                 carry += (uint32_t)__shfl((int)inc, 63, 64);
@@ -376,6 +389,7 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
                 if (lane == 0) {
                     s.l_hash[carry] = 11650396u & t.lr_mask;
                     s.l_val[carry] = 1.0f;
+                    if (p.nn.n_layers) s.l_combo[carry] = NC;
                 }
                 carry += 1;
             }
@@ -445,16 +459,209 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
 }
 
 size_t example_kernel_lds_bytes(const KernelParams &p, int optimizer) {
-    size_t off[17];
+    size_t off[19];
     return lds_layout(p.F, p.k, p.max_ffm, p.max_lr, optimizer == FWGPU_OPT_ADAGRAD_LUT && p.update && !p.lut_global,
-                      p.records ? p.max_rec : 0, p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, off);
+                      p.records ? p.max_rec : 0, p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), off);
+}
+
+
+// ------------------------------------------------------------------ deep head (a18), per-example reference semantics
+struct NnBuf {
+    float *x;    // [X]  inputs: LR slots then triangle (the Join span); BlockCopy output 1 (kept as values)
+    float *xg;   // [X]  d logit / d x : through the layers + (topology "one") the final neuron's direct part
+    float *h;    // [sum_width] post-activation outputs of the hidden layers
+    float *m;    // [sum_width] ReLU 0/1 masks, then the layers' output gradients
+    float *fg;   // [max_in] final neuron's input gradient / per-layer scratch
+    float *prod; // [max_lr] w*v of every LR entry
+};
+__device__ __forceinline__ NnBuf nn_buf(const KernelParams &p, const Lds &s) {
+    NnBuf b;
+    b.x = s.nn;
+    b.xg = b.x + p.nn.X;
+    b.h = b.xg + p.nn.X;
+    b.m = b.h + p.nn.sum_width;
+    b.fg = b.m + p.nn.sum_width;
+    b.prod = b.fg + p.nn.max_in;
+    return b;
+}
+template <bool COH>
+__device__ __forceinline__ float nn_ld(const float *p) {
+    if (COH) return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void nn_st(float *p, float v) {
+    if (COH)
+        __hip_atomic_store(reinterpret_cast<unsigned *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *p = v;
+}
+__device__ __forceinline__ uint32_t tri_index(uint32_t a, uint32_t b) {  // row-major lower triangle, block_misc.rs:871-882
+    const uint32_t i = a > b ? a : b, j = a > b ? b : a;
+    return i * (i + 1) / 2 + j;
+}
+
+// x = [per-combo LR sums, triangle of the FFM pair outputs]; then the layers; returns the logit (same value in all threads).
+// block_lr.rs:36-45, block_misc.rs:864-883, block_neural.rs:196-222, block_relu.rs:38-54, regressor.rs:307-319
+template <int VEC, bool COH>
+__device__ __forceinline__ float nn_forward(const KernelParams &p, const Lds &s, uint32_t nl, int tid, int bd) {
+    const int lane = tid & 63, wave = tid >> 6, nw = bd >> 6;
+    const NnBuf b = nn_buf(p, s);
+    const DevNN &n = p.nn;
+    const uint32_t F = p.F, k = p.k, R = p.R, C = p.num_combos;
+    for (uint32_t i = tid; i < nl; i += bd) b.prod[i] = lr_load<COH>(p.lr, s.l_hash[i]).x * s.l_val[i];
+    __syncthreads();
+    for (uint32_t c = tid; c < C; c += bd) {  // each combo slot sums its entries in buffer order
+        float acc = 0.0f;
+        for (uint32_t i = 0; i < nl; ++i)
+            if (s.l_combo[i] == c) acc += b.prod[i];
+        b.x[c] = acc;
+    }
+    const uint32_t T = F * (F + 1) / 2;
+    for (uint32_t t = tid; t < T; t += bd) {
+        uint32_t i = (uint32_t)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while ((i + 1) * (i + 2) / 2 <= t) ++i;
+        while (i * (i + 1) / 2 > t) --i;
+        const uint32_t j = t - i * (i + 1) / 2;
+        float dot = 0.0f;
+        if (i != j) {
+            for (uint32_t kk = 0; kk < k; ++kk) dot += s.T[i * R + j * k + kk] * s.T[j * R + i * k + kk];
+        } else {
+            // Diagonal in the reference's own form (block_ffm.rs:231-243): per feature, sum_k w * v * (contra - w * v).
+            // A field with one feature gives EXACTLY 0 this way; "0.5 * (dot - dcf)" leaves a 1e-10 residue there and the
+            // first AdaGrad step of a dense weight (nn_init_acc_gradient = 0) blows any nonzero input up to O(lr).
+            for (uint32_t e = s.fstart[i]; e < s.fend[i]; ++e) {
+                const float v = s.e_val[e];
+                float corr = 0.0f;
+                for (uint32_t kk = 0; kk < k; ++kk) {
+                    const float w = s.selfw[e * k + kk];
+                    corr += w * (v * (s.T[i * R + i * k + kk] - w * v));
+                }
+                dot += corr * 0.5f;
+            }
+        }
+        b.x[C + t] = dot;  // triangle (block_misc.rs:864-883): 2 * (0.5 * dot) off the diagonal
+    }
+    __syncthreads();
+    const float *in_vec = b.x;
+    uint32_t hoff = 0;
+    for (uint32_t l = 0; l < n.n_layers; ++l) {
+        const uint32_t in = n.in[l], out = n.out[l];
+        const float *W = n.w + n.off[l];
+        for (uint32_t j = wave; j < out; j += nw) {
+            float dot = 0.0f;
+            for (uint32_t i = lane; i < in; i += 64) dot += nn_ld<COH>(W + (size_t)j * in + i) * in_vec[i];
+            dot = wave_sum(dot);
+            const float pre = nn_ld<COH>(W + (size_t)in * out + j) + dot;
+            if (n.relu[l]) {
+                b.h[hoff + j] = pre < 0.0f ? 0.0f : pre;
+                b.m[hoff + j] = pre < 0.0f ? 0.0f : 1.0f;
+            } else {
+                b.h[hoff + j] = pre;
+                b.m[hoff + j] = 1.0f;
+            }
+        }
+        __syncthreads();
+        in_vec = b.h + hoff;
+        hoff += out;
+    }
+    // final neuron over [h_last, x] (topology "one") or h_last (topology "two")
+    const uint32_t L = n.n_layers, fin = n.in[L], wl = n.out[L - 1];
+    const float *Wf = n.w + n.off[L];
+    float dot = 0.0f;
+    for (uint32_t i = tid; i < fin; i += bd) dot += nn_ld<COH>(Wf + i) * (i < wl ? in_vec[i] : b.x[i - wl]);
+    dot = wave_sum(dot);
+    if (lane == 0) s.red[wave] = dot;
+    __syncthreads();
+    float z = 0.0f;
+    for (int w = 0; w < nw; ++w) z += s.red[w];
+    z = nn_ld<COH>(Wf + fin) + z;
+    __syncthreads();
+    return z;
+}
+
+// One BlockNeuronLayer backward (block_neural.rs:252-340): neuron by neuron (j), every input i: AdaGrad step on
+// W[j][i] with gradient og[j]*in[i]; in_grad[i] += W_old[j][i]*og[j].  Thread i owns column i, so the j order of the
+// reference is kept per weight and no two threads touch the same weight.  in_vals and in_grad may alias.
+template <int OPT, bool COH>
+__device__ __forceinline__ void nn_layer_backward(const DevNN &n, uint32_t l, const float *og, const float *in_a,
+                                                  uint32_t split, const float *in_b, float *grad_a, float *grad_b,
+                                                  int tid, int bd) {
+    const uint32_t in = n.in[l], out = n.out[l];
+    float *W = n.w + n.off[l], *A = n.acc + n.off[l];
+    for (uint32_t i = tid; i < in; i += bd) {
+        const float xi = i < split ? in_a[i] : in_b[i - split];
+        float oe = 0.0f;
+        for (uint32_t j = 0; j < out; ++j) {
+            const float gg = og[j];
+            if (gg == 0.0f) continue;  // block_neural.rs:275-277
+            const size_t ix = (size_t)j * in + i;
+            const float w = nn_ld<COH>(W + ix);
+            float acc = OPT == FWGPU_OPT_SGD ? 0.0f : nn_ld<COH>(A + ix);
+            const float upd = opt_step<OPT>(gg * xi, acc, n.rate, n.minus_power_t, n.lut);
+            oe += w * gg;
+            nn_st<COH>(W + ix, w - upd);
+            if (OPT != FWGPU_OPT_SGD) nn_st<COH>(A + ix, acc);
+        }
+        if (i < split)
+            grad_a[i] = oe;
+        else
+            grad_b[i - split] = oe;
+    }
+    for (uint32_t j = tid; j < out; j += bd) {  // bias terms (block_neural.rs:296-306)
+        const float gg = og[j];
+        if (gg != 0.0f) {
+            const size_t ix = (size_t)in * out + j;
+            const float w = nn_ld<COH>(W + ix);
+            float acc = OPT == FWGPU_OPT_SGD ? 0.0f : nn_ld<COH>(A + ix);
+            const float upd = opt_step<OPT>(gg, acc, n.rate, n.minus_power_t, n.lut);
+            nn_st<COH>(W + ix, w - upd);
+            if (OPT != FWGPU_OPT_SGD) nn_st<COH>(A + ix, acc);
+        }
+    }
+}
+
+// The unwinding of the head: final neuron, then [ReLU mask, layer] from last to first, BlockCopy summing both branches.
+// Leaves d logit/d x in xg[] (LR slot gradients first, then the triangle gradients).
+template <int OPT, bool COH>
+__device__ __forceinline__ void nn_backward(const KernelParams &p, const Lds &s, float g, int tid, int bd) {
+    const NnBuf b = nn_buf(p, s);
+    const DevNN &n = p.nn;
+    const uint32_t L = n.n_layers, X = n.X, wl = n.out[L - 1];
+    uint32_t hoff_last = n.sum_width - wl;
+    if (tid == 0) b.fg[0] = g;  // og of the single final neuron
+    __syncthreads();
+    // final neuron: inputs [h_last | x], input gradients -> [h_last (in place) | xg]
+    nn_layer_backward<OPT, COH>(n, L, b.fg, b.h + hoff_last, wl, b.x, b.h + hoff_last, b.xg, tid, bd);
+    if (n.topology != 1)
+        for (uint32_t i = tid; i < X; i += bd) b.xg[i] = 0.0f;
+    __syncthreads();
+    uint32_t hoff = hoff_last;
+    for (int l = (int)L - 1; l >= 0; --l) {
+        const uint32_t out = n.out[l];
+        // BlockRELU backward (block_relu.rs:105-110): mask * upstream gradient -> this layer's output gradient
+        for (uint32_t j = tid; j < out; j += bd) b.m[hoff + j] = b.m[hoff + j] * b.h[hoff + j];
+        __syncthreads();
+        if (l > 0) {
+            const uint32_t pin = n.out[l - 1];
+            nn_layer_backward<OPT, COH>(n, l, b.m + hoff, b.h + hoff - pin, pin, b.h + hoff - pin, b.h + hoff - pin,
+                                            b.h + hoff - pin, tid, bd);
+            hoff -= pin;
+        } else {
+            // first layer: inputs x; its input gradient is ADDED to the copy branch (BlockCopy, block_misc.rs:456-475)
+            nn_layer_backward<OPT, COH>(n, 0, b.m + hoff, b.x, X, b.x, b.fg, b.fg, tid, bd);
+            __syncthreads();
+            for (uint32_t i = tid; i < X; i += bd) b.xg[i] = b.fg[i] + b.xg[i];
+        }
+        __syncthreads();
+    }
 }
 
 // Update of one FFM feature row by one wave (block_ffm.rs:269-286), U rows at a time for memory-level
 // parallelism.  idx[u] == 0xffffffff marks an unused slot.
 template <int VEC, int OPT, int AUX, int U>
 __device__ __forceinline__ void update_rows(const KernelParams &p, const Lds &s, const uint32_t (&idx)[U], float g,
-                                            int lane) {
+                                            int lane, const float *gpair = nullptr) {
     typedef typename Vec<VEC>::type V;
     const uint32_t R = p.R, k = p.k;
     const uint32_t nchunk = (R + 64 * VEC - 1) / (64 * VEC);
@@ -496,7 +703,10 @@ __device__ __forceinline__ void update_rows(const KernelParams &p, const Lds &s,
                 float t = Vec<VEC>::get(tv, j);
                 if (self) t = __fsub_rn(t, __fmul_rn(Vec<VEC>::get(sw, j), v));  // contra - w*v  block_ffm.rs:238
                 const float G = __fmul_rn(v, t);             // gradient cache      block_ffm.rs:239, 249
-                const float grad = __fmul_rn(g, G);           // block_ffm.rs:278
+                // general gradient of output (f, z): uniform g, or -- deep head -- the mirrored triangle gradient
+                // (block_misc.rs:822-832)
+                const float gz = gpair ? gpair[tri_index(f, VEC == 1 ? (inb ? e0 / k : 0) : z)] : g;
+                const float grad = __fmul_rn(gz, G);          // block_ffm.rs:278
                 float acc = Vec<VEC>::get(av[u], j);
                 const float upd = opt_step<OPT>(grad, acc, p.ffm_rate, p.ffm_minus_power_t, s.lut);
                 Vec<VEC>::set(av[u], j, acc);
@@ -516,9 +726,9 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
     constexpr int UU = 4;  // feature rows in flight per wave in the update phase (x2 tables)
     extern __shared__ __align__(16) unsigned char smem[];
     const bool use_lut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global;
-    size_t off[17];
+    size_t off[19];
     lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut, p.records ? p.max_rec : 0,
-               p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, off);
+               p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), off);
     Lds s;
     s.T = reinterpret_cast<float *>(smem + off[0]);
     s.selfw = reinterpret_cast<float *>(smem + off[1]);
@@ -537,6 +747,8 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
     s.set_lr = reinterpret_cast<uint32_t *>(smem + off[14]);
     s.rec = reinterpret_cast<uint32_t *>(smem + off[15]);
     s.tcnt = reinterpret_cast<uint32_t *>(smem + off[16]);
+    s.l_combo = reinterpret_cast<uint32_t *>(smem + off[17]);
+    s.nn = reinterpret_cast<float *>(smem + off[18]);
     SetGeom geom;
     geom.setf_n = set_size(p.max_ffm);
     geom.setl_n = set_size(p.max_lr);
@@ -673,6 +885,8 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         float wsum = 0.0f;
         if (p.has_lr) wsum += lr_t;
         if (k) wsum += 0.5f * (dot_t - dc_t);
+        // deep head: the sigmoid sees the final neuron's output instead (regressor.rs:191-323)
+        if (p.nn.n_layers) wsum = nn_forward<VEC, COH>(p, s, nl, tid, bd);
 
         // ---------------- sigmoid / log-loss gradient (block_loss_functions.rs:105-153)
         float pr, g;
@@ -695,13 +909,20 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         // ---------------- update.  g == 0 leaves every weight and accumulator unchanged in all three
         // optimizers (acc += 0, w -= 0), so the whole phase is skipped.
         if (do_update && g != 0.0f) {
+            // deep head: unwind it first; afterwards every LR slot and every FFM pair has its own general gradient
+            const float *gx = nullptr, *gpair = nullptr;
+            if (p.nn.n_layers) {
+                nn_backward<OPT, COH>(p, s, g, tid, bd);
+                gx = nn_buf(p, s).xg;
+                gpair = gx + p.num_combos;
+            }
             // LR (block_lr.rs:135-150): the thread owning the FIRST occurrence of a hash applies all
             // occurrences in buffer order, so duplicates chain exactly like the reference's loop.
             if (p.has_lr && !s.ctr[3]) {
                 for (uint32_t t = tid; t < nl; t += bd) {
                     const uint32_t h = s.l_hash[t];
                     float2 wa = lr_load<COH>(p.lr, h);
-                    const float grad = g * s.l_val[t];
+                    const float grad = (gx ? gx[s.l_combo[t]] : g) * s.l_val[t];
                     const float upd = opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, p.lut_lr);
                     wa.x -= upd;
                     lr_store<COH>(p.lr, h, wa);
@@ -715,7 +936,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                         float2 wa = lr_load<COH>(p.lr, h);
                         for (uint32_t j = t; j < nl; ++j) {
                             if (s.l_hash[j] == h) {
-                                const float grad = g * s.l_val[j];
+                                const float grad = (gx ? gx[s.l_combo[j]] : g) * s.l_val[j];
                                 const float upd = opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, p.lut_lr);
                                 wa.x -= upd;
                             }
@@ -734,7 +955,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                         const uint32_t i = i0 + u;
                         idx[u] = (i < nf && !(s.e_fld[i] & 0x80000000u)) ? i : 0xffffffffu;
                     }
-                    update_rows<VEC, OPT, AUX, UU>(p, s, idx, g, lane);
+                    update_rows<VEC, OPT, AUX, UU>(p, s, idx, g, lane, gpair);
                 }
                 // phase B: overlapping rows, strictly in buffer order on one wave
                 if (s.ctr[1]) {
@@ -744,7 +965,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                         for (uint32_t i = 0; i < nf; ++i) {
                             if (s.e_fld[i] & 0x80000000u) {
                                 uint32_t idx[1] = {i};
-                                update_rows<VEC, OPT, AUX, 1>(p, s, idx, g, lane);
+                                update_rows<VEC, OPT, AUX, 1>(p, s, idx, g, lane, gpair);
                                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                                 __builtin_amdgcn_s_waitcnt(0);
                             }
@@ -827,9 +1048,9 @@ __global__ void __launch_bounds__(1024) fw_example_kernel_r(const KernelParams p
     constexpr int UA = 4;  // accumulator rows in flight per wave in the update phase
     extern __shared__ __align__(16) unsigned char smem[];
     const bool use_lut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global;
-    size_t off[17];
+    size_t off[19];
     lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut, p.records ? p.max_rec : 0,
-               p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, off);
+               p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), off);
     Lds s;
     s.T = reinterpret_cast<float *>(smem + off[0]);
     s.selfw = reinterpret_cast<float *>(smem + off[1]);
@@ -848,6 +1069,8 @@ __global__ void __launch_bounds__(1024) fw_example_kernel_r(const KernelParams p
     s.set_lr = reinterpret_cast<uint32_t *>(smem + off[14]);
     s.rec = reinterpret_cast<uint32_t *>(smem + off[15]);
     s.tcnt = reinterpret_cast<uint32_t *>(smem + off[16]);
+    s.l_combo = reinterpret_cast<uint32_t *>(smem + off[17]);
+    s.nn = reinterpret_cast<float *>(smem + off[18]);
     SetGeom geom;
     geom.setf_n = set_size(p.max_ffm);
     geom.setl_n = set_size(p.max_lr);
@@ -1170,7 +1393,7 @@ hipError_t launch_example_kernel(const KernelParams &p, int optimizer, bool cohe
     // Entries that did not come through the translator's mask (raw fwgpu_learn calls) may be unaligned.
     if (p.k % 4 == 0 && p.aligned4) {
         // single-chunk rows: the register-resident kernel (v2); p.kernel_version == 1 forces v1 (tests, A/B runs)
-        if (p.R <= 64 * 4 && p.kernel_version != 1) return launch_resident(p, optimizer, coherent, grid, threads, lds, stream);
+        if (p.R <= 64 * 4 && p.kernel_version != 1 && p.nn.n_layers == 0) return launch_resident(p, optimizer, coherent, grid, threads, lds, stream);
         return launch_v<4>(p, optimizer, coherent, grid, threads, lds, stream);
     }
     return launch_v<1>(p, optimizer, coherent, grid, threads, lds, stream);

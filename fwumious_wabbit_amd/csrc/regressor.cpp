@@ -45,6 +45,7 @@ void HostBatch::clear() {
     ffm_fld.clear();
     lr_hash.clear();
     lr_val.clear();
+    lr_combo.clear();
     label.clear();
     importance.clear();
     ffm_off.assign(1, 0);
@@ -76,6 +77,7 @@ int append_example(const fwgpu_regressor *r, HostBatch &hb, const fwgpu_lr_entry
         if (lr[i].combo_index >= r->cfg.num_combos) return fail(FWGPU_ERR_RANGE, "lr entry: combo_index >= num_combos");
         hb.lr_hash.push_back(lr[i].hash);
         hb.lr_val.push_back(lr[i].value);
+        hb.lr_combo.push_back((uint16_t)lr[i].combo_index);
     }
     hb.ffm_off.push_back((uint32_t)hb.ffm_hash.size());
     hb.lr_off.push_back((uint32_t)hb.lr_hash.size());
@@ -94,7 +96,7 @@ int batch_alloc(fwgpu_regressor *r, uint32_t n, uint64_t n_lr, uint64_t n_ffm, f
     b->n = n;
     b->n_lr = n_lr;
     b->n_ffm = n_ffm;
-    size_t o = 0, off[10];
+    size_t o = 0, off[11];
     off[0] = o; o = up256(o + 4 * n_ffm);
     off[1] = o; o = up256(o + 4 * n_ffm);
     off[2] = o; o = up256(o + n_ffm);
@@ -105,6 +107,7 @@ int batch_alloc(fwgpu_regressor *r, uint32_t n, uint64_t n_lr, uint64_t n_ffm, f
     off[7] = o; o = up256(o + 4 * (size_t)n);
     off[8] = o; o = up256(o + 4 * (size_t)n);
     off[9] = o; o = up256(o + 4 * (size_t)n);
+    off[10] = o; o = up256(o + 2 * n_lr);
     b->dev_bytes = std::max<size_t>(o, 256);
     FWGPU_HIP(hipSetDevice(r->device));
     FWGPU_HIP(hipMalloc(&b->dev, b->dev_bytes));
@@ -119,6 +122,7 @@ int batch_alloc(fwgpu_regressor *r, uint32_t n, uint64_t n_lr, uint64_t n_ffm, f
     b->label = reinterpret_cast<float *>(base + off[7]);
     b->importance = reinterpret_cast<float *>(base + off[8]);
     b->pred = reinterpret_cast<float *>(base + off[9]);
+    b->lr_combo = reinterpret_cast<uint16_t *>(base + off[10]);
     *out = b.release();
     return FWGPU_OK;
 }
@@ -257,6 +261,7 @@ int batch_upload(fwgpu_batch *b, const HostBatch &hb, hipStream_t stream) {
     UP(b->ffm_off, hb.ffm_off);
     UP(b->lr_hash, hb.lr_hash);
     UP(b->lr_val, hb.lr_val);
+    UP(b->lr_combo, hb.lr_combo);
     UP(b->lr_off, hb.lr_off);
     UP(b->label, hb.label);
     UP(b->importance, hb.importance);
@@ -281,6 +286,9 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
     p.lr_hash = b->lr_hash;
     p.lr_val = b->lr_val;
     p.lr_off = b->lr_off;
+    p.lr_combo = b->lr_combo;
+    p.nn = r->nn;
+    p.num_combos = r->cfg.num_combos;
     p.label = b->label;
     p.importance = b->importance;
     p.pred = b->pred;
@@ -415,10 +423,15 @@ int fwgpu_free(fwgpu_regressor *r) {
     (void)hipFree(r->d_ffm_acc);
     (void)hipFree(r->d_lut_lr);
     (void)hipFree(r->d_lut_ffm);
+    (void)hipFree(r->d_nn_w);
+    (void)hipFree(r->d_nn_acc);
+    (void)hipFree(r->d_lut_nn);
     if (r->pinned) (void)hipHostFree(r->pinned);
     delete r;
     return FWGPU_OK;
 }
+
+static int nn_init_weights(fwgpu_regressor *r);
 
 int fwgpu_init_weights(fwgpu_regressor *r) {
     if (!r) return fail(FWGPU_ERR_INVALID, "NULL regressor");
@@ -430,7 +443,104 @@ int fwgpu_init_weights(fwgpu_regressor *r) {
     if (r->ffm_len)
         FWGPU_HIP(launch_ffm_init(r->d_ffm_w, r->d_ffm_acc, r->ffm_len, c.ffm_k, c.ffm_init_width, c.ffm_init_zero_band,
                                   c.ffm_init_center, initial_acc(c.optimizer, c.ffm_init_acc_gradient), 0));
+    if (r->nn.n_layers) {
+        int rc = nn_init_weights(r);
+        if (rc) return rc;
+    }
     FWGPU_HIP(hipDeviceSynchronize());
+    return FWGPU_OK;
+}
+
+int fwgpu_set_nn(fwgpu_regressor *r, const fwgpu_nn_config *nn) {
+    if (!r || !nn) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    if (r->cfg.wiring != FWGPU_WIRING_REGRESSOR) return fail(FWGPU_ERR_INVALID, "the deep head needs the REGRESSOR wiring");
+    if (nn->n_layers == 0 || nn->n_layers > FWGPU_NN_MAX_LAYERS) return fail(FWGPU_ERR_INVALID, "nn: n_layers must be in 1..8");
+    if (nn->topology != 1 && nn->topology != 2)
+        return fail(FWGPU_ERR_INVALID, "unknown nn topology (\"one\" and \"two\" are supported; \"four\"/\"five\" use block_normalize, out of scope)");
+    FWGPU_HIP(hipSetDevice(r->device));
+    DevNN d{};
+    const uint32_t F = r->cfg.ffm_k ? r->cfg.ffm_num_fields : 0;
+    d.n_layers = nn->n_layers;
+    d.topology = nn->topology;
+    d.X = r->cfg.num_combos + F * (F + 1) / 2;  // the Join span (regressor.rs:185-189)
+    uint32_t in = d.X, off = 0;
+    d.max_in = d.X;
+    for (uint32_t l = 0; l < nn->n_layers; l++) {
+        if (nn->width[l] == 0 || nn->width[l] > 4096) return fail(FWGPU_ERR_INVALID, "nn: layer width must be in 1..4096");
+        if (nn->init[l] > FWGPU_NN_INIT_ZERO) return fail(FWGPU_ERR_INVALID, "nn: unknown init type");
+        if (in >= 16000) return fail(FWGPU_ERR_INVALID, "nn: too many inputs (MAX_NUM_INPUTS, block_neural.rs:27)");
+        d.in[l] = in;
+        d.out[l] = nn->width[l];
+        d.off[l] = off;
+        d.relu[l] = nn->relu[l] ? 1 : 0;
+        off += (in + 1) * nn->width[l];  // +1: bias term (block_neural.rs:86)
+        d.sum_width += nn->width[l];
+        in = nn->width[l];
+        d.max_in = std::max(d.max_in, in);
+    }
+    const uint32_t L = nn->n_layers;
+    d.in[L] = in + (nn->topology == 1 ? d.X : 0);  // Join(h_last, copy of x), regressor.rs:307-311
+    d.out[L] = 1;
+    d.off[L] = off;
+    off += d.in[L] + 1;
+    d.max_in = std::max(d.max_in, d.in[L]);
+    d.rate = nn->nn_learning_rate;
+    d.minus_power_t = -nn->nn_power_t;
+    if (r->d_nn_w) (void)hipFree(r->d_nn_w);
+    if (r->d_nn_acc) (void)hipFree(r->d_nn_acc);
+    if (r->d_lut_nn) (void)hipFree(r->d_lut_nn);
+    r->nn_len = off;
+    FWGPU_HIP(hipMalloc((void **)&r->d_nn_w, (size_t)off * 4));
+    FWGPU_HIP(hipMalloc((void **)&r->d_nn_acc, (size_t)off * 4));
+    FWGPU_HIP(hipMalloc((void **)&r->d_lut_nn, kLutSize * sizeof(float)));
+    FWGPU_HIP(hipMemset(r->d_nn_w, 0, (size_t)off * 4));
+    std::vector<float> lut(kLutSize);
+    lut_init(lut.data(), nn->nn_learning_rate, nn->nn_power_t, nn->nn_init_acc_gradient);  // block_neural.rs:111-112
+    FWGPU_HIP(hipMemcpy(r->d_lut_nn, lut.data(), kLutSize * sizeof(float), hipMemcpyHostToDevice));
+    FWGPU_HIP(launch_fill(r->d_nn_acc, off, initial_acc(r->cfg.optimizer, nn->nn_init_acc_gradient), 0));
+    FWGPU_HIP(hipDeviceSynchronize());
+    d.w = r->d_nn_w;
+    d.acc = r->d_nn_acc;
+    d.lut = r->d_lut_nn;
+    r->nn = d;
+    r->nn_cfg = *nn;
+    return FWGPU_OK;
+}
+
+// block_neural.rs:367-424.  The reference seeds Xoshiro256++ per layer and samples rand_distr Normal / Uniform;
+// that stream is third-party and unpinned, so the library uses its own deterministic generator with the same
+// distributions: Hu = N(0, sqrt(2/in)), Xavier = U(+-sqrt(6)/sqrt(in*out)), One, Zero; biases are always 0.
+static int nn_init_weights(fwgpu_regressor *r) {
+    const DevNN &d = r->nn;
+    std::vector<float> w(r->nn_len, 0.0f);
+    auto rng = [](uint64_t &s) {
+        uint64_t z = (s += 0x9e3779b97f4a7c15ULL);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+        return z ^ (z >> 31);
+    };
+    auto u01 = [&](uint64_t &s) { return ((double)(rng(s) >> 11) + 0.5) * (1.0 / 9007199254740992.0); };
+    for (uint32_t l = 0; l <= d.n_layers; l++) {
+        const uint32_t in = d.in[l], out = d.out[l];
+        const size_t bias = (size_t)in * out;
+        const uint32_t init = l == d.n_layers ? (uint32_t)FWGPU_NN_INIT_ONE : r->nn_cfg.init[l];  // regressor.rs:312-319
+        uint64_t st = 0x5eed0000ULL + 7919ULL * l + in + (bias + out);
+        float *wl = w.data() + d.off[l];
+        for (size_t i = 0; i < bias; i++) {
+            switch (init) {
+            case FWGPU_NN_INIT_XAVIER: wl[i] = (float)((2.0 * u01(st) - 1.0) * (sqrt(6.0) / sqrt((double)bias))); break;
+            case FWGPU_NN_INIT_HU: {
+                const double u1 = u01(st), u2 = u01(st);
+                wl[i] = (float)(sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2) * sqrt(2.0 / (double)in));
+                break;
+            }
+            case FWGPU_NN_INIT_ONE: wl[i] = 1.0f; break;
+            default: wl[i] = 0.0f;
+            }
+        }
+    }
+    FWGPU_HIP(hipMemcpy(r->d_nn_w, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    FWGPU_HIP(launch_fill(r->d_nn_acc, r->nn_len, initial_acc(r->cfg.optimizer, r->nn_cfg.nn_init_acc_gradient), 0));
     return FWGPU_OK;
 }
 
@@ -594,6 +704,8 @@ static int table_ptr(fwgpu_regressor *r, int which, float **p, uint64_t *n) {
     case FWGPU_TABLE_LR: *p = r->d_lr; *n = r->lr_len * 2; return FWGPU_OK;
     case FWGPU_TABLE_FFM_W: *p = r->d_ffm_w; *n = r->ffm_len; return FWGPU_OK;
     case FWGPU_TABLE_FFM_ACC: *p = r->d_ffm_acc; *n = r->ffm_len; return FWGPU_OK;
+    case FWGPU_TABLE_NN_W: *p = r->d_nn_w; *n = r->nn_len; return FWGPU_OK;
+    case FWGPU_TABLE_NN_ACC: *p = r->d_nn_acc; *n = r->nn_len; return FWGPU_OK;
     }
     return fail(FWGPU_ERR_INVALID, "unknown table");
 }
@@ -727,14 +839,14 @@ int fwgpu_debug_coherence_probe(int device, int use_sc1, uint32_t iters, uint32_
 
 static uint64_t serialized_elems(const fwgpu_regressor *r) {
     // sum of get_serialized_len(): block_lr.rs:253-255 (weights_len), block_ffm.rs:831-833 (ffm_weights_len)
-    return r->lr_len + r->ffm_len;
+    return r->lr_len + r->ffm_len + r->nn_len;  // + block_neural.rs:426-428 (weights_len of every dense layer)
 }
 
 int fwgpu_serialized_len(fwgpu_regressor *r, uint64_t *n_bytes) {
     if (!r || !n_bytes) return fail(FWGPU_ERR_INVALID, "NULL argument");
     const bool sgd = r->cfg.optimizer == FWGPU_OPT_SGD;
     // SGD's PerWeightStore is PhantomData (0 bytes): optimizer.rs:20
-    *n_bytes = 8 + r->lr_len * (sgd ? 4 : 8) + r->ffm_len * (sgd ? 4 : 8);
+    *n_bytes = 8 + r->lr_len * (sgd ? 4 : 8) + r->ffm_len * (sgd ? 4 : 8) + r->nn_len * (sgd ? 4 : 8);
     return FWGPU_OK;
 }
 
@@ -765,6 +877,16 @@ int fwgpu_write_weights(fwgpu_regressor *r, uint8_t *buf, uint64_t cap, uint64_t
         if (!sgd) {
             FWGPU_HIP(hipMemcpy(o, r->d_ffm_acc, r->ffm_len * 4, hipMemcpyDeviceToHost));
             o += r->ffm_len * 4;
+        }
+    }
+    // dense layers in block order, each: weights then optimizer state (block_neural.rs:430-438)
+    for (uint32_t l = 0; r->nn.n_layers && l <= r->nn.n_layers; l++) {
+        const size_t len = ((size_t)r->nn.in[l] + 1) * r->nn.out[l];
+        FWGPU_HIP(hipMemcpy(o, r->d_nn_w + r->nn.off[l], len * 4, hipMemcpyDeviceToHost));
+        o += len * 4;
+        if (!sgd) {
+            FWGPU_HIP(hipMemcpy(o, r->d_nn_acc + r->nn.off[l], len * 4, hipMemcpyDeviceToHost));
+            o += len * 4;
         }
     }
     if (written) *written = (uint64_t)(o - buf);
@@ -800,6 +922,15 @@ int fwgpu_read_weights(fwgpu_regressor *r, const uint8_t *buf, uint64_t len) {
         if (!sgd) {
             FWGPU_HIP(hipMemcpy(r->d_ffm_acc, o, r->ffm_len * 4, hipMemcpyHostToDevice));
             o += r->ffm_len * 4;
+        }
+    }
+    for (uint32_t l = 0; r->nn.n_layers && l <= r->nn.n_layers; l++) {  // block_neural.rs:440-448
+        const size_t len = ((size_t)r->nn.in[l] + 1) * r->nn.out[l];
+        FWGPU_HIP(hipMemcpy(r->d_nn_w + r->nn.off[l], o, len * 4, hipMemcpyHostToDevice));
+        o += len * 4;
+        if (!sgd) {
+            FWGPU_HIP(hipMemcpy(r->d_nn_acc + r->nn.off[l], o, len * 4, hipMemcpyHostToDevice));
+            o += len * 4;
         }
     }
     return FWGPU_OK;

@@ -61,6 +61,13 @@ class ModelInstance:
     ffm_init_acc_gradient: float = 0.0
     init_acc_gradient: float = 1.0
     optimizer: int = Optimizer.SGD
+    # deep head (nn_config.layers / topology, model_instance.rs:32-44, 139-142): one dict per hidden layer with the
+    # reference's keys: width (default 20), activation ("relu" | "none"), init ("hu" default | "xavier" | "one" | "zero")
+    nn_layers: List[dict] = field(default_factory=list)
+    nn_topology: str = "one"
+    nn_learning_rate: float = 0.02
+    nn_power_t: float = 0.45
+    nn_init_acc_gradient: float = 0.0
     # not in the reference: which graph the regressor is wired as (tests of the bare FFM block) and the device
     wiring: int = capi.WIRING_REGRESSOR
     device: int = 0
@@ -184,6 +191,19 @@ class Regressor:
         self.h = C.c_void_p()
         cfg = mi.to_config()
         check(self.L.fwgpu_create(C.byref(cfg), C.byref(self.h)))
+        if mi.nn_layers:  # regressor.rs:191-320
+            nn = capi.NNConfig()
+            nn.n_layers = len(mi.nn_layers)
+            for i, layer in enumerate(mi.nn_layers):
+                nn.width[i] = int(layer.get("width", 20))
+                nn.relu[i] = int(layer.get("activation", "none") == "relu")
+                nn.init[i] = capi.NN_INIT[layer.get("init", "hu")]
+            if mi.nn_topology not in ("one", "two"):
+                raise ValueError(f'unknown nn topology: "{mi.nn_topology}"')
+            nn.topology = {"one": 1, "two": 2}[mi.nn_topology]
+            nn.nn_learning_rate, nn.nn_power_t, nn.nn_init_acc_gradient = (mi.nn_learning_rate, mi.nn_power_t,
+                                                                            mi.nn_init_acc_gradient)
+            check(self.L.fwgpu_set_nn(self.h, C.byref(nn)))
         if init_weights:
             self.allocate_and_init_weights()
 

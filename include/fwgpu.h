@@ -110,12 +110,32 @@ int fwgpu_learn(fwgpu_regressor *r, const fwgpu_lr_entry *lr, uint32_t n_lr, con
 int fwgpu_predict(fwgpu_regressor *r, const fwgpu_lr_entry *lr, uint32_t n_lr, const fwgpu_ffm_entry *ffm,
                   uint32_t n_ffm, float *prediction);
 
+/* ---------------------------------------------------------------- deep head (BASELINE config E)
+ * fwgpu_set_nn <= the `--nn_layers / --nn N:width:W / --nn N:activation:relu / --nn N:init:hu / --nn_topology` part of
+ * Regressor::new_without_weights (regressor.rs:191-320): BlockCopy -> [BlockNeuronLayer -> BlockRELU]* -> Join ->
+ * single neuron (InitType::One) in front of the sigmoid.  Call after fwgpu_create and before fwgpu_init_weights.
+ * Per-example semantics are the reference's (block_neural.rs:252-340: every dense weight with a non-zero upstream
+ * gradient takes an AdaGrad step, neuron by neuron).  Hidden-layer init Hu / Xavier uses the library's own
+ * deterministic generator: the reference draws from rand_xoshiro + rand_distr (third party, parity unpinned). */
+#define FWGPU_NN_MAX_LAYERS 8
+enum { FWGPU_NN_INIT_XAVIER = 0, FWGPU_NN_INIT_HU = 1, FWGPU_NN_INIT_ONE = 2, FWGPU_NN_INIT_ZERO = 3 };
+typedef struct fwgpu_nn_config {
+    uint32_t n_layers;                     /* hidden layers */
+    uint32_t width[FWGPU_NN_MAX_LAYERS];   /* --nn N:width:W (default 20) */
+    uint32_t relu[FWGPU_NN_MAX_LAYERS];    /* --nn N:activation:relu -> 1, none -> 0 */
+    uint32_t init[FWGPU_NN_MAX_LAYERS];    /* --nn N:init:... (default hu) */
+    uint32_t topology;                     /* 1 = "one" (default, model_instance.rs:42), 2 = "two" */
+    float nn_learning_rate, nn_power_t, nn_init_acc_gradient; /* model_instance.rs:426-428 */
+} fwgpu_nn_config;
+int fwgpu_set_nn(fwgpu_regressor *r, const fwgpu_nn_config *nn);
+
 /* ---------------------------------------------------------------- weight (de)serialisation
  * fwgpu_serialized_len / fwgpu_write_weights / fwgpu_read_weights
  *      <= Regressor::write_weights_to_buf / overwrite_weights_from_buf    regressor.rs:426-469
  * Blob = u64 LE total element count (sum of get_serialized_len), then per block, in order:
  *   LR : 2^b x {f32 w, f32 acc}   (SGD: {f32 w})              block_lr.rs:257-275, block_helpers.rs:17-28
  *   FFM: len x f32 w, then len x f32 acc (SGD: no acc part)   block_ffm.rs:835-863
+ *   NN : per dense layer, weights then optimizer state        block_neural.rs:430-448
  * fwgpu_serialized_len returns the byte size of that blob. */
 int fwgpu_serialized_len(fwgpu_regressor *r, uint64_t *n_bytes);
 int fwgpu_write_weights(fwgpu_regressor *r, uint8_t *buf, uint64_t cap, uint64_t *written);
@@ -124,7 +144,8 @@ int fwgpu_read_weights(fwgpu_regressor *r, const uint8_t *buf, uint64_t len);
 /* Raw table access (tests, weight patching).  which: 0 = LR table as interleaved {w,acc} floats
  * (2*2^b floats), 1 = FFM weights, 2 = FFM optimizer state (each 2^ffm_bits + F*k floats,
  * block_ffm.rs:92-94).  Offsets and counts are in floats. */
-enum { FWGPU_TABLE_LR = 0, FWGPU_TABLE_FFM_W = 1, FWGPU_TABLE_FFM_ACC = 2 };
+enum { FWGPU_TABLE_LR = 0, FWGPU_TABLE_FFM_W = 1, FWGPU_TABLE_FFM_ACC = 2,
+       FWGPU_TABLE_NN_W = 3, FWGPU_TABLE_NN_ACC = 4 /* all dense layers back to back: hidden layers, then the final neuron */ };
 int fwgpu_table_len(fwgpu_regressor *r, int which, uint64_t *n_floats);
 int fwgpu_table_read(fwgpu_regressor *r, int which, uint64_t offset, uint64_t count, float *host_out);
 int fwgpu_table_write(fwgpu_regressor *r, int which, uint64_t offset, uint64_t count, const float *host_in);

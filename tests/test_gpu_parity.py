@@ -127,6 +127,118 @@ def test_lr_only_model():
                    interactions=[(0, 1)])
 
 
+# ------------------------------------------------------------------ deep head (SURVEY a18, config E shape)
+def _nn_stream_parity(n_ns, k, bits, ffm_bits, optimizer, layers, topology, n, seed, mean_extra=1.0, ids=3000,
+                      interactions=(), nn_lr=0.02, nn_power_t=0.45, nn_init_acc=0.0, weight_tol=2e-5, **kw):
+    mi, ocfg, ots = make_pair(n_ns, k, bits, ffm_bits, optimizer, interactions=interactions, **kw)
+    mi.nn_layers = [dict(width=w, activation=a, init=i) for w, a, i in layers]
+    mi.nn_topology = topology
+    mi.nn_learning_rate, mi.nn_power_t, mi.nn_init_acc_gradient = nn_lr, nn_power_t, nn_init_acc
+    nn = fwo.make_nn_config(layers, topology, nn_lr, nn_power_t, nn_init_acc)
+    recs, off = fw.synth_records(n_ns, mean_extra, 1.1, ids, 0.1, seed, 0, n)
+    y = record_labels(recs, off)
+    om = fwo.Model(ocfg, nn=nn)
+    L = len(layers)
+    w0 = np.concatenate([om.nn_weights(l).copy() for l in range(L + 1)])
+    _, p_ref = om.run_stream(ots, recs, off, holdout_after=0, nthreads=1)
+    w1 = np.concatenate([om.nn_weights(l) for l in range(L + 1)])
+    a1 = np.concatenate([om.nn_acc(l) for l in range(L + 1)])
+    assert not np.array_equal(w0, w1)  # the head did learn
+    outs = []
+    for kind in ("entries", "records"):
+        re = fw.Regressor(mi)
+        assert re.table_len(capi.TABLE_NN_W) == w0.size
+        re.table_write(capi.TABLE_NN_W, w0)  # Hu / Xavier draws are implementation-defined: load the same ones
+        fbt = fw.FeatureBufferTranslator(mi)
+        b = re.batch_from_records(fbt, recs, off) if kind == "entries" else re.record_batch(fbt, recs, off)
+        re.learn_batch(b, capi.MODE_SEQUENTIAL, True)
+        p_gpu = b.predictions()
+        d_ll = np.abs(logloss(p_gpu, y) - logloss(p_ref, y))
+        assert d_ll.max() < LOGLOSS_TOL, f"{kind}: max per-example |d logloss| = {d_ll.max()} at {d_ll.argmax()}"
+
+        def close(a, b_):
+            return bool(np.all(np.abs(a - b_) <= weight_tol + 1e-5 * np.abs(b_)))
+
+        assert close(re.table_read(capi.TABLE_NN_W), w1)
+        if optimizer != fw.Optimizer.SGD:
+            assert close(re.table_read(capi.TABLE_NN_ACC), a1)
+        assert close(re.table_read(capi.TABLE_LR), om.lr_table)
+        if k:
+            assert close(re.table_read(capi.TABLE_FFM_W), om.ffm_weights)
+            assert close(re.table_read(capi.TABLE_FFM_ACC), om.ffm_acc)
+        outs.append((p_gpu, re.table_checksum(capi.TABLE_NN_W), re.table_checksum(capi.TABLE_FFM_W)))
+        b.close()
+        re.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1:] == outs[1][1:]
+
+
+def test_deep_head_topology_one_relu_layers():
+    # config E in small: LR + FFM -> triangle -> [relu, relu] -> final neuron over [h, x]
+    _nn_stream_parity(6, 4, 12, 12, fw.Optimizer.AdagradLUT, [(12, "relu", "hu"), (8, "relu", "hu")], "one", n=600,
+                      seed=21, interactions=[(0, 1)])
+
+
+def test_deep_head_k16_scalar_and_topology_two():
+    _nn_stream_parity(5, 16, 13, 14, fw.Optimizer.AdagradLUT, [(25, "relu", "xavier")], "one", n=300, seed=22)
+    _nn_stream_parity(3, 5, 12, 12, fw.Optimizer.AdagradLUT, [(9, "none", "hu"), (7, "relu", "xavier")], "two", n=400,
+                      seed=23)
+
+
+def test_deep_head_sgd_and_flex():
+    _nn_stream_parity(4, 4, 12, 12, fw.Optimizer.SGD, [(10, "relu", "hu")], "one", n=400, seed=24, lr=0.05, ffm_lr=0.05)
+    _nn_stream_parity(4, 8, 12, 12, fw.Optimizer.AdagradFlex, [(10, "relu", "hu")], "one", n=400, seed=25,
+                      nn_init_acc=1.0, weight_tol=5e-5)
+
+
+def test_deep_head_blob_round_trip_and_inference():
+    mi, _, _ = make_pair(4, 4, 12, 12, fw.Optimizer.AdagradLUT)
+    mi.nn_layers = [dict(width=6, activation="relu", init="hu"), dict(width=5, activation="relu", init="xavier")]
+    recs, off = fw.synth_records(4, 1.0, 1.1, 3000, 0.1, 26, 0, 200)
+    re = fw.Regressor(mi)
+    fbt = fw.FeatureBufferTranslator(mi)
+    b = re.record_batch(fbt, recs, off)
+    re.learn_batch(b, capi.MODE_SEQUENTIAL, True)
+    blob = re.write_weights_to_buf()
+    X = mi.num_combos + 4 * 5 // 2
+    n_nn = (X + 1) * 6 + (6 + 1) * 5 + (5 + X) + 1
+    assert re.table_len(capi.TABLE_NN_W) == n_nn
+    lr_n, ffm_n = re.table_len(capi.TABLE_LR) // 2, re.table_len(capi.TABLE_FFM_W)  # LR table: {w, acc} pairs
+    assert len(blob) == 8 + 8 * (lr_n + ffm_n + n_nn)
+    assert int(np.frombuffer(blob[:8], dtype=np.uint64)[0]) == lr_n + ffm_n + n_nn
+    # first dense layer: weights then accumulators, right after the FFM arrays
+    o = 8 + 8 * (lr_n + ffm_n)
+    l0 = (X + 1) * 6
+    nn_w = re.table_read(capi.TABLE_NN_W)
+    assert np.array_equal(np.frombuffer(blob[o:o + 4 * l0], dtype=np.float32), nn_w[:l0])
+    assert np.array_equal(np.frombuffer(blob[o + 4 * l0:o + 8 * l0], dtype=np.float32), re.table_read(capi.TABLE_NN_ACC)[:l0])
+    # inference pass == sequential no-update pass; a second regressor loaded from the blob predicts the same
+    re.learn_batch(b, capi.MODE_HOGWILD, False)
+    p1 = b.predictions().copy()
+    re2 = fw.Regressor(mi)
+    re2.overwrite_weights_from_buf(blob)
+    b2 = re2.record_batch(fw.FeatureBufferTranslator(mi), recs, off)
+    re2.learn_batch(b2, capi.MODE_SEQUENTIAL, False)
+    assert np.array_equal(p1, b2.predictions())
+    for x in (b, b2, re, re2):
+        x.close()
+
+
+def test_deep_head_hogwild_learns():
+    mi, ocfg, ots = make_pair(8, 4, 16, 16, fw.Optimizer.AdagradLUT, lr=0.025, ffm_lr=0.025, power_t=0.38, ffm_power_t=0.38)
+    mi.nn_layers = [dict(width=16, activation="relu", init="hu")]
+    recs, off = fw.synth_records(8, 1.0, 1.1, 2000, 0.1, 27, 0, 60000)
+    y = record_labels(recs, off)
+    re = fw.Regressor(mi)
+    b = re.record_batch(fw.FeatureBufferTranslator(mi), recs, off)
+    re.learn_batch(b, capi.MODE_HOGWILD, True)
+    p = b.predictions()
+    assert np.all(np.isfinite(p))
+    ll = logloss(p, y)
+    assert ll[-10000:].mean() < ll[:10000].mean() - 0.01 and ll[-10000:].mean() < 0.69
+    b.close()
+    re.close()
+
+
 def test_sequential_mode_is_deterministic():
     mi, _, _ = make_pair(10, 4, 12, 12, fw.Optimizer.AdagradLUT)
     recs, off = fw.synth_records(10, 1.0, 1.1, 3000, 0.1, 9, 0, 600)
