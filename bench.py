@@ -34,6 +34,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # reference algorithm (scripts/oracle_convergence.py: hold-out log-loss 2.12 vs 0.659 at 0.025), and a diverged run
 # saturates the sigmoid, which skips updates and inflates examples/sec.
 LR, POWER_T, INIT_ACC = 0.025, 0.38, 1.0
+# deep head (config E only): the reference's defaults (model_instance.rs:139-142) except init_acc 0 -> 1.0 like the blocks above
+NN_LR, NN_POWER_T, NN_INIT_ACC = 0.02, 0.45, 1.0
 
 
 def build_model_instance(fw, args, device):
@@ -43,7 +45,10 @@ def build_model_instance(fw, args, device):
         ffm_init_acc_gradient=INIT_ACC, bit_precision=args.bits, ffm_bit_precision=args.ffm_bits, ffm_k=args.k,
         add_constant_feature=True, optimizer=fw.Optimizer.AdagradLUT,
         feature_combo_descs=[fw.FeatureComboDesc([fw.NamespaceDescriptor(i)]) for i in range(F)],
-        ffm_fields=[[fw.NamespaceDescriptor(i)] for i in range(F)], device=device)
+        ffm_fields=[[fw.NamespaceDescriptor(i)] for i in range(F)], device=device,
+        # config E: `--nn_layers 2 --nn 0:width:256 --nn 0:activation:relu ...`, topology "one" 
+        nn_layers=[dict(width=args.nn_width, activation="relu", init="hu") for _ in range(args.nn_layers)],
+        nn_topology="one", nn_learning_rate=NN_LR, nn_power_t=NN_POWER_T, nn_init_acc_gradient=NN_INIT_ACC)
 
 
 def gen_records(fw, args, first, n, threads=8):
@@ -68,7 +73,15 @@ def gen_records(fw, args, first, n, threads=8):
 def algorithmic_bytes(args, batch, n_words):
     """train, AdaGrad: n_ffm*16*R + n_lr*16 + 4*record_len + 4 per example."""
     R = args.fields * args.k
-    return batch.n_ffm * 16 * R + batch.n_lr * 16 + 4 * n_words + 4 * batch.n
+    b = batch.n_ffm * 16 * R + batch.n_lr * 16 + 4 * n_words + 4 * batch.n
+    if args.nn_layers:  # config E: + the dense weights once per launch (16 B each: w, acc read and written)
+        X = args.fields + 1 + args.fields * (args.fields + 1) // 2
+        wn, i = 0, X
+        for _ in range(args.nn_layers):
+            wn += (i + 1) * args.nn_width
+            i = args.nn_width
+        b += 16 * (wn + i + X + 1)
+    return b
 
 
 def logloss(p, y):
@@ -90,10 +103,13 @@ def cpu_baseline(args, n_examples):
                            ffm_num_fields=F)
     ots = fwo.TranslatorSpec([([(i, False)], 1.0) for i in range(F)], [[(i, False)] for i in range(F)], True, args.bits,
                              args.k, args.ffm_bits)
+    nn = None
+    if args.nn_layers:
+        nn = fwo.make_nn_config([(args.nn_width, "relu", "hu")] * args.nn_layers, "one", NN_LR, NN_POWER_T, NN_INIT_ACC)
     try:
-        om = fwo.Model(ocfg, native=True)
+        om = fwo.Model(ocfg, native=True, nn=nn)
     except Exception:
-        om = fwo.Model(ocfg, native=False)
+        om = fwo.Model(ocfg, native=False, nn=nn)
     recs, off = gen_records(fw, args, 10_000_000, n_examples)
     # single thread = the reference's default execution mode (main.rs:213-270)
     n1 = min(n_examples, 4000)
@@ -116,8 +132,8 @@ def cpu_baseline(args, n_examples):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=16384, help="examples per step per GPU")
     ap.add_argument("--fields", type=int, default=30)
     ap.add_argument("--k", type=int, default=8)
@@ -129,6 +145,8 @@ def main():
     ap.add_argument("--p-weighted", dest="p_weighted", type=float, default=0.1)
     ap.add_argument("--seed", type=int, default=20240612)
     ap.add_argument("--holdout", type=int, default=8192)
+    ap.add_argument("--nn-layers", dest="nn_layers", type=int, default=0, help="config E: hidden ReLU layers of the deep head")
+    ap.add_argument("--nn-width", dest="nn_width", type=int, default=256)
     ap.add_argument("--threads", type=int, default=0, help="workgroup size override")
     ap.add_argument("--wgs-per-cu", dest="wgs", type=int, default=0)
     ap.add_argument("--sync-every", dest="sync_every", type=int, default=0, help="N>1: steps between delta all-reduces")
@@ -187,7 +205,10 @@ def main():
     sptr = stream.cuda_stream
 
     # ---- N>1: replicas + delta all-reduce (local SGD with summed deltas)
-    sync_every = args.sync_every or max(1, K // 2)
+    # Cadence: one exchange per 32 steps (0.5 M examples per GPU, ~150 ms of training); a shorter run still times one
+    # whole exchange, started at its midpoint.  Every exchange started in the timed region also lands inside it.
+    sync_every = args.sync_every or (32 if K >= 48 else max(1, K // 2))
+    last_sync_step = K - 1 if args.blocking_sync or K < 3 else K - 2  # an exchange started at the very last step could not overlap anything
     syncer = None
     if use_dist:
         from fwumious_wabbit_amd.dist_sync import DeltaAllReduce
@@ -218,7 +239,7 @@ def main():
         ev[2 * i].record(stream)
         re.learn_batch(batches[W + i], capi.MODE_HOGWILD, True, sptr)
         ev[2 * i + 1].record(stream)
-        if use_dist and (i + 1) % sync_every == 0:
+        if use_dist and (i + 1) % sync_every == 0 and i <= last_sync_step:
             sync_replicas()
     if use_dist:
         syncer.finish()  # the exchange still in flight lands INSIDE the timed region
@@ -276,7 +297,8 @@ def main():
             "saturated_fraction_last_step": saturated,
             "config": {
                 "hyperparameters": f"AdagradLUT lr={LR} power_t={POWER_T} init_acc_gradient={INIT_ACC} (run_one.sh)",
-                "workload": f"BASELINE.json configs[2]: synthetic {args.fields}-field k={args.k} FFM + LR, "
+                "workload": f"BASELINE.json configs[{4 if args.nn_layers else 2}]: synthetic {args.fields}-field k={args.k} FFM + LR"
+                            + (f" + deep head {args.nn_layers}x{args.nn_width} ReLU (topology one, per-example updates)" if args.nn_layers else "") + ", "
                             f"{args.ffm_bits}-bit FFM hash, {args.bits}-bit LR hash, ~{int(args.fields * (1 + args.mean_extra))} nnz/example, "
                             f"AdagradLUT, fused learn (record translation + forward + sigmoid/log-loss + AdaGrad scatter-update)",
                 "examples_per_step_per_gpu": B,
@@ -290,7 +312,9 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "fw_example_kernel_r<AdagradLUT, coherent, MAXR=12> (register-resident rows)",
+                "kernel": ("fw_example_kernel_r<AdagradLUT, coherent, MAXR=12> (register-resident rows)"
+                           if args.k % 4 == 0 and args.fields * args.k <= 256 and not args.nn_layers else
+                           "fw_example_kernel<VEC=4, AdagradLUT, coherent> (generic rows" + (" + deep head)" if args.nn_layers else ")")),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -548,17 +548,34 @@ __device__ __forceinline__ float nn_forward(const KernelParams &p, const Lds &s,
     for (uint32_t l = 0; l < n.n_layers; ++l) {
         const uint32_t in = n.in[l], out = n.out[l];
         const float *W = n.w + n.off[l];
-        for (uint32_t j = wave; j < out; j += nw) {
-            float dot = 0.0f;
-            for (uint32_t i = lane; i < in; i += 64) dot += nn_ld<COH>(W + (size_t)j * in + i) * in_vec[i];
-            dot = wave_sum(dot);
-            const float pre = nn_ld<COH>(W + (size_t)in * out + j) + dot;
-            if (n.relu[l]) {
-                b.h[hoff + j] = pre < 0.0f ? 0.0f : pre;
-                b.m[hoff + j] = pre < 0.0f ? 0.0f : 1.0f;
-            } else {
-                b.h[hoff + j] = pre;
-                b.m[hoff + j] = 1.0f;
+        // a wave computes JU neurons per pass so that JU * ceil(in / 64) weight loads are in flight per lane
+        constexpr int JU = 4;
+        for (uint32_t j0 = wave * JU; j0 < out; j0 += nw * JU) {
+            float dot[JU];
+#pragma unroll
+            for (int u = 0; u < JU; ++u) dot[u] = 0.0f;
+            for (uint32_t i = lane; i < in; i += 64) {
+                float w[JU];
+#pragma unroll
+                for (int u = 0; u < JU; ++u) w[u] = j0 + u < out ? nn_ld<COH>(W + (size_t)(j0 + u) * in + i) : 0.0f;
+                const float xi = in_vec[i];
+#pragma unroll
+                for (int u = 0; u < JU; ++u) dot[u] += w[u] * xi;
+            }
+#pragma unroll
+            for (int u = 0; u < JU; ++u) {
+                const uint32_t j = j0 + u;
+                const float d = wave_sum(dot[u]);
+                if (j < out) {
+                    const float pre = nn_ld<COH>(W + (size_t)in * out + j) + d;
+                    if (n.relu[l]) {
+                        b.h[hoff + j] = pre < 0.0f ? 0.0f : pre;
+                        b.m[hoff + j] = pre < 0.0f ? 0.0f : 1.0f;
+                    } else {
+                        b.h[hoff + j] = pre;
+                        b.m[hoff + j] = 1.0f;
+                    }
+                }
             }
         }
         __syncthreads();
@@ -592,16 +609,30 @@ __device__ __forceinline__ void nn_layer_backward(const DevNN &n, uint32_t l, co
     for (uint32_t i = tid; i < in; i += bd) {
         const float xi = i < split ? in_a[i] : in_b[i - split];
         float oe = 0.0f;
-        for (uint32_t j = 0; j < out; ++j) {
-            const float gg = og[j];
-            if (gg == 0.0f) continue;  // block_neural.rs:275-277
-            const size_t ix = (size_t)j * in + i;
-            const float w = nn_ld<COH>(W + ix);
-            float acc = OPT == FWGPU_OPT_SGD ? 0.0f : nn_ld<COH>(A + ix);
-            const float upd = opt_step<OPT>(gg * xi, acc, n.rate, n.minus_power_t, n.lut);
-            oe += w * gg;
-            nn_st<COH>(W + ix, w - upd);
-            if (OPT != FWGPU_OPT_SGD) nn_st<COH>(A + ix, acc);
+        constexpr int JU = 8;  // weights (and accumulators) of JU neurons in flight per thread
+        for (uint32_t j0 = 0; j0 < out; j0 += JU) {
+            float w[JU], a[JU], gg[JU];
+#pragma unroll
+            for (int u = 0; u < JU; ++u) {
+                const uint32_t j = j0 + u;
+                gg[u] = j < out ? og[j] : 0.0f;
+                w[u] = 0.0f;
+                a[u] = 0.0f;
+                if (gg[u] != 0.0f) {  // block_neural.rs:275-277
+                    const size_t ix = (size_t)j * in + i;
+                    w[u] = nn_ld<COH>(W + ix);
+                    if (OPT != FWGPU_OPT_SGD) a[u] = nn_ld<COH>(A + ix);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < JU; ++u) {
+                if (gg[u] == 0.0f) continue;
+                const size_t ix = (size_t)(j0 + u) * in + i;
+                const float upd = opt_step<OPT>(gg[u] * xi, a[u], n.rate, n.minus_power_t, n.lut);
+                oe += w[u] * gg[u];
+                nn_st<COH>(W + ix, w[u] - upd);
+                if (OPT != FWGPU_OPT_SGD) nn_st<COH>(A + ix, a[u]);
+            }
         }
         if (i < split)
             grad_a[i] = oe;
