@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfwgpu.so")
+# FWGPU_LIBRARY: an alternative build of the same C ABI (kernel tuning experiments); default = the in-tree build
+LIB_PATH = os.environ.get("FWGPU_LIBRARY") or os.path.join(_HERE, "lib", "libfwgpu.so")
 
 OK = 0
 OPT_SGD, OPT_ADAGRAD_FLEX, OPT_ADAGRAD_LUT = 100, 200, 300

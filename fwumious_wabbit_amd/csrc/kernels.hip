@@ -191,13 +191,13 @@ __device__ __forceinline__ bool set_contains(const uint32_t *tab, uint32_t mask,
     }
 }
 
-__host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t max_ffm, uint32_t max_lr, bool lut,
+__host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t max_ffm, uint32_t max_lr, uint32_t n_luts,
                                              uint32_t max_rec, uint32_t tr_items, uint32_t nn_floats, size_t *off /*[19]*/) {
     size_t o = 0;
     size_t R = (size_t)F * k;
     off[0] = o; o = align16(o + 4 * F * R);
     off[1] = o; o = align16(o + 4 * (size_t)max_ffm * k);
-    off[2] = o; o = align16(o + (lut ? 4 * (size_t)kLutSize : 0));
+    off[2] = o; o = align16(o + 4 * (size_t)kLutSize * n_luts);
     off[3] = o; o = align16(o + 4 * (size_t)max_ffm);
     off[4] = o; o = align16(o + 4 * (size_t)max_ffm);
     off[5] = o; o = align16(o + 4 * (size_t)max_ffm);
@@ -259,20 +259,64 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, int lane) {
 // Brings example `ex` into LDS: either copies its pre-translated entries, or translates its raw record
 // (FeatureBufferTranslator::translate, feature_buffer.rs:178-338, bit-exact hashing) on the spot; then finds the field
 // boundaries and runs the O(1) pre-filters for overlapping FFM rows / duplicate LR hashes (exact scan only if they hit).
+// The next example's record, fetched into registers while the current example is still being worked on: its offsets
+// first (rec_prefetch_offsets), then -- one phase later, when those have arrived -- up to PW words per thread.
+struct RecPrefetch {
+    static constexpr int PW = 2;
+    uint64_t r0, r1;
+    uint32_t w[PW];
+    uint32_t ex;  // the example this belongs to (0xffffffff: nothing fetched)
+};
+__device__ __forceinline__ void rec_prefetch_offsets(const KernelParams &p, uint32_t ex, RecPrefetch &pf) {
+    pf.ex = 0xffffffffu;
+    if (p.records && ex < p.n_examples) {
+        pf.r0 = p.rec_off[ex];
+        pf.r1 = p.rec_off[ex + 1];
+        pf.ex = ex;
+    }
+}
+__device__ __forceinline__ void rec_prefetch_words(const KernelParams &p, RecPrefetch &pf, int tid, int bd) {
+    if (pf.ex == 0xffffffffu) return;
+    const uint32_t len = (uint32_t)(pf.r1 - pf.r0);
+#pragma unroll
+    for (int u = 0; u < RecPrefetch::PW; ++u) {
+        const uint32_t i = tid + u * bd;
+        pf.w[u] = i < len ? p.records[pf.r0 + i] : 0u;
+    }
+}
+
+// debug: shader-clock stamps inside the stage phase (slots 8.. of fwgpu_debug_phase_ticks)
+struct StageTicker {
+    unsigned long long *out;
+    unsigned long long last;
+    __device__ __forceinline__ void stamp(int slot) {
+        if (out) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            atomicAdd(out + slot, now - last);
+            last = now;
+        }
+    }
+};
+
 // Must be called by every thread of the workgroup (it contains barriers).
 __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const Lds &s, const SetGeom &g, uint32_t ex,
-                                                  int tid, int bd) {
+                                                  int tid, int bd, const RecPrefetch *pf = nullptr,
+                                                  unsigned long long *tick_out = nullptr) {
+    StageTicker tk{tick_out, tick_out ? __builtin_amdgcn_s_memtime() : 0ull};
     const int lane = tid & 63, wave = tid >> 6;
     const uint32_t F = p.F, R = p.R;
     StageOut o;
     const uint32_t *grec = nullptr;
     uint32_t rec_len = 0, fo = 0, lo = 0;
+    const bool pre = pf && pf->ex == ex;
     if (p.records) {
-        const uint64_t r0 = p.rec_off[ex];
+        const uint64_t r0 = pre ? pf->r0 : p.rec_off[ex];
         grec = p.records + r0;
-        rec_len = (uint32_t)(p.rec_off[ex + 1] - r0);
-        o.label = (float)grec[1];              // feature_buffer.rs:187
-        o.imp = __uint_as_float(grec[2]);      // feature_buffer.rs:188-189
+        rec_len = (uint32_t)((pre ? pf->r1 : p.rec_off[ex + 1]) - r0);
+        if (!pre) {
+            o.label = (float)grec[1];              // feature_buffer.rs:187
+            o.imp = __uint_as_float(grec[2]);      // feature_buffer.rs:188-189
+        }
         o.nf = o.nl = 0;
     } else {
         fo = p.ffm_off[ex];
@@ -281,6 +325,18 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
         o.nl = p.lr_off[ex + 1] - lo;
         o.label = p.label[ex];
         o.imp = p.importance[ex];
+    }
+    if (pre) {
+        // the record arrives from registers; label and importance are read back from its LDS copy
+#pragma unroll
+        for (int u = 0; u < RecPrefetch::PW; ++u) {
+            const uint32_t i = tid + u * bd;
+            if (i < rec_len) s.rec[i] = pf->w[u];
+        }
+        for (uint32_t i = tid + RecPrefetch::PW * bd; i < rec_len; i += bd) s.rec[i] = grec[i];
+        __syncthreads();
+        o.label = (float)s.rec[1];
+        o.imp = __uint_as_float(s.rec[2]);
     }
     o.do_update = p.update && (o.imp != 0.0f);  // regressor.rs:366
     const bool do_update = o.do_update;
@@ -314,8 +370,10 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
     } else {
         const DevTranslator &t = p.tr;
         const uint32_t NP = t.n_pairs, NC = t.n_combos;
-        for (uint32_t i = tid; i < rec_len; i += bd) s.rec[i] = grec[i];
+        if (!pre)
+            for (uint32_t i = tid; i < rec_len; i += bd) s.rec[i] = grec[i];
         __syncthreads();
+        tk.stamp(8);
         // Wave 0 builds the ffm_buffer, wave 1 the lr_buffer: per 64 items count -> wave scan -> emit, all inside one
         // wave, so no workgroup barrier is needed between the steps.
         if (wave == 0) {
@@ -396,6 +454,7 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
             if (lane == 0) s.ctr[5] = carry;
         }
         __syncthreads();
+        tk.stamp(9);
         o.nf = s.ctr[4];
         o.nl = s.ctr[5];
     }
@@ -411,6 +470,7 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
         for (uint32_t i = tid; i < nl; i += bd)
             if (set_insert(s.set_lr, g.setl_n - 1, g.setl_shift, s.l_hash[i])) s.ctr[3] = 1;
     __syncthreads();
+    tk.stamp(10);
     if (do_update)
         for (uint32_t i = tid; i < nf; i += bd)
             if (set_contains(s.set_ffm, g.setf_n - 1, g.setf_shift, (s.e_hash[i] >> g.blk_shift) + 1)) s.ctr[2] = 1;
@@ -428,6 +488,7 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
             if (s.fstart[f] == s.fend[f]) s.dcf[f] = 0.0f;
     }
     __syncthreads();
+    tk.stamp(11);
     if (do_update && s.ctr[2]) {
         // Rare: some rows may overlap.  Exact scan: does an EARLIER feature's row [h_j, h_j+R) overlap mine?
         // (rows are R long but start on a next_pow2(k) grid: block_ffm.rs:92-94, feature_buffer.rs:141-148)
@@ -460,7 +521,7 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
 
 size_t example_kernel_lds_bytes(const KernelParams &p, int optimizer) {
     size_t off[19];
-    return lds_layout(p.F, p.k, p.max_ffm, p.max_lr, optimizer == FWGPU_OPT_ADAGRAD_LUT && p.update && !p.lut_global,
+    return lds_layout(p.F, p.k, p.max_ffm, p.max_lr, (optimizer == FWGPU_OPT_ADAGRAD_LUT && p.update && !p.lut_global) ? 1 : 0,
                       p.records ? p.max_rec : 0, p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), off);
 }
 
@@ -758,7 +819,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
     extern __shared__ __align__(16) unsigned char smem[];
     const bool use_lut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global;
     size_t off[19];
-    lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut, p.records ? p.max_rec : 0,
+    lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut ? 1 : 0, p.records ? p.max_rec : 0,
                p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), off);
     Lds s;
     s.T = reinterpret_cast<float *>(smem + off[0]);
@@ -793,6 +854,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
     const uint32_t F = p.F, k = p.k, R = p.R;
     const uint32_t nchunk = R ? (R + 64 * VEC - 1) / (64 * VEC) : 0;
 
+    const float *lut_lr = p.lut_lr;  // 201 lookups per example: read through L1 (an LDS copy measured no faster)
     if (use_lut)
         for (int i = tid; i < kLutSize; i += bd) s.lut[i] = p.lut_ffm[i];
     else
@@ -954,7 +1016,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                     const uint32_t h = s.l_hash[t];
                     float2 wa = lr_load<COH>(p.lr, h);
                     const float grad = (gx ? gx[s.l_combo[t]] : g) * s.l_val[t];
-                    const float upd = opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, p.lut_lr);
+                    const float upd = opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, lut_lr);
                     wa.x -= upd;
                     lr_store<COH>(p.lr, h, wa);
                 }
@@ -968,7 +1030,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                         for (uint32_t j = t; j < nl; ++j) {
                             if (s.l_hash[j] == h) {
                                 const float grad = (gx ? gx[s.l_combo[j]] : g) * s.l_val[j];
-                                const float upd = opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, p.lut_lr);
+                                const float upd = opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, lut_lr);
                                 wa.x -= upd;
                             }
                         }
@@ -1071,16 +1133,29 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return v;
 }
 
+#ifndef FW_UA
+#define FW_UA 4
+#endif
+#ifndef FW_UO
+#define FW_UO 2
+#endif
+#ifndef FW_LB_THREADS
+#define FW_LB_THREADS 512
+#endif
+#ifndef FW_LB_WAVES
+#define FW_LB_WAVES 4
+#endif
 template <int OPT, bool COH, int MAXR>
-__global__ void __launch_bounds__(1024) fw_example_kernel_r(const KernelParams p) {
+__global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_r(const KernelParams p) {
     typedef f4 V;
     constexpr int VEC = 4;
     constexpr int AUX = COH ? kAuxSc1 : kAuxPlain;
-    constexpr int UA = 4;  // accumulator rows in flight per wave in the update phase
+    constexpr int UA = FW_UA;  // accumulator rows in flight per wave in the update phase
+    constexpr int UO = FW_UO;  // overflow rows (w + acc) in flight per wave
     extern __shared__ __align__(16) unsigned char smem[];
     const bool use_lut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global;
     size_t off[19];
-    lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut, p.records ? p.max_rec : 0,
+    lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut ? 1 : 0, p.records ? p.max_rec : 0,
                p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), off);
     Lds s;
     s.T = reinterpret_cast<float *>(smem + off[0]);
@@ -1119,6 +1194,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel_r(const KernelParams p
     const uint32_t z = inb ? e0 / k : 0xfffffffeu;
     const uint32_t kk0 = inb ? e0 - z * k : 0;
 
+    const float *lut_lr = p.lut_lr;  // 201 lookups per example: read through L1 (an LDS copy measured no faster)
     if (use_lut)
         for (int i = tid; i < kLutSize; i += bd) s.lut[i] = p.lut_ffm[i];
     else
@@ -1134,12 +1210,16 @@ __global__ void __launch_bounds__(1024) fw_example_kernel_r(const KernelParams p
     }
     if (timing) tk_last = __builtin_amdgcn_s_memtime();
 
+    RecPrefetch pf;
+    rec_prefetch_offsets(p, blockIdx.x, pf);
+    rec_prefetch_words(p, pf, tid, bd);
     for (uint32_t ex = blockIdx.x; ex < p.n_examples; ex += gridDim.x) {
         if (gridDim.x == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in-order mode: see fw_example_kernel
         __syncthreads();
         FW_TICK(6);
         if (timing) atomicAdd(p.ticks + 7, 1ull);
-        const StageOut so = stage_example(p, s, geom, ex, tid, bd);
+        const StageOut so = stage_example(p, s, geom, ex, tid, bd, &pf, timing ? p.ticks : nullptr);
+        rec_prefetch_offsets(p, ex + gridDim.x, pf);  // lands during the gather
         const uint32_t nf = so.nf, nl = so.nl;
         const float label = so.label, imp = so.imp;
         const bool do_update = so.do_update;
@@ -1244,6 +1324,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel_r(const KernelParams p
         float lrs = 0.0f;
         if (p.has_lr)
             for (uint32_t i = tid; i < nl; i += bd) lrs += lr_load<COH>(p.lr, s.l_hash[i]).x * s.l_val[i];
+        rec_prefetch_words(p, pf, tid, bd);  // the next record: lands during the update phase
         dot = wave_sum(dot);
         lrs = wave_sum(lrs);
         if (lane == 0) {
@@ -1280,11 +1361,13 @@ __global__ void __launch_bounds__(1024) fw_example_kernel_r(const KernelParams p
 
         if (do_update && g != 0.0f) {
             if (p.has_lr && !s.ctr[3]) {
+                // The entry is read again here rather than kept from the forward pass: keeping it saved no time and
+                // widened the hogwild read-modify-write window of hot entries (constant feature) by two phases.
                 for (uint32_t t = tid; t < nl; t += bd) {
                     const uint32_t h = s.l_hash[t];
                     float2 wa = lr_load<COH>(p.lr, h);
                     const float grad = g * s.l_val[t];
-                    const float upd = opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, p.lut_lr);
+                    const float upd = opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, lut_lr);
                     wa.x -= upd;
                     lr_store<COH>(p.lr, h, wa);
                 }
@@ -1298,7 +1381,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel_r(const KernelParams p
                         for (uint32_t j = t; j < nl; ++j) {
                             if (s.l_hash[j] == h) {
                                 const float grad = g * s.l_val[j];
-                                const float upd = opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, p.lut_lr);
+                                const float upd = opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, lut_lr);
                                 wa.x -= upd;
                             }
                         }
@@ -1356,14 +1439,14 @@ __global__ void __launch_bounds__(1024) fw_example_kernel_r(const KernelParams p
                 }
             }
             // phase A, overflow rows of this range: the v1 route (fresh read of w)
-            for (uint32_t i0 = lo + MAXR; i0 < hi; i0 += 2) {
-                uint32_t idx[2];
+            for (uint32_t i0 = lo + MAXR; i0 < hi; i0 += UO) {
+                uint32_t idx[UO];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < UO; ++u) {
                     const uint32_t i = i0 + u;
                     idx[u] = (i < hi && !(s.e_fld[i] & 0x80000000u)) ? i : 0xffffffffu;
                 }
-                update_rows<VEC, OPT, AUX, 2>(p, s, idx, g, lane);
+                update_rows<VEC, OPT, AUX, UO>(p, s, idx, g, lane);
             }
             // phase B: rows overlapping an earlier row of this example, strictly in buffer order on one wave
             if (s.ctr[1]) {
@@ -1424,7 +1507,7 @@ hipError_t launch_example_kernel(const KernelParams &p, int optimizer, bool cohe
     // Entries that did not come through the translator's mask (raw fwgpu_learn calls) may be unaligned.
     if (p.k % 4 == 0 && p.aligned4) {
         // single-chunk rows: the register-resident kernel (v2); p.kernel_version == 1 forces v1 (tests, A/B runs)
-        if (p.R <= 64 * 4 && p.kernel_version != 1 && p.nn.n_layers == 0) return launch_resident(p, optimizer, coherent, grid, threads, lds, stream);
+        if (p.R <= 64 * 4 && p.kernel_version != 1 && p.nn.n_layers == 0 && threads <= FW_LB_THREADS) return launch_resident(p, optimizer, coherent, grid, threads, lds, stream);
         return launch_v<4>(p, optimizer, coherent, grid, threads, lds, stream);
     }
     return launch_v<1>(p, optimizer, coherent, grid, threads, lds, stream);

@@ -799,19 +799,19 @@ int fwgpu_delta_finish(void *table, void *snapshot, const void *local_delta, con
     return FWGPU_OK;
 }
 
-int fwgpu_debug_phase_ticks(fwgpu_regressor *r, int enable, uint64_t *out8) {
+int fwgpu_debug_phase_ticks(fwgpu_regressor *r, int enable, uint64_t *out16) {
     if (!r) return fail(FWGPU_ERR_INVALID, "NULL regressor");
     FWGPU_HIP(hipSetDevice(r->device));
     FWGPU_HIP(hipDeviceSynchronize());
-    if (out8) {
+    if (out16) {
         if (r->d_ticks)
-            FWGPU_HIP(hipMemcpy(out8, r->d_ticks, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            FWGPU_HIP(hipMemcpy(out16, r->d_ticks, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
         else
-            memset(out8, 0, 8 * sizeof(uint64_t));
+            memset(out16, 0, 16 * sizeof(uint64_t));
     }
     if (enable) {
-        if (!r->d_ticks) FWGPU_HIP(hipMalloc((void **)&r->d_ticks, 8 * sizeof(uint64_t)));
-        FWGPU_HIP(hipMemset(r->d_ticks, 0, 8 * sizeof(uint64_t)));
+        if (!r->d_ticks) FWGPU_HIP(hipMalloc((void **)&r->d_ticks, 16 * sizeof(uint64_t)));
+        FWGPU_HIP(hipMemset(r->d_ticks, 0, 16 * sizeof(uint64_t)));
     } else if (r->d_ticks) {
         (void)hipFree(r->d_ticks);
         r->d_ticks = nullptr;

@@ -253,8 +253,8 @@ int fwgpu_delta_finish(void *table, void *snapshot, const void *local_delta, con
 /* Per-phase shader-clock accounting of the example kernel (debug): enable=1 allocates/zeroes 8 device counters that
  * every workgroup's thread 0 adds to: [0] stage entries, [1] field boundaries + overlap scan, [2] row gather,
  * [3] dot + LR forward + sigmoid, [4] LR update, [5] FFM update, [6] wait for the slowest wave, [7] examples.
- * out8 (may be NULL) receives the counters accumulated so far. */
-int fwgpu_debug_phase_ticks(fwgpu_regressor *r, int enable, uint64_t *out8);
+ * out16 (may be NULL) receives the counters accumulated so far. */
+int fwgpu_debug_phase_ticks(fwgpu_regressor *r, int enable, uint64_t *out16);
 /* 0 = automatic kernel choice, 1 = force the generic kernel (v1), 2 = register-resident rows (v2) where applicable. */
 int fwgpu_debug_set_kernel_version(fwgpu_regressor *r, int version);
 /* Tuning switches for experiments. option 1: value 1 = read the AdaGrad LUT from global memory instead of an LDS copy. */

@@ -9,6 +9,7 @@ import bench
 
 class A: pass
 args = A(); args.fields, args.k, args.bits, args.ffm_bits = 30, 8, 28, 28
+args.nn_layers, args.nn_width = 0, 256
 args.mean_extra, args.zipf, args.ids, args.p_weighted, args.seed = 5.67, 1.05, 10_000_000, 0.1, 20240612
 B = int(os.environ.get("B", 16384)); NB = 3
 mi = bench.build_model_instance(fw, args, 0)
@@ -31,13 +32,14 @@ def run(threads, wgs, update=True, reps=6, label=""):
     for i in range(2):
         re.learn_batch(batches[i % NB], capi.MODE_HOGWILD, update)
     batches[1].predictions()
-    out = (C.c_uint64 * 8)()
+    out = (C.c_uint64 * 16)()
     capi.check(L.fwgpu_debug_phase_ticks(re.h, 0, out))
     t = np.array(list(out), dtype=np.float64)
     tot = t[:7].sum()
     per_ex = tot / max(t[7], 1)
     br = " ".join(f"{n}={100*v/tot:.0f}%" for n, v in zip(names[:7], t[:7]))
-    print(f"{label} threads={threads} wgs/cu={wgs or 'auto'} update={update}: {dt*1e3:.3f} ms/launch {B/dt/1e6:.2f} Mex/s | ticks/example={per_ex:.0f} | {br}", flush=True)
+    sub = " ".join(f"s{j}={100*t[8+j]/tot:.1f}%" for j in range(8) if t[8+j])
+    print(f"{label} threads={threads} wgs/cu={wgs or 'auto'} update={update}: {dt*1e3:.3f} ms/launch {B/dt/1e6:.2f} Mex/s | ticks/example={per_ex:.0f} | {br} | stage parts: {sub}", flush=True)
 
 use_records = os.environ.get("RECORDS", "1") == "1"
 if use_records:
@@ -46,7 +48,7 @@ quick = os.environ.get("QUICK", "0") == "1"
 for lutg in ((0,) if quick else (0, 1)):
     capi.check(L.fwgpu_debug_set_option(re.h, 1, lutg))
     print(f"--- kernel v2, lut_global={lutg}, records={use_records}")
-    for th, w in (((512, 2),) if quick else ((512, 2), (384, 2), (320, 3), (384, 3), (256, 4), (448, 2))):
+    for th, w in (((int(os.environ.get("THREADS", 512)), int(os.environ.get("WGS", 2))),) if quick else ((512, 2), (384, 2), (320, 3), (384, 3), (256, 4), (448, 2))):
         run(th, w)
         if quick:
             run(th, w, update=False)

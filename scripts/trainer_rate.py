@@ -7,6 +7,7 @@ import fwumious_wabbit_amd as fw
 import bench
 class A: pass
 args = A(); args.fields, args.k, args.bits, args.ffm_bits = 30, 8, 28, 28
+args.nn_layers, args.nn_width = 0, 256
 args.mean_extra, args.zipf, args.ids, args.p_weighted, args.seed = 5.67, 1.05, 10_000_000, 0.1, 20240612
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 mi = bench.build_model_instance(fw, args, 0)
