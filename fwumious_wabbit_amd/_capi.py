@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FWGPU_LIBRARY") or os.path.join(_HERE, "lib", "libfwgpu.so")
 
 OK = 0
+ERR_PARSE, ERR_IO, PARSE_FLUSH, PARSE_HOGWILD_LOAD = 6, 7, 100, 101
 OPT_SGD, OPT_ADAGRAD_FLEX, OPT_ADAGRAD_LUT = 100, 200, 300
 WIRING_REGRESSOR, WIRING_FFM_ONLY = 0, 1
 MODE_SEQUENTIAL, MODE_HOGWILD = 0, 1
@@ -92,6 +93,7 @@ class FwgpuError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"fwgpu error {code}: {msg}")
         self.code = code
+        self.message = msg
 
 
 _lib = None
@@ -148,11 +150,35 @@ def lib():
         "fwgpu_debug_set_option": [vp, i32, i32],
         "fwgpu_debug_coherence_probe": [i32, i32, u32, P(u32), P(u32)],
         "fwgpu_synth_records": [P(SynthConfig), u64, u32, vp, u64, vp, P(u64)],
+        "fwgpu_debug_format_f32": [f32, C.c_char_p, u32],
+        "fwgpu_vwmap_from_csv": [C.c_char_p, u64, P(vp)],
+        "fwgpu_vwmap_from_json": [C.c_char_p, u64, P(vp)],
+        "fwgpu_vwmap_to_json": [vp, vp, u64, P(u64)],
+        "fwgpu_vwmap_lookup": [vp, C.c_char_p, u64, i32, P(u32), P(u32)],
+        "fwgpu_parser_create": [vp, P(vp)],
+        "fwgpu_parser_parse_line": [vp, C.c_char_p, u64, vp, u32, P(u32)],
+        "fwgpu_parser_parse_with_prefix": [vp, C.c_char_p, u64, C.c_char_p, u64, vp, u32, P(u32)],
+        "fwgpu_parser_parse_buffer": [vp, C.c_char_p, u64, vp, u64, vp, u64, P(u64), P(u64), P(u64)],
+        "fwgpu_cache_open": [C.c_char_p, vp, P(vp)],
+        "fwgpu_cache_push_records": [vp, vp, u64],
+        "fwgpu_cache_write_finish": [vp],
+        "fwgpu_cache_next_records": [vp, vp, u64, vp, u64, P(u64), P(u64)],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = i32
+    for name in ("fwgpu_vwmap_free", "fwgpu_parser_free", "fwgpu_cache_free"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = None
+    for name in ("fwgpu_vwmap_num_namespaces", "fwgpu_vwmap_num_entries"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = u32
+    for name in ("fwgpu_cache_is_reading", "fwgpu_cache_is_writing"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = i32
+    L.fwgpu_parser_command_argument.argtypes = [vp]
+    L.fwgpu_parser_command_argument.restype = C.c_char_p
     L.fwgpu_murmur3_32.argtypes = [C.c_char_p, C.c_size_t, u32]
     L.fwgpu_murmur3_32.restype = u32
     L.fwgpu_lr_hash_mask.argtypes = [u32]

@@ -37,7 +37,12 @@ enum {
     FWGPU_ERR_DEVICE = 2,  /* HIP error or no device */
     FWGPU_ERR_OOM = 3,
     FWGPU_ERR_RANGE = 4,   /* buffer too small / index out of range */
-    FWGPU_ERR_FORMAT = 5   /* malformed record or weight blob */
+    FWGPU_ERR_FORMAT = 5,  /* malformed record, weight blob, cache or model file */
+    FWGPU_ERR_PARSE = 6,   /* the text parser rejected a line; fwgpu_last_error() holds the reference's message */
+    FWGPU_ERR_IO = 7,      /* file could not be opened / read / written */
+    /* not errors: commands the text parser hands back instead of a record (parser.rs:31-57) */
+    FWGPU_PARSE_FLUSH = 100,
+    FWGPU_PARSE_HOGWILD_LOAD = 101
 };
 
 /* model_instance.rs:24-28 `enum Optimizer` */
@@ -259,7 +264,60 @@ int fwgpu_debug_phase_ticks(fwgpu_regressor *r, int enable, uint64_t *out16);
 int fwgpu_debug_set_kernel_version(fwgpu_regressor *r, int version);
 /* Tuning switches for experiments. option 1: value 1 = read the AdaGrad LUT from global memory instead of an LDS copy. */
 int fwgpu_debug_set_option(fwgpu_regressor *r, int option, int value);
+/* an f32 as serde_json / ryu prints it in the embedded JSON documents ("0.1", "1.0", "1e-7"); NUL-terminated */
+int fwgpu_debug_format_f32(float v, char *buf, uint32_t cap);
 int fwgpu_debug_coherence_probe(int device, int use_sc1, uint32_t iters, uint32_t *stale_words, uint32_t *timeouts);
+
+/* ---------------------------------------------------------------- feed path: namespace map, VW text parser, input cache
+ * (SURVEY.md 8 f1/f3).  Host-side code; none of it needs a device.
+ *
+ * vw_namespace_map.csv (vwmap.rs:106-151): "vwname,verbose[,f32]" per line, namespace_index = line number,
+ * optional "_namespace_skip_prefix,N".  The JSON form is serde_json::to_vec_pretty(vw_source) as embedded in cache and
+ * model files (persistence.rs:36-53); fwgpu_vwmap_to_json reproduces it byte for byte (buf == NULL: size query). */
+typedef struct fwgpu_vwmap fwgpu_vwmap;
+int fwgpu_vwmap_from_csv(const char *csv, uint64_t len, fwgpu_vwmap **out);
+int fwgpu_vwmap_from_json(const char *json, uint64_t len, fwgpu_vwmap **out);
+void fwgpu_vwmap_free(fwgpu_vwmap *vw);
+uint32_t fwgpu_vwmap_num_namespaces(const fwgpu_vwmap *vw); /* max namespace_index + 1 (vwmap.rs:83-88) */
+uint32_t fwgpu_vwmap_num_entries(const fwgpu_vwmap *vw);
+int fwgpu_vwmap_to_json(const fwgpu_vwmap *vw, char *buf, uint64_t cap, uint64_t *len);
+/* name -> namespace_index / format; verbose != 0 looks the verbose name up (map_verbose_to_namespace_descriptor) */
+int fwgpu_vwmap_lookup(const fwgpu_vwmap *vw, const char *name, uint64_t len, int verbose, uint32_t *index,
+                       uint32_t *is_f32);
+
+/* VowpalParser (parser.rs:24-461).  fwgpu_parser_parse_line = next_vowpal_to_size on one line as read_until(b'\n')
+ * delivers it (the newline, when present, is part of `line`); the record (parser.rs:57-74) is copied to `out`
+ * (out == NULL: only *n_words).  len == 0 -> end of stream, *n_words = 0.  Returns FWGPU_OK, FWGPU_PARSE_FLUSH,
+ * FWGPU_PARSE_HOGWILD_LOAD (file name via fwgpu_parser_command_argument) or FWGPU_ERR_PARSE with the reference's
+ * message in fwgpu_last_error().  fwgpu_parser_parse_with_prefix = next_vowpal_with_cache (parser.rs:195-211): the
+ * cached context bytes followed by the request's bytes.  fwgpu_parser_parse_buffer parses many lines into records laid
+ * out back to back (rec_off: n_records + 1 word offsets), stopping at max_records, a full buffer, or the first line
+ * that is not an example (*consumed = bytes fully parsed; the return value says why it stopped). */
+typedef struct fwgpu_parser fwgpu_parser;
+int fwgpu_parser_create(const fwgpu_vwmap *vw, fwgpu_parser **out);
+void fwgpu_parser_free(fwgpu_parser *p);
+int fwgpu_parser_parse_line(fwgpu_parser *p, const char *line, uint64_t len, uint32_t *out, uint32_t cap, uint32_t *n_words);
+int fwgpu_parser_parse_with_prefix(fwgpu_parser *p, const char *prefix, uint64_t prefix_len, const char *line, uint64_t len,
+                                   uint32_t *out, uint32_t cap, uint32_t *n_words);
+const char *fwgpu_parser_command_argument(const fwgpu_parser *p);
+int fwgpu_parser_parse_buffer(fwgpu_parser *p, const char *text, uint64_t len, uint32_t *words, uint64_t words_cap,
+                              uint64_t *rec_off, uint64_t max_records, uint64_t *n_records, uint64_t *n_words,
+                              uint64_t *consumed);
+
+/* RecordCache (cache.rs:54-232).  fwgpu_cache_open(input, vw): if "<input>.fwcache" exists and its header ("FWCA",
+ * version 11, vw_source equal to `vw`) verifies, the cache is opened for reading; otherwise "<input>.fwcache.writing" is
+ * created for writing and renamed by fwgpu_cache_write_finish (cache.rs:70-131, 146-152).  Inputs whose name ends in
+ * "gz" use an LZ4 frame stream (cache.rs:73).  fwgpu_cache_next_records = bulk get_next_record: whole records into
+ * `words`, rec_off[0..n_records] word offsets; *n_records == 0 at end of file. */
+typedef struct fwgpu_cache fwgpu_cache;
+int fwgpu_cache_open(const char *input_filename, const fwgpu_vwmap *vw, fwgpu_cache **out);
+int fwgpu_cache_is_reading(const fwgpu_cache *c);
+int fwgpu_cache_is_writing(const fwgpu_cache *c);
+int fwgpu_cache_push_records(fwgpu_cache *c, const uint32_t *words, uint64_t n_words);
+int fwgpu_cache_write_finish(fwgpu_cache *c);
+int fwgpu_cache_next_records(fwgpu_cache *c, uint32_t *words, uint64_t words_cap, uint64_t *rec_off, uint64_t max_records,
+                             uint64_t *n_records, uint64_t *n_words);
+void fwgpu_cache_free(fwgpu_cache *c);
 
 /* ---------------------------------------------------------------- synthetic record streams
  * Generates records in the parser's output format (parser.rs:57-74) for the BASELINE.json configs:

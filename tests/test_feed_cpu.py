@@ -1,0 +1,245 @@
+"""Feed path on the CPU: namespace map, VW text parser against the reference's own known-answer tests
+(tests/golden/parser_kats.json), serde-compatible JSON, LZ4 frames against an independent implementation (pyarrow's
+liblz4), and the .fwcache reader / writer."""
+import ctypes as C
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import fwumious_wabbit_amd as fw
+from fwumious_wabbit_amd import capi
+from fwumious_wabbit_amd.feed import FlushCommand, HogwildLoadCommand, RecordCache, VowpalParser, VwNamespaceMap
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KATS = json.load(open(os.path.join(HERE, "golden", "parser_kats.json")))
+
+
+@pytest.mark.parametrize("group", KATS["groups"], ids=[g["name"] for g in KATS["groups"]])
+def test_parser_reference_kats(group):
+    vw = VwNamespaceMap(group["vwmap"])
+    rr = VowpalParser(vw)  # ONE parser for the whole group, like the reference tests: no state may leak between lines
+    for case in group["cases"]:
+        line = case["line"].encode()
+        if "error" in case:
+            with pytest.raises(capi.FwgpuError) as e:
+                rr.next_vowpal(line)
+            assert e.value.code == capi.ERR_PARSE and e.value.message == case["error"], case
+        elif case.get("command") == "flush":
+            with pytest.raises(FlushCommand):
+                rr.next_vowpal(line)
+        elif case.get("command") == "hogwild_load":
+            with pytest.raises(HogwildLoadCommand) as e:
+                rr.next_vowpal(line)
+            assert e.value.filename == case["filename"]
+        elif "cached" in case:
+            got = rr.next_vowpal_with_cache(case["cached"].encode(), line)
+            assert got.tolist() == case["record"], case
+        else:
+            got = rr.next_vowpal(line)
+            assert got.tolist() == case["record"], case
+            if "size" in case:  # next_vowpal_with_size: the line's length without its newline
+                assert len(line.rstrip(b"\n")) == case["size"]
+
+
+def test_vwmap_reference_kats():
+    for k in KATS["vwmap"]:
+        if "error" in k:
+            with pytest.raises(capi.FwgpuError) as e:
+                VwNamespaceMap(k["csv"])
+            assert e.value.message == k["error"]
+            continue
+        vw = VwNamespaceMap(k["csv"])
+        src = json.loads(vw.to_json())
+        assert src["namespace_skip_prefix"] == k["skip_prefix"]
+        got = [[e["namespace_vwname"], e["namespace_verbose"], e["namespace_index"], e["namespace_format"]] for e in src["entries"]]
+        assert got == k["entries"]
+        assert vw.num_namespaces == max(e[2] for e in k["entries"]) + 1
+
+
+def test_vw_source_json_is_serde_pretty_and_round_trips():
+    vw = VwNamespaceMap("A,featureA\nB,featureB,f32\n_namespace_skip_prefix,1\n")
+    expect = (b'{\n  "namespace_skip_prefix": 1,\n  "entries": [\n    {\n      "namespace_vwname": "A",\n'
+              b'      "namespace_verbose": "featureA",\n      "namespace_index": 0,\n      "namespace_format": "Categorical"\n'
+              b'    },\n    {\n      "namespace_vwname": "B",\n      "namespace_verbose": "featureB",\n'
+              b'      "namespace_index": 1,\n      "namespace_format": "F32"\n    }\n  ]\n}')
+    assert vw.to_json() == expect
+    vw2 = VwNamespaceMap.new_from_buf(expect)
+    assert vw2.to_json() == expect and vw2.lookup("B") == (1, True) and vw2.lookup("featureA", verbose=True) == (0, False)
+    assert VwNamespaceMap("").to_json() == b'{\n  "namespace_skip_prefix": 0,\n  "entries": []\n}'
+    with pytest.raises(capi.FwgpuError):
+        VwNamespaceMap.new_from_buf(b'{"namespace_skip_prefix": 0}')  # missing field `entries`
+
+
+def test_f32_text_matches_ryu_layout():
+    L = capi.lib()
+    buf = C.create_string_buffer(64)
+
+    def fmt(x):
+        capi.check(L.fwgpu_debug_format_f32(C.c_float(x), buf, 64))
+        return buf.value.decode()
+
+    known = {0.1: "0.1", 1.0: "1.0", 0.025: "0.025", 0.38: "0.38", 0.0: "0.0", -2.5: "-2.5", 1e-7: "1e-7", 1e-6: "0.000001",
+             1e-5: "0.00001", 1e12: "1000000000000.0", 1e13: "1e13", 1.5e10: "15000000000.0", 3.4028235e38: "3.4028235e38",
+             1.17549435e-38: "1.1754944e-38", 16777216.0: "16777216.0", 0.3: "0.3", 123456.79: "123456.79"}
+    for x, t in known.items():
+        assert fmt(x) == t, (x, fmt(x), t)
+    # every output parses back to the same f32 and is the shortest digit string numpy finds
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([rng.standard_normal(300).astype(np.float32) * np.float32(10.0) ** rng.integers(-12, 12, 300).astype(np.float32),
+                         rng.integers(0, 2 ** 32, 300, dtype=np.uint64).astype(np.uint32).view(np.float32)])
+    for x in xs[np.isfinite(xs)]:
+        t = fmt(float(x))
+        assert np.float32(t) == x
+        digits = np.format_float_scientific(x, unique=True, trim="-").split("e")[0].replace(".", "").replace("-", "")
+        assert t.replace(".", "").replace("-", "").split("e")[0].strip("0") == digits.strip("0"), (x, t, digits)
+
+
+def _frame_via_pyarrow(data: bytes) -> bytes:
+    pa = pytest.importorskip("pyarrow")
+    return pa.compress(data, codec="lz4", asbytes=True)  # arrow's "lz4" codec is the LZ4 FRAME format (liblz4)
+
+
+def _records(n, seed=3):
+    recs, off = fw.synth_records(6, 2.0, 1.1, 5000, 0.3, seed, 0, n)
+    return recs, off
+
+
+VW6 = "".join(f"{chr(65 + i)},ns{i}\n" for i in range(6))
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_cache_write_then_read(tmp_path, gz):
+    vw = VwNamespaceMap(VW6)
+    inp = str(tmp_path / ("train.vw.gz" if gz else "train.vw"))
+    recs, off = _records(3000)
+    rc = RecordCache(inp, True, vw)
+    assert rc.writing and not rc.reading and os.path.exists(inp + ".fwcache.writing")
+    for i in range(0, 3000, 500):  # pushed in pieces, like push_record per example
+        rc.push_records(recs[int(off[i]):int(off[i + 500])])
+    rc.write_finish()
+    rc.close()
+    assert os.path.exists(inp + ".fwcache") and not os.path.exists(inp + ".fwcache.writing")
+    raw = open(inp + ".fwcache", "rb").read()
+    if gz:
+        pa = pytest.importorskip("pyarrow")
+        assert raw[:4] == struct.pack("<I", 0x184D2204)
+        # an independent LZ4 implementation reads the frame we wrote
+        raw = pa.Codec("lz4").decompress(raw, decompressed_size=16 + len(vw.to_json()) + recs.nbytes, asbytes=True)
+        assert len(open(inp + ".fwcache", "rb").read()) < len(raw)  # and it did compress
+    # cache.rs:12-26 layout
+    assert raw[:4] == b"FWCA" and struct.unpack("<I", raw[4:8])[0] == 11
+    jl = struct.unpack("<Q", raw[8:16])[0]
+    assert raw[16:16 + jl] == vw.to_json()
+    assert raw[16 + jl:] == recs.tobytes()
+    # second open: reading mode; records come back identical, in bulk, across small buffers
+    rc = RecordCache(inp, True, vw)
+    assert rc.reading and not rc.writing
+    got, n = [], 0
+    while True:
+        w, o = rc.next_records(words_cap=4096, max_records=100)
+        if len(o) <= 1:
+            break
+        assert o[0] == 0 and o[-1] == len(w) and all(w[int(a)] == int(b) - int(a) for a, b in zip(o[:-1], o[1:]))
+        got.append(w)
+        n += len(o) - 1
+    assert n == 3000 and np.array_equal(np.concatenate(got), recs)
+    rc.close()
+    # a different namespace map invalidates the cache: it is rewritten (cache.rs:96-102, 177-182)
+    rc = RecordCache(inp, True, VwNamespaceMap(VW6 + "G,ns6\n"))
+    assert rc.writing and not rc.reading
+    rc.close()
+
+
+def test_cache_reads_frames_written_by_liblz4(tmp_path):
+    """the reference writes gz caches through liblz4 (linked blocks, content checksum): decode such a stream"""
+    vw = VwNamespaceMap(VW6)
+    recs, _ = _records(20000, seed=9)
+    js = vw.to_json()
+    payload = b"FWCA" + struct.pack("<I", 11) + struct.pack("<Q", len(js)) + js + recs.tobytes()
+    inp = str(tmp_path / "big.vw.gz")
+    with open(inp + ".fwcache", "wb") as f:
+        f.write(_frame_via_pyarrow(payload))
+    rc = RecordCache(inp, True, vw)
+    assert rc.reading
+    got = []
+    while True:
+        w, o = rc.next_records()
+        if len(o) <= 1:
+            break
+        got.append(w)
+    assert np.array_equal(np.concatenate(got), recs)
+    rc.close()
+    # a frame WITH a content checksum (ours has one, like the lz4 crate's default): a flipped payload byte is caught,
+    # by the block decoder or at the latest by the checksum at the end of the frame
+    inp2 = str(tmp_path / "own.vw.gz")
+    rc = RecordCache(inp2, True, vw)
+    rc.push_records(recs)
+    rc.write_finish()
+    rc.close()
+    raw = bytearray(open(inp2 + ".fwcache", "rb").read())
+    assert raw[4] & 0x04  # FLG.C_Checksum
+    raw[len(raw) // 2] ^= 0x55
+    open(inp2 + ".fwcache", "wb").write(bytes(raw))
+    rc = RecordCache(inp2, True, vw)
+    assert rc.reading
+    with pytest.raises(capi.FwgpuError):
+        while len(rc.next_records()[1]) > 1:
+            pass
+    rc.close()
+
+
+def test_cache_rejects_bad_headers(tmp_path):
+    vw = VwNamespaceMap(VW6)
+    inp = str(tmp_path / "x.vw")
+    js = vw.to_json()
+    for blob in (b"FWFW" + struct.pack("<I", 11) + struct.pack("<Q", len(js)) + js,   # wrong magic
+                 b"FWCA" + struct.pack("<I", 10) + struct.pack("<Q", len(js)) + js,   # older version
+                 b"FWCA" + struct.pack("<I", 11) + struct.pack("<Q", 5) + b"{bad}"):  # broken JSON
+        open(inp + ".fwcache", "wb").write(blob)
+        rc = RecordCache(inp, True, vw)
+        assert rc.writing and not rc.reading  # falls back to rebuilding the cache
+        rc.close()
+    # a file that ends inside a record
+    recs, off = _records(10)
+    open(inp + ".fwcache", "wb").write(b"FWCA" + struct.pack("<I", 11) + struct.pack("<Q", len(js)) + js + recs.tobytes()[:-8])
+    rc = RecordCache(inp, True, vw)
+    assert rc.reading
+    w, o = rc.next_records()
+    assert len(o) - 1 == 9
+    with pytest.raises(capi.FwgpuError):
+        rc.next_records()
+    rc.close()
+    assert not RecordCache(inp, False, vw).reading  # enabled = false: neither reads nor writes
+
+
+def test_text_to_records_in_bulk_equals_line_by_line():
+    vw = VwNamespaceMap(VW6)
+    rng = np.random.default_rng(11)
+    lines = []
+    for i in range(2000):
+        parts = [str(1 if rng.random() < 0.4 else -1)]
+        if rng.random() < 0.2:
+            parts.append(f"{rng.random() * 3:.3f}")
+        for ns in rng.permutation(6)[: rng.integers(1, 7)]:
+            feats = " ".join(f"f{rng.integers(0, 1000)}" + (f":{rng.random() * 2:.2f}" if rng.random() < 0.2 else "")
+                             for _ in range(rng.integers(1, 5)))
+            parts.append(f"|{chr(65 + ns)}" + (":0.5" if rng.random() < 0.1 else "") + " " + feats)
+        lines.append(" ".join(parts) + "\n")
+    text = "".join(lines).encode()
+    p = VowpalParser(vw)
+    one_by_one = [p.next_vowpal(l.encode()) for l in lines]
+    words, off, used, rc = p.parse_buffer(text)
+    assert rc == capi.OK and used == len(text) and len(off) == 2001
+    assert np.array_equal(words, np.concatenate(one_by_one))
+    # a command line stops the bulk parse exactly there
+    words2, off2, used2, rc2 = p.parse_buffer("".join(lines[:5]).encode() + b"flush\n" + lines[5].encode())
+    assert rc2 == capi.PARSE_FLUSH and len(off2) == 6 and used2 == len("".join(lines[:5]))
+    # records from text feed the translator like synthetic ones: hashes masked, values kept
+    mi = fw.ModelInstance(bit_precision=18, ffm_k=4, ffm_bit_precision=18, add_constant_feature=True,
+                          feature_combo_descs=[fw.FeatureComboDesc([fw.NamespaceDescriptor(i)]) for i in range(6)],
+                          ffm_fields=[[fw.NamespaceDescriptor(i)] for i in range(6)])
+    fb = fw.FeatureBufferTranslator(mi).translate(one_by_one[0])
+    assert len(fb.lr_buffer) >= 2 and fb.label in (0.0, 1.0)
