@@ -159,6 +159,16 @@ def lib():
         "fwgpu_parser_parse_line": [vp, C.c_char_p, u64, vp, u32, P(u32)],
         "fwgpu_parser_parse_with_prefix": [vp, C.c_char_p, u64, C.c_char_p, u64, vp, u32, P(u32)],
         "fwgpu_parser_parse_buffer": [vp, C.c_char_p, u64, vp, u64, vp, u64, P(u64), P(u64), P(u64)],
+        "fwgpu_mi_from_json": [C.c_char_p, u64, P(vp)],
+        "fwgpu_mi_to_json": [vp, vp, u64, P(u64)],
+        "fwgpu_mi_configs": [vp, i32, P(Config), P(TranslatorConfig), P(NNConfig)],
+        "fwgpu_mi_set_inference": [vp, i32],
+        "fwgpu_model_save": [C.c_char_p, vp, vp, vp, i32],
+        "fwgpu_model_read_header": [C.c_char_p, P(vp), P(vp)],
+        "fwgpu_model_load": [C.c_char_p, i32, i32, P(vp), P(vp), P(vp)],
+        "fwgpu_model_convert_inference": [C.c_char_p, C.c_char_p, i32],
+        "fwgpu_quantize_ffm_weights": [vp, u64, vp, u64],
+        "fwgpu_dequantize_ffm_weights": [vp, u64, vp],
         "fwgpu_cache_open": [C.c_char_p, vp, P(vp)],
         "fwgpu_cache_push_records": [vp, vp, u64],
         "fwgpu_cache_write_finish": [vp],
@@ -168,7 +178,7 @@ def lib():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = i32
-    for name in ("fwgpu_vwmap_free", "fwgpu_parser_free", "fwgpu_cache_free"):
+    for name in ("fwgpu_vwmap_free", "fwgpu_parser_free", "fwgpu_cache_free", "fwgpu_mi_free"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = None
     for name in ("fwgpu_vwmap_num_namespaces", "fwgpu_vwmap_num_entries"):

@@ -301,6 +301,10 @@ class Writer {
         sep();
         out += "null";
     }
+    void raw(const std::string &text) {
+        sep();
+        out += text;
+    }
 
   private:
     struct Level {

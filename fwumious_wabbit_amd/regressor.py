@@ -208,6 +208,15 @@ class Regressor:
             self.allocate_and_init_weights()
 
     @classmethod
+    def from_handle(cls, mi, handle):
+        """wrap a regressor the library created itself (fwgpu_model_load)"""
+        self = cls.__new__(cls)
+        self.L = capi.lib()
+        self.mi = mi
+        self.h = handle
+        return self
+
+    @classmethod
     def new_without_weights(cls, mi):  # regressor.rs:173
         return cls(mi, init_weights=False)
 

@@ -319,6 +319,37 @@ int fwgpu_cache_next_records(fwgpu_cache *c, uint32_t *words, uint64_t words_cap
                              uint64_t *n_records, uint64_t *n_words);
 void fwgpu_cache_free(fwgpu_cache *c);
 
+/* ---------------------------------------------------------------- model files
+ * File = "FWRE", u32 version 6, u64 + JSON(vw_source), u64 + JSON(ModelInstance), weights blob (persistence.rs:17-97,
+ * regressor.rs:426-469).  ModelInstance (model_instance.rs:47-97) crosses the boundary as an opaque handle made from /
+ * rendered to that JSON; fwgpu_mi_to_json reproduces serde_json::to_vec_pretty (nn layer keys sorted: the reference's
+ * HashMap order is arbitrary).  fwgpu_mi_configs fills the structs fwgpu_create / fwgpu_set_nn / the translator take
+ * (any of the three may be NULL); their array pointers stay valid while the handle lives.  Features of ModelInstance this
+ * path does not implement (transformed namespaces, nn topologies four/five, layernorm, dropout, maxnorm) are
+ * rejected there, never ignored. */
+typedef struct fwgpu_model_instance fwgpu_model_instance;
+int fwgpu_mi_from_json(const char *json, uint64_t len, fwgpu_model_instance **out);
+void fwgpu_mi_free(fwgpu_model_instance *mi);
+int fwgpu_mi_to_json(const fwgpu_model_instance *mi, char *buf, uint64_t cap, uint64_t *len);
+int fwgpu_mi_configs(fwgpu_model_instance *mi, int device, fwgpu_config *cfg, fwgpu_translator_config *tr,
+                     fwgpu_nn_config *nn);
+int fwgpu_mi_set_inference(fwgpu_model_instance *mi, int dequantize_weights); /* main.rs:141-145 */
+/* save_regressor_to_filename (persistence.rs:73-89); quantize_weights: FFM weights as f16 buckets (block_ffm.rs:835-848) */
+int fwgpu_model_save(const char *path, const fwgpu_vwmap *vw, const fwgpu_model_instance *mi, fwgpu_regressor *r,
+                     int quantize_weights);
+/* load_regressor_without_weights (persistence.rs:91-125): header only, no device */
+int fwgpu_model_read_header(const char *path, fwgpu_vwmap **vw, fwgpu_model_instance **mi);
+/* new_regressor_from_filename (persistence.rs:127-174).  *r == NULL: a regressor is created on `device` (immutable != 0:
+ * optimizer forced to SGD, only the weights kept).  *r != NULL: hogwild_load (persistence.rs:176-187), the weights
+ * are loaded into the existing regressor.  vw / mi may be NULL. */
+int fwgpu_model_load(const char *path, int device, int immutable, fwgpu_vwmap **vw, fwgpu_model_instance **mi,
+                     fwgpu_regressor **r);
+/* --convert_inference_regressor (main.rs:136-148): training file -> inference file; host only */
+int fwgpu_model_convert_inference(const char *in_path, const char *out_path, int quantize_weights);
+/* quantization.rs:42-98: out = 8-byte header {f32 increment, f32 min} + n f16 bucket numbers (8 + 2n bytes) */
+int fwgpu_quantize_ffm_weights(const float *weights, uint64_t n, uint8_t *out, uint64_t cap);
+int fwgpu_dequantize_ffm_weights(const uint8_t *in, uint64_t n, float *weights);
+
 /* ---------------------------------------------------------------- synthetic record streams
  * Generates records in the parser's output format (parser.rs:57-74) for the BASELINE.json configs:
  * n_namespaces namespaces == fields; per namespace 1+Poisson(mean_extra) features (exactly 1 when
