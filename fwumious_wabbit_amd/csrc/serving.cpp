@@ -1,0 +1,238 @@
+// The reference's serving FFI, same symbols and signatures (lib.rs:150-234): new_fw_predictor_prototype, clone_lite,
+// fw_predict, fw_predict_with_cache, fw_setup_cache, free_predictor -- a binary that links libfw.so can link this library
+// instead.  Each call parses the VW text, translates the record and runs the example kernel on the device.
+//
+// Context cache (lib.rs:88-148, block_ffm.rs:442-782, block_lr.rs:165-255): the reference pre-computes the context
+// features' partial sums once per request and finishes them per candidate.  One GPU launch per candidate gains
+// nothing from that; what fits the device is scoring ALL candidates of a request in one launch.  So fw_setup_cache keeps the
+// context text, fw_predict_with_cache scores context + candidate (the very line the reference reassembles in
+// next_vowpal_with_cache, parser.rs:195-211; identical result, the cache being an optimisation), and
+// fwgpu_predictor_predict_batch scores n candidates with one batched launch.
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "fw_ffi.h"
+#include "fwgpu_internal.h"
+
+using namespace fwgpu;
+
+namespace {
+
+struct SharedModel {  // what clone_lite shares: the immutable regressor and the descriptions it was built from
+    fwgpu_regressor *re = nullptr;
+    fwgpu_vwmap *vw = nullptr;
+    fwgpu_model_instance *mi = nullptr;
+    fwgpu_translator_config tr{};
+    uint32_t num_namespaces = 0;
+    std::mutex mu;  // the regressor's single-example staging buffers are shared
+    ~SharedModel() {
+        if (re) fwgpu_free(re);
+        if (vw) fwgpu_vwmap_free(vw);
+        if (mi) fwgpu_mi_free(mi);
+    }
+};
+
+// shellwords::split (lib.rs:161): whitespace separated words, '...' and "..." quoting, backslash escapes
+std::vector<std::string> shell_split(const char *s) {
+    std::vector<std::string> out;
+    std::string cur;
+    bool in_word = false;
+    char quote = 0;
+    for (const char *p = s; *p; ++p) {
+        const char c = *p;
+        if (quote) {
+            if (c == quote) quote = 0;
+            else if (c == '\\' && quote == '"' && p[1]) cur += *++p;
+            else cur += c;
+        } else if (c == '\'' || c == '"') {
+            quote = c;
+            in_word = true;
+        } else if (c == '\\' && p[1]) {
+            cur += *++p;
+            in_word = true;
+        } else if (c == ' ' || c == '\t' || c == '\n') {
+            if (in_word) out.push_back(cur);
+            cur.clear();
+            in_word = false;
+        } else {
+            cur += c;
+            in_word = true;
+        }
+    }
+    if (in_word) out.push_back(cur);
+    return out;
+}
+
+}  // namespace
+
+struct FfiPredictor {
+    std::shared_ptr<SharedModel> model;
+    fwgpu_parser *parser = nullptr;
+    std::string cached_text;  // PredictorCache.input_buffer_size bytes of the context line (lib.rs:64-67)
+    bool has_cache = false;
+    std::vector<uint32_t> record;
+    std::vector<fwgpu_lr_entry> lr;
+    std::vector<fwgpu_ffm_entry> ffm;
+    ~FfiPredictor() {
+        if (parser) fwgpu_parser_free(parser);
+    }
+};
+
+namespace {
+
+constexpr float kEofErrorCode = -1.0f, kExceptionErrorCode = -1.0f;  // lib.rs:47-48
+
+// parse -> translate -> predict (lib.rs:70-86)
+float predict_line(FfiPredictor *p, const char *prefix, size_t prefix_len, const char *text, size_t len) {
+    uint32_t n_words = 0;
+    p->record.resize(std::max<size_t>(p->record.size(), 4096));
+    int rc;
+    for (;;) {
+        rc = fwgpu_parser_parse_with_prefix(p->parser, prefix, prefix_len, text, len, p->record.data(), (uint32_t)p->record.size(), &n_words);
+        if (rc == FWGPU_ERR_RANGE && p->record.size() < (1u << 24)) {
+            p->record.resize(p->record.size() * 4);
+            continue;
+        }
+        break;
+    }
+    if (rc != FWGPU_OK) return kExceptionErrorCode;  // parse errors and commands alike ("Reading result ... returns error")
+    if (n_words == 0) return kEofErrorCode;
+    SharedModel &m = *p->model;
+    p->lr.resize(std::max<size_t>(p->lr.size(), 1024));
+    p->ffm.resize(std::max<size_t>(p->ffm.size(), 1024));
+    uint32_t n_lr = 0, n_ffm = 0;
+    float label = 0, imp = 0;
+    for (;;) {
+        rc = fwgpu_translate(&m.tr, p->record.data(), n_words, p->lr.data(), (uint32_t)p->lr.size(), &n_lr, p->ffm.data(),
+                             (uint32_t)p->ffm.size(), &n_ffm, &label, &imp);
+        if (rc == FWGPU_ERR_RANGE && p->lr.size() < (1u << 24)) {
+            p->lr.resize(p->lr.size() * 4);
+            p->ffm.resize(p->ffm.size() * 4);
+            continue;
+        }
+        break;
+    }
+    if (rc != FWGPU_OK) return kExceptionErrorCode;
+    float out = 0.0f;
+    std::lock_guard<std::mutex> g(m.mu);
+    rc = fwgpu_predict(m.re, p->lr.data(), n_lr, p->ffm.data(), n_ffm, &out);
+    return rc == FWGPU_OK ? out : kExceptionErrorCode;
+}
+
+}  // namespace
+
+extern "C" {
+
+FfiPredictor *new_fw_predictor_prototype(const char *command) {  // lib.rs:150-185
+    if (!command) {
+        set_error("new_fw_predictor_prototype: NULL command");
+        return nullptr;
+    }
+    const std::vector<std::string> words = shell_split(command);
+    std::string weights;
+    int device = 0;
+    for (size_t i = 0; i + 1 < words.size(); i++) {
+        if (words[i] == "-i" || words[i] == "--initial_regressor") weights = words[i + 1];
+        if (words[i] == "--device") device = std::atoi(words[i + 1].c_str());  // ours: which GPU serves
+    }
+    for (const auto &w : words)
+        if (w.rfind("--initial_regressor=", 0) == 0) weights = w.substr(std::strlen("--initial_regressor="));
+    if (weights.empty()) {
+        set_error("Cannot resolve input weights file name");  // the reference panics here (lib.rs:164-167)
+        return nullptr;
+    }
+    auto model = std::make_shared<SharedModel>();
+    if (fwgpu_model_load(weights.c_str(), device, /*immutable=*/1, &model->vw, &model->mi, &model->re) != FWGPU_OK) return nullptr;
+    if (fwgpu_mi_configs(model->mi, device, nullptr, &model->tr, nullptr) != FWGPU_OK) return nullptr;
+    model->num_namespaces = fwgpu_vwmap_num_namespaces(model->vw);
+    auto p = std::make_unique<FfiPredictor>();
+    p->model = model;
+    if (fwgpu_parser_create(model->vw, &p->parser) != FWGPU_OK) return nullptr;
+    return p.release();
+}
+
+FfiPredictor *clone_lite(FfiPredictor *prototype) {  // lib.rs:187-205: cheap copy, one per thread, shared weights
+    if (!prototype) return nullptr;
+    auto p = std::make_unique<FfiPredictor>();
+    p->model = prototype->model;
+    if (fwgpu_parser_create(p->model->vw, &p->parser) != FWGPU_OK) return nullptr;
+    return p.release();
+}
+
+float fw_predict(FfiPredictor *ptr, const char *input_buffer) {  // lib.rs:207-212
+    if (!ptr || !input_buffer) return kExceptionErrorCode;
+    return predict_line(ptr, nullptr, 0, input_buffer, std::strlen(input_buffer));
+}
+
+float fw_setup_cache(FfiPredictor *ptr, const char *input_buffer) {  // lib.rs:224-232, 110-147
+    if (!ptr || !input_buffer) return kExceptionErrorCode;
+    size_t len = std::strlen(input_buffer);
+    // the context line must itself parse (next_vowpal_with_size), and an empty one is EOF
+    uint32_t n_words = 0;
+    const int rc = fwgpu_parser_parse_line(ptr->parser, input_buffer, len, nullptr, 0, &n_words);
+    if (rc != FWGPU_OK) return kExceptionErrorCode;
+    if (n_words == 0) return kEofErrorCode;
+    if (len && input_buffer[len - 1] == '\n') len -= 1;  // "ignore last newline byte" (parser.rs:184-193)
+    ptr->cached_text.assign(input_buffer, len);
+    ptr->has_cache = true;
+    return 0.0f;
+}
+
+float fw_predict_with_cache(FfiPredictor *ptr, const char *input_buffer) {  // lib.rs:214-222, 88-108
+    if (!ptr || !input_buffer) return kExceptionErrorCode;
+    return predict_line(ptr, ptr->cached_text.data(), ptr->cached_text.size(), input_buffer, std::strlen(input_buffer));
+}
+
+void free_predictor(FfiPredictor *ptr) { delete ptr; }  // lib.rs:234-236
+
+// All candidates of a request in one launch.  inputs[i] is what fw_predict (with_cache == 0) or fw_predict_with_cache
+// (with_cache != 0) would be given; out[i] what it would return (-1.0 for a line that does not parse).
+int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, uint32_t n, int with_cache, float *out) {
+    if (!ptr || (!inputs && n) || (!out && n)) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    SharedModel &m = *ptr->model;
+    std::vector<uint32_t> words;
+    std::vector<uint64_t> off(1, 0);
+    std::vector<uint32_t> slot;  // which input each record belongs to
+    std::vector<uint32_t> rec(4096);
+    for (uint32_t i = 0; i < n; i++) {
+        out[i] = kExceptionErrorCode;
+        if (!inputs[i]) continue;
+        uint32_t nw = 0;
+        int rc;
+        for (;;) {
+            rc = fwgpu_parser_parse_with_prefix(ptr->parser, with_cache ? ptr->cached_text.data() : nullptr,
+                                                with_cache ? ptr->cached_text.size() : 0, inputs[i], std::strlen(inputs[i]),
+                                                rec.data(), (uint32_t)rec.size(), &nw);
+            if (rc == FWGPU_ERR_RANGE && rec.size() < (1u << 24)) {
+                rec.resize(rec.size() * 4);
+                continue;
+            }
+            break;
+        }
+        if (rc != FWGPU_OK || nw == 0) {
+            if (rc == FWGPU_OK) out[i] = kEofErrorCode;
+            continue;
+        }
+        rec[1] = 0;  // a request carries no label (NO_LABEL = 0xff); the prediction does not depend on it
+        words.insert(words.end(), rec.begin(), rec.begin() + nw);
+        off.push_back(words.size());
+        slot.push_back(i);
+    }
+    if (slot.empty()) return FWGPU_OK;
+    std::lock_guard<std::mutex> g(m.mu);
+    fwgpu_batch *b = nullptr;
+    int rc = fwgpu_record_batch_create(m.re, &m.tr, words.data(), off.data(), (uint32_t)slot.size(), &b);
+    if (rc != FWGPU_OK) return rc;
+    rc = fwgpu_learn_batch(m.re, b, FWGPU_MODE_HOGWILD, /*update=*/0, nullptr);
+    std::vector<float> preds(slot.size());
+    if (rc == FWGPU_OK) rc = fwgpu_batch_predictions(b, preds.data(), (uint32_t)preds.size(), nullptr);
+    fwgpu_batch_free(b);
+    if (rc != FWGPU_OK) return rc;
+    for (size_t j = 0; j < slot.size(); j++) out[slot[j]] = preds[j];
+    return FWGPU_OK;
+}
+
+}  // extern "C"

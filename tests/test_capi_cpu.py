@@ -27,6 +27,13 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
     assert capi.lib().fwgpu_abi_version() == 1
+    # the reference's serving FFI (lib.rs:150-236) under its own names
+    ffi = open(os.path.join(ROOT, "include", "fw_ffi.h")).read()
+    ffi = re.sub(r"/\*.*?\*/", "", ffi, flags=re.S)
+    ffi_names = re.findall(r"\b(\w+)\s*\(", ffi)
+    assert {"new_fw_predictor_prototype", "clone_lite", "fw_predict", "fw_predict_with_cache", "fw_setup_cache",
+            "free_predictor", "fwgpu_predictor_predict_batch"} <= set(ffi_names)
+    assert not [n for n in ffi_names if not hasattr(L, n)]
 
 
 def test_struct_layouts_match_header():

@@ -204,3 +204,51 @@ def test_text_to_cache_to_training_to_serving_chain(tmp_path):
         assert abs(server.predict(fbt_s.translate(rec)) - re.predict(fbt.translate(rec))) < 1e-7
     re.close()
     server.close()
+
+
+def test_serving_ffi_matches_the_regressor(tmp_path):
+    """lib.rs:150-236 through the exported reference symbols: fw_predict == Regressor::predict on the parsed line;
+    setup_cache + predict_with_cache == predicting the whole line (block_ffm.rs:1325-1447 test_ffm_k1_with_cache and
+    friends assert exactly this equality); the batched call == the single calls"""
+    from fwumious_wabbit_amd.serving import Predictor
+    vw = VwNamespaceMap(VW6)
+    mi, re, recs, off = _trained(fw.Optimizer.AdagradLUT, seed=61)
+    path = str(tmp_path / "model.fw")
+    P.save_regressor_to_filename(path, mi, vw, re)
+    pr = Predictor(f"fw -i {path} -t --foreground")
+    parser = VowpalParser(vw)
+    fbt = fw.FeatureBufferTranslator(mi)
+    rng = np.random.default_rng(5)
+
+    def feats(ns):
+        return f"|A{ns} " + " ".join(f"{rng.integers(0, 3000)}" + (f":{rng.random() * 2:.3f}" if rng.random() < 0.3 else "")
+                                      for _ in range(rng.integers(1, 4)))
+
+    lines = []
+    for _ in range(64):
+        lines.append(" ".join(feats(ns) for ns in rng.permutation(6)[: rng.integers(2, 7)]) + "\n")
+    want = np.array([re.predict(fbt.translate(parser.next_vowpal(l.encode()))) for l in lines], dtype=np.float32)
+    got = np.array([pr.predict(l) for l in lines], dtype=np.float32)
+    assert np.array_equal(got, want)
+    assert np.array_equal(pr.predict_batch(lines), want)
+    # context + candidates: the context namespaces first, each candidate adds the rest
+    ctx = "|A0 17 23:0.5 |A1 99 "
+    cands = [f"|A2 {i} |A3 {i * 7}:1.5 |A5 {i % 3}\n" for i in range(40)]
+    assert pr.setup_cache(ctx + "\n") == 0.0
+    with_cache = np.array([pr.predict_with_cache(c) for c in cands], dtype=np.float32)
+    whole = np.array([pr.predict(ctx + c) for c in cands], dtype=np.float32)
+    assert np.array_equal(with_cache, whole)
+    assert np.array_equal(pr.predict_batch(cands, with_cache=True), whole)
+    # a clone shares the weights, has its own (empty) cache
+    cl = pr.clone_lite()
+    assert cl.predict(lines[0]) == want[0] and cl.predict_with_cache(cands[0]) == pr.predict(cands[0])
+    # error codes (lib.rs:47-48): EOF and unparsable lines give -1.0; the batch marks only the bad entries
+    assert pr.predict("") == -1.0 and pr.predict("|UNKNOWN x\n") == -1.0 and pr.setup_cache("") == -1.0
+    mixed = pr.predict_batch([lines[0], "|UNKNOWN x\n", lines[1]])
+    assert mixed[0] == want[0] and mixed[1] == -1.0 and mixed[2] == want[1]
+    with pytest.raises(capi.FwgpuError):
+        Predictor("fw -t")  # "Cannot resolve input weights file name"
+    with pytest.raises(capi.FwgpuError):
+        Predictor(f"fw -i {path}.missing")
+    for x in (cl, pr, re):
+        x.close()
