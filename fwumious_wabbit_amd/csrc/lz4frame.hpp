@@ -88,8 +88,8 @@ class XXH32 {
     size_t fill_;
 };
 
-// Decodes one LZ4 block appending to `out` (which may already hold history the block refers back to).
-inline void decode_block(const uint8_t *src, size_t n, std::vector<uint8_t> &out) {
+// Decodes one LZ4 block into buf[pos..cap); buf[0..pos) is history the block may refer back to.  Returns the new end.
+inline size_t decode_block(const uint8_t *src, size_t n, uint8_t *buf, size_t pos, size_t cap) {
     const uint8_t *p = src, *e = src + n;
     while (p < e) {
         const unsigned tok = *p++;
@@ -103,13 +103,15 @@ inline void decode_block(const uint8_t *src, size_t n, std::vector<uint8_t> &out
             } while (b == 255);
         }
         if ((size_t)(e - p) < lit) throw std::runtime_error("LZ4: literals run past the block");
-        out.insert(out.end(), p, p + lit);
+        if (cap - pos < lit) throw std::runtime_error("LZ4: block decodes past the declared maximum");
+        std::memcpy(buf + pos, p, lit);
+        pos += lit;
         p += lit;
         if (p >= e) break;  // the last sequence has no match part
         if (e - p < 2) throw std::runtime_error("LZ4: truncated offset");
         const size_t offset = (size_t)p[0] | ((size_t)p[1] << 8);
         p += 2;
-        if (offset == 0 || offset > out.size()) throw std::runtime_error("LZ4: offset outside the window");
+        if (offset == 0 || offset > pos) throw std::runtime_error("LZ4: offset outside the window");
         size_t ml = tok & 15;
         if (ml == 15) {
             unsigned b;
@@ -120,10 +122,19 @@ inline void decode_block(const uint8_t *src, size_t n, std::vector<uint8_t> &out
             } while (b == 255);
         }
         ml += 4;
-        size_t from = out.size() - offset;
-        out.reserve(out.size() + ml);
-        for (size_t i = 0; i < ml; i++) out.push_back(out[from + i]);  // byte-wise: overlapping copies replicate
+        if (cap - pos < ml) throw std::runtime_error("LZ4: block decodes past the declared maximum");
+        // overlapping copies replicate the last `offset` bytes: copy in non-overlapping pieces that double each time
+        uint8_t *d = buf + pos;
+        const uint8_t *sfrom = d - offset;
+        size_t done = 0;
+        while (done < ml) {
+            const size_t piece = std::min(ml - done, offset + done);
+            std::memcpy(d + done, sfrom, piece);
+            done += piece;
+        }
+        pos += ml;
     }
+    return pos;
 }
 
 // Greedy single-pass LZ4 block compressor (hash of 4 bytes -> last position).  Returns the compressed size.
@@ -182,10 +193,10 @@ class FrameReader {
     size_t read(uint8_t *dst, size_t n) {
         size_t got = 0;
         while (got < n) {
-            if (pos_ == window_.size()) {
+            if (pos_ == end_) {
                 if (done_ || !next_block()) break;
             }
-            const size_t take = std::min(n - got, window_.size() - pos_);
+            const size_t take = std::min(n - got, end_ - pos_);
             std::memcpy(dst + got, window_.data() + pos_, take);
             pos_ += take;
             got += take;
@@ -199,7 +210,7 @@ class FrameReader {
     bool block_indep_ = true, block_checksum_ = false, content_checksum_ = false;
     size_t max_block_ = 0;
     std::vector<uint8_t> window_, block_;
-    size_t pos_ = 0;
+    size_t pos_ = 0, end_ = 0;  // window_[pos_..end_) = decoded bytes not handed out yet; [0..pos_) = history
     XXH32 content_hash_;
 
     void need(uint8_t *b, size_t n, const char *what) {
@@ -261,8 +272,7 @@ class FrameReader {
                 if (rd32(b) != content_hash_.digest()) throw std::runtime_error("LZ4 frame: content checksum mismatch");
             }
             header_read_ = false;  // a concatenated frame may follow
-            window_.clear();
-            pos_ = 0;
+            pos_ = end_ = 0;
             read_header();
             if (done_) return false;
             return next_block();
@@ -277,13 +287,17 @@ class FrameReader {
             if (rd32(b) != XXH32::hash(block_.data(), len)) throw std::runtime_error("LZ4 frame: block checksum mismatch");
         }
         // keep the last 64 KiB as history for linked blocks, drop everything already handed out
-        size_t keep = block_indep_ ? 0 : std::min<size_t>(window_.size(), 65536);
-        if (keep < window_.size()) window_.erase(window_.begin(), window_.end() - (long)keep);
-        pos_ = window_.size();
-        if (raw) window_.insert(window_.end(), block_.begin(), block_.end());
-        else decode_block(block_.data(), len, window_);
-        if (window_.size() - pos_ > max_block_) throw std::runtime_error("LZ4 frame: block decodes past the declared maximum");
-        if (content_checksum_) content_hash_.update(window_.data() + pos_, window_.size() - pos_);
+        const size_t keep = block_indep_ ? 0 : std::min<size_t>(end_, 65536);
+        if (window_.size() < 65536 + max_block_) window_.resize(65536 + max_block_);
+        if (keep && end_ > keep) std::memmove(window_.data(), window_.data() + end_ - keep, keep);
+        pos_ = keep;
+        if (raw) {
+            std::memcpy(window_.data() + pos_, block_.data(), len);
+            end_ = pos_ + len;
+        } else {
+            end_ = decode_block(block_.data(), len, window_.data(), pos_, pos_ + max_block_);
+        }
+        if (content_checksum_) content_hash_.update(window_.data() + pos_, end_ - pos_);
         return true;
     }
 };

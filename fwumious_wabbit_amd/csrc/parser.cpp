@@ -44,7 +44,39 @@ struct fwgpu_parser {
     fwgpu_vwmap vw_copy;
     std::vector<uint32_t> seed;  // murmur3::hash32(vwname) per entry (parser.rs:83)
     std::vector<uint32_t> out;   // output_buffer
+    std::string scratch;         // padded copy of a line that has no readable byte after it
     std::string cmd_arg;         // filename of the last hogwild_load command
+    // vwname -> entry: the reference walks a 256-ary radix tree (radix_tree.rs); a small open-addressing table on the
+    // name's bytes does the same exact-match lookup without allocating
+    std::vector<int32_t> ns_table;
+    uint32_t ns_mask = 0;
+    static uint32_t name_hash(const unsigned char *s, size_t n) {
+        uint32_t h = 2166136261u;
+        for (size_t i = 0; i < n; i++) h = (h ^ s[i]) * 16777619u;
+        return h;
+    }
+    void build_ns_table() {
+        uint32_t cap = 16;
+        while (cap < 4 * vw_copy.entries.size()) cap <<= 1;
+        ns_table.assign(cap, -1);
+        ns_mask = cap - 1;
+        for (size_t i = 0; i < vw_copy.entries.size(); i++) {
+            const std::string &nm = vw_copy.entries[i].vwname;
+            // later entries with the same vwname replace earlier ones, like HashMap::insert (vwmap.rs:75-78)
+            uint32_t slot = name_hash(reinterpret_cast<const unsigned char *>(nm.data()), nm.size()) & ns_mask;
+            while (ns_table[slot] >= 0 && vw_copy.entries[ns_table[slot]].vwname != nm) slot = (slot + 1) & ns_mask;
+            ns_table[slot] = (int32_t)i;
+        }
+    }
+    int find_ns(const unsigned char *s, size_t n) const {
+        uint32_t slot = name_hash(s, n) & ns_mask;
+        while (ns_table[slot] >= 0) {
+            const std::string &nm = vw_copy.entries[ns_table[slot]].vwname;
+            if (nm.size() == n && std::memcmp(nm.data(), s, n) == 0) return ns_table[slot];
+            slot = (slot + 1) & ns_mask;
+        }
+        return -1;
+    }
 };
 
 namespace fwgpu {
@@ -164,9 +196,8 @@ static int parse_line(fwgpu_parser *ps, const char *line, size_t size) {
     std::vector<uint32_t> &ob = ps->out;
     const size_t bufpos = vw.num_namespaces + kHeaderLen;
     ob.assign(bufpos, kNoFeatures);
-    std::string padded(line, size);
-    padded.append(2, '\0');
-    const unsigned char *p = reinterpret_cast<const unsigned char *>(padded.data());
+    // `line` has at least one readable byte after `size` (callers copy the rare line that does not)
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(line);
     size_t i_start, i_end = 0;
     auto parse_float_or_error = [&](size_t a, size_t b, const char *what, float *out) -> int {
         if (b - a == 4 && std::memcmp(p + a, "NONE", 4) == 0) {  // parser.rs:123-130
@@ -252,12 +283,12 @@ static int parse_line(fwgpu_parser *ps, const char *line, size_t size) {
             } else {
                 ns_weight = 1.0f;
             }
-            const std::string name(reinterpret_cast<const char *>(p + i_start), i_end_first - i_start);
-            auto it = vw.by_vwname.find(name);
-            if (it == vw.by_vwname.end())
-                return fail(FWGPU_ERR_PARSE, "Feature name was not predeclared in vw_namespace_map.csv: " + name);
-            const VwEntry &e = vw.entries[it->second];
-            ns_seed = ps->seed[it->second];
+            const int ei = ps->find_ns(p + i_start, i_end_first - i_start);
+            if (ei < 0)
+                return fail(FWGPU_ERR_PARSE, "Feature name was not predeclared in vw_namespace_map.csv: " +
+                                                 std::string(reinterpret_cast<const char *>(p + i_start), i_end_first - i_start));
+            const VwEntry &e = vw.entries[ei];
+            ns_seed = ps->seed[ei];
             ns_slot = e.index + kHeaderLen;
             ns_f32 = e.f32;
             ns_count = 0;
@@ -426,6 +457,7 @@ int fwgpu_parser_create(const fwgpu_vwmap *vw, fwgpu_parser **out) {
     p->vw = &p->vw_copy;
     for (const auto &e : vw->entries)  // murmur3::hash32(vwname): seed 0 (parser.rs:82-84)
         p->seed.push_back(murmur3_32(reinterpret_cast<const uint8_t *>(e.vwname.data()), e.vwname.size(), 0));
+    p->build_ns_table();
     *out = p.release();
     return FWGPU_OK;
 }
@@ -436,7 +468,9 @@ int fwgpu_parser_parse_line(fwgpu_parser *p, const char *line, uint64_t len, uin
     if (!p || !n_words || (!line && len)) return fail(FWGPU_ERR_INVALID, "NULL argument");
     *n_words = 0;
     if (len == 0) return FWGPU_OK;  // end of stream: empty record (parser.rs:172)
-    const int rc = parse_line(p, line, len);
+    p->scratch.assign(line, len);
+    p->scratch.push_back('\0');
+    const int rc = parse_line(p, p->scratch.data(), len);
     if (rc != FWGPU_OK) return rc;
     *n_words = (uint32_t)p->out.size();
     if (!out) return FWGPU_OK;
@@ -472,7 +506,14 @@ int fwgpu_parser_parse_buffer(fwgpu_parser *p, const char *text, uint64_t len, u
     while (pos < len && nr < max_records) {
         const char *nl = static_cast<const char *>(std::memchr(text + pos, '\n', len - pos));
         const uint64_t line_len = nl ? (uint64_t)(nl - (text + pos)) + 1 : len - pos;
-        const int rc = parse_line(p, text + pos, line_len);
+        int rc;
+        if (pos + line_len < len) {
+            rc = parse_line(p, text + pos, line_len);  // in place: the next line's first byte is readable
+        } else {
+            p->scratch.assign(text + pos, line_len);
+            p->scratch.push_back('\0');
+            rc = parse_line(p, p->scratch.data(), line_len);
+        }
         if (rc != FWGPU_OK) {
             *n_records = nr;
             *n_words = nw;
