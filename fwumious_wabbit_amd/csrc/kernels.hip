@@ -331,36 +331,28 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
         for (uint32_t i = tid; i < rec_len; i += bd) s.rec[i] = grec[i];
         __syncthreads();
         tk.stamp(8);
-        // Wave 0 builds the ffm_buffer, wave 1 the lr_buffer: per 64 items count -> wave scan -> emit, all inside one
-        // wave, so no workgroup barrier is needed between the steps.
+        // Two steps.  (1) wave 0 counts the features of every (field, namespace) pair, wave 1 the entries of every LR
+        // combo, each with a wave64 prefix scan -> start offsets in LDS.  (2) after a barrier EVERY thread emits one
+        // output entry: it finds its pair / combo by binary search in the offsets and decodes its own feature(s), so the
+        // emit is one step deep instead of "features per namespace" steps on two waves.
+        uint32_t *ffm_base = s.tcnt;            // [NP + 1]
+        uint32_t *lr_base = s.tcnt + NP + 1;    // [NC + 1]
         if (wave == 0) {
-            // ffm_buffer, ordered by field (feature_buffer.rs:314-335)
             uint32_t carry = 0;
             for (uint32_t b0 = 0; b0 < NP; b0 += 64) {
                 const uint32_t j = b0 + lane;
                 const bool on = j < NP && k_nonzero(p.k);
-                const uint32_t ns = on ? t.pair_ns[j] : 0;
-                const uint32_t cnt = on ? slot_count(s.rec, ns) : 0;
+                const uint32_t cnt = on ? slot_count(s.rec, t.pair_ns[j]) : 0;
                 const uint32_t inc = wave_scan_incl(cnt, lane);
-                const uint32_t base = carry + inc - cnt;
-                if (on) {
-                    const bool f32 = t.pair_f32[j] != 0;
-                    const uint32_t fld = t.pair_field[j];
-                    for (uint32_t q = 0; q < cnt; ++q) {
-                        uint32_t h;
-                        float v;
-                        slot_get(s.rec, ns, f32, q, h, v);
-                        s.e_hash[base + q] = h & t.ffm_mask;
-                        s.e_val[base + q] = v;
-                        s.e_fld[base + q] = fld;
-                    }
-                }
+                if (j < NP) ffm_base[j] = carry + inc - cnt;
                 carry += (uint32_t)__shfl((int)inc, 63, 64);
             }
-            if (lane == 0) s.ctr[4] = carry;
+            if (lane == 0) {
+                ffm_base[NP] = carry;
+                s.ctr[4] = carry;
+            }
         }
         if (wave == (bd > 64 ? 1 : 0)) {
-            // lr_buffer (feature_buffer.rs:194-276): hash = (h_prev * 16777619) ^ h_next, values multiply
             uint32_t carry = 0;
             for (uint32_t b0 = 0; b0 < NC; b0 += 64) {
                 const uint32_t c = b0 + lane;
@@ -369,46 +361,73 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
                 uint32_t total = on ? 1 : 0;
                 for (uint32_t m = m0; m < m1; ++m) total *= slot_count(s.rec, t.combo_ns[m]);
                 const uint32_t inc = wave_scan_incl(total, lane);
-                const uint32_t base = carry + inc - total;
-                if (on) {
-                    const float cw = t.combo_w[c];
-                    for (uint32_t idx = 0; idx < total; ++idx) {
-                        // digits of idx, first namespace most significant (the reference's loop nesting)
-                        uint32_t rem = idx, div = total;
-                        uint32_t hash = 0;
-                        float val = 1.0f;
-                        for (uint32_t m = m0; m < m1; ++m) {
-                            const uint32_t cm = slot_count(s.rec, t.combo_ns[m]);
-                            div /= cm;
-                            const uint32_t q = rem / div;
-                            rem -= q * div;
-                            uint32_t h;
-                            float v;
-                            slot_get(s.rec, t.combo_ns[m], t.combo_f32[m] != 0, q, h, v);
-                            if (m == m0) {
-                                hash = h;
-                                val = v;
-                            } else {
-                                hash = (hash * 16777619u) ^ h;  // feature_buffer.rs:242-251 (wrapping)
-                                val = val * v;
-                            }
-                        }
-                        s.l_hash[base + idx] = hash & t.lr_mask;
-                        s.l_val[base + idx] = val * cw;
-                        if (p.nn.n_layers) s.l_combo[base + idx] = c;
-                    }
-                }
+                if (c < NC) lr_base[c] = carry + inc - total;
                 carry += (uint32_t)__shfl((int)inc, 63, 64);
             }
-            if (p.has_lr && t.add_const) {  // feature_buffer.rs:270-276
-                if (lane == 0) {
+            if (lane == 0) {
+                lr_base[NC] = carry;
+                const bool add_const = p.has_lr && t.add_const;
+                if (add_const) {  // feature_buffer.rs:270-276
                     s.l_hash[carry] = 11650396u & t.lr_mask;
                     s.l_val[carry] = 1.0f;
                     if (p.nn.n_layers) s.l_combo[carry] = NC;
                 }
-                carry += 1;
+                s.ctr[5] = carry + (add_const ? 1u : 0u);
             }
-            if (lane == 0) s.ctr[5] = carry;
+        }
+        __syncthreads();
+        // ffm_buffer, ordered by field (feature_buffer.rs:314-335): entry e belongs to the last pair whose start <= e
+        const uint32_t nf_all = s.ctr[4];
+        for (uint32_t e = tid; e < nf_all; e += bd) {
+            uint32_t lo_ = 0, hi_ = NP;  // invariant: ffm_base[lo_] <= e < ffm_base[hi_]
+            while (hi_ - lo_ > 1) {
+                const uint32_t mid = (lo_ + hi_) >> 1;
+                if (ffm_base[mid] <= e) lo_ = mid;
+                else hi_ = mid;
+            }
+            const uint32_t j = lo_;
+            uint32_t h;
+            float v;
+            slot_get(s.rec, t.pair_ns[j], t.pair_f32[j] != 0, e - ffm_base[j], h, v);
+            s.e_hash[e] = h & t.ffm_mask;
+            s.e_val[e] = v;
+            s.e_fld[e] = t.pair_field[j];
+        }
+        // lr_buffer (feature_buffer.rs:194-276): hash = (h_prev * 16777619) ^ h_next, values multiply.  Threads are
+        // taken from the top of the workgroup so that the waves busy with the ffm_buffer above are not the same ones.
+        const uint32_t nl_combo = lr_base[NC];
+        for (uint32_t e = (uint32_t)(bd - 1 - tid); e < nl_combo; e += bd) {
+            uint32_t lo_ = 0, hi_ = NC;
+            while (hi_ - lo_ > 1) {
+                const uint32_t mid = (lo_ + hi_) >> 1;
+                if (lr_base[mid] <= e) lo_ = mid;
+                else hi_ = mid;
+            }
+            const uint32_t c = lo_;
+            const uint32_t m0 = t.combo_off[c], m1 = t.combo_off[c + 1];
+            // digits of the entry's index within the combo, first namespace most significant (the reference's loop nesting)
+            uint32_t rem = e - lr_base[c], div = lr_base[c + 1] - lr_base[c];
+            uint32_t hash = 0;
+            float val = 1.0f;
+            for (uint32_t m = m0; m < m1; ++m) {
+                const uint32_t cm = slot_count(s.rec, t.combo_ns[m]);
+                div /= cm;
+                const uint32_t q = rem / div;
+                rem -= q * div;
+                uint32_t h;
+                float v;
+                slot_get(s.rec, t.combo_ns[m], t.combo_f32[m] != 0, q, h, v);
+                if (m == m0) {
+                    hash = h;
+                    val = v;
+                } else {
+                    hash = (hash * 16777619u) ^ h;  // feature_buffer.rs:242-251 (wrapping)
+                    val = val * v;
+                }
+            }
+            s.l_hash[e] = hash & t.lr_mask;
+            s.l_val[e] = val * t.combo_w[c];
+            if (p.nn.n_layers) s.l_combo[e] = c;
         }
         __syncthreads();
         tk.stamp(9);
