@@ -96,6 +96,79 @@ __global__ void atomic_rows(float *w, float *a, const uint32_t *rows, uint32_t n
     }
 }
 
+// ---- interleaved layout experiment: ONE table, per 8-float block [8 x w][8 x acc] (64 B), so a feature's row is 2R
+// contiguous floats (64 B aligned): the forward pass reads the w halves (32 of every 64 B), the update reads the acc halves
+// and writes whole 64 B blocks.
+template <int AUX, int U>
+__global__ void read_rows_il(const float *tab, const uint32_t *rows, uint32_t nrows, uint32_t R, float *sink) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t voff = (lane >> 1) * 64 + (lane & 1) * 16;  // w half of block lane/2
+    f4 acc = {0, 0, 0, 0};
+    for (uint32_t i = wave * U; i < nrows; i += nwaves * U) {
+        u4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t r = i + u < nrows ? i + u : i;
+            const uint32_t h = __builtin_amdgcn_readfirstlane(rows[r]);
+            v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc(tab + 2 * (size_t)h, R * 8), voff, 0, AUX);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += __builtin_bit_cast(f4, v[u]);
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 123.456f) sink[0] = acc.x;
+}
+template <int U, bool LOAD_W>
+__global__ void rmw_rows_il(float *tab, const uint32_t *rows, uint32_t nrows, uint32_t R) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t voff = (lane >> 1) * 64 + (lane & 1) * 16;
+    for (uint32_t i = wave * U; i < nrows; i += nwaves * U) {
+        u4 vw[U], va[U];
+        uint32_t h[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t r = i + u < nrows ? i + u : i;
+            h[u] = __builtin_amdgcn_readfirstlane(rows[r]);
+            vw[u] = u4{1, 2, 3, (unsigned)i};
+            if (LOAD_W) vw[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc(tab + 2 * (size_t)h[u], R * 8), voff, 0, 16);
+            va[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc(tab + 2 * (size_t)h[u], R * 8), voff + 32, 0, 16);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            f4 x = __builtin_bit_cast(f4, vw[u]), y = __builtin_bit_cast(f4, va[u]);
+            y += x * x;
+            x -= y * 1e-9f;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, x), rsrc(tab + 2 * (size_t)h[u], R * 8), voff, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, y), rsrc(tab + 2 * (size_t)h[u], R * 8), voff + 32, 0, 16);
+        }
+    }
+}
+// same access pattern on the current layout (two tables), w kept from the forward pass: read acc, write w and acc
+template <int U>
+__global__ void upd_rows_sep(float *w, float *a, const uint32_t *rows, uint32_t nrows, uint32_t R) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t i = wave * U; i < nrows; i += nwaves * U) {
+        u4 va[U];
+        uint32_t h[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t r = i + u < nrows ? i + u : i;
+            h[u] = __builtin_amdgcn_readfirstlane(rows[r]);
+            va[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc(a + h[u], R * 4), lane * 16, 0, 16);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            f4 x = {1.0f, 2.0f, 3.0f, (float)i}, y = __builtin_bit_cast(f4, va[u]);
+            y += x * x;
+            x -= y * 1e-9f;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, x), rsrc(w + h[u], R * 4), lane * 16, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, y), rsrc(a + h[u], R * 4), lane * 16, 0, 16);
+        }
+    }
+}
+
 __global__ void stream_read(const f4 *tab, size_t n, float *sink) {
     f4 acc = {0, 0, 0, 0};
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc += tab[i];
@@ -130,13 +203,15 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&rows, nrows * 4));
     CK(hipMemset(w, 0, (tab_floats + 64) * 4));
     CK(hipMemset(a, 0, (tab_floats + 64) * 4));
+    const uint32_t align_mask = argc > 3 ? (uint32_t)atoi(argv[3]) - 1 : 7u;  // row start granularity in floats
+    printf("row starts aligned to %u floats\n", align_mask + 1);
     std::vector<uint32_t> h(nrows);
     uint64_t s = 88172645463325252ull;
     for (auto &x : h) {
         s ^= s << 13;
         s ^= s >> 7;
         s ^= s << 17;
-        x = (uint32_t)(s >> 20) & ((1u << 28) - 1) & ~7u;
+        x = (uint32_t)(s >> 20) & ((1u << 28) - 1) & ~align_mask;
     }
     CK(hipMemcpy(rows, h.data(), nrows * 4, hipMemcpyHostToDevice));
     const double row_bytes = (double)nrows * R * 4;
@@ -144,6 +219,26 @@ int main(int argc, char **argv) {
     {
         float ms = time_ms([&] { hipLaunchKernelGGL(stream_read, dim3(2048), dim3(256), 0, 0, (const f4 *)w, tab_floats / 4, sink); });
         printf("stream read 1 GiB                         : %7.3f ms  %7.1f GB/s\n", ms, tab_floats * 4 / ms / 1e6);
+    }
+    if (argc > 2) {  // layout experiment only: rowbw 240 il
+        float *il;
+        CK(hipMalloc(&il, (2 * tab_floats + 256) * 4));
+        CK(hipMemset(il, 0, (2 * tab_floats + 256) * 4));
+        for (int wpc : {16, 32}) {
+            const int blocks = 256 * wpc / 4;
+#define T(name, mult, ...)                                                                                   \
+    {                                                                                                        \
+        float ms = time_ms([&] { __VA_ARGS__; });                                                            \
+        printf("%-44s waves/CU=%2d : %7.3f ms  %7.1f GB/s (%d x row bytes)\n", name, wpc, ms, mult * row_bytes / ms / 1e6, mult); \
+    }
+            T("separate: forward read w", 1, hipLaunchKernelGGL((read_rows<16, 4>), dim3(blocks), dim3(256), 0, 0, w, rows, nrows, R, sink));
+            T("interleaved: forward read w halves", 1, hipLaunchKernelGGL((read_rows_il<16, 4>), dim3(blocks), dim3(256), 0, 0, il, rows, nrows, R, sink));
+            T("separate: read acc, write w + acc", 3, hipLaunchKernelGGL((upd_rows_sep<4>), dim3(blocks), dim3(256), 0, 0, w, a, rows, nrows, R));
+            T("interleaved: read acc, write 64 B blocks", 3, hipLaunchKernelGGL((rmw_rows_il<4, false>), dim3(blocks), dim3(256), 0, 0, il, rows, nrows, R));
+            T("separate: read w + acc, write both", 4, hipLaunchKernelGGL((rmw_rows<4>), dim3(blocks), dim3(256), 0, 0, w, a, rows, nrows, R));
+            T("interleaved: read + write whole blocks", 4, hipLaunchKernelGGL((rmw_rows_il<4, true>), dim3(blocks), dim3(256), 0, 0, il, rows, nrows, R));
+        }
+        return 0;
     }
     for (int wpc : {8, 16, 24, 32}) {  // waves per CU
         const int blocks = 256 * wpc / 4;  // 256-thread blocks
