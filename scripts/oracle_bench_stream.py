@@ -8,6 +8,7 @@ import bench
 from oracle import fwo
 class A: pass
 args = A(); args.fields, args.k, args.bits, args.ffm_bits = 30, 8, 28, 28
+args.nn_layers, args.nn_width = 0, 256
 args.mean_extra, args.zipf, args.ids, args.p_weighted, args.seed = 5.67, 1.05, 10_000_000, 0.1, 20240612
 n_train = int(sys.argv[1]) if len(sys.argv) > 1 else 14 * 16384
 threads = int(sys.argv[2]) if len(sys.argv) > 2 else 1
