@@ -169,6 +169,7 @@ def lib():
         "fwgpu_model_convert_inference": [C.c_char_p, C.c_char_p, i32],
         "fwgpu_quantize_ffm_weights": [vp, u64, vp, u64],
         "fwgpu_dequantize_ffm_weights": [vp, u64, vp],
+        "fwgpu_trainer_digest_cache": [vp, vp, u64, P(u64)],
         "fwgpu_cache_open": [C.c_char_p, vp, P(vp)],
         "fwgpu_cache_push_records": [vp, vp, u64],
         "fwgpu_cache_write_finish": [vp],

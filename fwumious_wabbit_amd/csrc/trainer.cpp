@@ -32,6 +32,10 @@ struct fwgpu_trainer {
     int cur = 0;
     hipStream_t stream = nullptr;
     uint64_t seen = 0;
+    // chunk buffers of fwgpu_trainer_digest_cache
+    std::unique_ptr<uint32_t[]> cache_words[2];
+    std::unique_ptr<uint64_t[]> cache_off[2];
+    uint64_t cache_off_cap = 0;
 };
 
 static int flush(fwgpu_trainer *tr) {
@@ -163,6 +167,61 @@ int fwgpu_digest_records(fwgpu_trainer *tr, const uint32_t *records, const uint6
         }
     }
     return FWGPU_OK;
+}
+
+// Cache file -> trainer without leaving native code (main.rs:213-270 with a cache: get_next_record -> digest_example).
+// A reader thread fills one chunk from the file while the previous chunk is copied to pinned memory and shipped.
+int fwgpu_trainer_digest_cache(fwgpu_trainer *tr, fwgpu_cache *cache, uint64_t max_records, uint64_t *n_digested) {
+    if (!tr || !cache) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    const uint64_t chunk_records = std::max<uint64_t>(4 * (uint64_t)tr->micro_batch, 65536);
+    const uint64_t chunk_words = 8ull << 20;  // 32 MiB of records per chunk
+    struct Chunk {
+        uint32_t *words = nullptr;
+        uint64_t *off = nullptr;
+        uint64_t n = 0, nw = 0;
+        int rc = FWGPU_OK;
+        std::string msg;
+    } chunks[2];
+    for (int k = 0; k < 2; k++) {  // buffers live in the trainer: no per-call allocation or zero fill
+        if (!tr->cache_words[k]) tr->cache_words[k].reset(new uint32_t[chunk_words]);
+        if (!tr->cache_off[k] || tr->cache_off_cap < chunk_records + 1) tr->cache_off[k].reset(new uint64_t[chunk_records + 1]);
+        chunks[k].words = tr->cache_words[k].get();
+        chunks[k].off = tr->cache_off[k].get();
+    }
+    tr->cache_off_cap = chunk_records + 1;
+    uint64_t left = max_records ? max_records : ~0ull, done = 0;
+    auto read_chunk = [&](Chunk &c, uint64_t want) {
+        c.rc = fwgpu_cache_next_records(cache, c.words, chunk_words, c.off, std::min(want, chunk_records), &c.n, &c.nw);
+        if (c.rc) c.msg = fwgpu_last_error();
+    };
+    int cur = 0;
+    read_chunk(chunks[cur], left);
+    int rc = FWGPU_OK;
+    while (true) {
+        Chunk &c = chunks[cur];
+        if (c.rc) {
+            rc = fail(c.rc, c.msg);
+            break;
+        }
+        if (c.n == 0) break;  // end of file
+        left -= c.n;
+        std::thread reader;
+        Chunk &next = chunks[cur ^ 1];
+        const bool more = left > 0;
+        if (more) reader = std::thread(read_chunk, std::ref(next), left);
+        uint64_t i = 0;
+        while (i < c.n && rc == FWGPU_OK) {  // fwgpu_digest_records takes a 32-bit count
+            const uint32_t take = (uint32_t)std::min<uint64_t>(c.n - i, 1u << 30);
+            rc = fwgpu_digest_records(tr, c.words, c.off + i, take);
+            i += take;
+        }
+        if (reader.joinable()) reader.join();
+        done += c.n;
+        if (rc || !more) break;
+        cur ^= 1;
+    }
+    if (n_digested) *n_digested = done;
+    return rc;
 }
 
 int fwgpu_finish(fwgpu_trainer *tr) {

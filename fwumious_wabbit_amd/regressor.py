@@ -392,6 +392,12 @@ class HogwildTrainer:
         rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
         check(capi.lib().fwgpu_digest_records(self.h, ptr(records), ptr(rec_off), len(rec_off) - 1))
 
+    def digest_cache(self, cache, max_records=0) -> int:
+        """the example loop over a RecordCache opened for reading (main.rs:213-270), in native code"""
+        n = C.c_uint64()
+        check(capi.lib().fwgpu_trainer_digest_cache(self.h, cache.h, max_records, C.byref(n)))
+        return n.value
+
     def block_until_workers_finished(self):
         """hogwild.rs:55-60"""
         check(capi.lib().fwgpu_finish(self.h))

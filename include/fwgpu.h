@@ -318,6 +318,10 @@ int fwgpu_cache_write_finish(fwgpu_cache *c);
 int fwgpu_cache_next_records(fwgpu_cache *c, uint32_t *words, uint64_t words_cap, uint64_t *rec_off, uint64_t max_records,
                              uint64_t *n_records, uint64_t *n_words);
 void fwgpu_cache_free(fwgpu_cache *c);
+/* The example loop over a cache file (main.rs:213-270: get_next_record -> digest_example) in native code: up to max_records
+ * (0 = to the end of the file) are read, copied to pinned memory and learned; a reader thread overlaps the file with the
+ * device.  Call fwgpu_finish afterwards, as after fwgpu_digest_records. */
+int fwgpu_trainer_digest_cache(fwgpu_trainer *tr, fwgpu_cache *cache, uint64_t max_records, uint64_t *n_digested);
 
 /* ---------------------------------------------------------------- model files
  * File = "FWRE", u32 version 6, u64 + JSON(vw_source), u64 + JSON(ModelInstance), weights blob (persistence.rs:17-97,

@@ -22,3 +22,34 @@ for mb in (4096, 16384, 65536):
     dt = time.perf_counter() - t0
     print(f"micro_batch={mb}: {n} records ({recs.nbytes/1e6:.0f} MB) in {dt*1e3:.1f} ms = {n/dt/1e6:.2f} M examples/s from host memory", flush=True)
     tr.close()
+
+# ---- the same stream through a .fwcache file: file -> RecordCache.next_records -> digest_records -> device
+import tempfile
+from fwumious_wabbit_amd.feed import RecordCache, VwNamespaceMap
+vw = VwNamespaceMap("".join(f"A{i},ns{i}\n" for i in range(args.fields)))
+d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+inp = os.path.join(d, "stream.vw")
+c = RecordCache(inp, True, vw); c.push_records(recs); c.write_finish(); c.close()
+for rep in range(2):
+    tr = fw.HogwildTrainer(re, mi, micro_batch=16384)
+    c = RecordCache(inp, True, vw)
+    t0 = time.perf_counter(); seen = 0
+    while True:
+        w, o = c.next_records(words_cap=1 << 25, max_records=1 << 17)
+        if len(o) <= 1:
+            break
+        tr.digest_records(w, o); seen += len(o) - 1
+    tr.block_until_workers_finished()
+    dt = time.perf_counter() - t0
+    print(f"cache file -> trainer (pass {rep}): {seen} records in {dt*1e3:.1f} ms = {seen/dt/1e6:.2f} M examples/s", flush=True)
+    c.close(); tr.close()
+for rep in range(2):
+    tr = fw.HogwildTrainer(re, mi, micro_batch=16384)
+    c = RecordCache(inp, True, vw)
+    t0 = time.perf_counter()
+    seen = tr.digest_cache(c)
+    tr.block_until_workers_finished()
+    dt = time.perf_counter() - t0
+    print(f"cache file -> trainer, native loop (pass {rep}): {seen} records in {dt*1e3:.1f} ms = {seen/dt/1e6:.2f} M examples/s", flush=True)
+    c.close(); tr.close()
+os.remove(inp + ".fwcache")

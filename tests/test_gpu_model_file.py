@@ -252,3 +252,37 @@ def test_serving_ffi_matches_the_regressor(tmp_path):
         Predictor(f"fw -i {path}.missing")
     for x in (cl, pr, re):
         x.close()
+
+
+def test_trainer_digests_a_cache_file_natively(tmp_path):
+    """fwgpu_trainer_digest_cache: the example loop over a .fwcache (main.rs:213-270) without leaving native code"""
+    vw = VwNamespaceMap(VW6)
+    mi, ocfg, ots = make_pair(6, 4, 16, 16, fw.Optimizer.AdagradLUT, lr=0.05, ffm_lr=0.05)
+    n_train, n_hold = 30000, 3000
+    recs, off = fw.synth_records(6, 1.0, 1.1, 20000, 0.2, 71, 0, n_train + n_hold)
+    y = record_labels(recs, off)
+    for gz in (False, True):
+        inp = str(tmp_path / ("s.vw.gz" if gz else "s.vw"))
+        c = RecordCache(inp, True, vw)
+        c.push_records(recs[: int(off[n_train])])
+        c.write_finish()
+        c.close()
+        re = fw.Regressor(mi)
+        tr = fw.HogwildTrainer(re, mi, micro_batch=2048)
+        c = RecordCache(inp, True, vw)
+        assert tr.digest_cache(c, max_records=10000) == 10000  # a bounded slice first ...
+        assert tr.digest_cache(c) == n_train - 10000           # ... then the rest of the file
+        assert tr.digest_cache(c) == 0                         # end of file
+        tr.block_until_workers_finished()
+        assert tr.examples_seen() == n_train
+        hb = re.record_batch(fw.FeatureBufferTranslator(mi), recs[int(off[n_train]):], off[n_train:] - off[n_train])
+        re.learn_batch(hb, capi.MODE_HOGWILD, False)
+        gpu_hold = float(logloss(hb.predictions(), y[n_train:]).mean())
+        from oracle import fwo
+        om = fwo.Model(ocfg)
+        om.run_stream(ots, recs[: int(off[n_train])], off[: n_train + 1], nthreads=1, want_preds=False)
+        _, p = om.run_stream(ots, recs[int(off[n_train]):], off[n_train:] - off[n_train], holdout_after=1, nthreads=1)
+        ref_hold = float(logloss(p, y[n_train:]).mean())
+        assert abs(gpu_hold - ref_hold) < 0.03, (gpu_hold, ref_hold)
+        for x in (c, tr, re, hb):
+            x.close()
