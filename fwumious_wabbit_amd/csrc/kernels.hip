@@ -208,9 +208,21 @@ __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t ma
     off[10] = o; o = align16(o + 4 * 3 * 16);
     off[11] = o; o = align16(o + 4 * 8);
     off[12] = o; o = align16(o + 4 * (size_t)F);
-    off[13] = o; o = align16(o + 4 * (size_t)set_size(max_ffm));
-    off[14] = o; o = align16(o + 4 * (size_t)set_size(max_lr));
-    off[15] = o; o = align16(o + 4 * (size_t)max_rec);
+    // The record copy and the two hash sets are only alive during the stage phase, T only from the end of the stage phase on:
+    // when they fit they live INSIDE T's region (config C: 6.4 KB of 28.8 KB), which is what lets a third workgroup fit a CU.
+    {
+        const size_t a13 = 0, a14 = align16(a13 + 4 * (size_t)set_size(max_ffm)), a15 = align16(a14 + 4 * (size_t)set_size(max_lr)),
+                     aend = align16(a15 + 4 * (size_t)max_rec);
+        if (aend <= 4 * F * R) {
+            off[13] = a13;
+            off[14] = a14;
+            off[15] = a15;
+        } else {
+            off[13] = o; o = align16(o + 4 * (size_t)set_size(max_ffm));
+            off[14] = o; o = align16(o + 4 * (size_t)set_size(max_lr));
+            off[15] = o; o = align16(o + 4 * (size_t)max_rec);
+        }
+    }
     off[16] = o; o = align16(o + 4 * (size_t)tr_items);
     off[17] = o; o = align16(o + (nn_floats ? 4 * (size_t)max_lr : 0));
     off[18] = o; o = align16(o + 4 * (size_t)nn_floats);
@@ -450,7 +462,11 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
     if (do_update)
         for (uint32_t i = tid; i < nf; i += bd)
             if (set_contains(s.set_ffm, g.setf_n - 1, g.setf_shift, (s.e_hash[i] >> g.blk_shift) + 1)) s.ctr[2] = 1;
-    // T columns and self-pair corrections of empty fields are zero (block_ffm.rs:168-180)
+    __syncthreads();
+    tk.stamp(11);
+    // (the hash sets and the record copy, which may share T's LDS region, are dead from here on)
+    // T columns and self-pair corrections of empty fields are zero (block_ffm.rs:168-180).  No barrier is needed before
+    // the gather: it writes the columns of the non-empty fields only, and a barrier follows it.
     if (p.k) {
         const uint32_t per = R / (p.k % 4 == 0 ? 4 : 1), vecw = p.k % 4 == 0 ? 4 : 1;
         for (uint32_t idx = tid; idx < F * per; idx += bd) {
@@ -463,8 +479,6 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
         for (uint32_t f = tid; f < F; f += bd)
             if (s.fstart[f] == s.fend[f]) s.dcf[f] = 0.0f;
     }
-    __syncthreads();
-    tk.stamp(11);
     if (do_update && s.ctr[2]) {
         // Rare: some rows may overlap.  Exact scan: does an EARLIER feature's row [h_j, h_j+R) overlap mine?
         // (rows are R long but start on a next_pow2(k) grid: block_ffm.rs:92-94, feature_buffer.rs:141-148)
