@@ -150,6 +150,8 @@ def main():
     ap.add_argument("--threads", type=int, default=0, help="workgroup size override")
     ap.add_argument("--wgs-per-cu", dest="wgs", type=int, default=0)
     ap.add_argument("--sync-every", dest="sync_every", type=int, default=0, help="N>1: steps between delta all-reduces")
+    ap.add_argument("--combine", choices=["mean", "sum"], default="mean",
+                    help="N>1: the agreed model moves by the mean (default) or the sum of the replicas' deltas")
     ap.add_argument("--blocking-sync", dest="blocking_sync", action="store_true",
                     help="N>1: blocking delta all-reduce instead of the overlapped one")
     ap.add_argument("--force-dist", dest="force_dist", action="store_true",
@@ -215,7 +217,7 @@ def main():
 
         # zero-copy torch views of the library's tables; torch.distributed (RCCL) does the exchange
         syncer = DeltaAllReduce([re.table_as_torch(w) for w in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)],
-                                overlap=not args.blocking_sync)
+                                overlap=not args.blocking_sync, combine=args.combine)
 
     def sync_replicas():
         # table <- snapshot + sum_r (table_r - snapshot): every replica ends with the same tables, having applied
@@ -305,7 +307,7 @@ def main():
                 "global_batch": B * world,
                 "mode": "hogwild (device-wide concurrent examples, racy RMW, sc1 accesses)",
                 "parallelism": ("1 GPU" if not use_dist else
-                                f"dp{world}: replicas, {'blocking' if args.blocking_sync else 'overlapped'} RCCL delta all-reduce of {syncer.bytes_per_sync() / 1e9:.2f} GB every "
+                                f"dp{world}: replicas, {'blocking' if args.blocking_sync else 'overlapped'} RCCL all-reduce of the replicas' {args.combine} delta, {syncer.bytes_per_sync() / 1e9:.2f} GB every "
                                 f"{sync_every} steps ({syncer.n_syncs} syncs incl. warmup)"),
                 "holdout_examples": args.holdout,
                 "prep_seconds": prep_s,

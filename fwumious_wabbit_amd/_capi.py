@@ -143,7 +143,7 @@ def lib():
         "fwgpu_trainer_free": [vp],
         "fwgpu_trainer_examples_seen": [vp, P(u64)],
         "fwgpu_set_launch": [vp, u32, u32],
-        "fwgpu_delta_start": [vp, vp, vp, vp, u64, vp],
+        "fwgpu_delta_start": [vp, vp, vp, vp, u64, f32, vp],
         "fwgpu_delta_finish": [vp, vp, vp, vp, u64, vp],
         "fwgpu_debug_phase_ticks": [vp, i32, vp],
         "fwgpu_debug_set_kernel_version": [vp, i32],

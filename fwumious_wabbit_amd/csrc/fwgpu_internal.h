@@ -110,7 +110,7 @@ hipError_t launch_ffm_init(float *w, float *acc, uint64_t len, uint32_t k, float
 hipError_t launch_fill(float *p, uint64_t n, float v, hipStream_t stream);
 hipError_t launch_fill_lr(float *lr, uint64_t n_entries, float w, float acc, hipStream_t stream);
 hipError_t launch_checksum(const float *p, uint64_t n, unsigned long long *out, hipStream_t stream);
-hipError_t launch_delta_start(const float *t, const float *s0, float *d, float *D, uint64_t n, hipStream_t stream);
+hipError_t launch_delta_start(const float *t, const float *s0, float *d, float *D, uint64_t n, float scale, hipStream_t stream);
 hipError_t launch_delta_finish(float *t, float *s0, const float *d, const float *D, uint64_t n, hipStream_t stream);
 hipError_t launch_coherence_probe(unsigned *scratch, int use_sc1, unsigned iters, unsigned blocks, hipStream_t stream);
 

@@ -1593,15 +1593,18 @@ hipError_t launch_checksum(const float *p, uint64_t n, unsigned long long *out, 
 // ------------------------------------------------------------------ replica delta bookkeeping (multi-GPU sync)
 // start : d = D = t - s0                    (D is then all-reduced in place over RCCL)
 // finish: s0 += D ; t += D - d              (others' updates land; local updates made meanwhile stay in t)
-__global__ void delta_start_kernel(const float *t, const float *s0, float *d, float *D, unsigned long long n) {
+__global__ void delta_start_kernel(const float *t, const float *s0, float *d, float *D, unsigned long long n, float scale) {
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i * 4 < n; i += stride) {
         if (i * 4 + 4 <= n) {
             const f4 x = reinterpret_cast<const f4 *>(t)[i] - reinterpret_cast<const f4 *>(s0)[i];
             reinterpret_cast<f4 *>(d)[i] = x;
-            reinterpret_cast<f4 *>(D)[i] = x;
+            reinterpret_cast<f4 *>(D)[i] = x * scale;
         } else {
-            for (unsigned long long j = i * 4; j < n; ++j) d[j] = D[j] = t[j] - s0[j];
+            for (unsigned long long j = i * 4; j < n; ++j) {
+                d[j] = t[j] - s0[j];
+                D[j] = d[j] * scale;
+            }
         }
     }
 }
@@ -1621,9 +1624,9 @@ __global__ void delta_finish_kernel(float *t, float *s0, const float *d, const f
         }
     }
 }
-hipError_t launch_delta_start(const float *t, const float *s0, float *d, float *D, uint64_t n, hipStream_t stream) {
+hipError_t launch_delta_start(const float *t, const float *s0, float *d, float *D, uint64_t n, float scale, hipStream_t stream) {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(delta_start_kernel, dim3(2048), dim3(256), 0, stream, t, s0, d, D, (unsigned long long)n);
+    hipLaunchKernelGGL(delta_start_kernel, dim3(2048), dim3(256), 0, stream, t, s0, d, D, (unsigned long long)n, scale);
     return hipGetLastError();
 }
 hipError_t launch_delta_finish(float *t, float *s0, const float *d, const float *D, uint64_t n, hipStream_t stream) {

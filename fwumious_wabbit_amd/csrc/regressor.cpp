@@ -782,10 +782,10 @@ int fwgpu_table_checksum(fwgpu_regressor *r, int which, uint64_t *checksum) {
 }
 
 int fwgpu_delta_start(const void *table, const void *snapshot, void *local_delta, void *summed_delta, uint64_t n_floats,
-                      void *stream) {
+                      float scale, void *stream) {
     if (!table || !snapshot || !local_delta || !summed_delta) return fail(FWGPU_ERR_INVALID, "NULL argument");
     FWGPU_HIP(launch_delta_start(static_cast<const float *>(table), static_cast<const float *>(snapshot),
-                                 static_cast<float *>(local_delta), static_cast<float *>(summed_delta), n_floats,
+                                 static_cast<float *>(local_delta), static_cast<float *>(summed_delta), n_floats, scale,
                                  static_cast<hipStream_t>(stream)));
     return FWGPU_OK;
 }

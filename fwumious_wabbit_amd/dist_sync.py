@@ -3,14 +3,20 @@
 Every rank trains its own replica on its own shard of the stream.  A sync makes every replica apply what the OTHER
 ranks changed since the last agreed snapshot `s0`:
 
-    blocking :  d = t - s0 ; D = all_reduce(d) ; s0 <- s0 + D ; t <- s0
-    overlapped: start():  d = t - s0 ; launch all_reduce(D <- d) asynchronously; training continues on t
+    blocking :  d = t - s0 ; D = all_reduce(c*d) ; s0 <- s0 + D ; t <- s0
+    overlapped: start():  d = t - s0 ; launch all_reduce(D <- c*d) asynchronously; training continues on t
                 finish(): wait ; t <- t + (D - d) ; s0 <- s0 + D
 
+c = 1/world_size (combine="mean", the default): the agreed model moves by the MEAN of the replicas' deltas (local SGD /
+model averaging, weights and AdaGrad accumulators alike).  c = 1 (combine="sum") applies everyone's updates on top of
+each other; measured on the BASELINE config-C stream (scripts/replica_sim.py, 48 steps, exchange every 32): hold-out log-loss
+0.643 (1 replica) -> mean: 0.626 / 0.617 / 0.614 at 2 / 4 / 8 replicas; sum: 0.675 / 3.8 / 18.3 (diverged) -- every replica
+steps with its own small accumulators, so N summed steps on a hot weight are N over-sized steps.
+
 With `u` = the local updates made while the all-reduce was in flight, `t = s0 + d + u` before finish() and
-`t = (s0 + D) + u` after it, so the next delta is exactly `u`: nothing is lost or applied twice.  Replicas agree up to their
-not-yet-synchronised local updates -- the multi-GPU analogue of hogwild.rs staleness (weights AND AdaGrad accumulators
-are summed).  The tensors are zero-copy views of the library's tables (Regressor.table_as_torch); torch is only plumbing.
+`t = (s0 + D) + u` after it, so the next local delta is `(D - d) + u`... measured against the new snapshot it is exactly `u`:
+nothing is lost or applied twice.  Replicas agree up to their not-yet-synchronised local updates -- the multi-GPU analogue of
+hogwild.rs staleness.  The tensors are zero-copy views of the library's tables (Regressor.table_as_torch); torch is only plumbing.
 
 xGMI note: a ring all-reduce of the 4.3 GB of tables is bound by one link per hop; large buckets (256 MiB) amortise
 launch and ring latency, and the overlapped mode hides the transfer behind `sync_every` steps of training.
@@ -20,7 +26,7 @@ import torch.distributed as dist
 
 
 class DeltaAllReduce:
-    def __init__(self, tables, bucket_elems=1 << 26, group=None, overlap=False):
+    def __init__(self, tables, bucket_elems=1 << 26, group=None, overlap=False, combine="mean"):
         """tables: list of 1-D float32 tensors (views of the regressor's tables); bucket_elems: all-reduce bucket size in
         elements (2^26 floats = 256 MiB); overlap: keep a delta buffer per table and run the all-reduce asynchronously."""
         self.tables = list(tables)
@@ -28,10 +34,15 @@ class DeltaAllReduce:
         self.bucket = int(bucket_elems)
         self.group = group
         self.overlap = bool(overlap)
+        assert combine in ("mean", "sum")
+        self.combine = combine
         self.n_syncs = 0
         self._local = [torch.empty_like(t) for t in self.tables] if overlap else None   # d (kept)
         self._summed = [torch.empty_like(t) for t in self.tables] if overlap else None  # D (all-reduced in place)
         self._works = None
+
+    def _scale(self):
+        return 1.0 / dist.get_world_size(self.group) if self.combine == "mean" else 1.0
 
     # ---- blocking
     def sync(self):
@@ -41,6 +52,8 @@ class DeltaAllReduce:
             for a in range(0, t.numel(), self.bucket):
                 b = min(a + self.bucket, t.numel())
                 d = t[a:b] - s0[a:b]
+                if self._scale() != 1.0:
+                    d *= self._scale()
                 dist.all_reduce(d, op=dist.ReduceOp.SUM, group=self.group)
                 s0[a:b] += d
                 t[a:b] = s0[a:b]
@@ -57,10 +70,10 @@ class DeltaAllReduce:
                 from . import _capi as capi
 
                 capi.check(capi.lib().fwgpu_delta_start(t.data_ptr(), s0.data_ptr(), d.data_ptr(), D.data_ptr(), t.numel(),
-                                                        torch.cuda.current_stream(t.device).cuda_stream))
+                                                        self._scale(), torch.cuda.current_stream(t.device).cuda_stream))
             else:
                 torch.sub(t, s0, out=d)
-                D.copy_(d)
+                torch.mul(d, self._scale(), out=D)
             for a in range(0, t.numel(), self.bucket):
                 b = min(a + self.bucket, t.numel())
                 works.append(dist.all_reduce(D[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))

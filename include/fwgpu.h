@@ -242,11 +242,13 @@ int fwgpu_set_launch(fwgpu_regressor *r, uint32_t threads, uint32_t workgroups_p
 /* ---------------------------------------------------------------- multi-GPU replica bookkeeping (device pointers)
  * Data-parallel replicas exchange what each changed since the last agreed snapshot (replaces hogwild.rs's shared
  * memory across GPUs; the all-reduce itself is RCCL via torch.distributed, see fwumious_wabbit_amd/dist_sync.py):
- *   fwgpu_delta_start : local_delta = summed_delta = table - snapshot   (summed_delta is then all-reduced in place)
+ *   fwgpu_delta_start : local_delta = table - snapshot ; summed_delta = scale * local_delta
+ *                       (summed_delta is then all-reduced in place; scale = 1/world_size makes the sum the MEAN of the
+ *                        replicas' deltas, which is what keeps N >= 4 replicas from diverging: scripts/replica_sim.py)
  *   fwgpu_delta_finish: snapshot += summed_delta ; table += summed_delta - local_delta
  * One fused pass each over n_floats elements, enqueued on `stream`. */
 int fwgpu_delta_start(const void *table, const void *snapshot, void *local_delta, void *summed_delta, uint64_t n_floats,
-                      void *stream);
+                      float scale, void *stream);
 int fwgpu_delta_finish(void *table, void *snapshot, const void *local_delta, const void *summed_delta, uint64_t n_floats,
                        void *stream);
 

@@ -16,7 +16,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, combine="sum"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -24,7 +24,8 @@ def _worker(rank, world, port, out):
     base_w = torch.randn(1000, generator=g)          # identical initial tables on every rank
     base_a = torch.rand(777, generator=g)
     w, a = base_w.clone(), base_a.clone()
-    sync = DeltaAllReduce([w, a], bucket_elems=256)  # several buckets, last one ragged
+    sync = DeltaAllReduce([w, a], bucket_elems=256, combine=combine)  # several buckets, last one ragged
+    c = 1.0 / world if combine == "mean" else 1.0
     expect_w, expect_a = base_w.clone(), base_a.clone()
     for step in range(3):
         # each rank applies its own sparse "training" updates
@@ -32,7 +33,7 @@ def _worker(rank, world, port, out):
         idx = torch.randint(0, 1000, (50,), generator=gr)
         w[idx] -= 0.01 * (rank + 1)
         a[idx % 777] += 0.5
-        # what the union of all ranks' updates amounts to
+        # what the agreed model is after the exchange: everyone's updates on top of each other (sum) or their mean
         for r in range(world):
             g2 = torch.Generator().manual_seed(100 * step + r)
             i2 = torch.randint(0, 1000, (50,), generator=g2)
@@ -40,8 +41,8 @@ def _worker(rank, world, port, out):
             dw[i2] -= 0.01 * (r + 1)          # same semantics as the in-place op above (last write per index)
             da = torch.zeros(777)
             da[i2 % 777] += 0.5
-            expect_w += dw
-            expect_a += da
+            expect_w += c * dw
+            expect_a += c * da
         sync.sync()
         assert torch.allclose(w, expect_w, atol=1e-6) and torch.allclose(a, expect_a, atol=1e-6)
         assert torch.equal(w, sync.snapshots[0]) and torch.equal(a, sync.snapshots[1])
@@ -53,13 +54,13 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def _worker_overlap(rank, world, port, out):
+def _worker_overlap(rank, world, port, out, combine="sum"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     base = torch.linspace(-1, 1, 900)
     t = base.clone()
-    sync = DeltaAllReduce([t], bucket_elems=256, overlap=True)
+    sync = DeltaAllReduce([t], bucket_elems=256, overlap=True, combine=combine)
     # the bookkeeping invariant: table == agreed snapshot + (all landed deltas of others already inside it) + local tail
     total = base.clone()          # what a single sequential learner applying everyone's updates would hold
     local_unsynced = torch.zeros(900)
@@ -83,6 +84,8 @@ def _worker_overlap(rank, world, port, out):
     sync.finish()      # land the last exchange
     sync.step()        # exchange the remaining local tails ...
     sync.finish()      # ... and land them: now every replica holds everything
+    if combine == "mean":  # every update ends up in exactly one exchange and enters the agreed model with weight 1/world
+        total = base + (total - base) / world
     assert torch.allclose(t, total, atol=1e-5), float((t - total).abs().max())
     gathered = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(gathered, t)
@@ -92,21 +95,26 @@ def _worker_overlap(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_overlapped_delta_allreduce_world2_gloo():
+import pytest
+
+
+@pytest.mark.parametrize("combine", ["mean", "sum"])
+def test_overlapped_delta_allreduce_world2_gloo(combine):
     world = 2
     port = _free_port()
     with mp.Manager() as m:
         out = m.dict()
-        mp.spawn(_worker_overlap, args=(world, port, out), nprocs=world, join=True)
+        mp.spawn(_worker_overlap, args=(world, port, out, combine), nprocs=world, join=True)
         assert out[0] == out[1] == 5
 
 
-def test_delta_allreduce_world2_gloo():
+@pytest.mark.parametrize("combine", ["mean", "sum"])
+def test_delta_allreduce_world2_gloo(combine):
     world = 2
     port = _free_port()
     with mp.Manager() as m:
         out = m.dict()
-        mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, out, combine), nprocs=world, join=True)
         assert len(out) == world and abs(out[0] - out[1]) == 0.0
 
 

@@ -568,7 +568,7 @@ def test_delta_kernels_match_torch_reference():
     import torch
 
     L = capi.lib()
-    for n in (1, 3, 4, 1027, 1 << 20):
+    for n, scale in ((1, 1.0), (3, 0.5), (4, 1.0), (1027, 0.125), (1 << 20, 0.25)):
         g = torch.Generator(device="cpu").manual_seed(n)
         t = torch.randn(n, generator=g).cuda()
         s0 = torch.randn(n, generator=g).cuda()
@@ -576,14 +576,15 @@ def test_delta_kernels_match_torch_reference():
         D = torch.empty(n, device="cuda")
         t0, s00 = t.clone(), s0.clone()
         st = torch.cuda.current_stream().cuda_stream
-        capi.check(L.fwgpu_delta_start(t.data_ptr(), s0.data_ptr(), d.data_ptr(), D.data_ptr(), n, st))
-        assert torch.equal(d, t0 - s00) and torch.equal(D, d)
+        capi.check(L.fwgpu_delta_start(t.data_ptr(), s0.data_ptr(), d.data_ptr(), D.data_ptr(), n, scale, st))
+        assert torch.equal(d, t0 - s00) and torch.equal(D, d * scale)
         D += 0.5  # "others" contributed 0.5 everywhere
         t += 0.25  # local updates while the exchange was in flight
         capi.check(L.fwgpu_delta_finish(t.data_ptr(), s0.data_ptr(), d.data_ptr(), D.data_ptr(), n, st))
         torch.cuda.synchronize()
-        assert torch.allclose(s0, s00 + (t0 - s00) + 0.5, atol=1e-6)
-        assert torch.allclose(t, t0 + 0.25 + 0.5, atol=1e-6)
+        assert torch.allclose(s0, s00 + scale * (t0 - s00) + 0.5, atol=1e-6)
+        # the local delta is replaced by the agreed one; updates made meanwhile stay
+        assert torch.allclose(t, s00 + scale * (t0 - s00) + 0.5 + 0.25, atol=1e-6)
 
 
 def test_table_torch_view_is_zero_copy():
