@@ -682,6 +682,13 @@ int fwgpu_model_load(const char *path, int device, int immutable, fwgpu_vwmap **
 
         fwgpu_regressor *r = *r_inout;
         const bool own = r == nullptr;
+        struct Guard {  // frees a regressor created here unless the load completes
+            fwgpu_regressor **r;
+            bool armed;
+            ~Guard() {
+                if (armed && *r) fwgpu_free(*r);
+            }
+        } guard{&r, own};
         if (own) {
             if (immutable) mi->optimizer = FWGPU_OPT_SGD;  // persistence.rs:164
             fwgpu_config cfg;
@@ -692,10 +699,7 @@ int fwgpu_model_load(const char *path, int device, int immutable, fwgpu_vwmap **
             if (rc) return rc;
             if (nn.n_layers) rc = fwgpu_set_nn(r, &nn);
             if (!rc) rc = fwgpu_init_weights(r);  // allocate_and_init_weights, then overwritten (persistence.rs:160-161)
-            if (rc) {
-                fwgpu_free(r);
-                return rc;
-            }
+            if (rc) return rc;
         }
         // bring the file's layout to the regressor's
         std::vector<uint8_t> blob;
@@ -707,7 +711,6 @@ int fwgpu_model_load(const char *path, int device, int immutable, fwgpu_vwmap **
             std::memcpy(blob.data() + 8, w.data(), w.size());
         } else {
             if (file_opt == FWGPU_OPT_SGD) {
-                if (own) fwgpu_free(r);
                 return fail(FWGPU_ERR_INVALID, "an inference (SGD) model file carries no optimizer state to resume training from");
             }
             blob.resize(8 + blob_body_bytes(file_opt, false, s));
@@ -723,11 +726,9 @@ int fwgpu_model_load(const char *path, int device, int immutable, fwgpu_vwmap **
         }
         std::memcpy(blob.data(), &count, 8);
         rc = fwgpu_read_weights(r, blob.data(), blob.size());
-        if (rc) {
-            if (own) fwgpu_free(r);
-            return rc;
-        }
+        if (rc) return rc;
         fill_views(mi.get());
+        guard.armed = false;
         *r_inout = r;
         if (vw_out) *vw_out = vw.release();
         if (mi_out) *mi_out = mi.release();

@@ -12,6 +12,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "fw_ffi.h"
@@ -28,7 +29,9 @@ struct SharedModel {  // what clone_lite shares: the immutable regressor and the
     fwgpu_translator_config tr{};
     uint32_t num_namespaces = 0;
     std::mutex mu;  // the regressor's single-example staging buffers are shared
+    fwgpu_batch *batch = nullptr;  // device buffers of fwgpu_predictor_predict_batch, grown on demand and reused
     ~SharedModel() {
+        if (batch) fwgpu_batch_free(batch);
         if (re) fwgpu_free(re);
         if (vw) fwgpu_vwmap_free(vw);
         if (mi) fwgpu_mi_free(mi);
@@ -193,43 +196,79 @@ void free_predictor(FfiPredictor *ptr) { delete ptr; }  // lib.rs:234-236
 int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, uint32_t n, int with_cache, float *out) {
     if (!ptr || (!inputs && n) || (!out && n)) return fail(FWGPU_ERR_INVALID, "NULL argument");
     SharedModel &m = *ptr->model;
+    // parse on a few host threads (each with its own parser: VowpalParser is not thread safe, clone_lite's reason)
+    const unsigned T = n >= 256 ? std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    struct Part {
+        std::vector<uint32_t> words;
+        std::vector<uint64_t> len;
+        std::vector<uint32_t> slot;
+    };
+    std::vector<Part> parts(T);
+    auto work = [&](unsigned k) {
+        fwgpu_parser *parser = ptr->parser;
+        fwgpu_parser *own = nullptr;
+        if (k > 0) {
+            if (fwgpu_parser_create(m.vw, &own) != FWGPU_OK) return;
+            parser = own;
+        }
+        Part &pt = parts[k];
+        std::vector<uint32_t> rec(4096);
+        const uint32_t a = (uint32_t)((uint64_t)n * k / T), e = (uint32_t)((uint64_t)n * (k + 1) / T);
+        for (uint32_t i = a; i < e; i++) {
+            out[i] = kExceptionErrorCode;
+            if (!inputs[i]) continue;
+            uint32_t nw = 0;
+            int rc;
+            for (;;) {
+                rc = fwgpu_parser_parse_with_prefix(parser, with_cache ? ptr->cached_text.data() : nullptr,
+                                                    with_cache ? ptr->cached_text.size() : 0, inputs[i], std::strlen(inputs[i]),
+                                                    rec.data(), (uint32_t)rec.size(), &nw);
+                if (rc == FWGPU_ERR_RANGE && rec.size() < (1u << 24)) {
+                    rec.resize(rec.size() * 4);
+                    continue;
+                }
+                break;
+            }
+            if (rc != FWGPU_OK || nw == 0) {
+                if (rc == FWGPU_OK) out[i] = kEofErrorCode;
+                continue;
+            }
+            rec[1] = 0;  // a request carries no label (NO_LABEL = 0xff); the prediction does not depend on it
+            pt.words.insert(pt.words.end(), rec.begin(), rec.begin() + nw);
+            pt.len.push_back(nw);
+            pt.slot.push_back(i);
+        }
+        if (own) fwgpu_parser_free(own);
+    };
+    {
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < T; k++) th.emplace_back(work, k);
+        work(0);
+        for (auto &x : th) x.join();
+    }
     std::vector<uint32_t> words;
     std::vector<uint64_t> off(1, 0);
     std::vector<uint32_t> slot;  // which input each record belongs to
-    std::vector<uint32_t> rec(4096);
-    for (uint32_t i = 0; i < n; i++) {
-        out[i] = kExceptionErrorCode;
-        if (!inputs[i]) continue;
-        uint32_t nw = 0;
-        int rc;
-        for (;;) {
-            rc = fwgpu_parser_parse_with_prefix(ptr->parser, with_cache ? ptr->cached_text.data() : nullptr,
-                                                with_cache ? ptr->cached_text.size() : 0, inputs[i], std::strlen(inputs[i]),
-                                                rec.data(), (uint32_t)rec.size(), &nw);
-            if (rc == FWGPU_ERR_RANGE && rec.size() < (1u << 24)) {
-                rec.resize(rec.size() * 4);
-                continue;
-            }
-            break;
-        }
-        if (rc != FWGPU_OK || nw == 0) {
-            if (rc == FWGPU_OK) out[i] = kEofErrorCode;
-            continue;
-        }
-        rec[1] = 0;  // a request carries no label (NO_LABEL = 0xff); the prediction does not depend on it
-        words.insert(words.end(), rec.begin(), rec.begin() + nw);
-        off.push_back(words.size());
-        slot.push_back(i);
+    for (const Part &pt : parts) {
+        words.insert(words.end(), pt.words.begin(), pt.words.end());
+        for (uint64_t l : pt.len) off.push_back(off.back() + l);
+        slot.insert(slot.end(), pt.slot.begin(), pt.slot.end());
     }
     if (slot.empty()) return FWGPU_OK;
     std::lock_guard<std::mutex> g(m.mu);
-    fwgpu_batch *b = nullptr;
-    int rc = fwgpu_record_batch_create(m.re, &m.tr, words.data(), off.data(), (uint32_t)slot.size(), &b);
+    const uint32_t nrec = (uint32_t)slot.size();
+    if (!m.batch || m.batch->n_cap < nrec || m.batch->words_cap < words.size()) {
+        if (m.batch) fwgpu_batch_free(m.batch);
+        m.batch = nullptr;
+        int rc0 = record_batch_alloc(m.re, &m.tr, std::max<uint32_t>(nrec * 2, 256), std::max<uint64_t>(words.size() * 2, 1 << 16), &m.batch);
+        if (rc0 != FWGPU_OK) return rc0;
+    }
+    fwgpu_batch *b = m.batch;
+    int rc = record_batch_upload(b, &m.tr, words.data(), off.data(), nrec, 0);
     if (rc != FWGPU_OK) return rc;
     rc = fwgpu_learn_batch(m.re, b, FWGPU_MODE_HOGWILD, /*update=*/0, nullptr);
     std::vector<float> preds(slot.size());
     if (rc == FWGPU_OK) rc = fwgpu_batch_predictions(b, preds.data(), (uint32_t)preds.size(), nullptr);
-    fwgpu_batch_free(b);
     if (rc != FWGPU_OK) return rc;
     for (size_t j = 0; j < slot.size(); j++) out[slot[j]] = preds[j];
     return FWGPU_OK;
