@@ -243,3 +243,48 @@ def test_text_to_records_in_bulk_equals_line_by_line():
                           ffm_fields=[[fw.NamespaceDescriptor(i)] for i in range(6)])
     fb = fw.FeatureBufferTranslator(mi).translate(one_by_one[0])
     assert len(fb.lr_buffer) >= 2 and fb.label in (0.0, 1.0)
+
+
+def test_reference_example_lines_parse_and_translate_like_the_oracle():
+    """examples/basic/datasets/train.vw (the reference's own production-like lines: 58 namespaces, several features per
+    namespace, `|w:2` namespace weights, 2/3/4-way --interactions): parser -> records -> host translator vs the oracle's
+    translator, bit for bit; record structure checked against the format description (parser.rs:57-74)"""
+    import gzip
+    from oracle import fwo
+    base = os.path.join(HERE, "golden", "example_basic")
+    vw = VwNamespaceMap.new_from_csv_filepath(os.path.join(base, "vw_namespace_map.csv"))
+    NS = vw.num_namespaces
+    assert NS == 58
+    with gzip.open(os.path.join(base, "train.vw.gz"), "rb") as f:
+        text = f.read()
+    p = VowpalParser(vw)
+    words, off, used, rc = p.parse_buffer(text)
+    assert rc == capi.OK and used == len(text) and len(off) == 101
+    keeps = "B C D F G H L O S U W e f g h i o p q r v x".split()
+    inter = "4G 4GHX 4GUW 4K 4c 4go 4v BC BD BGO BX CO DG DW GU Gx KR MN UW Ug eg".split()
+    combos = [[vw.lookup(c)[0] for c in k] for k in keeps + inter]
+    nd = fw.NamespaceDescriptor
+    mi = fw.ModelInstance(bit_precision=25, add_constant_feature=True,
+                          feature_combo_descs=[fw.FeatureComboDesc([nd(i) for i in c]) for c in combos],
+                          ffm_k=4, ffm_bit_precision=20, ffm_fields=[[nd(vw.lookup("B")[0]), nd(vw.lookup("C")[0])], [nd(vw.lookup("O")[0])],
+                                                                     [nd(vw.lookup("w")[0])]])
+    ots = fwo.TranslatorSpec([([(i, False) for i in c], 1.0) for c in combos],
+                             [[(vw.lookup("B")[0], False), (vw.lookup("C")[0], False)], [(vw.lookup("O")[0], False)], [(vw.lookup("w")[0], False)]],
+                             True, 25, 4, 20)
+    fbt = fw.FeatureBufferTranslator(mi)
+    lines = text.split(b"\n")
+    n_multi = 0
+    for i in range(100):
+        r = words[int(off[i]):int(off[i + 1])]
+        assert r[0] == len(r) and r[1] in (0, 1) and r[2] == 0x3F800000
+        assert np.array_equal(r, p.next_vowpal(lines[i] + b"\n"))
+        # `|w:2 w...` : one feature with namespace weight 2 -> out-of-place pair (hash, 2.0)
+        slot = int(r[3 + vw.lookup("w")[0]])
+        assert slot & 0x80000000 and struct.unpack("<f", struct.pack("<I", int(r[(slot >> 16) & 0x3fff] if False else r[((slot >> 16) & 0x3fff) + 1])))[0] == 2.0
+        n_multi += sum(1 for ns in range(NS) if (int(r[3 + ns]) & 0x80000000) and int(r[3 + ns]) != 0x80000000
+                       and ((int(r[3 + ns]) & 0xffff) - ((int(r[3 + ns]) >> 16) & 0x3fff)) > 2)
+        fb = fbt.translate(r)
+        lr, ffm, label, imp = ots.translate(r)
+        assert fb.lr_buffer.tobytes() == lr.tobytes() and fb.ffm_buffer.tobytes() == ffm.tobytes()
+        assert fb.label == label and fb.example_importance == imp
+    assert n_multi > 20  # the data does exercise several-features-per-namespace slots

@@ -130,3 +130,49 @@ def test_examples_ffm_end_to_end(tmp_path):
     assert _balanced_accuracy(_predict(re_inf, mi_inf, ew, eo), record_labels(ew, eo)) > 0.95
     for x in (re, re_full, re_inf):
         x.close()
+
+
+BASIC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "example_basic")
+KEEPS = "B C D F G H L O S U W e f g h i o p q r v x".split()
+INTERACTIONS = "4G 4GHX 4GUW 4K 4c 4go 4v BC BD BGO BX CO DG DW GU Gx KR MN UW Ug eg".split()
+
+
+@pytest.mark.parametrize("name,interactions,power_t,optimizer", [
+    ("basic", INTERACTIONS, 0.39, fw.Optimizer.AdagradLUT),           # examples/basic/run.sh:12-13
+    ("vw-compatibility", [], 0.35, fw.Optimizer.AdagradFlex)])        # examples/vw-compatibility/run.sh:15-16, --vwcompat
+def test_reference_example_datasets_lr(tmp_path, name, interactions, power_t, optimizer):
+    """The reference's production-like example lines (58 namespaces, 2/3/4-way interactions, namespace weights, several
+    features per namespace) through parser -> device translation -> LR learner, against the oracle and the host translator"""
+    from oracle import fwo
+    vw = VwNamespaceMap.new_from_csv_filepath(os.path.join(BASIC, "vw_namespace_map.csv"))
+    with gzip.open(os.path.join(BASIC, "train.vw.gz"), "rb") as f:
+        text = f.read()
+    words, off, used, rc = VowpalParser(vw).parse_buffer(text)
+    assert rc == capi.OK and used == len(text) and len(off) == 101
+    nd = fw.NamespaceDescriptor
+    combos = [[vw.lookup(c)[0] for c in k] for k in KEEPS + interactions]  # single-letter vw names
+    mi = fw.ModelInstance(learning_rate=0.025, power_t=power_t, bit_precision=25, add_constant_feature=True, init_acc_gradient=1.0,
+                          optimizer=optimizer, feature_combo_descs=[fw.FeatureComboDesc([nd(i) for i in c]) for c in combos])
+    ocfg = fwo.make_config(optimizer=optimizer, learning_rate=0.025, power_t=power_t, init_acc_gradient=1.0, bit_precision=25,
+                           num_combos=len(combos) + 1, ffm_k=0, ffm_bit_precision=18, ffm_num_fields=0, ffm_learning_rate=0.025,
+                           ffm_power_t=power_t, ffm_init_acc_gradient=1.0)
+    ots = fwo.TranslatorSpec([([(i, False) for i in c], 1.0) for c in combos], [], True, 25, 0, 18)
+    y = record_labels(words, off)
+    # three passes over the 100 lines so that weights matter
+    w3 = np.concatenate([words] * 3)
+    o3 = np.concatenate([off[:-1], off[:-1] + off[-1], off + 2 * off[-1]])
+    _, p_ref = fwo.Model(ocfg).run_stream(ots, w3, o3, holdout_after=0, nthreads=1)
+    out = []
+    for kind in ("entries", "records"):
+        re = fw.Regressor(mi)
+        fbt = fw.FeatureBufferTranslator(mi)
+        b = re.batch_from_records(fbt, w3, o3) if kind == "entries" else re.record_batch(fbt, w3, o3)
+        re.learn_batch(b, capi.MODE_SEQUENTIAL, True)
+        p = b.predictions().copy()
+        assert np.abs(logloss(p, np.tile(y, 3)) - logloss(p_ref, np.tile(y, 3))).max() < 1e-4
+        assert np.abs(p - p_ref).max() < 5e-6
+        out.append((p, re.table_checksum(capi.TABLE_LR)))
+        b.close()
+        re.close()
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]  # device translation == host translation
+    assert len(np.unique(out[0][0][200:])) > 50  # and it is not predicting a constant
