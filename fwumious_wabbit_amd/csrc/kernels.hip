@@ -1065,14 +1065,39 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
 }
 
 // ------------------------------------------------------------------ launch
-template <int VEC, int OPT, bool COH>
-static hipError_t launch_t(const KernelParams &p, uint32_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
-    auto kern = fw_example_kernel<VEC, OPT, COH>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+// grid == 0: persistent launch.  The grid is what the device can keep RESIDENT (occupancy of this very kernel at this
+// workgroup size and LDS size, times the CUs): a larger grid would queue workgroups behind the resident ones and leave the
+// device half empty for the tail of the launch (measured: +19 % time with 3 workgroups per CU requested and 2 resident).
+template <typename K>
+static hipError_t launch_persistent(K kern, const KernelParams &p, uint32_t grid, uint32_t threads, size_t lds,
+                                    hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    if (grid == 0) {
+        // the query is a pure function of (kernel, workgroup size, LDS size): remember the last answer per kernel
+        static thread_local uint32_t c_threads = 0;
+        static thread_local size_t c_lds = 0;
+        static thread_local int c_per_cu = 0;
+        int per_cu = c_per_cu;
+        if (c_threads != threads || c_lds != lds || c_per_cu == 0) {
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, (int)threads, lds);
+            if (e != hipSuccess) return e;
+            if (per_cu < 1) per_cu = 1;
+            c_threads = threads;
+            c_lds = lds;
+            c_per_cu = per_cu;
+        }
+        if (p.host_wgs_cap && (uint32_t)per_cu > p.host_wgs_cap) per_cu = (int)p.host_wgs_cap;
+        const uint64_t g = (uint64_t)per_cu * (p.host_cus ? p.host_cus : 1);
+        grid = (uint32_t)(g < p.n_examples ? g : p.n_examples);
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, p);
     return hipGetLastError();
+}
+
+template <int VEC, int OPT, bool COH>
+static hipError_t launch_t(const KernelParams &p, uint32_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
+    return launch_persistent(fw_example_kernel<VEC, OPT, COH>, p, grid, threads, lds, stream);
 }
 
 template <int VEC>
@@ -1124,7 +1149,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 }
 
 #ifndef FW_UA
-#define FW_UA 4
+#define FW_UA 2
 #endif
 #ifndef FW_UO
 #define FW_UO 2
@@ -1132,8 +1157,10 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #ifndef FW_LB_THREADS
 #define FW_LB_THREADS 512
 #endif
+// 6 waves per SIMD (<= 85 VGPRs): three 512-thread workgroups per CU.  Occupancy beats residency: 2 resident rows per
+// wave at 3 workgroups/CU is 10 % faster (training) / 22 % faster (inference) than 12 resident rows at 2 workgroups/CU.
 #ifndef FW_LB_WAVES
-#define FW_LB_WAVES 4
+#define FW_LB_WAVES 6
 #endif
 template <int OPT, bool COH, int MAXR>
 __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_r(const KernelParams p) {
@@ -1459,16 +1486,11 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
 }
 
 #ifndef FW_MAXR
-#define FW_MAXR 12
+#define FW_MAXR 2
 #endif
 template <int OPT, bool COH>
 static hipError_t launch_r(const KernelParams &p, uint32_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
-    auto kern = fw_example_kernel_r<OPT, COH, FW_MAXR>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, p);
-    return hipGetLastError();
+    return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR>, p, grid, threads, lds, stream);
 }
 
 static hipError_t launch_resident(const KernelParams &p, int optimizer, bool coherent, uint32_t grid, uint32_t threads,

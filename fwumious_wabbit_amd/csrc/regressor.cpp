@@ -312,18 +312,15 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
     p.tr = b->tr;
     p.kernel_version = r->launch.kernel_version;
     p.lut_global = r->launch.lut_global;
+    p.host_cus = r->num_cus;
+    p.host_wgs_cap = r->launch.workgroups_per_cu;
     return p;
 }
 
 uint32_t pick_grid(const fwgpu_regressor *r, const KernelParams &p, int mode, uint32_t threads) {
-    if (mode == FWGPU_MODE_SEQUENTIAL) return 1;
-    const size_t lds = std::max<size_t>(example_kernel_lds_bytes(p, r->cfg.optimizer), 1024);
-    uint32_t per_cu = (uint32_t)std::max<size_t>(1, r->lds_per_cu / lds);
-    per_cu = std::min<uint32_t>(per_cu, 2048 / threads);  // 32 waves per CU
-    per_cu = std::max<uint32_t>(per_cu, 1);
-    if (r->launch.workgroups_per_cu) per_cu = std::min(per_cu, r->launch.workgroups_per_cu);
-    const uint64_t g = (uint64_t)per_cu * (uint64_t)r->num_cus;
-    return (uint32_t)std::min<uint64_t>(g, p.n_examples);
+    (void)r; (void)p; (void)threads;
+    // SEQUENTIAL: one workgroup walks the batch.  HOGWILD: 0 = "what the device keeps resident" (launch_persistent)
+    return mode == FWGPU_MODE_SEQUENTIAL ? 1u : 0u;
 }
 
 static int run_batch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, hipStream_t stream) {
