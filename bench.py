@@ -272,7 +272,7 @@ def main():
     # read side) committed under profiles/, reported only when the run uses the profiled configuration.
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_v3_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_v4_pmc.json")) as f:
             pmc = json.load(f)
         if (B == pmc["examples_per_launch"] and args.fields == 30 and args.k == 8 and args.ffm_bits == 28
                 and not args.threads and not args.wgs):
@@ -314,7 +314,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("fw_example_kernel_r<AdagradLUT, coherent, MAXR=12> (register-resident rows)"
+                "kernel": ("fw_example_kernel_r<AdagradLUT, coherent, MAXR=2> (3 workgroups x 512 threads per CU)"
                            if args.k % 4 == 0 and args.fields * args.k <= 256 and not args.nn_layers else
                            "fw_example_kernel<VEC=4, AdagradLUT, coherent> (generic rows" + (" + deep head)" if args.nn_layers else ")")),
                 "achieved": achieved,
@@ -322,7 +322,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": "profiles/r01_v3_pmc.json (rocprofv3 PMC, separate passes)" if traffic else None,
+                "traffic_source": "profiles/r01_v4_pmc.json (rocprofv3 PMC, separate passes)" if traffic else None,
                 "pattern_ceiling_note": "tools/rowbw.hip: random 960 B rows read 6.4 TB/s, written 3.2 TB/s; read w+acc, write w+acc = 4.2 TB/s",
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": avg_kernel_ms,
