@@ -1075,14 +1075,16 @@ static hipError_t launch_persistent(K kern, const KernelParams &p, uint32_t grid
     if (e != hipSuccess) return e;
     if (grid == 0) {
         // the query is a pure function of (kernel, workgroup size, LDS size): remember the last answer per kernel
+        static thread_local const void *c_kern = nullptr;  // (all example kernels share this instantiation: same signature)
         static thread_local uint32_t c_threads = 0;
         static thread_local size_t c_lds = 0;
         static thread_local int c_per_cu = 0;
         int per_cu = c_per_cu;
-        if (c_threads != threads || c_lds != lds || c_per_cu == 0) {
+        if (c_kern != reinterpret_cast<const void *>(kern) || c_threads != threads || c_lds != lds || c_per_cu == 0) {
             e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, (int)threads, lds);
             if (e != hipSuccess) return e;
             if (per_cu < 1) per_cu = 1;
+            c_kern = reinterpret_cast<const void *>(kern);
             c_threads = threads;
             c_lds = lds;
             c_per_cu = per_cu;
