@@ -90,6 +90,7 @@ struct KernelParams {
     float lr_rate, lr_minus_power_t;    // SGD / AdagradFlex parameters of the LR block
     float ffm_rate, ffm_minus_power_t;  // ... of the FFM block
     int32_t lut_global;                 // 1: AdaGrad LUT read from global memory (through L1) instead of an LDS copy
+    uint32_t *work;                     // next example to process (zeroed before every launch)
     uint32_t host_cus, host_wgs_cap;    // host side only: persistent grid = occupancy x CUs (capped), when launched with grid 0
     int32_t kernel_version;             // 0 = auto, 1 = force the v1 kernel, 2 = v2 where applicable
     unsigned long long *ticks;          // optional [8] per-phase shader-clock accumulators (debug), else NULL
@@ -137,6 +138,7 @@ struct fwgpu_batch {
     float *label = nullptr;
     float *importance = nullptr;
     float *pred = nullptr;
+    uint32_t *work = nullptr;  // device counter the workgroups of a launch take their examples from
     // raw-record batches (device-side translation)
     uint32_t *records = nullptr;
     uint64_t *rec_off = nullptr;

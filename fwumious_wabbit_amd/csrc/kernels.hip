@@ -861,16 +861,25 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
     }
     if (timing) tk_last = __builtin_amdgcn_s_memtime();
 
-    for (uint32_t ex = blockIdx.x; ex < p.n_examples; ex += gridDim.x) {
+    // Examples are handed out by a device counter, not by a static stride: a workgroup that becomes resident late (another
+    // kernel -- RCCL during a replica exchange -- holds its slot, or the grid was over-subscribed) finds the work already
+    // done instead of running its whole share alone after everyone else has finished.  One workgroup gets 0, 1, 2, ...
+    // (the in-order mode).  The next ticket is requested one example ahead, so its latency is never waited for.
+    if (tid == 0) s.ctr[6] = atomicAdd(p.work, 1u);
+    for (;;) {
         // Previous example's LDS reads are done.  A workgroup-scope barrier does not drain vmcnt on this target,
         // so in the in-order (single workgroup) mode every wave first waits for its own table stores to be
         // acknowledged: the next example must read what this one wrote.  Concurrent (hogwild) grids skip the
         // wait and let the stores drain under the next example's gather.
         if (gridDim.x == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        const uint32_t ex = s.ctr[6];
+        if (ex >= p.n_examples) break;
         FW_TICK(6);
         if (timing) tk[7] += 1;
         const StageOut so = stage_example(p, s, geom, ex, tid, bd);
+        uint32_t next_ticket = 0;  // (every thread is past its read of ctr[6]: the stage phase has barriers)
+        if (tid == 0) next_ticket = atomicAdd(p.work, 1u);
         const uint32_t nf = so.nf, nl = so.nl;
         const float label = so.label, imp = so.imp;
         const bool do_update = so.do_update;
@@ -1058,6 +1067,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
             }
             FW_TICK(5);
         }
+        if (tid == 0) s.ctr[6] = next_ticket;  // published by the loop-top barrier
     }
     if (timing)
         for (int i = 0; i < 8; ++i) atomicAdd(p.ticks + i, tk[i]);
@@ -1229,12 +1239,17 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
     }
     if (timing) tk_last = __builtin_amdgcn_s_memtime();
 
-    for (uint32_t ex = blockIdx.x; ex < p.n_examples; ex += gridDim.x) {
+    if (tid == 0) s.ctr[6] = atomicAdd(p.work, 1u);  // examples come from a device counter: see fw_example_kernel
+    for (;;) {
         if (gridDim.x == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in-order mode: see fw_example_kernel
         __syncthreads();
+        const uint32_t ex = s.ctr[6];
+        if (ex >= p.n_examples) break;
         FW_TICK(6);
         if (timing) atomicAdd(p.ticks + 7, 1ull);
         const StageOut so = stage_example(p, s, geom, ex, tid, bd, timing ? p.ticks : nullptr);
+        uint32_t next_ticket = 0;
+        if (tid == 0) next_ticket = atomicAdd(p.work, 1u);
         const uint32_t nf = so.nf, nl = so.nl;
         const float label = so.label, imp = so.imp;
         const bool do_update = so.do_update;
@@ -1483,6 +1498,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
             }
             FW_TICK(5);
         }
+        if (tid == 0) s.ctr[6] = next_ticket;  // published by the loop-top barrier
     }
 #undef FW_TICK
 }

@@ -111,6 +111,7 @@ int batch_alloc(fwgpu_regressor *r, uint32_t n, uint64_t n_lr, uint64_t n_ffm, f
     b->dev_bytes = std::max<size_t>(o, 256);
     FWGPU_HIP(hipSetDevice(r->device));
     FWGPU_HIP(hipMalloc(&b->dev, b->dev_bytes));
+    FWGPU_HIP(hipMalloc((void **)&b->work, 64));
     unsigned char *base = static_cast<unsigned char *>(b->dev);
     b->ffm_hash = reinterpret_cast<uint32_t *>(base + off[0]);
     b->ffm_val = reinterpret_cast<float *>(base + off[1]);
@@ -146,6 +147,7 @@ int record_batch_alloc(fwgpu_regressor *r, const fwgpu_translator_config *t, uin
     const size_t o_pred = o; o = up256b(o + 4 * (size_t)n_cap);
     b->dev_bytes = std::max<size_t>(o, 256);
     FWGPU_HIP(hipMalloc(&b->dev, b->dev_bytes));
+    FWGPU_HIP(hipMalloc((void **)&b->work, 64));
     unsigned char *base = static_cast<unsigned char *>(b->dev);
     b->records = reinterpret_cast<uint32_t *>(base + o_rec);
     b->rec_off = reinterpret_cast<uint64_t *>(base + o_off);
@@ -312,6 +314,7 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
     p.tr = b->tr;
     p.kernel_version = r->launch.kernel_version;
     p.lut_global = r->launch.lut_global;
+    p.work = b->work;
     p.host_cus = r->num_cus;
     p.host_wgs_cap = r->launch.workgroups_per_cu;
     return p;
@@ -335,6 +338,7 @@ static int run_batch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, h
     if (lds > r->lds_per_cu)
         return fail(FWGPU_ERR_RANGE, "example does not fit the 160 KiB LDS (k*F^2 or features per example too large)");
     const uint32_t grid = pick_grid(r, p, mode, threads);
+    FWGPU_HIP(hipMemsetAsync(b->work, 0, sizeof(uint32_t), stream));
     // An updating launch always uses device-scope (sc1) accesses; read-only launches use cached loads.
     FWGPU_HIP(launch_example_kernel(p, r->cfg.optimizer, update != 0, grid, threads, stream));
     return FWGPU_OK;
@@ -657,6 +661,7 @@ int fwgpu_batch_free(fwgpu_batch *b) {
     if (!b) return FWGPU_OK;
     if (b->dev) (void)hipFree(b->dev);
     if (b->tr_dev) (void)hipFree(b->tr_dev);
+    if (b->work) (void)hipFree(b->work);
     delete b;
     return FWGPU_OK;
 }
