@@ -9,6 +9,11 @@
 //   fw::FeatureBufferTranslator  feature_buffer.rs:33-44, 138-338
 //   fw::Regressor                regressor.rs:142-147; learn/predict 356-395; weights 426-469
 //   fw::HogwildTrainer           hogwild.rs:13-61
+//   fw::VwNamespaceMap           vwmap.rs:30-151, persistence.rs:36-53
+//   fw::VowpalParser             parser.rs:24-461 (FlushCommand / HogwildLoadCommand as exceptions)
+//   fw::RecordCache              cache.rs:54-232
+//   fw::persistence::*           persistence.rs:55-187, main.rs:136-148 (convert_inference_regressor)
+//   fw::Predictor                lib.rs:55-148 over the reference's own FFI symbols (include/fw_ffi.h)
 //
 // Errors: configuration errors throw std::runtime_error (the reference returns Err -> exit 1, main.rs:44-47);
 // violated internal invariants in learn/predict also throw (the reference panics).
@@ -19,6 +24,7 @@
 #include <string>
 #include <vector>
 
+#include "fw_ffi.h"
 #include "fwgpu.h"
 
 namespace fw {
@@ -238,6 +244,186 @@ class HogwildTrainer {  // hogwild.rs:13-61; num_workers has no meaning on the d
   private:
     FeatureBufferTranslator fbt_;
     fwgpu_trainer *h_ = nullptr;
+};
+
+// ---------------------------------------------------------------- feed path (vwmap.rs, parser.rs, cache.rs)
+class VwNamespaceMap {
+  public:
+    explicit VwNamespaceMap(const std::string &csv) { check(fwgpu_vwmap_from_csv(csv.data(), csv.size(), &h_)); }  // vwmap.rs:106
+    explicit VwNamespaceMap(fwgpu_vwmap *adopt) : h_(adopt) {}
+    ~VwNamespaceMap() { fwgpu_vwmap_free(h_); }
+    VwNamespaceMap(const VwNamespaceMap &) = delete;
+    VwNamespaceMap &operator=(const VwNamespaceMap &) = delete;
+    size_t num_namespaces() const { return fwgpu_vwmap_num_namespaces(h_); }
+    NamespaceDescriptor descriptor(const std::string &vwname) const {  // map_vwname_to_namespace_descriptor
+        uint32_t idx = 0, f32 = 0;
+        check(fwgpu_vwmap_lookup(h_, vwname.data(), vwname.size(), 0, &idx, &f32));
+        NamespaceDescriptor nd;
+        nd.namespace_index = static_cast<uint16_t>(idx);
+        nd.format_f32 = f32 != 0;
+        return nd;
+    }
+    std::string save_to_buf() const {  // the JSON of persistence.rs:37-42, without the u64 length prefix
+        uint64_t n = 0;
+        check(fwgpu_vwmap_to_json(h_, nullptr, 0, &n));
+        std::string s(n, '\0');
+        check(fwgpu_vwmap_to_json(h_, &s[0], n, &n));
+        return s;
+    }
+    fwgpu_vwmap *handle() const { return h_; }
+
+  private:
+    fwgpu_vwmap *h_ = nullptr;
+};
+
+struct FlushCommand : std::runtime_error {  // parser.rs:31
+    FlushCommand() : std::runtime_error("Not really an error: a \"flush\" command from client") {}
+};
+struct HogwildLoadCommand : std::runtime_error {  // parser.rs:33-37
+    std::string filename;
+    explicit HogwildLoadCommand(const std::string &f)
+        : std::runtime_error("Not really an error: a \"hogwild_load\" command from client to load: " + f), filename(f) {}
+};
+
+class VowpalParser {
+  public:
+    explicit VowpalParser(const VwNamespaceMap &vw) { check(fwgpu_parser_create(vw.handle(), &h_)); }  // parser.rs:78-105
+    ~VowpalParser() { fwgpu_parser_free(h_); }
+    VowpalParser(const VowpalParser &) = delete;
+    VowpalParser &operator=(const VowpalParser &) = delete;
+    // parser.rs:166-176 on one line (newline included when present); "" = end of stream -> empty record.
+    // Errors throw std::runtime_error carrying the reference's message.
+    const std::vector<uint32_t> &next_vowpal(const std::string &line) { return run(nullptr, 0, line); }
+    // parser.rs:195-211
+    const std::vector<uint32_t> &next_vowpal_with_cache(const std::string &cached, const std::string &line) {
+        return run(cached.data(), cached.size(), line);
+    }
+    std::vector<uint32_t> output_buffer;
+
+  private:
+    const std::vector<uint32_t> &run(const char *prefix, size_t plen, const std::string &line) {
+        output_buffer.resize(1 << 16);
+        uint32_t n = 0;
+        const int rc = fwgpu_parser_parse_with_prefix(h_, prefix, plen, line.data(), line.size(), output_buffer.data(),
+                                                      static_cast<uint32_t>(output_buffer.size()), &n);
+        if (rc == FWGPU_PARSE_FLUSH) throw FlushCommand();
+        if (rc == FWGPU_PARSE_HOGWILD_LOAD) throw HogwildLoadCommand(fwgpu_parser_command_argument(h_));
+        if (rc != FWGPU_OK) throw std::runtime_error(fwgpu_last_error());
+        output_buffer.resize(n);
+        return output_buffer;
+    }
+    fwgpu_parser *h_ = nullptr;
+};
+
+class RecordCache {
+  public:
+    RecordCache(const std::string &input_filename, bool enabled, const VwNamespaceMap &vw) {  // cache.rs:70-131
+        if (!enabled) return;
+        check(fwgpu_cache_open(input_filename.c_str(), vw.handle(), &h_));
+        reading = fwgpu_cache_is_reading(h_) != 0;
+        writing = fwgpu_cache_is_writing(h_) != 0;
+    }
+    ~RecordCache() { fwgpu_cache_free(h_); }
+    RecordCache(const RecordCache &) = delete;
+    RecordCache &operator=(const RecordCache &) = delete;
+    void push_record(const std::vector<uint32_t> &record_buf) {  // cache.rs:133-144
+        if (h_) check(fwgpu_cache_push_records(h_, record_buf.data(), record_buf.size()));
+    }
+    void write_finish() {  // cache.rs:146-152
+        if (h_) check(fwgpu_cache_write_finish(h_));
+        writing = false;
+    }
+    std::vector<uint32_t> get_next_record() {  // cache.rs:187-232: empty at end of file
+        if (!reading) throw std::runtime_error("next_recrod() called on reading cache, when not opened in reading mode");
+        std::vector<uint32_t> rec(1 << 16);
+        uint64_t off[2] = {0, 0}, nr = 0, nw = 0;
+        check(fwgpu_cache_next_records(h_, rec.data(), rec.size(), off, 1, &nr, &nw));
+        rec.resize(nr ? nw : 0);
+        return rec;
+    }
+    fwgpu_cache *handle() const { return h_; }
+    bool reading = false, writing = false;
+
+  private:
+    fwgpu_cache *h_ = nullptr;
+};
+
+// ---------------------------------------------------------------- persistence.rs
+namespace persistence {
+
+inline std::string model_instance_json(const ModelInstance &mi) {  // what serde would emit for the fields this mirror carries
+    auto f = [](float v) {
+        char b[64];
+        check(fwgpu_debug_format_f32(v, b, sizeof b));
+        return std::string(b);
+    };
+    auto nd = [](const NamespaceDescriptor &d) {
+        return std::string("{\"namespace_index\":") + std::to_string(d.namespace_index) +
+               ",\"namespace_type\":\"Primitive\",\"namespace_format\":\"" + (d.format_f32 ? "F32" : "Categorical") + "\"}";
+    };
+    std::string s = "{\"learning_rate\":" + f(mi.learning_rate) + ",\"minimum_learning_rate\":0.0,\"power_t\":" + f(mi.power_t) +
+                    ",\"bit_precision\":" + std::to_string(mi.bit_precision) +
+                    ",\"add_constant_feature\":" + (mi.add_constant_feature ? "true" : "false") + ",\"feature_combo_descs\":[";
+    for (size_t i = 0; i < mi.feature_combo_descs.size(); i++) {
+        s += std::string(i ? "," : "") + "{\"namespace_descriptors\":[";
+        for (size_t j = 0; j < mi.feature_combo_descs[i].namespace_descriptors.size(); j++)
+            s += std::string(j ? "," : "") + nd(mi.feature_combo_descs[i].namespace_descriptors[j]);
+        s += "],\"weight\":" + f(mi.feature_combo_descs[i].weight) + "}";
+    }
+    s += "],\"ffm_fields\":[";
+    for (size_t i = 0; i < mi.ffm_fields.size(); i++) {
+        s += std::string(i ? "," : "") + "[";
+        for (size_t j = 0; j < mi.ffm_fields[i].size(); j++) s += std::string(j ? "," : "") + nd(mi.ffm_fields[i][j]);
+        s += "]";
+    }
+    const char *opt = mi.optimizer == Optimizer::SGD ? "SGD" : mi.optimizer == Optimizer::AdagradFlex ? "AdagradFlex" : "AdagradLUT";
+    s += "],\"ffm_k\":" + std::to_string(mi.ffm_k) + ",\"ffm_bit_precision\":" + std::to_string(mi.ffm_bit_precision) +
+         ",\"fastmath\":true,\"ffm_initialization_type\":\"default\",\"ffm_k_threshold\":0.0,\"ffm_init_center\":" +
+         f(mi.ffm_init_center) + ",\"ffm_init_width\":" + f(mi.ffm_init_width) + ",\"ffm_init_zero_band\":" + f(mi.ffm_init_zero_band) +
+         ",\"ffm_init_acc_gradient\":" + f(mi.ffm_init_acc_gradient) + ",\"init_acc_gradient\":" + f(mi.init_acc_gradient) +
+         ",\"ffm_learning_rate\":" + f(mi.ffm_learning_rate) + ",\"ffm_power_t\":" + f(mi.ffm_power_t) +
+         ",\"nn_init_acc_gradient\":0.0,\"nn_learning_rate\":0.02,\"nn_power_t\":0.45,\"nn_config\":{\"layers\":[],\"topology\":\"one\"}," +
+         "\"optimizer\":\"" + opt + "\",\"transform_namespaces\":{\"v\":[]},\"dequantize_weights\":false}";
+    return s;
+}
+
+// persistence.rs:73-89
+inline void save_regressor_to_filename(const std::string &filename, const ModelInstance &mi, const VwNamespaceMap &vw, Regressor &re,
+                                       bool quantize_weights = false) {
+    const std::string js = model_instance_json(mi);
+    fwgpu_model_instance *h = nullptr;
+    check(fwgpu_mi_from_json(js.data(), js.size(), &h));
+    const int rc = fwgpu_model_save(filename.c_str(), vw.handle(), h, re.handle(), quantize_weights ? 1 : 0);
+    fwgpu_mi_free(h);
+    check(rc);
+}
+// persistence.rs:176-187
+inline void hogwild_load(Regressor &re, const std::string &filename, int device = 0) {
+    fwgpu_regressor *r = re.handle();
+    check(fwgpu_model_load(filename.c_str(), device, 0, nullptr, nullptr, &r));
+}
+// main.rs:136-148
+inline void convert_inference_regressor(const std::string &in, const std::string &out, bool quantize_weights = false) {
+    check(fwgpu_model_convert_inference(in.c_str(), out.c_str(), quantize_weights ? 1 : 0));
+}
+
+}  // namespace persistence
+
+// lib.rs:55-148: the serving predictor, through the reference's own exported symbols
+class Predictor {
+  public:
+    explicit Predictor(const std::string &command) : p_(new_fw_predictor_prototype(command.c_str())) {
+        if (!p_) throw std::runtime_error(fwgpu_last_error());
+    }
+    ~Predictor() { free_predictor(p_); }
+    Predictor(const Predictor &) = delete;
+    Predictor &operator=(const Predictor &) = delete;
+    float predict(const std::string &input) { return fw_predict(p_, input.c_str()); }
+    float setup_cache(const std::string &input) { return fw_setup_cache(p_, input.c_str()); }
+    float predict_with_cache(const std::string &input) { return fw_predict_with_cache(p_, input.c_str()); }
+
+  private:
+    FfiPredictor *p_;
 };
 
 }  // namespace fw

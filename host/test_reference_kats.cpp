@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 #include "fw_host.hpp"
 
@@ -356,6 +357,98 @@ static void test_hogwild_trainer() {
     ASSERT_TRUE(threw);
 }
 
+// parser.rs:474-859 test_vowpal (a representative subset; the whole table runs in tests/test_feed_cpu.py)
+static void test_vowpal() {
+    const uint32_t ONE = 1065353216u, NOF = 1u << 31, M31 = NOF - 1, NOT_SINGLE = NOF;
+    auto nd = [&](uint32_t a, uint32_t b) { return ((a << 16) + b) | NOT_SINGLE; };
+    VwNamespaceMap vw("\nA,featureA\nB,featureB\nC,featureC\n");
+    VowpalParser rr(vw);
+    auto eq = [](const std::vector<uint32_t> &a, std::vector<uint32_t> b) { return a == b; };
+    ASSERT_TRUE(eq(rr.next_vowpal("1 |A a\n"), {6, 1, ONE, 2988156968u & M31, NOF, NOF}));
+    ASSERT_TRUE(eq(rr.next_vowpal("-1 |B b\n"), {6, 0, ONE, NOF, 2422381320u & M31, NOF}));
+    ASSERT_TRUE(eq(rr.next_vowpal("1 |A a b\n"), {10, 1, ONE, nd(6, 10), NOF, NOF, 2988156968u & M31, ONE, 3529656005u & M31, ONE}));
+    ASSERT_TRUE(eq(rr.next_vowpal("1 |A:3 a:2.0\n"), {8, 1, ONE, nd(6, 8), NOF, NOF, 2988156968u & M31, 0x40c00000u}));  // 6.0f
+    ASSERT_TRUE(eq(rr.next_vowpal("|A a\n"), {6, 0xff, ONE, 2988156968u & M31, NOF, NOF}));
+    ASSERT_TRUE(rr.next_vowpal("").empty());
+    bool flush = false, load = false;
+    std::string msg;
+    try { rr.next_vowpal("flush"); } catch (const FlushCommand &) { flush = true; }
+    try { rr.next_vowpal("hogwild_load   /path/to/filename  "); } catch (const HogwildLoadCommand &e) { load = e.filename == "/path/to/filename"; }
+    try { rr.next_vowpal("1 |UNDECLARED_NAMESPACE a\n"); } catch (const std::runtime_error &e) { msg = e.what(); }
+    ASSERT_TRUE(flush && load);
+    ASSERT_TRUE(msg == "Feature name was not predeclared in vw_namespace_map.csv: UNDECLARED_NAMESPACE");
+    // parser.rs:1096-1123 test_cache: the cached context text followed by the request's text
+    VwNamespaceMap vw2("\nAA,featureA\nBB,featureB\nCC,featureC\n");
+    VowpalParser r2(vw2);
+    const std::vector<uint32_t> full = {8, 255, 1065353216, 2147876872u, 1123906636, 2147483648u, 292540976, 1086324736};
+    ASSERT_TRUE(r2.next_vowpal("|BB b |AA:3 a:2.0 \n") == full);
+    ASSERT_TRUE(r2.next_vowpal_with_cache("|BB b ", "|AA:3 a:2.0 \n") == full);
+}
+
+// cache.rs + persistence.rs + lib.rs in one chain (persistence.rs:206-643 style: what is saved predicts the same when loaded)
+static void test_cache_model_file_and_predictor() {
+    VwNamespaceMap vw("A,animal\nB,food\n");
+    VowpalParser pa(vw);
+    const std::string dir = "/tmp/fw_host_test";
+    std::system(("rm -rf " + dir + " && mkdir -p " + dir).c_str());
+    const std::string input = dir + "/train.vw";
+    std::vector<std::vector<uint32_t>> recs;
+    {
+        RecordCache c(input, true, vw);
+        ASSERT_TRUE(c.writing && !c.reading);
+        for (int i = 0; i < 200; i++) {
+            const std::string line = std::string(i % 3 ? "1" : "-1") + " |A a" + std::to_string(i % 7) + " |B f" + std::to_string(i % 5) + (i % 4 ? "" : ":1.5") + "\n";
+            recs.push_back(pa.next_vowpal(line));
+            c.push_record(recs.back());
+        }
+        c.write_finish();
+    }
+    ModelInstance mi = ModelInstance::new_empty();
+    mi.learning_rate = mi.ffm_learning_rate = 0.1f;
+    mi.power_t = mi.ffm_power_t = 0.0f;
+    mi.bit_precision = 14;
+    mi.ffm_bit_precision = 14;
+    mi.ffm_k = 4;
+    mi.ffm_init_acc_gradient = 1.0f;
+    mi.optimizer = Optimizer::AdagradLUT;
+    const NamespaceDescriptor a = vw.descriptor("A"), b = vw.descriptor("B");
+    mi.feature_combo_descs = {{{a}, 1.0f}, {{b}, 1.0f}, {{a, b}, 1.0f}};
+    mi.ffm_fields = {{a}, {b}};
+    Regressor re(mi);
+    FeatureBufferTranslator fbt(mi);
+    PortBuffer pb;
+    {
+        RecordCache c(input, true, vw);  // second open: the cache is read, record by record, identical to what was pushed
+        ASSERT_TRUE(c.reading && !c.writing);
+        size_t n = 0;
+        for (;;) {
+            const std::vector<uint32_t> r = c.get_next_record();
+            if (r.empty()) break;
+            ASSERT_TRUE(n < recs.size() && r == recs[n]);
+            fbt.translate(r, n);
+            re.learn(fbt.feature_buffer, pb, true);
+            n++;
+        }
+        ASSERT_TRUE(n == 200);
+    }
+    const std::string model = dir + "/model.fw", inference = dir + "/model.fw.inference";
+    persistence::save_regressor_to_filename(model, mi, vw, re);
+    persistence::convert_inference_regressor(model, inference);
+    Predictor pr("fw -i " + inference + " -t");
+    for (int i = 0; i < 10; i++) {
+        const std::string req = "|A a" + std::to_string(i % 7) + " |B f" + std::to_string(i % 5) + "\n";
+        fbt.translate(pa.next_vowpal(req), 0);
+        const float want = re.predict(fbt.feature_buffer, pb);
+        ASSERT_NEAR(pr.predict(req), want);
+        ASSERT_TRUE(pr.setup_cache("|A a" + std::to_string(i % 7) + " \n") == 0.0f);
+        ASSERT_NEAR(pr.predict_with_cache("|B f" + std::to_string(i % 5) + "\n"), want);
+    }
+    ASSERT_TRUE(pr.predict("") == -1.0f && pr.predict("|Z z\n") == -1.0f);  // EOF / parse error codes (lib.rs:47-48)
+    Regressor fresh(mi);
+    persistence::hogwild_load(fresh, model);  // persistence.rs:176-187
+    ASSERT_TRUE(fresh.write_weights_to_buf() == re.write_weights_to_buf());
+}
+
 int main() {
     struct T {
         const char *name;
@@ -373,7 +466,9 @@ int main() {
                  {"test_ffm_multivalue", test_ffm_multivalue},
                  {"test_hogwild_load", test_hogwild_load},
                  {"test_translation", test_translation},
-                 {"test_hogwild_trainer", test_hogwild_trainer}};
+                 {"test_hogwild_trainer", test_hogwild_trainer},
+                 {"test_vowpal", test_vowpal},
+                 {"test_cache_model_file_and_predictor", test_cache_model_file_and_predictor}};
     for (const auto &t : tests) {
         t.fn();
         std::printf("ok %s\n", t.name);

@@ -610,4 +610,4 @@ def test_cpp_host_mirror_reference_tests():
         subprocess.run(["make", "-C", os.path.join(ROOT, "host")], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "all 14 tests passed" in r.stdout
+    assert "all 16 tests passed" in r.stdout
