@@ -88,7 +88,8 @@ namespace {
 
 constexpr float kEofErrorCode = -1.0f, kExceptionErrorCode = -1.0f;  // lib.rs:47-48
 
-// parse -> translate -> predict (lib.rs:70-86)
+// parse -> translate -> predict (lib.rs:70-86).  The record goes to the device as it is (one small copy) and is translated
+// in the example kernel's stage phase, like every other record batch; fwgpu_predictor_predict_batch is the same path with n > 1.
 float predict_line(FfiPredictor *p, const char *prefix, size_t prefix_len, const char *text, size_t len) {
     uint32_t n_words = 0;
     p->record.resize(std::max<size_t>(p->record.size(), 4096));
@@ -103,26 +104,20 @@ float predict_line(FfiPredictor *p, const char *prefix, size_t prefix_len, const
     }
     if (rc != FWGPU_OK) return kExceptionErrorCode;  // parse errors and commands alike ("Reading result ... returns error")
     if (n_words == 0) return kEofErrorCode;
+    p->record[1] = 0;  // no label in a request (NO_LABEL = 0xff); the prediction does not depend on it
     SharedModel &m = *p->model;
-    p->lr.resize(std::max<size_t>(p->lr.size(), 1024));
-    p->ffm.resize(std::max<size_t>(p->ffm.size(), 1024));
-    uint32_t n_lr = 0, n_ffm = 0;
-    float label = 0, imp = 0;
-    for (;;) {
-        rc = fwgpu_translate(&m.tr, p->record.data(), n_words, p->lr.data(), (uint32_t)p->lr.size(), &n_lr, p->ffm.data(),
-                             (uint32_t)p->ffm.size(), &n_ffm, &label, &imp);
-        if (rc == FWGPU_ERR_RANGE && p->lr.size() < (1u << 24)) {
-            p->lr.resize(p->lr.size() * 4);
-            p->ffm.resize(p->ffm.size() * 4);
-            continue;
-        }
-        break;
-    }
-    if (rc != FWGPU_OK) return kExceptionErrorCode;
-    float out = 0.0f;
     std::lock_guard<std::mutex> g(m.mu);
-    rc = fwgpu_predict(m.re, p->lr.data(), n_lr, p->ffm.data(), n_ffm, &out);
-    return rc == FWGPU_OK ? out : kExceptionErrorCode;
+    if (!m.batch || m.batch->words_cap < n_words) {
+        if (m.batch) fwgpu_batch_free(m.batch);
+        m.batch = nullptr;
+        if (record_batch_alloc(m.re, &m.tr, 256, std::max<uint64_t>(2 * (uint64_t)n_words, 1 << 16), &m.batch) != FWGPU_OK) return kExceptionErrorCode;
+    }
+    const uint64_t off[2] = {0, n_words};
+    if (record_batch_upload(m.batch, &m.tr, p->record.data(), off, 1, 0) != FWGPU_OK) return kExceptionErrorCode;
+    if (fwgpu_learn_batch(m.re, m.batch, FWGPU_MODE_SEQUENTIAL, /*update=*/0, nullptr) != FWGPU_OK) return kExceptionErrorCode;
+    float out = 0.0f;
+    if (fwgpu_batch_predictions(m.batch, &out, 1, nullptr) != FWGPU_OK) return kExceptionErrorCode;
+    return out;
 }
 
 }  // namespace
