@@ -154,6 +154,9 @@ def main():
                     help="N>1: the agreed model moves by the mean (default) or the sum of the replicas' deltas")
     ap.add_argument("--blocking-sync", dest="blocking_sync", action="store_true",
                     help="N>1: blocking delta all-reduce instead of the overlapped one")
+    ap.add_argument("--dist-backend", dest="dist_backend", default="nccl",
+                    help="torch.distributed backend; 'gloo' + --same-device lets the N>1 path be exercised on a one-GPU box")
+    ap.add_argument("--same-device", dest="same_device", action="store_true", help="debug: every rank uses cuda:0")
     ap.add_argument("--force-dist", dest="force_dist", action="store_true",
                     help="run the RCCL replica-sync path even with one rank (smoke test of the N>1 code on one GPU)")
     ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
@@ -168,7 +171,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path)")
     torch.cuda.set_device(local_rank)
@@ -176,7 +179,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     mi = build_model_instance(fw, args, local_rank)
