@@ -101,6 +101,7 @@ struct LaunchConfig {
     uint32_t workgroups_per_cu = 0;  // 0: as many as LDS allows (capped)
     int32_t kernel_version = 0;      // 0 = auto
     int32_t lut_global = 0;
+    bool threads_set = false;  // fwgpu_set_launch chose the workgroup size: no automatic choice
 };
 
 size_t example_kernel_lds_bytes(const KernelParams &p, int optimizer);

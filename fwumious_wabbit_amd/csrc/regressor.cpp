@@ -335,6 +335,9 @@ static int run_batch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, h
     if ((uint64_t)p.max_ffm > 4ull * threads)
         return fail(FWGPU_ERR_RANGE, "an example has more than 4096 FFM features");
     const size_t lds = example_kernel_lds_bytes(p, r->cfg.optimizer);
+    // When the LDS footprint lets only ONE workgroup live on a CU (k = 16 rows: T alone is 57.6 KB), the CU's waves have
+    // to come from that workgroup: 1024 threads (measured at k = 16: 1.53 -> 1.82 M examples/s; with the deep head 0.67 -> 0.79).
+    if (!r->launch.threads_set && mode == FWGPU_MODE_HOGWILD && 2 * lds > r->lds_per_cu) threads = 1024;
     if (lds > r->lds_per_cu)
         return fail(FWGPU_ERR_RANGE, "example does not fit the 160 KiB LDS (k*F^2 or features per example too large)");
     const uint32_t grid = pick_grid(r, p, mode, threads);
@@ -550,6 +553,7 @@ int fwgpu_set_launch(fwgpu_regressor *r, uint32_t threads, uint32_t workgroups_p
     if (threads) {
         if (threads % 64 || threads > 1024) return fail(FWGPU_ERR_INVALID, "threads must be a multiple of 64, <= 1024");
         r->launch.threads = threads;
+        r->launch.threads_set = true;
     }
     r->launch.workgroups_per_cu = workgroups_per_cu;
     return FWGPU_OK;
