@@ -288,3 +288,72 @@ def test_reference_example_lines_parse_and_translate_like_the_oracle():
         assert fb.lr_buffer.tobytes() == lr.tobytes() and fb.ffm_buffer.tobytes() == ffm.tobytes()
         assert fb.label == label and fb.example_importance == imp
     assert n_multi > 20  # the data does exercise several-features-per-namespace slots
+
+
+def test_lz4_frame_flag_variants_and_xxh32_against_the_xxhash_library(tmp_path):
+    """Frames carrying content size, block checksums and a content checksum (every optional part of the frame descriptor):
+    built here from liblz4's blocks with checksums from the independent `xxhash` package, read by the library's decoder
+    (which verifies all of them with its own xxHash32)."""
+    xxhash = pytest.importorskip("xxhash")
+    vw = VwNamespaceMap(VW6)
+    recs, _ = _records(30000, seed=13)
+    js = vw.to_json()
+    payload = b"FWCA" + struct.pack("<I", 11) + struct.pack("<Q", len(js)) + js + recs.tobytes()
+    src = _frame_via_pyarrow(payload)
+    assert src[:4] == struct.pack("<I", 0x184D2204)
+    flg, bd = src[4], src[5]
+    pos = 6 + (8 if flg & 0x08 else 0) + (4 if flg & 0x01 else 0) + 1
+    blocks = []
+    while True:
+        (sz,) = struct.unpack("<I", src[pos:pos + 4])
+        pos += 4
+        if sz == 0:
+            break
+        n = sz & 0x7fffffff
+        blocks.append((sz, src[pos:pos + n]))
+        pos += n + (4 if flg & 0x10 else 0)
+    assert len(blocks) >= 2  # several blocks, so linked-block history is exercised if liblz4 linked them
+
+    def build(with_size, with_block_sums, with_content_sum, corrupt=None):
+        f = 0x40 | (flg & 0x20) | (0x08 if with_size else 0) | (0x10 if with_block_sums else 0) | (0x04 if with_content_sum else 0)
+        desc = bytes([f, bd]) + (struct.pack("<Q", len(payload)) if with_size else b"")
+        out = struct.pack("<I", 0x184D2204) + desc + bytes([(xxhash.xxh32(desc, seed=0).intdigest() >> 8) & 0xff])
+        for i, (sz, data) in enumerate(blocks):
+            out += struct.pack("<I", sz) + data
+            if with_block_sums:
+                d = xxhash.xxh32(data, seed=0).intdigest()
+                out += struct.pack("<I", d ^ (1 if corrupt == ("block", i) else 0))
+        out += struct.pack("<I", 0)
+        if with_content_sum:
+            out += struct.pack("<I", xxhash.xxh32(payload, seed=0).intdigest() ^ (1 if corrupt == ("content",) else 0))
+        return out
+
+    def read_all(frame):
+        inp = str(tmp_path / "v.vw.gz")
+        open(inp + ".fwcache", "wb").write(frame)
+        rc = RecordCache(inp, True, vw)
+        if not rc.reading:
+            rc.close()
+            os.remove(inp + ".fwcache.writing")
+            raise capi.FwgpuError(5, "header rejected")
+        got = []
+        try:
+            while True:
+                w, o = rc.next_records()
+                if len(o) <= 1:
+                    break
+                got.append(w)
+        finally:
+            rc.close()
+        return np.concatenate(got)
+
+    for flags in [(False, False, False), (True, False, False), (False, True, False), (False, False, True), (True, True, True)]:
+        assert np.array_equal(read_all(build(*flags)), recs), flags
+    for corrupt in (("block", 0), ("block", len(blocks) - 1), ("content",)):
+        with pytest.raises(capi.FwgpuError):
+            read_all(build(True, True, True, corrupt=corrupt))
+    # a wrong header checksum is rejected before any block is read (the cache is then rebuilt)
+    bad = bytearray(build(True, False, False))
+    bad[4 + 2 + 8] ^= 0xff
+    with pytest.raises(capi.FwgpuError):
+        read_all(bytes(bad))
