@@ -9,7 +9,7 @@ import shutil
 SRC = "/root/reference/examples/basic/datasets"
 dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "example_basic")
 os.makedirs(dst, exist_ok=True)
-shutil.copy(os.path.join(SRC, "vw_namespace_map.csv"), os.path.join(dst, "vw_namespace_map.csv"))
-with open(os.path.join(SRC, "train.vw"), "rb") as f, gzip.GzipFile(os.path.join(dst, "train.vw.gz"), "wb", mtime=0) as g:
-    g.write(f.read())
+for name in ("vw_namespace_map.csv", "train.vw"):
+    with open(os.path.join(SRC, name), "rb") as f, gzip.GzipFile(os.path.join(dst, name + ".gz"), "wb", mtime=0) as g:
+        g.write(f.read())
 print(os.listdir(dst))

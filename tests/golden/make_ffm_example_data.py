@@ -18,9 +18,6 @@ with tempfile.TemporaryDirectory() as d:
                            "--num_eval_examples", "3000"], cwd=d)
     for name in ("train.vw", "test-easy.vw", "test-hard.vw", "vw_namespace_map.csv"):
         src = os.path.join(d, "datasets", name)
-        if name.endswith(".csv"):
-            shutil.copy(src, os.path.join(out_dir, name))
-        else:
-            with open(src, "rb") as f, gzip.GzipFile(os.path.join(out_dir, name + ".gz"), "wb", mtime=0) as g:
-                g.write(f.read())
+        with open(src, "rb") as f, gzip.GzipFile(os.path.join(out_dir, name + ".gz"), "wb", mtime=0) as g:
+            g.write(f.read())
         print(name, os.path.getsize(src), "bytes")

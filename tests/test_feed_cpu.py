@@ -252,7 +252,7 @@ def test_reference_example_lines_parse_and_translate_like_the_oracle():
     import gzip
     from oracle import fwo
     base = os.path.join(HERE, "golden", "example_basic")
-    vw = VwNamespaceMap.new_from_csv_filepath(os.path.join(base, "vw_namespace_map.csv"))
+    vw = VwNamespaceMap(gzip.open(os.path.join(base, "vw_namespace_map.csv.gz"), "rt").read())
     NS = vw.num_namespaces
     assert NS == 58
     with gzip.open(os.path.join(base, "train.vw.gz"), "rb") as f:

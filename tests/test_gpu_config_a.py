@@ -79,7 +79,7 @@ def _balanced_accuracy(p, y, threshold=0.5):
 
 def test_examples_ffm_end_to_end(tmp_path):
     from oracle import fwo
-    vw = VwNamespaceMap.new_from_csv_filepath(os.path.join(DATA, "vw_namespace_map.csv"))
+    vw = VwNamespaceMap(gzip.open(os.path.join(DATA, "vw_namespace_map.csv.gz"), "rt").read())
     train = _unpack("train.vw", tmp_path)
     mi = _model_instance(vw)
     # ---- training pass: text -> records (-c writes the cache), single-thread semantics, predictions like `-p`
@@ -144,7 +144,7 @@ def test_reference_example_datasets_lr(tmp_path, name, interactions, power_t, op
     """The reference's production-like example lines (58 namespaces, 2/3/4-way interactions, namespace weights, several
     features per namespace) through parser -> device translation -> LR learner, against the oracle and the host translator"""
     from oracle import fwo
-    vw = VwNamespaceMap.new_from_csv_filepath(os.path.join(BASIC, "vw_namespace_map.csv"))
+    vw = VwNamespaceMap(gzip.open(os.path.join(BASIC, "vw_namespace_map.csv.gz"), "rt").read())
     with gzip.open(os.path.join(BASIC, "train.vw.gz"), "rb") as f:
         text = f.read()
     words, off, used, rc = VowpalParser(vw).parse_buffer(text)
