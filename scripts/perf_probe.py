@@ -45,10 +45,10 @@ use_records = os.environ.get("RECORDS", "1") == "1"
 if use_records:
     batches = [re.record_batch(fbt, recs[int(off[s*B]):int(off[(s+1)*B])], off[s*B:(s+1)*B+1] - off[s*B]) for s in range(NB)]
 quick = os.environ.get("QUICK", "0") == "1"
-for lutg in ((0,) if quick else (0, 1)):
+for lutg in ((int(os.environ.get("LUTG", 0)),) if quick else (0, 1)):
     capi.check(L.fwgpu_debug_set_option(re.h, 1, lutg))
     print(f"--- kernel v2, lut_global={lutg}, records={use_records}")
-    for th, w in (((int(os.environ.get("THREADS", 512)), int(os.environ.get("WGS", 2))),) if quick else ((512, 2), (384, 2), (320, 3), (384, 3), (256, 4), (448, 2))):
+    for th, w in (((int(os.environ.get("THREADS", 512)), int(os.environ.get("WGS", 0))),) if quick else ((512, 2), (384, 2), (320, 3), (384, 3), (256, 4), (448, 2))):
         run(th, w)
         if quick:
             run(th, w, update=False)
