@@ -64,6 +64,7 @@ class Parser {
 
   private:
     const char *p_, *e_;
+    int depth_ = 0;
     [[noreturn]] void fail(const char *what) { throw std::runtime_error(std::string("JSON: ") + what); }
     void ws() {
         while (p_ < e_ && (*p_ == ' ' || *p_ == '\n' || *p_ == '\t' || *p_ == '\r')) ++p_;
@@ -144,6 +145,12 @@ class Parser {
         return o;
     }
     Value value() {
+        struct Depth {  // the documents read here nest 5 deep; a hostile file must not overflow the stack
+            int &d;
+            explicit Depth(int &x) : d(x) { ++d; }
+            ~Depth() { --d; }
+        } guard(depth_);
+        if (depth_ > 64) fail("nested too deeply");
         ws();
         if (p_ >= e_) fail("unexpected end");
         Value v;

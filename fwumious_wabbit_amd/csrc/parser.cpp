@@ -312,6 +312,9 @@ static int parse_line(fwgpu_parser *ps, const char *line, size_t size) {
                 if (ns_f32) {
                     const size_t fs = i_start + vw.skip_prefix;
                     float v;
+                    if (fs > i_end_first)  // name shorter than _namespace_skip_prefix: the reference slices start > end here (UB)
+                        return fail(FWGPU_ERR_PARSE, "Failed parsing feature value to float (for float namespace): feature name "
+                                                     "shorter than _namespace_skip_prefix");
                     if (i_end_first != fs) {
                         int rc = parse_float_or_error(fs, i_end_first, "Failed parsing feature value to float (for float namespace)", &v);
                         if (rc) return rc;
@@ -470,7 +473,12 @@ int fwgpu_parser_parse_line(fwgpu_parser *p, const char *line, uint64_t len, uin
     if (len == 0) return FWGPU_OK;  // end of stream: empty record (parser.rs:172)
     p->scratch.assign(line, len);
     p->scratch.push_back('\0');
-    const int rc = parse_line(p, p->scratch.data(), len);
+    int rc;
+    try {
+        rc = parse_line(p, p->scratch.data(), len);
+    } catch (const std::exception &e) {  // nothing may unwind across the C ABI
+        return fail(FWGPU_ERR_PARSE, std::string("Cannot parse an example: ") + e.what());
+    }
     if (rc != FWGPU_OK) return rc;
     *n_words = (uint32_t)p->out.size();
     if (!out) return FWGPU_OK;
@@ -507,12 +515,16 @@ int fwgpu_parser_parse_buffer(fwgpu_parser *p, const char *text, uint64_t len, u
         const char *nl = static_cast<const char *>(std::memchr(text + pos, '\n', len - pos));
         const uint64_t line_len = nl ? (uint64_t)(nl - (text + pos)) + 1 : len - pos;
         int rc;
-        if (pos + line_len < len) {
-            rc = parse_line(p, text + pos, line_len);  // in place: the next line's first byte is readable
-        } else {
-            p->scratch.assign(text + pos, line_len);
-            p->scratch.push_back('\0');
-            rc = parse_line(p, p->scratch.data(), line_len);
+        try {
+            if (pos + line_len < len) {
+                rc = parse_line(p, text + pos, line_len);  // in place: the next line's first byte is readable
+            } else {
+                p->scratch.assign(text + pos, line_len);
+                p->scratch.push_back('\0');
+                rc = parse_line(p, p->scratch.data(), line_len);
+            }
+        } catch (const std::exception &e) {
+            rc = fail(FWGPU_ERR_PARSE, std::string("Cannot parse an example: ") + e.what());
         }
         if (rc != FWGPU_OK) {
             *n_records = nr;

@@ -357,3 +357,98 @@ def test_lz4_frame_flag_variants_and_xxh32_against_the_xxhash_library(tmp_path):
     bad[4 + 2 + 8] ^= 0xff
     with pytest.raises(capi.FwgpuError):
         read_all(bytes(bad))
+
+
+def test_parser_survives_garbage():
+    """No input may crash the parser or make it read outside the line: random bytes, truncated and spliced valid lines,
+    absurdly long tokens.  Every call must end in a record, a command or a parse error."""
+    vw = VwNamespaceMap(VW6 + "_namespace_skip_prefix,1\nG,fl,f32\n")
+    p = VowpalParser(vw)
+    rng = np.random.default_rng(99)
+    good = [b"1 |A a b:2 |B:0.5 c |G G1.5 Gx\n", b"-1 0.25 |C x |D y:3e2 |E z:NONE\n", b"|F only |A q\n", b"flush\n",
+            b"hogwild_load /x/y\n"]
+    outcomes = {"ok": 0, "err": 0, "cmd": 0}
+    for i in range(4000):
+        kind = i % 4
+        if kind == 0:
+            line = bytes(rng.integers(0, 256, size=int(rng.integers(1, 200)), dtype=np.uint8))
+        elif kind == 1:
+            g = good[int(rng.integers(0, len(good)))]
+            line = g[: int(rng.integers(1, len(g) + 1))]
+        elif kind == 2:
+            a, b_ = good[int(rng.integers(0, 3))], good[int(rng.integers(0, 3))]
+            cut = int(rng.integers(0, len(a)))
+            line = a[:cut] + bytes(rng.integers(32, 127, size=int(rng.integers(0, 8)), dtype=np.uint8)) + b_[int(rng.integers(0, len(b_))):]
+        else:
+            line = b"1 |A " + b"x" * int(rng.integers(1, 5000)) + b":" + b"9" * int(rng.integers(0, 400)) + b"\n"
+        try:
+            r = p.next_vowpal(line)
+            assert len(r) == 0 or r[0] == len(r)
+            outcomes["ok"] += 1
+        except capi.FwgpuError as e:
+            assert e.code == capi.ERR_PARSE
+            outcomes["err"] += 1
+        except (FlushCommand, HogwildLoadCommand):
+            outcomes["cmd"] += 1
+    assert outcomes["ok"] > 500 and outcomes["err"] > 500 and outcomes["cmd"] > 10, outcomes
+    # the bulk entry point on a buffer that ends without a newline and contains NUL bytes
+    words, off, used, rc = p.parse_buffer(b"1 |A a\n-1 |B b\x00c\n1 |C tail")
+    assert rc == capi.OK and len(off) == 4 and used == len(b"1 |A a\n-1 |B b\x00c\n1 |C tail")
+
+
+def test_cache_and_json_readers_survive_garbage(tmp_path):
+    """Corrupted cache files (raw and LZ4) and corrupted JSON must end in an error or in clean records, never in a crash."""
+    from fwumious_wabbit_amd import persistence as P
+    vw = VwNamespaceMap(VW6)
+    recs, _ = _records(300, seed=17)
+    rng = np.random.default_rng(123)
+    for gz in (False, True):
+        inp = str(tmp_path / ("g.vw.gz" if gz else "g.vw"))
+        c = RecordCache(inp, True, vw)
+        c.push_records(recs)
+        c.write_finish()
+        c.close()
+        good = open(inp + ".fwcache", "rb").read()
+        for trial in range(150):
+            b = bytearray(good)
+            for _ in range(int(rng.integers(1, 6))):
+                kind = int(rng.integers(0, 3))
+                pos = int(rng.integers(0, len(b)))
+                if kind == 0:
+                    b[pos] = int(rng.integers(0, 256))
+                elif kind == 1:
+                    del b[pos:pos + int(rng.integers(1, 64))]
+                else:
+                    b[pos:pos] = bytes(rng.integers(0, 256, size=int(rng.integers(1, 64)), dtype=np.uint8))
+            open(inp + ".fwcache", "wb").write(bytes(b))
+            rc = RecordCache(inp, True, vw)
+            try:
+                if rc.reading:
+                    for _ in range(1000):
+                        w, o = rc.next_records(words_cap=1 << 16, max_records=64)
+                        if len(o) <= 1:
+                            break
+                        assert all(w[int(a)] == int(b_) - int(a) for a, b_ in zip(o[:-1], o[1:]))
+            except capi.FwgpuError:
+                pass
+            finally:
+                rc.close()
+            for leftover in (inp + ".fwcache.writing",):
+                if os.path.exists(leftover):
+                    os.remove(leftover)
+    # JSON documents: mutated vw_source / ModelInstance text
+    mi = fw.ModelInstance(ffm_k=2, ffm_fields=[[fw.NamespaceDescriptor(0)]], feature_combo_descs=[fw.FeatureComboDesc([fw.NamespaceDescriptor(0)])])
+    docs = [vw.to_json(), P.ModelInstanceHandle.from_model_instance(mi).to_json()]
+    for doc in docs:
+        for trial in range(300):
+            b = bytearray(doc)
+            for _ in range(int(rng.integers(1, 4))):
+                pos = int(rng.integers(0, len(b)))
+                b[pos:pos + int(rng.integers(0, 3))] = bytes(rng.integers(32, 127, size=int(rng.integers(0, 4)), dtype=np.uint8))
+            try:
+                if doc is docs[0]:
+                    VwNamespaceMap.new_from_buf(bytes(b)).to_json()
+                else:
+                    P.ModelInstanceHandle.from_json(bytes(b)).to_json()
+            except capi.FwgpuError:
+                pass
