@@ -134,3 +134,37 @@ def test_bad_config_is_rejected_before_touching_the_device():
     with pytest.raises(capi.FwgpuError) as ei:
         fw.Regressor(mi)
     assert ei.value.code == 1 and "FFM_CONTRA_BUF_LEN" in str(ei.value)  # block_ffm.rs:96-101
+
+
+def test_host_translator_survives_garbage_records():
+    """FeatureBufferTranslator::translate on the host: corrupted record words (slot offsets pointing anywhere, wrong lengths)
+    must be rejected or translated within bounds, never crash (the reference indexes unchecked: feature_buffer.rs:47-108)."""
+    from helpers import make_pair
+
+    mi, _, ots = make_pair(8, 4, 16, 16, fw.Optimizer.AdagradLUT, interactions=[(0, 1), (2, 3)])
+    fbt = fw.FeatureBufferTranslator(mi)
+    recs, off = fw.synth_records(8, 2.0, 1.1, 1000, 0.5, 5, 0, 50)
+    rng = np.random.default_rng(7)
+    ok = bad = 0
+    for trial in range(3000):
+        i = int(rng.integers(0, 50))
+        r = recs[int(off[i]):int(off[i + 1])].copy()
+        for _ in range(int(rng.integers(1, 4))):
+            kind = int(rng.integers(0, 4))
+            pos = int(rng.integers(0, len(r)))
+            if kind == 0:
+                r[pos] = rng.integers(0, 2 ** 32, dtype=np.uint64).astype(np.uint32)
+            elif kind == 1:
+                r[pos] ^= np.uint32(1) << np.uint32(rng.integers(0, 32))
+            elif kind == 2:
+                r = r[: max(1, pos)]
+            else:
+                if len(r) > 11:
+                    r[3 + int(rng.integers(0, 8))] = np.uint32(0x80000000 | (int(rng.integers(0, 0x4000)) << 16) | int(rng.integers(0, 0x10000)))
+        try:
+            fb = fbt.translate(r)
+            assert len(fb.lr_buffer) <= 8192 and len(fb.ffm_buffer) <= 8192
+            ok += 1
+        except capi.FwgpuError:
+            bad += 1
+    assert ok > 100 and bad > 100, (ok, bad)
