@@ -394,6 +394,13 @@ struct File {
         for (int i = 7; i >= 0; i--) v = (v << 8) | b[i];
         return v;
     }
+    uint64_t remaining() {  // bytes between the read position and the end of the file
+        const long here = std::ftell(f);
+        std::fseek(f, 0, SEEK_END);
+        const long end = std::ftell(f);
+        std::fseek(f, here, SEEK_SET);
+        return end > here ? (uint64_t)(end - here) : 0;
+    }
     void put_u64(uint64_t v) {
         uint8_t b[8];
         for (int i = 0; i < 8; i++) b[i] = (uint8_t)(v >> (8 * i));
@@ -677,6 +684,7 @@ int fwgpu_model_load(const char *path, int device, int immutable, fwgpu_vwmap **
         const int file_opt = mi->optimizer;
         const bool quantized = mi->dequantize_weights == 1;  // persistence.rs:147-153
         const uint64_t body = blob_body_bytes(file_opt, quantized, s);
+        if (in.remaining() < body) return fail(FWGPU_ERR_FORMAT, "model file: truncated weights");  // before allocating `body` bytes
         std::vector<uint8_t> src(body);
         in.need(src.data(), body, "weights");
 
@@ -758,6 +766,7 @@ int fwgpu_model_convert_inference(const char *in_path, const char *out_path, int
                                               ", expected " + std::to_string(s.elems()));
         // the reference reads with weight_quantization = dequantize_weights && !conversion_flag == false (persistence.rs:147-153)
         const uint64_t body = blob_body_bytes(mi->optimizer, false, s);
+        if (in.remaining() < body) return fail(FWGPU_ERR_FORMAT, "model file: truncated weights");
         std::vector<uint8_t> src(body), w;
         in.need(src.data(), body, "weights");
         to_weights_only(src.data(), mi->optimizer, false, s, w);
