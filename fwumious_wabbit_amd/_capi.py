@@ -143,6 +143,7 @@ def lib():
         "fwgpu_trainer_free": [vp],
         "fwgpu_trainer_examples_seen": [vp, P(u64)],
         "fwgpu_set_launch": [vp, u32, u32],
+        "fwgpu_set_max_in_flight": [vp, u32],
         "fwgpu_delta_start": [vp, vp, vp, vp, u64, f32, vp],
         "fwgpu_delta_finish": [vp, vp, vp, vp, u64, vp],
         "fwgpu_debug_phase_ticks": [vp, i32, vp],
@@ -170,6 +171,8 @@ def lib():
         "fwgpu_quantize_ffm_weights": [vp, u64, vp, u64],
         "fwgpu_dequantize_ffm_weights": [vp, u64, vp],
         "fwgpu_trainer_digest_cache": [vp, vp, u64, P(u64)],
+        "fwgpu_trainer_digest_text": [vp, vp, vp, C.c_char_p, u64, u32, P(u64), P(u64)],
+        "fwgpu_parser_clone": [vp, P(vp)],
         "fwgpu_cache_open": [C.c_char_p, vp, P(vp)],
         "fwgpu_cache_push_records": [vp, vp, u64],
         "fwgpu_cache_write_finish": [vp],

@@ -91,7 +91,7 @@ struct KernelParams {
     float ffm_rate, ffm_minus_power_t;  // ... of the FFM block
     int32_t lut_global;                 // 1: AdaGrad LUT read from global memory (through L1) instead of an LDS copy
     uint32_t *work;                     // next example to process (zeroed before every launch)
-    uint32_t host_cus, host_wgs_cap;    // host side only: persistent grid = occupancy x CUs (capped), when launched with grid 0
+    uint32_t host_cus, host_wgs_cap, host_grid_cap;    // host side only: persistent grid = occupancy x CUs (capped), when launched with grid 0
     int32_t kernel_version;             // 0 = auto, 1 = force the v1 kernel, 2 = v2 where applicable
     unsigned long long *ticks;          // optional [8] per-phase shader-clock accumulators (debug), else NULL
 };
@@ -101,7 +101,8 @@ struct LaunchConfig {
     uint32_t workgroups_per_cu = 0;  // 0: as many as LDS allows (capped)
     int32_t kernel_version = 0;      // 0 = auto
     int32_t lut_global = 0;
-    bool threads_set = false;  // fwgpu_set_launch chose the workgroup size: no automatic choice
+    bool threads_set = false;
+    uint32_t max_in_flight = 0;  // cap on the persistent grid = examples processed concurrently (0: what the device holds)  // fwgpu_set_launch chose the workgroup size: no automatic choice
 };
 
 size_t example_kernel_lds_bytes(const KernelParams &p, int optimizer);

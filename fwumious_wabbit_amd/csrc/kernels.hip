@@ -1102,6 +1102,7 @@ static hipError_t launch_persistent(K kern, const KernelParams &p, uint32_t grid
         if (p.host_wgs_cap && (uint32_t)per_cu > p.host_wgs_cap) per_cu = (int)p.host_wgs_cap;
         const uint64_t g = (uint64_t)per_cu * (p.host_cus ? p.host_cus : 1);
         grid = (uint32_t)(g < p.n_examples ? g : p.n_examples);
+        if (p.host_grid_cap && grid > p.host_grid_cap) grid = p.host_grid_cap;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, p);
     return hipGetLastError();

@@ -467,6 +467,11 @@ int fwgpu_parser_create(const fwgpu_vwmap *vw, fwgpu_parser **out) {
 
 void fwgpu_parser_free(fwgpu_parser *p) { delete p; }
 
+int fwgpu_parser_clone(const fwgpu_parser *src, fwgpu_parser **out) {  // VowpalParser: derive(Clone) (parser.rs:23)
+    if (!src || !out) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    return fwgpu_parser_create(&src->vw_copy, out);
+}
+
 int fwgpu_parser_parse_line(fwgpu_parser *p, const char *line, uint64_t len, uint32_t *out, uint32_t cap, uint32_t *n_words) {
     if (!p || !n_words || (!line && len)) return fail(FWGPU_ERR_INVALID, "NULL argument");
     *n_words = 0;

@@ -317,6 +317,7 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
     p.work = b->work;
     p.host_cus = r->num_cus;
     p.host_wgs_cap = r->launch.workgroups_per_cu;
+    p.host_grid_cap = r->launch.max_in_flight;
     return p;
 }
 
@@ -556,6 +557,12 @@ int fwgpu_set_launch(fwgpu_regressor *r, uint32_t threads, uint32_t workgroups_p
         r->launch.threads_set = true;
     }
     r->launch.workgroups_per_cu = workgroups_per_cu;
+    return FWGPU_OK;
+}
+
+int fwgpu_set_max_in_flight(fwgpu_regressor *r, uint32_t n_examples) {
+    if (!r) return fail(FWGPU_ERR_INVALID, "NULL regressor");
+    r->launch.max_in_flight = n_examples;
     return FWGPU_OK;
 }
 

@@ -4,6 +4,8 @@
 // micro-batch i+1 overlaps the kernel of micro-batch i.  The host only validates slot words (count_record).
 #include <string.h>
 
+#include <string>
+
 #include <algorithm>
 #include <memory>
 #include <thread>
@@ -221,6 +223,108 @@ int fwgpu_trainer_digest_cache(fwgpu_trainer *tr, fwgpu_cache *cache, uint64_t m
         cur ^= 1;
     }
     if (n_digested) *n_digested = done;
+    return rc;
+}
+
+// Text -> trainer in native code (main.rs:213-270 without a cache, or its first pass with `-c`): the buffer is cut at line
+// boundaries into one slice per host thread, every slice is parsed by its own parser clone (VowpalParser is not thread
+// safe), the records are digested in the original order and, when `cache` is open for writing, appended to it.
+int fwgpu_trainer_digest_text(fwgpu_trainer *tr, fwgpu_parser *parser, fwgpu_cache *cache, const char *text, uint64_t len,
+                              uint32_t threads, uint64_t *n_examples, uint64_t *consumed) {
+    if (!tr || !parser || (!text && len)) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    const unsigned T = std::max(1u, std::min<unsigned>(threads ? threads : 8, 64));
+    struct Slice {
+        uint64_t begin = 0, end = 0, used = 0, nr = 0, nw = 0;
+        std::vector<uint32_t> words;
+        std::vector<uint64_t> off;
+        int rc = FWGPU_OK;
+        std::string msg;
+    };
+    std::vector<Slice> sl(T);
+    uint64_t pos = 0;
+    for (unsigned k = 0; k < T; k++) {  // slice k ends at the first line break at or after its proportional share
+        sl[k].begin = pos;
+        uint64_t e = k + 1 == T ? len : std::max<uint64_t>(pos, len * (k + 1) / T);
+        if (e < len) {
+            const void *nl = memchr(text + e, '\n', len - e);
+            e = nl ? (uint64_t)(static_cast<const char *>(nl) - text) + 1 : len;
+        }
+        sl[k].end = pos = e;
+    }
+    auto work = [&](unsigned k) {
+        Slice &s = sl[k];
+        const uint64_t n = s.end - s.begin;
+        if (!n) return;
+        fwgpu_parser *p = parser, *own = nullptr;
+        if (k > 0) {
+            s.rc = fwgpu_parser_clone(parser, &own);
+            if (s.rc) {
+                s.msg = fwgpu_last_error();
+                return;
+            }
+            p = own;
+        }
+        uint64_t lines = 0;
+        for (const char *q = text + s.begin, *e = text + s.end; q < e; lines++) {
+            const void *nl = memchr(q, '\n', (size_t)(e - q));
+            q = nl ? static_cast<const char *>(nl) + 1 : e;
+        }
+        // a feature token takes >= 2 bytes of text and <= 2 words of record; the per-line header depends on the namespace
+        // map, so the buffer grows whenever a pass stops short without an error
+        s.words.resize(n + lines * 64 + 4096);
+        s.off.assign(lines + 1, 0);
+        std::vector<uint64_t> tmp(lines + 1);
+        while (s.used < n) {
+            uint64_t nr = 0, nw = 0, used = 0;
+            s.rc = fwgpu_parser_parse_buffer(p, text + s.begin + s.used, n - s.used, s.words.data() + s.nw, s.words.size() - s.nw,
+                                             tmp.data(), lines - s.nr, &nr, &nw, &used);
+            for (uint64_t j = 1; j <= nr; j++) s.off[s.nr + j] = s.nw + tmp[j];
+            s.nr += nr;
+            s.nw += nw;
+            s.used += used;
+            if (s.rc != FWGPU_OK) {
+                s.msg = fwgpu_last_error();
+                break;
+            }
+            if (s.used < n) {  // out of room (not a command, not an error): grow and go on
+                if (s.words.size() > (1ull << 33)) {
+                    s.rc = FWGPU_ERR_RANGE;
+                    s.msg = "digest_text: a slice needs more than 32 GiB of records";
+                    break;
+                }
+                s.words.resize(s.words.size() * 2);
+            }
+        }
+        if (own) fwgpu_parser_free(own);
+    };
+    {
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < T; k++) th.emplace_back(work, k);
+        work(0);
+        for (auto &x : th) x.join();
+    }
+    uint64_t done = 0, used = 0;
+    int rc = FWGPU_OK;
+    for (unsigned k = 0; k < T && rc == FWGPU_OK; k++) {
+        Slice &s = sl[k];
+        uint64_t i = 0;
+        while (i < s.nr && rc == FWGPU_OK) {
+            const uint32_t take = (uint32_t)std::min<uint64_t>(s.nr - i, 1u << 30);
+            // offsets are relative to the slice's first word
+            rc = fwgpu_digest_records(tr, s.words.data(), s.off.data() + i, take);
+            i += take;
+        }
+        if (rc == FWGPU_OK && cache && s.nw) rc = fwgpu_cache_push_records(cache, s.words.data(), s.nw);
+        if (rc != FWGPU_OK) break;
+        done += s.nr;
+        used = s.begin + s.used;
+        if (s.rc != FWGPU_OK) {  // a command or a bad line stopped this slice: stop here, in order
+            rc = (s.rc == FWGPU_PARSE_FLUSH || s.rc == FWGPU_PARSE_HOGWILD_LOAD) ? s.rc : fail(s.rc, s.msg);
+            break;
+        }
+    }
+    if (n_examples) *n_examples = done;
+    if (consumed) *consumed = used;
     return rc;
 }
 

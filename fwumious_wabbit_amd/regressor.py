@@ -307,6 +307,10 @@ class Regressor:
         check(self.L.fwgpu_set_launch(self.h, threads, workgroups_per_cu))
 
     # ---- tables
+    def set_max_in_flight(self, n):
+        """cap on the examples a HOGWILD launch processes concurrently (16 = hogwild.rs's default thread count; 0 = no cap)"""
+        check(self.L.fwgpu_set_max_in_flight(self.h, n))
+
     def table_len(self, which):
         n = C.c_uint64(0)
         check(self.L.fwgpu_table_len(self.h, which, C.byref(n)))
@@ -397,6 +401,16 @@ class HogwildTrainer:
         n = C.c_uint64()
         check(capi.lib().fwgpu_trainer_digest_cache(self.h, cache.h, max_records, C.byref(n)))
         return n.value
+
+    def digest_text(self, parser, text: bytes, cache=None, threads=0):
+        """VW text -> device in native code; returns (examples learned, bytes consumed, status): status is OK, PARSE_FLUSH,
+        PARSE_HOGWILD_LOAD; parse errors raise"""
+        n, used = C.c_uint64(), C.c_uint64()
+        rc = capi.lib().fwgpu_trainer_digest_text(self.h, parser.h, cache.h if cache is not None else None, text, len(text),
+                                                  threads, C.byref(n), C.byref(used))
+        if rc not in (capi.OK, capi.PARSE_FLUSH, capi.PARSE_HOGWILD_LOAD):
+            check(rc)
+        return n.value, used.value, rc
 
     def block_until_workers_finished(self):
         """hogwild.rs:55-60"""

@@ -238,6 +238,10 @@ int fwgpu_trainer_examples_seen(const fwgpu_trainer *tr, uint64_t *n);
  * threads: workgroup size (multiple of 64, <=1024); workgroups_per_cu: persistent grid = CUs*this.
  * 0 keeps the default.  Does not change results in SEQUENTIAL mode. */
 int fwgpu_set_launch(fwgpu_regressor *r, uint32_t threads, uint32_t workgroups_per_cu);
+/* HOGWILD launches process as many examples concurrently as the device holds workgroups (768 on MI355X at config C).  On a
+ * small or tiny-example data set that much staleness keeps the model from learning (hogwild.rs runs 16 threads): n caps
+ * the examples in flight, n = 16 is the reference's default degree of concurrency, 0 = no cap. */
+int fwgpu_set_max_in_flight(fwgpu_regressor *r, uint32_t n_examples);
 
 /* ---------------------------------------------------------------- multi-GPU replica bookkeeping (device pointers)
  * Data-parallel replicas exchange what each changed since the last agreed snapshot (replaces hogwild.rs's shared
@@ -324,6 +328,14 @@ void fwgpu_cache_free(fwgpu_cache *c);
  * (0 = to the end of the file) are read, copied to pinned memory and learned; a reader thread overlaps the file with the
  * device.  Call fwgpu_finish afterwards, as after fwgpu_digest_records. */
 int fwgpu_trainer_digest_cache(fwgpu_trainer *tr, fwgpu_cache *cache, uint64_t max_records, uint64_t *n_digested);
+/* The same loop over VW TEXT (no cache, or the cache-writing first pass of `-c`): `text` is cut at line breaks into one
+ * slice per host thread (threads == 0: 8), each parsed by a clone of `parser`; the records are learned in the original
+ * order and appended to `cache` when it is non-NULL and open for writing.  Stops at the first line that is not an
+ * example: the return value says why (FWGPU_PARSE_FLUSH, FWGPU_PARSE_HOGWILD_LOAD, FWGPU_ERR_PARSE), *consumed = bytes
+ * fully digested, *n_examples = examples learned. */
+int fwgpu_parser_clone(const fwgpu_parser *src, fwgpu_parser **out);
+int fwgpu_trainer_digest_text(fwgpu_trainer *tr, fwgpu_parser *parser, fwgpu_cache *cache, const char *text, uint64_t len,
+                              uint32_t threads, uint64_t *n_examples, uint64_t *consumed);
 
 /* ---------------------------------------------------------------- model files
  * File = "FWRE", u32 version 6, u64 + JSON(vw_source), u64 + JSON(ModelInstance), weights blob (persistence.rs:17-97,

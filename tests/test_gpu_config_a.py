@@ -176,3 +176,44 @@ def test_reference_example_datasets_lr(tmp_path, name, interactions, power_t, op
         re.close()
     assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]  # device translation == host translation
     assert len(np.unique(out[0][0][200:])) > 50  # and it is not predicting a constant
+
+
+def test_text_to_trainer_natively_with_cache_writing(tmp_path):
+    """fwgpu_trainer_digest_text: the reference's training loop over VW text with `-c` (main.rs:213-270), all in native
+    code: several parser threads, records learned in file order (hogwild on the device), cache written on the way"""
+    vw = VwNamespaceMap(gzip.open(os.path.join(DATA, "vw_namespace_map.csv.gz"), "rt").read())
+    train = _unpack("train.vw", tmp_path)
+    text = open(train, "rb").read()
+    mi = _model_instance(vw)
+    re = fw.Regressor(mi)
+    # 30 000 two-feature examples: with 768 of them in flight every example reads weights that are thousands of updates stale
+    # and the latent factors do not form (balanced accuracy 0.49 on the hard set); 16 in flight = hogwild.rs's default
+    re.set_max_in_flight(16)
+    tr = fw.HogwildTrainer(re, mi, micro_batch=2048)
+    parser = VowpalParser(vw)
+    cache = RecordCache(train, True, vw)
+    assert cache.writing
+    n, used, rc = tr.digest_text(parser, text, cache=cache, threads=5)
+    tr.block_until_workers_finished()
+    cache.write_finish()
+    cache.close()
+    assert rc == capi.OK and n == 30000 and used == len(text) and tr.examples_seen() == 30000
+    # the cache holds exactly what a single parser produces for the whole file
+    words, off, _, _ = VowpalParser(vw).parse_buffer(text)
+    raw = open(train + ".fwcache", "rb").read()
+    assert raw.endswith(words.tobytes()) and raw[:4] == b"FWCA"
+    # the hogwild-trained model solves the reference's hard test set too
+    hw, ho, _ = _records_of(_unpack("test-hard.vw", tmp_path), vw, False)
+    assert _balanced_accuracy(_predict(re, mi, hw, ho), record_labels(hw, ho)) > 0.80
+    # a command in the middle stops the digestion exactly there, in order
+    lines = text.split(b"\n")
+    mixed = b"\n".join(lines[:1000]) + b"\nflush\n" + b"\n".join(lines[1000:2000]) + b"\n"
+    re2 = fw.Regressor(mi)
+    tr2 = fw.HogwildTrainer(re2, mi, micro_batch=512)
+    n2, used2, rc2 = tr2.digest_text(parser, mixed, threads=4)
+    tr2.block_until_workers_finished()
+    assert rc2 == capi.PARSE_FLUSH and n2 == 1000 and used2 == len(b"\n".join(lines[:1000]) + b"\n") and tr2.examples_seen() == 1000
+    with pytest.raises(capi.FwgpuError):
+        tr2.digest_text(parser, b"1 |A x\n1 |NOPE y\n", threads=1)
+    for x in (tr, tr2, re, re2):
+        x.close()
