@@ -235,10 +235,17 @@ int fwgpu_trainer_digest_text(fwgpu_trainer *tr, fwgpu_parser *parser, fwgpu_cac
     const unsigned T = std::max(1u, std::min<unsigned>(threads ? threads : 8, 64));
     struct Slice {
         uint64_t begin = 0, end = 0, used = 0, nr = 0, nw = 0;
-        std::vector<uint32_t> words;
+        std::unique_ptr<uint32_t[]> words;  // uninitialised on purpose: zero-filling hundreds of MB costs more than parsing them
+        uint64_t words_cap = 0;
         std::vector<uint64_t> off;
         int rc = FWGPU_OK;
         std::string msg;
+        void grow(uint64_t cap) {
+            std::unique_ptr<uint32_t[]> nb(new uint32_t[cap]);
+            if (nw) memcpy(nb.get(), words.get(), nw * 4);
+            words = std::move(nb);
+            words_cap = cap;
+        }
     };
     std::vector<Slice> sl(T);
     uint64_t pos = 0;
@@ -271,12 +278,12 @@ int fwgpu_trainer_digest_text(fwgpu_trainer *tr, fwgpu_parser *parser, fwgpu_cac
         }
         // a feature token takes >= 2 bytes of text and <= 2 words of record; the per-line header depends on the namespace
         // map, so the buffer grows whenever a pass stops short without an error
-        s.words.resize(n + lines * 64 + 4096);
+        s.grow(n + lines * 64 + 4096);
         s.off.assign(lines + 1, 0);
         std::vector<uint64_t> tmp(lines + 1);
         while (s.used < n) {
             uint64_t nr = 0, nw = 0, used = 0;
-            s.rc = fwgpu_parser_parse_buffer(p, text + s.begin + s.used, n - s.used, s.words.data() + s.nw, s.words.size() - s.nw,
+            s.rc = fwgpu_parser_parse_buffer(p, text + s.begin + s.used, n - s.used, s.words.get() + s.nw, s.words_cap - s.nw,
                                              tmp.data(), lines - s.nr, &nr, &nw, &used);
             for (uint64_t j = 1; j <= nr; j++) s.off[s.nr + j] = s.nw + tmp[j];
             s.nr += nr;
@@ -287,12 +294,12 @@ int fwgpu_trainer_digest_text(fwgpu_trainer *tr, fwgpu_parser *parser, fwgpu_cac
                 break;
             }
             if (s.used < n) {  // out of room (not a command, not an error): grow and go on
-                if (s.words.size() > (1ull << 33)) {
+                if (s.words_cap > (1ull << 33)) {
                     s.rc = FWGPU_ERR_RANGE;
                     s.msg = "digest_text: a slice needs more than 32 GiB of records";
                     break;
                 }
-                s.words.resize(s.words.size() * 2);
+                s.grow(s.words_cap * 2);
             }
         }
         if (own) fwgpu_parser_free(own);
@@ -311,10 +318,10 @@ int fwgpu_trainer_digest_text(fwgpu_trainer *tr, fwgpu_parser *parser, fwgpu_cac
         while (i < s.nr && rc == FWGPU_OK) {
             const uint32_t take = (uint32_t)std::min<uint64_t>(s.nr - i, 1u << 30);
             // offsets are relative to the slice's first word
-            rc = fwgpu_digest_records(tr, s.words.data(), s.off.data() + i, take);
+            rc = fwgpu_digest_records(tr, s.words.get(), s.off.data() + i, take);
             i += take;
         }
-        if (rc == FWGPU_OK && cache && s.nw) rc = fwgpu_cache_push_records(cache, s.words.data(), s.nw);
+        if (rc == FWGPU_OK && cache && s.nw) rc = fwgpu_cache_push_records(cache, s.words.get(), s.nw);
         if (rc != FWGPU_OK) break;
         done += s.nr;
         used = s.begin + s.used;

@@ -70,3 +70,14 @@ if gpu:
         t0 = time.perf_counter(); pr.predict_batch(req[:nb]); dtb = time.perf_counter() - t0
         print(f"predict_batch({nb}): {dtb * 1e3:.2f} ms = {nb / dtb:,.0f} predictions/s")
     print(f"fw_predict (one request per call, ~200 features): {dt1 * 1e6:.0f} us per call")
+if gpu:
+    big = text * 8  # 160 000 lines, ~295 MB of text
+    for th in (1, 8, 16):
+        re2 = fw.Regressor(mi)
+        tr = fw.HogwildTrainer(re2, mi, micro_batch=16384)
+        t0 = time.perf_counter()
+        n, used, rc = tr.digest_text(p, big, threads=th)
+        tr.block_until_workers_finished()
+        dt = time.perf_counter() - t0
+        print(f"text -> trainer, native, {th} parser threads: {n / dt:,.0f} lines/s ({len(big) / dt / 1e6:,.0f} MB/s of text)")
+        tr.close(); re2.close()
