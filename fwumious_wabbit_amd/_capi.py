@@ -173,6 +173,9 @@ def lib():
         "fwgpu_trainer_digest_cache": [vp, vp, u64, P(u64)],
         "fwgpu_trainer_digest_text": [vp, vp, vp, C.c_char_p, u64, u32, P(u64), P(u64)],
         "fwgpu_parser_clone": [vp, P(vp)],
+        "fwgpu_input_open": [C.c_char_p, P(vp)],
+        "fwgpu_input_read": [vp, vp, u64, P(u64)],
+        "fwgpu_trainer_digest_file": [vp, vp, vp, C.c_char_p, u32, P(u64)],
         "fwgpu_cache_open": [C.c_char_p, vp, P(vp)],
         "fwgpu_cache_push_records": [vp, vp, u64],
         "fwgpu_cache_write_finish": [vp],
@@ -182,7 +185,7 @@ def lib():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = i32
-    for name in ("fwgpu_vwmap_free", "fwgpu_parser_free", "fwgpu_cache_free", "fwgpu_mi_free"):
+    for name in ("fwgpu_vwmap_free", "fwgpu_parser_free", "fwgpu_cache_free", "fwgpu_mi_free", "fwgpu_input_close"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = None
     for name in ("fwgpu_vwmap_num_namespaces", "fwgpu_vwmap_num_entries"):

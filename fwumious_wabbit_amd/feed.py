@@ -165,3 +165,24 @@ class RecordCache:
             self.close()
         except Exception:
             pass
+
+
+def create_buffered_input(input_filename: str):
+    """buffer_handler.rs:8-37: a reader over .vw / .gz / .zst input; iterate for chunks of decompressed bytes"""
+    L = capi.lib()
+    h = C.c_void_p()
+    capi.check(L.fwgpu_input_open(input_filename.encode(), C.byref(h)))
+
+    def chunks(size=1 << 20):
+        buf = C.create_string_buffer(size)
+        n = C.c_uint64()
+        try:
+            while True:
+                capi.check(L.fwgpu_input_read(h, buf, size, C.byref(n)))
+                if n.value == 0:
+                    return
+                yield buf.raw[: n.value]
+        finally:
+            L.fwgpu_input_close(h)
+
+    return chunks()

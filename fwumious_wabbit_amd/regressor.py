@@ -412,6 +412,15 @@ class HogwildTrainer:
             check(rc)
         return n.value, used.value, rc
 
+    def digest_file(self, parser, filename: str, cache=None, threads=0):
+        """the example loop over a .vw / .gz / .zst file (main.rs:213-270), in native code -> (examples learned, status)"""
+        n = C.c_uint64()
+        rc = capi.lib().fwgpu_trainer_digest_file(self.h, parser.h, cache.h if cache is not None else None, filename.encode(),
+                                                  threads, C.byref(n))
+        if rc not in (capi.OK, capi.PARSE_FLUSH, capi.PARSE_HOGWILD_LOAD):
+            check(rc)
+        return n.value, rc
+
     def block_until_workers_finished(self):
         """hogwild.rs:55-60"""
         check(capi.lib().fwgpu_finish(self.h))

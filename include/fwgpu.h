@@ -334,6 +334,16 @@ int fwgpu_trainer_digest_cache(fwgpu_trainer *tr, fwgpu_cache *cache, uint64_t m
  * example: the return value says why (FWGPU_PARSE_FLUSH, FWGPU_PARSE_HOGWILD_LOAD, FWGPU_ERR_PARSE), *consumed = bytes
  * fully digested, *n_examples = examples learned. */
 int fwgpu_parser_clone(const fwgpu_parser *src, fwgpu_parser **out);
+/* create_buffered_input (buffer_handler.rs:8-37): ".vw" plain, ".gz" gzip (several members allowed, MultiGzDecoder), ".zst"
+ * zstd (libzstd.so.1 resolved at run time); any other extension is refused with the reference's message.
+ * fwgpu_input_read fills `buf` with decompressed bytes, *n == 0 at the end.  fwgpu_trainer_digest_file = the example loop
+ * over such a file: 64 MiB windows cut at line breaks -> fwgpu_trainer_digest_text. */
+typedef struct fwgpu_input fwgpu_input;
+int fwgpu_input_open(const char *filename, fwgpu_input **out);
+int fwgpu_input_read(fwgpu_input *in, char *buf, uint64_t cap, uint64_t *n);
+void fwgpu_input_close(fwgpu_input *in);
+int fwgpu_trainer_digest_file(fwgpu_trainer *tr, fwgpu_parser *parser, fwgpu_cache *cache, const char *filename,
+                              uint32_t threads, uint64_t *n_examples);
 int fwgpu_trainer_digest_text(fwgpu_trainer *tr, fwgpu_parser *parser, fwgpu_cache *cache, const char *text, uint64_t len,
                               uint32_t threads, uint64_t *n_examples, uint64_t *consumed);
 

@@ -452,3 +452,28 @@ def test_cache_and_json_readers_survive_garbage(tmp_path):
                     P.ModelInstanceHandle.from_json(bytes(b)).to_json()
             except capi.FwgpuError:
                 pass
+
+
+def test_create_buffered_input_vw_gz_zst(tmp_path):
+    """buffer_handler.rs:77-137: the same bytes come back from .vw, .gz (also multi-member) and .zst; other extensions are refused"""
+    import gzip
+    from fwumious_wabbit_amd.feed import create_buffered_input
+    contents = b"".join(b"%d |A a%d |B b%d\n" % (i % 2 * 2 - 1, i, i * 7) for i in range(50000))
+    (tmp_path / "x.vw").write_bytes(contents)
+    assert b"".join(create_buffered_input(str(tmp_path / "x.vw"))) == contents
+    with gzip.open(tmp_path / "x.gz", "wb") as f:
+        f.write(contents)
+    assert b"".join(create_buffered_input(str(tmp_path / "x.gz"))) == contents
+    with open(tmp_path / "multi.gz", "wb") as f:  # MultiGzDecoder: members back to back
+        f.write(gzip.compress(contents[:100000]) + gzip.compress(contents[100000:]))
+    assert b"".join(create_buffered_input(str(tmp_path / "multi.gz"))) == contents
+    pa = pytest.importorskip("pyarrow")
+    (tmp_path / "x.zst").write_bytes(pa.compress(contents, codec="zstd", asbytes=True))
+    assert b"".join(create_buffered_input(str(tmp_path / "x.zst"))) == contents
+    (tmp_path / "x.txt").write_bytes(contents)
+    with pytest.raises(capi.FwgpuError) as e:
+        create_buffered_input(str(tmp_path / "x.txt"))
+    assert e.value.message == "Please specify a valid input format (.vw, .zst, .gz)"
+    (tmp_path / "bad.gz").write_bytes(gzip.compress(contents)[:-200] + b"garbage" * 40)
+    with pytest.raises(capi.FwgpuError):
+        b"".join(create_buffered_input(str(tmp_path / "bad.gz")))

@@ -217,3 +217,34 @@ def test_text_to_trainer_natively_with_cache_writing(tmp_path):
         tr2.digest_text(parser, b"1 |A x\n1 |NOPE y\n", threads=1)
     for x in (tr, tr2, re, re2):
         x.close()
+
+
+def test_gz_input_file_to_trainer_then_cache_pass(tmp_path):
+    """`fw --data train.vw.gz -c`: gzip text in (buffer_handler.rs:19-23), LZ4 cache out (cache.rs:73), everything native;
+    the second pass trains from the cache alone"""
+    import shutil
+    vw = VwNamespaceMap(gzip.open(os.path.join(DATA, "vw_namespace_map.csv.gz"), "rt").read())
+    src = str(tmp_path / "train.vw.gz")
+    shutil.copy(os.path.join(DATA, "train.vw.gz"), src)
+    mi = _model_instance(vw)
+    re = fw.Regressor(mi)
+    re.set_max_in_flight(16)
+    tr = fw.HogwildTrainer(re, mi, micro_batch=1024)
+    parser = VowpalParser(vw)
+    cache = RecordCache(src, True, vw)
+    assert cache.writing
+    n, rc = tr.digest_file(parser, src, cache=cache, threads=4)
+    tr.block_until_workers_finished()
+    cache.write_finish()
+    cache.close()
+    assert rc == capi.OK and n == 30000
+    raw = open(src + ".fwcache", "rb").read()
+    assert raw[:4] == (0x184D2204).to_bytes(4, "little")  # an LZ4 frame, because the input name ends in "gz"
+    cache = RecordCache(src, True, vw)
+    assert cache.reading
+    assert tr.digest_cache(cache) == 30000  # second pass over the same data, from the cache
+    tr.block_until_workers_finished()
+    hw, ho, _ = _records_of(_unpack("test-hard.vw", tmp_path), vw, False)
+    assert _balanced_accuracy(_predict(re, mi, hw, ho), record_labels(hw, ho)) > 0.80
+    for x in (cache, tr, re):
+        x.close()
