@@ -600,7 +600,10 @@ __device__ __forceinline__ float nn_forward(const KernelParams &p, const Lds &s,
         const uint32_t in = n.in[l], out = n.out[l];
         const float *W = n.w + n.off[l];
         // a wave computes JU neurons per pass so that JU * ceil(in / 64) weight loads are in flight per lane
-        constexpr int JU = 4;
+#ifndef FW_NN_FJU
+#define FW_NN_FJU 4
+#endif
+        constexpr int JU = FW_NN_FJU;
         for (uint32_t j0 = wave * JU; j0 < out; j0 += nw * JU) {
             float dot[JU];
 #pragma unroll
@@ -660,7 +663,10 @@ __device__ __forceinline__ void nn_layer_backward(const DevNN &n, uint32_t l, co
     for (uint32_t i = tid; i < in; i += bd) {
         const float xi = i < split ? in_a[i] : in_b[i - split];
         float oe = 0.0f;
-        constexpr int JU = 8;  // weights (and accumulators) of JU neurons in flight per thread
+#ifndef FW_NN_BJU
+#define FW_NN_BJU 8
+#endif
+        constexpr int JU = FW_NN_BJU;  // weights (and accumulators) of JU neurons in flight per thread
         for (uint32_t j0 = 0; j0 < out; j0 += JU) {
             float w[JU], a[JU], gg[JU];
 #pragma unroll
