@@ -335,10 +335,22 @@ static int run_batch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, h
     if ((uint64_t)p.max_ffm > 4ull * threads) threads = 1024;
     if ((uint64_t)p.max_ffm > 4ull * threads)
         return fail(FWGPU_ERR_RANGE, "an example has more than 4096 FFM features");
-    const size_t lds = example_kernel_lds_bytes(p, r->cfg.optimizer);
+    size_t lds = example_kernel_lds_bytes(p, r->cfg.optimizer);
     // When the LDS footprint lets only ONE workgroup live on a CU (k = 16 rows: T alone is 57.6 KB), the CU's waves have
     // to come from that workgroup: 1024 threads (measured at k = 16: 1.53 -> 1.82 M examples/s; with the deep head 0.67 -> 0.79).
-    if (!r->launch.threads_set && mode == FWGPU_MODE_HOGWILD && 2 * lds > r->lds_per_cu) threads = 1024;
+    if (!r->launch.threads_set && mode == FWGPU_MODE_HOGWILD && 2 * lds > r->lds_per_cu) {
+        // ... unless giving up the LDS copy of the AdaGrad LUT (8 KB) is what lets a SECOND workgroup in: two examples in
+        // flight with the LUT read through L1 beat one example with the LUT in LDS (k = 16: 1.82 -> 1.93 M examples/s)
+        KernelParams q = p;
+        q.lut_global = 1;
+        const size_t lds_nolut = example_kernel_lds_bytes(q, r->cfg.optimizer);
+        if (!p.lut_global && 2 * lds_nolut <= r->lds_per_cu) {
+            p.lut_global = 1;
+            lds = lds_nolut;
+        } else {
+            threads = 1024;
+        }
+    }
     if (lds > r->lds_per_cu)
         return fail(FWGPU_ERR_RANGE, "example does not fit the 160 KiB LDS (k*F^2 or features per example too large)");
     const uint32_t grid = pick_grid(r, p, mode, threads);
