@@ -27,7 +27,6 @@ struct SharedModel {  // what clone_lite shares: the immutable regressor and the
     fwgpu_vwmap *vw = nullptr;
     fwgpu_model_instance *mi = nullptr;
     fwgpu_translator_config tr{};
-    uint32_t num_namespaces = 0;
     std::mutex mu;  // the regressor's single-example staging buffers are shared
     fwgpu_batch *batch = nullptr;  // device buffers of fwgpu_predictor_predict_batch, grown on demand and reused
     ~SharedModel() {
@@ -77,8 +76,6 @@ struct FfiPredictor {
     std::string cached_text;  // PredictorCache.input_buffer_size bytes of the context line (lib.rs:64-67)
     bool has_cache = false;
     std::vector<uint32_t> record;
-    std::vector<fwgpu_lr_entry> lr;
-    std::vector<fwgpu_ffm_entry> ffm;
     ~FfiPredictor() {
         if (parser) fwgpu_parser_free(parser);
     }
@@ -145,7 +142,6 @@ FfiPredictor *new_fw_predictor_prototype(const char *command) {  // lib.rs:150-1
     auto model = std::make_shared<SharedModel>();
     if (fwgpu_model_load(weights.c_str(), device, /*immutable=*/1, &model->vw, &model->mi, &model->re) != FWGPU_OK) return nullptr;
     if (fwgpu_mi_configs(model->mi, device, nullptr, &model->tr, nullptr) != FWGPU_OK) return nullptr;
-    model->num_namespaces = fwgpu_vwmap_num_namespaces(model->vw);
     auto p = std::make_unique<FfiPredictor>();
     p->model = model;
     if (fwgpu_parser_create(model->vw, &p->parser) != FWGPU_OK) return nullptr;
