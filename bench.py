@@ -134,7 +134,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=16384, help="examples per step per GPU")
+    ap.add_argument("--batch", type=int, default=65536, help="examples per step per GPU")
     ap.add_argument("--fields", type=int, default=30)
     ap.add_argument("--k", type=int, default=8)
     ap.add_argument("--bits", type=int, default=28)
@@ -278,7 +278,7 @@ def main():
     # read side) committed under profiles/, reported only when the run uses the profiled configuration.
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_v5_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_v6_pmc.json")) as f:
             pmc = json.load(f)
         if (B == pmc["examples_per_launch"] and args.fields == 30 and args.k == 8 and args.ffm_bits == 28
                 and not args.threads and not args.wgs):
@@ -328,10 +328,11 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": "profiles/r01_v5_pmc.json (rocprofv3 PMC, separate passes)" if traffic else None,
+                "traffic_source": "profiles/r01_v6_pmc.json (rocprofv3 PMC, separate passes)" if traffic else None,
                 "pattern_ceiling_note": "tools/rowbw.hip: random 960 B rows read 6.4 TB/s, written 3.2 TB/s; read w+acc, write w+acc = 4.2 TB/s",
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": avg_kernel_ms,
+                "launch_ms_min_median_max": [float(np.min(kernel_ms)), float(np.median(kernel_ms)), float(np.max(kernel_ms))],
             },
         }
         if args.cpu and world == 1:

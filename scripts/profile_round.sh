@@ -9,7 +9,7 @@ mkdir -p $OUT
 timeout 600 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 tail -c 600 $OUT/${TAG}_bench.json
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline"
+CMD="python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o trace -- $CMD > $OUT/${TAG}_trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --pmc FETCH_SIZE -d $OUT/${TAG}_fetch -o fetch -- $CMD > $OUT/${TAG}_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --pmc WRITE_SIZE -d $OUT/${TAG}_write -o write -- $CMD > $OUT/${TAG}_write.log 2>&1

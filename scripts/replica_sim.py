@@ -13,7 +13,7 @@ class A: pass
 args = A(); args.fields, args.k, args.bits, args.ffm_bits = 30, 8, 28, 28
 args.nn_layers, args.nn_width = 0, 256
 args.mean_extra, args.zipf, args.ids, args.p_weighted, args.seed = 5.67, 1.05, 10_000_000, 0.1, 20240612
-K = int(os.environ.get("STEPS", 48)); SYNC = int(os.environ.get("SYNC", 32)); B = 16384
+K = int(os.environ.get("STEPS", 48)); SYNC = int(os.environ.get("SYNC", 32)); B = int(os.environ.get("B", 16384))
 TABLES = (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)
 hrecs, hoff = bench.gen_records(fw, args, 1_000_000_000, 8192)
 hy = hrecs[hoff[:-1].astype(np.int64) + 1].astype(np.float32)
@@ -56,7 +56,11 @@ def run(N, rule):
     del views, snap
     torch.cuda.empty_cache()
 
-run(1, "sum")
-for N in (2, 4, 8):
-    for rule in ("sum", "mean"):
-        run(N, rule)
+if os.environ.get("ONLY_MEAN"):
+    for N in (1, 4, 8):
+        run(N, "mean")
+else:
+    run(1, "sum")
+    for N in (2, 4, 8):
+        for rule in ("sum", "mean"):
+            run(N, rule)
