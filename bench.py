@@ -231,6 +231,10 @@ def main():
         # while the following steps train.
         syncer.step()
 
+    # device warm-up that touches no model state (clock ramp, page tables): predict-only passes over the hold-out batch
+    for _ in range(64):
+        re.learn_batch(hbatch, capi.MODE_HOGWILD, False, sptr)
+    torch.cuda.synchronize()
     for i in range(W):
         re.learn_batch(batches[i], capi.MODE_HOGWILD, True, sptr)
     if use_dist and W:
