@@ -242,6 +242,22 @@ def test_serving_ffi_matches_the_regressor(tmp_path):
     # a clone shares the weights, has its own (empty) cache
     cl = pr.clone_lite()
     assert cl.predict(lines[0]) == want[0] and cl.predict_with_cache(cands[0]) == pr.predict(cands[0])
+    # lib.rs:187-190: "it is safe to use multiple threads, each accessing only one predictor"
+    import threading
+    clones = [pr.clone_lite() for _ in range(4)]
+    got_mt = [None] * 4
+
+    def serve(k):
+        got_mt[k] = np.array([clones[k].predict(l) for l in lines], dtype=np.float32)
+
+    threads = [threading.Thread(target=serve, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert all(np.array_equal(g, want) for g in got_mt)
+    for c in clones:
+        c.close()
     # error codes (lib.rs:47-48): EOF and unparsable lines give -1.0; the batch marks only the bad entries
     assert pr.predict("") == -1.0 and pr.predict("|UNKNOWN x\n") == -1.0 and pr.setup_cache("") == -1.0
     mixed = pr.predict_batch([lines[0], "|UNKNOWN x\n", lines[1]])
