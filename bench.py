@@ -21,6 +21,9 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
+# the host driver of this pool only supports dmabuf IPC: RCCL between processes needs this (already exported on the boxes)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
