@@ -611,3 +611,39 @@ def test_cpp_host_mirror_reference_tests():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all 16 tests passed" in r.stdout
+
+
+def test_very_large_examples():
+    """An example with thousands of features (1024-thread workgroups, the generic kernel) next to ordinary ones: same results
+    as the oracle in the in-order mode; more than 4096 FFM features in one example is refused, not mis-trained."""
+    k, F = 4, 5
+    mi, ocfg, _ = make_pair(F, k, 16, 16, fw.Optimizer.AdagradLUT, lr=0.02, ffm_lr=0.02)
+    rng = np.random.default_rng(31)
+
+    def example(n_ffm, n_lr):
+        fields = np.sort(rng.integers(0, F, n_ffm))
+        ffm = [(int(rng.integers(0, 1 << 14)) * 4, float(rng.choice([1.0, 0.5, 2.0])), int(f) * k) for f in fields]
+        lr = [(int(rng.integers(0, 1 << 16)), float(rng.choice([1.0, 0.25])), int(rng.integers(0, F))) for _ in range(n_lr)]
+        return lr, ffm
+
+    sizes = [(5, 6), (1200, 1500), (8, 3), (2000, 10), (0, 1500), (12, 7)]
+    exs = [example(a, b) for a, b in sizes]
+    labels = [1.0, 0.0, 1.0, 1.0, 0.0, 1.0]
+    om = fwo.Model(ocfg)
+    p_ref = [om.learn(fwo.lr_entries(lr), fwo.ffm_entries(ffm), y, 1.0, True) for (lr, ffm), y in zip(exs, labels)]
+    re = fw.Regressor(mi)
+    b = re.batch([fw.lr_and_ffm_vec(lr, ffm, y, 1.0) for (lr, ffm), y in zip(exs, labels)])
+    re.learn_batch(b, capi.MODE_SEQUENTIAL, True)
+    p = b.predictions()
+    assert np.abs(p - np.array(p_ref, dtype=np.float32)).max() < 2e-5, (p, p_ref)
+    assert np.abs(re.table_read(capi.TABLE_FFM_W) - om.ffm_weights).max() < 2e-5
+    assert np.abs(re.table_read(capi.TABLE_LR) - om.lr_table).max() < 1e-4
+    # the concurrent mode copes with the same batch (results are order dependent: only sanity is checked)
+    re.learn_batch(b, capi.MODE_HOGWILD, True)
+    assert np.all(np.isfinite(b.predictions()))
+    for too_big in ((4100, 1), (3900, 3900)):  # more than 4096 FFM features / does not fit the LDS: refused loudly
+        with pytest.raises(capi.FwgpuError):
+            lr, ffm = example(*too_big)
+            re.learn(fw.lr_and_ffm_vec(lr, ffm, 1.0, 1.0), None, True)
+    b.close()
+    re.close()
