@@ -142,6 +142,8 @@ def lib():
         "fwgpu_finish": [vp],
         "fwgpu_trainer_free": [vp],
         "fwgpu_trainer_examples_seen": [vp, P(u64)],
+        "fwgpu_trainer_set_holdout": [vp, u64, i32],
+        "fwgpu_trainer_predictions": [vp, vp, u64, P(u64)],
         "fwgpu_set_launch": [vp, u32, u32],
         "fwgpu_set_max_in_flight": [vp, u32],
         "fwgpu_delta_start": [vp, vp, vp, vp, u64, f32, vp],

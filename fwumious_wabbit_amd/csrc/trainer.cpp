@@ -34,23 +34,44 @@ struct fwgpu_trainer {
     int cur = 0;
     hipStream_t stream = nullptr;
     uint64_t seen = 0;
+    // hold-out / test-only protocol (main.rs:184-185, 238-241): examples numbered >= holdout_after (from 1) are predicted,
+    // never learned; their predictions are kept in stream order
+    uint64_t holdout_after = 0;
+    bool testonly = false;
+    bool slot_predict[2] = {false, false};
+    uint32_t slot_n[2] = {0, 0};
+    float *pred_host[2] = {nullptr, nullptr};  // pinned
+    uint32_t pred_cap[2] = {0, 0};
+    std::vector<float> preds;
     // chunk buffers of fwgpu_trainer_digest_cache
     std::unique_ptr<uint32_t[]> cache_words[2];
     std::unique_ptr<uint64_t[]> cache_off[2];
     uint64_t cache_off_cap = 0;
 };
 
-static int flush(fwgpu_trainer *tr) {
+static bool predict_mode(const fwgpu_trainer *tr) {  // for the NEXT example (number seen + 1)
+    return tr->testonly || (tr->holdout_after && tr->seen + 1 >= tr->holdout_after);
+}
+
+// waits for slot c's launch and, if it was a predict-only one, appends its predictions (slots retire in launch order)
+static int retire(fwgpu_trainer *tr, int c) {
+    if (!tr->in_flight[c]) return FWGPU_OK;
+    FWGPU_HIP(hipEventSynchronize(tr->done[c]));
+    tr->in_flight[c] = false;
+    if (tr->slot_predict[c]) tr->preds.insert(tr->preds.end(), tr->pred_host[c], tr->pred_host[c] + tr->slot_n[c]);
+    tr->slot_predict[c] = false;
+    return FWGPU_OK;
+}
+
+static int flush(fwgpu_trainer *tr, bool predict = false) {
     const int c = tr->cur;
     const uint32_t n = (uint32_t)(tr->off[c].size() - 1);
     if (n == 0) return FWGPU_OK;
     fwgpu_regressor *r = tr->r;
     FWGPU_HIP(hipSetDevice(r->device));
     // device buffer c may still be read by its previous kernel
-    if (tr->in_flight[c]) {
-        FWGPU_HIP(hipEventSynchronize(tr->done[c]));
-        tr->in_flight[c] = false;
-    }
+    int rrc = retire(tr, c);
+    if (rrc) return rrc;
     const uint64_t words = tr->rec_used[c];
     fwgpu_batch *b = tr->dev[c];
     if (!b || b->n_cap < n || b->words_cap < words) {
@@ -62,18 +83,27 @@ static int flush(fwgpu_trainer *tr) {
     }
     int rc = record_batch_upload(b, &tr->t, tr->rec[c], tr->off[c].data(), n, tr->stream, &tr->stats[c]);
     if (rc) return rc;
-    rc = fwgpu_learn_batch(r, b, FWGPU_MODE_HOGWILD, 1, tr->stream);
+    rc = fwgpu_learn_batch(r, b, FWGPU_MODE_HOGWILD, predict ? 0 : 1, tr->stream);
     if (rc) return rc;
+    if (predict) {
+        if (tr->pred_cap[c] < n) {
+            if (tr->pred_host[c]) (void)hipHostFree(tr->pred_host[c]);
+            tr->pred_host[c] = nullptr;
+            FWGPU_HIP(hipHostMalloc((void **)&tr->pred_host[c], (size_t)std::max(n, tr->micro_batch) * 4, hipHostMallocDefault));
+            tr->pred_cap[c] = std::max(n, tr->micro_batch);
+        }
+        FWGPU_HIP(hipMemcpyAsync(tr->pred_host[c], b->pred, (size_t)n * 4, hipMemcpyDeviceToHost, tr->stream));
+    }
+    tr->slot_predict[c] = predict;
+    tr->slot_n[c] = n;
     FWGPU_HIP(hipEventRecord(tr->done[c], tr->stream));
     tr->in_flight[c] = true;
     // Staging buffer c stays untouched until its copies and kernel are done; switch to the other buffer, which may be
     // refilled once ITS previous micro-batch has completed.
     tr->cur ^= 1;
     const int c2 = tr->cur;
-    if (tr->in_flight[c2]) {
-        FWGPU_HIP(hipEventSynchronize(tr->done[c2]));
-        tr->in_flight[c2] = false;
-    }
+    rrc = retire(tr, c2);
+    if (rrc) return rrc;
     tr->rec_used[c2] = 0;
     tr->off[c2].assign(1, 0);
     tr->stats[c2] = RecordStats();
@@ -124,7 +154,12 @@ int fwgpu_digest_records(fwgpu_trainer *tr, const uint32_t *records, const uint6
     while (i < n) {
         const int c = tr->cur;
         const uint32_t have = (uint32_t)(tr->off[c].size() - 1);
-        const uint32_t take = std::min<uint32_t>(n - i, tr->micro_batch - have);
+        uint32_t take = std::min<uint32_t>(n - i, tr->micro_batch - have);
+        const bool predicting = predict_mode(tr);
+        if (!predicting && tr->holdout_after) {  // a micro-batch never straddles the hold-out boundary
+            const uint64_t until = tr->holdout_after - 1 - tr->seen;  // examples that may still be learned (>= 1 here)
+            if (take > until) take = (uint32_t)until;
+        }
         // the records are copied (main.rs:243 `Vec::from(buffer)`)
         const uint64_t w0 = rec_off[i], w1 = rec_off[i + take];
         const uint64_t base = tr->rec_used[c];
@@ -163,8 +198,8 @@ int fwgpu_digest_records(fwgpu_trainer *tr, const uint32_t *records, const uint6
         for (uint32_t j = 1; j <= take; j++) tr->off[c].push_back(base + (rec_off[i + j] - w0));
         tr->seen += take;
         i += take;
-        if (tr->off[c].size() - 1 >= tr->micro_batch) {
-            int rc = flush(tr);
+        if (tr->off[c].size() - 1 >= tr->micro_batch || (!predicting && predict_mode(tr))) {
+            int rc = flush(tr, predicting);  // the last learned example closes its micro-batch
             if (rc) return rc;
         }
     }
@@ -335,13 +370,36 @@ int fwgpu_trainer_digest_text(fwgpu_trainer *tr, fwgpu_parser *parser, fwgpu_cac
     return rc;
 }
 
+int fwgpu_trainer_set_holdout(fwgpu_trainer *tr, uint64_t holdout_after, int testonly) {
+    if (!tr) return fail(FWGPU_ERR_INVALID, "NULL trainer");
+    if (tr->off[tr->cur].size() > 1) return fail(FWGPU_ERR_INVALID, "set the hold-out before digesting (or right after fwgpu_finish)");
+    tr->holdout_after = holdout_after;
+    tr->testonly = testonly != 0;
+    return FWGPU_OK;
+}
+
+int fwgpu_trainer_predictions(fwgpu_trainer *tr, float *out, uint64_t cap, uint64_t *n) {
+    if (!tr || !n) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    *n = tr->preds.size();
+    if (!out) return FWGPU_OK;
+    if (cap < tr->preds.size()) return fail(FWGPU_ERR_RANGE, "buffer too small for the predictions");
+    if (!tr->preds.empty()) memcpy(out, tr->preds.data(), tr->preds.size() * 4);
+    return FWGPU_OK;
+}
+
 int fwgpu_finish(fwgpu_trainer *tr) {
     if (!tr) return fail(FWGPU_ERR_INVALID, "NULL trainer");
-    int rc = flush(tr);
+    // the open micro-batch holds examples of ONE kind; they were predicted iff the example before `seen + 1` was
+    const bool last_predict = tr->testonly || (tr->holdout_after && tr->seen >= tr->holdout_after);
+    int rc = flush(tr, last_predict);
     if (rc) return rc;
     FWGPU_HIP(hipSetDevice(tr->r->device));
     FWGPU_HIP(hipStreamSynchronize(tr->stream));
-    tr->in_flight[0] = tr->in_flight[1] = false;
+    // slots retire in launch order: the one launched before the current filling slot's predecessor first
+    rc = retire(tr, tr->cur);
+    if (rc) return rc;
+    rc = retire(tr, tr->cur ^ 1);
+    if (rc) return rc;
     return FWGPU_OK;
 }
 
@@ -352,6 +410,7 @@ int fwgpu_trainer_free(fwgpu_trainer *tr) {
     for (int i = 0; i < 2; i++) {
         if (tr->dev[i]) fwgpu_batch_free(tr->dev[i]);
         if (tr->rec[i]) (void)hipHostFree(tr->rec[i]);
+        if (tr->pred_host[i]) (void)hipHostFree(tr->pred_host[i]);
         if (tr->done[i]) (void)hipEventDestroy(tr->done[i]);
     }
     if (tr->stream) (void)hipStreamDestroy(tr->stream);

@@ -396,6 +396,18 @@ class HogwildTrainer:
         rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
         check(capi.lib().fwgpu_digest_records(self.h, ptr(records), ptr(rec_off), len(rec_off) - 1))
 
+    def set_holdout(self, holdout_after=0, testonly=False):
+        """main.rs:184-185, 238-241: examples numbered >= holdout_after (from 1), or all with testonly, are predicted, not learned"""
+        check(capi.lib().fwgpu_trainer_set_holdout(self.h, holdout_after, int(testonly)))
+
+    def predictions(self) -> np.ndarray:
+        """predictions of the examples that were not learned, in stream order (call after block_until_workers_finished)"""
+        n = C.c_uint64()
+        check(capi.lib().fwgpu_trainer_predictions(self.h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.float32)
+        check(capi.lib().fwgpu_trainer_predictions(self.h, ptr(out), out.size, C.byref(n)))
+        return out
+
     def digest_cache(self, cache, max_records=0) -> int:
         """the example loop over a RecordCache opened for reading (main.rs:213-270), in native code"""
         n = C.c_uint64()

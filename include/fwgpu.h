@@ -233,6 +233,13 @@ int fwgpu_digest_records(fwgpu_trainer *tr, const uint32_t *records, const uint6
 int fwgpu_finish(fwgpu_trainer *tr);
 int fwgpu_trainer_free(fwgpu_trainer *tr);
 int fwgpu_trainer_examples_seen(const fwgpu_trainer *tr, uint64_t *n);
+/* The hold-out / test-only protocol of the reference's example loop (main.rs:184-185, 238-241, `--holdout_after N`, `-t`):
+ * examples are numbered from 1 in the order they are digested; those numbered >= holdout_after (0 = none), or all of them
+ * when testonly != 0, are predicted with update = false and never learned.  Their predictions are kept in stream order and
+ * can be fetched after fwgpu_finish (out == NULL: count only).  Learned examples have no prediction here, like the
+ * reference's hogwild branch (it prints 0.0, main.rs:242-243). */
+int fwgpu_trainer_set_holdout(fwgpu_trainer *tr, uint64_t holdout_after, int testonly);
+int fwgpu_trainer_predictions(fwgpu_trainer *tr, float *out, uint64_t cap, uint64_t *n);
 
 /* ---------------------------------------------------------------- launch tuning (optional)
  * threads: workgroup size (multiple of 64, <=1024); workgroups_per_cu: persistent grid = CUs*this.

@@ -647,3 +647,40 @@ def test_very_large_examples():
             re.learn(fw.lr_and_ffm_vec(lr, ffm, 1.0, 1.0), None, True)
     b.close()
     re.close()
+
+
+def test_trainer_holdout_and_testonly_protocol():
+    """main.rs:238-241: `--holdout_after N` examples numbered >= N are predicted with the model as it is, never learned;
+    `-t` learns nothing.  The kept predictions equal a predict-only pass over the same examples afterwards."""
+    mi, _, _ = make_pair(8, 4, 16, 16, fw.Optimizer.AdagradLUT, lr=0.05, ffm_lr=0.05)
+    recs, off = fw.synth_records(8, 1.0, 1.1, 5000, 0.2, 91, 0, 12000)
+    re = fw.Regressor(mi)
+    tr = fw.HogwildTrainer(re, mi, micro_batch=1024)
+    tr.set_holdout(holdout_after=10001)
+    # fed in uneven slices, one of them straddling the boundary
+    for a, b_ in ((0, 3000), (3000, 9990), (9990, 10030), (10030, 12000)):
+        tr.digest_records(recs[int(off[a]):int(off[b_])], off[a:b_ + 1] - off[a])
+    tr.block_until_workers_finished()
+    assert tr.examples_seen() == 12000
+    p_hold = tr.predictions()
+    assert len(p_hold) == 2000
+    sums = [re.table_checksum(t) for t in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)]
+    hb = re.record_batch(fw.FeatureBufferTranslator(mi), recs[int(off[10000]):], off[10000:] - off[10000])
+    re.learn_batch(hb, capi.MODE_HOGWILD, False)
+    assert np.array_equal(hb.predictions(), p_hold)  # same model, same examples, same order
+    # exactly the first 10 000 were learned: a model trained on those alone (in-order mode for determinism is not
+    # needed: only WHICH rows were touched is compared) has touched the same accumulators
+    re2 = fw.Regressor(mi)
+    b2 = re2.record_batch(fw.FeatureBufferTranslator(mi), recs[: int(off[10000])], off[:10001])
+    re2.learn_batch(b2, capi.MODE_HOGWILD, True)
+    b2.predictions()
+    assert np.array_equal(re.table_read(capi.TABLE_FFM_ACC) != 0, re2.table_read(capi.TABLE_FFM_ACC) != 0)
+    # -t: nothing moves, every example gets a prediction
+    tr2 = fw.HogwildTrainer(re, mi, micro_batch=700)
+    tr2.set_holdout(testonly=True)
+    tr2.digest_records(recs[: int(off[3000])], off[:3001])
+    tr2.block_until_workers_finished()
+    assert len(tr2.predictions()) == 3000
+    assert [re.table_checksum(t) for t in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)] == sums
+    for x in (hb, b2, tr, tr2, re, re2):
+        x.close()
