@@ -247,7 +247,8 @@ int fwgpu_trainer_predictions(fwgpu_trainer *tr, float *out, uint64_t cap, uint6
 int fwgpu_set_launch(fwgpu_regressor *r, uint32_t threads, uint32_t workgroups_per_cu);
 /* HOGWILD launches process as many examples concurrently as the device holds workgroups (768 on MI355X at config C).  On a
  * small or tiny-example data set that much staleness keeps the model from learning (hogwild.rs runs 16 threads): n caps
- * the examples in flight, n = 16 is the reference's default degree of concurrency, 0 = no cap. */
+ * the examples in flight, n = 16 is the reference's default degree of concurrency, n = 1 is its single-thread loop (one
+ * workgroup walks the stream in order: identical to FWGPU_MODE_SEQUENTIAL), 0 = no cap. */
 int fwgpu_set_max_in_flight(fwgpu_regressor *r, uint32_t n_examples);
 
 /* ---------------------------------------------------------------- multi-GPU replica bookkeeping (device pointers)

@@ -684,3 +684,22 @@ def test_trainer_holdout_and_testonly_protocol():
     assert [re.table_checksum(t) for t in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)] == sums
     for x in (hb, b2, tr, tr2, re, re2):
         x.close()
+
+
+def test_one_example_in_flight_is_the_sequential_mode():
+    """fwgpu_set_max_in_flight(1): the trainer (a HOGWILD launcher) then IS the reference's single-thread loop"""
+    mi, _, _ = make_pair(6, 4, 12, 12, fw.Optimizer.AdagradLUT)
+    recs, off = fw.synth_records(6, 1.0, 1.1, 3000, 0.2, 93, 0, 2500)
+    re_a = fw.Regressor(mi)
+    b = re_a.record_batch(fw.FeatureBufferTranslator(mi), recs, off)
+    re_a.learn_batch(b, capi.MODE_SEQUENTIAL, True)
+    b.predictions()
+    re_b = fw.Regressor(mi)
+    re_b.set_max_in_flight(1)
+    tr = fw.HogwildTrainer(re_b, mi, micro_batch=600)
+    tr.digest_records(recs, off)
+    tr.block_until_workers_finished()
+    for t in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC):
+        assert re_a.table_checksum(t) == re_b.table_checksum(t)
+    for x in (b, tr, re_a, re_b):
+        x.close()
