@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--nn-width", dest="nn_width", type=int, default=256)
     ap.add_argument("--threads", type=int, default=0, help="workgroup size override")
     ap.add_argument("--wgs-per-cu", dest="wgs", type=int, default=0)
+    ap.add_argument("--max-in-flight", dest="max_in_flight", type=int, default=0,
+                    help="cap on concurrently processed examples (hogwild.rs runs 16 threads; 0 = what the device holds)")
     ap.add_argument("--sync-every", dest="sync_every", type=int, default=0, help="N>1: steps between delta all-reduces")
     ap.add_argument("--combine", choices=["mean", "sum"], default="mean",
                     help="N>1: the agreed model moves by the mean (default) or the sum of the replicas' deltas")
@@ -192,6 +194,8 @@ def main():
     re = fw.Regressor(mi)
     if args.threads or args.wgs:
         re.set_launch(args.threads, args.wgs)
+    if args.max_in_flight:
+        re.set_max_in_flight(args.max_in_flight)
     fbt = fw.FeatureBufferTranslator(mi)
 
     K, W, B = args.steps, args.warmup, args.batch
