@@ -1136,19 +1136,20 @@ static hipError_t launch_v(const KernelParams &p, int optimizer, bool coherent, 
     }
 }
 
-// ------------------------------------------------------------------ v2: register-resident rows
+// ------------------------------------------------------------------ v2: static wave ranges, occupancy-tuned
 //
 // Same math and same LDS stage / dot / sigmoid / LR code as fw_example_kernel, but the FFM row traffic is organised
-// for memory-level parallelism and to read every weight row from HBM exactly once:
+// for memory-level parallelism:
 //   * every wave owns a CONTIGUOUS range of the example's features, cut at field boundaries and balanced by the rule
-//     owner(field) = floor(first_feature_index * n_waves / n_features)  (monotone, so ranges are contiguous);
-//   * the wave issues ALL its row loads up front (up to MAXR rows of 16 B/lane in flight per wave) into a statically
-//     indexed register array and consumes them in buffer order (field sums stay bit-identical to the reference);
-//   * the rows STAY in registers through dot/sigmoid, so the update phase loads only the accumulator rows
-//     (UA at a time) and writes w and acc: HBM traffic per row = read w, read acc, write w, write acc = the
-//     algorithmic 16 B/float;
-//   * rows beyond MAXR of a wave's range, and rows that overlap an earlier row of the same example (rare), take the
-//     v1 route (transient load in the gather, update_rows with a fresh read of w).
+//     owner(field) = floor(first_feature_index * n_waves / n_features)  (monotone, so ranges are contiguous); the range is
+//     uniform per wave and kept in SGPRs;
+//   * the wave issues its row loads in deep batches: the first MAXR rows of its range into a statically indexed register
+//     array that STAYS resident through dot/sigmoid (their update then loads only the accumulator rows, UA at a time), the
+//     rest four at a time; field sums are accumulated in buffer order (bit-identical to the reference);
+//   * rows beyond MAXR, and rows that overlap an earlier row of the same example (rare), are re-read in the update
+//     (update_rows, UO rows in flight).
+// MAXR = 12 (128 VGPRs, two workgroups per CU) keeps half of the rows resident; the shipped MAXR = 2 (<= 85 VGPRs, three
+// workgroups per CU) re-reads almost every row and is faster: occupancy beats residency.
 // Only for 16 B-aligned single-chunk rows (k % 4 == 0, R <= 256 floats): BASELINE configs B and C.
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #pragma unroll
