@@ -56,7 +56,9 @@ def run(N, rule):
     del views, snap
     torch.cuda.empty_cache()
 
-if os.environ.get("ONLY_MEAN"):
+if os.environ.get("ONLY_N"):
+    run(int(os.environ["ONLY_N"]), "mean")
+elif os.environ.get("ONLY_MEAN"):
     for N in (1, 4, 8):
         run(N, "mean")
 else:
