@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -30,8 +31,13 @@ struct ZstdApi {
     size_t (*decompressStream)(void *, OutBuf *, InBuf *) = nullptr;
     unsigned (*isError)(size_t) = nullptr;
     const char *(*getErrorName)(size_t) = nullptr;
-    bool load() {
-        if (lib) return true;
+    std::once_flag once;
+    bool ok = false;
+    bool load() {  // several threads may open .zst inputs at the same time
+        std::call_once(once, [this] { ok = load_once(); });
+        return ok;
+    }
+    bool load_once() {
         for (const char *name : {"libzstd.so.1", "libzstd.so"}) {
             lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (lib) break;

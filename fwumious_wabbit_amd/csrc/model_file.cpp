@@ -610,6 +610,10 @@ int fwgpu_model_save(const char *path, const fwgpu_vwmap *vw, const fwgpu_model_
     if (rc) return rc;
     if (mi->optimizer != r->cfg.optimizer || need != 8 + blob_body_bytes(r->cfg.optimizer, false, s))
         return fail(FWGPU_ERR_INVALID, "model_save: the regressor was not built from this ModelInstance");
+    // The header must announce a quantised FFM blob (the reference only quantises on the convert path, after setting
+    // dequantize_weights = Some(true): main.rs:141-145); otherwise the file could not be read back.
+    if (quantize_weights && s.ffm_len && mi->dequantize_weights != 1)
+        return fail(FWGPU_ERR_INVALID, "model_save: quantize_weights needs a ModelInstance with dequantize_weights = true");
     try {
         std::vector<uint8_t> blob(need);
         uint64_t written = 0;

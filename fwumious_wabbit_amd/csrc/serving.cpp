@@ -195,6 +195,7 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
         std::vector<uint32_t> slot;
     };
     std::vector<Part> parts(T);
+    for (uint32_t i = 0; i < n; i++) out[i] = kExceptionErrorCode;  // a worker that cannot start leaves its slice marked
     auto work = [&](unsigned k) {
         fwgpu_parser *parser = ptr->parser;
         fwgpu_parser *own = nullptr;

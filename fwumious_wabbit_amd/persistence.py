@@ -100,6 +100,8 @@ class ModelInstanceHandle:
 def save_regressor_to_filename(filename: str, mi: ModelInstance, vwmap: VwNamespaceMap, re: Regressor,
                                quantize_weights: bool = False, extra=None):
     """persistence.rs:73-89"""
+    if quantize_weights:  # the header has to announce the f16-bucket FFM blob (main.rs:141-145 sets it before saving)
+        extra = dict(extra or {}, dequantize_weights=True)
     h = ModelInstanceHandle.from_model_instance(mi, extra)
     capi.check(capi.lib().fwgpu_model_save(filename.encode(), vwmap.h, h.h, re.h, int(quantize_weights)))
     h.close()

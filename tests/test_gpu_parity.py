@@ -239,6 +239,68 @@ def test_deep_head_hogwild_learns():
     re.close()
 
 
+
+# ------------------------------------------------------------------ BASELINE configs at their real shapes
+def test_config_e_real_geometry_sequential_parity():
+    """BASELINE configs[4]: F = 30, k = 16 (two-chunk rows, R = 480), 2 x 256 ReLU head, topology one
+    (regressor.rs:191-323, block_neural.rs:196-340, block_relu.rs:79-112) -- per-example parity with the oracle in
+    the in-order mode, entries and records, NN / FFM / LR tables compared afterwards.  Tables are 20-bit so the
+    oracle's copy stays small; the geometry (row length, head widths, ~200 nnz) is the real one."""
+    _nn_stream_parity(30, 16, 20, 20, fw.Optimizer.AdagradLUT, [(256, "relu", "hu"), (256, "relu", "hu")], "one", n=96,
+                      seed=31, mean_extra=5.67, ids=100000, lr=0.025, ffm_lr=0.025, power_t=0.38, ffm_power_t=0.38,
+                      nn_lr=0.025, nn_power_t=0.38, nn_init_acc=1.0)
+
+
+def test_config_e_real_geometry_hogwild_1024_thread_workgroups():
+    """Same geometry in the concurrent mode (the library picks its k = 16 launch shape by itself): finite predictions,
+    the loss falls, and a later predict-only pass over the same weights equals the in-order predict-only pass."""
+    mi, ocfg, ots = make_pair(30, 16, 20, 20, fw.Optimizer.AdagradLUT, lr=0.025, ffm_lr=0.025, power_t=0.38, ffm_power_t=0.38)
+    mi.nn_layers = [dict(width=256, activation="relu", init="hu"), dict(width=256, activation="relu", init="hu")]
+    mi.nn_learning_rate, mi.nn_power_t, mi.nn_init_acc_gradient = 0.025, 0.38, 1.0
+    recs, off = fw.synth_records(30, 5.67, 1.05, 100000, 0.1, 32, 0, 12000)
+    y = record_labels(recs, off)
+    re = fw.Regressor(mi)
+    b = re.record_batch(fw.FeatureBufferTranslator(mi), recs, off)
+    re.learn_batch(b, capi.MODE_HOGWILD, True)
+    p = b.predictions()
+    assert np.all(np.isfinite(p))
+    ll = logloss(p, y)
+    assert ll[-3000:].mean() < ll[:3000].mean() and ll[-3000:].mean() < 0.6931
+    re.learn_batch(b, capi.MODE_HOGWILD, False)
+    p1 = b.predictions().copy()
+    re.learn_batch(b, capi.MODE_SEQUENTIAL, False)
+    assert np.abs(b.predictions() - p1).max() < PRED_TOL
+    b.close()
+    re.close()
+
+
+def test_config_b_real_size_sequential_parity_and_hogwild_holdout():
+    """BASELINE configs[1]: 10 fields, k = 4, 22-bit FFM and LR tables, micro-batch 4096, seed 20240611.
+    One 4096-example micro-batch in the in-order mode against the oracle per example and on the final tables; then
+    hogwild training in 4096-example micro-batches against the sequential oracle's hold-out loss."""
+    _stream_parity(10, 4, 22, 22, fw.Optimizer.AdagradLUT, n=4096, mean_extra=0.0, p_weighted=0.0, ids=100000,
+                   seed=20240611)
+    n_train, n_hold = 10 * 4096, 8192
+    mi, ocfg, ots = make_pair(10, 4, 22, 22, fw.Optimizer.AdagradLUT)
+    recs, off = fw.synth_records(10, 0.0, 1.1, 100000, 0.0, 20240611, 0, n_train + n_hold)
+    y = record_labels(recs, off)
+    ref_hold, _ = _holdout_loss_oracle(ocfg, ots, recs, off, n_train)
+    re = fw.Regressor(mi)
+    fbt = fw.FeatureBufferTranslator(mi)
+    for s in range(0, n_train, 4096):
+        b = re.record_batch(fbt, recs[int(off[s]):int(off[s + 4096])], off[s:s + 4097] - off[s])
+        re.learn_batch(b, capi.MODE_HOGWILD, True)
+        b.close()
+    hb = re.record_batch(fbt, recs[int(off[n_train]):], off[n_train:] - off[n_train])
+    re.learn_batch(hb, capi.MODE_HOGWILD, False)
+    gpu_hold = float(logloss(hb.predictions(), y[n_train:]).mean())
+    print(f"config B hold-out: gpu hogwild {gpu_hold:.4f} oracle sequential {ref_hold:.4f}")
+    assert abs(gpu_hold - ref_hold) < HOLDOUT_TOL, (gpu_hold, ref_hold)
+    assert gpu_hold < 0.6931
+    hb.close()
+    re.close()
+
+
 def test_sequential_mode_is_deterministic():
     mi, _, _ = make_pair(10, 4, 12, 12, fw.Optimizer.AdagradLUT)
     recs, off = fw.synth_records(10, 1.0, 1.1, 3000, 0.1, 9, 0, 600)
