@@ -87,6 +87,9 @@ struct KernelParams {
     int32_t has_lr;            // wiring REGRESSOR: LR block participates
     int32_t update;
     int32_t aligned4;          // every FFM row of the batch starts on a 16-byte boundary
+    int32_t window;            // FFM rows are updated as the whole 128 B lines they touch (v2 kernel; kernels.hip update_rows_win)
+    uint32_t k_log2;           // log2(k) when k is a power of two, else 0xff
+    int32_t chain;             // rows of the same hash inside one example are chained to the first and applied from registers (set with window)
     float lr_rate, lr_minus_power_t;    // SGD / AdagradFlex parameters of the LR block
     float ffm_rate, ffm_minus_power_t;  // ... of the FFM block
     int32_t lut_global;                 // 1: AdaGrad LUT read from global memory (through L1) instead of an LDS copy
@@ -101,6 +104,7 @@ struct LaunchConfig {
     uint32_t workgroups_per_cu = 0;  // 0: as many as LDS allows (capped)
     int32_t kernel_version = 0;      // 0 = auto
     int32_t lut_global = 0;
+    int32_t window = 1;              // whole-line FFM row updates: 0 off, 1 auto (tables > Infinity Cache), 2 always (debug option 2)
     bool threads_set = false;
     uint32_t max_in_flight = 0;  // cap on the persistent grid = examples processed concurrently (0: what the device holds)  // fwgpu_set_launch chose the workgroup size: no automatic choice
 };

@@ -135,7 +135,7 @@ struct Lds {
     float *lut;      // 2048 (AdagradLUT only)
     uint32_t *e_hash;  // max_ffm
     float *e_val;
-    uint32_t *e_fld;  // field | dep<<31
+    uint32_t *e_fld;  // field (low 8 bits) | kRowHasChain | kRowChained | kRowDep
     uint32_t *l_hash;  // max_lr
     float *l_val;
     uint32_t *fstart, *fend;  // F
@@ -143,6 +143,8 @@ struct Lds {
     float *dcf;               // F: per-field self-pair correction
     uint32_t *set_ffm;        // open-addressing set of FFM row block keys (overlap pre-filter)
     uint32_t *set_lr;         // open-addressing set of LR hashes (duplicate pre-filter)
+    uint32_t *set_own;        // per slot of set_ffm: first entry index carrying that hash (duplicate-row chains)
+    uint32_t *set_blk;        // open-addressing set of FFM row block keys of first occurrences (chains: set_ffm then holds hashes)
     uint32_t *rec;            // raw record staged for device-side translation (max_rec words)
     uint32_t *tcnt;           // per (field,namespace) pair and per combo: entry count, then exclusive offset
     uint32_t *l_combo;        // combo slot of each LR entry (deep head only)
@@ -171,6 +173,11 @@ __host__ __device__ inline uint32_t log2u(uint32_t pow2) {
     return l;
 }
 constexpr uint32_t kSetEmpty = 0xffffffffu;
+// e_fld flag bits of an FFM entry (set in the stage phase of updating launches)
+constexpr uint32_t kRowDep = 0x80000000u;       // overlaps an earlier row of another hash: applied in buffer order, after all others
+constexpr uint32_t kRowChained = 0x40000000u;   // same hash as an earlier row: applied by that row's owner, from registers
+constexpr uint32_t kRowHasChain = 0x20000000u;  // later rows of the same hash are chained to this one
+constexpr uint32_t kFldMask = 0xffu;
 // returns true if `key` was already present
 __device__ __forceinline__ bool set_insert(uint32_t *tab, uint32_t mask, uint32_t shift, uint32_t key) {
     uint32_t slot = (key * 2654435761u) >> shift;
@@ -180,6 +187,20 @@ __device__ __forceinline__ bool set_insert(uint32_t *tab, uint32_t mask, uint32_
         if (old == key) return true;
         slot = (slot + 1) & mask;
     }
+}
+// insert that reports the slot (the caller keeps per-key data in a parallel array)
+__device__ __forceinline__ uint32_t set_insert_slot(uint32_t *tab, uint32_t mask, uint32_t shift, uint32_t key) {
+    uint32_t slot = (key * 2654435761u) >> shift;
+    for (;;) {
+        const uint32_t old = atomicCAS(&tab[slot], kSetEmpty, key);
+        if (old == kSetEmpty || old == key) return slot;
+        slot = (slot + 1) & mask;
+    }
+}
+__device__ __forceinline__ uint32_t set_find_slot(const uint32_t *tab, uint32_t mask, uint32_t shift, uint32_t key) {
+    uint32_t slot = (key * 2654435761u) >> shift;
+    while (tab[slot] != key) slot = (slot + 1) & mask;  // the key is known to be present
+    return slot;
 }
 __device__ __forceinline__ bool set_contains(const uint32_t *tab, uint32_t mask, uint32_t shift, uint32_t key) {
     uint32_t slot = (key * 2654435761u) >> shift;
@@ -192,7 +213,7 @@ __device__ __forceinline__ bool set_contains(const uint32_t *tab, uint32_t mask,
 }
 
 __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t max_ffm, uint32_t max_lr, uint32_t n_luts,
-                                             uint32_t max_rec, uint32_t tr_items, uint32_t nn_floats, size_t *off /*[19]*/) {
+                                             uint32_t max_rec, uint32_t tr_items, uint32_t nn_floats, size_t *off /*[21]*/) {
     size_t o = 0;
     size_t R = (size_t)F * k;
     off[0] = o; o = align16(o + 4 * F * R);
@@ -212,15 +233,20 @@ __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t ma
     // when they fit they live INSIDE T's region (config C: 6.4 KB of 28.8 KB), which is what lets a third workgroup fit a CU.
     {
         const size_t a13 = 0, a14 = align16(a13 + 4 * (size_t)set_size(max_ffm)), a15 = align16(a14 + 4 * (size_t)set_size(max_lr)),
-                     aend = align16(a15 + 4 * (size_t)max_rec);
+                     a19 = align16(a15 + 4 * (size_t)max_rec), a20 = align16(a19 + 4 * (size_t)set_size(max_ffm)),
+                     aend = align16(a20 + 4 * (size_t)set_size(max_ffm));
         if (aend <= 4 * F * R) {
             off[13] = a13;
             off[14] = a14;
             off[15] = a15;
+            off[19] = a19;
+            off[20] = a20;
         } else {
             off[13] = o; o = align16(o + 4 * (size_t)set_size(max_ffm));
             off[14] = o; o = align16(o + 4 * (size_t)set_size(max_lr));
             off[15] = o; o = align16(o + 4 * (size_t)max_rec);
+            off[19] = o; o = align16(o + 4 * (size_t)set_size(max_ffm));
+            off[20] = o; o = align16(o + 4 * (size_t)set_size(max_ffm));
         }
     }
     off[16] = o; o = align16(o + 4 * (size_t)tr_items);
@@ -235,6 +261,15 @@ __device__ __forceinline__ bool k_nonzero(uint32_t k) { return k != 0; }
 struct SetGeom {
     uint32_t setf_n, setl_n, setf_shift, setl_shift, blk_shift;
 };
+// 2^blk_shift >= the longest span two rows can conflict over: rows that conflict then have block keys
+// (hash >> blk_shift) differing by <= 1.  Plain rows conflict when they share a float (span R); whole-line updates
+// (KernelParams::window) conflict when they share a 128 B line (span <= R + 31 floats rounded up to whole lines).
+__device__ __forceinline__ uint32_t conflict_blk_shift(const KernelParams &p) {
+    const uint32_t span = p.window ? ((p.R + 31u + 31u) & ~31u) : p.R;
+    uint32_t sh = 0;
+    while ((1u << sh) < span) sh++;
+    return sh;
+}
 struct StageOut {
     uint32_t nf, nl;
     float label, imp;
@@ -309,7 +344,11 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
         o.imp = p.importance[ex];
     }
     o.do_update = p.update && (o.imp != 0.0f);  // regressor.rs:366
+#ifdef FW_ABL_NO_SETS
+    const bool do_update = false;
+#else
     const bool do_update = o.do_update;
+#endif
 
     for (uint32_t i = tid; i < F; i += bd) {
         s.fstart[i] = 0;
@@ -322,7 +361,13 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
         s.ctr[3] = 0;  // duplicate LR hashes in this example
     }
     if (do_update) {
-        for (uint32_t i = tid; i < g.setf_n; i += bd) s.set_ffm[i] = kSetEmpty;
+        for (uint32_t i = tid; i < g.setf_n; i += bd) {
+            s.set_ffm[i] = kSetEmpty;
+            if (p.chain) {
+                s.set_own[i] = 0xffffffffu;
+                s.set_blk[i] = kSetEmpty;
+            }
+        }
         for (uint32_t i = tid; i < g.setl_n; i += bd) s.set_lr[i] = kSetEmpty;
     }
     if (!p.records) {
@@ -452,16 +497,42 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
         const uint32_t f = s.e_fld[i];
         if (i == 0 || s.e_fld[i - 1] != f) s.fstart[f] = i;
         if (i == nf - 1 || s.e_fld[i + 1] != f) s.fend[f] = i + 1;
-        if (do_update && set_insert(s.set_ffm, g.setf_n - 1, g.setf_shift, s.e_hash[i] >> g.blk_shift)) s.ctr[2] = 1;
+        if (do_update) {
+            if (p.chain) {  // set_ffm holds the row hashes; set_own the first entry carrying each
+                const uint32_t sl = set_insert_slot(s.set_ffm, g.setf_n - 1, g.setf_shift, s.e_hash[i]);
+                atomicMin(&s.set_own[sl], i);
+            } else if (set_insert(s.set_ffm, g.setf_n - 1, g.setf_shift, s.e_hash[i] >> g.blk_shift)) {
+                s.ctr[2] = 1;
+            }
+        }
     }
     if (do_update && p.has_lr)
         for (uint32_t i = tid; i < nl; i += bd)
             if (set_insert(s.set_lr, g.setl_n - 1, g.setl_shift, s.l_hash[i])) s.ctr[3] = 1;
     __syncthreads();
     tk.stamp(10);
-    if (do_update)
+    if (do_update && p.chain) {
+        // Rows of the SAME hash (a feature drawn twice, or two features colliding: 98 % of config C's examples have some)
+        // are chained to the first one: its owner applies them in buffer order from registers (update_rows_win).  Only
+        // first occurrences enter the overlap pre-filter, so duplicates alone never trigger the exact scan.
+        for (uint32_t i = tid; i < nf; i += bd) {
+            const uint32_t h = s.e_hash[i];
+            const uint32_t own = s.set_own[set_find_slot(s.set_ffm, g.setf_n - 1, g.setf_shift, h)];
+            if (own != i) {
+                atomicOr(&s.e_fld[i], kRowChained);
+                atomicOr(&s.e_fld[own], kRowHasChain);
+            } else if (set_insert(s.set_blk, g.setf_n - 1, g.setf_shift, h >> g.blk_shift)) {
+                s.ctr[2] = 1;
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < nf; i += bd)
+            if (!(s.e_fld[i] & kRowChained) && set_contains(s.set_blk, g.setf_n - 1, g.setf_shift, (s.e_hash[i] >> g.blk_shift) + 1))
+                s.ctr[2] = 1;
+    } else if (do_update) {
         for (uint32_t i = tid; i < nf; i += bd)
             if (set_contains(s.set_ffm, g.setf_n - 1, g.setf_shift, (s.e_hash[i] >> g.blk_shift) + 1)) s.ctr[2] = 1;
+    }
     __syncthreads();
     tk.stamp(11);
     // (the hash sets and the record copy, which may share T's LDS region, are dead from here on)
@@ -489,8 +560,14 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
             uint32_t d = 0;
             for (uint32_t j = 0; j < i; ++j) {
                 const uint32_t hj = s.e_hash[j];
-                const uint32_t diff = h > hj ? h - hj : hj - h;
-                d |= (diff < R) ? 1u : 0u;
+                if (p.chain && hj == h) continue;  // same row: chained, not a dependency
+                if (p.window) {  // whole-line updates: do the 128 B line spans [h & ~31, round_up(h + R, 32)) intersect?
+                    const uint32_t a0 = h & ~31u, a1 = (h + R + 31u) & ~31u, b0 = hj & ~31u, b1 = (hj + R + 31u) & ~31u;
+                    d |= (a0 < b1 && b0 < a1) ? 1u : 0u;
+                } else {
+                    const uint32_t diff = h > hj ? h - hj : hj - h;
+                    d |= (diff < R) ? 1u : 0u;
+                }
             }
             my_dep[slot & 3] = d;
         }
@@ -499,7 +576,9 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
         uint32_t any = 0;
         for (uint32_t i = tid; i < nf; i += bd, ++slot) {
             if (my_dep[slot & 3]) {
-                s.e_fld[i] |= 0x80000000u;
+                // (a row that overlaps an earlier row of another hash leaves its chain: every later row of its hash overlaps
+                // that row too, so the whole tail of the chain is applied in order in phase B)
+                s.e_fld[i] = (s.e_fld[i] & ~kRowChained) | kRowDep;
                 any = 1;
             }
         }
@@ -510,7 +589,7 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
 }
 
 size_t example_kernel_lds_bytes(const KernelParams &p, int optimizer) {
-    size_t off[19];
+    size_t off[21];
     return lds_layout(p.F, p.k, p.max_ffm, p.max_lr, (optimizer == FWGPU_OPT_ADAGRAD_LUT && p.update && !p.lut_global) ? 1 : 0,
                       p.records ? p.max_rec : 0, p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), off);
 }
@@ -768,7 +847,7 @@ __device__ __forceinline__ void update_rows(const KernelParams &p, const Lds &s,
             if (idx[u] != 0xffffffffu) {
                 const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[idx[u]]);
                 val[u] = s.e_val[idx[u]];
-                fld[u] = s.e_fld[idx[u]] & 0x7fffffffu;
+                fld[u] = s.e_fld[idx[u]] & kFldMask;
                 rw[u] = make_rsrc(p.ffm_w + h, R * 4);
                 wv[u] = Vec<VEC>::template load<AUX>(rw[u], e0 * 4);
                 if (OPT != FWGPU_OPT_SGD) {
@@ -806,6 +885,134 @@ __device__ __forceinline__ void update_rows(const KernelParams &p, const Lds &s,
     }
 }
 
+
+// ---- whole-line ("window") update of FFM rows.
+// A row is R floats from byte 4*hash of the table: 32 B aligned at k = 8, so its first and last 128 B line are usually
+// partial.  tools/rowceil.hip (profiles/r02_rowceil.txt): a partial-line write costs as much as 4-5 whole lines at the
+// memory side (fill + write-back), which is what held random 960 B row writes at 3.2-3.5 TB/s while 1024 B whole-line
+// rows write at 6.8 TB/s.  Here the wave reads and writes back the WHOLE lines the row touches: window = the 128 B
+// aligned span [4h & ~127, round_up(4h + 4R, 128)), 16 B per lane, 64 lanes per 1 KiB chunk.  Lanes outside the row
+// carry the neighbouring weights through unchanged.  In the in-order mode this is exact; between concurrent examples it
+// widens hogwild's unsynchronised read-modify-write from "the same float" to "the same 128 B line" for the (at most two)
+// edge lines of a row.  Rows whose WINDOWS intersect inside one example are serialised like overlapping rows.
+template <int OPT, int AUX, int U, int NCH>
+__device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds &s, const uint32_t (&idx)[U], float g,
+                                                int lane, uint32_t nf, const float *gpair = nullptr) {
+    const uint32_t R = p.R, k = p.k, ksh = p.k_log2;
+#ifdef FW_PROF_UPD  // debug build only: where does an update iteration spend its time (thread 0 of every workgroup)
+    const bool prof = p.ticks != nullptr && threadIdx.x == 0;
+    unsigned long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0;
+    if (p.ticks) {
+        pt0 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // earlier stores acknowledged
+        pt1 = __builtin_amdgcn_s_memtime();
+    }
+#endif
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        f4 wv[U], av[U];
+        uint32_t hh[U], sb[U], nb[U];
+        bool on[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            wv[u] = f4{0.f, 0.f, 0.f, 0.f};
+            av[u] = wv[u];
+            on[u] = false;
+            hh[u] = sb[u] = nb[u] = 0;
+            if (idx[u] != 0xffffffffu) {
+                hh[u] = __builtin_amdgcn_readfirstlane(s.e_hash[idx[u]]);
+                sb[u] = (hh[u] * 4u) & 127u;                          // row start within its first line, bytes
+                nb[u] = (sb[u] + R * 4u + 127u) & ~127u;              // whole lines covered, bytes
+                if (nb[u] > (uint32_t)NCH * 1024u) {                  // (wave-uniform) the row straddles one line more than
+                    sb[u] = 0;                                        // NCH chunks hold (k = 8: rows starting 96 B into a line
+                    nb[u] = R * 4u;                                   // span 9): this row keeps float-granular accesses
+                }
+                on[u] = nb[u] > (uint32_t)c * 1024u;                  // wave-uniform
+                if (on[u]) {
+                    const uint32_t fl = hh[u] - (sb[u] >> 2);         // float index of the window start
+                    wv[u] = Vec<4>::template load<AUX>(make_rsrc(p.ffm_w + fl, nb[u]), c * 1024 + lane * 16);
+                    if (OPT != FWGPU_OPT_SGD)
+                        av[u] = Vec<4>::template load<AUX>(make_rsrc(p.ffm_acc + fl, nb[u]), c * 1024 + lane * 16);
+                }
+            }
+        }
+#ifdef FW_PROF_UPD
+        if (p.ticks) {
+            pt2 = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this batch's loads have landed
+            pt3 = __builtin_amdgcn_s_memtime();
+        }
+#endif
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!on[u]) continue;
+            const uint32_t fbits = __builtin_amdgcn_readfirstlane(s.e_fld[idx[u]]);
+            const int e = c * 256 + lane * 4 - (int)(sb[u] >> 2);    // this lane's first element of the row
+            const bool inb = e >= 0 && e < (int)R;
+            const uint32_t z = inb ? (uint32_t)e >> ksh : 0xfffffffeu;
+            f4 wn = wv[u], an = av[u];
+            // one occurrence of the row (entry i): gradient from the pre-update weights (T and selfw were taken in the
+            // gather), AdaGrad step on the running (wn, an)
+            auto apply = [&](uint32_t i, uint32_t f) {
+                const float v = s.e_val[i];
+                const bool self = z == f;
+                f4 tv = f4{0.f, 0.f, 0.f, 0.f}, sw = tv;
+                if (inb) tv = Vec<4>::lds_load(s.T + f * R + e);
+                if (self) sw = Vec<4>::lds_load(s.selfw + i * k + (e - (int)(z << ksh)));
+                const float gz = (gpair && inb) ? gpair[tri_index(f, z)] : g;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = tv[j];
+                    if (self) t = __fsub_rn(t, __fmul_rn(sw[j], v));     // contra - w*v  block_ffm.rs:238
+                    const float G = __fmul_rn(v, t);                     // block_ffm.rs:239, 249
+                    const float grad = __fmul_rn(gz, G);                 // block_ffm.rs:278
+                    float acc = an[j];
+                    const float upd = opt_step<OPT>(grad, acc, p.ffm_rate, p.ffm_minus_power_t, s.lut);
+                    an[j] = acc;
+                    wn[j] = wn[j] - upd;                                 // block_ffm.rs:282
+                }
+            };
+            apply(idx[u], fbits & kFldMask);
+            if (fbits & kRowHasChain) {
+                // later entries with the same hash, in buffer order: exactly the reference's sequence of updates on this row
+                // (block_ffm.rs:269-286 walks the buffer; each occurrence sees the previous one's w and acc)
+                for (uint32_t base = idx[u] + 1; base < nf; base += 64) {
+                    const uint32_t j = base + lane;
+                    unsigned long long m = __ballot(j < nf && s.e_hash[j] == hh[u] && (s.e_fld[j] & kRowChained));
+                    while (m) {
+                        const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                        m &= m - 1;
+                        const uint32_t jj = base + b;
+                        apply(jj, __builtin_amdgcn_readfirstlane(s.e_fld[jj]) & kFldMask);
+                    }
+                }
+            }
+            if (!inb) {  // neighbouring weights: written back bit for bit
+                wn = wv[u];
+                an = av[u];
+            }
+            const uint32_t fl = hh[u] - (sb[u] >> 2);
+#ifdef FW_ABL_NO_STORE
+            if (wn[0] == 123.456f && an[1] == 654.321f)
+#endif
+            Vec<4>::template store<AUX>(wn, make_rsrc(p.ffm_w + fl, nb[u]), c * 1024 + lane * 16);
+#ifdef FW_ABL_NO_STORE
+            if (wn[0] == 123.456f && an[1] == 654.321f)
+#endif
+            if (OPT != FWGPU_OPT_SGD) Vec<4>::template store<AUX>(an, make_rsrc(p.ffm_acc + fl, nb[u]), c * 1024 + lane * 16);
+        }
+    }
+#ifdef FW_PROF_UPD
+    if (prof) {
+        const unsigned long long pt4 = __builtin_amdgcn_s_memtime();
+        atomicAdd(p.ticks + 12, pt1 - pt0);  // draining the previous batch's stores
+        atomicAdd(p.ticks + 13, pt3 - pt2);  // load latency (issue done -> data)
+        atomicAdd(p.ticks + 14, (pt2 - pt1) + (pt4 - pt3));  // issue + compute + store issue
+        atomicAdd(p.ticks + 15, 1ull);
+    }
+#endif
+}
+
 template <int VEC, int OPT, bool COH>
 __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) {
     typedef typename Vec<VEC>::type V;
@@ -814,7 +1021,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
     constexpr int UU = 4;  // feature rows in flight per wave in the update phase (x2 tables)
     extern __shared__ __align__(16) unsigned char smem[];
     const bool use_lut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global;
-    size_t off[19];
+    size_t off[21];
     lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut ? 1 : 0, p.records ? p.max_rec : 0,
                p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), off);
     Lds s;
@@ -834,6 +1041,8 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
     s.set_ffm = reinterpret_cast<uint32_t *>(smem + off[13]);
     s.set_lr = reinterpret_cast<uint32_t *>(smem + off[14]);
     s.rec = reinterpret_cast<uint32_t *>(smem + off[15]);
+    s.set_own = reinterpret_cast<uint32_t *>(smem + off[19]);
+    s.set_blk = reinterpret_cast<uint32_t *>(smem + off[20]);
     s.tcnt = reinterpret_cast<uint32_t *>(smem + off[16]);
     s.l_combo = reinterpret_cast<uint32_t *>(smem + off[17]);
     s.nn = reinterpret_cast<float *>(smem + off[18]);
@@ -842,8 +1051,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
     geom.setl_n = set_size(p.max_lr);
     geom.setf_shift = 32 - log2u(geom.setf_n);
     geom.setl_shift = 32 - log2u(geom.setl_n);
-    geom.blk_shift = 0;  // 2^blk_shift >= R: rows that overlap have block keys (hash >> blk_shift) differing by <= 1
-    while ((1u << geom.blk_shift) < p.R) geom.blk_shift++;
+    geom.blk_shift = conflict_blk_shift(p);
 
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = bd >> 6;
@@ -1051,7 +1259,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
 #pragma unroll
                     for (int u = 0; u < UU; ++u) {
                         const uint32_t i = i0 + u;
-                        idx[u] = (i < nf && !(s.e_fld[i] & 0x80000000u)) ? i : 0xffffffffu;
+                        idx[u] = (i < nf && !(s.e_fld[i] & kRowDep)) ? i : 0xffffffffu;
                     }
                     update_rows<VEC, OPT, AUX, UU>(p, s, idx, g, lane, gpair);
                 }
@@ -1061,7 +1269,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                     __syncthreads();
                     if (wave == 0) {
                         for (uint32_t i = 0; i < nf; ++i) {
-                            if (s.e_fld[i] & 0x80000000u) {
+                            if (s.e_fld[i] & kRowDep) {
                                 uint32_t idx[1] = {i};
                                 update_rows<VEC, OPT, AUX, 1>(p, s, idx, g, lane, gpair);
                                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -1182,7 +1390,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #ifndef FW_LB_WAVES
 #define FW_LB_WAVES 6
 #endif
-template <int OPT, bool COH, int MAXR>
+template <int OPT, bool COH, int MAXR, bool WIN>
 __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_r(const KernelParams p) {
     typedef f4 V;
     constexpr int VEC = 4;
@@ -1191,7 +1399,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
     constexpr int UO = FW_UO;  // overflow rows (w + acc) in flight per wave
     extern __shared__ __align__(16) unsigned char smem[];
     const bool use_lut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global;
-    size_t off[19];
+    size_t off[21];
     lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut ? 1 : 0, p.records ? p.max_rec : 0,
                p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), off);
     Lds s;
@@ -1211,6 +1419,8 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
     s.set_ffm = reinterpret_cast<uint32_t *>(smem + off[13]);
     s.set_lr = reinterpret_cast<uint32_t *>(smem + off[14]);
     s.rec = reinterpret_cast<uint32_t *>(smem + off[15]);
+    s.set_own = reinterpret_cast<uint32_t *>(smem + off[19]);
+    s.set_blk = reinterpret_cast<uint32_t *>(smem + off[20]);
     s.tcnt = reinterpret_cast<uint32_t *>(smem + off[16]);
     s.l_combo = reinterpret_cast<uint32_t *>(smem + off[17]);
     s.nn = reinterpret_cast<float *>(smem + off[18]);
@@ -1219,8 +1429,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
     geom.setl_n = set_size(p.max_lr);
     geom.setf_shift = 32 - log2u(geom.setf_n);
     geom.setl_shift = 32 - log2u(geom.setl_n);
-    geom.blk_shift = 0;  // 2^blk_shift >= R: rows that overlap have block keys (hash >> blk_shift) differing by <= 1
-    while ((1u << geom.blk_shift) < p.R) geom.blk_shift++;
+    geom.blk_shift = conflict_blk_shift(p);
 
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = bd >> 6;
@@ -1282,7 +1491,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
         if (cnt == 0) lo = 0;
 
         // ---------------- gather: all row loads up front, rows stay resident
-        V rows[MAXR];
+        V rows[MAXR > 0 ? MAXR : 1];
 #pragma unroll
         for (int sl = 0; sl < MAXR; ++sl) {
             rows[sl] = Vec<VEC>::zero();
@@ -1298,7 +1507,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
             // consume one row (buffer order): field switch -> flush the finished field's sum, transposed, into T
 #define FW_CONSUME(ROW, IDX)                                                                                  \
     {                                                                                                         \
-        const uint32_t f_ = __builtin_amdgcn_readfirstlane(s.e_fld[(IDX)] & 0x7fffffffu);                      \
+        const uint32_t f_ = __builtin_amdgcn_readfirstlane(s.e_fld[(IDX)] & kFldMask);                         \
         const float v_ = s.e_val[(IDX)];                                                                      \
         if (f_ != cur) {                                                                                      \
             if (cur != 0xffffffffu) {                                                                         \
@@ -1332,7 +1541,11 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
                     r[u] = Vec<VEC>::zero();
                     if (i + u < hi) {
                         const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[i + u]);
+    #ifdef FW_ABL_PLAIN_GATHER
+                        r[u] = Vec<VEC>::template load<kAuxPlain>(make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
+#else
                         r[u] = Vec<VEC>::template load<AUX>(make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
+#endif
                     }
                 }
 #pragma unroll
@@ -1400,8 +1613,17 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
         if (tid == 0) p.pred[ex] = pr;
         FW_TICK(3);
 
+#ifdef FW_ABL_SKIP_UPDATE
+        if (do_update && g == 123.456f) {
+#else
         if (do_update && g != 0.0f) {
-            if (p.has_lr && !s.ctr[3]) {
+#endif
+#ifdef FW_ABL_NO_LR_UPD
+            const bool lr_upd = false;
+#else
+            const bool lr_upd = p.has_lr;
+#endif
+            if (lr_upd && !s.ctr[3]) {
                 // The entry is read again here rather than kept from the forward pass: keeping it saved no time and
                 // widened the hogwild read-modify-write window of hot entries (constant feature) by two phases.
                 for (uint32_t t = tid; t < nl; t += bd) {
@@ -1412,7 +1634,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
                     wa.x -= upd;
                     lr_store<COH>(p.lr, h, wa);
                 }
-            } else if (p.has_lr) {
+            } else if (lr_upd) {
                 for (uint32_t t = tid; t < nl; t += bd) {
                     const uint32_t h = s.l_hash[t];
                     bool first = true;
@@ -1441,7 +1663,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
                         av[u] = Vec<VEC>::zero();
                         if (OPT != FWGPU_OPT_SGD && (uint32_t)(g0 + u) < cnt) {
                             const uint32_t i = lo + g0 + u;
-                            if (!(s.e_fld[i] & 0x80000000u)) {
+                            if (!(s.e_fld[i] & kRowDep)) {
                                 const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[i]);
                                 av[u] = Vec<VEC>::template load<AUX>(make_rsrc(p.ffm_acc + h, R * 4), e0 * 4);
                             }
@@ -1452,8 +1674,8 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
                         if (g0 + u < MAXR && (uint32_t)(g0 + u) < cnt) {
                             const uint32_t i = lo + g0 + u;
                             const uint32_t fb = s.e_fld[i];
-                            if (!(fb & 0x80000000u)) {
-                                const uint32_t f = __builtin_amdgcn_readfirstlane(fb);
+                            if (!(fb & kRowDep)) {
+                                const uint32_t f = __builtin_amdgcn_readfirstlane(fb & kFldMask);
                                 const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[i]);
                                 const float v = s.e_val[i];
                                 V wv = rows[(g0 + u) < MAXR ? (g0 + u) : 0];
@@ -1480,14 +1702,21 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
                 }
             }
             // phase A, overflow rows of this range: the v1 route (fresh read of w)
+#ifdef FW_ABL_NO_FFM_UPD
+            for (uint32_t i0 = hi; i0 < hi; i0 += UO) {
+#else
             for (uint32_t i0 = lo + MAXR; i0 < hi; i0 += UO) {
+#endif
                 uint32_t idx[UO];
 #pragma unroll
                 for (int u = 0; u < UO; ++u) {
                     const uint32_t i = i0 + u;
-                    idx[u] = (i < hi && !(s.e_fld[i] & 0x80000000u)) ? i : 0xffffffffu;
+                    idx[u] = (i < hi && !(s.e_fld[i] & (kRowDep | kRowChained))) ? i : 0xffffffffu;
                 }
-                update_rows<VEC, OPT, AUX, UO>(p, s, idx, g, lane);
+                if (WIN)
+                    update_rows_win<OPT, AUX, UO, 1>(p, s, idx, g, lane, nf);
+                else
+                    update_rows<VEC, OPT, AUX, UO>(p, s, idx, g, lane);
             }
             // phase B: rows overlapping an earlier row of this example, strictly in buffer order on one wave
             if (s.ctr[1]) {
@@ -1495,9 +1724,12 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
                 __syncthreads();
                 if (wave == 0) {
                     for (uint32_t i = 0; i < nf; ++i) {
-                        if (s.e_fld[i] & 0x80000000u) {
+                        if (s.e_fld[i] & kRowDep) {
                             uint32_t idx[1] = {i};
-                            update_rows<VEC, OPT, AUX, 1>(p, s, idx, g, lane);
+                            if (WIN)
+                                update_rows_win<OPT, AUX, 1, 1>(p, s, idx, g, lane, nf);
+                            else
+                                update_rows<VEC, OPT, AUX, 1>(p, s, idx, g, lane);
                             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                             __builtin_amdgcn_s_waitcnt(0);
                         }
@@ -1514,9 +1746,13 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
 #ifndef FW_MAXR
 #define FW_MAXR 2
 #endif
+#ifndef FW_MAXR_WIN
+#define FW_MAXR_WIN 0
+#endif
 template <int OPT, bool COH>
 static hipError_t launch_r(const KernelParams &p, uint32_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
-    return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR>, p, grid, threads, lds, stream);
+    if (p.window) return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR_WIN, true>, p, grid, threads, lds, stream);
+    return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR, false>, p, grid, threads, lds, stream);
 }
 
 static hipError_t launch_resident(const KernelParams &p, int optimizer, bool coherent, uint32_t grid, uint32_t threads,
@@ -1535,16 +1771,21 @@ static hipError_t launch_resident(const KernelParams &p, int optimizer, bool coh
     }
 }
 
-hipError_t launch_example_kernel(const KernelParams &p, int optimizer, bool coherent, uint32_t grid, uint32_t threads,
+hipError_t launch_example_kernel(const KernelParams &p_in, int optimizer, bool coherent, uint32_t grid, uint32_t threads,
                                  hipStream_t stream) {
-    if (p.n_examples == 0) return hipSuccess;
+    if (p_in.n_examples == 0) return hipSuccess;
+    KernelParams p = p_in;
+    const bool v2 = p.k % 4 == 0 && p.aligned4 && p.R <= 64 * 4 && p.kernel_version != 1 && p.nn.n_layers == 0 && threads <= FW_LB_THREADS;
+    // whole-line updates: only where the kernel that implements them runs, only for updating launches
+    p.window = (p.window && v2 && p.update && p.k_log2 != 0xffu) ? 1 : 0;
+    p.chain = p.window;
     const size_t lds = example_kernel_lds_bytes(p, optimizer);
     // 16-byte row vectors need k % 4 == 0: then R % 4 == 0 and hash & mask is a multiple of next_pow2(k) >= 4
     // floats (feature_buffer.rs:141-148), so every row starts 16-byte aligned.
     // Entries that did not come through the translator's mask (raw fwgpu_learn calls) may be unaligned.
     if (p.k % 4 == 0 && p.aligned4) {
         // single-chunk rows: the register-resident kernel (v2); p.kernel_version == 1 forces v1 (tests, A/B runs)
-        if (p.R <= 64 * 4 && p.kernel_version != 1 && p.nn.n_layers == 0 && threads <= FW_LB_THREADS) return launch_resident(p, optimizer, coherent, grid, threads, lds, stream);
+        if (v2) return launch_resident(p, optimizer, coherent, grid, threads, lds, stream);
         return launch_v<4>(p, optimizer, coherent, grid, threads, lds, stream);
     }
     return launch_v<1>(p, optimizer, coherent, grid, threads, lds, stream);

@@ -303,6 +303,14 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
     p.has_lr = r->cfg.wiring == FWGPU_WIRING_REGRESSOR;
     p.update = update ? 1 : 0;
     p.aligned4 = b->aligned4 ? 1 : 0;
+    // Whole-line row updates pay where partial-line writes reach HBM, i.e. when w + acc do not fit the 256 MiB Infinity
+    // Cache (profiles/r02_rowceil.txt: cache-resident tables write partial lines at full rate).  Small tables also are
+    // where concurrent examples would meet on a line most often, so they keep float-granular writes.
+    // (launch_example_kernel keeps the flag only where the whole-line path exists.)
+    p.window = r->launch.window == 2 || (r->launch.window == 1 && r->ffm_len * 8ull > (256ull << 20)) ? 1 : 0;
+    p.k_log2 = 0xffu;
+    for (uint32_t l = 0; l < 16; l++)
+        if ((1u << l) == r->cfg.ffm_k) p.k_log2 = l;
     p.lr_rate = r->cfg.learning_rate;
     p.lr_minus_power_t = -r->cfg.power_t;
     p.ffm_rate = r->cfg.ffm_learning_rate;
@@ -582,6 +590,10 @@ int fwgpu_debug_set_option(fwgpu_regressor *r, int option, int value) {
     if (!r) return fail(FWGPU_ERR_INVALID, "NULL regressor");
     switch (option) {
     case 1: r->launch.lut_global = value ? 1 : 0; return FWGPU_OK;
+    case 2:  // whole-line FFM row updates: 0 off, 1 auto (tables larger than the Infinity Cache; default), 2 always
+        if (value < 0 || value > 2) return fail(FWGPU_ERR_INVALID, "window option: 0, 1 or 2");
+        r->launch.window = value;
+        return FWGPU_OK;
     }
     return fail(FWGPU_ERR_INVALID, "unknown debug option");
 }

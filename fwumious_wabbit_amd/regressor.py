@@ -306,6 +306,11 @@ class Regressor:
     def set_launch(self, threads=0, workgroups_per_cu=0):
         check(self.L.fwgpu_set_launch(self.h, threads, workgroups_per_cu))
 
+    def set_whole_line_updates(self, mode):
+        """FFM rows written back as the whole 128 B lines they touch: 0 off, 1 auto (tables larger than the Infinity
+        Cache; the default), 2 always (kernels.hip update_rows_win)"""
+        check(self.L.fwgpu_debug_set_option(self.h, 2, int(mode)))
+
     # ---- tables
     def set_max_in_flight(self, n):
         """cap on the examples a HOGWILD launch processes concurrently (16 = hogwild.rs's default thread count; 0 = no cap)"""

@@ -38,7 +38,9 @@ def run(threads, wgs, update=True, reps=6, label=""):
     tot = t[:7].sum()
     per_ex = tot / max(t[7], 1)
     br = " ".join(f"{n}={100*v/tot:.0f}%" for n, v in zip(names[:7], t[:7]))
-    sub = " ".join(f"s{j}={100*t[8+j]/tot:.1f}%" for j in range(8) if t[8+j])
+    sub = " ".join(f"s{j}={100*t[8+j]/tot:.1f}%" for j in range(4) if t[8+j])
+    if t[15]:
+        sub += f" | per update batch: store-drain {t[12]/t[15]:.0f} load-wait {t[13]/t[15]:.0f} issue+compute {t[14]/t[15]:.0f} ticks, {t[15]/max(t[7],1):.1f} batches/example"
     print(f"{label} threads={threads} wgs/cu={wgs or 'auto'} update={update}: {dt*1e3:.3f} ms/launch {B/dt/1e6:.2f} Mex/s | ticks/example={per_ex:.0f} | {br} | stage parts: {sub}", flush=True)
 
 use_records = os.environ.get("RECORDS", "1") == "1"
@@ -47,6 +49,7 @@ if use_records:
 quick = os.environ.get("QUICK", "0") == "1"
 for lutg in ((int(os.environ.get("LUTG", 0)),) if quick else (0, 1)):
     capi.check(L.fwgpu_debug_set_option(re.h, 1, lutg))
+    capi.check(L.fwgpu_debug_set_option(re.h, 2, int(os.environ.get("WINDOW", 1))))
     print(f"--- kernel v2, lut_global={lutg}, records={use_records}")
     for th, w in (((int(os.environ.get("THREADS", 512)), int(os.environ.get("WGS", 0))),) if quick else ((512, 2), (384, 2), (320, 3), (384, 3), (256, 4), (448, 2))):
         run(th, w)

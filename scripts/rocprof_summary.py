@@ -14,7 +14,7 @@ for path in sys.argv[1:]:
     try:
         rows = list(cur.execute("select kernel_name, counter_name, value, duration, grid_size, workgroup_size, lds_block_size, vgpr_count, sgpr_count from counters_collection where kernel_name like '%fw_example_kernel%'"))
         if rows:
-            print("# PMC per dispatch: kernel, counter, value(KB), duration_us, grid, wg, lds, vgpr, sgpr")
+            print("# PMC per dispatch (FETCH_SIZE / WRITE_SIZE are in KB): kernel, counter, value, duration_us, grid, wg, lds, vgpr, sgpr")
             for r in rows: print(f"{r[0]}, {r[1]}, {r[2]:.1f}, {r[3]/1e3:.1f}, {r[4]}, {r[5]}, {r[6]}, {r[7]}, {r[8]}")
     except sqlite3.Error as e:
         print("no counters_collection:", e)

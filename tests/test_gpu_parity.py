@@ -55,7 +55,7 @@ def test_smoke_entry():
 
 # ------------------------------------------------------------------ streams: sequential mode == reference single thread
 def _stream_parity(n_ns, k, bits, ffm_bits, optimizer, n, mean_extra, p_weighted, ids, seed, interactions=(),
-                   weight_tol=2e-5, **kw):
+                   weight_tol=2e-5, whole_lines=None, **kw):
     mi, ocfg, ots = make_pair(n_ns, k, bits, ffm_bits, optimizer, interactions=interactions, **kw)
     recs, off = fw.synth_records(n_ns, mean_extra, 1.1, ids, p_weighted, seed, 0, n)
     y = record_labels(recs, off)
@@ -65,6 +65,8 @@ def _stream_parity(n_ns, k, bits, ffm_bits, optimizer, n, mean_extra, p_weighted
     # both ways of feeding the device: entries translated on the host, and raw records translated inside the kernel
     for kind in ("entries", "records"):
         re = fw.Regressor(mi)
+        if whole_lines is not None:
+            re.set_whole_line_updates(whole_lines)
         fbt = fw.FeatureBufferTranslator(mi)
         b = re.batch_from_records(fbt, recs, off) if kind == "entries" else re.record_batch(fbt, recs, off)
         re.learn_batch(b, capi.MODE_SEQUENTIAL, True)
@@ -102,6 +104,25 @@ def test_sequential_stream_config_c_like():
     # 30 fields, k=8, ~200 nnz per example, weighted features, LR interactions
     _stream_parity(30, 8, 18, 18, fw.Optimizer.AdagradLUT, n=300, mean_extra=5.67, p_weighted=0.1, ids=100000, seed=2,
                    interactions=[(0, 1), (3, 7)])
+
+
+@pytest.mark.parametrize("whole_lines", [0, 2])
+def test_sequential_stream_whole_line_row_updates(whole_lines):
+    """The whole-line ("window") update path of the v2 kernel (forced on: these tables are far smaller than the Infinity
+    Cache, where it is off by default) must be exact in the in-order mode: rows whose 128 B line spans intersect are
+    serialised, neighbouring weights pass through bit for bit.  Tiny tables: heavy collisions, overlaps and shared lines;
+    k = 8 rows with all four start phases (0/32/64/96 B into a line, the last one spilling into a ninth line), k = 4 rows
+    of 2-3 lines, k = 16 single-field rows."""
+    _stream_parity(30, 8, 18, 18, fw.Optimizer.AdagradLUT, n=300, mean_extra=5.67, p_weighted=0.1, ids=100000, seed=41,
+                   whole_lines=whole_lines)
+    _stream_parity(30, 8, 15, 15, fw.Optimizer.AdagradLUT, n=200, mean_extra=2.0, p_weighted=0.1, ids=3000, seed=42,
+                   whole_lines=whole_lines)
+    _stream_parity(10, 4, 12, 12, fw.Optimizer.AdagradLUT, n=1500, mean_extra=0.0, p_weighted=0.0, ids=3000, seed=43,
+                   whole_lines=whole_lines)
+    _stream_parity(12, 16, 14, 14, fw.Optimizer.AdagradFlex, n=400, mean_extra=1.0, p_weighted=0.2, ids=2000, seed=44,
+                   init_acc=1.0, ffm_init_acc=1.0, weight_tol=5e-5, whole_lines=whole_lines)
+    _stream_parity(6, 4, 12, 12, fw.Optimizer.SGD, n=800, mean_extra=1.0, p_weighted=0.2, ids=500, seed=45, lr=0.05,
+                   ffm_lr=0.05, whole_lines=whole_lines)
 
 
 def test_sequential_stream_config_a_like_scalar_path():

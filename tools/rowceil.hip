@@ -131,6 +131,48 @@ __global__ void rows_win(float *w, float *a, const uint32_t *rows, uint32_t nrow
     }
 }
 
+// ---- line-interleaved layout experiment: ONE table, 128 B lines alternate w / acc (line 2j = w line j, 2j+1 = acc line j),
+// so a row's w AND acc lines form one contiguous span of 2 x (whole lines of the row).  MODE 0: forward read (w lines only),
+// MODE 1: update = read the whole span, write the whole span (whole lines).
+template <int U, int MODE>
+__global__ void rows_il128(float *tab, const uint32_t *rows, uint32_t nrows, uint32_t R, float *sink) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    f4 keep = {0, 0, 0, 0};
+    // lane -> byte offset inside the interleaved span: line (lane / 8) of the w (or acc) array, 16 B piece lane % 8
+    const uint32_t off_w = (lane >> 3) * 256 + (lane & 7) * 16, off_a = off_w + 128;
+    for (uint32_t i = wave * U; i < nrows; i += nwaves * U) {
+        u4 vw[U], va[U];
+        uint32_t s[U], nb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t r = i + u < nrows ? i + u : i;
+            const uint32_t h = __builtin_amdgcn_readfirstlane(rows[r]);
+            s[u] = ((h * 4u) & ~127u) * 2u;                                   // byte offset of the span in the interleaved table
+            nb[u] = ((((h * 4u) & 127u) + R * 4u + 127u) & ~127u) * 2u;       // bytes of the span (<= 2304)
+            if (nb[u] > 2048u) nb[u] = 2048u;                                 // (9-line rows: tail ignored in this experiment)
+            __amdgpu_buffer_rsrc_t rs = rsrc((char *)tab + s[u], nb[u]);
+            vw[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, off_w, 0, 16);
+            va[u] = u4{1, 2, 3, 4};
+            if (MODE == 1) va[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, off_a, 0, 16);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            f4 x = __builtin_bit_cast(f4, vw[u]), y = __builtin_bit_cast(f4, va[u]);
+            y += x * x;
+            x -= y * 1e-9f;
+            if (MODE == 1) {
+                __amdgpu_buffer_rsrc_t rs = rsrc((char *)tab + s[u], nb[u]);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, x), rs, off_w, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, y), rs, off_a, 0, 16);
+            } else {
+                keep += x;
+            }
+        }
+    }
+    if (keep.x + keep.y + keep.z + keep.w == 123.456f) sink[0] = keep.x;
+}
+
 template <typename F>
 static float time_ms(F launch, int reps = 4) {
     hipEvent_t a, b;
@@ -236,6 +278,29 @@ int main(int argc, char **argv) {
             printf("%-46s waves/CU=32 U=4 : %7.3f ms  %7.1f GB/s (4 x row bytes)\n", "read-all kernel, then write-all kernel", ms,
                    4 * row_bytes / ms / 1e6);
         }
+    }
+    {   // line-interleaved w/acc layout (one 2 GiB table)
+        float *il;
+        CK(hipMalloc(&il, tab_floats * 8 + 8192));
+        CK(hipMemset(il, 0, tab_floats * 8 + 8192));
+        const uint32_t R = 240;
+        std::vector<uint32_t> h(nrows);
+        gen_rows(h, 88172645463325252ull, 8, 28);
+        CK(hipMemcpy(rows, h.data(), nrows * 4, hipMemcpyHostToDevice));
+        const double row_bytes = (double)nrows * R * 4;
+        printf("== line-interleaved layout (w line, acc line, w line, ...), R=240, starts aligned to 32 B\n");
+        for (int wpc : {16, 32}) {
+            const int blocks = 256 * wpc / 4;
+#define IL(name, mult, U, MODE)                                                                                        \
+    {                                                                                                                  \
+        float ms = time_ms([&] { hipLaunchKernelGGL((rows_il128<U, MODE>), dim3(blocks), dim3(256), 0, 0, il, rows, nrows, R, sink); }); \
+        printf("%-46s waves/CU=%2d U=%d : %7.3f ms  %7.1f GB/s (%d x ROW bytes)\n", name, wpc, U, ms, mult * row_bytes / ms / 1e6, mult); \
+    }
+            IL("IL128 forward: read w lines only", 1, 4, 0);
+            IL("IL128 update: read + write whole span", 4, 4, 1);
+            IL("IL128 update: read + write whole span U=2", 4, 2, 1);
+        }
+        CK(hipFree(il));
     }
     // locality: the same number of rows drawn from a smaller span of the table (MALL = 256 MiB)
     {
