@@ -141,9 +141,9 @@ struct Lds {
     uint32_t *fstart, *fend;  // F
     float *red;               // 3*16
     float *dcf;               // F: per-field self-pair correction
-    uint32_t *set_ffm;        // open-addressing set of FFM row block keys (overlap pre-filter)
-    uint32_t *set_lr;         // open-addressing set of LR hashes (duplicate pre-filter)
-    uint32_t *set_own;        // per slot of set_ffm: first entry index carrying that hash (duplicate-row chains)
+    uint32_t *set_ffm;        // open-addressing set: FFM row block keys (overlap pre-filter), or -- chains -- first entry index of every row hash
+    uint32_t *set_lr;         // open-addressing set: first entry index of every LR hash
+    uint32_t *l_flag;         // per LR entry: kRowChained / kRowHasChain (duplicate LR hashes, block_lr.rs:135-150 order)
     uint32_t *set_blk;        // open-addressing set of FFM row block keys of first occurrences (chains: set_ffm then holds hashes)
     uint32_t *rec;            // raw record staged for device-side translation (max_rec words)
     uint32_t *tcnt;           // per (field,namespace) pair and per combo: entry count, then exclusive offset
@@ -188,19 +188,29 @@ __device__ __forceinline__ bool set_insert(uint32_t *tab, uint32_t mask, uint32_
         slot = (slot + 1) & mask;
     }
 }
-// insert that reports the slot (the caller keeps per-key data in a parallel array)
-__device__ __forceinline__ uint32_t set_insert_slot(uint32_t *tab, uint32_t mask, uint32_t shift, uint32_t key) {
+// Index-valued variant: the table holds entry INDICES, the key of a slot is keys[tab[slot]].  Inserting entry i under
+// keys[i] leaves the SMALLEST index of every key in its slot, i.e. the first occurrence in buffer order.
+__device__ __forceinline__ void first_insert(uint32_t *tab, uint32_t mask, uint32_t shift, const uint32_t *keys, uint32_t i) {
+    const uint32_t key = keys[i];
     uint32_t slot = (key * 2654435761u) >> shift;
     for (;;) {
-        const uint32_t old = atomicCAS(&tab[slot], kSetEmpty, key);
-        if (old == kSetEmpty || old == key) return slot;
+        const uint32_t old = atomicCAS(&tab[slot], kSetEmpty, i);
+        if (old == kSetEmpty) return;
+        if (keys[old] == key) {  // (the slot may change meanwhile, but only to another index of the same key)
+            atomicMin(&tab[slot], i);
+            return;
+        }
         slot = (slot + 1) & mask;
     }
 }
-__device__ __forceinline__ uint32_t set_find_slot(const uint32_t *tab, uint32_t mask, uint32_t shift, uint32_t key) {
+// first occurrence of a key that is known to be present
+__device__ __forceinline__ uint32_t first_find(const uint32_t *tab, uint32_t mask, uint32_t shift, const uint32_t *keys, uint32_t key) {
     uint32_t slot = (key * 2654435761u) >> shift;
-    while (tab[slot] != key) slot = (slot + 1) & mask;  // the key is known to be present
-    return slot;
+    for (;;) {
+        const uint32_t v = tab[slot];
+        if (keys[v] == key) return v;
+        slot = (slot + 1) & mask;
+    }
 }
 __device__ __forceinline__ bool set_contains(const uint32_t *tab, uint32_t mask, uint32_t shift, uint32_t key) {
     uint32_t slot = (key * 2654435761u) >> shift;
@@ -213,7 +223,7 @@ __device__ __forceinline__ bool set_contains(const uint32_t *tab, uint32_t mask,
 }
 
 __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t max_ffm, uint32_t max_lr, uint32_t n_luts,
-                                             uint32_t max_rec, uint32_t tr_items, uint32_t nn_floats, size_t *off /*[21]*/) {
+                                             uint32_t max_rec, uint32_t tr_items, uint32_t nn_floats, bool chain, size_t *off /*[23]*/) {
     size_t o = 0;
     size_t R = (size_t)F * k;
     off[0] = o; o = align16(o + 4 * F * R);
@@ -233,23 +243,21 @@ __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t ma
     // when they fit they live INSIDE T's region (config C: 6.4 KB of 28.8 KB), which is what lets a third workgroup fit a CU.
     {
         const size_t a13 = 0, a14 = align16(a13 + 4 * (size_t)set_size(max_ffm)), a15 = align16(a14 + 4 * (size_t)set_size(max_lr)),
-                     a19 = align16(a15 + 4 * (size_t)max_rec), a20 = align16(a19 + 4 * (size_t)set_size(max_ffm)),
-                     aend = align16(a20 + 4 * (size_t)set_size(max_ffm));
+                     a20 = align16(a15 + 4 * (size_t)max_rec), aend = align16(a20 + (chain ? 4 * (size_t)set_size(max_ffm) : 0));
         if (aend <= 4 * F * R) {
             off[13] = a13;
             off[14] = a14;
             off[15] = a15;
-            off[19] = a19;
             off[20] = a20;
         } else {
             off[13] = o; o = align16(o + 4 * (size_t)set_size(max_ffm));
             off[14] = o; o = align16(o + 4 * (size_t)set_size(max_lr));
             off[15] = o; o = align16(o + 4 * (size_t)max_rec);
-            off[19] = o; o = align16(o + 4 * (size_t)set_size(max_ffm));
-            off[20] = o; o = align16(o + 4 * (size_t)set_size(max_ffm));
+            off[20] = o; o = align16(o + (chain ? 4 * (size_t)set_size(max_ffm) : 0));
         }
     }
     off[16] = o; o = align16(o + 4 * (size_t)tr_items);
+    off[21] = o; o = align16(o + 4 * (size_t)max_lr);
     off[17] = o; o = align16(o + (nn_floats ? 4 * (size_t)max_lr : 0));
     off[18] = o; o = align16(o + 4 * (size_t)nn_floats);
     return o;
@@ -363,12 +371,10 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
     if (do_update) {
         for (uint32_t i = tid; i < g.setf_n; i += bd) {
             s.set_ffm[i] = kSetEmpty;
-            if (p.chain) {
-                s.set_own[i] = 0xffffffffu;
-                s.set_blk[i] = kSetEmpty;
-            }
+            if (p.chain) s.set_blk[i] = kSetEmpty;
         }
         for (uint32_t i = tid; i < g.setl_n; i += bd) s.set_lr[i] = kSetEmpty;
+        for (uint32_t i = tid; i < p.max_lr; i += bd) s.l_flag[i] = 0;
     }
     if (!p.records) {
         for (uint32_t i = tid; i < o.nf; i += bd) {
@@ -498,9 +504,8 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
         if (i == 0 || s.e_fld[i - 1] != f) s.fstart[f] = i;
         if (i == nf - 1 || s.e_fld[i + 1] != f) s.fend[f] = i + 1;
         if (do_update) {
-            if (p.chain) {  // set_ffm holds the row hashes; set_own the first entry carrying each
-                const uint32_t sl = set_insert_slot(s.set_ffm, g.setf_n - 1, g.setf_shift, s.e_hash[i]);
-                atomicMin(&s.set_own[sl], i);
+            if (p.chain) {  // set_ffm: first entry of every row hash
+                first_insert(s.set_ffm, g.setf_n - 1, g.setf_shift, s.e_hash, i);
             } else if (set_insert(s.set_ffm, g.setf_n - 1, g.setf_shift, s.e_hash[i] >> g.blk_shift)) {
                 s.ctr[2] = 1;
             }
@@ -508,16 +513,24 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
     }
     if (do_update && p.has_lr)
         for (uint32_t i = tid; i < nl; i += bd)
-            if (set_insert(s.set_lr, g.setl_n - 1, g.setl_shift, s.l_hash[i])) s.ctr[3] = 1;
+            first_insert(s.set_lr, g.setl_n - 1, g.setl_shift, s.l_hash, i);
     __syncthreads();
     tk.stamp(10);
+    if (do_update && p.has_lr)  // duplicate LR hashes: later occurrences are chained to the first (lr_update)
+        for (uint32_t i = tid; i < nl; i += bd) {
+            const uint32_t own = first_find(s.set_lr, g.setl_n - 1, g.setl_shift, s.l_hash, s.l_hash[i]);
+            if (own != i) {
+                atomicOr(&s.l_flag[i], kRowChained);
+                atomicOr(&s.l_flag[own], kRowHasChain);
+            }
+        }
     if (do_update && p.chain) {
         // Rows of the SAME hash (a feature drawn twice, or two features colliding: 98 % of config C's examples have some)
         // are chained to the first one: its owner applies them in buffer order from registers (update_rows_win).  Only
         // first occurrences enter the overlap pre-filter, so duplicates alone never trigger the exact scan.
         for (uint32_t i = tid; i < nf; i += bd) {
             const uint32_t h = s.e_hash[i];
-            const uint32_t own = s.set_own[set_find_slot(s.set_ffm, g.setf_n - 1, g.setf_shift, h)];
+            const uint32_t own = first_find(s.set_ffm, g.setf_n - 1, g.setf_shift, s.e_hash, h);
             if (own != i) {
                 atomicOr(&s.e_fld[i], kRowChained);
                 atomicOr(&s.e_fld[own], kRowHasChain);
@@ -589,9 +602,9 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
 }
 
 size_t example_kernel_lds_bytes(const KernelParams &p, int optimizer) {
-    size_t off[21];
+    size_t off[23];
     return lds_layout(p.F, p.k, p.max_ffm, p.max_lr, (optimizer == FWGPU_OPT_ADAGRAD_LUT && p.update && !p.lut_global) ? 1 : 0,
-                      p.records ? p.max_rec : 0, p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), off);
+                      p.records ? p.max_rec : 0, p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off);
 }
 
 
@@ -824,6 +837,32 @@ __device__ __forceinline__ void nn_backward(const KernelParams &p, const Lds &s,
     }
 }
 
+// LR update (block_lr.rs:135-150).  Entries with the same hash are applied by the thread owning the FIRST occurrence, in
+// buffer order, on one register copy of {w, acc}: duplicates chain exactly like the reference's loop (regressor.rs:629-655
+// pins this).  The entry is read again here rather than kept from the forward pass: keeping it saved no time and widened
+// the hogwild read-modify-write window of hot entries (constant feature) by two phases.
+template <int OPT, bool COH>
+__device__ __forceinline__ void lr_update(const KernelParams &p, const Lds &s, uint32_t nl, float g, const float *gx,
+                                          const float *lut_lr, int tid, int bd) {
+    for (uint32_t t = tid; t < nl; t += bd) {
+        const uint32_t fl = s.l_flag[t];
+        if (fl & kRowChained) continue;
+        const uint32_t h = s.l_hash[t];
+        float2 wa = lr_load<COH>(p.lr, h);
+        {
+            const float grad = (gx ? gx[s.l_combo[t]] : g) * s.l_val[t];
+            wa.x -= opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, lut_lr);
+        }
+        if (fl & kRowHasChain)
+            for (uint32_t j = t + 1; j < nl; ++j)
+                if (s.l_hash[j] == h) {
+                    const float grad = (gx ? gx[s.l_combo[j]] : g) * s.l_val[j];
+                    wa.x -= opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, lut_lr);
+                }
+        lr_store<COH>(p.lr, h, wa);
+    }
+}
+
 // Update of one FFM feature row by one wave (block_ffm.rs:269-286), U rows at a time for memory-level
 // parallelism.  idx[u] == 0xffffffff marks an unused slot.
 template <int VEC, int OPT, int AUX, int U>
@@ -908,49 +947,52 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
         pt1 = __builtin_amdgcn_s_memtime();
     }
 #endif
+    // NCH 1 KiB chunks per row, all loaded before anything is computed (one memory round trip per batch of U rows).
+    // A k = 8 row that starts 96 B into a line spans 9 lines: its second chunk is the one extra line (8 lanes).
+    f4 wv[U][NCH], av[U][NCH];
+    uint32_t hh[U], sb[U], nb[U];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        f4 wv[U], av[U];
-        uint32_t hh[U], sb[U], nb[U];
-        bool on[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            wv[u] = f4{0.f, 0.f, 0.f, 0.f};
-            av[u] = wv[u];
-            on[u] = false;
-            hh[u] = sb[u] = nb[u] = 0;
-            if (idx[u] != 0xffffffffu) {
-                hh[u] = __builtin_amdgcn_readfirstlane(s.e_hash[idx[u]]);
-                sb[u] = (hh[u] * 4u) & 127u;                          // row start within its first line, bytes
-                nb[u] = (sb[u] + R * 4u + 127u) & ~127u;              // whole lines covered, bytes
-                if (nb[u] > (uint32_t)NCH * 1024u) {                  // (wave-uniform) the row straddles one line more than
-                    sb[u] = 0;                                        // NCH chunks hold (k = 8: rows starting 96 B into a line
-                    nb[u] = R * 4u;                                   // span 9): this row keeps float-granular accesses
-                }
-                on[u] = nb[u] > (uint32_t)c * 1024u;                  // wave-uniform
-                if (on[u]) {
-                    const uint32_t fl = hh[u] - (sb[u] >> 2);         // float index of the window start
-                    wv[u] = Vec<4>::template load<AUX>(make_rsrc(p.ffm_w + fl, nb[u]), c * 1024 + lane * 16);
-                    if (OPT != FWGPU_OPT_SGD)
-                        av[u] = Vec<4>::template load<AUX>(make_rsrc(p.ffm_acc + fl, nb[u]), c * 1024 + lane * 16);
-                }
+    for (int u = 0; u < U; ++u) {
+        hh[u] = sb[u] = nb[u] = 0;
+        if (idx[u] != 0xffffffffu) {
+            hh[u] = __builtin_amdgcn_readfirstlane(s.e_hash[idx[u]]);
+            sb[u] = (hh[u] * 4u) & 127u;                          // row start within its first line, bytes
+            nb[u] = (sb[u] + R * 4u + 127u) & ~127u;              // whole lines covered, bytes
+            if (nb[u] > (uint32_t)NCH * 1024u) {                  // (wave-uniform) more lines than NCH chunks hold:
+                sb[u] = 0;                                        // this row keeps float-granular accesses
+                nb[u] = R * 4u;
             }
         }
-#ifdef FW_PROF_UPD
-        if (p.ticks) {
-            pt2 = __builtin_amdgcn_s_memtime();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this batch's loads have landed
-            pt3 = __builtin_amdgcn_s_memtime();
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            wv[u][c] = f4{0.f, 0.f, 0.f, 0.f};
+            av[u][c] = wv[u][c];
+            if (nb[u] > (uint32_t)c * 1024u) {                    // wave-uniform
+                const uint32_t fl = hh[u] - (sb[u] >> 2);         // float index of the window start
+                wv[u][c] = Vec<4>::template load<AUX>(make_rsrc(p.ffm_w + fl, nb[u]), c * 1024 + lane * 16);
+                if (OPT != FWGPU_OPT_SGD)
+                    av[u][c] = Vec<4>::template load<AUX>(make_rsrc(p.ffm_acc + fl, nb[u]), c * 1024 + lane * 16);
+            }
         }
+    }
+#ifdef FW_PROF_UPD
+    if (p.ticks) {
+        pt2 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this batch's loads have landed
+        pt3 = __builtin_amdgcn_s_memtime();
+    }
 #endif
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!on[u]) continue;
-            const uint32_t fbits = __builtin_amdgcn_readfirstlane(s.e_fld[idx[u]]);
+    for (int u = 0; u < U; ++u) {
+        if (nb[u] == 0) continue;
+        const uint32_t fbits = __builtin_amdgcn_readfirstlane(s.e_fld[idx[u]]);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (nb[u] <= (uint32_t)c * 1024u) continue;
             const int e = c * 256 + lane * 4 - (int)(sb[u] >> 2);    // this lane's first element of the row
             const bool inb = e >= 0 && e < (int)R;
             const uint32_t z = inb ? (uint32_t)e >> ksh : 0xfffffffeu;
-            f4 wn = wv[u], an = av[u];
+            f4 wn = wv[u][c], an = av[u][c];
             // one occurrence of the row (entry i): gradient from the pre-update weights (T and selfw were taken in the
             // gather), AdaGrad step on the running (wn, an)
             auto apply = [&](uint32_t i, uint32_t f) {
@@ -988,8 +1030,8 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
                 }
             }
             if (!inb) {  // neighbouring weights: written back bit for bit
-                wn = wv[u];
-                an = av[u];
+                wn = wv[u][c];
+                an = av[u][c];
             }
             const uint32_t fl = hh[u] - (sb[u] >> 2);
 #ifdef FW_ABL_NO_STORE
@@ -1021,9 +1063,9 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
     constexpr int UU = 4;  // feature rows in flight per wave in the update phase (x2 tables)
     extern __shared__ __align__(16) unsigned char smem[];
     const bool use_lut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global;
-    size_t off[21];
+    size_t off[23];
     lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut ? 1 : 0, p.records ? p.max_rec : 0,
-               p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), off);
+               p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off);
     Lds s;
     s.T = reinterpret_cast<float *>(smem + off[0]);
     s.selfw = reinterpret_cast<float *>(smem + off[1]);
@@ -1041,7 +1083,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
     s.set_ffm = reinterpret_cast<uint32_t *>(smem + off[13]);
     s.set_lr = reinterpret_cast<uint32_t *>(smem + off[14]);
     s.rec = reinterpret_cast<uint32_t *>(smem + off[15]);
-    s.set_own = reinterpret_cast<uint32_t *>(smem + off[19]);
+    s.l_flag = reinterpret_cast<uint32_t *>(smem + off[21]);
     s.set_blk = reinterpret_cast<uint32_t *>(smem + off[20]);
     s.tcnt = reinterpret_cast<uint32_t *>(smem + off[16]);
     s.l_combo = reinterpret_cast<uint32_t *>(smem + off[17]);
@@ -1222,35 +1264,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                 gx = nn_buf(p, s).xg;
                 gpair = gx + p.num_combos;
             }
-            // LR (block_lr.rs:135-150): the thread owning the FIRST occurrence of a hash applies all
-            // occurrences in buffer order, so duplicates chain exactly like the reference's loop.
-            if (p.has_lr && !s.ctr[3]) {
-                for (uint32_t t = tid; t < nl; t += bd) {
-                    const uint32_t h = s.l_hash[t];
-                    float2 wa = lr_load<COH>(p.lr, h);
-                    const float grad = (gx ? gx[s.l_combo[t]] : g) * s.l_val[t];
-                    const float upd = opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, lut_lr);
-                    wa.x -= upd;
-                    lr_store<COH>(p.lr, h, wa);
-                }
-            } else if (p.has_lr) {
-                for (uint32_t t = tid; t < nl; t += bd) {
-                    const uint32_t h = s.l_hash[t];
-                    bool first = true;
-                    for (uint32_t j = 0; j < t; ++j) first = first && (s.l_hash[j] != h);
-                    if (first) {
-                        float2 wa = lr_load<COH>(p.lr, h);
-                        for (uint32_t j = t; j < nl; ++j) {
-                            if (s.l_hash[j] == h) {
-                                const float grad = (gx ? gx[s.l_combo[j]] : g) * s.l_val[j];
-                                const float upd = opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, lut_lr);
-                                wa.x -= upd;
-                            }
-                        }
-                        lr_store<COH>(p.lr, h, wa);
-                    }
-                }
-            }
+            if (p.has_lr) lr_update<OPT, COH>(p, s, nl, g, gx, lut_lr, tid, bd);
             FW_TICK(4);
             if (k) {
                 // phase A: rows with no earlier overlapping row, all waves, UU rows each
@@ -1379,6 +1393,9 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #ifndef FW_UA
 #define FW_UA 2
 #endif
+#ifndef FW_WIN_NCH  // 1 KiB chunks per row in the whole-line update.  2 would give the k = 8 rows that span 9 lines their ninth line too: measured slower (3.96 vs 3.86 ms, the extra registers spill)
+#define FW_WIN_NCH 1
+#endif
 #ifndef FW_UO
 #define FW_UO 2
 #endif
@@ -1399,9 +1416,9 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
     constexpr int UO = FW_UO;  // overflow rows (w + acc) in flight per wave
     extern __shared__ __align__(16) unsigned char smem[];
     const bool use_lut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global;
-    size_t off[21];
+    size_t off[23];
     lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut ? 1 : 0, p.records ? p.max_rec : 0,
-               p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), off);
+               p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off);
     Lds s;
     s.T = reinterpret_cast<float *>(smem + off[0]);
     s.selfw = reinterpret_cast<float *>(smem + off[1]);
@@ -1419,7 +1436,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
     s.set_ffm = reinterpret_cast<uint32_t *>(smem + off[13]);
     s.set_lr = reinterpret_cast<uint32_t *>(smem + off[14]);
     s.rec = reinterpret_cast<uint32_t *>(smem + off[15]);
-    s.set_own = reinterpret_cast<uint32_t *>(smem + off[19]);
+    s.l_flag = reinterpret_cast<uint32_t *>(smem + off[21]);
     s.set_blk = reinterpret_cast<uint32_t *>(smem + off[20]);
     s.tcnt = reinterpret_cast<uint32_t *>(smem + off[16]);
     s.l_combo = reinterpret_cast<uint32_t *>(smem + off[17]);
@@ -1623,35 +1640,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
 #else
             const bool lr_upd = p.has_lr;
 #endif
-            if (lr_upd && !s.ctr[3]) {
-                // The entry is read again here rather than kept from the forward pass: keeping it saved no time and
-                // widened the hogwild read-modify-write window of hot entries (constant feature) by two phases.
-                for (uint32_t t = tid; t < nl; t += bd) {
-                    const uint32_t h = s.l_hash[t];
-                    float2 wa = lr_load<COH>(p.lr, h);
-                    const float grad = g * s.l_val[t];
-                    const float upd = opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, lut_lr);
-                    wa.x -= upd;
-                    lr_store<COH>(p.lr, h, wa);
-                }
-            } else if (lr_upd) {
-                for (uint32_t t = tid; t < nl; t += bd) {
-                    const uint32_t h = s.l_hash[t];
-                    bool first = true;
-                    for (uint32_t j = 0; j < t; ++j) first = first && (s.l_hash[j] != h);
-                    if (first) {
-                        float2 wa = lr_load<COH>(p.lr, h);
-                        for (uint32_t j = t; j < nl; ++j) {
-                            if (s.l_hash[j] == h) {
-                                const float grad = g * s.l_val[j];
-                                const float upd = opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, lut_lr);
-                                wa.x -= upd;
-                            }
-                        }
-                        lr_store<COH>(p.lr, h, wa);
-                    }
-                }
-            }
+            if (lr_upd) lr_update<OPT, COH>(p, s, nl, g, nullptr, lut_lr, tid, bd);
             FW_TICK(4);
             // phase A, resident rows: w comes from registers (read once, in the gather); only acc is loaded
 #pragma unroll
@@ -1714,7 +1703,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
                     idx[u] = (i < hi && !(s.e_fld[i] & (kRowDep | kRowChained))) ? i : 0xffffffffu;
                 }
                 if (WIN)
-                    update_rows_win<OPT, AUX, UO, 1>(p, s, idx, g, lane, nf);
+                    update_rows_win<OPT, AUX, UO, FW_WIN_NCH>(p, s, idx, g, lane, nf);
                 else
                     update_rows<VEC, OPT, AUX, UO>(p, s, idx, g, lane);
             }
@@ -1727,7 +1716,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
                         if (s.e_fld[i] & kRowDep) {
                             uint32_t idx[1] = {i};
                             if (WIN)
-                                update_rows_win<OPT, AUX, 1, 1>(p, s, idx, g, lane, nf);
+                                update_rows_win<OPT, AUX, 1, FW_WIN_NCH>(p, s, idx, g, lane, nf);
                             else
                                 update_rows<VEC, OPT, AUX, 1>(p, s, idx, g, lane);
                             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -1771,14 +1760,22 @@ static hipError_t launch_resident(const KernelParams &p, int optimizer, bool coh
     }
 }
 
+// Does this launch run on the register-resident kernel (v2)?  16 B-aligned single-chunk rows, no deep head.
+static bool uses_resident_kernel(const KernelParams &p, uint32_t threads) {
+    return p.k % 4 == 0 && p.aligned4 && p.R <= 64 * 4 && p.kernel_version != 1 && p.nn.n_layers == 0 && threads <= FW_LB_THREADS;
+}
+// Whole-line updates and duplicate-row chains exist in the v2 kernel's update path only, and only updating launches need them.
+void resolve_row_mode(KernelParams &p, uint32_t threads) {
+    p.window = (p.window && uses_resident_kernel(p, threads) && p.update && p.k_log2 != 0xffu) ? 1 : 0;
+    p.chain = p.window;
+}
+
 hipError_t launch_example_kernel(const KernelParams &p_in, int optimizer, bool coherent, uint32_t grid, uint32_t threads,
                                  hipStream_t stream) {
     if (p_in.n_examples == 0) return hipSuccess;
     KernelParams p = p_in;
-    const bool v2 = p.k % 4 == 0 && p.aligned4 && p.R <= 64 * 4 && p.kernel_version != 1 && p.nn.n_layers == 0 && threads <= FW_LB_THREADS;
-    // whole-line updates: only where the kernel that implements them runs, only for updating launches
-    p.window = (p.window && v2 && p.update && p.k_log2 != 0xffu) ? 1 : 0;
-    p.chain = p.window;
+    const bool v2 = uses_resident_kernel(p, threads);
+    resolve_row_mode(p, threads);  // (idempotent: run_batch has normally done it already, to size the LDS)
     const size_t lds = example_kernel_lds_bytes(p, optimizer);
     // 16-byte row vectors need k % 4 == 0: then R % 4 == 0 and hash & mask is a multiple of next_pow2(k) >= 4
     // floats (feature_buffer.rs:141-148), so every row starts 16-byte aligned.

@@ -343,6 +343,7 @@ static int run_batch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, h
     if ((uint64_t)p.max_ffm > 4ull * threads) threads = 1024;
     if ((uint64_t)p.max_ffm > 4ull * threads)
         return fail(FWGPU_ERR_RANGE, "an example has more than 4096 FFM features");
+    resolve_row_mode(p, threads);
     size_t lds = example_kernel_lds_bytes(p, r->cfg.optimizer);
     // When the LDS footprint lets only ONE workgroup live on a CU (k = 16 rows: T alone is 57.6 KB), the CU's waves have
     // to come from that workgroup: 1024 threads (measured at k = 16: 1.53 -> 1.82 M examples/s; with the deep head 0.67 -> 0.79).
@@ -357,6 +358,8 @@ static int run_batch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, h
             lds = lds_nolut;
         } else {
             threads = 1024;
+            resolve_row_mode(p, threads);
+            lds = example_kernel_lds_bytes(p, r->cfg.optimizer);
         }
     }
     if (lds > r->lds_per_cu)
