@@ -1390,6 +1390,9 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return v;
 }
 
+#ifndef FW_UG  // rows in flight per wave in the v2 gather
+#define FW_UG 4
+#endif
 #ifndef FW_UA
 #define FW_UA 2
 #endif
@@ -1397,7 +1400,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #define FW_WIN_NCH 1
 #endif
 #ifndef FW_UO
-#define FW_UO 2
+#define FW_UO 1
 #endif
 #ifndef FW_LB_THREADS
 #define FW_LB_THREADS 512
@@ -1551,10 +1554,10 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
             for (int sl = 0; sl < MAXR; ++sl)
                 if ((uint32_t)sl < cnt) FW_CONSUME(rows[sl], lo + sl)
             // overflow rows of this range: transient (they are re-read in the update phase)
-            for (uint32_t i = lo + MAXR; i < hi; i += 4) {
-                V r[4];
+            for (uint32_t i = lo + MAXR; i < hi; i += FW_UG) {
+                V r[FW_UG];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < FW_UG; ++u) {
                     r[u] = Vec<VEC>::zero();
                     if (i + u < hi) {
                         const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[i + u]);
@@ -1566,7 +1569,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < FW_UG; ++u)
                     if (i + u < hi) FW_CONSUME(r[u], i + u)
             }
             if (cur != 0xffffffffu) {
