@@ -119,6 +119,11 @@ def lib():
         "fwgpu_set_nn": [vp, P(NNConfig)],
         "fwgpu_learn": [vp, vp, u32, vp, u32, f32, f32, i32, P(f32)],
         "fwgpu_predict": [vp, vp, u32, vp, u32, P(f32)],
+        "fwgpu_setup_cache": [vp, vp, u32, vp, u32, P(vp)],
+        "fwgpu_predict_with_cache": [vp, vp, vp, u32, vp, u32, P(f32)],
+        "fwgpu_block_cache_filter": [vp, vp, u32, vp, P(u32)],
+        "fwgpu_block_cache_free": [vp],
+        "fwgpu_batch_set_cache": [vp, vp],
         "fwgpu_serialized_len": [vp, P(u64)],
         "fwgpu_write_weights": [vp, vp, u64, P(u64)],
         "fwgpu_read_weights": [vp, vp, u64],

@@ -97,6 +97,11 @@ struct KernelParams {
     uint32_t host_cus, host_wgs_cap, host_grid_cap;    // host side only: persistent grid = occupancy x CUs (capped), when launched with grid 0
     int32_t kernel_version;             // 0 = auto, 1 = force the v1 kernel, 2 = v2 where applicable
     unsigned long long *ticks;          // optional [8] per-phase shader-clock accumulators (debug), else NULL
+    // ---- serving context cache (regressor.rs:397-423, block_ffm.rs:442-782): the context features' field sums, in T's layout
+    const float *ctx_T;                 // [F*R] T[z][f][k] partial sums of the cached features (NULL: none); read-only launches only
+    const float *ctx_dcf;               // [F]   their self-pair corrections
+    float *emit_T;                      // setup_cache: example 0's T and dcf are written here after the gather
+    float *emit_dcf;
 };
 
 struct LaunchConfig {
@@ -125,8 +130,11 @@ hipError_t launch_coherence_probe(unsigned *scratch, int use_sc1, unsigned iters
 
 }  // namespace fwgpu
 
+struct fwgpu_block_cache;
 struct fwgpu_batch {
     fwgpu_regressor *owner = nullptr;
+    const fwgpu_block_cache *cache = nullptr;  // context cache the next predict-only launch of this batch starts from
+    float *emit_T = nullptr, *emit_dcf = nullptr;  // setup_cache launch: where example 0's field sums go
     uint32_t n = 0;
     uint64_t n_lr = 0, n_ffm = 0;
     uint32_t max_lr = 0, max_ffm = 0;
@@ -178,6 +186,14 @@ struct fwgpu_regressor {
     fwgpu_batch *one = nullptr;
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
+};
+
+// Vec<BlockCache> of the reference (regressor.rs:40-50): what setup_cache leaves behind for predict_with_cache
+struct fwgpu_block_cache {
+    fwgpu_regressor *owner = nullptr;
+    float *d_T = nullptr;    // [F*R] + [F] (dcf) in one allocation
+    float *d_dcf = nullptr;
+    std::vector<uint64_t> present;  // sorted (hash << 32 | contra_field_index) of the cached FFM features (features_present)
 };
 
 namespace fwgpu {

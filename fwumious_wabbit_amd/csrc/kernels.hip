@@ -555,13 +555,16 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
         const uint32_t per = R / (p.k % 4 == 0 ? 4 : 1), vecw = p.k % 4 == 0 ? 4 : 1;
         for (uint32_t idx = tid; idx < F * per; idx += bd) {
             const uint32_t f = idx / per, q = idx - f * per;
-            if (s.fstart[f] == s.fend[f]) {
+            if (s.fstart[f] == s.fend[f]) {  // (with a context cache: the cached features' sums stand alone)
                 const uint32_t ee = q * vecw, zz = ee / p.k;
-                for (uint32_t j = 0; j < vecw; ++j) s.T[zz * R + f * p.k + (ee - zz * p.k) + j] = 0.0f;
+                for (uint32_t j = 0; j < vecw; ++j) {
+                    const uint32_t ix = zz * R + f * p.k + (ee - zz * p.k) + j;
+                    s.T[ix] = p.ctx_T ? p.ctx_T[ix] : 0.0f;
+                }
             }
         }
         for (uint32_t f = tid; f < F; f += bd)
-            if (s.fstart[f] == s.fend[f]) s.dcf[f] = 0.0f;
+            if (s.fstart[f] == s.fend[f]) s.dcf[f] = p.ctx_dcf ? p.ctx_dcf[f] : 0.0f;
     }
     if (do_update && s.ctr[2]) {
         // Rare: some rows may overlap.  Exact scan: does an EARLIER feature's row [h_j, h_j+R) overlap mine?
@@ -1160,6 +1163,10 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                     const uint32_t z = inb ? e0 / k : 0;
                     const bool self = inb && (z == f);
                     V acc = Vec<VEC>::zero();
+                    if (p.ctx_T && inb) {  // context cache: the cached features of this field come first (block_ffm.rs:548-556)
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) Vec<VEC>::set(acc, j, p.ctx_T[z * R + f * k + (e0 - z * k) + j]);
+                    }
                     for (uint32_t i = fs; i < fe; i += UG) {
                         V r[UG];
                         float v[UG];
@@ -1193,11 +1200,16 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                     if (inb) Vec<VEC>::lds_store(s.T + z * R + f * k + (e0 - z * k), acc);
                 }
                 dc = wave_sum(dc);
+                if (p.ctx_dcf) dc += p.ctx_dcf[f];
                 s.dcf[f] = dc;  // same value from all 64 lanes
             }
         }
         __syncthreads();
         FW_TICK(2);
+        if (p.emit_T && ex == 0) {  // setup_cache: keep this example's field sums (Regressor::setup_cache, regressor.rs:409-423)
+            for (uint32_t i = tid; i < F * R; i += bd) p.emit_T[i] = s.T[i];
+            for (uint32_t f = tid; f < F; f += bd) p.emit_dcf[f] = s.dcf[f];
+        }
 
         // ---------------- all-pairs dot from LDS + LR forward
         float dot = 0.0f;
@@ -1533,9 +1545,12 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
             if (cur != 0xffffffffu) {                                                                         \
                 if (inb) Vec<VEC>::lds_store(s.T + z * R + cur * k + kk0, acc);                                \
                 dc = wave_sum(dc);                                                                            \
+                if (p.ctx_dcf) dc += p.ctx_dcf[cur];                                                          \
                 s.dcf[cur] = dc;                                                                              \
             }                                                                                                 \
             acc = Vec<VEC>::zero();                                                                           \
+            if (p.ctx_T && inb) /* context cache: the cached features of the field come first */              \
+                acc = *reinterpret_cast<const f4 *>(p.ctx_T + z * R + f_ * k + kk0);                           \
             dc = 0.0f;                                                                                        \
             cur = f_;                                                                                         \
         }                                                                                                     \
@@ -1575,12 +1590,17 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
             if (cur != 0xffffffffu) {
                 if (inb) Vec<VEC>::lds_store(s.T + z * R + cur * k + kk0, acc);
                 dc = wave_sum(dc);
+                if (p.ctx_dcf) dc += p.ctx_dcf[cur];
                 s.dcf[cur] = dc;
             }
 #undef FW_CONSUME
         }
         __syncthreads();
         FW_TICK(2);
+        if (p.emit_T && ex == 0) {  // setup_cache: keep this example's field sums (Regressor::setup_cache, regressor.rs:409-423)
+            for (uint32_t i = tid; i < F * R; i += bd) p.emit_T[i] = s.T[i];
+            for (uint32_t f = tid; f < F; f += bd) p.emit_dcf[f] = s.dcf[f];
+        }
 
         // ---------------- all-pairs dot from LDS + LR forward (identical to fw_example_kernel)
         float dot = 0.0f;

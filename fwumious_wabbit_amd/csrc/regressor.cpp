@@ -316,6 +316,14 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
     p.ffm_rate = r->cfg.ffm_learning_rate;
     p.ffm_minus_power_t = -r->cfg.ffm_power_t;
     p.ticks = r->d_ticks;
+    if (!update && b->cache) {  // predict_with_cache: the field sums start from the cached features' (regressor.rs:397-407)
+        p.ctx_T = b->cache->d_T;
+        p.ctx_dcf = b->cache->d_dcf;
+    }
+    if (!update) {
+        p.emit_T = b->emit_T;
+        p.emit_dcf = b->emit_dcf;
+    }
     p.records = b->records;
     p.rec_off = b->rec_off;
     p.max_rec = (b->max_rec + 3) & ~3u;
@@ -692,6 +700,117 @@ int fwgpu_record_batch_create(fwgpu_regressor *r, const fwgpu_translator_config 
         return rc;
     }
     *out = b;
+    return FWGPU_OK;
+}
+
+// ------------------------------------------------------------------ context cache (serving)
+// Regressor::setup_cache / predict_with_cache (regressor.rs:397-423) with BlockFFM's cache (block_ffm.rs:442-782): the field
+// sums ("contra fields") and self-pair corrections of the context's features are computed once, on the device, and every
+// candidate then gathers only the rows of the features that are NOT in `features_present`.  BlockLR's cache is inert in the
+// reference (prepare_forward_cache skips every feature: `hash & IS_NOT_SINGLE_MASK == 0` always holds for a masked hash,
+// block_lr.rs:236-239), so LR entries are always all read, exactly like there.
+
+static uint64_t cache_key(const fwgpu_ffm_entry &e) { return ((uint64_t)e.hash << 32) | e.contra_field_index; }  // regressor.rs:25-38
+
+int fwgpu_setup_cache(fwgpu_regressor *r, const fwgpu_lr_entry *lr, uint32_t n_lr, const fwgpu_ffm_entry *ffm,
+                      uint32_t n_ffm, fwgpu_block_cache **cache) {
+    if (!r || !cache) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    if ((n_lr && !lr) || (n_ffm && !ffm)) return fail(FWGPU_ERR_INVALID, "NULL entry buffer");
+    if (r->nn.n_layers) return fail(FWGPU_ERR_INVALID, "the context cache does not cover models with a deep head");
+    FWGPU_HIP(hipSetDevice(r->device));
+    const uint32_t F = r->cfg.ffm_k ? r->cfg.ffm_num_fields : 0, R = F * r->cfg.ffm_k;
+    fwgpu_block_cache *c = *cache;
+    if (c && c->owner != r) return fail(FWGPU_ERR_INVALID, "cache belongs to another regressor");
+    if (!c) {  // should_create (regressor.rs:415-417)
+        c = new fwgpu_block_cache();
+        c->owner = r;
+        if (hipMalloc((void **)&c->d_T, ((size_t)F * R + F + 4) * sizeof(float)) != hipSuccess) {
+            delete c;
+            return fail(FWGPU_ERR_DEVICE, "setup_cache: allocation failed");
+        }
+        c->d_dcf = c->d_T + (size_t)F * R;
+    }
+    HostBatch hb;
+    hb.clear();
+    float pred = 0.0f;
+    int rc = append_example(r, hb, lr, n_lr, ffm, n_ffm, 0.0f, 1.0f);
+    if (rc == FWGPU_OK) rc = ensure_one(r, (uint32_t)hb.lr_hash.size(), (uint32_t)hb.ffm_hash.size());
+    if (rc == FWGPU_OK) rc = batch_upload(r->one, hb, 0);
+    if (rc == FWGPU_OK) {
+        r->one->cache = nullptr;
+        r->one->emit_T = c->d_T;
+        r->one->emit_dcf = c->d_dcf;
+        rc = run_batch(r, r->one, FWGPU_MODE_SEQUENTIAL, 0, 0);
+        r->one->emit_T = r->one->emit_dcf = nullptr;
+    }
+    if (rc == FWGPU_OK && hipMemcpy(&pred, r->one->pred, sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(FWGPU_ERR_DEVICE, "setup_cache: launch failed");
+    if (rc != FWGPU_OK) {
+        if (!*cache) {
+            (void)hipFree(c->d_T);
+            delete c;
+        }
+        return rc;
+    }
+    c->present.clear();
+    for (uint32_t i = 0; i < (r->cfg.ffm_k ? n_ffm : 0); i++) c->present.push_back(cache_key(ffm[i]));
+    std::sort(c->present.begin(), c->present.end());
+    c->present.erase(std::unique(c->present.begin(), c->present.end()), c->present.end());
+    *cache = c;
+    return FWGPU_OK;
+}
+
+int fwgpu_block_cache_free(fwgpu_block_cache *c) {
+    if (!c) return FWGPU_OK;
+    if (c->d_T) (void)hipFree(c->d_T);
+    delete c;
+    return FWGPU_OK;
+}
+
+// The FFM entries forward_with_cache still gathers: those whose (hash, contra_field_index) is not in features_present
+// (block_ffm.rs:548, 600).  out may alias ffm.
+int fwgpu_block_cache_filter(const fwgpu_block_cache *c, const fwgpu_ffm_entry *ffm, uint32_t n_ffm, fwgpu_ffm_entry *out, uint32_t *n_out) {
+    if (!c || !n_out || (n_ffm && (!ffm || !out))) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < n_ffm; i++)
+        if (!std::binary_search(c->present.begin(), c->present.end(), cache_key(ffm[i]))) out[m++] = ffm[i];
+    *n_out = m;
+    return FWGPU_OK;
+}
+
+int fwgpu_predict_with_cache(fwgpu_regressor *r, const fwgpu_block_cache *c, const fwgpu_lr_entry *lr, uint32_t n_lr,
+                             const fwgpu_ffm_entry *ffm, uint32_t n_ffm, float *prediction) {
+    if (!r || !c || !prediction) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    if (c->owner != r) return fail(FWGPU_ERR_INVALID, "cache belongs to another regressor");
+    if ((n_lr && !lr) || (n_ffm && !ffm)) return fail(FWGPU_ERR_INVALID, "NULL entry buffer");
+    FWGPU_HIP(hipSetDevice(r->device));
+    std::vector<fwgpu_ffm_entry> rest(n_ffm);
+    uint32_t m = 0;
+    int rc = fwgpu_block_cache_filter(c, ffm, n_ffm, rest.data(), &m);
+    if (rc) return rc;
+    HostBatch hb;
+    hb.clear();
+    rc = append_example(r, hb, lr, n_lr, rest.data(), m, 0.0f, 1.0f);
+    if (rc) return rc;
+    rc = ensure_one(r, (uint32_t)hb.lr_hash.size(), (uint32_t)hb.ffm_hash.size());
+    if (rc) return rc;
+    rc = batch_upload(r->one, hb, 0);
+    if (rc) return rc;
+    r->one->cache = c;
+    rc = run_batch(r, r->one, FWGPU_MODE_SEQUENTIAL, 0, 0);
+    r->one->cache = nullptr;
+    if (rc) return rc;
+    FWGPU_HIP(hipMemcpy(prediction, r->one->pred, sizeof(float), hipMemcpyDeviceToHost));
+    return FWGPU_OK;
+}
+
+// Predict-only launches of this batch start every example's field sums from the cache (NULL detaches it): the batch must
+// then hold only the entries fwgpu_block_cache_filter leaves.
+int fwgpu_batch_set_cache(fwgpu_batch *b, const fwgpu_block_cache *c) {
+    if (!b) return fail(FWGPU_ERR_INVALID, "NULL batch");
+    if (c && c->owner != b->owner) return fail(FWGPU_ERR_INVALID, "cache belongs to another regressor");
+    if (c && b->records) return fail(FWGPU_ERR_INVALID, "a context cache needs an entry batch (records are translated whole on the device)");
+    b->cache = c;
     return FWGPU_OK;
 }
 

@@ -2,12 +2,11 @@
 // fw_predict, fw_predict_with_cache, fw_setup_cache, free_predictor -- a binary that links libfw.so can link this library
 // instead.  Each call parses the VW text, translates the record and runs the example kernel on the device.
 //
-// Context cache (lib.rs:88-148, block_ffm.rs:442-782, block_lr.rs:165-255): the reference pre-computes the context
-// features' partial sums once per request and finishes them per candidate.  One GPU launch per candidate gains
-// nothing from that; what fits the device is scoring ALL candidates of a request in one launch.  So fw_setup_cache keeps the
-// context text, fw_predict_with_cache scores context + candidate (the very line the reference reassembles in
-// next_vowpal_with_cache, parser.rs:195-211; identical result, the cache being an optimisation), and
-// fwgpu_predictor_predict_batch scores n candidates with one batched launch.
+// Context cache (lib.rs:88-148, block_ffm.rs:442-782, block_lr.rs:165-255): fw_setup_cache translates the context line and
+// has the device compute its features' field sums once (fwgpu_setup_cache); fw_predict_with_cache parses context + candidate
+// (the very line the reference reassembles in next_vowpal_with_cache, parser.rs:195-211), translates it on the host and ships
+// only the entries that are not in the cache; fwgpu_predictor_predict_batch does that for all candidates of a request in one
+// launch.  Models with a deep head keep the uncached route (whole line scored), which gives the same result.
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -75,9 +74,13 @@ struct FfiPredictor {
     fwgpu_parser *parser = nullptr;
     std::string cached_text;  // PredictorCache.input_buffer_size bytes of the context line (lib.rs:64-67)
     bool has_cache = false;
+    fwgpu_block_cache *cache = nullptr;  // PredictorCache.blocks: the context's field sums, on the device
     std::vector<uint32_t> record;
+    std::vector<fwgpu_lr_entry> lr;
+    std::vector<fwgpu_ffm_entry> ffm;
     ~FfiPredictor() {
         if (parser) fwgpu_parser_free(parser);
+        if (cache) fwgpu_block_cache_free(cache);
     }
 };
 
@@ -104,6 +107,13 @@ float predict_line(FfiPredictor *p, const char *prefix, size_t prefix_len, const
     p->record[1] = 0;  // no label in a request (NO_LABEL = 0xff); the prediction does not depend on it
     SharedModel &m = *p->model;
     std::lock_guard<std::mutex> g(m.mu);
+    if (prefix && p->cache) {  // predict_with_cache (lib.rs:88-108): translate, then only the uncached features are gathered
+        float label, imp, out = 0.0f;
+        if (translate_record(&m.tr, p->record.data(), n_words, p->lr, p->ffm, &label, &imp) != FWGPU_OK) return kExceptionErrorCode;
+        if (fwgpu_predict_with_cache(m.re, p->cache, p->lr.data(), (uint32_t)p->lr.size(), p->ffm.data(), (uint32_t)p->ffm.size(), &out) != FWGPU_OK)
+            return kExceptionErrorCode;
+        return out;
+    }
     if (!m.batch || m.batch->words_cap < n_words) {
         if (m.batch) fwgpu_batch_free(m.batch);
         m.batch = nullptr;
@@ -169,9 +179,22 @@ float fw_setup_cache(FfiPredictor *ptr, const char *input_buffer) {  // lib.rs:2
     const int rc = fwgpu_parser_parse_line(ptr->parser, input_buffer, len, nullptr, 0, &n_words);
     if (rc != FWGPU_OK) return kExceptionErrorCode;
     if (n_words == 0) return kEofErrorCode;
+    ptr->record.resize(std::max<size_t>(ptr->record.size(), (size_t)n_words));
+    if (fwgpu_parser_parse_line(ptr->parser, input_buffer, len, ptr->record.data(), (uint32_t)ptr->record.size(), &n_words) != FWGPU_OK)
+        return kExceptionErrorCode;
     if (len && input_buffer[len - 1] == '\n') len -= 1;  // "ignore last newline byte" (parser.rs:184-193)
     ptr->cached_text.assign(input_buffer, len);
     ptr->has_cache = true;
+    SharedModel &m = *ptr->model;
+    if (m.re->nn.n_layers == 0 && m.re->cfg.ffm_k != 0) {
+        // translate_and_filter(buffer, 0, Some(Primitive)) + Regressor::setup_cache (lib.rs:133-146); every namespace this
+        // library accepts is primitive (transformed namespaces are refused when the model is loaded)
+        float label, imp;
+        std::lock_guard<std::mutex> g(m.mu);
+        if (translate_record(&m.tr, ptr->record.data(), n_words, ptr->lr, ptr->ffm, &label, &imp) != FWGPU_OK) return kExceptionErrorCode;
+        if (fwgpu_setup_cache(m.re, ptr->lr.data(), (uint32_t)ptr->lr.size(), ptr->ffm.data(), (uint32_t)ptr->ffm.size(), &ptr->cache) != FWGPU_OK)
+            return kExceptionErrorCode;
+    }
     return 0.0f;
 }
 
@@ -189,10 +212,15 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
     SharedModel &m = *ptr->model;
     // parse on a few host threads (each with its own parser: VowpalParser is not thread safe, clone_lite's reason)
     const unsigned T = n >= 256 ? std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    const bool cached = with_cache && ptr->cache;  // candidates reduced to the entries the context cache does not cover
     struct Part {
         std::vector<uint32_t> words;
         std::vector<uint64_t> len;
         std::vector<uint32_t> slot;
+        // cached route: translated on the host, filtered (forward_with_cache gathers only what features_present lacks)
+        std::vector<fwgpu_lr_entry> lr;
+        std::vector<fwgpu_ffm_entry> ffm;
+        std::vector<uint32_t> n_lr, n_ffm;
     };
     std::vector<Part> parts(T);
     for (uint32_t i = 0; i < n; i++) out[i] = kExceptionErrorCode;  // a worker that cannot start leaves its slice marked
@@ -205,6 +233,8 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
         }
         Part &pt = parts[k];
         std::vector<uint32_t> rec(4096);
+        std::vector<fwgpu_lr_entry> t_lr;
+        std::vector<fwgpu_ffm_entry> t_ffm;
         const uint32_t a = (uint32_t)((uint64_t)n * k / T), e = (uint32_t)((uint64_t)n * (k + 1) / T);
         for (uint32_t i = a; i < e; i++) {
             out[i] = kExceptionErrorCode;
@@ -226,6 +256,18 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
                 continue;
             }
             rec[1] = 0;  // a request carries no label (NO_LABEL = 0xff); the prediction does not depend on it
+            if (cached) {
+                float label, imp;
+                if (translate_record(&m.tr, rec.data(), nw, t_lr, t_ffm, &label, &imp) != FWGPU_OK) continue;
+                uint32_t kept = 0;
+                if (fwgpu_block_cache_filter(ptr->cache, t_ffm.data(), (uint32_t)t_ffm.size(), t_ffm.data(), &kept) != FWGPU_OK) continue;
+                pt.lr.insert(pt.lr.end(), t_lr.begin(), t_lr.end());
+                pt.ffm.insert(pt.ffm.end(), t_ffm.begin(), t_ffm.begin() + kept);
+                pt.n_lr.push_back((uint32_t)t_lr.size());
+                pt.n_ffm.push_back(kept);
+                pt.slot.push_back(i);
+                continue;
+            }
             pt.words.insert(pt.words.end(), rec.begin(), rec.begin() + nw);
             pt.len.push_back(nw);
             pt.slot.push_back(i);
@@ -249,6 +291,31 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
     if (slot.empty()) return FWGPU_OK;
     std::lock_guard<std::mutex> g(m.mu);
     const uint32_t nrec = (uint32_t)slot.size();
+    if (cached) {  // one entry batch, every example starting from the cached field sums
+        HostBatch hb;
+        hb.clear();
+        for (const Part &pt : parts) {
+            size_t ol = 0, of = 0;
+            for (size_t j = 0; j < pt.n_lr.size(); j++) {
+                int rc0 = append_example(m.re, hb, pt.lr.data() + ol, pt.n_lr[j], pt.ffm.data() + of, pt.n_ffm[j], 0.0f, 1.0f);
+                if (rc0 != FWGPU_OK) return rc0;
+                ol += pt.n_lr[j];
+                of += pt.n_ffm[j];
+            }
+        }
+        fwgpu_batch *eb = nullptr;
+        int rc0 = batch_alloc(m.re, nrec, hb.lr_hash.size(), hb.ffm_hash.size(), &eb);
+        if (rc0 != FWGPU_OK) return rc0;
+        rc0 = batch_upload(eb, hb, 0);
+        if (rc0 == FWGPU_OK) rc0 = fwgpu_batch_set_cache(eb, ptr->cache);
+        if (rc0 == FWGPU_OK) rc0 = fwgpu_learn_batch(m.re, eb, FWGPU_MODE_HOGWILD, /*update=*/0, nullptr);
+        std::vector<float> preds(nrec);
+        if (rc0 == FWGPU_OK) rc0 = fwgpu_batch_predictions(eb, preds.data(), nrec, nullptr);
+        fwgpu_batch_free(eb);
+        if (rc0 != FWGPU_OK) return rc0;
+        for (size_t j = 0; j < slot.size(); j++) out[slot[j]] = preds[j];
+        return FWGPU_OK;
+    }
     if (!m.batch || m.batch->n_cap < nrec || m.batch->words_cap < words.size()) {
         if (m.batch) fwgpu_batch_free(m.batch);
         m.batch = nullptr;

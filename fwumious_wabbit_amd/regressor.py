@@ -165,6 +165,10 @@ class Batch:
         check(capi.lib().fwgpu_batch_size(self.h, C.byref(n), C.byref(n_lr), C.byref(n_ffm)))
         self.n, self.n_lr, self.n_ffm = n.value, n_lr.value, n_ffm.value
 
+    def set_cache(self, cache):
+        """predict-only launches of this entry batch start every example from the context cache (None detaches it)"""
+        check(capi.lib().fwgpu_batch_set_cache(self.h, cache.h if cache is not None else None))
+
     def predictions(self, stream=None):
         out = np.zeros(self.n, dtype=np.float32)
         check(capi.lib().fwgpu_batch_predictions(self.h, ptr(out), self.n, stream))
@@ -174,6 +178,33 @@ class Batch:
         if self.h:
             capi.lib().fwgpu_batch_free(self.h)
             self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BlockCache:
+    """Vec<BlockCache> (regressor.rs:40-50): what setup_cache leaves on the device for predict_with_cache"""
+
+    def __init__(self, regressor):
+        self.h = C.c_void_p()
+        self.regressor = regressor
+
+    def filter(self, ffm_entries) -> np.ndarray:
+        """the FFM entries forward_with_cache still gathers (block_ffm.rs:548, 600)"""
+        ffm = np.ascontiguousarray(ffm_entries, dtype=FFM_ENTRY)
+        out = np.zeros(len(ffm), dtype=FFM_ENTRY)
+        n = C.c_uint32(0)
+        check(capi.lib().fwgpu_block_cache_filter(self.h, ptr(ffm), len(ffm), ptr(out), C.byref(n)))
+        return out[: n.value]
+
+    def close(self):
+        if self.h:
+            capi.lib().fwgpu_block_cache_free(self.h)
+            self.h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -255,6 +286,24 @@ class Regressor:
         ffm = np.ascontiguousarray(fb.ffm_buffer, dtype=FFM_ENTRY)
         out = C.c_float(0)
         check(self.L.fwgpu_predict(self.h, ptr(lr), len(lr), ptr(ffm), len(ffm), C.byref(out)))
+        return out.value
+
+    # ---- serving context cache (regressor.rs:397-423)
+    def setup_cache(self, fb: FeatureBuffer, cache=None):
+        """Regressor::setup_cache: the context features' field sums are computed once on the device; returns the cache
+        (pass an existing one to refill it, as the reference does with should_create == false)"""
+        lr = np.ascontiguousarray(fb.lr_buffer, dtype=LR_ENTRY)
+        ffm = np.ascontiguousarray(fb.ffm_buffer, dtype=FFM_ENTRY)
+        cache = cache if cache is not None else BlockCache(self)
+        check(self.L.fwgpu_setup_cache(self.h, ptr(lr), len(lr), ptr(ffm), len(ffm), C.byref(cache.h)))
+        return cache
+
+    def predict_with_cache(self, fb: FeatureBuffer, pb, cache) -> float:
+        """Regressor::predict_with_cache: fb is the FeatureBuffer of context + candidate"""
+        lr = np.ascontiguousarray(fb.lr_buffer, dtype=LR_ENTRY)
+        ffm = np.ascontiguousarray(fb.ffm_buffer, dtype=FFM_ENTRY)
+        out = C.c_float(0)
+        check(self.L.fwgpu_predict_with_cache(self.h, cache.h, ptr(lr), len(lr), ptr(ffm), len(ffm), C.byref(out)))
         return out.value
 
     # ---- micro-batches

@@ -115,6 +115,27 @@ int fwgpu_learn(fwgpu_regressor *r, const fwgpu_lr_entry *lr, uint32_t n_lr, con
 int fwgpu_predict(fwgpu_regressor *r, const fwgpu_lr_entry *lr, uint32_t n_lr, const fwgpu_ffm_entry *ffm,
                   uint32_t n_ffm, float *prediction);
 
+/* ---------------------------------------------------------------- serving context cache
+ * fwgpu_setup_cache        <= Regressor::setup_cache(&FeatureBuffer, &mut Vec<BlockCache>, should_create)  regressor.rs:409-423
+ *                             (*cache == NULL creates it; otherwise the existing cache is refilled)
+ * fwgpu_predict_with_cache <= Regressor::predict_with_cache(&FeatureBuffer, &mut PortBuffer, &[BlockCache]) -> f32
+ *                             regressor.rs:397-407.  fb is the FeatureBuffer of context + candidate, as the reference's
+ *                             caller passes it (lib.rs:88-108).
+ * The cache is BlockFFM's (block_ffm.rs:442-782): the context features' field sums and self-pair corrections, computed once
+ * on the device, plus `features_present` (regressor.rs:25-38: hash + contra_field_index).  A candidate then gathers only the
+ * FFM rows of the features that are not present in the cache.  BlockLR's cache never holds anything in the reference
+ * (block_lr.rs:236-239 skips every masked hash), so LR entries are all read, as there.  Models with a deep head: refused.
+ * fwgpu_block_cache_filter: the FFM entries forward_with_cache still gathers (what an entry batch used with
+ * fwgpu_batch_set_cache: must hold); predict-only launches of that batch then start every example from the cache. */
+typedef struct fwgpu_block_cache fwgpu_block_cache;
+int fwgpu_setup_cache(fwgpu_regressor *r, const fwgpu_lr_entry *lr, uint32_t n_lr, const fwgpu_ffm_entry *ffm,
+                      uint32_t n_ffm, fwgpu_block_cache **cache);
+int fwgpu_predict_with_cache(fwgpu_regressor *r, const fwgpu_block_cache *cache, const fwgpu_lr_entry *lr, uint32_t n_lr,
+                             const fwgpu_ffm_entry *ffm, uint32_t n_ffm, float *prediction);
+int fwgpu_block_cache_filter(const fwgpu_block_cache *cache, const fwgpu_ffm_entry *ffm, uint32_t n_ffm, fwgpu_ffm_entry *out,
+                       uint32_t *n_out);
+int fwgpu_block_cache_free(fwgpu_block_cache *cache);
+
 /* ---------------------------------------------------------------- deep head (BASELINE config E)
  * fwgpu_set_nn <= the `--nn_layers / --nn N:width:W / --nn N:activation:relu / --nn N:init:hu / --nn_topology` part of
  * Regressor::new_without_weights (regressor.rs:191-320): BlockCopy -> [BlockNeuronLayer -> BlockRELU]* -> Join ->
@@ -170,6 +191,8 @@ int fwgpu_batch_create(fwgpu_regressor *r, const fwgpu_lr_entry *lr, const uint3
                        const float *importance, uint32_t n_examples, fwgpu_batch **out);
 int fwgpu_batch_free(fwgpu_batch *b);
 int fwgpu_batch_size(const fwgpu_batch *b, uint32_t *n_examples, uint64_t *n_lr, uint64_t *n_ffm);
+/* predict-only launches of an ENTRY batch start every example's field sums from this context cache (NULL detaches it) */
+int fwgpu_batch_set_cache(fwgpu_batch *b, const fwgpu_block_cache *cache);
 /* Enqueue one pass over the batch on `stream`: for every example, Regressor::learn(fb, update)
  * (update=0: Regressor::predict).  Predictions land in the batch's device buffer. Asynchronous. */
 int fwgpu_learn_batch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, void *stream);

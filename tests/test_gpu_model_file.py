@@ -237,8 +237,11 @@ def test_serving_ffi_matches_the_regressor(tmp_path):
     assert pr.setup_cache(ctx + "\n") == 0.0
     with_cache = np.array([pr.predict_with_cache(c) for c in cands], dtype=np.float32)
     whole = np.array([pr.predict(ctx + c) for c in cands], dtype=np.float32)
-    assert np.array_equal(with_cache, whole)
-    assert np.array_equal(pr.predict_batch(cands, with_cache=True), whole)
+    # the context's field sums now come from the device-side cache: same numbers up to the order of the f32 sums
+    # (the reference's own *_with_cache tests use assert_epsilon!, 5e-6: block_helpers.rs:30-40)
+    assert np.abs(with_cache - whole).max() < 2e-6
+    assert np.abs(pr.predict_batch(cands, with_cache=True) - whole).max() < 2e-6
+    assert np.array_equal(pr.predict_batch(cands, with_cache=True), with_cache)  # batched == single, same route
     # a clone shares the weights, has its own (empty) cache
     cl = pr.clone_lite()
     assert cl.predict(lines[0]) == want[0] and cl.predict_with_cache(cands[0]) == pr.predict(cands[0])

@@ -414,6 +414,101 @@ def test_device_translation_of_crafted_records_matches_host_translation():
     re.close()
 
 
+
+# ------------------------------------------------------------------ serving context cache
+CACHE_TOL = 5e-6  # assert_epsilon! of the reference's *_with_cache tests (block_helpers.rs:30-40)
+
+
+@pytest.mark.parametrize("sc", [s for s in KATS["scenarios"] if any(st["ffm"] for st in s["steps"])],
+                         ids=[s["name"] for s in KATS["scenarios"] if any(st["ffm"] for st in s["steps"])])
+def test_reference_with_cache_twins(sc):
+    """Every reference FFM test has a *_with_cache twin (block_ffm.rs:1325-2037) asserting that setup_cache on PART of the
+    example followed by predict_with_cache on the whole example gives the SAME numbers as the plain prediction.  Here: before
+    every step of every FFM KAT scenario, a cache is set up from each single feature and from the first half of the features,
+    and predict_with_cache must reproduce the step's expected prediction."""
+    mi = mi_from_cfg(sc["config"], sc["wiring"])
+    re = fw.Regressor(mi)
+    if "ffm_fill" in sc:
+        re.ffm_fill(sc["ffm_fill"])
+    cache = None
+    for i, st in enumerate(sc["steps"]):
+        fb = fw.lr_and_ffm_vec(st["lr"], st["ffm"], st["label"], st["importance"])
+        want = st.get("current_code", st["expect"]) if st.get("stale") else st["expect"]
+        ffm = list(st["ffm"])
+        subsets = [[f] for f in ffm] + ([ffm[: len(ffm) // 2]] if len(ffm) > 1 else []) + [[]]
+        for sub in subsets:
+            cache = re.setup_cache(fw.lr_and_ffm_vec(st["lr"], sub, st["label"], st["importance"]), cache)
+            got = re.predict_with_cache(fb, None, cache)
+            assert abs(got - want) < CACHE_TOL, f"{sc['name']} step {i} cache {sub}: got {got!r} want {want!r}"
+        if st["op"] == "predict" or not st["update"]:
+            re.predict(fb)
+        else:
+            re.learn(fb, None, True)
+    if cache is not None:
+        cache.close()
+    re.close()
+
+
+@pytest.mark.parametrize("k,n_ns", [(8, 30), (4, 10), (10, 3), (16, 30)])
+def test_context_cache_random_contexts(k, n_ns):
+    """predict_with_cache(context + candidate) == predict(context + candidate) on a trained model, for contexts made of
+    whole namespaces, of single features, with duplicates, with fields that only the context / only the candidate fills;
+    the cached route through an entry batch (all candidates of a request in one launch) gives the single calls' numbers."""
+    mi, ocfg, ots = make_pair(n_ns, k, 16, 16, fw.Optimizer.AdagradLUT, lr=0.05, ffm_lr=0.05)
+    recs, off = fw.synth_records(n_ns, 2.0, 1.1, 3000, 0.3, 71, 0, 400)
+    re = fw.Regressor(mi)
+    fbt = fw.FeatureBufferTranslator(mi)
+    b = re.record_batch(fbt, recs[: int(off[300])], off[:301])
+    re.learn_batch(b, capi.MODE_SEQUENTIAL, True)
+    b.close()
+    rng = np.random.default_rng(k)
+    worst = 0.0
+    for i in range(300, 360):
+        fb = fbt.translate(recs[int(off[i]):int(off[i + 1])])
+        ffm = np.asarray(fb.ffm_buffer)
+        plain = re.predict(fb)
+        fields = np.unique(ffm["contra_field_index"])
+        ctx_fields = rng.choice(fields, size=max(1, len(fields) // 2), replace=False) if len(fields) else fields
+        # (a context holds ALL occurrences of its features: features_present is keyed by hash + field, regressor.rs:25-38)
+        third = set(zip(ffm["hash"][::3].tolist(), ffm["contra_field_index"][::3].tolist()))
+        in_third = np.array([(h, f) in third for h, f in zip(ffm["hash"].tolist(), ffm["contra_field_index"].tolist())], dtype=bool)
+        for ctx in (ffm[np.isin(ffm["contra_field_index"], ctx_fields)], ffm[in_third], ffm[:0], ffm):
+            cfb = fw.FeatureBuffer(label=0.0, example_importance=1.0, example_number=0, lr_buffer=fb.lr_buffer, ffm_buffer=ctx)
+            cache = re.setup_cache(cfb)
+            got = re.predict_with_cache(fb, None, cache)
+            worst = max(worst, abs(got - plain))
+            # the entries the cache does not cover: nothing of the context, everything else, order kept
+            rest = cache.filter(ffm)
+            keys = set(zip(ctx["hash"].tolist(), ctx["contra_field_index"].tolist()))
+            keep = np.array([(h, f) not in keys for h, f in zip(ffm["hash"].tolist(), ffm["contra_field_index"].tolist())], dtype=bool)
+            assert np.array_equal(rest, ffm[keep])
+            cache.close()
+    assert worst < CACHE_TOL, worst
+    # one request: a context + 50 candidates through ONE launch of an entry batch that holds only the uncovered entries
+    fb0 = fbt.translate(recs[int(off[360]):int(off[361])])
+    ctx = np.asarray(fb0.ffm_buffer)
+    ctx = ctx[ctx["contra_field_index"] < (n_ns // 2) * k]
+    cache = re.setup_cache(fw.FeatureBuffer(label=0.0, example_importance=1.0, example_number=0, lr_buffer=fb0.lr_buffer, ffm_buffer=ctx))
+    fulls, cut = [], []
+    for i in range(361, 400):
+        fbi = fbt.translate(recs[int(off[i]):int(off[i + 1])])
+        cand = np.asarray(fbi.ffm_buffer)
+        cand = cand[cand["contra_field_index"] >= (n_ns // 2) * k]
+        whole = np.concatenate([ctx, cand])
+        fulls.append(fw.FeatureBuffer(label=0.0, example_importance=1.0, example_number=0, lr_buffer=fbi.lr_buffer, ffm_buffer=whole))
+        cut.append(fw.FeatureBuffer(label=0.0, example_importance=1.0, example_number=0, lr_buffer=fbi.lr_buffer, ffm_buffer=cache.filter(whole)))
+    want = np.array([re.predict(f) for f in fulls], dtype=np.float32)
+    single = np.array([re.predict_with_cache(f, None, cache) for f in fulls], dtype=np.float32)
+    eb = re.batch(cut)
+    eb.set_cache(cache)
+    re.learn_batch(eb, capi.MODE_HOGWILD, False)
+    batched = eb.predictions()
+    assert np.abs(single - want).max() < CACHE_TOL and np.abs(batched - want).max() < CACHE_TOL
+    eb.set_cache(None)
+    eb.close()
+    cache.close()
+    re.close()
+
 # ------------------------------------------------------------------ hogwild mode and the record-stream trainer
 def _holdout_loss_oracle(ocfg, ots, recs, off, n_train):
     om = fwo.Model(ocfg)
