@@ -124,6 +124,9 @@ def lib():
         "fwgpu_block_cache_filter": [vp, vp, u32, vp, P(u32)],
         "fwgpu_block_cache_free": [vp],
         "fwgpu_batch_set_cache": [vp, vp],
+        "fwgpu_split_create": [vp, u32, u32, P(vp)],
+        "fwgpu_split_free": [vp],
+        "fwgpu_learn_batch_sync": [vp, vp, vp, i32, vp],
         "fwgpu_serialized_len": [vp, P(u64)],
         "fwgpu_write_weights": [vp, vp, u64, P(u64)],
         "fwgpu_read_weights": [vp, vp, u64],

@@ -102,6 +102,16 @@ struct KernelParams {
     const float *ctx_dcf;               // [F]   their self-pair corrections
     float *emit_T;                      // setup_cache: example 0's T and dcf are written here after the gather
     float *emit_dcf;
+    // ---- synchronous micro-batch ("split") pipeline: FWD -> [exchange] -> MID -> [head / exchange] -> UPD  (kernels.hip)
+    float *split;                       // [n * split_len] per example: T[F*R], dcf[F], LR sums[split_nlr], field counts[F], label, importance
+    uint32_t split_len, split_nlr;      // floats per example; LR sums kept: 1 (total) or num_combos (deep head)
+    float *split_selfw;                 // [n * selfw_stride] the gather's copy of every entry's own slot (stays on the rank)
+    uint32_t selfw_stride;
+    float *gbuf;                        // [n] general gradient of every example (MID -> UPD)
+    float *xbuf, *dxbuf;                // deep head, mini-batched: x and d logit/d x per example [n * nn.X]
+    uint32_t own_lo_ffm, own_hi_ffm;    // this rank owns the FFM rows with own_lo <= hash < own_hi (sharded tables)...
+    uint32_t own_lo_lr, own_hi_lr;      // ... and these LR entries
+    uint32_t home_lo, home_hi;          // examples of the launch whose label / counts this rank contributes (its own shard of the batch)
 };
 
 struct LaunchConfig {
@@ -119,6 +129,11 @@ void resolve_row_mode(KernelParams &p, uint32_t threads);  // settles KernelPara
 // Enqueue the example kernel.  grid==1 gives the sequential (in-order) semantics.
 hipError_t launch_example_kernel(const KernelParams &p, int optimizer, bool coherent, uint32_t grid,
                                  uint32_t threads, hipStream_t stream);
+// split pipeline: phase 1 = FWD (gather the owned rows, write the split records), 3 = UPD (updates of the owned rows from the
+// records and the gradients); the MID step (records -> logit -> prediction, general gradient / deep-head input) is its own kernel
+hipError_t launch_example_phase(const KernelParams &p, int optimizer, int phase, uint32_t grid, uint32_t threads, hipStream_t stream);
+hipError_t launch_split_mid(const KernelParams &p, uint32_t n_examples, hipStream_t stream);
+uint32_t split_record_len(uint32_t F, uint32_t R, uint32_t nlr);
 hipError_t launch_ffm_init(float *w, float *acc, uint64_t len, uint32_t k, float init_width, float init_zero_band,
                            float init_center, float acc0, hipStream_t stream);
 hipError_t launch_fill(float *p, uint64_t n, float v, hipStream_t stream);
@@ -188,6 +203,13 @@ struct fwgpu_regressor {
     size_t pinned_bytes = 0;
 };
 
+// device buffers of one synchronous micro-batch (regressor.cpp "split pipeline")
+struct fwgpu_split {
+    fwgpu_regressor *owner = nullptr;
+    uint32_t n_cap = 0, split_len = 0, nlr = 1, selfw_stride = 0;
+    float *d_split = nullptr, *d_selfw = nullptr, *d_g = nullptr, *d_x = nullptr, *d_dx = nullptr;
+};
+
 // Vec<BlockCache> of the reference (regressor.rs:40-50): what setup_cache leaves behind for predict_with_cache
 struct fwgpu_block_cache {
     fwgpu_regressor *owner = nullptr;
@@ -241,5 +263,13 @@ uint32_t lr_hash_mask(uint32_t bit_precision);
 uint32_t ffm_hash_mask(uint32_t ffm_bits, uint32_t ffm_k);
 void lut_init(float *lut, float learning_rate, float power_t, float init_acc);
 KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int update);
+struct SplitRanges {  // what a rank owns (sharded tables) and which examples of the launch are its own
+    uint32_t ffm_lo = 0, ffm_hi = 0xffffffffu, lr_lo = 0, lr_hi = 0xffffffffu, home_lo = 0, home_hi = 0xffffffffu;
+};
+int split_forward(fwgpu_regressor *r, fwgpu_batch *b, fwgpu_split *sp, int mode, const SplitRanges &rg, hipStream_t stream);
+int split_mid(fwgpu_regressor *r, fwgpu_split *sp, uint32_t first, uint32_t n, float *d_pred, bool head, hipStream_t stream);
+int split_update(fwgpu_regressor *r, fwgpu_batch *b, fwgpu_split *sp, int mode, const SplitRanges &rg, bool head, hipStream_t stream);
+// mini-batched deep head on the records' x (head.hip): forward, sigmoid, backward, one AdaGrad step per dense weight
+int head_step(fwgpu_regressor *r, fwgpu_split *sp, uint32_t first, uint32_t n, float *d_pred, bool update, hipStream_t stream);
 uint32_t pick_grid(const fwgpu_regressor *r, const KernelParams &p, int mode, uint32_t threads);
 }  // namespace fwgpu

@@ -846,11 +846,12 @@ __device__ __forceinline__ void nn_backward(const KernelParams &p, const Lds &s,
 // the hogwild read-modify-write window of hot entries (constant feature) by two phases.
 template <int OPT, bool COH>
 __device__ __forceinline__ void lr_update(const KernelParams &p, const Lds &s, uint32_t nl, float g, const float *gx,
-                                          const float *lut_lr, int tid, int bd) {
+                                          const float *lut_lr, int tid, int bd, uint32_t lo = 0, uint32_t hi = 0xffffffffu) {
     for (uint32_t t = tid; t < nl; t += bd) {
         const uint32_t fl = s.l_flag[t];
         if (fl & kRowChained) continue;
         const uint32_t h = s.l_hash[t];
+        if (h < lo || h >= hi) continue;  // sharded tables: another rank's entry
         float2 wa = lr_load<COH>(p.lr, h);
         {
             const float grad = (gx ? gx[s.l_combo[t]] : g) * s.l_val[t];
@@ -1058,7 +1059,16 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
 #endif
 }
 
-template <int VEC, int OPT, bool COH>
+// split record of one example (floats): T[F*R] | dcf[F] | LR sums[nlr] | feature count per field[F] | label | importance | pad
+__host__ __device__ inline uint32_t split_len_of(uint32_t F, uint32_t R, uint32_t nlr) { return (F * R + F + nlr + F + 2 + 3) & ~3u; }
+uint32_t split_record_len(uint32_t F, uint32_t R, uint32_t nlr) { return split_len_of(F, R, nlr); }
+
+// PH = 0: the fused learn / predict step.  PH = 1 (FWD) and PH = 3 (UPD): the two table-touching halves of the synchronous
+// micro-batch pipeline -- every example of the batch sees the weights of the batch start, updates are applied afterwards:
+//   FWD : stage, gather the rows this rank OWNS (all of them on one GPU), write T / dcf / LR sums to the example's split record
+//   (exchange: records summed over the ranks; MID kernel: logit, prediction, general gradient; or the mini-batched deep head)
+//   UPD : stage, T and the entries' own slots back from the records, AdaGrad on the owned rows and LR entries
+template <int VEC, int OPT, bool COH, int PH = 0>
 __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) {
     typedef typename Vec<VEC>::type V;
     constexpr int AUX = COH ? kAuxSc1 : kAuxPlain;
@@ -1144,7 +1154,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         const bool do_update = so.do_update;
         FW_TICK(1);
         // ---------------- gather: field sums, transposed into LDS
-        if (k) {
+        if (k && PH != 3) {
             for (;;) {
                 // Dynamic field -> wave assignment.  Every lane takes part in the atomic (lane 0 adds 1, the others
                 // add 0, so lane 0 always gets the old counter) and NO lane-conditional BRANCH may sit in this
@@ -1170,19 +1180,22 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                     for (uint32_t i = fs; i < fe; i += UG) {
                         V r[UG];
                         float v[UG];
+                        bool on[UG];
 #pragma unroll
                         for (int u = 0; u < UG; ++u) {
                             r[u] = Vec<VEC>::zero();
                             v[u] = 0.0f;
-                            if (i + u < fe) {
+                            on[u] = i + u < fe;
+                            if (on[u]) {
                                 const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[i + u]);
+                                if (PH == 1) on[u] = h >= p.own_lo_ffm && h < p.own_hi_ffm;  // sharded tables: owned rows only
                                 v[u] = s.e_val[i + u];
-                                r[u] = Vec<VEC>::template load<AUX>(make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
+                                if (on[u]) r[u] = Vec<VEC>::template load<AUX>(make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
                             }
                         }
 #pragma unroll
                         for (int u = 0; u < UG; ++u) {
-                            if (i + u < fe) {
+                            if (on[u]) {
                                 float ss = 0.0f;
 #pragma unroll
                                 for (int j = 0; j < VEC; ++j) {
@@ -1210,10 +1223,61 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
             for (uint32_t i = tid; i < F * R; i += bd) p.emit_T[i] = s.T[i];
             for (uint32_t f = tid; f < F; f += bd) p.emit_dcf[f] = s.dcf[f];
         }
+        if (PH == 1) {
+            // ---------------- FWD: this rank's share of the example goes to its split record
+            float *rec = p.split + (size_t)ex * p.split_len;
+            const bool home = ex >= p.home_lo && ex < p.home_hi;
+            for (uint32_t i = tid; i < F * R; i += bd) rec[i] = s.T[i];
+            for (uint32_t f = tid; f < F; f += bd) {
+                rec[F * R + f] = s.dcf[f];
+                rec[F * R + F + p.split_nlr + f] = home ? (float)(s.fend[f] - s.fstart[f]) : 0.0f;
+            }
+            if (tid == 0) {
+                rec[F * R + 2 * F + p.split_nlr] = home ? label : 0.0f;
+                rec[F * R + 2 * F + p.split_nlr + 1] = home ? imp : 0.0f;
+            }
+            for (uint32_t i = tid; i < nf * k; i += bd) p.split_selfw[(size_t)ex * p.selfw_stride + i] = s.selfw[i];
+            if (p.split_nlr > 1) {  // deep head: one sum per LR combo slot, entries in buffer order (block_lr.rs:36-45)
+                for (uint32_t c = tid; c < p.split_nlr; c += bd) {
+                    float acc = 0.0f;
+                    for (uint32_t i = 0; i < nl; ++i) {
+                        const uint32_t h = s.l_hash[i];
+                        if (s.l_combo[i] == c && h >= p.own_lo_lr && h < p.own_hi_lr) acc += lr_load<COH>(p.lr, h).x * s.l_val[i];
+                    }
+                    rec[F * R + F + c] = acc;
+                }
+            } else {
+                float lrs = 0.0f;
+                if (p.has_lr)
+                    for (uint32_t i = tid; i < nl; i += bd) {
+                        const uint32_t h = s.l_hash[i];
+                        if (h >= p.own_lo_lr && h < p.own_hi_lr) lrs += lr_load<COH>(p.lr, h).x * s.l_val[i];
+                    }
+                lrs = wave_sum(lrs);
+                if (lane == 0) s.red[32 + wave] = lrs;
+                __syncthreads();
+                if (tid == 0) {
+                    float t = 0.0f;
+                    for (int w = 0; w < nw; ++w) t += s.red[32 + w];
+                    rec[F * R + F] = t;
+                }
+            }
+            if (tid == 0) s.ctr[6] = next_ticket;
+            continue;
+        }
+        float g_split = 0.0f;
+        if (PH == 3) {
+            // ---------------- UPD: the batch-start field sums and own slots come back from the records
+            const float *rec = p.split + (size_t)ex * p.split_len;
+            for (uint32_t i = tid; i < F * R; i += bd) s.T[i] = rec[i];
+            for (uint32_t i = tid; i < nf * k; i += bd) s.selfw[i] = p.split_selfw[(size_t)ex * p.selfw_stride + i];
+            g_split = p.gbuf[ex];
+            __syncthreads();
+        }
 
         // ---------------- all-pairs dot from LDS + LR forward
         float dot = 0.0f;
-        if (k) {
+        if (k && PH == 0) {
             const uint32_t nq = F * R / VEC;
             for (uint32_t q = tid; q < nq; q += bd) {
                 const uint32_t e0 = q * VEC;
@@ -1225,6 +1289,11 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                 for (int j = 0; j < VEC; ++j) dot += Vec<VEC>::get(x, j) * Vec<VEC>::get(y, j);
             }
         }
+        float pr, g;
+        if (PH == 3) {
+            pr = 0.0f;
+            g = g_split;
+        } else {
         float lrs = 0.0f;
         if (p.has_lr)
             for (uint32_t i = tid; i < nl; i += bd) lrs += lr_load<COH>(p.lr, s.l_hash[i]).x * s.l_val[i];
@@ -1249,7 +1318,6 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         if (p.nn.n_layers) wsum = nn_forward<VEC, COH>(p, s, nl, tid, bd);
 
         // ---------------- sigmoid / log-loss gradient (block_loss_functions.rs:105-153)
-        float pr, g;
         if (isnan(wsum)) {
             pr = logistic(0.0f);
             g = 0.0f;
@@ -1264,19 +1332,25 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
             g = -(label - pr) * imp;
         }
         if (tid == 0) p.pred[ex] = pr;
+        }  // PH != 3
         FW_TICK(3);
 
         // ---------------- update.  g == 0 leaves every weight and accumulator unchanged in all three
         // optimizers (acc += 0, w -= 0), so the whole phase is skipped.
-        if (do_update && g != 0.0f) {
+        const bool head_split = PH == 3 && p.dxbuf != nullptr;  // mini-batched deep head: per-slot gradients come from the head kernels
+        if (do_update && (g != 0.0f || head_split)) {
             // deep head: unwind it first; afterwards every LR slot and every FFM pair has its own general gradient
             const float *gx = nullptr, *gpair = nullptr;
-            if (p.nn.n_layers) {
+            if (head_split) {
+                gx = p.dxbuf + (size_t)ex * p.nn.X;
+                gpair = gx + p.num_combos;
+            } else if (p.nn.n_layers) {
                 nn_backward<OPT, COH>(p, s, g, tid, bd);
                 gx = nn_buf(p, s).xg;
                 gpair = gx + p.num_combos;
             }
-            if (p.has_lr) lr_update<OPT, COH>(p, s, nl, g, gx, lut_lr, tid, bd);
+            const uint32_t olo = PH == 3 ? p.own_lo_ffm : 0u, ohi = PH == 3 ? p.own_hi_ffm : 0xffffffffu;
+            if (p.has_lr) lr_update<OPT, COH>(p, s, nl, g, gx, lut_lr, tid, bd, PH == 3 ? p.own_lo_lr : 0u, PH == 3 ? p.own_hi_lr : 0xffffffffu);
             FW_TICK(4);
             if (k) {
                 // phase A: rows with no earlier overlapping row, all waves, UU rows each
@@ -1285,7 +1359,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
 #pragma unroll
                     for (int u = 0; u < UU; ++u) {
                         const uint32_t i = i0 + u;
-                        idx[u] = (i < nf && !(s.e_fld[i] & kRowDep)) ? i : 0xffffffffu;
+                        idx[u] = (i < nf && !(s.e_fld[i] & kRowDep) && s.e_hash[i] >= olo && s.e_hash[i] < ohi) ? i : 0xffffffffu;
                     }
                     update_rows<VEC, OPT, AUX, UU>(p, s, idx, g, lane, gpair);
                 }
@@ -1295,7 +1369,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                     __syncthreads();
                     if (wave == 0) {
                         for (uint32_t i = 0; i < nf; ++i) {
-                            if (s.e_fld[i] & kRowDep) {
+                            if ((s.e_fld[i] & kRowDep) && s.e_hash[i] >= olo && s.e_hash[i] < ohi) {
                                 uint32_t idx[1] = {i};
                                 update_rows<VEC, OPT, AUX, 1>(p, s, idx, g, lane, gpair);
                                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -1368,6 +1442,102 @@ static hipError_t launch_v(const KernelParams &p, int optimizer, bool coherent, 
         return coherent ? launch_t<VEC, FWGPU_OPT_ADAGRAD_LUT, true>(p, grid, threads, lds, stream)
                         : launch_t<VEC, FWGPU_OPT_ADAGRAD_LUT, false>(p, grid, threads, lds, stream);
     }
+}
+
+// ------------------------------------------------------------------ split pipeline: phase launches and the MID kernel
+template <int VEC>
+static hipError_t launch_phase_v(const KernelParams &p, int optimizer, int phase, uint32_t grid, uint32_t threads, size_t lds,
+                                 hipStream_t stream) {
+    if (phase == 1) return launch_persistent(fw_example_kernel<VEC, FWGPU_OPT_SGD, false, 1>, p, grid, threads, lds, stream);
+    switch (optimizer) {
+    case FWGPU_OPT_SGD: return launch_persistent(fw_example_kernel<VEC, FWGPU_OPT_SGD, true, 3>, p, grid, threads, lds, stream);
+    case FWGPU_OPT_ADAGRAD_FLEX: return launch_persistent(fw_example_kernel<VEC, FWGPU_OPT_ADAGRAD_FLEX, true, 3>, p, grid, threads, lds, stream);
+    default: return launch_persistent(fw_example_kernel<VEC, FWGPU_OPT_ADAGRAD_LUT, true, 3>, p, grid, threads, lds, stream);
+    }
+}
+
+hipError_t launch_example_phase(const KernelParams &p_in, int optimizer, int phase, uint32_t grid, uint32_t threads, hipStream_t stream) {
+    if (p_in.n_examples == 0) return hipSuccess;
+    KernelParams p = p_in;
+    p.window = p.chain = 0;  // (the generic kernel's update path)
+    p.update = phase == 3 ? 1 : 0;
+    const size_t lds = example_kernel_lds_bytes(p, optimizer);
+    if (p.k % 4 == 0 && p.aligned4) return launch_phase_v<4>(p, optimizer, phase, grid, threads, lds, stream);
+    return launch_phase_v<1>(p, optimizer, phase, grid, threads, lds, stream);
+}
+
+// MID: one workgroup per example.  From the (summed) split record: the logit exactly as the fused kernel forms it
+// (LR sum + 0.5 * (sum_e T[e] * T[perm(e)] - sum_f dcf[f])), sigmoid / log-loss (block_loss_functions.rs:105-153) -> prediction and
+// general gradient; or, with a mini-batched deep head, the head's input x = [LR combo sums, triangle of the pair outputs]
+// (block_misc.rs:864-883; a field holding at most one feature has a diagonal of exactly 0, as in the reference's own form).
+__global__ void __launch_bounds__(256) split_mid_kernel(const KernelParams p, uint32_t n) {
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t F = p.F, k = p.k, R = p.R, C = p.split_nlr;
+    for (uint32_t ex = blockIdx.x; ex < n; ex += gridDim.x) {
+        const float *rec = p.split + (size_t)ex * p.split_len;
+        const float *T = rec, *dcf = rec + F * R, *lrs = dcf + F, *cnt = lrs + C;
+        const float label = cnt[F], imp = cnt[F + 1];
+        if (p.xbuf) {
+            float *x = p.xbuf + (size_t)ex * p.nn.X;
+            for (uint32_t c = tid; c < C; c += 256) x[c] = lrs[c];
+            const uint32_t NT = F * (F + 1) / 2;
+            for (uint32_t t = tid; t < NT; t += 256) {
+                uint32_t i = (uint32_t)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+                while ((i + 1) * (i + 2) / 2 <= t) ++i;
+                while (i * (i + 1) / 2 > t) --i;
+                const uint32_t j = t - i * (i + 1) / 2;
+                float dot = 0.0f;
+                for (uint32_t kk = 0; kk < k; ++kk) dot += T[i * R + j * k + kk] * T[j * R + i * k + kk];
+                if (i == j) dot = cnt[i] <= 1.0f ? 0.0f : 0.5f * (dot - dcf[i]);
+                x[C + t] = dot;
+            }
+            if (tid == 0) {  // the head kernel needs them next to x
+                p.gbuf[2 * (size_t)ex] = label;
+                p.gbuf[2 * (size_t)ex + 1] = imp;
+            }
+            continue;
+        }
+        float dot = 0.0f;
+        for (uint32_t e = tid; e < F * R; e += 256) {
+            const uint32_t a = e / R, rem = e - a * R, b = rem / k, kk = rem - b * k;
+            dot += T[e] * T[b * R + a * k + kk];
+        }
+        dot = wave_sum(dot);
+        __syncthreads();
+        if (lane == 0) red[wave] = dot;
+        __syncthreads();
+        if (tid == 0) {
+            float dot_t = 0.0f, dc_t = 0.0f;
+            for (int w = 0; w < 4; ++w) dot_t += red[w];
+            for (uint32_t f = 0; f < F; ++f) dc_t += dcf[f];
+            float wsum = 0.0f;
+            if (p.has_lr) wsum += lrs[0];
+            if (k) wsum += 0.5f * (dot_t - dc_t);
+            float pr, g;
+            if (isnan(wsum)) {
+                pr = logistic(0.0f);
+                g = 0.0f;
+            } else if (wsum < -50.0f) {
+                pr = logistic(-50.0f);
+                g = 0.0f;
+            } else if (wsum > 50.0f) {
+                pr = logistic(50.0f);
+                g = 0.0f;
+            } else {
+                pr = logistic(wsum);
+                g = -(label - pr) * imp;
+            }
+            p.pred[ex] = pr;
+            p.gbuf[ex] = g;  // importance 0 gives g = 0: the UPD phase then skips the example (regressor.rs:366)
+        }
+    }
+}
+
+hipError_t launch_split_mid(const KernelParams &p, uint32_t n, hipStream_t stream) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(split_mid_kernel, dim3(n < 4096 ? n : 4096), dim3(256), 0, stream, p, n);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ v2: static wave ranges, occupancy-tuned

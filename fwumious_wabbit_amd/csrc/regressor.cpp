@@ -343,10 +343,10 @@ uint32_t pick_grid(const fwgpu_regressor *r, const KernelParams &p, int mode, ui
     return mode == FWGPU_MODE_SEQUENTIAL ? 1u : 0u;
 }
 
-static int run_batch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, hipStream_t stream) {
-    if (b->n == 0) return FWGPU_OK;
-    KernelParams p = make_params(r, b, update);
-    uint32_t threads = r->launch.threads;
+// launch shape of a batch: workgroup size, LDS copy of the LUT or not (settles p.window / p.chain / p.lut_global)
+static int prepare_launch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, KernelParams &p, uint32_t &threads) {
+    p = make_params(r, b, update);
+    threads = r->launch.threads;
     if (mode == FWGPU_MODE_SEQUENTIAL) threads = std::max<uint32_t>(threads, 512);
     if ((uint64_t)p.max_ffm > 4ull * threads) threads = 1024;
     if ((uint64_t)p.max_ffm > 4ull * threads)
@@ -372,6 +372,15 @@ static int run_batch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, h
     }
     if (lds > r->lds_per_cu)
         return fail(FWGPU_ERR_RANGE, "example does not fit the 160 KiB LDS (k*F^2 or features per example too large)");
+    return FWGPU_OK;
+}
+
+static int run_batch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, hipStream_t stream) {
+    if (b->n == 0) return FWGPU_OK;
+    KernelParams p;
+    uint32_t threads = 0;
+    int rc = prepare_launch(r, b, mode, update, p, threads);
+    if (rc) return rc;
     const uint32_t grid = pick_grid(r, p, mode, threads);
     FWGPU_HIP(hipMemsetAsync(b->work, 0, sizeof(uint32_t), stream));
     // An updating launch always uses device-scope (sc1) accesses; read-only launches use cached loads.
@@ -701,6 +710,133 @@ int fwgpu_record_batch_create(fwgpu_regressor *r, const fwgpu_translator_config 
     }
     *out = b;
     return FWGPU_OK;
+}
+
+// ------------------------------------------------------------------ synchronous micro-batch ("split") pipeline
+// FWD (gather -> split records) -> MID (records -> prediction + general gradient) -> UPD (AdaGrad from the records): every
+// example of the batch sees the weights of the batch start, like the examples in flight at once in hogwild.rs, but with a
+// defined staleness (the batch).  It is what the owner-sharded multi-GPU mode (dist.cpp) and the mini-batched deep head
+// (head.hip) are built from; on one GPU fwgpu_learn_batch_sync runs the three steps back to back.
+
+int fwgpu_split_create(fwgpu_regressor *r, uint32_t n_examples, uint32_t max_ffm_per_example, fwgpu_split **out) {
+    if (!r || !out || !n_examples) return fail(FWGPU_ERR_INVALID, "split_create: bad argument");
+    FWGPU_HIP(hipSetDevice(r->device));
+    std::unique_ptr<fwgpu_split> sp(new fwgpu_split());
+    sp->owner = r;
+    sp->n_cap = n_examples;
+    const uint32_t F = r->cfg.ffm_k ? r->cfg.ffm_num_fields : 0, R = F * r->cfg.ffm_k;
+    sp->nlr = r->nn.n_layers ? r->cfg.num_combos : 1;
+    sp->split_len = split_record_len(F, R, sp->nlr);
+    sp->selfw_stride = (std::max<uint32_t>(4, (max_ffm_per_example + 3) & ~3u)) * std::max<uint32_t>(1, r->cfg.ffm_k);
+    const uint32_t X = r->nn.n_layers ? r->nn.X : 0;
+    const size_t bytes[5] = {(size_t)n_examples * sp->split_len * 4, (size_t)n_examples * sp->selfw_stride * 4,
+                             (size_t)n_examples * 2 * 4 + 64, (size_t)n_examples * X * 4, (size_t)n_examples * X * 4};
+    float **ptrs[5] = {&sp->d_split, &sp->d_selfw, &sp->d_g, &sp->d_x, &sp->d_dx};
+    for (int i = 0; i < 5; i++) {
+        if (!bytes[i]) continue;
+        if (hipMalloc((void **)ptrs[i], bytes[i]) != hipSuccess) {
+            fwgpu_split_free(sp.release());
+            return fail(FWGPU_ERR_DEVICE, "split_create: allocation failed");
+        }
+    }
+    *out = sp.release();
+    return FWGPU_OK;
+}
+
+int fwgpu_split_free(fwgpu_split *sp) {
+    if (!sp) return FWGPU_OK;
+    for (float *q : {sp->d_split, sp->d_selfw, sp->d_g, sp->d_x, sp->d_dx})
+        if (q) (void)hipFree(q);
+    delete sp;
+    return FWGPU_OK;
+}
+
+}  // extern "C"
+namespace fwgpu {
+static int split_params(fwgpu_regressor *r, fwgpu_batch *b, fwgpu_split *sp, int mode, int update, const SplitRanges &rg,
+                        KernelParams &p, uint32_t &threads) {
+    if (!r || !b || !sp) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    if (b->owner != r || sp->owner != r) return fail(FWGPU_ERR_INVALID, "batch / split buffers belong to another regressor");
+    if (b->n > sp->n_cap) return fail(FWGPU_ERR_RANGE, "split buffers are smaller than the batch");
+    int rc = prepare_launch(r, b, mode, update, p, threads);
+    if (rc) return rc;
+    if ((uint64_t)p.max_ffm * std::max<uint32_t>(1, p.k) > sp->selfw_stride)
+        return fail(FWGPU_ERR_RANGE, "split buffers: an example has more FFM features than they were created for");
+    p.split = sp->d_split;
+    p.split_len = sp->split_len;
+    p.split_nlr = sp->nlr;
+    p.split_selfw = sp->d_selfw;
+    p.selfw_stride = sp->selfw_stride;
+    p.gbuf = sp->d_g;
+    p.own_lo_ffm = rg.ffm_lo;
+    p.own_hi_ffm = rg.ffm_hi;
+    p.own_lo_lr = rg.lr_lo;
+    p.own_hi_lr = rg.lr_hi;
+    p.home_lo = rg.home_lo;
+    p.home_hi = rg.home_hi;
+    return FWGPU_OK;
+}
+
+int split_forward(fwgpu_regressor *r, fwgpu_batch *b, fwgpu_split *sp, int mode, const SplitRanges &rg, hipStream_t stream) {
+    if (b && b->n == 0) return FWGPU_OK;
+    KernelParams p;
+    uint32_t threads = 0;
+    int rc = split_params(r, b, sp, mode, 0, rg, p, threads);
+    if (rc) return rc;
+    FWGPU_HIP(hipMemsetAsync(b->work, 0, sizeof(uint32_t), stream));
+    FWGPU_HIP(launch_example_phase(p, r->cfg.optimizer, 1, pick_grid(r, p, mode, threads), threads, stream));
+    return FWGPU_OK;
+}
+
+// records [first, first + n) of `sp` -> predictions into pred (device, n floats) and general gradients / head inputs
+int split_mid(fwgpu_regressor *r, fwgpu_split *sp, uint32_t first, uint32_t n, float *d_pred, bool head, hipStream_t stream) {
+    if (!n) return FWGPU_OK;
+    KernelParams p{};
+    p.F = r->cfg.ffm_k ? r->cfg.ffm_num_fields : 0;
+    p.k = r->cfg.ffm_k;
+    p.R = p.F * p.k;
+    p.has_lr = r->cfg.wiring == FWGPU_WIRING_REGRESSOR;
+    p.nn = r->nn;
+    p.split = sp->d_split + (size_t)first * sp->split_len;
+    p.split_len = sp->split_len;
+    p.split_nlr = sp->nlr;
+    p.pred = d_pred;
+    p.gbuf = head ? sp->d_g + 2 * (size_t)first : sp->d_g + first;
+    p.xbuf = head ? sp->d_x + (size_t)first * r->nn.X : nullptr;
+    FWGPU_HIP(launch_split_mid(p, n, stream));
+    return FWGPU_OK;
+}
+
+int split_update(fwgpu_regressor *r, fwgpu_batch *b, fwgpu_split *sp, int mode, const SplitRanges &rg, bool head, hipStream_t stream) {
+    if (b && b->n == 0) return FWGPU_OK;
+    KernelParams p;
+    uint32_t threads = 0;
+    int rc = split_params(r, b, sp, mode, 1, rg, p, threads);
+    if (rc) return rc;
+    p.dxbuf = head ? sp->d_dx : nullptr;
+    FWGPU_HIP(hipMemsetAsync(b->work, 0, sizeof(uint32_t), stream));
+    FWGPU_HIP(launch_example_phase(p, r->cfg.optimizer, 3, pick_grid(r, p, mode, threads), threads, stream));
+    return FWGPU_OK;
+}
+}  // namespace fwgpu
+extern "C" {
+
+// One synchronous micro-batch on one GPU: all of b's examples are scored with the weights as they are, then all updates are
+// applied (FWGPU_MODE_SEQUENTIAL: in example order, on one workgroup -- the deterministic mode the oracle's micro-batch
+// mode is compared with; FWGPU_MODE_HOGWILD: concurrently).  Models with a deep head take the mini-batched head (head.hip).
+int fwgpu_learn_batch_sync(fwgpu_regressor *r, fwgpu_batch *b, fwgpu_split *sp, int mode, void *stream_) {
+    if (!r || !b || !sp) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    if (mode != FWGPU_MODE_SEQUENTIAL && mode != FWGPU_MODE_HOGWILD) return fail(FWGPU_ERR_INVALID, "unknown mode");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    FWGPU_HIP(hipSetDevice(r->device));
+    SplitRanges rg;
+    rg.home_hi = b->n;
+    const bool head = r->nn.n_layers != 0;
+    int rc = split_forward(r, b, sp, mode, rg, stream);
+    if (rc == FWGPU_OK) rc = split_mid(r, sp, 0, b->n, b->pred, head, stream);
+    if (rc == FWGPU_OK && head) rc = head_step(r, sp, 0, b->n, b->pred, /*update=*/true, stream);
+    if (rc == FWGPU_OK) rc = split_update(r, b, sp, mode, rg, head, stream);
+    return rc;
 }
 
 // ------------------------------------------------------------------ context cache (serving)

@@ -186,6 +186,25 @@ class Batch:
             pass
 
 
+class SplitBuffers:
+    """device buffers of one synchronous micro-batch (fwgpu_split)"""
+
+    def __init__(self, regressor, n_examples, max_ffm_per_example):
+        self.h = C.c_void_p()
+        check(capi.lib().fwgpu_split_create(regressor.h, n_examples, max_ffm_per_example, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            capi.lib().fwgpu_split_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class BlockCache:
     """Vec<BlockCache> (regressor.rs:40-50): what setup_cache leaves on the device for predict_with_cache"""
 
@@ -351,6 +370,14 @@ class Regressor:
 
     def learn_batch(self, batch: Batch, mode=capi.MODE_SEQUENTIAL, update=True, stream=None):
         check(self.L.fwgpu_learn_batch(self.h, batch.h, mode, int(update), stream))
+
+    # ---- synchronous micro-batches (the step of the sharded multi-GPU mode and of the mini-batched deep head)
+    def split_buffers(self, n_examples, max_ffm_per_example=512):
+        return SplitBuffers(self, n_examples, max_ffm_per_example)
+
+    def learn_batch_sync(self, batch, split, mode=capi.MODE_HOGWILD, stream=None):
+        """every example of the batch is scored with the weights of the batch start, then all updates are applied"""
+        check(self.L.fwgpu_learn_batch_sync(self.h, batch.h, split.h, mode, stream))
 
     def set_launch(self, threads=0, workgroups_per_cu=0):
         check(self.L.fwgpu_set_launch(self.h, threads, workgroups_per_cu))

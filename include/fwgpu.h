@@ -191,6 +191,14 @@ int fwgpu_batch_create(fwgpu_regressor *r, const fwgpu_lr_entry *lr, const uint3
                        const float *importance, uint32_t n_examples, fwgpu_batch **out);
 int fwgpu_batch_free(fwgpu_batch *b);
 int fwgpu_batch_size(const fwgpu_batch *b, uint32_t *n_examples, uint64_t *n_lr, uint64_t *n_ffm);
+/* Synchronous micro-batch: every example of the batch is scored with the weights of the batch start, then all updates are
+ * applied (FWGPU_MODE_SEQUENTIAL: in example order; FWGPU_MODE_HOGWILD: concurrently).  This is the step the owner-sharded
+ * multi-GPU mode (fwgpu_dist_*) runs across GPUs, and the mode in which a deep head trains mini-batched on the matrix cores.
+ * fwgpu_split = the device buffers of one such batch (n_examples x {field sums, own slots, gradients}). */
+typedef struct fwgpu_split fwgpu_split;
+int fwgpu_split_create(fwgpu_regressor *r, uint32_t n_examples, uint32_t max_ffm_per_example, fwgpu_split **out);
+int fwgpu_split_free(fwgpu_split *sp);
+int fwgpu_learn_batch_sync(fwgpu_regressor *r, fwgpu_batch *b, fwgpu_split *sp, int mode, void *hip_stream);
 /* predict-only launches of an ENTRY batch start every example's field sums from this context cache (NULL detaches it) */
 int fwgpu_batch_set_cache(fwgpu_batch *b, const fwgpu_block_cache *cache);
 /* Enqueue one pass over the batch on `stream`: for every example, Regressor::learn(fb, update)

@@ -1032,3 +1032,168 @@ double fwo_run_stream(fwo_model *m, const fwo_translator *t, const uint32_t *rec
     scratch_free(&s);
     return dt;
 }
+
+/* ------------------------------------------------------------------ synchronous micro-batch (see fw_oracle.h) */
+typedef struct {
+    fwo_lr_entry *lr;
+    fwo_ffm_entry *ffm;
+    uint32_t n_lr, n_ffm;
+    float *G;   /* gradient cache of the frozen forward pass (block_ffm.rs:220-261) */
+    float g;    /* general gradient */
+    float *dx;  /* deep head: d logit / d x from the frozen dense weights, [X] */
+    int update;
+} mb_example;
+
+void fwo_learn_minibatch(fwo_model *m, const fwo_translator *t, const uint32_t *records, const uint64_t *rec_off, uint64_t n,
+                         float *preds) {
+    const fwo_config *c = &m->cfg;
+    const uint32_t F = c->ffm_k ? c->ffm_num_fields : 0, k = c->ffm_k, C = c->num_combos, T = F * (F + 1) / 2, X = C + T;
+    const uint32_t L = m->nn.n_layers;
+    const int head = L && c->wiring == FWO_WIRING_REGRESSOR;
+    fwo_scratch s;
+    scratch_init(&s, c);
+    mb_example *ex = (mb_example *)calloc(n ? n : 1, sizeof(mb_example));
+    fwo_lr_entry *lr = (fwo_lr_entry *)malloc(sizeof(fwo_lr_entry) * FWO_EX_CAP);
+    fwo_ffm_entry *ffm = (fwo_ffm_entry *)malloc(sizeof(fwo_ffm_entry) * FWO_EX_CAP);
+    /* dense gradient sums, same layout as the weights (per layer W[j*in+i], then the biases) */
+    double unused = 0.0;
+    (void)unused;
+    float *dW[FWO_NN_MAX_LAYERS + 1] = {0};
+    if (head)
+        for (uint32_t l = 0; l <= L; l++) dW[l] = (float *)calloc((size_t)(m->nn_in[l] + 1) * m->nn_out[l], sizeof(float));
+    /* ---- pass 1: every example against the weights of the batch start */
+    for (uint64_t e = 0; e < n; e++) {
+        mb_example *x = &ex[e];
+        float label, imp;
+        fwo_translate(t, records + rec_off[e], lr, FWO_EX_CAP, &x->n_lr, ffm, FWO_EX_CAP, &x->n_ffm, &label, &imp);
+        x->lr = (fwo_lr_entry *)malloc(sizeof(fwo_lr_entry) * (x->n_lr + 1));
+        x->ffm = (fwo_ffm_entry *)malloc(sizeof(fwo_ffm_entry) * (x->n_ffm + 1));
+        memcpy(x->lr, lr, sizeof(fwo_lr_entry) * x->n_lr);
+        memcpy(x->ffm, ffm, sizeof(fwo_ffm_entry) * x->n_ffm);
+        x->update = imp != 0.0f; /* regressor.rs:366 */
+        lr_forward(m, lr, x->n_lr, s.lr_out);
+        if (F) {
+            ensure_grads(&s, x->n_ffm * F * k);
+            ffm_fb_forward(m, ffm, x->n_ffm, &s);
+            x->G = (float *)malloc(sizeof(float) * ((size_t)x->n_ffm * F * k + 1));
+            memcpy(x->G, s.grads, sizeof(float) * (size_t)x->n_ffm * F * k);
+            fwo_triangle_forward(s.ffm_out, F, s.tri);
+        }
+        float p;
+        if (!head) {
+            if (c->wiring == FWO_WIRING_FFM_ONLY)
+                p = sigmoid_block(s.ffm_out, F * F, NULL, 0, label, imp, &x->g);
+            else
+                p = sigmoid_block(s.lr_out, C, s.tri, T, label, imp, &x->g);
+        } else {
+            /* frozen head: forward, then backward for the input gradients and the weight-gradient sums */
+            float *xin = (float *)malloc(sizeof(float) * (X + 1));
+            memcpy(xin, s.lr_out, sizeof(float) * C);
+            if (T) memcpy(xin + C, s.tri, sizeof(float) * T);
+            float *pre[FWO_NN_MAX_LAYERS], *post[FWO_NN_MAX_LAYERS];
+            const float *h = xin;
+            for (uint32_t l = 0; l < L; l++) {
+                pre[l] = (float *)malloc(sizeof(float) * m->nn_out[l]);
+                post[l] = (float *)malloc(sizeof(float) * m->nn_out[l]);
+                nn_layer_forward(m->nn_w[l], m->nn_in[l], m->nn_out[l], h, pre[l]);
+                for (uint32_t j = 0; j < m->nn_out[l]; j++) {
+                    const float wv = pre[l][j];
+                    post[l][j] = (m->nn.relu[l] && wv < 0.0f) ? 0.0f : wv;
+                    pre[l][j] = (m->nn.relu[l] && wv < 0.0f) ? 0.0f : 1.0f;
+                }
+                h = post[l];
+            }
+            const uint32_t fin = m->nn_in[L], wl = m->nn_out[L - 1];
+            float *fx = (float *)malloc(sizeof(float) * (fin + 1));
+            memcpy(fx, h, sizeof(float) * wl);
+            if (m->nn.topology == 1) memcpy(fx + wl, xin, sizeof(float) * X);
+            float z;
+            nn_layer_forward(m->nn_w[L], fin, 1, fx, &z);
+            p = sigmoid_block(&z, 1, NULL, 0, label, imp, &x->g);
+            x->dx = (float *)calloc(X + 1, sizeof(float));
+            if (x->update && x->g != 0.0f) {
+                const float g = x->g;
+                float *gin = (float *)calloc(fin + 1, sizeof(float)); /* final neuron */
+                for (uint32_t i = 0; i < fin; i++) {
+                    dW[L][i] += g * fx[i];
+                    gin[i] = m->nn_w[L][i] * g;
+                }
+                dW[L][fin] += g;
+                if (m->nn.topology == 1)
+                    for (uint32_t i = 0; i < X; i++) x->dx[i] = gin[wl + i];
+                float *grad_h = gin;
+                float *tmp = NULL;
+                for (int l = (int)L - 1; l >= 0; l--) {
+                    const uint32_t in = m->nn_in[l], out = m->nn_out[l];
+                    const float *in_vec = l == 0 ? xin : post[l - 1];
+                    float *oe = (float *)calloc(in + 1, sizeof(float));
+                    for (uint32_t j = 0; j < out; j++) {
+                        const float gg = pre[l][j] * grad_h[j]; /* block_relu.rs:105-110 */
+                        if (gg == 0.0f) continue;
+                        const size_t jo = (size_t)j * in;
+                        for (uint32_t i = 0; i < in; i++) {
+                            dW[l][jo + i] += gg * in_vec[i];
+                            oe[i] += m->nn_w[l][jo + i] * gg;
+                        }
+                        dW[l][(size_t)in * out + j] += gg;
+                    }
+                    free(tmp);
+                    tmp = oe;
+                    grad_h = oe;
+                }
+                for (uint32_t i = 0; i < X; i++) x->dx[i] += grad_h[i]; /* BlockCopy sums both branches */
+                free(tmp);
+                free(gin);
+            }
+            for (uint32_t l = 0; l < L; l++) {
+                free(pre[l]);
+                free(post[l]);
+            }
+            free(fx);
+            free(xin);
+        }
+        if (preds) preds[e] = p;
+    }
+    /* ---- pass 2: the sparse updates, example by example */
+    for (uint64_t e = 0; e < n; e++) {
+        mb_example *x = &ex[e];
+        if (x->update && (head || x->g != 0.0f)) {
+            if (head) {
+                for (uint32_t i = 0; i < C; i++) s.lr_out[i] = x->dx[i];
+                for (uint32_t i = 0; i < T; i++) s.tri[i] = x->dx[C + i];
+            } else {
+                for (uint32_t i = 0; i < C; i++) s.lr_out[i] = x->g;
+                for (uint32_t i = 0; i < T; i++) s.tri[i] = x->g;
+            }
+            if (F) {
+                if (c->wiring == FWO_WIRING_FFM_ONLY)
+                    for (uint32_t i = 0; i < F * F; i++) s.ffm_out[i] = x->g;
+                else
+                    fwo_triangle_backward(s.tri, F, s.ffm_out);
+                ensure_grads(&s, x->n_ffm * F * k);
+                memcpy(s.grads, x->G, sizeof(float) * (size_t)x->n_ffm * F * k);
+                ffm_fb_update(m, x->ffm, x->n_ffm, &s);
+            }
+            if (c->wiring != FWO_WIRING_FFM_ONLY) lr_update(m, x->lr, x->n_lr, s.lr_out);
+        }
+        free(x->lr);
+        free(x->ffm);
+        free(x->G);
+        free(x->dx);
+    }
+    /* ---- the dense weights: one optimizer step each with the summed gradient */
+    if (head)
+        for (uint32_t l = 0; l <= L; l++) {
+            const size_t nw = (size_t)(m->nn_in[l] + 1) * m->nn_out[l];
+            for (size_t i = 0; i < nw; i++) {
+                if (dW[l][i] == 0.0f) continue;
+                const float upd = opt_step(c->optimizer, m->nn.nn_learning_rate, m->nn.nn_power_t, m->lut_nn, dW[l][i], &m->nn_acc[l][i]);
+                m->nn_w[l][i] -= upd;
+            }
+            free(dW[l]);
+        }
+    free(ex);
+    free(lr);
+    free(ffm);
+    scratch_free(&s);
+}

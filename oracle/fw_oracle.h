@@ -162,6 +162,16 @@ int fwo_translate(const fwo_translator *t, const uint32_t *record, fwo_lr_entry 
 double fwo_run_stream(fwo_model *m, const fwo_translator *t, const uint32_t *records, const uint64_t *rec_off,
                       uint64_t n, uint64_t holdout_after, int nthreads, float *preds);
 
+/* ---- synchronous micro-batch: the checker of the library's fwgpu_learn_batch_sync / sharded multi-GPU step ----
+ * NOT a mode of the reference (which updates after every example): it is what N hogwild threads do when they all read the
+ * weights at the same moment.  All n examples are scored with the weights as they are (forward passes of
+ * block_lr.rs:28-47 / block_ffm.rs:163-261 and, with a deep head, block_neural.rs:196-222); then, per example in order, the
+ * FFM and LR updates (block_ffm.rs:265-288, block_lr.rs:135-150) with the gradients of that frozen forward pass.  Deep
+ * head: the dense gradients are SUMMED over the batch and every dense weight takes ONE optimizer step with the sum
+ * (mini-batch AdaGrad), input gradients come from the frozen weights.  preds: the n predictions. */
+void fwo_learn_minibatch(fwo_model *m, const fwo_translator *t, const uint32_t *records, const uint64_t *rec_off, uint64_t n,
+                         float *preds);
+
 #ifdef __cplusplus
 }
 #endif

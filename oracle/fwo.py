@@ -147,6 +147,8 @@ def lib(native=False):
     L.fwo_ffm_hash_mask.argtypes = [C.c_uint32, C.c_uint32]
     L.fwo_translate.restype = C.c_int
     L.fwo_translate.argtypes = [C.POINTER(Translator), vp, vp, C.c_uint32, u32p, vp, C.c_uint32, u32p, f32p, f32p]
+    L.fwo_learn_minibatch.restype = None
+    L.fwo_learn_minibatch.argtypes = [vp, C.POINTER(Translator), vp, vp, C.c_uint64, vp]
     L.fwo_run_stream.restype = C.c_double
     L.fwo_run_stream.argtypes = [vp, C.POINTER(Translator), vp, vp, C.c_uint64, C.c_uint64, C.c_int, vp]
     _lib_cache[native] = L
@@ -301,6 +303,15 @@ class Model:
     def predict(self, lr=None, ffm=None):
         lr, ffm = self._ex(lr, ffm)
         return self.L.fwo_predict(self.h, _ptr(lr), len(lr), _ptr(ffm), len(ffm))
+
+    def learn_minibatch(self, tspec, records, rec_off):
+        """synchronous micro-batch (fw_oracle.h): all examples scored against the current weights, then all updates"""
+        records = np.ascontiguousarray(records, dtype=np.uint32)
+        rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
+        n = len(rec_off) - 1
+        preds = np.zeros(n, dtype=np.float32)
+        self.L.fwo_learn_minibatch(self.h, C.byref(tspec.c), _ptr(records), _ptr(rec_off), n, _ptr(preds))
+        return preds
 
     def run_stream(self, tspec, records, rec_off, holdout_after=0, nthreads=1, want_preds=True):
         records = np.ascontiguousarray(records, dtype=np.uint32)

@@ -415,6 +415,99 @@ def test_device_translation_of_crafted_records_matches_host_translation():
 
 
 
+
+# ------------------------------------------------------------------ synchronous micro-batches (split pipeline)
+def _sync_parity(n_ns, k, bits, ffm_bits, optimizer, n, mb, seed, mean_extra=1.0, ids=3000, p_weighted=0.2, weight_tol=2e-5,
+                 interactions=(), nn=None, **kw):
+    """fwgpu_learn_batch_sync in the in-order mode == the oracle's micro-batch mode (fw_oracle.h): per micro-batch all
+    examples are scored with the weights of the batch start, then the updates are applied in example order."""
+    mi, ocfg, ots = make_pair(n_ns, k, bits, ffm_bits, optimizer, interactions=interactions, **kw)
+    onn = None
+    if nn:
+        layers, topology, nn_lr, nn_pt, nn_acc = nn
+        mi.nn_layers = [dict(width=w, activation=a, init=i) for w, a, i in layers]
+        mi.nn_topology = topology
+        mi.nn_learning_rate, mi.nn_power_t, mi.nn_init_acc_gradient = nn_lr, nn_pt, nn_acc
+        onn = fwo.make_nn_config(layers, topology, nn_lr, nn_pt, nn_acc)
+    recs, off = fw.synth_records(n_ns, mean_extra, 1.1, ids, p_weighted, seed, 0, n)
+    y = record_labels(recs, off)
+    om = fwo.Model(ocfg, nn=onn)
+    re = fw.Regressor(mi)
+    if nn:
+        L = len(nn[0])
+        w0 = np.concatenate([om.nn_weights(l).copy() for l in range(L + 1)])
+        re.table_write(capi.TABLE_NN_W, w0)
+    fbt = fw.FeatureBufferTranslator(mi)
+    sp = re.split_buffers(mb, 512)
+    worst = 0.0
+    for s0 in range(0, n, mb):
+        e0 = min(n, s0 + mb)
+        sub, so = recs[int(off[s0]):int(off[e0])], off[s0:e0 + 1] - off[s0]
+        p_ref = om.learn_minibatch(ots, sub, so)
+        b = re.record_batch(fbt, sub, so)
+        re.learn_batch_sync(b, sp, capi.MODE_SEQUENTIAL)
+        p_gpu = b.predictions()
+        d = np.abs(logloss(p_gpu, y[s0:e0]) - logloss(p_ref, y[s0:e0])).max()
+        worst = max(worst, d)
+        assert d < LOGLOSS_TOL, f"micro-batch at {s0}: max per-example |d logloss| = {d}"
+        b.close()
+
+    def close(a, b_):
+        return bool(np.all(np.abs(a - b_) <= weight_tol + 1e-5 * np.abs(b_)))
+
+    assert close(re.table_read(capi.TABLE_LR), om.lr_table)
+    if k:
+        assert close(re.table_read(capi.TABLE_FFM_W), om.ffm_weights)
+        assert close(re.table_read(capi.TABLE_FFM_ACC), om.ffm_acc)
+    if nn:
+        w1 = np.concatenate([om.nn_weights(l) for l in range(L + 1)])
+        a1 = np.concatenate([om.nn_acc(l) for l in range(L + 1)])
+        assert close(re.table_read(capi.TABLE_NN_W), w1), np.abs(re.table_read(capi.TABLE_NN_W) - w1).max()
+        if optimizer != fw.Optimizer.SGD:
+            assert close(re.table_read(capi.TABLE_NN_ACC), a1)
+    sp.close()
+    re.close()
+    return worst
+
+
+def test_sync_micro_batch_matches_oracle_micro_batch_mode():
+    _sync_parity(10, 4, 14, 14, fw.Optimizer.AdagradLUT, n=1024, mb=128, seed=51)
+    _sync_parity(30, 8, 18, 18, fw.Optimizer.AdagradLUT, n=192, mb=64, seed=52, mean_extra=5.67, ids=100000, p_weighted=0.1,
+                 interactions=[(0, 1)])
+    _sync_parity(2, 10, 13, 13, fw.Optimizer.AdagradLUT, n=600, mb=100, seed=53, mean_extra=0.0, ids=300, p_weighted=0.0,
+                 interactions=[(0, 1)], power_t=0.0, ffm_power_t=0.0)
+    _sync_parity(6, 8, 12, 12, fw.Optimizer.AdagradFlex, n=512, mb=64, seed=54, init_acc=1.0, ffm_init_acc=1.0, weight_tol=5e-5)
+    _sync_parity(6, 4, 12, 12, fw.Optimizer.SGD, n=512, mb=64, seed=55, lr=0.05, ffm_lr=0.05)
+    _sync_parity(8, 0, 14, 14, fw.Optimizer.AdagradLUT, n=600, mb=50, seed=56, interactions=[(0, 1)])
+    _sync_parity(30, 16, 16, 18, fw.Optimizer.AdagradLUT, n=96, mb=32, seed=57, ids=20000, p_weighted=0.1)
+
+
+def test_sync_micro_batch_hogwild_learns_like_the_fused_kernel():
+    """The concurrent form of the same step on a stream: hold-out loss close to the fused hogwild kernel's."""
+    n_train, n_hold, mb = 16384, 4096, 2048
+    mi, ocfg, ots = make_pair(10, 4, 18, 18, fw.Optimizer.AdagradLUT)
+    recs, off = fw.synth_records(10, 0.0, 1.1, 100000, 0.0, 20240611, 0, n_train + n_hold)
+    y = record_labels(recs, off)
+    losses = []
+    for sync in (False, True):
+        re = fw.Regressor(mi)
+        fbt = fw.FeatureBufferTranslator(mi)
+        sp = re.split_buffers(mb, 64)
+        for s0 in range(0, n_train, mb):
+            b = re.record_batch(fbt, recs[int(off[s0]):int(off[s0 + mb])], off[s0:s0 + mb + 1] - off[s0])
+            if sync:
+                re.learn_batch_sync(b, sp, capi.MODE_HOGWILD)
+            else:
+                re.learn_batch(b, capi.MODE_HOGWILD, True)
+            b.close()
+        hb = re.record_batch(fbt, recs[int(off[n_train]):], off[n_train:] - off[n_train])
+        re.learn_batch(hb, capi.MODE_HOGWILD, False)
+        losses.append(float(logloss(hb.predictions(), y[n_train:]).mean()))
+        sp.close()
+        re.close()
+    print("hold-out: fused hogwild", losses[0], "synchronous micro-batches of", mb, ":", losses[1])
+    assert losses[1] < 0.6931 and abs(losses[1] - losses[0]) < HOLDOUT_TOL
+
 # ------------------------------------------------------------------ serving context cache (SURVEY 8 f4)
 CACHE_TOL = 5e-6  # assert_epsilon! of the reference's *_with_cache tests (block_helpers.rs:30-40)
 
