@@ -124,6 +124,20 @@ def lib():
         "fwgpu_block_cache_filter": [vp, vp, u32, vp, P(u32)],
         "fwgpu_block_cache_free": [vp],
         "fwgpu_batch_set_cache": [vp, vp],
+        "fwgpu_dist_unique_id": [vp, u64],
+        "fwgpu_dist_init": [vp, vp, i32, i32, P(vp)],
+        "fwgpu_dist_free": [vp],
+        "fwgpu_dist_set_mode": [vp, i32],
+        "fwgpu_dist_group_set_mode": [vp, i32],
+        "fwgpu_dist_rank": [vp, P(i32), P(i32)],
+        "fwgpu_dist_ranges": [vp, P(u32), P(u32), P(u32), P(u32)],
+        "fwgpu_dist_learn_sharded": [vp, P(TranslatorConfig), vp, vp, u32, vp],
+        "fwgpu_dist_gather_tables": [vp],
+        "fwgpu_dist_all_reduce_sum": [vp, vp, u64, vp],
+        "fwgpu_dist_group_create": [vp, i32, P(vp)],
+        "fwgpu_dist_group_free": [vp],
+        "fwgpu_dist_group_learn_sharded": [vp, P(TranslatorConfig), vp, vp, u32, vp],
+        "fwgpu_dist_group_gather_tables": [vp],
         "fwgpu_split_create": [vp, u32, u32, P(vp)],
         "fwgpu_split_free": [vp],
         "fwgpu_learn_batch_sync": [vp, vp, vp, i32, vp],

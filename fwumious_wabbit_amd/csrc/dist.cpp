@@ -1,0 +1,504 @@
+// Multi-GPU inside the library (BASELINE configs[3]): one process per GPU over RCCL / xGMI, or -- for tests and
+// single-box emulation -- several ranks inside one process.
+//
+// Mode "sharded" = owner-sharded tables, synchronous micro-batches (what replaces hogwild.rs:24-103 across GPUs):
+//   every rank OWNS a contiguous range of the FFM table and of the LR table (rows are owned by their start address) and keeps
+//   only that range current.  One step takes a micro-batch of B records from every rank:
+//     X1  all-gather the records (a record is ~1.7 KB at config C) and the batch shape
+//     P1  FWD over all N*B examples, owned rows only: partial field sums T / self-pair corrections / LR sums -> split records
+//     X2  reduce-scatter (sum) of the split records: every rank gets the complete records of its own B examples
+//     P2  MID on the own examples: logit, prediction, general gradient
+//     X3  all-gather of the gradients and of the completed records
+//     P3  UPD over all N*B examples, owned rows only: AdaGrad per occurrence, exactly as on one GPU
+//   The result is the synchronous micro-batch of fwgpu_learn_batch_sync with batch N*B, whatever N is (sums of field sums are
+//   taken in another order: 1e-7 relative).  Rows that straddle an ownership boundary (R floats out of table/N) see the next
+//   owner's copy of their tail diverge: 6e-6 of the rows at config C with 8 ranks.
+//
+// RCCL is resolved at run time (dlopen librccl.so.1): a process that never calls fwgpu_dist_init does not load it, and a
+// Python process that already holds torch's copy reuses it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "fwgpu_internal.h"
+
+using namespace fwgpu;
+
+namespace {
+
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::once_flag once;
+    bool ok = false;
+    bool load() {
+        std::call_once(once, [this] {
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (lib) break;
+            }
+            if (!lib) return;
+#define SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(lib, name))
+            SYM(GetUniqueId, "ncclGetUniqueId");
+            SYM(CommInitRank, "ncclCommInitRank");
+            SYM(CommDestroy, "ncclCommDestroy");
+            SYM(AllReduce, "ncclAllReduce");
+            SYM(AllGather, "ncclAllGather");
+            SYM(ReduceScatter, "ncclReduceScatter");
+            SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+            ok = GetUniqueId && CommInitRank && CommDestroy && AllReduce && AllGather && ReduceScatter;
+        });
+        return ok;
+    }
+};
+RcclApi g_rccl;
+
+#define FWGPU_NCCL(call)                                                                                                  \
+    do {                                                                                                                  \
+        ncclResult_t e_ = (call);                                                                                         \
+        if (e_ != ncclSuccess)                                                                                            \
+            return fail(FWGPU_ERR_DEVICE, std::string(#call) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e_) : "RCCL error")); \
+    } while (0)
+
+}  // namespace
+
+// One rank of the job.
+struct fwgpu_dist {
+    fwgpu_regressor *r = nullptr;
+    int rank = 0, n = 1;
+    ncclComm_t comm = nullptr;       // NULL: member of an in-process group
+    hipStream_t stream = nullptr;
+    SplitRanges rg;
+    int mode = FWGPU_MODE_HOGWILD;   // FWGPU_MODE_SEQUENTIAL: every phase on one workgroup, in example order (deterministic: tests)
+    // per-step state (grown on demand)
+    uint32_t B = 0;                  // records per rank in the current step
+    uint64_t wcap = 0;               // words reserved per rank in the gathered batch
+    fwgpu_batch *gb = nullptr;       // gathered record batch, N*B examples
+    uint32_t gb_ncap = 0;
+    uint64_t gb_wcap = 0;
+    fwgpu_split *sp = nullptr;       // split records of the N*B examples
+    uint32_t sp_n = 0, sp_ffm = 0;
+    float *d_own = nullptr;          // [B * split_len] the completed records of the own examples
+    size_t own_cap = 0;
+    uint32_t *d_shape = nullptr;     // [n * 4] per rank: max_lr, max_ffm, max_rec, n_records (all-gathered)
+    const fwgpu_translator_config *tr = nullptr;
+    ~fwgpu_dist() {
+        if (gb) fwgpu_batch_free(gb);
+        if (sp) fwgpu_split_free(sp);
+        if (d_own) (void)hipFree(d_own);
+        if (d_shape) (void)hipFree(d_shape);
+        if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+struct fwgpu_dist_group {
+    std::vector<std::unique_ptr<fwgpu_dist>> ranks;
+};
+
+namespace {
+
+void set_ranges(fwgpu_dist *d) {
+    const fwgpu_regressor *r = d->r;
+    const uint64_t ffm_span = r->cfg.ffm_k ? (1ull << r->cfg.ffm_bit_precision) : 0, lr_span = r->lr_len;
+    // contiguous, equal ranges; row starts are multiples of next_pow2(k) <= 2^ffm_bits / n for every sane n
+    const uint64_t fper = ffm_span / d->n, lper = lr_span / d->n;
+    d->rg.ffm_lo = (uint32_t)(fper * d->rank);
+    d->rg.ffm_hi = d->rank == d->n - 1 ? 0xffffffffu : (uint32_t)(fper * (d->rank + 1));
+    d->rg.lr_lo = (uint32_t)(lper * d->rank);
+    d->rg.lr_hi = d->rank == d->n - 1 ? 0xffffffffu : (uint32_t)(lper * (d->rank + 1));
+}
+
+// ---- step, rank-local parts.  S0: take this rank's records, size the buffers.
+int step_begin(fwgpu_dist *d, const fwgpu_translator_config *t, const uint32_t *records, const uint64_t *rec_off, uint32_t n,
+               uint32_t shape[4]) {
+    if (!t || (n && (!records || !rec_off))) return fail(FWGPU_ERR_INVALID, "dist step: NULL argument");
+    FWGPU_HIP(hipSetDevice(d->r->device));
+    RecordStats st;
+    int rc = count_records(t, records, rec_off, n, &st);
+    if (rc) return rc;
+    shape[0] = st.max_lr;
+    shape[1] = st.max_ffm;
+    shape[2] = st.max_rec;
+    shape[3] = n;
+    d->tr = t;
+    d->B = n;
+    return FWGPU_OK;
+}
+
+// after the shapes of all ranks are known: (re)allocate the gathered batch and the split buffers, upload the own records into
+// their slot of the gathered batch
+int step_upload(fwgpu_dist *d, const uint32_t *records, const uint64_t *rec_off, const uint32_t *shapes /*[n*4]*/) {
+    uint32_t max_lr = 0, max_ffm = 0, max_rec = 0;
+    for (int j = 0; j < d->n; j++) {
+        if (shapes[4 * j + 3] != d->B) return fail(FWGPU_ERR_INVALID, "sharded step: every rank must bring the same number of records");
+        max_lr = std::max(max_lr, shapes[4 * j]);
+        max_ffm = std::max(max_ffm, shapes[4 * j + 1]);
+        max_rec = std::max(max_rec, shapes[4 * j + 2]);
+    }
+    const uint32_t B = d->B, NB = B * (uint32_t)d->n;
+    const uint64_t wcap = ((uint64_t)B * max_rec + 63) & ~63ull;  // words per rank (upper bound: every record of maximal length)
+    d->wcap = wcap;
+    if (!d->gb || d->gb_ncap < NB || d->gb_wcap < wcap * d->n) {
+        if (d->gb) fwgpu_batch_free(d->gb);
+        d->gb = nullptr;
+        int rc = record_batch_alloc(d->r, d->tr, NB, wcap * d->n, &d->gb);
+        if (rc) return rc;
+        d->gb_ncap = NB;
+        d->gb_wcap = wcap * d->n;
+    }
+    if (!d->sp || d->sp_n < NB || d->sp_ffm < max_ffm) {
+        if (d->sp) fwgpu_split_free(d->sp);
+        d->sp = nullptr;
+        int rc = fwgpu_split_create(d->r, NB, std::max<uint32_t>(max_ffm, 16), &d->sp);
+        if (rc) return rc;
+        d->sp_n = NB;
+        d->sp_ffm = max_ffm;
+    }
+    const size_t own_floats = (size_t)B * d->sp->split_len;
+    if (d->own_cap < own_floats) {
+        if (d->d_own) (void)hipFree(d->d_own);
+        d->d_own = nullptr;
+        FWGPU_HIP(hipMalloc((void **)&d->d_own, own_floats * 4));
+        d->own_cap = own_floats;
+    }
+    fwgpu_batch *gb = d->gb;
+    gb->n = NB;
+    gb->max_lr = d->r->cfg.wiring == FWGPU_WIRING_FFM_ONLY ? 0 : max_lr;
+    gb->max_ffm = max_ffm;
+    gb->max_rec = max_rec;
+    gb->aligned4 = true;
+    gb->rec_self_len = true;
+    // own records into slot `rank`: words at rank * wcap, offsets rebased onto the gathered buffer
+    const uint64_t words = B ? rec_off[B] - rec_off[0] : 0;
+    if (words > wcap) return fail(FWGPU_ERR_RANGE, "sharded step: records longer than announced");
+    std::vector<uint64_t> off(B);
+    for (uint32_t i = 0; i < B; i++) off[i] = rec_off[i] - rec_off[0] + wcap * d->rank;
+    if (B) {
+        FWGPU_HIP(hipMemcpyAsync(gb->records + wcap * d->rank, records + rec_off[0], words * 4, hipMemcpyHostToDevice, d->stream));
+        FWGPU_HIP(hipMemcpyAsync(gb->rec_off + (size_t)B * d->rank, off.data(), (size_t)B * 8, hipMemcpyHostToDevice, d->stream));
+        FWGPU_HIP(hipStreamSynchronize(d->stream));  // `off` lives on this stack frame
+    }
+    return FWGPU_OK;
+}
+
+int phase_fwd(fwgpu_dist *d) {
+    SplitRanges rg = d->rg;
+    rg.home_lo = d->B * d->rank;
+    rg.home_hi = d->B * (d->rank + 1);
+    return split_forward(d->r, d->gb, d->sp, d->mode, rg, d->stream);
+}
+int phase_mid(fwgpu_dist *d) {
+    // the completed records of the own examples sit in d_own; MID reads them through a split view of their own
+    fwgpu_split view = *d->sp;
+    view.d_split = d->d_own;
+    view.d_g = d->sp->d_g + (size_t)d->B * d->rank;  // own slice of the gathered gradient array
+    return split_mid(d->r, &view, 0, d->B, d->gb->pred + (size_t)d->B * d->rank, false, d->stream);
+}
+int phase_upd(fwgpu_dist *d) { return split_update(d->r, d->gb, d->sp, d->mode, d->rg, false, d->stream); }
+
+int finish(fwgpu_dist *d, float *preds) {
+    if (preds && d->B)
+        FWGPU_HIP(hipMemcpyAsync(preds, d->gb->pred + (size_t)d->B * d->rank, (size_t)d->B * 4, hipMemcpyDeviceToHost, d->stream));
+    FWGPU_HIP(hipStreamSynchronize(d->stream));
+    return FWGPU_OK;
+}
+
+int make_rank(fwgpu_regressor *r, int rank, int n, fwgpu_dist **out) {
+    if (!r || !out || n < 1 || rank < 0 || rank >= n) return fail(FWGPU_ERR_INVALID, "dist: bad rank / size");
+    if (r->nn.n_layers) return fail(FWGPU_ERR_INVALID, "dist: the sharded mode does not cover models with a deep head yet");
+    if (r->cfg.ffm_k && ((1ull << r->cfg.ffm_bit_precision) / n) % 64 != 0)
+        return fail(FWGPU_ERR_INVALID, "dist: the FFM table does not split into n ranges of whole 256 B blocks");
+    FWGPU_HIP(hipSetDevice(r->device));
+    std::unique_ptr<fwgpu_dist> d(new fwgpu_dist());
+    d->r = r;
+    d->rank = rank;
+    d->n = n;
+    FWGPU_HIP(hipDeviceSynchronize());  // (the rank's stream does not wait for the NULL stream: table initialisation must be done)
+    FWGPU_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    FWGPU_HIP(hipMalloc((void **)&d->d_shape, (size_t)n * 4 * sizeof(uint32_t)));
+    set_ranges(d.get());
+    *out = d.release();
+    return FWGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------ RCCL: one rank per process
+int fwgpu_dist_unique_id(uint8_t *id, uint64_t cap) {
+    if (!id || cap < sizeof(ncclUniqueId)) return fail(FWGPU_ERR_INVALID, "unique id buffer must hold 128 bytes");
+    if (!g_rccl.load()) return fail(FWGPU_ERR_DEVICE, "librccl.so.1 is not available");
+    ncclUniqueId u;
+    FWGPU_NCCL(g_rccl.GetUniqueId(&u));
+    std::memcpy(id, &u, sizeof(u));
+    return FWGPU_OK;
+}
+
+int fwgpu_dist_init(fwgpu_regressor *r, const uint8_t *unique_id, int rank, int n_ranks, fwgpu_dist **out) {
+    if (!unique_id) return fail(FWGPU_ERR_INVALID, "NULL unique id");
+    if (!g_rccl.load()) return fail(FWGPU_ERR_DEVICE, "librccl.so.1 is not available");
+    fwgpu_dist *d = nullptr;
+    int rc = make_rank(r, rank, n_ranks, &d);
+    if (rc) return rc;
+    ncclUniqueId u;
+    std::memcpy(&u, unique_id, sizeof(u));
+    ncclResult_t e = g_rccl.CommInitRank(&d->comm, n_ranks, u, rank);
+    if (e != ncclSuccess) {
+        delete d;
+        return fail(FWGPU_ERR_DEVICE, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "failed"));
+    }
+    *out = d;
+    return FWGPU_OK;
+}
+
+int fwgpu_dist_free(fwgpu_dist *d) {
+    delete d;
+    return FWGPU_OK;
+}
+
+int fwgpu_dist_set_mode(fwgpu_dist *d, int mode) {
+    if (!d || (mode != FWGPU_MODE_SEQUENTIAL && mode != FWGPU_MODE_HOGWILD)) return fail(FWGPU_ERR_INVALID, "dist_set_mode: bad argument");
+    d->mode = mode;
+    return FWGPU_OK;
+}
+
+int fwgpu_dist_rank(const fwgpu_dist *d, int *rank, int *n_ranks) {
+    if (!d) return fail(FWGPU_ERR_INVALID, "NULL dist");
+    if (rank) *rank = d->rank;
+    if (n_ranks) *n_ranks = d->n;
+    return FWGPU_OK;
+}
+
+// what this rank owns: FFM rows starting in [ffm_lo, ffm_hi), LR entries [lr_lo, lr_hi)  (hi == 0xffffffff: to the end)
+int fwgpu_dist_ranges(const fwgpu_dist *d, uint32_t *ffm_lo, uint32_t *ffm_hi, uint32_t *lr_lo, uint32_t *lr_hi) {
+    if (!d) return fail(FWGPU_ERR_INVALID, "NULL dist");
+    if (ffm_lo) *ffm_lo = d->rg.ffm_lo;
+    if (ffm_hi) *ffm_hi = d->rg.ffm_hi;
+    if (lr_lo) *lr_lo = d->rg.lr_lo;
+    if (lr_hi) *lr_hi = d->rg.lr_hi;
+    return FWGPU_OK;
+}
+
+// One sharded step: this rank's micro-batch of n records in, their n predictions out (host buffer, may be NULL).  Collective:
+// every rank of the job calls it with the same n.
+int fwgpu_dist_learn_sharded(fwgpu_dist *d, const fwgpu_translator_config *t, const uint32_t *records, const uint64_t *rec_off,
+                             uint32_t n, float *preds) {
+    if (!d || !d->comm) return fail(FWGPU_ERR_INVALID, "not an RCCL rank (fwgpu_dist_init)");
+    uint32_t shape[4];
+    int rc = step_begin(d, t, records, rec_off, n, shape);
+    if (rc) return rc;
+    // X1a: batch shapes
+    FWGPU_HIP(hipMemcpyAsync(d->d_shape + 4 * d->rank, shape, sizeof(shape), hipMemcpyHostToDevice, d->stream));
+    FWGPU_NCCL(g_rccl.AllGather(d->d_shape + 4 * d->rank, d->d_shape, 4, ncclUint32, d->comm, d->stream));
+    std::vector<uint32_t> shapes((size_t)d->n * 4);
+    FWGPU_HIP(hipMemcpyAsync(shapes.data(), d->d_shape, shapes.size() * 4, hipMemcpyDeviceToHost, d->stream));
+    FWGPU_HIP(hipStreamSynchronize(d->stream));
+    rc = step_upload(d, records, rec_off, shapes.data());
+    if (rc) return rc;
+    if (n == 0) return FWGPU_OK;
+    fwgpu_batch *gb = d->gb;
+    const uint32_t B = d->B;
+    const size_t SL = d->sp->split_len;
+    // X1b: records and their offsets (in place: every rank's slot of the gathered batch)
+    FWGPU_NCCL(g_rccl.AllGather(gb->records + d->wcap * d->rank, gb->records, d->wcap, ncclUint32, d->comm, d->stream));
+    FWGPU_NCCL(g_rccl.AllGather(gb->rec_off + (size_t)B * d->rank, gb->rec_off, B, ncclUint64, d->comm, d->stream));
+    rc = phase_fwd(d);
+    if (rc) return rc;
+    // X2: every rank receives the sum of all ranks' partial records of ITS examples
+    FWGPU_NCCL(g_rccl.ReduceScatter(d->sp->d_split, d->d_own, (size_t)B * SL, ncclFloat, ncclSum, d->comm, d->stream));
+    rc = phase_mid(d);
+    if (rc) return rc;
+    // X3: gradients and completed records to everyone
+    FWGPU_NCCL(g_rccl.AllGather(d->sp->d_g + (size_t)B * d->rank, d->sp->d_g, B, ncclFloat, d->comm, d->stream));
+    FWGPU_NCCL(g_rccl.AllGather(d->d_own, d->sp->d_split, (size_t)B * SL, ncclFloat, d->comm, d->stream));
+    rc = phase_upd(d);
+    if (rc) return rc;
+    return finish(d, preds);
+}
+
+// Every rank's owned range into every rank's tables (before saving the model, or before predicting on one GPU).
+int fwgpu_dist_gather_tables(fwgpu_dist *d) {
+    if (!d || !d->comm) return fail(FWGPU_ERR_INVALID, "not an RCCL rank (fwgpu_dist_init)");
+    fwgpu_regressor *r = d->r;
+    FWGPU_HIP(hipSetDevice(r->device));
+    if (r->cfg.ffm_k) {
+        const uint64_t per = (1ull << r->cfg.ffm_bit_precision) / d->n;
+        FWGPU_NCCL(g_rccl.AllGather(r->d_ffm_w + per * d->rank, r->d_ffm_w, per, ncclFloat, d->comm, d->stream));
+        FWGPU_NCCL(g_rccl.AllGather(r->d_ffm_acc + per * d->rank, r->d_ffm_acc, per, ncclFloat, d->comm, d->stream));
+        // the spill-over tail behind 2^ffm_bits belongs to the last rank
+        const uint64_t tail = r->ffm_len - (1ull << r->cfg.ffm_bit_precision);
+        if (tail && d->n > 1) {
+            // (broadcast from the last rank through an all-reduce of a masked copy would need scratch; the tail is R floats:
+            // a gather of one block more from the last rank is the cheap route)
+            // every rank contributes its tail; the last rank's is kept
+            float *tmp = nullptr;
+            FWGPU_HIP(hipMalloc((void **)&tmp, tail * 4 * d->n * 2));
+            FWGPU_NCCL(g_rccl.AllGather(r->d_ffm_w + (1ull << r->cfg.ffm_bit_precision), tmp, tail, ncclFloat, d->comm, d->stream));
+            FWGPU_NCCL(g_rccl.AllGather(r->d_ffm_acc + (1ull << r->cfg.ffm_bit_precision), tmp + tail * d->n, tail, ncclFloat, d->comm, d->stream));
+            FWGPU_HIP(hipMemcpyAsync(r->d_ffm_w + (1ull << r->cfg.ffm_bit_precision), tmp + tail * (d->n - 1), tail * 4, hipMemcpyDeviceToDevice, d->stream));
+            FWGPU_HIP(hipMemcpyAsync(r->d_ffm_acc + (1ull << r->cfg.ffm_bit_precision), tmp + tail * d->n + tail * (d->n - 1), tail * 4, hipMemcpyDeviceToDevice, d->stream));
+            FWGPU_HIP(hipStreamSynchronize(d->stream));
+            (void)hipFree(tmp);
+        }
+    }
+    const uint64_t lper = r->lr_len / d->n;  // entries of 2 floats ({w, acc}; SGD keeps the same stride on the device)
+    FWGPU_NCCL(g_rccl.AllGather(r->d_lr + 2 * lper * d->rank, r->d_lr, 2 * lper, ncclFloat, d->comm, d->stream));
+    FWGPU_HIP(hipStreamSynchronize(d->stream));
+    return FWGPU_OK;
+}
+
+// Dense all-reduce of a device float buffer over the job (replica mode: table deltas; deep head: dense gradient sums)
+int fwgpu_dist_all_reduce_sum(fwgpu_dist *d, float *device_buf, uint64_t count, void *hip_stream) {
+    if (!d || !d->comm) return fail(FWGPU_ERR_INVALID, "not an RCCL rank (fwgpu_dist_init)");
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : d->stream;
+    FWGPU_NCCL(g_rccl.AllReduce(device_buf, device_buf, count, ncclFloat, ncclSum, d->comm, s));
+    if (!hip_stream) FWGPU_HIP(hipStreamSynchronize(s));
+    return FWGPU_OK;
+}
+
+// ------------------------------------------------------------------ in-process group: the same step, collectives by copies
+// n regressors (one per rank; usually all on one device, which is how the one-GPU box emulates N GPUs and how the tests run).
+int fwgpu_dist_group_create(fwgpu_regressor *const *regs, int n, fwgpu_dist_group **out) {
+    if (!regs || !out || n < 1) return fail(FWGPU_ERR_INVALID, "dist group: bad argument");
+    std::unique_ptr<fwgpu_dist_group> g(new fwgpu_dist_group());
+    for (int i = 0; i < n; i++) {
+        fwgpu_dist *d = nullptr;
+        int rc = make_rank(regs[i], i, n, &d);
+        if (rc) return rc;
+        g->ranks.emplace_back(d);
+    }
+    *out = g.release();
+    return FWGPU_OK;
+}
+
+int fwgpu_dist_group_set_mode(fwgpu_dist_group *g, int mode) {
+    if (!g) return fail(FWGPU_ERR_INVALID, "NULL group");
+    for (auto &d : g->ranks) {
+        int rc = fwgpu_dist_set_mode(d.get(), mode);
+        if (rc) return rc;
+    }
+    return FWGPU_OK;
+}
+
+int fwgpu_dist_group_free(fwgpu_dist_group *g) {
+    delete g;
+    return FWGPU_OK;
+}
+
+int fwgpu_dist_group_learn_sharded(fwgpu_dist_group *g, const fwgpu_translator_config *t, const uint32_t *const *records,
+                                   const uint64_t *const *rec_off, uint32_t n, float *const *preds) {
+    if (!g || !records || !rec_off) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    const int N = (int)g->ranks.size();
+    std::vector<uint32_t> shapes((size_t)N * 4);
+    for (int j = 0; j < N; j++) {
+        int rc = step_begin(g->ranks[j].get(), t, records[j], rec_off[j], n, &shapes[4 * j]);
+        if (rc) return rc;
+    }
+    for (int j = 0; j < N; j++) {
+        int rc = step_upload(g->ranks[j].get(), records[j], rec_off[j], shapes.data());
+        if (rc) return rc;
+    }
+    if (n == 0) return FWGPU_OK;
+    const uint32_t B = n;
+    const size_t SL = g->ranks[0]->sp->split_len;
+    auto sync_all = [&]() -> int {
+        for (auto &d : g->ranks) FWGPU_HIP(hipStreamSynchronize(d->stream));
+        return FWGPU_OK;
+    };
+    // X1: all-gather of records and offsets = copy slot j of rank j into slot j of everyone else
+    for (int j = 0; j < N; j++) {
+        fwgpu_dist *src = g->ranks[j].get();
+        for (int i = 0; i < N; i++) {
+            if (i == j) continue;
+            fwgpu_dist *dst = g->ranks[i].get();
+            FWGPU_HIP(hipMemcpyAsync(dst->gb->records + dst->wcap * j, src->gb->records + src->wcap * j, src->wcap * 4, hipMemcpyDeviceToDevice, dst->stream));
+            FWGPU_HIP(hipMemcpyAsync(dst->gb->rec_off + (size_t)B * j, src->gb->rec_off + (size_t)B * j, (size_t)B * 8, hipMemcpyDeviceToDevice, dst->stream));
+        }
+    }
+    int rc = sync_all();
+    if (rc) return rc;
+    for (auto &d : g->ranks) {
+        rc = phase_fwd(d.get());
+        if (rc) return rc;
+    }
+    rc = sync_all();
+    if (rc) return rc;
+    // X2: reduce-scatter: rank i's own records = sum over ranks j (in rank order) of j's partial records of i's examples
+    for (int i = 0; i < N; i++) {
+        fwgpu_dist *dst = g->ranks[i].get();
+        for (int j = 0; j < N; j++) {
+            const float *part = g->ranks[j]->sp->d_split + (size_t)B * i * SL;
+            if (j == 0)
+                FWGPU_HIP(hipMemcpyAsync(dst->d_own, part, (size_t)B * SL * 4, hipMemcpyDeviceToDevice, dst->stream));
+            else
+                FWGPU_HIP(launch_add(dst->d_own, part, (uint64_t)B * SL, dst->stream));
+        }
+    }
+    rc = sync_all();
+    if (rc) return rc;
+    for (auto &d : g->ranks) {
+        rc = phase_mid(d.get());
+        if (rc) return rc;
+    }
+    rc = sync_all();
+    if (rc) return rc;
+    // X3: all-gather of gradients and completed records
+    for (int j = 0; j < N; j++) {
+        fwgpu_dist *src = g->ranks[j].get();
+        for (int i = 0; i < N; i++) {
+            fwgpu_dist *dst = g->ranks[i].get();
+            if (i != j)
+                FWGPU_HIP(hipMemcpyAsync(dst->sp->d_g + (size_t)B * j, src->sp->d_g + (size_t)B * j, (size_t)B * 4, hipMemcpyDeviceToDevice, dst->stream));
+            FWGPU_HIP(hipMemcpyAsync(dst->sp->d_split + (size_t)B * j * SL, src->d_own, (size_t)B * SL * 4, hipMemcpyDeviceToDevice, dst->stream));
+        }
+    }
+    rc = sync_all();
+    if (rc) return rc;
+    for (auto &d : g->ranks) {
+        rc = phase_upd(d.get());
+        if (rc) return rc;
+    }
+    for (int j = 0; j < N; j++) {
+        rc = finish(g->ranks[j].get(), preds ? preds[j] : nullptr);
+        if (rc) return rc;
+    }
+    return FWGPU_OK;
+}
+
+// every rank's owned range into every rank's tables
+int fwgpu_dist_group_gather_tables(fwgpu_dist_group *g) {
+    if (!g) return fail(FWGPU_ERR_INVALID, "NULL group");
+    const int N = (int)g->ranks.size();
+    for (int j = 0; j < N; j++) {
+        fwgpu_regressor *src = g->ranks[j]->r;
+        for (int i = 0; i < N; i++) {
+            if (i == j) continue;
+            fwgpu_regressor *dst = g->ranks[i]->r;
+            if (src->cfg.ffm_k) {
+                const uint64_t span = 1ull << src->cfg.ffm_bit_precision, per = span / N;
+                const uint64_t lo = per * j, cnt = j == N - 1 ? src->ffm_len - lo : per;
+                FWGPU_HIP(hipMemcpy(dst->d_ffm_w + lo, src->d_ffm_w + lo, cnt * 4, hipMemcpyDeviceToDevice));
+                FWGPU_HIP(hipMemcpy(dst->d_ffm_acc + lo, src->d_ffm_acc + lo, cnt * 4, hipMemcpyDeviceToDevice));
+            }
+            const uint64_t lper = src->lr_len / N, llo = lper * j, lcnt = j == N - 1 ? src->lr_len - llo : lper;
+            FWGPU_HIP(hipMemcpy(dst->d_lr + 2 * llo, src->d_lr + 2 * llo, lcnt * 8, hipMemcpyDeviceToDevice));
+        }
+    }
+    return FWGPU_OK;
+}
+
+}  // extern "C"

@@ -78,6 +78,7 @@ struct KernelParams {
     const uint32_t *records;
     const uint64_t *rec_off;  // [n+1] u32-word offsets
     uint32_t max_rec;         // longest record of the batch, in words (LDS capacity)
+    int32_t rec_self_len;     // record lengths come from the records' word 0 (gathered batches have gaps between ranks)
     DevTranslator tr;
     DevNN nn;
     uint32_t num_combos;
@@ -137,6 +138,7 @@ uint32_t split_record_len(uint32_t F, uint32_t R, uint32_t nlr);
 hipError_t launch_ffm_init(float *w, float *acc, uint64_t len, uint32_t k, float init_width, float init_zero_band,
                            float init_center, float acc0, hipStream_t stream);
 hipError_t launch_fill(float *p, uint64_t n, float v, hipStream_t stream);
+hipError_t launch_add(float *dst, const float *src, uint64_t n, hipStream_t stream);
 hipError_t launch_fill_lr(float *lr, uint64_t n_entries, float w, float acc, hipStream_t stream);
 hipError_t launch_checksum(const float *p, uint64_t n, unsigned long long *out, hipStream_t stream);
 hipError_t launch_delta_start(const float *t, const float *s0, float *d, float *D, uint64_t n, float scale, hipStream_t stream);
@@ -173,6 +175,7 @@ struct fwgpu_batch {
     uint32_t *records = nullptr;
     uint64_t *rec_off = nullptr;
     uint32_t max_rec = 0;
+    bool rec_self_len = false;
     uint64_t n_words = 0;
     uint64_t words_cap = 0;
     uint32_t n_cap = 0;

@@ -339,7 +339,9 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
     if (p.records) {
         const uint64_t r0 = p.rec_off[ex];
         grec = p.records + r0;
-        rec_len = (uint32_t)(p.rec_off[ex + 1] - r0);
+        // gathered batches (sharded multi-GPU step) have gaps between the ranks' records: the record carries its own
+        // length in word 0 (parser.rs:57-60)
+        rec_len = p.rec_self_len ? grec[0] : (uint32_t)(p.rec_off[ex + 1] - r0);
         o.label = (float)grec[1];              // feature_buffer.rs:187
         o.imp = __uint_as_float(grec[2]);      // feature_buffer.rs:188-189
         o.nf = o.nl = 0;
@@ -2068,6 +2070,16 @@ hipError_t launch_checksum(const float *p, uint64_t n, unsigned long long *out, 
     return hipGetLastError();
 }
 
+
+__global__ void add_kernel(float *dst, const float *src, unsigned long long n) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] += src[i];
+}
+hipError_t launch_add(float *dst, const float *src, uint64_t n, hipStream_t stream) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(add_kernel, dim3(1024), dim3(256), 0, stream, dst, src, (unsigned long long)n);
+    return hipGetLastError();
+}
 
 // ------------------------------------------------------------------ replica delta bookkeeping (multi-GPU sync)
 // start : d = D = t - s0                    (D is then all-reduced in place over RCCL)

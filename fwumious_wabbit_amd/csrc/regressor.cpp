@@ -325,6 +325,7 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
         p.emit_dcf = b->emit_dcf;
     }
     p.records = b->records;
+    p.rec_self_len = b->rec_self_len ? 1 : 0;
     p.rec_off = b->rec_off;
     p.max_rec = (b->max_rec + 3) & ~3u;
     p.tr = b->tr;

@@ -1,0 +1,101 @@
+"""Multi-GPU inside libfwgpu (include/fwgpu.h, fwgpu_dist_*): owner-sharded synchronous steps over RCCL, one process per GPU
+(DistRank), or with every rank inside this process (DistGroup: tests, single-box emulation of an N-GPU job)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+from ._capi import check, ptr
+
+
+def unique_id() -> bytes:
+    """ncclGetUniqueId: call on ONE rank, hand the 128 bytes to all ranks (e.g. torch.distributed.broadcast_object_list)"""
+    buf = (C.c_uint8 * 128)()
+    check(capi.lib().fwgpu_dist_unique_id(buf, 128))
+    return bytes(buf)
+
+
+def _recs(records, rec_off):
+    return np.ascontiguousarray(records, dtype=np.uint32), np.ascontiguousarray(rec_off, dtype=np.uint64)
+
+
+class DistRank:
+    """one rank of an RCCL job (fwgpu_dist_init); every rank builds the same model first"""
+
+    def __init__(self, regressor, uid: bytes, rank: int, n_ranks: int):
+        self.h = C.c_void_p()
+        self.regressor = regressor
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        check(capi.lib().fwgpu_dist_init(regressor.h, buf, rank, n_ranks, C.byref(self.h)))
+        self.rank, self.n = rank, n_ranks
+
+    def set_mode(self, mode):
+        check(capi.lib().fwgpu_dist_set_mode(self.h, mode))
+
+    def ranges(self):
+        v = [C.c_uint32() for _ in range(4)]
+        check(capi.lib().fwgpu_dist_ranges(self.h, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
+    def learn_sharded(self, translator, records, rec_off) -> np.ndarray:
+        records, rec_off = _recs(records, rec_off)
+        n = len(rec_off) - 1
+        out = np.zeros(n, dtype=np.float32)
+        check(capi.lib().fwgpu_dist_learn_sharded(self.h, C.byref(translator.c), ptr(records), rec_off.ctypes.data_as(C.c_void_p), n, ptr(out)))
+        return out
+
+    def gather_tables(self):
+        check(capi.lib().fwgpu_dist_gather_tables(self.h))
+
+    def all_reduce_sum(self, device_ptr: int, count: int, stream=None):
+        check(capi.lib().fwgpu_dist_all_reduce_sum(self.h, C.c_void_p(device_ptr), count, stream))
+
+    def close(self):
+        if self.h:
+            capi.lib().fwgpu_dist_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DistGroup:
+    """all ranks of a job inside this process (fwgpu_dist_group_*): regressors[j] is rank j's model"""
+
+    def __init__(self, regressors):
+        self.regressors = list(regressors)
+        self.n = len(self.regressors)
+        arr = (C.c_void_p * self.n)(*[r.h for r in self.regressors])
+        self.h = C.c_void_p()
+        check(capi.lib().fwgpu_dist_group_create(arr, self.n, C.byref(self.h)))
+
+    def set_mode(self, mode):
+        check(capi.lib().fwgpu_dist_group_set_mode(self.h, mode))
+
+    def learn_sharded(self, translator, records_per_rank, rec_off_per_rank):
+        """one step: rank j brings records_per_rank[j] (the same number of records on every rank) -> its predictions"""
+        rr = [_recs(a, b) for a, b in zip(records_per_rank, rec_off_per_rank)]
+        n = len(rr[0][1]) - 1
+        outs = [np.zeros(n, dtype=np.float32) for _ in rr]
+        recp = (C.c_void_p * self.n)(*[a.ctypes.data for a, _ in rr])
+        offp = (C.c_void_p * self.n)(*[b.ctypes.data for _, b in rr])
+        outp = (C.c_void_p * self.n)(*[o.ctypes.data for o in outs])
+        check(capi.lib().fwgpu_dist_group_learn_sharded(self.h, C.byref(translator.c), recp, offp, n, outp))
+        return outs
+
+    def gather_tables(self):
+        check(capi.lib().fwgpu_dist_group_gather_tables(self.h))
+
+    def close(self):
+        if self.h:
+            capi.lib().fwgpu_dist_group_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -249,6 +249,43 @@ int fwgpu_batch_from_records(fwgpu_regressor *r, const fwgpu_translator_config *
 int fwgpu_record_batch_create(fwgpu_regressor *r, const fwgpu_translator_config *t, const uint32_t *records,
                               const uint64_t *rec_off, uint32_t n, fwgpu_batch **out);
 
+/* ---------------------------------------------------------------- multi-GPU (replaces hogwild.rs:24-103 across GPUs)
+ * One process per GPU over RCCL / xGMI.  fwgpu_dist_unique_id on one rank, the 128 bytes to every rank by any side channel
+ * (the Rust caller of hogwild.rs:51-60 would use its own launcher's), then fwgpu_dist_init on every rank with its regressor
+ * (every rank creates and initialises the SAME model: weight init is deterministic).
+ *
+ * fwgpu_dist_learn_sharded: the owner-sharded synchronous step.  Every rank owns a contiguous range of the FFM table and of
+ * the LR table (fwgpu_dist_ranges) and brings a micro-batch of n records; the records are all-gathered, every rank gathers
+ * the rows it owns for ALL examples, the partial field sums are reduce-scattered to the examples' home ranks, which compute
+ * prediction and gradient; gradients and field sums are all-gathered and every rank applies the AdaGrad updates of the rows it
+ * owns.  Semantics: fwgpu_learn_batch_sync with a micro-batch of n_ranks * n examples (every example sees the weights of the
+ * step's start; per-occurrence AdaGrad on every row, as on one GPU).  Collective call: same n on every rank.
+ * fwgpu_dist_gather_tables: every rank's owned range into every rank's tables (before saving or single-GPU prediction).
+ * fwgpu_dist_all_reduce_sum: plain RCCL all-reduce of a device float buffer (replica mode: table deltas).
+ * The fwgpu_dist_group_* functions run the same step with all ranks inside ONE process (collectives become device copies):
+ * the tests and the single-box emulation of an N-GPU job use them. */
+typedef struct fwgpu_dist fwgpu_dist;
+typedef struct fwgpu_dist_group fwgpu_dist_group;
+int fwgpu_dist_unique_id(uint8_t *id, uint64_t cap /* >= 128 */);
+int fwgpu_dist_init(fwgpu_regressor *r, const uint8_t *unique_id, int rank, int n_ranks, fwgpu_dist **out);
+int fwgpu_dist_free(fwgpu_dist *d);
+/* FWGPU_MODE_HOGWILD (default): the examples of a phase run concurrently; FWGPU_MODE_SEQUENTIAL: in example order on one
+ * workgroup (deterministic, for parity checks) */
+int fwgpu_dist_set_mode(fwgpu_dist *d, int mode);
+int fwgpu_dist_group_set_mode(fwgpu_dist_group *g, int mode);
+int fwgpu_dist_rank(const fwgpu_dist *d, int *rank, int *n_ranks);
+int fwgpu_dist_ranges(const fwgpu_dist *d, uint32_t *ffm_lo, uint32_t *ffm_hi, uint32_t *lr_lo, uint32_t *lr_hi);
+int fwgpu_dist_learn_sharded(fwgpu_dist *d, const fwgpu_translator_config *t, const uint32_t *records, const uint64_t *rec_off,
+                             uint32_t n, float *predictions);
+int fwgpu_dist_gather_tables(fwgpu_dist *d);
+int fwgpu_dist_all_reduce_sum(fwgpu_dist *d, float *device_buf, uint64_t count, void *hip_stream);
+int fwgpu_dist_group_create(fwgpu_regressor *const *regressors, int n_ranks, fwgpu_dist_group **out);
+int fwgpu_dist_group_free(fwgpu_dist_group *g);
+int fwgpu_dist_group_learn_sharded(fwgpu_dist_group *g, const fwgpu_translator_config *t, const uint32_t *const *records,
+                                   const uint64_t *const *rec_off, uint32_t n, float *const *predictions);
+int fwgpu_dist_group_gather_tables(fwgpu_dist_group *g);
+
+
 /* ---------------------------------------------------------------- HogwildTrainer replacement
  * fwgpu_trainer_create  <= HogwildTrainer::new(regressor, &model_instance, num_workers)  hogwild.rs:24-49
  * fwgpu_digest_records  <= HogwildTrainer::digest_example(Vec<u32>)                      hogwild.rs:51-53

@@ -1,0 +1,139 @@
+"""Multi-GPU modes inside the library, on the one-GPU box: all ranks of a job inside one process
+(fwgpu_dist_group_*: the same step as the RCCL path, collectives done by device copies)."""
+import numpy as np
+import pytest
+
+import fwumious_wabbit_amd as fw
+from fwumious_wabbit_amd import _capi as capi
+from fwumious_wabbit_amd.dist import DistGroup
+from helpers import logloss, make_pair, record_labels
+from oracle import fwo
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_sharded(n_ranks, mi, recs, off, per_rank, n_steps, mode=capi.MODE_SEQUENTIAL):
+    regs = [fw.Regressor(mi) for _ in range(n_ranks)]
+    fbt = fw.FeatureBufferTranslator(mi)
+    g = DistGroup(regs)
+    g.set_mode(mode)
+    preds = np.zeros(n_steps * n_ranks * per_rank, dtype=np.float32)
+    for s in range(n_steps):
+        base = s * n_ranks * per_rank
+        rr, oo = [], []
+        for j in range(n_ranks):
+            a, b = base + j * per_rank, base + (j + 1) * per_rank
+            rr.append(recs[int(off[a]):int(off[b])])
+            oo.append(off[a:b + 1] - off[a])
+        outs = g.learn_sharded(fbt, rr, oo)
+        for j in range(n_ranks):
+            preds[base + j * per_rank: base + (j + 1) * per_rank] = outs[j]
+    g.gather_tables()
+    tables = [[r.table_read(t) for t in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)] for r in regs]
+    g.close()
+    for r in regs:
+        r.close()
+    return preds, tables
+
+
+@pytest.mark.parametrize("n_ns,k,bits,ffm_bits,extra,ids", [(10, 4, 14, 14, 0.0, 3000), (30, 8, 16, 18, 3.0, 50000)])
+def test_sharded_step_equals_the_single_gpu_synchronous_step(n_ns, k, bits, ffm_bits, extra, ids):
+    """N ranks x B records per step == one GPU running fwgpu_learn_batch_sync on the N*B records, == the oracle's micro-batch
+    mode: predictions per example and final tables (after gather_tables every rank holds the whole model)."""
+    mi, ocfg, ots = make_pair(n_ns, k, bits, ffm_bits, fw.Optimizer.AdagradLUT, lr=0.05, ffm_lr=0.05)
+    steps, gb = 6, 96  # global micro-batch of 96 examples
+    R = n_ns * k
+    # Rows that START below an ownership boundary and reach across it are updated in their owner's copy only (dist.cpp header):
+    # the one place where N ranks differ from one table.  These test tables are tiny (R / (table / N) = 0.4 % here, 6e-6 at
+    # config C), so the comparison runs on examples without such rows; their effect is measured in the next test.
+    recs0, off0 = fw.synth_records(n_ns, extra, 1.1, ids, 0.1, 81, 0, 3 * steps * gb)
+    fbt0 = fw.FeatureBufferTranslator(mi)
+    bounds = [j * (1 << ffm_bits) // 4 for j in range(1, 4)]
+    keep_rec = []
+    for i in range(len(off0) - 1):
+        h = np.asarray(fbt0.translate(recs0[int(off0[i]):int(off0[i + 1])]).ffm_buffer)["hash"].astype(np.int64)
+        if not any(((h < b) & (h + R > b)).any() for b in bounds):
+            keep_rec.append(i)
+        if len(keep_rec) == steps * gb:
+            break
+    assert len(keep_rec) == steps * gb
+    recs = np.concatenate([recs0[int(off0[i]):int(off0[i + 1])] for i in keep_rec])
+    off = np.concatenate([[0], np.cumsum([int(off0[i + 1] - off0[i]) for i in keep_rec])]).astype(np.uint64)
+    y = record_labels(recs, off)
+    om = fwo.Model(ocfg)
+    p_ref = np.concatenate([om.learn_minibatch(ots, recs[int(off[s * gb]):int(off[(s + 1) * gb])], off[s * gb:(s + 1) * gb + 1] - off[s * gb])
+                            for s in range(steps)])
+    ref_tabs = [om.lr_table, om.ffm_weights, om.ffm_acc]
+
+    def close(a, b):
+        # AdagradLUT's step is piecewise constant in the accumulator (2048 buckets over exponent + 3 mantissa bits,
+        # optimizer.rs:101-156): when a sum taken in another order lands one ulp across a bucket edge, ONE step of ONE weight
+        # changes by a few per cent.  A handful of such entries is f32 behaviour, not a defect; anything more is.
+        bad = np.abs(a - b) > 3e-5 + 1e-5 * np.abs(b)
+        return int(bad.sum()) <= max(3, a.size // 10000) and float(np.abs(a - b).max()) < 5e-3
+
+    for n_ranks in (1, 2, 4):
+        preds, tables = _run_sharded(n_ranks, mi, recs, off, gb // n_ranks, steps)
+        d = np.abs(logloss(preds, y) - logloss(p_ref, y)).max()
+        assert d < 1e-4, (n_ranks, d)
+        for tabs in tables:  # every rank ends with the same, complete model
+            for t in range(3):
+                assert close(tabs[t], ref_tabs[t]), (n_ranks, t, float(np.abs(tabs[t] - ref_tabs[t]).max()))
+        for t in range(3):
+            for tabs in tables[1:]:
+                assert np.array_equal(tabs[t], tables[0][t])
+
+
+def test_sharded_boundary_rows_are_a_small_documented_deviation():
+    """With rows that straddle ownership boundaries left in, N ranks still track the single-table result closely: hold-out
+    predictions of the final models agree to 1e-3 on these tiny tables (R / (table / N) = 0.2-0.4 %)."""
+    mi, ocfg, ots = make_pair(30, 8, 16, 18, fw.Optimizer.AdagradLUT, lr=0.05, ffm_lr=0.05)
+    recs, off = fw.synth_records(30, 3.0, 1.1, 50000, 0.1, 83, 0, 8 * 96 + 200)
+    outs = []
+    for n_ranks in (1, 4):
+        regs = [fw.Regressor(mi) for _ in range(n_ranks)]
+        fbt = fw.FeatureBufferTranslator(mi)
+        g = DistGroup(regs)
+        g.set_mode(capi.MODE_SEQUENTIAL)
+        per = 96 // n_ranks
+        for s in range(8):
+            rr = [recs[int(off[s * 96 + j * per]):int(off[s * 96 + (j + 1) * per])] for j in range(n_ranks)]
+            oo = [off[s * 96 + j * per:s * 96 + (j + 1) * per + 1] - off[s * 96 + j * per] for j in range(n_ranks)]
+            g.learn_sharded(fbt, rr, oo)
+        g.gather_tables()
+        hb = regs[0].record_batch(fbt, recs[int(off[8 * 96]):], off[8 * 96:] - off[8 * 96])
+        regs[0].learn_batch(hb, capi.MODE_HOGWILD, False)
+        outs.append(hb.predictions())
+        g.close()
+        for r in regs:
+            r.close()
+    assert np.abs(outs[0] - outs[1]).max() < 1e-3, float(np.abs(outs[0] - outs[1]).max())
+
+
+def test_sharded_ranks_touch_only_their_own_range():
+    """before gather_tables, rank j's tables differ from the initial ones only inside the range it owns (plus the R-float
+    overhang of rows that start at its upper edge)"""
+    n_ranks, per_rank = 4, 64
+    mi, ocfg, ots = make_pair(10, 4, 14, 14, fw.Optimizer.AdagradLUT)
+    recs, off = fw.synth_records(10, 1.0, 1.1, 3000, 0.1, 82, 0, n_ranks * per_rank)
+    regs = [fw.Regressor(mi) for _ in range(n_ranks)]
+    w0 = regs[0].table_read(capi.TABLE_FFM_W).copy()
+    lr0 = regs[0].table_read(capi.TABLE_LR).copy()
+    g = DistGroup(regs)
+    fbt = fw.FeatureBufferTranslator(mi)
+    rr = [recs[int(off[j * per_rank]):int(off[(j + 1) * per_rank])] for j in range(n_ranks)]
+    oo = [off[j * per_rank:(j + 1) * per_rank + 1] - off[j * per_rank] for j in range(n_ranks)]
+    g.learn_sharded(fbt, rr, oo)
+    span, R = 1 << 14, 10 * 4
+    for j, r in enumerate(regs):
+        w = r.table_read(capi.TABLE_FFM_W)
+        changed = np.nonzero(w != w0)[0]
+        assert len(changed) > 0
+        lo, hi = j * span // n_ranks, (j + 1) * span // n_ranks
+        assert changed.min() >= lo and changed.max() < hi + R
+        lrt = r.table_read(capi.TABLE_LR).reshape(-1, 2)
+        ch = np.nonzero((lrt != lr0.reshape(-1, 2)).any(axis=1))[0]
+        assert ch.min() >= lo and ch.max() < hi
+    g.close()
+    for r in regs:
+        r.close()
