@@ -137,7 +137,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=65536, help="examples per step per GPU")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="examples per step per GPU (default 65536; --dp-mode sharded: 2048 / n_gpus, the synchronous step is stable "
+                         "up to a GLOBAL micro-batch of ~2048 examples at these hyper-parameters, profiles/r02_sync_batch_stability.txt)")
     ap.add_argument("--fields", type=int, default=30)
     ap.add_argument("--k", type=int, default=8)
     ap.add_argument("--bits", type=int, default=28)
@@ -157,6 +159,13 @@ def main():
     ap.add_argument("--sync-every", dest="sync_every", type=int, default=0, help="N>1: steps between delta all-reduces")
     ap.add_argument("--combine", choices=["mean", "sum"], default="mean",
                     help="N>1: the agreed model moves by the mean (default) or the sum of the replicas' deltas")
+    ap.add_argument("--dp-mode", dest="dp_mode", choices=["replica", "sharded"], default="replica",
+                    help="N>1: 'replica' = full replicas + overlapped RCCL all-reduce of the table deltas every --sync-every steps "
+                         "(the timed mode of a multi-GPU run); 'sharded' = owner-sharded tables, synchronous step with all-gather / "
+                         "reduce-scatter of field sums (fwgpu_dist_learn_sharded_batch).  A replica run also times a short "
+                         "sharded leg and reports it as dp_modes.sharded")
+    ap.add_argument("--rccl", choices=["library", "torch"], default="library",
+                    help="N>1 replica exchange: through the library's own RCCL communicator (C ABI, fwgpu_dist_all_reduce_sum) or torch.distributed")
     ap.add_argument("--blocking-sync", dest="blocking_sync", action="store_true",
                     help="N>1: blocking delta all-reduce instead of the overlapped one")
     ap.add_argument("--dist-backend", dest="dist_backend", default="nccl",
@@ -198,6 +207,8 @@ def main():
         re.set_max_in_flight(args.max_in_flight)
     fbt = fw.FeatureBufferTranslator(mi)
 
+    if args.batch is None:
+        args.batch = max(64, 2048 // world) if (use_dist and args.dp_mode == "sharded") else 65536
     K, W, B = args.steps, args.warmup, args.batch
     # every rank trains on its own shard of the stream: examples [rank*(W+K)*B, ...)
     t0 = time.time()
@@ -219,22 +230,32 @@ def main():
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
 
-    # ---- N>1: replicas + delta all-reduce (local SGD with summed deltas)
+    # ---- N>1: replicas + delta all-reduce (local SGD: the agreed model moves by the mean of the replicas' deltas)
     # Cadence: one exchange per 32 steps (0.5 M examples per GPU, ~150 ms of training); a shorter run still times one
     # whole exchange, started at its midpoint.  Every exchange started in the timed region also lands inside it.
     sync_every = args.sync_every or (32 if K >= 48 else max(1, K // 2))
     last_sync_step = K - 1 if args.blocking_sync or K < 3 else K - 2  # an exchange started at the very last step could not overlap anything
     syncer = None
+    dist_rank = None
     if use_dist:
         from fwumious_wabbit_amd.dist_sync import DeltaAllReduce
 
-        # zero-copy torch views of the library's tables; torch.distributed (RCCL) does the exchange
-        syncer = DeltaAllReduce([re.table_as_torch(w) for w in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)],
-                                overlap=not args.blocking_sync, combine=args.combine)
+        if args.dist_backend == "nccl" and not args.same_device and not args.nn_layers:
+            # the library's own RCCL communicator (C ABI): rank 0 draws the id, torch.distributed is only the side channel
+            from fwumious_wabbit_amd.dist import DistRank, unique_id
+
+            box = [unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            dist_rank = DistRank(re, box[0], rank, world)
+        tabs = [capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC]
+        if args.nn_layers:  # the dense head is part of the replica (config E)
+            tabs += [capi.TABLE_NN_W, capi.TABLE_NN_ACC]
+        # zero-copy torch views of the library's tables
+        syncer = DeltaAllReduce([re.table_as_torch(w) for w in tabs], overlap=not args.blocking_sync, combine=args.combine,
+                                dist_rank=dist_rank if args.rccl == "library" else None)
 
     def sync_replicas():
-        # table <- snapshot + sum_r (table_r - snapshot): every replica ends with the same tables, having applied
-        # everyone's updates.  Overlapped mode: land the previous exchange, start the next; RCCL runs in the background
+        # table <- snapshot + mean_r (table_r - snapshot): every replica ends with the same tables.  Overlapped mode: land the previous exchange, start the next; RCCL runs in the background
         # while the following steps train.
         syncer.step()
 
@@ -242,9 +263,19 @@ def main():
     for _ in range(64):
         re.learn_batch(hbatch, capi.MODE_HOGWILD, False, sptr)
     torch.cuda.synchronize()
+    sharded_main = use_dist and args.dp_mode == "sharded"
+    if sharded_main and dist_rank is None:
+        raise SystemExit("--dp-mode sharded needs the RCCL backend (one rank per GPU) and a model without a deep head")
+
+    def step(b):
+        if sharded_main:  # owner-sharded synchronous step: all-gather records, reduce-scatter field sums, owner-side updates
+            dist_rank.learn_sharded_batch(fbt, b)
+        else:
+            re.learn_batch(b, capi.MODE_HOGWILD, True, sptr)
+
     for i in range(W):
-        re.learn_batch(batches[i], capi.MODE_HOGWILD, True, sptr)
-    if use_dist and W:
+        step(batches[i])
+    if use_dist and W and not sharded_main:
         sync_replicas()
         syncer.finish()
     torch.cuda.synchronize()
@@ -256,11 +287,11 @@ def main():
     t_start = time.perf_counter()
     for i in range(K):
         ev[2 * i].record(stream)
-        re.learn_batch(batches[W + i], capi.MODE_HOGWILD, True, sptr)
+        step(batches[W + i])
         ev[2 * i + 1].record(stream)
-        if use_dist and (i + 1) % sync_every == 0 and i <= last_sync_step:
+        if use_dist and not sharded_main and (i + 1) % sync_every == 0 and i <= last_sync_step:
             sync_replicas()
-    if use_dist:
+    if use_dist and not sharded_main:
         syncer.finish()  # the exchange still in flight lands INSIDE the timed region
     torch.cuda.synchronize()
     if use_dist:
@@ -273,6 +304,9 @@ def main():
         elapsed = float(tmax.item())
 
     kernel_ms = [ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(K)]
+    if sharded_main:  # the step runs on the library's own stream and is host-synchronous: the step time is the wall time
+        kernel_ms = [1e3 * elapsed / K] * K
+        dist_rank.gather_tables()  # every rank gets the whole model back for the hold-out pass
     avg_kernel_ms = float(np.mean(kernel_ms))
     alg_bytes = float(np.mean([algorithmic_bytes(args, batches[W + i], words[W + i]) for i in range(K)]))
 
@@ -283,6 +317,31 @@ def main():
     # the last timed step's examples were in that state (healthy training: 0)
     p_last = batches[W + K - 1].predictions(sptr)
     saturated = float(np.mean((p_last < 1e-20) | (p_last > 1.0 - 1e-7)))
+
+    # ---- the OTHER multi-GPU mode, timed on a short leg of its own (a replica run reports both; the owner-sharded step leaves
+    # every rank with only its own range current, so it comes last)
+    dp_modes = None
+    if use_dist and dist_rank is not None and not sharded_main:
+        Ks, Bs = min(K, 24), max(64, 2048 // world)  # global synchronous micro-batch of 2048 examples (stability limit, see --batch)
+        srecs, soff = gen_records(fw, args, 2_000_000_000 + rank * Ks * Bs, Ks * Bs)
+        sb = [re.record_batch(fbt, srecs[int(soff[j * Bs]):int(soff[(j + 1) * Bs])], soff[j * Bs:(j + 1) * Bs + 1] - soff[j * Bs]) for j in range(Ks)]
+        dist_rank.learn_sharded_batch(fbt, sb[0])  # warm-up: buffers, communicator channels
+        torch.cuda.synchronize()
+        dist.barrier()
+        ts = time.perf_counter()
+        for j in range(Ks):
+            dist_rank.learn_sharded_batch(fbt, sb[j])
+        torch.cuda.synchronize()
+        dist.barrier()
+        tsh = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tsh, op=dist.ReduceOp.MAX)
+        dp_modes = {"replica": "the timed mode of this line",
+                    "sharded": {"value": world * Ks * Bs / float(tsh.item()), "unit": "examples/sec", "steps": Ks,
+                                "examples_per_step_per_gpu": Bs, "ms_per_step": 1e3 * float(tsh.item()) / Ks,
+                                "what": "owner-sharded tables, synchronous step of n_gpus x examples_per_step_per_gpu examples: all-gather of "
+                                        "records, reduce-scatter + all-gather of field sums, owner-side AdaGrad (fwgpu_dist_learn_sharded_batch)"}}
+        for x in sb:
+            x.close()
 
     # HBM traffic per launch: PMC counters cannot be read from inside this process; the figure is the rocprofv3
     # measurement of this very command (separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 correction on the
@@ -324,7 +383,10 @@ def main():
                 "global_batch": B * world,
                 "mode": "hogwild (device-wide concurrent examples, racy RMW, sc1 accesses)",
                 "parallelism": ("1 GPU" if not use_dist else
-                                f"dp{world}: replicas, {'blocking' if args.blocking_sync else 'overlapped'} RCCL all-reduce of the replicas' {args.combine} delta, {syncer.bytes_per_sync() / 1e9:.2f} GB every "
+                                f"dp{world} sharded: owner-sharded tables, synchronous step of {world} x {B} examples (records all-gathered, field sums "
+                                f"reduce-scattered / all-gathered, owner-side AdaGrad), RCCL inside the library" if sharded_main else
+                                f"dp{world}: replicas, {'blocking' if args.blocking_sync else 'overlapped'} RCCL all-reduce ({'library communicator, C ABI' if syncer.dist_rank is not None else 'torch.distributed'}) "
+                                f"of the replicas' {args.combine} delta, {syncer.bytes_per_sync() / 1e9:.2f} GB every "
                                 f"{sync_every} steps ({syncer.n_syncs} syncs incl. warmup)"),
                 "holdout_examples": args.holdout,
                 "prep_seconds": prep_s,
@@ -346,6 +408,8 @@ def main():
                 "launch_ms_min_median_max": [float(np.min(kernel_ms)), float(np.median(kernel_ms)), float(np.max(kernel_ms))],
             },
         }
+        if dp_modes is not None:
+            out["dp_modes"] = dp_modes
         if args.cpu and world == 1:
             n_cpu = args.cpu_examples or 20000
             try:

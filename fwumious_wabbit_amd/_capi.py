@@ -132,6 +132,7 @@ def lib():
         "fwgpu_dist_rank": [vp, P(i32), P(i32)],
         "fwgpu_dist_ranges": [vp, P(u32), P(u32), P(u32), P(u32)],
         "fwgpu_dist_learn_sharded": [vp, P(TranslatorConfig), vp, vp, u32, vp],
+        "fwgpu_dist_learn_sharded_batch": [vp, P(TranslatorConfig), vp],
         "fwgpu_dist_gather_tables": [vp],
         "fwgpu_dist_all_reduce_sum": [vp, vp, u64, vp],
         "fwgpu_dist_group_create": [vp, i32, P(vp)],

@@ -94,6 +94,7 @@ struct fwgpu_dist {
     size_t own_cap = 0;
     uint32_t *d_shape = nullptr;     // [n * 4] per rank: max_lr, max_ffm, max_rec, n_records (all-gathered)
     const fwgpu_translator_config *tr = nullptr;
+    fwgpu_batch *src = nullptr;      // this step's own records, when they are already in HBM
     ~fwgpu_dist() {
         if (gb) fwgpu_batch_free(gb);
         if (sp) fwgpu_split_free(sp);
@@ -135,6 +136,21 @@ int step_begin(fwgpu_dist *d, const fwgpu_translator_config *t, const uint32_t *
     shape[3] = n;
     d->tr = t;
     d->B = n;
+    d->src = nullptr;
+    return FWGPU_OK;
+}
+// the rank's micro-batch is already a record batch in HBM (fwgpu_record_batch_create): its shape is known, nothing crosses PCIe
+int step_begin_batch(fwgpu_dist *d, const fwgpu_translator_config *t, fwgpu_batch *b, uint32_t shape[4]) {
+    if (!t || !b || !b->records) return fail(FWGPU_ERR_INVALID, "dist step: a record batch is needed");
+    if (b->owner != d->r) return fail(FWGPU_ERR_INVALID, "dist step: batch belongs to another regressor");
+    FWGPU_HIP(hipSetDevice(d->r->device));
+    shape[0] = b->max_lr;
+    shape[1] = b->max_ffm;
+    shape[2] = b->max_rec;
+    shape[3] = b->n;
+    d->tr = t;
+    d->B = b->n;
+    d->src = b;
     return FWGPU_OK;
 }
 
@@ -181,6 +197,12 @@ int step_upload(fwgpu_dist *d, const uint32_t *records, const uint64_t *rec_off,
     gb->max_rec = max_rec;
     gb->aligned4 = true;
     gb->rec_self_len = true;
+    if (d->src && B) {  // device to device: the words as they are, the offsets shifted onto the gathered buffer
+        if (d->src->n_words > wcap) return fail(FWGPU_ERR_RANGE, "sharded step: records longer than announced");
+        FWGPU_HIP(hipMemcpyAsync(gb->records + wcap * d->rank, d->src->records, d->src->n_words * 4, hipMemcpyDeviceToDevice, d->stream));
+        FWGPU_HIP(launch_offset_copy(gb->rec_off + (size_t)B * d->rank, d->src->rec_off, B, wcap * d->rank, d->stream));
+        return FWGPU_OK;
+    }
     // own records into slot `rank`: words at rank * wcap, offsets rebased onto the gathered buffer
     const uint64_t words = B ? rec_off[B] - rec_off[0] : 0;
     if (words > wcap) return fail(FWGPU_ERR_RANGE, "sharded step: records longer than announced");
@@ -295,14 +317,33 @@ int fwgpu_dist_ranges(const fwgpu_dist *d, uint32_t *ffm_lo, uint32_t *ffm_hi, u
 
 // One sharded step: this rank's micro-batch of n records in, their n predictions out (host buffer, may be NULL).  Collective:
 // every rank of the job calls it with the same n.
+static int rccl_step(fwgpu_dist *d, const uint32_t *records, const uint64_t *rec_off, uint32_t n, uint32_t shape[4], float *preds,
+                     float *d_preds);
+
 int fwgpu_dist_learn_sharded(fwgpu_dist *d, const fwgpu_translator_config *t, const uint32_t *records, const uint64_t *rec_off,
                              uint32_t n, float *preds) {
     if (!d || !d->comm) return fail(FWGPU_ERR_INVALID, "not an RCCL rank (fwgpu_dist_init)");
     uint32_t shape[4];
     int rc = step_begin(d, t, records, rec_off, n, shape);
     if (rc) return rc;
+    return rccl_step(d, records, rec_off, n, shape, preds, nullptr);
+}
+
+// The same step with the rank's micro-batch already in HBM (a record batch of this regressor); the predictions land in the
+// batch (fwgpu_batch_predictions).  Nothing crosses PCIe; the call returns when the step is enqueued and complete.
+int fwgpu_dist_learn_sharded_batch(fwgpu_dist *d, const fwgpu_translator_config *t, fwgpu_batch *b) {
+    if (!d || !d->comm) return fail(FWGPU_ERR_INVALID, "not an RCCL rank (fwgpu_dist_init)");
+    uint32_t shape[4];
+    int rc = step_begin_batch(d, t, b, shape);
+    if (rc) return rc;
+    return rccl_step(d, nullptr, nullptr, b->n, shape, nullptr, b->pred);
+}
+
+static int rccl_step(fwgpu_dist *d, const uint32_t *records, const uint64_t *rec_off, uint32_t n, uint32_t shape[4], float *preds,
+                     float *d_preds) {
+    int rc;
     // X1a: batch shapes
-    FWGPU_HIP(hipMemcpyAsync(d->d_shape + 4 * d->rank, shape, sizeof(shape), hipMemcpyHostToDevice, d->stream));
+    FWGPU_HIP(hipMemcpyAsync(d->d_shape + 4 * d->rank, shape, 4 * sizeof(uint32_t), hipMemcpyHostToDevice, d->stream));
     FWGPU_NCCL(g_rccl.AllGather(d->d_shape + 4 * d->rank, d->d_shape, 4, ncclUint32, d->comm, d->stream));
     std::vector<uint32_t> shapes((size_t)d->n * 4);
     FWGPU_HIP(hipMemcpyAsync(shapes.data(), d->d_shape, shapes.size() * 4, hipMemcpyDeviceToHost, d->stream));
@@ -327,6 +368,7 @@ int fwgpu_dist_learn_sharded(fwgpu_dist *d, const fwgpu_translator_config *t, co
     FWGPU_NCCL(g_rccl.AllGather(d->d_own, d->sp->d_split, (size_t)B * SL, ncclFloat, d->comm, d->stream));
     rc = phase_upd(d);
     if (rc) return rc;
+    if (d_preds) FWGPU_HIP(hipMemcpyAsync(d_preds, d->gb->pred + (size_t)B * d->rank, (size_t)B * 4, hipMemcpyDeviceToDevice, d->stream));
     return finish(d, preds);
 }
 

@@ -139,6 +139,7 @@ hipError_t launch_ffm_init(float *w, float *acc, uint64_t len, uint32_t k, float
                            float init_center, float acc0, hipStream_t stream);
 hipError_t launch_fill(float *p, uint64_t n, float v, hipStream_t stream);
 hipError_t launch_add(float *dst, const float *src, uint64_t n, hipStream_t stream);
+hipError_t launch_offset_copy(uint64_t *dst, const uint64_t *src, uint32_t n, uint64_t add, hipStream_t stream);
 hipError_t launch_fill_lr(float *lr, uint64_t n_entries, float w, float acc, hipStream_t stream);
 hipError_t launch_checksum(const float *p, uint64_t n, unsigned long long *out, hipStream_t stream);
 hipError_t launch_delta_start(const float *t, const float *s0, float *d, float *D, uint64_t n, float scale, hipStream_t stream);

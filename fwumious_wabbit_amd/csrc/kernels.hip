@@ -2071,6 +2071,15 @@ hipError_t launch_checksum(const float *p, uint64_t n, unsigned long long *out, 
 }
 
 
+__global__ void offset_copy_kernel(unsigned long long *dst, const unsigned long long *src, unsigned n, unsigned long long add) {
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i] + add;
+}
+hipError_t launch_offset_copy(uint64_t *dst, const uint64_t *src, uint32_t n, uint64_t add, hipStream_t stream) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(offset_copy_kernel, dim3(64), dim3(256), 0, stream, reinterpret_cast<unsigned long long *>(dst),
+                       reinterpret_cast<const unsigned long long *>(src), n, (unsigned long long)add);
+    return hipGetLastError();
+}
 __global__ void add_kernel(float *dst, const float *src, unsigned long long n) {
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] += src[i];

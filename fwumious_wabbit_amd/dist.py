@@ -44,6 +44,10 @@ class DistRank:
         check(capi.lib().fwgpu_dist_learn_sharded(self.h, C.byref(translator.c), ptr(records), rec_off.ctypes.data_as(C.c_void_p), n, ptr(out)))
         return out
 
+    def learn_sharded_batch(self, translator, batch):
+        """the same step with this rank's records already in HBM (Regressor.record_batch); predictions: batch.predictions()"""
+        check(capi.lib().fwgpu_dist_learn_sharded_batch(self.h, C.byref(translator.c), batch.h))
+
     def gather_tables(self):
         check(capi.lib().fwgpu_dist_gather_tables(self.h))
 

@@ -26,10 +26,15 @@ import torch.distributed as dist
 
 
 class DeltaAllReduce:
-    def __init__(self, tables, bucket_elems=1 << 26, group=None, overlap=False, combine="mean"):
+    def __init__(self, tables, bucket_elems=1 << 26, group=None, overlap=False, combine="mean", dist_rank=None):
         """tables: list of 1-D float32 tensors (views of the regressor's tables); bucket_elems: all-reduce bucket size in
-        elements (2^26 floats = 256 MiB); overlap: keep a delta buffer per table and run the all-reduce asynchronously."""
+        elements (2^26 floats = 256 MiB); overlap: keep a delta buffer per table and run the all-reduce asynchronously.
+        dist_rank: a fwumious_wabbit_amd.dist.DistRank -- the all-reduce then goes through the library's own RCCL
+        communicator (fwgpu_dist_all_reduce_sum, on a side stream) instead of torch.distributed."""
         self.tables = list(tables)
+        self.dist_rank = dist_rank
+        self._world = dist_rank.n if dist_rank is not None else None
+        self._side = torch.cuda.Stream() if dist_rank is not None else None
         self.snapshots = [t.clone() for t in self.tables]
         self.bucket = int(bucket_elems)
         self.group = group
@@ -42,7 +47,14 @@ class DeltaAllReduce:
         self._works = None
 
     def _scale(self):
-        return 1.0 / dist.get_world_size(self.group) if self.combine == "mean" else 1.0
+        world = self._world if self._world is not None else dist.get_world_size(self.group)
+        return 1.0 / world if self.combine == "mean" else 1.0
+
+    def _all_reduce(self, x, async_op=False):
+        if self.dist_rank is not None and x.is_cuda:  # the library's RCCL communicator, on the side stream
+            self.dist_rank.all_reduce_sum(x.data_ptr(), x.numel(), self._side.cuda_stream)
+            return None
+        return dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     # ---- blocking
     def sync(self):
@@ -54,7 +66,12 @@ class DeltaAllReduce:
                 d = t[a:b] - s0[a:b]
                 if self._scale() != 1.0:
                     d *= self._scale()
-                dist.all_reduce(d, op=dist.ReduceOp.SUM, group=self.group)
+                if self.dist_rank is not None and d.is_cuda:
+                    self._side.wait_stream(torch.cuda.current_stream())
+                    self._all_reduce(d)
+                    torch.cuda.current_stream().wait_stream(self._side)
+                else:
+                    self._all_reduce(d)
                 s0[a:b] += d
                 t[a:b] = s0[a:b]
         self.n_syncs += 1
@@ -74,9 +91,13 @@ class DeltaAllReduce:
             else:
                 torch.sub(t, s0, out=d)
                 torch.mul(d, self._scale(), out=D)
+            if self.dist_rank is not None and t.is_cuda:
+                self._side.wait_stream(torch.cuda.current_stream(t.device))  # D is ready when the side stream starts
             for a in range(0, t.numel(), self.bucket):
                 b = min(a + self.bucket, t.numel())
-                works.append(dist.all_reduce(D[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                w = self._all_reduce(D[a:b], async_op=True)
+                if w is not None:
+                    works.append(w)
         self._works = works
 
     def in_flight(self):
@@ -87,6 +108,8 @@ class DeltaAllReduce:
             return
         for w in self._works:
             w.wait()
+        if self.dist_rank is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
         self._works = None
         for t, s0, d, D in zip(self.tables, self.snapshots, self._local, self._summed):
             if t.is_cuda:

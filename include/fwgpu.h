@@ -277,6 +277,8 @@ int fwgpu_dist_rank(const fwgpu_dist *d, int *rank, int *n_ranks);
 int fwgpu_dist_ranges(const fwgpu_dist *d, uint32_t *ffm_lo, uint32_t *ffm_hi, uint32_t *lr_lo, uint32_t *lr_hi);
 int fwgpu_dist_learn_sharded(fwgpu_dist *d, const fwgpu_translator_config *t, const uint32_t *records, const uint64_t *rec_off,
                              uint32_t n, float *predictions);
+/* the same step with the rank's micro-batch already resident in HBM (a record batch): predictions land in the batch */
+int fwgpu_dist_learn_sharded_batch(fwgpu_dist *d, const fwgpu_translator_config *t, fwgpu_batch *b);
 int fwgpu_dist_gather_tables(fwgpu_dist *d);
 int fwgpu_dist_all_reduce_sum(fwgpu_dist *d, float *device_buf, uint64_t count, void *hip_stream);
 int fwgpu_dist_group_create(fwgpu_regressor *const *regressors, int n_ranks, fwgpu_dist_group **out);

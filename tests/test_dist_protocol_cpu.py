@@ -1,0 +1,172 @@
+"""world_size 2 and 4 gloo tests of the owner-sharded step's PROTOCOL (fwumious_wabbit_amd/csrc/dist.cpp), on CPU.
+
+The library has no CPU compute path, so what runs here is a miniature of the step with the oracle's arithmetic in numpy (LR block
++ AdagradLUT, block_lr.rs:28-47 / 135-150, optimizer.rs:101-156) and the real collectives over torch.distributed: all-gather of
+the examples, per-owner partial sums, reduce-scatter to the home ranks, sigmoid / gradient there, all-gather of the gradients,
+owner-side updates in example order, gather of the owned ranges.  It pins the algebra the GPU path implements with RCCL:
+N ranks == one learner running synchronous micro-batches of N*B examples, bit for bit for this model (every sum keeps its order)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import fwo
+
+BITS, B, STEPS, NNZ = 10, 16, 5, 6
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+
+def _make_lut(lr=0.1, power_t=0.5, init_acc=1.0):  # optimizer.rs:121-144
+    x = np.arange(2048, dtype=np.uint32)
+    a = (x << 20).view(np.float32).astype(np.float32) + np.float32(init_acc)
+    b = ((x + 1) << 20).astype(np.uint32).view(np.float32).astype(np.float32) + np.float32(init_acc)
+    with np.errstate(all="ignore"):
+        v = np.float32(lr) * (np.power(a, np.float32(-power_t)) + np.power(b, np.float32(-power_t))) * np.float32(0.5)
+    v = v.astype(np.float32)
+    v[~np.isfinite(v)] = np.float32(lr)
+    return v
+
+
+def _examples(step, n):
+    rng = np.random.default_rng(1000 + step)
+    idx = rng.integers(0, 1 << BITS, size=(n, NNZ)).astype(np.int64)
+    idx[:, 0] = 7  # a hot entry every example touches (the constant feature)
+    val = rng.choice([1.0, 0.5, 2.0], size=(n, NNZ)).astype(np.float32)
+    y = (rng.random(n) < 0.4).astype(np.float32)
+    return idx, val, y
+
+
+def _sigmoid_grad(wsum, y):  # block_loss_functions.rs:105-153
+    wsum = np.float32(wsum)
+    p = np.float32(1.0) / (np.float32(1.0) + np.exp(-wsum, dtype=np.float32))
+    return p, np.float32(-(y - p))
+
+
+def _apply(w, acc, lut, idx, val, g, lo, hi):
+    """owner-side updates of one example, entries in buffer order (block_lr.rs:135-150)"""
+    for h, v in zip(idx, val):
+        if lo <= h < hi:
+            grad = np.float32(g * v)
+            acc[h] = np.float32(acc[h] + grad * grad)
+            key = int(np.float32(acc[h]).view(np.uint32)) >> 20
+            w[h] = np.float32(w[h] - grad * lut[key])
+
+
+def _single_learner(n_ranks):
+    lut = _make_lut()
+    w = np.zeros(1 << BITS, dtype=np.float32)
+    acc = np.zeros(1 << BITS, dtype=np.float32)
+    preds = []
+    for s in range(STEPS):
+        idx, val, y = _examples(s, n_ranks * B)
+        gs = []
+        for e in range(len(y)):  # all examples against the weights of the batch start
+            wsum = np.float32(0.0)
+            for h, v in zip(idx[e], val[e]):
+                wsum = np.float32(wsum + w[h] * v)
+            p, g = _sigmoid_grad(wsum, y[e])
+            preds.append(p)
+            gs.append(g)
+        for e in range(len(y)):
+            _apply(w, acc, lut, idx[e], val[e], gs[e], 0, 1 << BITS)
+    return w, acc, np.array(preds, dtype=np.float32)
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lut = _make_lut()
+    per = (1 << BITS) // world
+    lo, hi = per * rank, per * (rank + 1)
+    w = np.zeros(1 << BITS, dtype=np.float32)   # full-size allocation, only [lo, hi) is kept current (as in dist.cpp)
+    acc = np.zeros(1 << BITS, dtype=np.float32)
+    preds = []
+    for s in range(STEPS):
+        idx_all, val_all, y_all = _examples(s, world * B)
+        mine = slice(rank * B, (rank + 1) * B)
+        # X1: all-gather of the examples (every rank brings its own B)
+        gi = [torch.zeros(B, NNZ, dtype=torch.int64) for _ in range(world)]
+        gv = [torch.zeros(B, NNZ, dtype=torch.float32) for _ in range(world)]
+        dist.all_gather(gi, torch.from_numpy(idx_all[mine].copy()))
+        dist.all_gather(gv, torch.from_numpy(val_all[mine].copy()))
+        idx = torch.cat(gi).numpy()
+        val = torch.cat(gv).numpy()
+        assert np.array_equal(idx, idx_all) and np.array_equal(val, val_all)
+        # P1: partial sums over the owned entries, entries in buffer order.  One slot per entry keeps the order of the
+        # final sum independent of N (the GPU path sums per owner first: 1e-7 relative, see the GPU tests)
+        part = np.zeros((world * B, NNZ), dtype=np.float32)
+        for e in range(world * B):
+            for j, (h, v) in enumerate(zip(idx[e], val[e])):
+                if lo <= h < hi:
+                    part[e, j] = np.float32(w[h] * v)
+        # X2: reduce-scatter (sum) to the home ranks
+        recv = torch.zeros(B, NNZ, dtype=torch.float32)
+        dist.reduce_scatter(recv, [torch.from_numpy(part[r * B:(r + 1) * B].copy()) for r in range(world)], op=dist.ReduceOp.SUM)
+        # P2: logit, prediction, general gradient of the own examples
+        g_own = np.zeros(B, dtype=np.float32)
+        for e in range(B):
+            wsum = np.float32(0.0)
+            for j in range(NNZ):
+                wsum = np.float32(wsum + recv[e, j].item())
+            p, g_own[e] = _sigmoid_grad(wsum, y_all[rank * B + e])
+            preds.append(p)
+        # X3: all-gather of the gradients
+        gg = [torch.zeros(B, dtype=torch.float32) for _ in range(world)]
+        dist.all_gather(gg, torch.from_numpy(g_own))
+        g_all = torch.cat(gg).numpy()
+        # P3: owner-side updates, example order
+        for e in range(world * B):
+            _apply(w, acc, lut, idx[e], val[e], g_all[e], lo, hi)
+    # gather_tables: every rank's owned range into every rank's tables
+    for tab in (w, acc):
+        parts = [torch.zeros(per, dtype=torch.float32) for _ in range(world)]
+        dist.all_gather(parts, torch.from_numpy(tab[lo:hi].copy()))
+        tab[:] = torch.cat(parts).numpy()
+    out[rank] = (w.copy(), acc.copy(), np.array(preds, dtype=np.float32))
+    dist.destroy_process_group()
+
+
+def _run(world):
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    return [out[r] for r in range(world)]
+
+
+def test_sharded_protocol_world2_and_world4_equal_one_learner():
+    for world in (2, 4):
+        w_ref, acc_ref, p_ref = _single_learner(world)
+        res = _run(world)
+        for r, (w, acc, preds) in enumerate(res):
+            assert np.array_equal(w, w_ref) and np.array_equal(acc, acc_ref), (world, r)
+            # rank r predicted examples [r*B, (r+1)*B) of every step
+            mine = np.concatenate([p_ref[s * world * B + r * B: s * world * B + (r + 1) * B] for s in range(STEPS)])
+            assert np.array_equal(preds, mine), (world, r)
+        assert np.count_nonzero(w_ref) > 100  # it did learn something
+
+
+def test_dist_symbols_are_exported_without_loading_rccl():
+    """the library resolves librccl only inside fwgpu_dist_init / fwgpu_dist_unique_id: importing it on a box without a GPU
+    (this one) must not need RCCL, and the multi-GPU entry points must be there"""
+    import ctypes as C
+
+    from fwumious_wabbit_amd import _capi as capi
+    L = capi.lib()
+    for name in ("fwgpu_dist_unique_id", "fwgpu_dist_init", "fwgpu_dist_learn_sharded", "fwgpu_dist_gather_tables",
+                 "fwgpu_dist_all_reduce_sum", "fwgpu_dist_group_create", "fwgpu_dist_group_learn_sharded",
+                 "fwgpu_learn_batch_sync", "fwgpu_split_create"):
+        assert hasattr(L, name)
+    with open("/proc/self/maps") as f:
+        assert "librccl" not in f.read() or "torch" in open("/proc/self/maps").read()
+    assert L.fwgpu_dist_init(None, None, 0, 1, C.byref(C.c_void_p())) != 0  # refused loudly, no crash

@@ -137,3 +137,41 @@ def test_sharded_ranks_touch_only_their_own_range():
     g.close()
     for r in regs:
         r.close()
+
+
+def test_rccl_rank_single_process():
+    """The RCCL path itself (librccl resolved at run time, communicator of one rank, the step's all-gathers and
+    reduce-scatter on it): the same numbers as the in-process group and as fwgpu_learn_batch_sync."""
+    from fwumious_wabbit_amd.dist import DistRank, unique_id
+    mi, ocfg, ots = make_pair(10, 4, 14, 14, fw.Optimizer.AdagradLUT)
+    recs, off = fw.synth_records(10, 1.0, 1.1, 3000, 0.1, 84, 0, 256)
+    fbt = fw.FeatureBufferTranslator(mi)
+    re_a, re_b = fw.Regressor(mi), fw.Regressor(mi)
+    d = DistRank(re_a, unique_id(), 0, 1)
+    d.set_mode(capi.MODE_SEQUENTIAL)
+    assert d.ranges() == (0, 0xFFFFFFFF, 0, 0xFFFFFFFF)
+    sp = re_b.split_buffers(128, 64)
+    for s0 in (0, 128):
+        sub, so = recs[int(off[s0]):int(off[s0 + 128])], off[s0:s0 + 129] - off[s0]
+        if s0 == 0:
+            p_a = d.learn_sharded(fbt, sub, so)
+        else:  # the device-resident form of the same call
+            ba = re_a.record_batch(fbt, sub, so)
+            d.learn_sharded_batch(fbt, ba)
+            p_a = ba.predictions()
+            ba.close()
+        b = re_b.record_batch(fbt, sub, so)
+        re_b.learn_batch_sync(b, sp, capi.MODE_SEQUENTIAL)
+        assert np.array_equal(p_a, b.predictions())
+        b.close()
+    d.gather_tables()
+    for t in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC):
+        assert re_a.table_checksum(t) == re_b.table_checksum(t)
+    # the plain all-reduce entry point (replica mode's exchange): one rank -> the buffer is unchanged
+    before = re_a.table_checksum(capi.TABLE_FFM_W)
+    d.all_reduce_sum(re_a.table_device_ptr(capi.TABLE_FFM_W), re_a.table_len(capi.TABLE_FFM_W))
+    assert re_a.table_checksum(capi.TABLE_FFM_W) == before
+    d.close()
+    sp.close()
+    re_a.close()
+    re_b.close()
