@@ -201,6 +201,7 @@ struct fwgpu_regressor {
     fwgpu_nn_config nn_cfg{};
     float *d_nn_w = nullptr, *d_nn_acc = nullptr, *d_lut_nn = nullptr;
     uint64_t nn_len = 0;
+    void *head_scratch = nullptr;  // mini-batched head (head.hip): activations, masks, gradients of the current batch
     // scratch for single-example calls
     fwgpu_batch *one = nullptr;
     void *pinned = nullptr;
@@ -275,5 +276,6 @@ int split_mid(fwgpu_regressor *r, fwgpu_split *sp, uint32_t first, uint32_t n, f
 int split_update(fwgpu_regressor *r, fwgpu_batch *b, fwgpu_split *sp, int mode, const SplitRanges &rg, bool head, hipStream_t stream);
 // mini-batched deep head on the records' x (head.hip): forward, sigmoid, backward, one AdaGrad step per dense weight
 int head_step(fwgpu_regressor *r, fwgpu_split *sp, uint32_t first, uint32_t n, float *d_pred, bool update, hipStream_t stream);
+void head_scratch_free(fwgpu_regressor *r);
 uint32_t pick_grid(const fwgpu_regressor *r, const KernelParams &p, int mode, uint32_t threads);
 }  // namespace fwgpu

@@ -1,11 +1,294 @@
-// Mini-batched deep head on the matrix cores (BASELINE config E) -- see head_step below.
+// Mini-batched deep head on the matrix cores (BASELINE config E: FFM k=16 + 2 x 256 ReLU, topology "one").
+//
+// The reference's head (block_neural.rs:196-340, block_relu.rs:38-112, regressor.rs:191-323) is per example: sgemv forward,
+// then every dense weight takes an AdaGrad step with that one example's gradient -- 20 B x 194 k weights = 3.9 MB of L2 traffic
+// per example, which is what holds the exact mode (kernels.hip nn_forward / nn_backward) at 0.8 M examples/s.  This file is the
+// explicit mini-batch mode that sits NEXT to it (never instead of it): inside a synchronous micro-batch (regressor.cpp
+// "split pipeline") the dense weights are frozen, the batch goes through the layers as GEMMs on
+// v_mfma_f32_32x32x2_f32 (exact f32, 157 TFLOP/s peak), the weight gradients are SUMMED over the batch and every dense weight
+// takes ONE optimizer step with the sum.  oracle/fw_oracle.c fwo_learn_minibatch is the CPU statement of the same mode.
+//
+//   x [n, X]  --W1-->  z1 -relu-> h1 [n, w1]  --W2-->  z2 -relu-> h2 [n, w2] ...   logit = w_f . [h_last | x] + b_f   (topology one)
+//   g = -(y - p) * importance ;  d h_last = g * w_f[:wl] ;  dx = g * w_f[wl:]  (+ the path through the layers)
+//   dW_l = dz_l^T . in_l  (K = n),  d in_l = dz_l . W_l ;  AdaGrad: acc += G^2 ; w -= G * lut[bits(acc) >> 20]   per weight, once
 #include "fwgpu_internal.h"
 
 namespace fwgpu {
 
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------------------- GEMM
+// C[M, N] (ldc) = op(A) . op(B)  [+ C]  with an epilogue.  f32 in, f32 accumulate, v_mfma_f32_32x32x2_f32.
+// Workgroup = 256 threads = 4 waves, 64 x 64 tile of C, wave (wr, wc) owns the 32 x 32 sub-tile; K in steps of 16 through LDS.
+//   A(m, k) = TA ? A[k * lda + m] : A[m * lda + k]        B(k, n) = TB ? B[n * ldb + k] : B[k * ldb + n]
+// EPI 0: C = acc          EPI 1: C = relu?(acc + bias[n]), mask[m, n] = acc + bias >= 0 (block_relu.rs:38-54)
+// EPI 2: C = acc * mul[m, n] (ReLU backward, block_relu.rs:105-110)          EPI 3: C += acc
+constexpr int kTM = 64, kTN = 64, kTK = 16, kPad = 4;
+
+template <bool TA, bool TB, int EPI>
+__global__ void __launch_bounds__(256) head_gemm(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int M,
+                                                 int N, int K, int lda, int ldb, int ldc, const float *__restrict__ bias,
+                                                 float *__restrict__ aux, int relu) {
+    __shared__ float As[kTK][kTM + kPad];  // k-major: lane i reads As[k][i] (consecutive lanes, consecutive banks)
+    __shared__ float Bs[kTK][kTN + kPad];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * kTM, n0 = blockIdx.x * kTN;
+    f16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k0 = 0; k0 < K; k0 += kTK) {
+        // stage: 64 x 16 elements of each operand, 4 per thread, the thread index running along the contiguous dimension
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = tid + 256 * r;
+            int m, k;
+            if (TA) {  // m contiguous in memory
+                m = e & 63;
+                k = e >> 6;
+            } else {  // k contiguous
+                k = e & 15;
+                m = e >> 4;
+            }
+            const int gm = m0 + m, gk = k0 + k;
+            float v = 0.0f;
+            if (gm < M && gk < K) v = TA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk];
+            As[k][m] = v;
+            int n, kb;
+            if (TB) {  // k contiguous
+                kb = e & 15;
+                n = e >> 4;
+            } else {  // n contiguous
+                n = e & 63;
+                kb = e >> 6;
+            }
+            const int gn = n0 + n, gkb = k0 + kb;
+            float u = 0.0f;
+            if (gn < N && gkb < K) u = TB ? B[(size_t)gn * ldb + gkb] : B[(size_t)gkb * ldb + gn];
+            Bs[kb][n] = u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < kTK; kk += 2) {
+            // 32x32x2: lane l feeds A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]
+            const float a = As[kk + (lane >> 5)][wr * 32 + (lane & 31)];
+            const float b = Bs[kk + (lane >> 5)][wc * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int col = n0 + wc * 32 + (lane & 31);
+    if (col < N) {
+        const float bj = (EPI == 1 && bias) ? bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < M) {
+                const size_t ix = (size_t)row * ldc + col;
+                float v = acc[r];
+                if (EPI == 1) {
+                    v += bj;
+                    const bool neg = relu && v < 0.0f;
+                    aux[ix] = neg ? 0.0f : 1.0f;
+                    v = neg ? 0.0f : v;
+                    C[ix] = v;
+                } else if (EPI == 2) {
+                    C[ix] = v * aux[ix];
+                } else if (EPI == 3) {
+                    C[ix] += v;
+                } else {
+                    C[ix] = v;
+                }
+            }
+        }
+    }
+}
+
+template <bool TA, bool TB, int EPI>
+static hipError_t gemm(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb, int ldc, const float *bias,
+                       float *aux, int relu, hipStream_t s) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    dim3 grid((N + kTN - 1) / kTN, (M + kTM - 1) / kTM);
+    hipLaunchKernelGGL((head_gemm<TA, TB, EPI>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias, aux, relu);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------- final neuron
+// One wave per example: logit = w_f . [h_last | x] + b_f (regressor.rs:307-319), sigmoid / log-loss gradient
+// (block_loss_functions.rs:105-153); then the final neuron's input gradients from the FROZEN w_f: d h_last (times the last
+// ReLU mask) and the direct part of dx.
+__global__ void __launch_bounds__(256) head_final_kernel(const float *__restrict__ h_last, const float *__restrict__ mask_last, const float *__restrict__ x,
+                                                         const float *__restrict__ wf, const float *__restrict__ yi, float *__restrict__ pred,
+                                                         float *__restrict__ gvec, float *__restrict__ dz_last, float *__restrict__ dx, int n, int wl,
+                                                         int X, int topo_one, int update) {
+    const int lane = threadIdx.x & 63;
+    const int ex = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ex >= n) return;
+    const int fin = wl + (topo_one ? X : 0);
+    float dot = 0.0f;
+    for (int i = lane; i < wl; i += 64) dot += wf[i] * h_last[(size_t)ex * wl + i];
+    if (topo_one)
+        for (int i = lane; i < X; i += 64) dot += wf[wl + i] * x[(size_t)ex * X + i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) dot += __shfl_xor(dot, m, 64);
+    const float z = wf[fin] + dot;
+    const float label = yi[2 * (size_t)ex], imp = yi[2 * (size_t)ex + 1];
+    float p, g;
+    if (isnan(z)) {
+        p = 1.0f / (1.0f + expf(-0.0f));
+        g = 0.0f;
+    } else if (z < -50.0f) {
+        p = 1.0f / (1.0f + expf(50.0f));
+        g = 0.0f;
+    } else if (z > 50.0f) {
+        p = 1.0f / (1.0f + expf(-50.0f));
+        g = 0.0f;
+    } else {
+        p = 1.0f / (1.0f + expf(-z));
+        g = -(label - p) * imp;
+    }
+    if (!update || imp == 0.0f) g = 0.0f;  // regressor.rs:366: importance 0 is a prediction, nothing is learned
+    if (lane == 0) {
+        pred[ex] = p;
+        gvec[ex] = g;
+    }
+    for (int i = lane; i < wl; i += 64) dz_last[(size_t)ex * wl + i] = g * wf[i] * mask_last[(size_t)ex * wl + i];
+    for (int i = lane; i < X; i += 64) dx[(size_t)ex * X + i] = topo_one ? g * wf[wl + i] : 0.0f;
+}
+
+// out[c] (+)= sum_e scale[e] * Mat[e, c]  (scale == NULL: plain column sums).  One thread per column, examples in order:
+// the bias gradients and the final neuron's weight gradients.  (Deterministic; these are n x (a few hundred) element passes.)
+__global__ void head_colsum_kernel(const float *__restrict__ mat, const float *__restrict__ scale, float *__restrict__ out, int n, int cols, int ld) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float acc = 0.0f;
+    for (int e = 0; e < n; ++e) acc += (scale ? scale[e] : 1.0f) * mat[(size_t)e * ld + c];
+    out[c] = acc;
+}
+__global__ void head_sum_kernel(const float *__restrict__ v, float *__restrict__ out, int n) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float acc = 0.0f;
+        for (int e = 0; e < n; ++e) acc += v[e];
+        *out = acc;
+    }
+}
+
+// One optimizer step per dense weight with the batch's summed gradient (optimizer.rs:15-162)
+__global__ void head_apply_kernel(float *__restrict__ w, float *__restrict__ acc, const float *__restrict__ dw, unsigned long long n, int optimizer,
+                                  float rate, float minus_power_t, const float *__restrict__ lut) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float g = dw[i];
+        if (g == 0.0f) continue;
+        float upd;
+        if (optimizer == FWGPU_OPT_SGD) {
+            upd = g * rate;
+        } else {
+            const float na = __fadd_rn(acc[i], __fmul_rn(g, g));
+            acc[i] = na;
+            if (optimizer == FWGPU_OPT_ADAGRAD_FLEX) {
+                upd = __fmul_rn(__fmul_rn(g, rate), powf(na, minus_power_t));
+                if (isnan(upd) || isinf(upd)) upd = 0.0f;
+            } else {
+                upd = __fmul_rn(g, lut[__float_as_uint(na) >> (31 - kLutBits)]);
+            }
+        }
+        w[i] -= upd;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- driver
+struct HeadScratch {
+    uint32_t n_cap = 0;
+    float *h[kNnMaxLayers] = {}, *m[kNnMaxLayers] = {}, *dz[kNnMaxLayers] = {};
+    float *gvec = nullptr, *dw = nullptr;
+};
+static HeadScratch &scratch_of(fwgpu_regressor *r) {
+    if (!r->head_scratch) r->head_scratch = new HeadScratch();
+    return *static_cast<HeadScratch *>(r->head_scratch);
+}
+void head_scratch_free(fwgpu_regressor *r) {
+    HeadScratch *hs = static_cast<HeadScratch *>(r->head_scratch);
+    if (!hs) return;
+    for (uint32_t l = 0; l < kNnMaxLayers; l++)
+        for (float *q : {hs->h[l], hs->m[l], hs->dz[l]})
+            if (q) (void)hipFree(q);
+    if (hs->gvec) (void)hipFree(hs->gvec);
+    if (hs->dw) (void)hipFree(hs->dw);
+    delete hs;
+    r->head_scratch = nullptr;
+}
+
 int head_step(fwgpu_regressor *r, fwgpu_split *sp, uint32_t first, uint32_t n, float *d_pred, bool update, hipStream_t stream) {
-    (void)r; (void)sp; (void)first; (void)n; (void)d_pred; (void)update; (void)stream;
-    return fail(FWGPU_ERR_INVALID, "mini-batched deep head: not built yet");
+    const DevNN &nn = r->nn;
+    const uint32_t L = nn.n_layers, X = nn.X;
+    if (!L) return fail(FWGPU_ERR_INVALID, "head_step: the model has no deep head");
+    if (!n) return FWGPU_OK;
+    HeadScratch &hs = scratch_of(r);
+    if (hs.n_cap < n) {
+        for (uint32_t l = 0; l < kNnMaxLayers; l++)
+            for (float **q : {&hs.h[l], &hs.m[l], &hs.dz[l]}) {
+                if (*q) (void)hipFree(*q);
+                *q = nullptr;
+            }
+        if (hs.gvec) (void)hipFree(hs.gvec);
+        hs.gvec = nullptr;
+        for (uint32_t l = 0; l < L; l++)
+            for (float **q : {&hs.h[l], &hs.m[l], &hs.dz[l]}) FWGPU_HIP(hipMalloc((void **)q, (size_t)n * nn.out[l] * sizeof(float)));
+        FWGPU_HIP(hipMalloc((void **)&hs.gvec, (size_t)n * sizeof(float)));
+        hs.n_cap = n;
+    }
+    if (!hs.dw) FWGPU_HIP(hipMalloc((void **)&hs.dw, (size_t)r->nn_len * sizeof(float)));
+    const float *x = sp->d_x + (size_t)first * X;
+    const float *yi = sp->d_g + 2 * (size_t)first;
+    float *dx = sp->d_dx + (size_t)first * X;
+    // ---- forward through the hidden layers: z = in . W^T + b, ReLU (or identity) with its mask
+    const float *in = x;
+    uint32_t in_w = X;
+    for (uint32_t l = 0; l < L; l++) {
+        const float *W = nn.w + nn.off[l];
+        FWGPU_HIP((gemm<false, true, 1>(in, W, hs.h[l], (int)n, (int)nn.out[l], (int)in_w, (int)in_w, (int)nn.in[l], (int)nn.out[l],
+                                       W + (size_t)nn.in[l] * nn.out[l], hs.m[l], (int)nn.relu[l], stream)));
+        in = hs.h[l];
+        in_w = nn.out[l];
+    }
+    // ---- final neuron, sigmoid, gradient; input gradients of the final neuron
+    const uint32_t wl = nn.out[L - 1];
+    const float *wf = nn.w + nn.off[L];
+    hipLaunchKernelGGL(head_final_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, hs.h[L - 1], hs.m[L - 1], x, wf, yi, d_pred, hs.gvec,
+                       hs.dz[L - 1], dx, (int)n, (int)wl, (int)X, nn.topology == 1 ? 1 : 0, update ? 1 : 0);
+    FWGPU_HIP(hipGetLastError());
+    if (!update) return FWGPU_OK;
+    float *dW = hs.dw;
+    // final neuron's weight gradients: sum_e g_e * [h_last | x]_e, bias: sum_e g_e
+    {
+        float *dwf = dW + nn.off[L];
+        hipLaunchKernelGGL(head_colsum_kernel, dim3((wl + 63) / 64), dim3(64), 0, stream, hs.h[L - 1], hs.gvec, dwf, (int)n, (int)wl, (int)wl);
+        if (nn.topology == 1)
+            hipLaunchKernelGGL(head_colsum_kernel, dim3((X + 63) / 64), dim3(64), 0, stream, x, hs.gvec, dwf + wl, (int)n, (int)X, (int)X);
+        hipLaunchKernelGGL(head_sum_kernel, dim3(1), dim3(64), 0, stream, hs.gvec, dwf + nn.in[L], (int)n);
+        FWGPU_HIP(hipGetLastError());
+    }
+    // ---- backward through the hidden layers (block_neural.rs:252-340 in matrix form, frozen weights)
+    for (int l = (int)L - 1; l >= 0; --l) {
+        const float *W = nn.w + nn.off[l];
+        const uint32_t out = nn.out[l], inw = nn.in[l];
+        const float *lin = l == 0 ? x : hs.h[l - 1];
+        // dW_l[j, i] = sum_e dz[e, j] * in[e, i]
+        FWGPU_HIP((gemm<true, false, 0>(hs.dz[l], lin, dW + nn.off[l], (int)out, (int)inw, (int)n, (int)out, (int)inw, (int)inw, nullptr, nullptr, 0, stream)));
+        hipLaunchKernelGGL(head_colsum_kernel, dim3((out + 63) / 64), dim3(64), 0, stream, hs.dz[l], (const float *)nullptr,
+                           dW + nn.off[l] + (size_t)inw * out, (int)n, (int)out, (int)out);
+        FWGPU_HIP(hipGetLastError());
+        if (l > 0) {  // d in = dz . W, then through the previous layer's ReLU mask
+            FWGPU_HIP((gemm<false, false, 2>(hs.dz[l], W, hs.dz[l - 1], (int)n, (int)inw, (int)out, (int)out, (int)inw, (int)inw, nullptr, hs.m[l - 1], 0, stream)));
+        } else {  // BlockCopy sums the two branches into dx (block_misc.rs:456-475)
+            FWGPU_HIP((gemm<false, false, 3>(hs.dz[0], W, dx, (int)n, (int)X, (int)out, (int)out, (int)inw, (int)X, nullptr, nullptr, 0, stream)));
+        }
+    }
+    // ---- one optimizer step per dense weight
+    hipLaunchKernelGGL(head_apply_kernel, dim3(512), dim3(256), 0, stream, nn.w, nn.acc, dW, (unsigned long long)r->nn_len, r->cfg.optimizer, nn.rate,
+                       nn.minus_power_t, nn.lut);
+    FWGPU_HIP(hipGetLastError());
+    return FWGPU_OK;
 }
 
 }  // namespace fwgpu

@@ -464,6 +464,7 @@ int fwgpu_free(fwgpu_regressor *r) {
     if (!r) return FWGPU_OK;
     (void)hipSetDevice(r->device);
     if (r->one) fwgpu_batch_free(r->one);
+    head_scratch_free(r);
     (void)hipFree(r->d_lr);
     (void)hipFree(r->d_ffm_w);
     (void)hipFree(r->d_ffm_acc);

@@ -482,6 +482,23 @@ def test_sync_micro_batch_matches_oracle_micro_batch_mode():
     _sync_parity(30, 16, 16, 18, fw.Optimizer.AdagradLUT, n=96, mb=32, seed=57, ids=20000, p_weighted=0.1)
 
 
+def test_mini_batched_deep_head_matches_oracle_micro_batch_mode():
+    """The MFMA head (head.hip): a deep head inside synchronous micro-batches = frozen dense weights per batch, gradients summed
+    over the batch, ONE optimizer step per dense weight -- against the oracle's statement of that mode (fw_oracle.h), in the
+    in-order mode.  Small shapes with ragged tiles, both topologies, identity and ReLU layers, three optimizers; then config E's
+    real geometry (F = 30, k = 16, 2 x 256 ReLU, topology one)."""
+    _sync_parity(6, 4, 12, 12, fw.Optimizer.AdagradLUT, n=384, mb=64, seed=61, interactions=[(0, 1)],
+                 nn=([(12, "relu", "hu"), (8, "relu", "hu")], "one", 0.02, 0.45, 1.0))
+    _sync_parity(5, 16, 13, 14, fw.Optimizer.AdagradLUT, n=200, mb=50, seed=62, nn=([(25, "relu", "xavier")], "one", 0.02, 0.45, 1.0))
+    _sync_parity(3, 5, 12, 12, fw.Optimizer.AdagradLUT, n=300, mb=75, seed=63,
+                 nn=([(9, "none", "hu"), (7, "relu", "xavier")], "two", 0.02, 0.45, 1.0))
+    _sync_parity(4, 4, 12, 12, fw.Optimizer.SGD, n=256, mb=64, seed=64, lr=0.05, ffm_lr=0.05, nn=([(10, "relu", "hu")], "one", 0.01, 0.45, 0.0))
+    _sync_parity(4, 8, 12, 12, fw.Optimizer.AdagradFlex, n=256, mb=64, seed=65, init_acc=1.0, ffm_init_acc=1.0, weight_tol=5e-5,
+                 nn=([(10, "relu", "hu")], "one", 0.02, 0.45, 1.0))
+    _sync_parity(30, 16, 20, 20, fw.Optimizer.AdagradLUT, n=128, mb=64, seed=66, mean_extra=5.67, ids=100000, p_weighted=0.1, lr=0.025,
+                 ffm_lr=0.025, power_t=0.38, ffm_power_t=0.38, nn=([(256, "relu", "hu"), (256, "relu", "hu")], "one", 0.025, 0.38, 1.0))
+
+
 def test_sync_micro_batch_hogwild_learns_like_the_fused_kernel():
     """The concurrent form of the same step on a stream: hold-out loss close to the fused hogwild kernel's."""
     n_train, n_hold, mb = 16384, 4096, 2048
