@@ -132,6 +132,59 @@ def cpu_baseline(args, n_examples):
             "single_thread_value": n1 / dt1}
 
 
+def measure_traffic(args):
+    """HBM bytes per learn launch of THIS workload, measured now: two short child runs of this script under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md's HBM section
+    prescribes; FETCH_SIZE doubled: on gfx950 it reports half of a 16 B/lane coalesced read; KB = 1024 B, calibrated on a 2 GiB
+    fill).  Returns (bytes per launch or None, description)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not on PATH"
+    fwd = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-traffic", "--batch", str(args.batch), "--fields", str(args.fields),
+           "--k", str(args.k), "--bits", str(args.bits), "--ffm-bits", str(args.ffm_bits), "--mean-extra", str(args.mean_extra),
+           "--zipf", str(args.zipf), "--ids", str(args.ids), "--p-weighted", str(args.p_weighted), "--seed", str(args.seed),
+           "--holdout", "256", "--nn-layers", str(args.nn_layers), "--nn-width", str(args.nn_width), "--head", args.head]
+    if args.sync:
+        fwd.append("--sync")
+    if args.threads:
+        fwd += ["--threads", str(args.threads)]
+    if args.wgs:
+        fwd += ["--wgs-per-cu", str(args.wgs)]
+    kb = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="fwbench_pmc_", dir="/tmp")
+            try:
+                env = dict(os.environ, TMPDIR="/tmp")
+                subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "t", "--", sys.executable,
+                                os.path.abspath(__file__)] + fwd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=300, check=False)
+                vals = []
+                for db in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
+                    con = sqlite3.connect(db)
+                    rows = list(con.execute("select kernel_name, value from counters_collection where counter_name = ? and "
+                                            "kernel_name like '%fw_example_kernel%'", (ctr,)))
+                    con.close()
+                    # the updating launches: coherent (sc1) instantiations, `<..., true, ...>`; predict-only passes are not
+                    vals += [v for name, v in rows if ", true" in name and "phase" not in name]
+                if not vals:
+                    return None, f"rocprofv3 --pmc {ctr}: no dispatch of the learn kernel found"
+                # every timed dispatch of the child has the same shape: take the median
+                kb[ctr] = float(np.median(vals))
+            finally:
+                shutil.rmtree(d, ignore_errors=True)
+    except Exception as e:  # a side measurement: never lose the bench line over it
+        return None, f"traffic measurement failed: {e!r}"
+    total = (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0
+    return total, (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE on child runs of the same command "
+                   f"(3 steps; median per learn dispatch: FETCH_SIZE {kb['FETCH_SIZE']:.0f} KB x2 (gfx950 16 B/lane correction) + WRITE_SIZE {kb['WRITE_SIZE']:.0f} KB)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,6 +205,11 @@ def main():
     ap.add_argument("--holdout", type=int, default=8192)
     ap.add_argument("--nn-layers", dest="nn_layers", type=int, default=0, help="config E: hidden ReLU layers of the deep head")
     ap.add_argument("--nn-width", dest="nn_width", type=int, default=256)
+    ap.add_argument("--head", choices=["minibatch", "exact"], default="exact",
+                    help="config E (--nn-layers > 0): 'minibatch' = synchronous micro-batches with the deep head on the matrix cores "
+                         "(frozen dense weights per batch, summed gradients, one AdaGrad step per weight: head.hip); 'exact' = the "
+                         "reference's per-example head inside the fused kernel")
+    ap.add_argument("--sync", action="store_true", help="run the steps as synchronous micro-batches (fwgpu_learn_batch_sync) also without a deep head")
     ap.add_argument("--threads", type=int, default=0, help="workgroup size override")
     ap.add_argument("--wgs-per-cu", dest="wgs", type=int, default=0)
     ap.add_argument("--max-in-flight", dest="max_in_flight", type=int, default=0,
@@ -173,6 +231,8 @@ def main():
     ap.add_argument("--same-device", dest="same_device", action="store_true", help="debug: every rank uses cuda:0")
     ap.add_argument("--force-dist", dest="force_dist", action="store_true",
                     help="run the RCCL replica-sync path even with one rank (smoke test of the N>1 code on one GPU)")
+    ap.add_argument("--no-traffic", dest="traffic", action="store_false",
+                    help="skip the live HBM-traffic measurement (two short rocprofv3 --pmc child runs of this very command)")
     ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
     ap.add_argument("--cpu-examples", dest="cpu_examples", type=int, default=0)
     args = ap.parse_args()
@@ -207,8 +267,10 @@ def main():
         re.set_max_in_flight(args.max_in_flight)
     fbt = fw.FeatureBufferTranslator(mi)
 
+    sync_steps = args.sync or (args.nn_layers > 0 and args.head == "minibatch")
     if args.batch is None:
-        args.batch = max(64, 2048 // world) if (use_dist and args.dp_mode == "sharded") else 65536
+        # synchronous micro-batches are stable up to ~2048 examples at these hyper-parameters (profiles/r02_sync_batch_stability.txt)
+        args.batch = max(64, 2048 // world) if (use_dist and args.dp_mode == "sharded") else (2048 if sync_steps else 65536)
     K, W, B = args.steps, args.warmup, args.batch
     # every rank trains on its own shard of the stream: examples [rank*(W+K)*B, ...)
     t0 = time.time()
@@ -267,9 +329,13 @@ def main():
     if sharded_main and dist_rank is None:
         raise SystemExit("--dp-mode sharded needs the RCCL backend (one rank per GPU) and a model without a deep head")
 
+    split = re.split_buffers(B, 1024) if sync_steps else None
+
     def step(b):
         if sharded_main:  # owner-sharded synchronous step: all-gather records, reduce-scatter field sums, owner-side updates
             dist_rank.learn_sharded_batch(fbt, b)
+        elif sync_steps:  # synchronous micro-batch on this GPU (deep head: mini-batched on the matrix cores)
+            re.learn_batch_sync(b, split, capi.MODE_HOGWILD, sptr)
         else:
             re.learn_batch(b, capi.MODE_HOGWILD, True, sptr)
 
@@ -346,15 +412,9 @@ def main():
     # HBM traffic per launch: PMC counters cannot be read from inside this process; the figure is the rocprofv3
     # measurement of this very command (separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 correction on the
     # read side) committed under profiles/, reported only when the run uses the profiled configuration.
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_v6_pmc.json")) as f:
-            pmc = json.load(f)
-        if (B == pmc["examples_per_launch"] and args.fields == 30 and args.k == 8 and args.ffm_bits == 28
-                and not args.threads and not args.wgs):
-            traffic = pmc["hbm_bytes_per_launch"]
-    except Exception:
-        pass
+    traffic, traffic_src = None, None
+    if args.traffic and rank == 0 and world == 1 and not use_dist:
+        traffic, traffic_src = measure_traffic(args)
 
     if rank == 0:
         achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
@@ -376,12 +436,13 @@ def main():
             "config": {
                 "hyperparameters": f"AdagradLUT lr={LR} power_t={POWER_T} init_acc_gradient={INIT_ACC} (run_one.sh)",
                 "workload": f"BASELINE.json configs[{4 if args.nn_layers else 2}]: synthetic {args.fields}-field k={args.k} FFM + LR"
-                            + (f" + deep head {args.nn_layers}x{args.nn_width} ReLU (topology one, per-example updates)" if args.nn_layers else "") + ", "
+                            + (f" + deep head {args.nn_layers}x{args.nn_width} ReLU (topology one, " + ("mini-batched on MFMA: summed dense gradients, one step per batch)" if sync_steps else "per-example updates)") if args.nn_layers else "") + ", "
                             f"{args.ffm_bits}-bit FFM hash, {args.bits}-bit LR hash, ~{int(args.fields * (1 + args.mean_extra))} nnz/example, "
                             f"AdagradLUT, fused learn (record translation + forward + sigmoid/log-loss + AdaGrad scatter-update)",
                 "examples_per_step_per_gpu": B,
                 "global_batch": B * world,
-                "mode": "hogwild (device-wide concurrent examples, racy RMW, sc1 accesses)",
+                "mode": ("synchronous micro-batches (every example sees the batch-start weights; FWD / MID / head on MFMA / UPD kernels)" if sync_steps
+                         else "hogwild (device-wide concurrent examples, racy RMW, sc1 accesses)"),
                 "parallelism": ("1 GPU" if not use_dist else
                                 f"dp{world} sharded: owner-sharded tables, synchronous step of {world} x {B} examples (records all-gathered, field sums "
                                 f"reduce-scattered / all-gathered, owner-side AdaGrad), RCCL inside the library" if sharded_main else
@@ -393,16 +454,19 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("fw_example_kernel_r<AdagradLUT, coherent, MAXR=2> (3 workgroups x 512 threads per CU)"
+                "kernel": ("FWD / MID / " + ("head GEMMs (v_mfma_f32_32x32x2_f32) / " if args.nn_layers else "") + "UPD kernels of the synchronous micro-batch (generic row kernel)"
+                           if sync_steps or sharded_main else
+                           "fw_example_kernel_r<AdagradLUT, coherent, MAXR=0, whole-line updates + duplicate-row chains> (3 workgroups x 512 threads per CU)"
                            if args.k % 4 == 0 and args.fields * args.k <= 256 and not args.nn_layers else
-                           "fw_example_kernel<VEC=4, AdagradLUT, coherent> (generic rows" + (" + deep head)" if args.nn_layers else ")")),
+                           "fw_example_kernel<VEC=4, AdagradLUT, coherent> (generic rows, duplicate-row chains" + (" + per-example deep head)" if args.nn_layers else ")")),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": "profiles/r01_v6_pmc.json (rocprofv3 PMC, separate passes)" if traffic else None,
-                "pattern_ceiling_note": "tools/rowbw.hip: random 960 B rows read 6.4 TB/s, written 3.2 TB/s; read w+acc, write w+acc = 4.2 TB/s",
+                "traffic_source": traffic_src,
+                "pattern_ceiling_note": "profiles/r02_rowceil.txt (tools/rowceil.hip, raw output): random 960 B rows read 6.4 TB/s; written 3.2-3.5 TB/s as they lie (32 B aligned: "
+                                        "partial 128 B lines cost 4-5 whole lines), 6.8 TB/s as whole lines; read w+acc and write both back as whole lines: 5.0 TB/s of row bytes = 0.62 of the 8 TB/s peak",
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": avg_kernel_ms,
                 "launch_ms_min_median_max": [float(np.min(kernel_ms)), float(np.median(kernel_ms)), float(np.max(kernel_ms))],

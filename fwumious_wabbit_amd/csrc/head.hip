@@ -155,21 +155,41 @@ __global__ void __launch_bounds__(256) head_final_kernel(const float *__restrict
     for (int i = lane; i < X; i += 64) dx[(size_t)ex * X + i] = topo_one ? g * wf[wl + i] : 0.0f;
 }
 
-// out[c] (+)= sum_e scale[e] * Mat[e, c]  (scale == NULL: plain column sums).  One thread per column, examples in order:
-// the bias gradients and the final neuron's weight gradients.  (Deterministic; these are n x (a few hundred) element passes.)
-__global__ void head_colsum_kernel(const float *__restrict__ mat, const float *__restrict__ scale, float *__restrict__ out, int n, int cols, int ld) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
-    float acc = 0.0f;
-    for (int e = 0; e < n; ++e) acc += (scale ? scale[e] : 1.0f) * mat[(size_t)e * ld + c];
-    out[c] = acc;
-}
-__global__ void head_sum_kernel(const float *__restrict__ v, float *__restrict__ out, int n) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        float acc = 0.0f;
-        for (int e = 0; e < n; ++e) acc += v[e];
-        *out = acc;
+// out[c] = sum_e scale[e] * Mat[e, c]  (scale == NULL: plain column sums): the bias gradients and the final neuron's weight
+// gradients.  Workgroup = 64 columns x 4 row groups; every group walks its quarter of the examples in order, the four partial
+// sums are added in a fixed order: deterministic, coalesced (64 consecutive columns per wave load).
+__global__ void __launch_bounds__(256) head_colsum_kernel(const float *__restrict__ mat, const float *__restrict__ scale, float *__restrict__ out, int n,
+                                                          int cols, int ld) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int per = (n + 3) / 4, e0 = grp * per, e1 = min(n, e0 + per);
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    if (c < cols) {
+        int e = e0;
+        for (; e + 4 <= e1; e += 4) {
+            a0 += (scale ? scale[e] : 1.0f) * mat[(size_t)e * ld + c];
+            a1 += (scale ? scale[e + 1] : 1.0f) * mat[(size_t)(e + 1) * ld + c];
+            a2 += (scale ? scale[e + 2] : 1.0f) * mat[(size_t)(e + 2) * ld + c];
+            a3 += (scale ? scale[e + 3] : 1.0f) * mat[(size_t)(e + 3) * ld + c];
+        }
+        for (; e < e1; ++e) a0 += (scale ? scale[e] : 1.0f) * mat[(size_t)e * ld + c];
     }
+    part[grp][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (grp == 0 && c < cols) out[c] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+__global__ void __launch_bounds__(256) head_sum_kernel(const float *__restrict__ v, float *__restrict__ out, int n) {
+    __shared__ float part[256];
+    float acc = 0.0f;
+    for (int e = threadIdx.x; e < n; e += 256) acc += v[e];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = part[0];
 }
 
 // One optimizer step per dense weight with the batch's summed gradient (optimizer.rs:15-162)
@@ -262,10 +282,10 @@ int head_step(fwgpu_regressor *r, fwgpu_split *sp, uint32_t first, uint32_t n, f
     // final neuron's weight gradients: sum_e g_e * [h_last | x]_e, bias: sum_e g_e
     {
         float *dwf = dW + nn.off[L];
-        hipLaunchKernelGGL(head_colsum_kernel, dim3((wl + 63) / 64), dim3(64), 0, stream, hs.h[L - 1], hs.gvec, dwf, (int)n, (int)wl, (int)wl);
+        hipLaunchKernelGGL(head_colsum_kernel, dim3((wl + 63) / 64), dim3(256), 0, stream, hs.h[L - 1], hs.gvec, dwf, (int)n, (int)wl, (int)wl);
         if (nn.topology == 1)
-            hipLaunchKernelGGL(head_colsum_kernel, dim3((X + 63) / 64), dim3(64), 0, stream, x, hs.gvec, dwf + wl, (int)n, (int)X, (int)X);
-        hipLaunchKernelGGL(head_sum_kernel, dim3(1), dim3(64), 0, stream, hs.gvec, dwf + nn.in[L], (int)n);
+            hipLaunchKernelGGL(head_colsum_kernel, dim3((X + 63) / 64), dim3(256), 0, stream, x, hs.gvec, dwf + wl, (int)n, (int)X, (int)X);
+        hipLaunchKernelGGL(head_sum_kernel, dim3(1), dim3(256), 0, stream, hs.gvec, dwf + nn.in[L], (int)n);
         FWGPU_HIP(hipGetLastError());
     }
     // ---- backward through the hidden layers (block_neural.rs:252-340 in matrix form, frozen weights)
@@ -275,7 +295,7 @@ int head_step(fwgpu_regressor *r, fwgpu_split *sp, uint32_t first, uint32_t n, f
         const float *lin = l == 0 ? x : hs.h[l - 1];
         // dW_l[j, i] = sum_e dz[e, j] * in[e, i]
         FWGPU_HIP((gemm<true, false, 0>(hs.dz[l], lin, dW + nn.off[l], (int)out, (int)inw, (int)n, (int)out, (int)inw, (int)inw, nullptr, nullptr, 0, stream)));
-        hipLaunchKernelGGL(head_colsum_kernel, dim3((out + 63) / 64), dim3(64), 0, stream, hs.dz[l], (const float *)nullptr,
+        hipLaunchKernelGGL(head_colsum_kernel, dim3((out + 63) / 64), dim3(256), 0, stream, hs.dz[l], (const float *)nullptr,
                            dW + nn.off[l] + (size_t)inw * out, (int)n, (int)out, (int)out);
         FWGPU_HIP(hipGetLastError());
         if (l > 0) {  // d in = dz . W, then through the previous layer's ReLU mask

@@ -873,7 +873,7 @@ __device__ __forceinline__ void lr_update(const KernelParams &p, const Lds &s, u
 // parallelism.  idx[u] == 0xffffffff marks an unused slot.
 template <int VEC, int OPT, int AUX, int U>
 __device__ __forceinline__ void update_rows(const KernelParams &p, const Lds &s, const uint32_t (&idx)[U], float g,
-                                            int lane, const float *gpair = nullptr) {
+                                            int lane, const float *gpair = nullptr, uint32_t nf = 0) {
     typedef typename Vec<VEC>::type V;
     const uint32_t R = p.R, k = p.k;
     const uint32_t nchunk = (R + 64 * VEC - 1) / (64 * VEC);
@@ -883,16 +883,16 @@ __device__ __forceinline__ void update_rows(const KernelParams &p, const Lds &s,
         const uint32_t z = inb ? e0 / k : 0;
         V wv[U], av[U];
         __amdgpu_buffer_rsrc_t rw[U], ra[U];
-        float val[U];
-        uint32_t fld[U];
+        uint32_t fld[U], hsh[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             wv[u] = Vec<VEC>::zero();
             av[u] = Vec<VEC>::zero();
+            fld[u] = hsh[u] = 0;
             if (idx[u] != 0xffffffffu) {
                 const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[idx[u]]);
-                val[u] = s.e_val[idx[u]];
-                fld[u] = s.e_fld[idx[u]] & kFldMask;
+                hsh[u] = h;
+                fld[u] = __builtin_amdgcn_readfirstlane(s.e_fld[idx[u]]);
                 rw[u] = make_rsrc(p.ffm_w + h, R * 4);
                 wv[u] = Vec<VEC>::template load<AUX>(rw[u], e0 * 4);
                 if (OPT != FWGPU_OPT_SGD) {
@@ -904,25 +904,41 @@ __device__ __forceinline__ void update_rows(const KernelParams &p, const Lds &s,
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (idx[u] == 0xffffffffu) continue;
-            const uint32_t f = fld[u];
-            const float v = val[u];
-            V tv = Vec<VEC>::zero(), sw = Vec<VEC>::zero();
-            const bool self = inb && (z == f);
-            if (inb) tv = Vec<VEC>::lds_load(s.T + f * R + e0);
-            if (self) sw = Vec<VEC>::lds_load(s.selfw + idx[u] * k + (e0 - z * k));
+            // one occurrence of the row (entry i of field f): gradient from the pre-update weights (T, selfw), optimizer step on
+            // the running register copy
+            auto apply = [&](uint32_t i, uint32_t f) {
+                const float v = s.e_val[i];
+                V tv = Vec<VEC>::zero(), sw = Vec<VEC>::zero();
+                const bool self = inb && (z == f);
+                if (inb) tv = Vec<VEC>::lds_load(s.T + f * R + e0);
+                if (self) sw = Vec<VEC>::lds_load(s.selfw + i * k + (e0 - z * k));
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                float t = Vec<VEC>::get(tv, j);
-                if (self) t = __fsub_rn(t, __fmul_rn(Vec<VEC>::get(sw, j), v));  // contra - w*v  block_ffm.rs:238
-                const float G = __fmul_rn(v, t);             // gradient cache      block_ffm.rs:239, 249
-                // general gradient of output (f, z): uniform g, or -- deep head -- the mirrored triangle gradient
-                // (block_misc.rs:822-832)
-                const float gz = gpair ? gpair[tri_index(f, VEC == 1 ? (inb ? e0 / k : 0) : z)] : g;
-                const float grad = __fmul_rn(gz, G);          // block_ffm.rs:278
-                float acc = Vec<VEC>::get(av[u], j);
-                const float upd = opt_step<OPT>(grad, acc, p.ffm_rate, p.ffm_minus_power_t, s.lut);
-                Vec<VEC>::set(av[u], j, acc);
-                Vec<VEC>::set(wv[u], j, Vec<VEC>::get(wv[u], j) - upd);  // block_ffm.rs:282
+                for (int j = 0; j < VEC; ++j) {
+                    float t = Vec<VEC>::get(tv, j);
+                    if (self) t = __fsub_rn(t, __fmul_rn(Vec<VEC>::get(sw, j), v));  // contra - w*v  block_ffm.rs:238
+                    const float G = __fmul_rn(v, t);             // gradient cache      block_ffm.rs:239, 249
+                    // general gradient of output (f, z): uniform g, or -- deep head -- the mirrored triangle gradient
+                    // (block_misc.rs:822-832)
+                    const float gz = gpair ? gpair[tri_index(f, VEC == 1 ? (inb ? e0 / k : 0) : z)] : g;
+                    const float grad = __fmul_rn(gz, G);          // block_ffm.rs:278
+                    float acc = Vec<VEC>::get(av[u], j);
+                    const float upd = opt_step<OPT>(grad, acc, p.ffm_rate, p.ffm_minus_power_t, s.lut);
+                    Vec<VEC>::set(av[u], j, acc);
+                    Vec<VEC>::set(wv[u], j, Vec<VEC>::get(wv[u], j) - upd);  // block_ffm.rs:282
+                }
+            };
+            apply(idx[u], fld[u] & kFldMask);
+            if (fld[u] & kRowHasChain) {  // later entries of the same hash, in buffer order (see update_rows_win)
+                for (uint32_t base = idx[u] + 1; base < nf; base += 64) {
+                    const uint32_t j = base + lane;
+                    unsigned long long m = __ballot(j < nf && s.e_hash[j] == hsh[u] && (s.e_fld[j] & kRowChained));
+                    while (m) {
+                        const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                        m &= m - 1;
+                        const uint32_t jj = base + b;
+                        apply(jj, __builtin_amdgcn_readfirstlane(s.e_fld[jj]) & kFldMask);
+                    }
+                }
             }
             Vec<VEC>::template store<AUX>(wv[u], rw[u], e0 * 4);
             if (OPT != FWGPU_OPT_SGD) Vec<VEC>::template store<AUX>(av[u], ra[u], e0 * 4);
@@ -1361,9 +1377,9 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
 #pragma unroll
                     for (int u = 0; u < UU; ++u) {
                         const uint32_t i = i0 + u;
-                        idx[u] = (i < nf && !(s.e_fld[i] & kRowDep) && s.e_hash[i] >= olo && s.e_hash[i] < ohi) ? i : 0xffffffffu;
+                        idx[u] = (i < nf && !(s.e_fld[i] & (kRowDep | kRowChained)) && s.e_hash[i] >= olo && s.e_hash[i] < ohi) ? i : 0xffffffffu;
                     }
-                    update_rows<VEC, OPT, AUX, UU>(p, s, idx, g, lane, gpair);
+                    update_rows<VEC, OPT, AUX, UU>(p, s, idx, g, lane, gpair, nf);
                 }
                 // phase B: overlapping rows, strictly in buffer order on one wave
                 if (s.ctr[1]) {
@@ -1373,7 +1389,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                         for (uint32_t i = 0; i < nf; ++i) {
                             if ((s.e_fld[i] & kRowDep) && s.e_hash[i] >= olo && s.e_hash[i] < ohi) {
                                 uint32_t idx[1] = {i};
-                                update_rows<VEC, OPT, AUX, 1>(p, s, idx, g, lane, gpair);
+                                update_rows<VEC, OPT, AUX, 1>(p, s, idx, g, lane, gpair, nf);
                                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                                 __builtin_amdgcn_s_waitcnt(0);
                             }
@@ -1461,8 +1477,9 @@ static hipError_t launch_phase_v(const KernelParams &p, int optimizer, int phase
 hipError_t launch_example_phase(const KernelParams &p_in, int optimizer, int phase, uint32_t grid, uint32_t threads, hipStream_t stream) {
     if (p_in.n_examples == 0) return hipSuccess;
     KernelParams p = p_in;
-    p.window = p.chain = 0;  // (the generic kernel's update path)
+    p.window = 0;  // (the generic kernel's update path)
     p.update = phase == 3 ? 1 : 0;
+    p.chain = p.update;
     const size_t lds = example_kernel_lds_bytes(p, optimizer);
     if (p.k % 4 == 0 && p.aligned4) return launch_phase_v<4>(p, optimizer, phase, grid, threads, lds, stream);
     return launch_phase_v<1>(p, optimizer, phase, grid, threads, lds, stream);
@@ -1962,7 +1979,9 @@ static bool uses_resident_kernel(const KernelParams &p, uint32_t threads) {
 // Whole-line updates and duplicate-row chains exist in the v2 kernel's update path only, and only updating launches need them.
 void resolve_row_mode(KernelParams &p, uint32_t threads) {
     p.window = (p.window && uses_resident_kernel(p, threads) && p.update && p.k_log2 != 0xffu) ? 1 : 0;
-    p.chain = p.window;
+    // chained duplicate rows: the generic kernel's update path and the whole-line path apply them from registers; the
+    // register-resident variant of the v2 kernel (window off) keeps the old route (duplicates serialised in phase B)
+    p.chain = (p.update && (p.window || !uses_resident_kernel(p, threads))) ? 1 : 0;
 }
 
 hipError_t launch_example_kernel(const KernelParams &p_in, int optimizer, bool coherent, uint32_t grid, uint32_t threads,
