@@ -210,6 +210,8 @@ def main():
                          "(frozen dense weights per batch, summed gradients, one AdaGrad step per weight: head.hip); 'exact' = the "
                          "reference's per-example head inside the fused kernel")
     ap.add_argument("--sync", action="store_true", help="run the steps as synchronous micro-batches (fwgpu_learn_batch_sync) also without a deep head")
+    ap.add_argument("--whole-lines", dest="whole_lines", type=int, default=None, choices=[0, 1, 2],
+                    help="FFM row updates as whole 128 B lines + duplicate-row chains: 0 off, 1 auto (default), 2 always (A/B runs)")
     ap.add_argument("--threads", type=int, default=0, help="workgroup size override")
     ap.add_argument("--wgs-per-cu", dest="wgs", type=int, default=0)
     ap.add_argument("--max-in-flight", dest="max_in_flight", type=int, default=0,
@@ -261,6 +263,10 @@ def main():
 
     mi = build_model_instance(fw, args, local_rank)
     re = fw.Regressor(mi)
+    if args.whole_lines is not None:
+        re.set_whole_line_updates(args.whole_lines)
+    if os.environ.get("FWGPU_BENCH_NO_CHAIN"):
+        capi.check(capi.lib().fwgpu_debug_set_option(re.h, 3, 1))
     if args.threads or args.wgs:
         re.set_launch(args.threads, args.wgs)
     if args.max_in_flight:

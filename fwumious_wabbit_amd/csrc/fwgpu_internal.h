@@ -90,6 +90,7 @@ struct KernelParams {
     int32_t aligned4;          // every FFM row of the batch starts on a 16-byte boundary
     int32_t window;            // FFM rows are updated as the whole 128 B lines they touch (v2 kernel; kernels.hip update_rows_win)
     uint32_t k_log2;           // log2(k) when k is a power of two, else 0xff
+    int32_t no_chain;          // debug option 3: duplicate rows are serialised in phase B instead of chained (A/B runs)
     int32_t chain;             // rows of the same hash inside one example are chained to the first and applied from registers (set with window)
     float lr_rate, lr_minus_power_t;    // SGD / AdagradFlex parameters of the LR block
     float ffm_rate, ffm_minus_power_t;  // ... of the FFM block
@@ -121,6 +122,7 @@ struct LaunchConfig {
     int32_t kernel_version = 0;      // 0 = auto
     int32_t lut_global = 0;
     int32_t window = 1;              // whole-line FFM row updates: 0 off, 1 auto (tables > Infinity Cache), 2 always (debug option 2)
+    int32_t no_chain = 0;            // debug option 3
     bool threads_set = false;
     uint32_t max_in_flight = 0;  // cap on the persistent grid = examples processed concurrently (0: what the device holds)  // fwgpu_set_launch chose the workgroup size: no automatic choice
 };

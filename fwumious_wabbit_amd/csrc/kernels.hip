@@ -328,6 +328,7 @@ struct StageTicker {
 };
 
 // Must be called by every thread of the workgroup (it contains barriers).
+template <bool CTX = true>  // CTX: the launch may carry a serving context cache (read-only launches only)
 __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const Lds &s, const SetGeom &g, uint32_t ex,
                                                   int tid, int bd, unsigned long long *tick_out = nullptr) {
     StageTicker tk{tick_out, tick_out ? __builtin_amdgcn_s_memtime() : 0ull};
@@ -561,12 +562,12 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
                 const uint32_t ee = q * vecw, zz = ee / p.k;
                 for (uint32_t j = 0; j < vecw; ++j) {
                     const uint32_t ix = zz * R + f * p.k + (ee - zz * p.k) + j;
-                    s.T[ix] = p.ctx_T ? p.ctx_T[ix] : 0.0f;
+                    s.T[ix] = (CTX && p.ctx_T) ? p.ctx_T[ix] : 0.0f;
                 }
             }
         }
         for (uint32_t f = tid; f < F; f += bd)
-            if (s.fstart[f] == s.fend[f]) s.dcf[f] = p.ctx_dcf ? p.ctx_dcf[f] : 0.0f;
+            if (s.fstart[f] == s.fend[f]) s.dcf[f] = (CTX && p.ctx_dcf) ? p.ctx_dcf[f] : 0.0f;
     }
     if (do_update && s.ctr[2]) {
         // Rare: some rows may overlap.  Exact scan: does an EARLIER feature's row [h_j, h_j+R) overlap mine?
@@ -761,7 +762,7 @@ __device__ __forceinline__ void nn_layer_backward(const DevNN &n, uint32_t l, co
         const float xi = i < split ? in_a[i] : in_b[i - split];
         float oe = 0.0f;
 #ifndef FW_NN_BJU
-#define FW_NN_BJU 8
+#define FW_NN_BJU 16
 #endif
         constexpr int JU = FW_NN_BJU;  // weights (and accumulators) of JU neurons in flight per thread
         for (uint32_t j0 = 0; j0 < out; j0 += JU) {
@@ -980,7 +981,11 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
             hh[u] = __builtin_amdgcn_readfirstlane(s.e_hash[idx[u]]);
             sb[u] = (hh[u] * 4u) & 127u;                          // row start within its first line, bytes
             nb[u] = (sb[u] + R * 4u + 127u) & ~127u;              // whole lines covered, bytes
+#ifdef FW_WIN_NOPASS  // A/B: float-granular accesses for every row (chains stay)
+            if (true) {
+#else
             if (nb[u] > (uint32_t)NCH * 1024u) {                  // (wave-uniform) more lines than NCH chunks hold:
+#endif
                 sb[u] = 0;                                        // this row keeps float-granular accesses
                 nb[u] = R * 4u;
             }
@@ -1086,12 +1091,18 @@ uint32_t split_record_len(uint32_t F, uint32_t R, uint32_t nlr) { return split_l
 //   FWD : stage, gather the rows this rank OWNS (all of them on one GPU), write T / dcf / LR sums to the example's split record
 //   (exchange: records summed over the ranks; MID kernel: logit, prediction, general gradient; or the mini-batched deep head)
 //   UPD : stage, T and the entries' own slots back from the records, AdaGrad on the owned rows and LR entries
-template <int VEC, int OPT, bool COH, int PH = 0>
+template <int VEC, int OPT, bool COH, int PH = 0, bool NN = true>
 __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) {
     typedef typename Vec<VEC>::type V;
     constexpr int AUX = COH ? kAuxSc1 : kAuxPlain;
-    constexpr int UG = 8;  // feature rows in flight per wave in the gather phase
-    constexpr int UU = 4;  // feature rows in flight per wave in the update phase (x2 tables)
+#ifndef FW_V1_UG
+#define FW_V1_UG 8
+#endif
+#ifndef FW_V1_UU
+#define FW_V1_UU 2
+#endif
+    constexpr int UG = FW_V1_UG;  // feature rows in flight per wave in the gather phase
+    constexpr int UU = FW_V1_UU;  // feature rows in flight per wave in the update phase (x2 tables)
     extern __shared__ __align__(16) unsigned char smem[];
     const bool use_lut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global;
     size_t off[23];
@@ -1164,7 +1175,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         if (ex >= p.n_examples) break;
         FW_TICK(6);
         if (timing) tk[7] += 1;
-        const StageOut so = stage_example(p, s, geom, ex, tid, bd);
+        const StageOut so = stage_example<!COH>(p, s, geom, ex, tid, bd);
         uint32_t next_ticket = 0;  // (every thread is past its read of ctr[6]: the stage phase has barriers)
         if (tid == 0) next_ticket = atomicAdd(p.work, 1u);
         const uint32_t nf = so.nf, nl = so.nl;
@@ -1191,7 +1202,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                     const uint32_t z = inb ? e0 / k : 0;
                     const bool self = inb && (z == f);
                     V acc = Vec<VEC>::zero();
-                    if (p.ctx_T && inb) {  // context cache: the cached features of this field come first (block_ffm.rs:548-556)
+                    if (!COH && p.ctx_T && inb) {  // context cache: the cached features of this field come first (block_ffm.rs:548-556)
 #pragma unroll
                         for (int j = 0; j < VEC; ++j) Vec<VEC>::set(acc, j, p.ctx_T[z * R + f * k + (e0 - z * k) + j]);
                     }
@@ -1231,13 +1242,13 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                     if (inb) Vec<VEC>::lds_store(s.T + z * R + f * k + (e0 - z * k), acc);
                 }
                 dc = wave_sum(dc);
-                if (p.ctx_dcf) dc += p.ctx_dcf[f];
+                if (!COH && p.ctx_dcf) dc += p.ctx_dcf[f];
                 s.dcf[f] = dc;  // same value from all 64 lanes
             }
         }
         __syncthreads();
         FW_TICK(2);
-        if (p.emit_T && ex == 0) {  // setup_cache: keep this example's field sums (Regressor::setup_cache, regressor.rs:409-423)
+        if (!COH && p.emit_T && ex == 0) {  // setup_cache: keep this example's field sums (Regressor::setup_cache, regressor.rs:409-423)
             for (uint32_t i = tid; i < F * R; i += bd) p.emit_T[i] = s.T[i];
             for (uint32_t f = tid; f < F; f += bd) p.emit_dcf[f] = s.dcf[f];
         }
@@ -1255,7 +1266,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                 rec[F * R + 2 * F + p.split_nlr + 1] = home ? imp : 0.0f;
             }
             for (uint32_t i = tid; i < nf * k; i += bd) p.split_selfw[(size_t)ex * p.selfw_stride + i] = s.selfw[i];
-            if (p.split_nlr > 1) {  // deep head: one sum per LR combo slot, entries in buffer order (block_lr.rs:36-45)
+            if (NN && p.split_nlr > 1) {  // deep head: one sum per LR combo slot, entries in buffer order (block_lr.rs:36-45)
                 for (uint32_t c = tid; c < p.split_nlr; c += bd) {
                     float acc = 0.0f;
                     for (uint32_t i = 0; i < nl; ++i) {
@@ -1333,7 +1344,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         if (p.has_lr) wsum += lr_t;
         if (k) wsum += 0.5f * (dot_t - dc_t);
         // deep head: the sigmoid sees the final neuron's output instead (regressor.rs:191-323)
-        if (p.nn.n_layers) wsum = nn_forward<VEC, COH>(p, s, nl, tid, bd);
+        if (NN && p.nn.n_layers) wsum = nn_forward<VEC, COH>(p, s, nl, tid, bd);
 
         // ---------------- sigmoid / log-loss gradient (block_loss_functions.rs:105-153)
         if (isnan(wsum)) {
@@ -1355,14 +1366,14 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
 
         // ---------------- update.  g == 0 leaves every weight and accumulator unchanged in all three
         // optimizers (acc += 0, w -= 0), so the whole phase is skipped.
-        const bool head_split = PH == 3 && p.dxbuf != nullptr;  // mini-batched deep head: per-slot gradients come from the head kernels
+        const bool head_split = NN && PH == 3 && p.dxbuf != nullptr;  // mini-batched deep head: per-slot gradients come from the head kernels
         if (do_update && (g != 0.0f || head_split)) {
             // deep head: unwind it first; afterwards every LR slot and every FFM pair has its own general gradient
             const float *gx = nullptr, *gpair = nullptr;
             if (head_split) {
                 gx = p.dxbuf + (size_t)ex * p.nn.X;
                 gpair = gx + p.num_combos;
-            } else if (p.nn.n_layers) {
+            } else if (NN && p.nn.n_layers) {
                 nn_backward<OPT, COH>(p, s, g, tid, bd);
                 gx = nn_buf(p, s).xg;
                 gpair = gx + p.num_combos;
@@ -1442,7 +1453,9 @@ static hipError_t launch_persistent(K kern, const KernelParams &p, uint32_t grid
 
 template <int VEC, int OPT, bool COH>
 static hipError_t launch_t(const KernelParams &p, uint32_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
-    return launch_persistent(fw_example_kernel<VEC, OPT, COH>, p, grid, threads, lds, stream);
+    // (models without a deep head run an instantiation without its code: fewer registers, no spills in the row loops)
+    if (p.nn.n_layers) return launch_persistent(fw_example_kernel<VEC, OPT, COH, 0, true>, p, grid, threads, lds, stream);
+    return launch_persistent(fw_example_kernel<VEC, OPT, COH, 0, false>, p, grid, threads, lds, stream);
 }
 
 template <int VEC>
@@ -1466,11 +1479,19 @@ static hipError_t launch_v(const KernelParams &p, int optimizer, bool coherent, 
 template <int VEC>
 static hipError_t launch_phase_v(const KernelParams &p, int optimizer, int phase, uint32_t grid, uint32_t threads, size_t lds,
                                  hipStream_t stream) {
-    if (phase == 1) return launch_persistent(fw_example_kernel<VEC, FWGPU_OPT_SGD, false, 1>, p, grid, threads, lds, stream);
+    if (p.nn.n_layers) {
+        if (phase == 1) return launch_persistent(fw_example_kernel<VEC, FWGPU_OPT_SGD, false, 1, true>, p, grid, threads, lds, stream);
+        switch (optimizer) {
+        case FWGPU_OPT_SGD: return launch_persistent(fw_example_kernel<VEC, FWGPU_OPT_SGD, true, 3, true>, p, grid, threads, lds, stream);
+        case FWGPU_OPT_ADAGRAD_FLEX: return launch_persistent(fw_example_kernel<VEC, FWGPU_OPT_ADAGRAD_FLEX, true, 3, true>, p, grid, threads, lds, stream);
+        default: return launch_persistent(fw_example_kernel<VEC, FWGPU_OPT_ADAGRAD_LUT, true, 3, true>, p, grid, threads, lds, stream);
+        }
+    }
+    if (phase == 1) return launch_persistent(fw_example_kernel<VEC, FWGPU_OPT_SGD, false, 1, false>, p, grid, threads, lds, stream);
     switch (optimizer) {
-    case FWGPU_OPT_SGD: return launch_persistent(fw_example_kernel<VEC, FWGPU_OPT_SGD, true, 3>, p, grid, threads, lds, stream);
-    case FWGPU_OPT_ADAGRAD_FLEX: return launch_persistent(fw_example_kernel<VEC, FWGPU_OPT_ADAGRAD_FLEX, true, 3>, p, grid, threads, lds, stream);
-    default: return launch_persistent(fw_example_kernel<VEC, FWGPU_OPT_ADAGRAD_LUT, true, 3>, p, grid, threads, lds, stream);
+    case FWGPU_OPT_SGD: return launch_persistent(fw_example_kernel<VEC, FWGPU_OPT_SGD, true, 3, false>, p, grid, threads, lds, stream);
+    case FWGPU_OPT_ADAGRAD_FLEX: return launch_persistent(fw_example_kernel<VEC, FWGPU_OPT_ADAGRAD_FLEX, true, 3, false>, p, grid, threads, lds, stream);
+    default: return launch_persistent(fw_example_kernel<VEC, FWGPU_OPT_ADAGRAD_LUT, true, 3, false>, p, grid, threads, lds, stream);
     }
 }
 
@@ -1479,7 +1500,7 @@ hipError_t launch_example_phase(const KernelParams &p_in, int optimizer, int pha
     KernelParams p = p_in;
     p.window = 0;  // (the generic kernel's update path)
     p.update = phase == 3 ? 1 : 0;
-    p.chain = p.update;
+    p.chain = p.update && !p.no_chain;
     const size_t lds = example_kernel_lds_bytes(p, optimizer);
     if (p.k % 4 == 0 && p.aligned4) return launch_phase_v<4>(p, optimizer, phase, grid, threads, lds, stream);
     return launch_phase_v<1>(p, optimizer, phase, grid, threads, lds, stream);
@@ -1685,7 +1706,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
         if (ex >= p.n_examples) break;
         FW_TICK(6);
         if (timing) atomicAdd(p.ticks + 7, 1ull);
-        const StageOut so = stage_example(p, s, geom, ex, tid, bd, timing ? p.ticks : nullptr);
+        const StageOut so = stage_example<!COH>(p, s, geom, ex, tid, bd, timing ? p.ticks : nullptr);
         uint32_t next_ticket = 0;
         if (tid == 0) next_ticket = atomicAdd(p.work, 1u);
         const uint32_t nf = so.nf, nl = so.nl;
@@ -1734,11 +1755,11 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
             if (cur != 0xffffffffu) {                                                                         \
                 if (inb) Vec<VEC>::lds_store(s.T + z * R + cur * k + kk0, acc);                                \
                 dc = wave_sum(dc);                                                                            \
-                if (p.ctx_dcf) dc += p.ctx_dcf[cur];                                                          \
+                if (!COH && p.ctx_dcf) dc += p.ctx_dcf[cur];                                                  \
                 s.dcf[cur] = dc;                                                                              \
             }                                                                                                 \
             acc = Vec<VEC>::zero();                                                                           \
-            if (p.ctx_T && inb) /* context cache: the cached features of the field come first */              \
+            if (!COH && p.ctx_T && inb) /* context cache: the cached features of the field come first */      \
                 acc = *reinterpret_cast<const f4 *>(p.ctx_T + z * R + f_ * k + kk0);                           \
             dc = 0.0f;                                                                                        \
             cur = f_;                                                                                         \
@@ -1779,14 +1800,14 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
             if (cur != 0xffffffffu) {
                 if (inb) Vec<VEC>::lds_store(s.T + z * R + cur * k + kk0, acc);
                 dc = wave_sum(dc);
-                if (p.ctx_dcf) dc += p.ctx_dcf[cur];
+                if (!COH && p.ctx_dcf) dc += p.ctx_dcf[cur];
                 s.dcf[cur] = dc;
             }
 #undef FW_CONSUME
         }
         __syncthreads();
         FW_TICK(2);
-        if (p.emit_T && ex == 0) {  // setup_cache: keep this example's field sums (Regressor::setup_cache, regressor.rs:409-423)
+        if (!COH && p.emit_T && ex == 0) {  // setup_cache: keep this example's field sums (Regressor::setup_cache, regressor.rs:409-423)
             for (uint32_t i = tid; i < F * R; i += bd) p.emit_T[i] = s.T[i];
             for (uint32_t f = tid; f < F; f += bd) p.emit_dcf[f] = s.dcf[f];
         }
@@ -1981,7 +2002,7 @@ void resolve_row_mode(KernelParams &p, uint32_t threads) {
     p.window = (p.window && uses_resident_kernel(p, threads) && p.update && p.k_log2 != 0xffu) ? 1 : 0;
     // chained duplicate rows: the generic kernel's update path and the whole-line path apply them from registers; the
     // register-resident variant of the v2 kernel (window off) keeps the old route (duplicates serialised in phase B)
-    p.chain = (p.update && (p.window || !uses_resident_kernel(p, threads))) ? 1 : 0;
+    p.chain = (p.update && !p.no_chain && (p.window || !uses_resident_kernel(p, threads))) ? 1 : 0;
 }
 
 hipError_t launch_example_kernel(const KernelParams &p_in, int optimizer, bool coherent, uint32_t grid, uint32_t threads,

@@ -308,6 +308,7 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
     // where concurrent examples would meet on a line most often, so they keep float-granular writes.
     // (launch_example_kernel keeps the flag only where the whole-line path exists.)
     p.window = r->launch.window == 2 || (r->launch.window == 1 && r->ffm_len * 8ull > (256ull << 20)) ? 1 : 0;
+    p.no_chain = r->launch.no_chain;
     p.k_log2 = 0xffu;
     for (uint32_t l = 0; l < 16; l++)
         if ((1u << l) == r->cfg.ffm_k) p.k_log2 = l;
@@ -612,6 +613,7 @@ int fwgpu_debug_set_option(fwgpu_regressor *r, int option, int value) {
     if (!r) return fail(FWGPU_ERR_INVALID, "NULL regressor");
     switch (option) {
     case 1: r->launch.lut_global = value ? 1 : 0; return FWGPU_OK;
+    case 3: r->launch.no_chain = value ? 1 : 0; return FWGPU_OK;  // duplicate-row chains off (A/B runs)
     case 2:  // whole-line FFM row updates: 0 off, 1 auto (tables larger than the Infinity Cache; default), 2 always
         if (value < 0 || value > 2) return fail(FWGPU_ERR_INVALID, "window option: 0, 1 or 2");
         r->launch.window = value;

@@ -8,5 +8,5 @@ mkdir -p $R/build/variants
 cd $R/fwumious_wabbit_amd/csrc
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -I$R/include -I. "$@" -c kernels.hip -o /tmp/k_$NAME.o
 O=$R/fwumious_wabbit_amd/lib/obj
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build/variants/libfwgpu_$NAME.so /tmp/k_$NAME.o $O/regressor.o $O/translate.o $O/trainer.o $O/parser.o $O/cache.o $O/model_file.o $O/serving.o $O/input.o -lz -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build/variants/libfwgpu_$NAME.so /tmp/k_$NAME.o $(ls $O/*.o | grep -v "/kernels.o") -lz -ldl
 echo built $R/build/variants/libfwgpu_$NAME.so

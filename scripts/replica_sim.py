@@ -18,7 +18,7 @@ TABLES = (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)
 hrecs, hoff = bench.gen_records(fw, args, 1_000_000_000, 8192)
 hy = hrecs[hoff[:-1].astype(np.int64) + 1].astype(np.float32)
 
-def run(N, rule):
+def run(N, rule, K=K):
     mi = bench.build_model_instance(fw, args, 0)
     reps = [fw.Regressor(mi) for _ in range(N)]
     fbt = fw.FeatureBufferTranslator(mi)
@@ -56,7 +56,14 @@ def run(N, rule):
     del views, snap
     torch.cuda.empty_cache()
 
-if os.environ.get("ONLY_N"):
+if os.environ.get("EQUAL_TOTAL"):
+    # the comparison that matters: N replicas x M examples each against ONE learner on the same N x M examples
+    print(f"# equal total examples: one learner on N*M examples vs N replicas (mean rule, exchange every {SYNC} steps) on M = {K * B} each")
+    run(1, "mean", K)
+    for N in (2, 4, 8):
+        run(1, "mean", K * N)
+        run(N, "mean", K)
+elif os.environ.get("ONLY_N"):
     run(int(os.environ["ONLY_N"]), "mean")
 elif os.environ.get("ONLY_MEAN"):
     for N in (1, 4, 8):
