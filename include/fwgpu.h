@@ -141,8 +141,15 @@ int fwgpu_block_cache_free(fwgpu_block_cache *cache);
  * Regressor::new_without_weights (regressor.rs:191-320): BlockCopy -> [BlockNeuronLayer -> BlockRELU]* -> Join ->
  * single neuron (InitType::One) in front of the sigmoid.  Call after fwgpu_create and before fwgpu_init_weights.
  * Per-example semantics are the reference's (block_neural.rs:252-340: every dense weight with a non-zero upstream
- * gradient takes an AdaGrad step, neuron by neuron).  Hidden-layer init Hu / Xavier uses the library's own
- * deterministic generator: the reference draws from rand_xoshiro + rand_distr (third party, parity unpinned). */
+ * gradient takes an AdaGrad step, neuron by neuron).
+ * INIT STREAM -- PARITY UNPINNED: hidden-layer init Hu / Xavier draws from the library's own deterministic generator.  The
+ * reference draws from Xoshiro256PlusPlus::seed_from_u64(..) + rand_distr::Normal (block_neural.rs:385-406; third-party crates,
+ * no reference test observes a value), so a model INITIALISED here has the reference's distribution but not its numbers: it is
+ * not the model `fw` would initialise from the same command line.  Cross-checks load identical weights on both sides
+ * (fwgpu_table_write(FWGPU_TABLE_NN_W) or a model file); InitType::One / Zero are exact.
+ * Mini-batch mode: inside fwgpu_learn_batch_sync a deep head trains mini-batched on the matrix cores (dense weights frozen per
+ * batch, gradients summed, ONE optimizer step per weight and batch) -- a different algorithm from the per-example one above,
+ * never chosen implicitly. */
 #define FWGPU_NN_MAX_LAYERS 8
 enum { FWGPU_NN_INIT_XAVIER = 0, FWGPU_NN_INIT_HU = 1, FWGPU_NN_INIT_ONE = 2, FWGPU_NN_INIT_ZERO = 3 };
 typedef struct fwgpu_nn_config {

@@ -9,12 +9,18 @@ mkdir -p $OUT
 timeout 600 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 tail -c 600 $OUT/${TAG}_bench.json
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline"
+CMD="python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-traffic"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o trace -- $CMD > $OUT/${TAG}_trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --pmc FETCH_SIZE -d $OUT/${TAG}_fetch -o fetch -- $CMD > $OUT/${TAG}_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --pmc WRITE_SIZE -d $OUT/${TAG}_write -o write -- $CMD > $OUT/${TAG}_write.log 2>&1
 cd $R
 python3 scripts/rocprof_summary.py $(find $OUT/${TAG}_trace $OUT/${TAG}_fetch $OUT/${TAG}_write -name "*.db" | sort) > $OUT/${TAG}_kernel_rocprofv3.txt 2>&1
 head -40 $OUT/${TAG}_kernel_rocprofv3.txt
-MASTER_ADDR=127.0.0.1 MASTER_PORT=29544 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 600 python3 bench.py --force-dist --no-cpu-baseline > $OUT/${TAG}_bench_dist1.json 2> $OUT/${TAG}_bench_dist1.err
-tail -c 1200 $OUT/${TAG}_bench_dist1.json | head -c 1200
+# the multi-GPU code paths with ONE rank over RCCL (library communicator): replica exchange + sharded leg, then the sharded step as the timed mode
+MASTER_ADDR=127.0.0.1 MASTER_PORT=29544 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 600 python3 bench.py --force-dist --no-cpu-baseline --no-traffic > $OUT/${TAG}_bench_dist1_replica.json 2> $OUT/${TAG}_bench_dist1_replica.err
+MASTER_ADDR=127.0.0.1 MASTER_PORT=29545 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 600 python3 bench.py --force-dist --dp-mode sharded --steps 96 --no-cpu-baseline --no-traffic > $OUT/${TAG}_bench_dist1_sharded.json 2> $OUT/${TAG}_bench_dist1_sharded.err
+tail -c 700 $OUT/${TAG}_bench_dist1_replica.json; echo; tail -c 400 $OUT/${TAG}_bench_dist1_sharded.json; echo
+# config E (configs[4]): exact head (the default) and the mini-batched MFMA head
+timeout 600 python3 bench.py --k 16 --nn-layers 2 --batch 8192 --steps 24 --warmup 2 > $OUT/${TAG}_configE_exact.json 2> $OUT/${TAG}_configE_exact.err
+timeout 600 python3 bench.py --k 16 --nn-layers 2 --head minibatch --batch 1024 --steps 192 --warmup 4 --no-cpu-baseline > $OUT/${TAG}_configE_minibatch.json 2> $OUT/${TAG}_configE_minibatch.err
+tail -c 500 $OUT/${TAG}_configE_exact.json | head -c 300; echo
