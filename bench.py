@@ -170,8 +170,13 @@ def measure_traffic(args):
                     rows = list(con.execute("select kernel_name, value from counters_collection where counter_name = ? and "
                                             "kernel_name like '%fw_example_kernel%'", (ctr,)))
                     con.close()
-                    # the updating launches: coherent (sc1) instantiations, `<..., true, ...>`; predict-only passes are not
-                    vals += [v for name, v in rows if ", true" in name and "phase" not in name]
+                    # the updating launches are the coherent (sc1) instantiations: template argument COH, the 2nd of
+                    # fw_example_kernel_r<OPT, COH, MAXR, WIN> and the 3rd of fw_example_kernel<VEC, OPT, COH, PHASE, NN>
+                    for name, v in rows:
+                        targs = name[name.index("<") + 1:name.index(">")].replace(" ", "").split(",") if "<" in name else []
+                        coh = targs[1] if "kernel_r<" in name else (targs[2] if len(targs) > 2 else "")
+                        if coh == "true":
+                            vals.append(v)
                 if not vals:
                     return None, f"rocprofv3 --pmc {ctr}: no dispatch of the learn kernel found"
                 # every timed dispatch of the child has the same shape: take the median

@@ -1184,14 +1184,12 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         FW_TICK(1);
         // ---------------- gather: field sums, transposed into LDS
         if (k && PH != 3) {
-            for (;;) {
-                // Dynamic field -> wave assignment.  Every lane takes part in the atomic (lane 0 adds 1, the others
-                // add 0, so lane 0 always gets the old counter) and NO lane-conditional BRANCH may sit in this
-                // loop: a lane-0-only statement here gets jump-threaded into the next iteration's increment and
-                // readfirstlane then runs under a divergent mask (lanes 1..63 spin on field 0 forever).
-                const uint32_t ticket = atomicAdd(&s.ctr[0], lane == 0 ? 1u : 0u);
-                const uint32_t f = __builtin_amdgcn_readfirstlane(ticket);
-                if (f >= F) break;
+            // Static field -> wave assignment: wave w takes the fields whose first feature index falls into its share
+            // (owner(f) = floor(fstart[f] * n_waves / n_features): contiguous, balanced by features, as in the v2 kernel).
+            // (Round 1 handed fields out through an LDS ticket; that loop was only correct as long as the compiler did not
+            // jump-thread a lane-conditional branch into it -- a hang inside a persistent kernel.  No atomics, no hazard.)
+            for (uint32_t f = 0; f < F; ++f) {
+                if (s.fstart[f] == s.fend[f] || (s.fstart[f] * (uint32_t)nw) / nf != (uint32_t)wave) continue;
                 const uint32_t fs = s.fstart[f], fe = s.fend[f];
                 // sum_{i in field f} v_i^2 |w_i[f*k..]|^2 (block_ffm.rs:418-426).  Reduced per field so that the
                 // result does not depend on which wave happened to take the field.
