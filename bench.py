@@ -395,6 +395,27 @@ def main():
     p_last = batches[W + K - 1].predictions(sptr)
     saturated = float(np.mean((p_last < 1e-20) | (p_last > 1.0 - 1e-7)))
 
+    # ---- secondary figure, never `value`: the same workload fed from HOST memory through the HogwildTrainer replacement
+    # (fwgpu_digest_records: pinned staging, PCIe, device-side translation + learn; hogwild.rs:51-60's boundary)
+    pcie = None
+    if rank == 0 and world == 1 and not use_dist and not sync_steps and args.cpu:
+        try:
+            n_p = 4 * min(B, 65536)
+            precs, poff = gen_records(fw, args, 3_000_000_000, n_p)
+            tr = fw.HogwildTrainer(re, mi, micro_batch=16384)
+            tr.digest_records(precs[: int(poff[4096])], poff[:4097])
+            tr.block_until_workers_finished()
+            tp = time.perf_counter()
+            tr.digest_records(precs, poff)
+            tr.block_until_workers_finished()
+            dtp = time.perf_counter() - tp
+            tr.close()
+            pcie = {"value": n_p / dtp, "unit": "examples/sec", "examples": n_p, "megabytes": precs.nbytes / 1e6,
+                    "what": "records in pageable host memory -> fwgpu_digest_records (pinned staging, PCIe, 16 384-example micro-batches) -> learned"}
+            del precs
+        except Exception as e:
+            pcie = {"value": None, "what": f"failed: {e!r}"}
+
     # ---- the OTHER multi-GPU mode, timed on a short leg of its own (a replica run reports both; the owner-sharded step leaves
     # every rank with only its own range current, so it comes last)
     dp_modes = None
@@ -483,6 +504,8 @@ def main():
                 "launch_ms_min_median_max": [float(np.min(kernel_ms)), float(np.median(kernel_ms)), float(np.max(kernel_ms))],
             },
         }
+        if pcie is not None:
+            out["pcie_inclusive"] = pcie
         if dp_modes is not None:
             out["dp_modes"] = dp_modes
         if args.cpu and world == 1:

@@ -25,7 +25,8 @@ with open(os.path.join(ROOT, "tests", "golden", "reference_kats.json")) as f:
 PRED_TOL = 1e-5      # |p_gpu - p_ref| on a single prediction (f32 summation-order noise is ~1e-7)
 LOGLOSS_TOL = 1e-4   # north_star: per-example log-loss tolerance
 # Concurrent (hogwild) training is a different, stale-gradient algorithm -- as is the reference's own hogwild mode --
-# so it is compared on the final hold-out log-loss of short streams (12-24k examples, loss still falling fast).
+# so it is compared on the final hold-out log-loss of short streams (12-24k examples, loss still falling fast: the whole learnable gap of
+# these streams is 0.04-0.09).  Measured spread of the gap over 12 runs: 0.0055 .. 0.0154 (scripts/holdout_spread.py).
 HOLDOUT_TOL = 0.02
 
 
@@ -668,9 +669,9 @@ def test_trainer_digest_records_matches_manual_batches():
     hb = re.batch_from_records(fw.FeatureBufferTranslator(mi), recs[int(off[n_train]):], off[n_train:] - off[n_train])
     re.learn_batch(hb, capi.MODE_HOGWILD, False)
     gpu_hold = float(logloss(hb.predictions(), y[n_train:]).mean())
-    # 12 000 tiny examples with ~500 in flight at once: measured gap to the sequential oracle 0.006 .. 0.015 over 12 runs
-    # (scripts/holdout_spread.py); the bound leaves room for the scheduling-dependent spread
-    assert abs(gpu_hold - ref_hold) < 1.5 * HOLDOUT_TOL, (gpu_hold, ref_hold)
+    # 12 000 tiny examples with ~500 in flight at once: measured gap to the sequential oracle 0.0055 .. 0.0154 over 12 runs
+    # (scripts/holdout_spread.py, round 2); the bound is that spread plus a third
+    assert abs(gpu_hold - ref_hold) < HOLDOUT_TOL, (gpu_hold, ref_hold)
     tr.close()
     re.close()
 
