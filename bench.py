@@ -317,9 +317,27 @@ def main():
             # the library's own RCCL communicator (C ABI): rank 0 draws the id, torch.distributed is only the side channel
             from fwumious_wabbit_amd.dist import DistRank, unique_id
 
-            box = [unique_id() if rank == 0 else None]
+            # (any failure here -- no librccl for the library, an id that does not get through -- leaves the torch.distributed
+            # exchange in place: a multi-GPU bench line must not die on the choice of communicator)
+            try:
+                box = [unique_id() if rank == 0 else None]
+            except Exception as e:
+                box = [None]
+                print(f"[bench] library RCCL unavailable ({e!r}): torch.distributed does the exchange", file=sys.stderr)
             dist.broadcast_object_list(box, src=0)
-            dist_rank = DistRank(re, box[0], rank, world)
+            if box[0] is not None:
+                try:
+                    dist_rank = DistRank(re, box[0], rank, world)
+                    ok = 1
+                except Exception as e:
+                    ok = 0
+                    print(f"[bench] fwgpu_dist_init failed on rank {rank} ({e!r})", file=sys.stderr)
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:  # all ranks or none
+                    if dist_rank is not None:
+                        dist_rank.close()
+                    dist_rank = None
         tabs = [capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC]
         if args.nn_layers:  # the dense head is part of the replica (config E)
             tabs += [capi.TABLE_NN_W, capi.TABLE_NN_ACC]
