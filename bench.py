@@ -224,11 +224,13 @@ def main():
     ap.add_argument("--sync-every", dest="sync_every", type=int, default=0, help="N>1: steps between delta all-reduces")
     ap.add_argument("--combine", choices=["mean", "sum"], default="mean",
                     help="N>1: the agreed model moves by the mean (default) or the sum of the replicas' deltas")
-    ap.add_argument("--dp-mode", dest="dp_mode", choices=["replica", "sharded"], default="replica",
+    ap.add_argument("--dp-mode", dest="dp_mode", choices=["replica", "sharded", "sparse"], default="replica",
                     help="N>1: 'replica' = full replicas + overlapped RCCL all-reduce of the table deltas every --sync-every steps "
                          "(the timed mode of a multi-GPU run); 'sharded' = owner-sharded tables, synchronous step with all-gather / "
                          "reduce-scatter of field sums (fwgpu_dist_learn_sharded_batch).  A replica run also times a short "
-                         "sharded leg and reports it as dp_modes.sharded")
+                         "sharded leg and reports it as dp_modes.sharded; 'sparse' = full replicas, per-micro-batch all-gather of "
+                         "deduplicated row gradients, one summed-gradient step per row (fwgpu_dist_learn_sparse_batch), also timed "
+                         "as dp_modes.sparse on a replica run")
     ap.add_argument("--rccl", choices=["library", "torch"], default="library",
                     help="N>1 replica exchange: through the library's own RCCL communicator (C ABI, fwgpu_dist_all_reduce_sum) or torch.distributed")
     ap.add_argument("--blocking-sync", dest="blocking_sync", action="store_true",
@@ -281,7 +283,8 @@ def main():
     sync_steps = args.sync or (args.nn_layers > 0 and args.head == "minibatch")
     if args.batch is None:
         # synchronous micro-batches are stable up to ~2048 examples at these hyper-parameters (profiles/r02_sync_batch_stability.txt)
-        args.batch = max(64, 2048 // world) if (use_dist and args.dp_mode == "sharded") else (2048 if sync_steps else 65536)
+        args.batch = (max(64, 2048 // world) if (use_dist and args.dp_mode == "sharded") else
+                      16384 if (use_dist and args.dp_mode == "sparse") else (2048 if sync_steps else 65536))
     K, W, B = args.steps, args.warmup, args.batch
     # every rank trains on its own shard of the stream: examples [rank*(W+K)*B, ...)
     t0 = time.time()
@@ -354,14 +357,17 @@ def main():
     for _ in range(64):
         re.learn_batch(hbatch, capi.MODE_HOGWILD, False, sptr)
     torch.cuda.synchronize()
-    sharded_main = use_dist and args.dp_mode == "sharded"
+    sparse_main = use_dist and args.dp_mode == "sparse"
+    sharded_main = (use_dist and args.dp_mode == "sharded") or sparse_main  # (both: synchronous steps inside the library, no replica exchange)
     if sharded_main and dist_rank is None:
-        raise SystemExit("--dp-mode sharded needs the RCCL backend (one rank per GPU) and a model without a deep head")
+        raise SystemExit(f"--dp-mode {args.dp_mode} needs the RCCL backend (one rank per GPU) and a model without a deep head")
 
     split = re.split_buffers(B, 1024) if sync_steps else None
 
     def step(b):
-        if sharded_main:  # owner-sharded synchronous step: all-gather records, reduce-scatter field sums, owner-side updates
+        if sparse_main:  # row-sparse gradient buckets: full replicas, all-gather of deduplicated row gradients, one step per row
+            dist_rank.learn_sparse_batch(fbt, b)
+        elif sharded_main:  # owner-sharded synchronous step: all-gather records, reduce-scatter field sums, owner-side updates
             dist_rank.learn_sharded_batch(fbt, b)
         elif sync_steps:  # synchronous micro-batch on this GPU (deep head: mini-batched on the matrix cores)
             re.learn_batch_sync(b, split, capi.MODE_HOGWILD, sptr)
@@ -401,7 +407,8 @@ def main():
     kernel_ms = [ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(K)]
     if sharded_main:  # the step runs on the library's own stream and is host-synchronous: the step time is the wall time
         kernel_ms = [1e3 * elapsed / K] * K
-        dist_rank.gather_tables()  # every rank gets the whole model back for the hold-out pass
+        if not sparse_main:
+            dist_rank.gather_tables()  # every rank gets the whole model back for the hold-out pass
     avg_kernel_ms = float(np.mean(kernel_ms))
     alg_bytes = float(np.mean([algorithmic_bytes(args, batches[W + i], words[W + i]) for i in range(K)]))
 
@@ -438,6 +445,23 @@ def main():
     # every rank with only its own range current, so it comes last)
     dp_modes = None
     if use_dist and dist_rank is not None and not sharded_main:
+        # row-sparse gradient buckets first (it keeps the replicas whole)
+        Kp, Bp = min(K, 8), 16384
+        precs_, poff_ = gen_records(fw, args, 2_500_000_000 + rank * Kp * Bp, Kp * Bp)
+        pb = [re.record_batch(fbt, precs_[int(poff_[j * Bp]):int(poff_[(j + 1) * Bp])], poff_[j * Bp:(j + 1) * Bp + 1] - poff_[j * Bp]) for j in range(Kp)]
+        dist_rank.learn_sparse_batch(fbt, pb[0])
+        torch.cuda.synchronize()
+        dist.barrier()
+        ts = time.perf_counter()
+        for j in range(Kp):
+            dist_rank.learn_sparse_batch(fbt, pb[j])
+        torch.cuda.synchronize()
+        dist.barrier()
+        tsp = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tsp, op=dist.ReduceOp.MAX)
+        for x in pb:
+            x.close()
+        del precs_
         Ks, Bs = min(K, 24), max(64, 2048 // world)  # global synchronous micro-batch of 2048 examples (stability limit, see --batch)
         srecs, soff = gen_records(fw, args, 2_000_000_000 + rank * Ks * Bs, Ks * Bs)
         sb = [re.record_batch(fbt, srecs[int(soff[j * Bs]):int(soff[(j + 1) * Bs])], soff[j * Bs:(j + 1) * Bs + 1] - soff[j * Bs]) for j in range(Ks)]
@@ -452,6 +476,10 @@ def main():
         tsh = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device="cuda")
         dist.all_reduce(tsh, op=dist.ReduceOp.MAX)
         dp_modes = {"replica": "the timed mode of this line",
+                    "sparse": {"value": world * Kp * Bp / float(tsp.item()), "unit": "examples/sec", "steps": Kp,
+                               "examples_per_step_per_gpu": Bp, "ms_per_step": 1e3 * float(tsp.item()) / Kp,
+                               "what": "full replicas, per-micro-batch all-gather of deduplicated row gradients, every rank applies all of "
+                                       "them: one summed-gradient AdaGrad step per row (fwgpu_dist_learn_sparse_batch)"},
                     "sharded": {"value": world * Ks * Bs / float(tsh.item()), "unit": "examples/sec", "steps": Ks,
                                 "examples_per_step_per_gpu": Bs, "ms_per_step": 1e3 * float(tsh.item()) / Ks,
                                 "what": "owner-sharded tables, synchronous step of n_gpus x examples_per_step_per_gpu examples: all-gather of "
@@ -494,6 +522,8 @@ def main():
                 "mode": ("synchronous micro-batches (every example sees the batch-start weights; FWD / MID / head on MFMA / UPD kernels)" if sync_steps
                          else "hogwild (device-wide concurrent examples, racy RMW, sc1 accesses)"),
                 "parallelism": ("1 GPU" if not use_dist else
+                                f"dp{world} sparse: full replicas, per-micro-batch all-gather of deduplicated row gradients of {world} x {B} examples, "
+                                f"one summed-gradient AdaGrad step per row on every replica, RCCL inside the library" if sparse_main else
                                 f"dp{world} sharded: owner-sharded tables, synchronous step of {world} x {B} examples (records all-gathered, field sums "
                                 f"reduce-scattered / all-gathered, owner-side AdaGrad), RCCL inside the library" if sharded_main else
                                 f"dp{world}: replicas, {'blocking' if args.blocking_sync else 'overlapped'} RCCL all-reduce ({'library communicator, C ABI' if syncer.dist_rank is not None else 'torch.distributed'}) "

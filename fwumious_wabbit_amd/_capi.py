@@ -139,6 +139,9 @@ def lib():
         "fwgpu_dist_group_free": [vp],
         "fwgpu_dist_group_learn_sharded": [vp, P(TranslatorConfig), vp, vp, u32, vp],
         "fwgpu_dist_group_gather_tables": [vp],
+        "fwgpu_dist_learn_sparse": [vp, P(TranslatorConfig), vp, vp, u32, vp],
+        "fwgpu_dist_learn_sparse_batch": [vp, P(TranslatorConfig), vp],
+        "fwgpu_dist_group_learn_sparse": [vp, P(TranslatorConfig), vp, vp, vp, vp],
         "fwgpu_split_create": [vp, u32, u32, P(vp)],
         "fwgpu_split_free": [vp],
         "fwgpu_learn_batch_sync": [vp, vp, vp, i32, vp],

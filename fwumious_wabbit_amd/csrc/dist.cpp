@@ -95,7 +95,40 @@ struct fwgpu_dist {
     uint32_t *d_shape = nullptr;     // [n * 4] per rank: max_lr, max_ffm, max_rec, n_records (all-gathered)
     const fwgpu_translator_config *tr = nullptr;
     fwgpu_batch *src = nullptr;      // this step's own records, when they are already in HBM
+    // row-sparse gradient mode (sparse.hip): one side per table
+    struct SparseSide {
+        uint32_t occ_cap = 0;        // occurrence slots (= bucket rows in the worst case) the buffers hold
+        uint32_t width = 1;          // floats per bucket row (R, or 1 for LR)
+        unsigned long long *key = nullptr, *key_sorted = nullptr;
+        uint2 *desc = nullptr;
+        uint32_t *flags = nullptr, *pos = nullptr, *bk_key = nullptr;
+        float *bk_rows = nullptr;
+        uint64_t all_cap = 0;        // gathered bucket rows of all ranks
+        uint32_t *all_key = nullptr;
+        float *all_rows = nullptr;
+        unsigned long long *m_key = nullptr, *m_key_sorted = nullptr;
+        uint32_t stride = 0;         // this step: bucket rows reserved per rank in the gathered arrays
+        void release() {
+            for (void *q : {(void *)key, (void *)key_sorted, (void *)desc, (void *)flags, (void *)pos, (void *)bk_key, (void *)bk_rows,
+                            (void *)all_key, (void *)all_rows, (void *)m_key, (void *)m_key_sorted})
+                if (q) (void)hipFree(q);
+            *this = SparseSide();
+        }
+    } sf, sl;
+    void *sp_tmp = nullptr;          // rocPRIM scratch
+    size_t sp_tmp_bytes = 0;
+    uint32_t *d_counts = nullptr;    // [2 + 2 * n]: own {ffm, lr} bucket rows, then every rank's
+    fwgpu_batch *ob = nullptr;       // own records of the step (host-record entry point)
+    uint32_t ob_ncap = 0;
+    uint64_t ob_wcap = 0;
+    fwgpu_batch *cur = nullptr;      // the batch this sparse step runs on
+    uint32_t occ_max_ffm = 0, occ_max_lr = 0;
     ~fwgpu_dist() {
+        sf.release();
+        sl.release();
+        if (sp_tmp) (void)hipFree(sp_tmp);
+        if (d_counts) (void)hipFree(d_counts);
+        if (ob) fwgpu_batch_free(ob);
         if (gb) fwgpu_batch_free(gb);
         if (sp) fwgpu_split_free(sp);
         if (d_own) (void)hipFree(d_own);
@@ -123,9 +156,17 @@ void set_ranges(fwgpu_dist *d) {
 }
 
 // ---- step, rank-local parts.  S0: take this rank's records, size the buffers.
+int check_shardable(const fwgpu_dist *d) {
+    const fwgpu_regressor *r = d->r;
+    if (r->cfg.ffm_k && (((1ull << r->cfg.ffm_bit_precision) / d->n) % 64 != 0 || (1ull << r->cfg.ffm_bit_precision) % d->n != 0))
+        return fail(FWGPU_ERR_INVALID, "sharded step: the FFM table does not split into n ranges of whole 256 B blocks");
+    return FWGPU_OK;
+}
+
 int step_begin(fwgpu_dist *d, const fwgpu_translator_config *t, const uint32_t *records, const uint64_t *rec_off, uint32_t n,
                uint32_t shape[4]) {
     if (!t || (n && (!records || !rec_off))) return fail(FWGPU_ERR_INVALID, "dist step: NULL argument");
+    if (int rc0 = check_shardable(d)) return rc0;
     FWGPU_HIP(hipSetDevice(d->r->device));
     RecordStats st;
     int rc = count_records(t, records, rec_off, n, &st);
@@ -143,6 +184,7 @@ int step_begin(fwgpu_dist *d, const fwgpu_translator_config *t, const uint32_t *
 int step_begin_batch(fwgpu_dist *d, const fwgpu_translator_config *t, fwgpu_batch *b, uint32_t shape[4]) {
     if (!t || !b || !b->records) return fail(FWGPU_ERR_INVALID, "dist step: a record batch is needed");
     if (b->owner != d->r) return fail(FWGPU_ERR_INVALID, "dist step: batch belongs to another regressor");
+    if (int rc0 = check_shardable(d)) return rc0;
     FWGPU_HIP(hipSetDevice(d->r->device));
     shape[0] = b->max_lr;
     shape[1] = b->max_ffm;
@@ -238,11 +280,225 @@ int finish(fwgpu_dist *d, float *preds) {
     return FWGPU_OK;
 }
 
+// ------------------------------------------------------------------ row-sparse gradient buckets (sparse.hip)
+int ceil_log2(uint64_t v) {
+    int b = 0;
+    while ((1ull << b) < v) ++b;
+    return b;
+}
+
+template <typename T>
+int grow(T *&q, size_t count) {
+    if (q) (void)hipFree(q);
+    q = nullptr;
+    FWGPU_HIP(hipMalloc((void **)&q, std::max<size_t>(count, 1) * sizeof(T)));
+    return FWGPU_OK;
+}
+
+int sparse_side_reserve(fwgpu_dist::SparseSide &s, uint32_t occ_cap, uint32_t width) {
+    if (s.occ_cap >= occ_cap && s.width == width) return FWGPU_OK;
+    s.release();
+    s.width = width;
+    int rc;
+    if ((rc = grow(s.key, occ_cap)) || (rc = grow(s.key_sorted, occ_cap)) || (rc = grow(s.desc, occ_cap)) ||
+        (rc = grow(s.flags, (size_t)occ_cap + 1)) || (rc = grow(s.pos, (size_t)occ_cap + 1)) || (rc = grow(s.bk_key, occ_cap)) ||
+        (rc = grow(s.bk_rows, (size_t)occ_cap * width)))
+        return rc;
+    s.occ_cap = occ_cap;
+    return FWGPU_OK;
+}
+
+int sparse_side_reserve_all(fwgpu_dist::SparseSide &s, uint64_t rows) {
+    if (s.all_cap >= rows) return FWGPU_OK;
+    for (void *q : {(void *)s.all_key, (void *)s.all_rows, (void *)s.m_key, (void *)s.m_key_sorted})
+        if (q) (void)hipFree(q);
+    s.all_key = nullptr;
+    s.all_rows = nullptr;
+    s.m_key = s.m_key_sorted = nullptr;
+    s.all_cap = 0;
+    int rc;
+    if ((rc = grow(s.all_key, rows)) || (rc = grow(s.all_rows, rows * s.width)) || (rc = grow(s.m_key, rows)) || (rc = grow(s.m_key_sorted, rows)))
+        return rc;
+    s.all_cap = rows;
+    return FWGPU_OK;
+}
+
+// S0: the step's records (host records are uploaded into the rank's own record batch; a device batch is used as it is)
+int sparse_begin(fwgpu_dist *d, const fwgpu_translator_config *t, const uint32_t *records, const uint64_t *rec_off, uint32_t n,
+                 fwgpu_batch *dev_batch, uint32_t shape[4]) {
+    if (d->r->nn.n_layers) return fail(FWGPU_ERR_INVALID, "sparse step: models with a deep head are not covered");
+    if (d->r->cfg.ffm_k > 64) return fail(FWGPU_ERR_INVALID, "sparse step: ffm_k > 64 is not covered");
+    FWGPU_HIP(hipSetDevice(d->r->device));
+    d->tr = t;
+    if (dev_batch) {
+        if (!t || !dev_batch->records) return fail(FWGPU_ERR_INVALID, "sparse step: a record batch is needed");
+        if (dev_batch->owner != d->r) return fail(FWGPU_ERR_INVALID, "sparse step: batch belongs to another regressor");
+        d->cur = dev_batch;
+    } else {
+        if (!t || (n && (!records || !rec_off))) return fail(FWGPU_ERR_INVALID, "sparse step: NULL argument");
+        RecordStats st;
+        int rc = count_records(t, records, rec_off, n, &st);
+        if (rc) return rc;
+        const uint64_t words = n ? rec_off[n] - rec_off[0] : 0;
+        if (!d->ob || d->ob_ncap < n || d->ob_wcap < words) {
+            if (d->ob) fwgpu_batch_free(d->ob);
+            d->ob = nullptr;
+            rc = record_batch_alloc(d->r, t, std::max<uint32_t>(n, 1), std::max<uint64_t>(words, 64), &d->ob);
+            if (rc) return rc;
+            d->ob_ncap = std::max<uint32_t>(n, 1);
+            d->ob_wcap = std::max<uint64_t>(words, 64);
+        }
+        if (n) {
+            rc = record_batch_upload(d->ob, t, records, rec_off, n, d->stream, &st);
+            if (rc) return rc;
+        } else {
+            d->ob->n = 0;
+            d->ob->max_lr = d->ob->max_ffm = d->ob->max_rec = 0;
+        }
+        d->cur = d->ob;
+    }
+    d->B = d->cur->n;
+    shape[0] = d->cur->max_lr;
+    shape[1] = d->cur->max_ffm;
+    shape[2] = d->cur->max_rec;
+    shape[3] = d->cur->n;
+    return FWGPU_OK;
+}
+
+// S1: buffers for the largest batch shape of the job, then FWD, MID and the local segment reduction; the bucket-row counts
+// {ffm, lr} end up in d_counts[0..1]
+int sparse_local(fwgpu_dist *d, const uint32_t *shapes /*[n*4]*/) {
+    fwgpu_regressor *r = d->r;
+    uint32_t max_lr = 0, max_ffm = 0, max_n = 0;
+    for (int j = 0; j < d->n; j++) {
+        max_lr = std::max(max_lr, shapes[4 * j]);
+        max_ffm = std::max(max_ffm, shapes[4 * j + 1]);
+        max_n = std::max(max_n, shapes[4 * j + 3]);
+    }
+    const bool has_lr = r->cfg.wiring != FWGPU_WIRING_FFM_ONLY, has_ffm = r->cfg.ffm_k != 0;
+    const uint32_t F = has_ffm ? r->cfg.ffm_num_fields : 0, R = F * r->cfg.ffm_k;
+    const uint64_t sf_cap = has_ffm ? (uint64_t)max_n * std::max<uint32_t>(4, (max_ffm + 3) & ~3u) : 0;
+    const uint64_t sl_cap = has_lr ? (uint64_t)max_n * std::max<uint32_t>(4, (max_lr + 3) & ~3u) : 0;
+    if (sf_cap >= 0xffffffffull || sl_cap >= 0xffffffffull) return fail(FWGPU_ERR_RANGE, "sparse step: micro-batch too large for 32-bit occurrence slots");
+    int rc;
+    if (has_ffm && (rc = sparse_side_reserve(d->sf, (uint32_t)sf_cap, R))) return rc;
+    if (has_lr && (rc = sparse_side_reserve(d->sl, (uint32_t)sl_cap, 1))) return rc;
+    const size_t tmp = sparse_tmp_bytes((uint32_t)std::max<uint64_t>(std::max(sf_cap, sl_cap) * (uint64_t)d->n, 1));
+    if (d->sp_tmp_bytes < tmp) {
+        if (d->sp_tmp) (void)hipFree(d->sp_tmp);
+        d->sp_tmp = nullptr;
+        FWGPU_HIP(hipMalloc(&d->sp_tmp, tmp));
+        d->sp_tmp_bytes = tmp;
+    }
+    if (!d->d_counts) {
+        FWGPU_HIP(hipMalloc((void **)&d->d_counts, (size_t)(2 + 2 * d->n) * 4));
+    }
+    FWGPU_HIP(hipMemsetAsync(d->d_counts, 0, (size_t)(2 + 2 * d->n) * 4, d->stream));
+    const uint32_t n = d->B;
+    if (!n) return FWGPU_OK;
+    if (!d->sp || d->sp_n < n || d->sp_ffm < max_ffm) {
+        if (d->sp) fwgpu_split_free(d->sp);
+        d->sp = nullptr;
+        rc = fwgpu_split_create(r, std::max(n, max_n), std::max<uint32_t>(max_ffm, 16), &d->sp);
+        if (rc) return rc;
+        d->sp_n = std::max(n, max_n);
+        d->sp_ffm = max_ffm;
+    }
+    OccBuffers occ;
+    occ.ffm_key = has_ffm ? d->sf.key : nullptr;
+    occ.ffm_desc = d->sf.desc;
+    occ.lr_key = has_lr ? d->sl.key : nullptr;
+    occ.lr_desc = d->sl.desc;
+    SplitRanges rg;  // full replica: every row is this rank's, every example of the launch is its own
+    rc = split_forward(r, d->cur, d->sp, FWGPU_MODE_HOGWILD, rg, d->stream, &occ, &d->occ_max_ffm, &d->occ_max_lr);
+    if (rc) return rc;
+    rc = split_mid(r, d->sp, 0, n, d->cur->pred, false, d->stream);
+    if (rc) return rc;
+    if (has_ffm) {
+        SparseReduceArgs a{};
+        a.keys = d->sf.key;
+        a.keys_sorted = d->sf.key_sorted;
+        a.n = n * d->occ_max_ffm;
+        a.key_bits = 32 + ceil_log2(r->ffm_len);
+        a.desc = d->sf.desc;
+        a.max_entries = d->occ_max_ffm;
+        a.flags = d->sf.flags;
+        a.pos = d->sf.pos;
+        a.tmp = d->sp_tmp;
+        a.tmp_bytes = d->sp_tmp_bytes;
+        a.R = R;
+        a.k = r->cfg.ffm_k;
+        a.split = d->sp->d_split;
+        a.split_len = d->sp->split_len;
+        a.selfw = d->sp->d_selfw;
+        a.selfw_stride = d->sp->selfw_stride;
+        a.gbuf = d->sp->d_g;
+        a.bk_key = d->sf.bk_key;
+        a.bk_rows = d->sf.bk_rows;
+        a.d_count = d->d_counts;
+        if (a.n > d->sf.occ_cap) return fail(FWGPU_ERR_RANGE, "sparse step: occurrence buffers too small");
+        FWGPU_HIP(sparse_reduce(a, d->stream));
+    }
+    if (has_lr) {
+        SparseReduceArgs a{};
+        a.keys = d->sl.key;
+        a.keys_sorted = d->sl.key_sorted;
+        a.n = n * d->occ_max_lr;
+        a.key_bits = 32 + ceil_log2(r->lr_len);
+        a.desc = d->sl.desc;
+        a.max_entries = d->occ_max_lr;
+        a.flags = d->sl.flags;
+        a.pos = d->sl.pos;
+        a.tmp = d->sp_tmp;
+        a.tmp_bytes = d->sp_tmp_bytes;
+        a.R = 0;
+        a.gbuf = d->sp->d_g;
+        a.bk_key = d->sl.bk_key;
+        a.bk_rows = d->sl.bk_rows;
+        a.d_count = d->d_counts + 1;
+        if (a.n > d->sl.occ_cap) return fail(FWGPU_ERR_RANGE, "sparse step: occurrence buffers too small");
+        FWGPU_HIP(sparse_reduce(a, d->stream));
+    }
+    return FWGPU_OK;
+}
+
+// S3: all ranks' buckets are in all_key / all_rows (stride rows per rank, counts on the device): merge and apply
+int sparse_apply_side(fwgpu_dist *d, fwgpu_dist::SparseSide &s, bool ffm, const uint32_t *all_key, const float *all_rows,
+                      const uint32_t *d_counts, uint32_t n_ranks, uint32_t stride) {
+    fwgpu_regressor *r = d->r;
+    if (!stride) return FWGPU_OK;
+    SparseApplyArgs a{};
+    a.all_key = all_key;
+    a.all_rows = all_rows;
+    a.counts = d_counts;
+    a.n_ranks = n_ranks;
+    a.stride = stride;
+    a.keys = s.m_key;
+    a.keys_sorted = s.m_key_sorted;
+    a.key_bits = 32 + ceil_log2(ffm ? r->ffm_len : r->lr_len);
+    a.tmp = d->sp_tmp;
+    a.tmp_bytes = d->sp_tmp_bytes;
+    if (ffm) {
+        a.R = s.width;
+        a.w = r->d_ffm_w;
+        a.acc = r->d_ffm_acc;
+        a.rate = r->cfg.ffm_learning_rate;
+        a.minus_power_t = -r->cfg.ffm_power_t;
+        a.lut = r->d_lut_ffm;
+    } else {
+        a.R = 0;
+        a.w = r->d_lr;
+        a.rate = r->cfg.learning_rate;
+        a.minus_power_t = -r->cfg.power_t;
+        a.lut = r->d_lut_lr;
+    }
+    FWGPU_HIP(sparse_apply(a, r->cfg.optimizer, d->stream));
+    return FWGPU_OK;
+}
+
 int make_rank(fwgpu_regressor *r, int rank, int n, fwgpu_dist **out) {
     if (!r || !out || n < 1 || rank < 0 || rank >= n) return fail(FWGPU_ERR_INVALID, "dist: bad rank / size");
     if (r->nn.n_layers) return fail(FWGPU_ERR_INVALID, "dist: the sharded mode does not cover models with a deep head yet");
-    if (r->cfg.ffm_k && ((1ull << r->cfg.ffm_bit_precision) / n) % 64 != 0)
-        return fail(FWGPU_ERR_INVALID, "dist: the FFM table does not split into n ranges of whole 256 B blocks");
     FWGPU_HIP(hipSetDevice(r->device));
     std::unique_ptr<fwgpu_dist> d(new fwgpu_dist());
     d->r = r;
@@ -412,6 +668,79 @@ int fwgpu_dist_all_reduce_sum(fwgpu_dist *d, float *device_buf, uint64_t count, 
     return FWGPU_OK;
 }
 
+// ------------------------------------------------------------------ row-sparse gradient buckets over RCCL
+// One step: this rank's micro-batch (any size, ranks may differ) is scored against the replica as it is; the deduplicated row
+// gradients of all ranks are all-gathered and every rank applies all of them in the same order -> replicas stay bit-identical.
+static int rccl_sparse_step(fwgpu_dist *d, uint32_t shape[4], float *preds) {
+    int rc;
+    const int N = d->n;
+    FWGPU_HIP(hipMemcpyAsync(d->d_shape + 4 * d->rank, shape, 4 * sizeof(uint32_t), hipMemcpyHostToDevice, d->stream));
+    if (N > 1) FWGPU_NCCL(g_rccl.AllGather(d->d_shape + 4 * d->rank, d->d_shape, 4, ncclUint32, d->comm, d->stream));
+    std::vector<uint32_t> shapes((size_t)N * 4);
+    FWGPU_HIP(hipMemcpyAsync(shapes.data(), d->d_shape, shapes.size() * 4, hipMemcpyDeviceToHost, d->stream));
+    FWGPU_HIP(hipStreamSynchronize(d->stream));
+    rc = sparse_local(d, shapes.data());
+    if (rc) return rc;
+    // bucket-row counts of every rank
+    uint32_t *all_counts = d->d_counts + 2;
+    if (N > 1)
+        FWGPU_NCCL(g_rccl.AllGather(d->d_counts, all_counts, 2, ncclUint32, d->comm, d->stream));
+    else
+        FWGPU_HIP(hipMemcpyAsync(all_counts, d->d_counts, 8, hipMemcpyDeviceToDevice, d->stream));
+    std::vector<uint32_t> counts((size_t)2 * N);
+    FWGPU_HIP(hipMemcpyAsync(counts.data(), all_counts, counts.size() * 4, hipMemcpyDeviceToHost, d->stream));
+    FWGPU_HIP(hipStreamSynchronize(d->stream));
+    for (int side = 0; side < 2; side++) {
+        fwgpu_dist::SparseSide &s = side == 0 ? d->sf : d->sl;
+        if (!s.occ_cap) continue;
+        uint32_t stride = 0;
+        for (int j = 0; j < N; j++) stride = std::max(stride, counts[2 * j + side]);
+        if (!stride) continue;
+        if (stride > s.occ_cap) return fail(FWGPU_ERR_RANGE, "sparse step: a rank sent more bucket rows than the buffers hold");
+        // per-rank counts of this side, contiguous on the device: reuse the flags array (free after the local reduction)
+        std::vector<uint32_t> side_counts(N);
+        for (int j = 0; j < N; j++) side_counts[j] = counts[2 * j + side];
+        FWGPU_HIP(hipMemcpyAsync(s.flags, side_counts.data(), (size_t)N * 4, hipMemcpyHostToDevice, d->stream));
+        FWGPU_HIP(hipStreamSynchronize(d->stream));  // side_counts is a local
+        const uint32_t *keys = s.bk_key;
+        const float *rows = s.bk_rows;
+        if (N > 1) {
+            rc = sparse_side_reserve_all(s, (uint64_t)stride * N);
+            if (rc) return rc;
+            FWGPU_NCCL(g_rccl.AllGather(s.bk_key, s.all_key, stride, ncclUint32, d->comm, d->stream));
+            FWGPU_NCCL(g_rccl.AllGather(s.bk_rows, s.all_rows, (size_t)stride * s.width, ncclFloat, d->comm, d->stream));
+            keys = s.all_key;
+            rows = s.all_rows;
+        } else {
+            rc = sparse_side_reserve_all(s, stride);  // (the merged key lists only; keys and rows are used in place)
+            if (rc) return rc;
+        }
+        rc = sparse_apply_side(d, s, side == 0, keys, rows, s.flags, (uint32_t)N, stride);
+        if (rc) return rc;
+    }
+    if (preds && d->B) FWGPU_HIP(hipMemcpyAsync(preds, d->cur->pred, (size_t)d->B * 4, hipMemcpyDeviceToHost, d->stream));
+    FWGPU_HIP(hipStreamSynchronize(d->stream));
+    return FWGPU_OK;
+}
+
+int fwgpu_dist_learn_sparse(fwgpu_dist *d, const fwgpu_translator_config *t, const uint32_t *records, const uint64_t *rec_off,
+                            uint32_t n, float *preds) {
+    if (!d || !d->comm) return fail(FWGPU_ERR_INVALID, "not an RCCL rank (fwgpu_dist_init)");
+    uint32_t shape[4];
+    int rc = sparse_begin(d, t, records, rec_off, n, nullptr, shape);
+    if (rc) return rc;
+    return rccl_sparse_step(d, shape, preds);
+}
+
+// the rank's micro-batch already in HBM (fwgpu_record_batch_create); predictions land in the batch
+int fwgpu_dist_learn_sparse_batch(fwgpu_dist *d, const fwgpu_translator_config *t, fwgpu_batch *b) {
+    if (!d || !d->comm) return fail(FWGPU_ERR_INVALID, "not an RCCL rank (fwgpu_dist_init)");
+    uint32_t shape[4];
+    int rc = sparse_begin(d, t, nullptr, nullptr, 0, b, shape);
+    if (rc) return rc;
+    return rccl_sparse_step(d, shape, nullptr);
+}
+
 // ------------------------------------------------------------------ in-process group: the same step, collectives by copies
 // n regressors (one per rank; usually all on one device, which is how the one-GPU box emulates N GPUs and how the tests run).
 int fwgpu_dist_group_create(fwgpu_regressor *const *regs, int n, fwgpu_dist_group **out) {
@@ -517,6 +846,60 @@ int fwgpu_dist_group_learn_sharded(fwgpu_dist_group *g, const fwgpu_translator_c
     for (int j = 0; j < N; j++) {
         rc = finish(g->ranks[j].get(), preds ? preds[j] : nullptr);
         if (rc) return rc;
+    }
+    return FWGPU_OK;
+}
+
+// Row-sparse step of an in-process group: records[j] / rec_off[j] / n[j] are rank j's micro-batch
+int fwgpu_dist_group_learn_sparse(fwgpu_dist_group *g, const fwgpu_translator_config *t, const uint32_t *const *records,
+                                  const uint64_t *const *rec_off, const uint32_t *n, float *const *preds) {
+    if (!g || !records || !rec_off || !n) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    const int N = (int)g->ranks.size();
+    std::vector<uint32_t> shapes((size_t)N * 4);
+    int rc;
+    for (int j = 0; j < N; j++)
+        if ((rc = sparse_begin(g->ranks[j].get(), t, records[j], rec_off[j], n[j], nullptr, &shapes[4 * j]))) return rc;
+    for (int j = 0; j < N; j++)
+        if ((rc = sparse_local(g->ranks[j].get(), shapes.data()))) return rc;
+    std::vector<uint32_t> counts((size_t)2 * N);
+    for (int j = 0; j < N; j++) {
+        fwgpu_dist *d = g->ranks[j].get();
+        FWGPU_HIP(hipMemcpyAsync(&counts[2 * j], d->d_counts, 8, hipMemcpyDeviceToHost, d->stream));
+        FWGPU_HIP(hipStreamSynchronize(d->stream));
+    }
+    for (int side = 0; side < 2; side++) {
+        uint32_t stride = 0;
+        for (int j = 0; j < N; j++) stride = std::max(stride, counts[2 * j + side]);
+        if (!stride) continue;
+        std::vector<uint32_t> side_counts(N);
+        for (int j = 0; j < N; j++) side_counts[j] = counts[2 * j + side];
+        for (int i = 0; i < N; i++) {
+            fwgpu_dist *dst = g->ranks[i].get();
+            fwgpu_dist::SparseSide &s = side == 0 ? dst->sf : dst->sl;
+            if (!s.occ_cap) continue;
+            if ((rc = sparse_side_reserve_all(s, (uint64_t)stride * N))) return rc;
+            FWGPU_HIP(hipMemcpyAsync(s.flags, side_counts.data(), (size_t)N * 4, hipMemcpyHostToDevice, dst->stream));
+            for (int j = 0; j < N; j++) {  // all-gather = rank j's bucket into slot j of everyone
+                fwgpu_dist *src = g->ranks[j].get();
+                const fwgpu_dist::SparseSide &q = side == 0 ? src->sf : src->sl;
+                const uint32_t c = side_counts[j];
+                if (!c) continue;
+                FWGPU_HIP(hipMemcpyAsync(s.all_key + (size_t)stride * j, q.bk_key, (size_t)c * 4, hipMemcpyDeviceToDevice, dst->stream));
+                FWGPU_HIP(hipMemcpyAsync(s.all_rows + (size_t)stride * j * s.width, q.bk_rows, (size_t)c * s.width * 4, hipMemcpyDeviceToDevice, dst->stream));
+            }
+            FWGPU_HIP(hipStreamSynchronize(dst->stream));  // side_counts is a local
+        }
+        for (int i = 0; i < N; i++) {
+            fwgpu_dist *dst = g->ranks[i].get();
+            fwgpu_dist::SparseSide &s = side == 0 ? dst->sf : dst->sl;
+            if (!s.occ_cap) continue;
+            if ((rc = sparse_apply_side(dst, s, side == 0, s.all_key, s.all_rows, s.flags, (uint32_t)N, stride))) return rc;
+        }
+    }
+    for (int j = 0; j < N; j++) {
+        fwgpu_dist *d = g->ranks[j].get();
+        if (preds && preds[j] && d->B) FWGPU_HIP(hipMemcpyAsync(preds[j], d->cur->pred, (size_t)d->B * 4, hipMemcpyDeviceToHost, d->stream));
+        FWGPU_HIP(hipStreamSynchronize(d->stream));
     }
     return FWGPU_OK;
 }

@@ -114,6 +114,11 @@ struct KernelParams {
     uint32_t own_lo_ffm, own_hi_ffm;    // this rank owns the FFM rows with own_lo <= hash < own_hi (sharded tables)...
     uint32_t own_lo_lr, own_hi_lr;      // ... and these LR entries
     uint32_t home_lo, home_hi;          // examples of the launch whose label / counts this rank contributes (its own shard of the batch)
+    // ---- row-sparse gradient mode (sparse.hip): the FWD phase lists every entry as an occurrence, slot = example * max_ffm + entry
+    unsigned long long *occ_ffm_key;    // [n * max_ffm] (row hash << 32 | slot), ~0 for unused slots and examples that do not update
+    uint2 *occ_ffm_desc;                // [n * max_ffm] {value bits, field}
+    unsigned long long *occ_lr_key;     // [n * max_lr]
+    uint2 *occ_lr_desc;                 // [n * max_lr]  {value bits, 0}
 };
 
 struct LaunchConfig {
@@ -137,6 +142,45 @@ hipError_t launch_example_kernel(const KernelParams &p, int optimizer, bool cohe
 hipError_t launch_example_phase(const KernelParams &p, int optimizer, int phase, uint32_t grid, uint32_t threads, hipStream_t stream);
 hipError_t launch_split_mid(const KernelParams &p, uint32_t n_examples, hipStream_t stream);
 uint32_t split_record_len(uint32_t F, uint32_t R, uint32_t nlr);
+// row-sparse gradient buckets (sparse.hip)
+struct SparseReduceArgs {
+    const unsigned long long *keys;   // [n] occurrence keys as the FWD phase wrote them
+    unsigned long long *keys_sorted;  // [n]
+    uint32_t n;
+    int key_bits;                     // 32 + bits of the largest hash
+    const uint2 *desc;
+    uint32_t max_entries;             // slot = example * max_entries + entry
+    uint32_t *flags, *pos;            // [n + 1]
+    void *tmp;
+    size_t tmp_bytes;
+    // FFM rows (R != 0): gradient rows from the split records; LR (R == 0): g * value
+    uint32_t R, k;
+    const float *split;
+    uint32_t split_len;
+    const float *selfw;
+    uint32_t selfw_stride;
+    const float *gbuf;
+    uint32_t *bk_key;                 // out: hash of every bucket row
+    float *bk_rows;                   // out: [rows * max(R, 1)]
+    uint32_t *d_count;                // out: number of bucket rows
+};
+struct SparseApplyArgs {
+    const uint32_t *all_key;          // [n_ranks * stride] bucket keys of every rank
+    const float *all_rows;            // [n_ranks * stride * max(R, 1)]
+    const uint32_t *counts;           // [n_ranks] device: valid rows per rank
+    uint32_t n_ranks, stride;
+    unsigned long long *keys, *keys_sorted;  // [n_ranks * stride]
+    int key_bits;
+    void *tmp;
+    size_t tmp_bytes;
+    uint32_t R;                       // 0: LR entries ({w, acc} pairs in `w`)
+    float *w, *acc;
+    float rate, minus_power_t;
+    const float *lut;
+};
+size_t sparse_tmp_bytes(uint32_t n_max);
+hipError_t sparse_reduce(const SparseReduceArgs &a, hipStream_t stream);
+hipError_t sparse_apply(const SparseApplyArgs &a, int optimizer, hipStream_t stream);
 hipError_t launch_ffm_init(float *w, float *acc, uint64_t len, uint32_t k, float init_width, float init_zero_band,
                            float init_center, float acc0, hipStream_t stream);
 hipError_t launch_fill(float *p, uint64_t n, float v, hipStream_t stream);
@@ -273,7 +317,12 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
 struct SplitRanges {  // what a rank owns (sharded tables) and which examples of the launch are its own
     uint32_t ffm_lo = 0, ffm_hi = 0xffffffffu, lr_lo = 0, lr_hi = 0xffffffffu, home_lo = 0, home_hi = 0xffffffffu;
 };
-int split_forward(fwgpu_regressor *r, fwgpu_batch *b, fwgpu_split *sp, int mode, const SplitRanges &rg, hipStream_t stream);
+struct OccBuffers {  // where the FWD phase lists the entries of every example (row-sparse gradient mode)
+    unsigned long long *ffm_key = nullptr, *lr_key = nullptr;
+    uint2 *ffm_desc = nullptr, *lr_desc = nullptr;
+};
+int split_forward(fwgpu_regressor *r, fwgpu_batch *b, fwgpu_split *sp, int mode, const SplitRanges &rg, hipStream_t stream,
+                  const OccBuffers *occ = nullptr, uint32_t *max_ffm = nullptr, uint32_t *max_lr = nullptr);
 int split_mid(fwgpu_regressor *r, fwgpu_split *sp, uint32_t first, uint32_t n, float *d_pred, bool head, hipStream_t stream);
 int split_update(fwgpu_regressor *r, fwgpu_batch *b, fwgpu_split *sp, int mode, const SplitRanges &rg, bool head, hipStream_t stream);
 // mini-batched deep head on the records' x (head.hip): forward, sigmoid, backward, one AdaGrad step per dense weight

@@ -27,6 +27,7 @@
 // (buffer_* ... sc1 / agent-scope relaxed atomics for the 8-byte LR entries).  Read-only launches use
 // plain cached loads.
 #include "fwgpu_internal.h"
+#include "fwgpu_device.h"
 
 namespace fwgpu {
 
@@ -80,25 +81,6 @@ struct Vec<1> {
     static __device__ __forceinline__ float get(const float &v, int) { return v; }
     static __device__ __forceinline__ void set(float &v, int, float x) { v = x; }
 };
-
-// ---- optimizer steps (optimizer.rs).  acc chain is kept free of FMA contraction so that, given the same
-// gradient, acc (and hence the integer LUT key) is bit-identical to the reference.
-template <int OPT>
-__device__ __forceinline__ float opt_step(float grad, float &acc, float rate, float minus_power_t, const float *lut) {
-    if (OPT == FWGPU_OPT_SGD) {
-        return grad * rate;  // optimizer.rs:36-38
-    } else if (OPT == FWGPU_OPT_ADAGRAD_FLEX) {  // optimizer.rs:76-88
-        float na = __fadd_rn(acc, __fmul_rn(grad, grad));
-        acc = na;
-        float u = __fmul_rn(__fmul_rn(grad, rate), powf(na, minus_power_t));
-        return (isnan(u) || isinf(u)) ? 0.0f : u;
-    } else {  // optimizer.rs:147-156
-        float na = __fadd_rn(acc, __fmul_rn(grad, grad));
-        acc = na;
-        uint32_t key = __float_as_uint(na) >> (31 - kLutBits);
-        return __fmul_rn(grad, lut[key]);
-    }
-}
 
 __device__ __forceinline__ float logistic(float t) { return 1.0f / (1.0f + expf(-t)); }  // block_loss_functions.rs:15-17
 
@@ -1264,6 +1246,25 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                 rec[F * R + 2 * F + p.split_nlr + 1] = home ? imp : 0.0f;
             }
             for (uint32_t i = tid; i < nf * k; i += bd) p.split_selfw[(size_t)ex * p.selfw_stride + i] = s.selfw[i];
+            // row-sparse gradient mode (sparse.hip): every entry of the example becomes one occurrence, key = (row, slot).
+            // Sorting the keys groups the occurrences of a row in (example, entry) order.
+            if (p.occ_ffm_key || p.occ_lr_key) {
+                const bool upd = imp != 0.0f;  // regressor.rs:366
+                if (p.occ_ffm_key)
+                for (uint32_t i = tid; i < p.max_ffm; i += bd) {
+                    const uint32_t slot = ex * p.max_ffm + i;
+                    const bool on = upd && i < nf;
+                    p.occ_ffm_key[slot] = on ? (((unsigned long long)s.e_hash[i] << 32) | slot) : ~0ull;
+                    if (on) p.occ_ffm_desc[slot] = uint2{__float_as_uint(s.e_val[i]), s.e_fld[i] & kFldMask};
+                }
+                if (p.occ_lr_key && p.has_lr)
+                    for (uint32_t i = tid; i < p.max_lr; i += bd) {
+                        const uint32_t slot = ex * p.max_lr + i;
+                        const bool on = upd && i < nl;
+                        p.occ_lr_key[slot] = on ? (((unsigned long long)s.l_hash[i] << 32) | slot) : ~0ull;
+                        if (on) p.occ_lr_desc[slot] = uint2{__float_as_uint(s.l_val[i]), 0u};
+                    }
+            }
             if (NN && p.split_nlr > 1) {  // deep head: one sum per LR combo slot, entries in buffer order (block_lr.rs:36-45)
                 for (uint32_t c = tid; c < p.split_nlr; c += bd) {
                     float acc = 0.0f;

@@ -781,12 +781,21 @@ static int split_params(fwgpu_regressor *r, fwgpu_batch *b, fwgpu_split *sp, int
     return FWGPU_OK;
 }
 
-int split_forward(fwgpu_regressor *r, fwgpu_batch *b, fwgpu_split *sp, int mode, const SplitRanges &rg, hipStream_t stream) {
+int split_forward(fwgpu_regressor *r, fwgpu_batch *b, fwgpu_split *sp, int mode, const SplitRanges &rg, hipStream_t stream,
+                  const OccBuffers *occ, uint32_t *max_ffm, uint32_t *max_lr) {
     if (b && b->n == 0) return FWGPU_OK;
     KernelParams p;
     uint32_t threads = 0;
     int rc = split_params(r, b, sp, mode, 0, rg, p, threads);
     if (rc) return rc;
+    if (occ) {
+        p.occ_ffm_key = occ->ffm_key;
+        p.occ_ffm_desc = occ->ffm_desc;
+        p.occ_lr_key = occ->lr_key;
+        p.occ_lr_desc = occ->lr_desc;
+    }
+    if (max_ffm) *max_ffm = p.max_ffm;  // the slot strides of the occurrence lists
+    if (max_lr) *max_lr = p.max_lr;
     FWGPU_HIP(hipMemsetAsync(b->work, 0, sizeof(uint32_t), stream));
     FWGPU_HIP(launch_example_phase(p, r->cfg.optimizer, 1, pick_grid(r, p, mode, threads), threads, stream));
     return FWGPU_OK;

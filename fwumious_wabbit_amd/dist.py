@@ -48,6 +48,18 @@ class DistRank:
         """the same step with this rank's records already in HBM (Regressor.record_batch); predictions: batch.predictions()"""
         check(capi.lib().fwgpu_dist_learn_sharded_batch(self.h, C.byref(translator.c), batch.h))
 
+    def learn_sparse(self, translator, records, rec_off) -> np.ndarray:
+        """row-sparse gradient buckets: this rank's micro-batch against its full replica, every rank applies all ranks' row
+        gradients (one optimizer step per row and global batch)"""
+        records, rec_off = _recs(records, rec_off)
+        n = len(rec_off) - 1
+        out = np.zeros(n, dtype=np.float32)
+        check(capi.lib().fwgpu_dist_learn_sparse(self.h, C.byref(translator.c), ptr(records), rec_off.ctypes.data_as(C.c_void_p), n, ptr(out)))
+        return out
+
+    def learn_sparse_batch(self, translator, batch):
+        check(capi.lib().fwgpu_dist_learn_sparse_batch(self.h, C.byref(translator.c), batch.h))
+
     def gather_tables(self):
         check(capi.lib().fwgpu_dist_gather_tables(self.h))
 
@@ -89,6 +101,17 @@ class DistGroup:
         outp = (C.c_void_p * self.n)(*[o.ctypes.data for o in outs])
         check(capi.lib().fwgpu_dist_group_learn_sharded(self.h, C.byref(translator.c), recp, offp, n, outp))
         return outs
+
+    def learn_sparse(self, translator, records_per_rank, rec_off_per_rank):
+        """one row-sparse step: rank j brings records_per_rank[j] (any number) -> its predictions"""
+        rr = [_recs(a, b) for a, b in zip(records_per_rank, rec_off_per_rank)]
+        ns = np.array([len(b) - 1 for _, b in rr], dtype=np.uint32)
+        outs = [np.zeros(max(int(n), 1), dtype=np.float32) for n in ns]
+        recp = (C.c_void_p * self.n)(*[a.ctypes.data for a, _ in rr])
+        offp = (C.c_void_p * self.n)(*[b.ctypes.data for _, b in rr])
+        outp = (C.c_void_p * self.n)(*[o.ctypes.data for o in outs])
+        check(capi.lib().fwgpu_dist_group_learn_sparse(self.h, C.byref(translator.c), recp, offp, ns.ctypes.data_as(C.c_void_p), outp))
+        return [o[:int(n)] for o, n in zip(outs, ns)]
 
     def gather_tables(self):
         check(capi.lib().fwgpu_dist_group_gather_tables(self.h))

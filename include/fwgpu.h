@@ -293,6 +293,19 @@ int fwgpu_dist_group_free(fwgpu_dist_group *g);
 int fwgpu_dist_group_learn_sharded(fwgpu_dist_group *g, const fwgpu_translator_config *t, const uint32_t *const *records,
                                    const uint64_t *const *rec_off, uint32_t n, float *const *predictions);
 int fwgpu_dist_group_gather_tables(fwgpu_dist_group *g);
+/* Row-sparse gradient buckets (north_star: "RCCL all-reduce of sparse gradient buckets"; replaces hogwild.rs:24-103's shared
+ * table ACROSS GPUs): every rank keeps a full replica and scores its own micro-batch (any size) against it; the gradients of the
+ * touched rows are summed per row on the rank (segment reduction over the sorted occurrence list), all-gathered as
+ * {row hash, R-float gradient row} buckets, and every rank applies all buckets in the same order: ONE optimizer step per row and
+ * global batch with the summed gradient.  Replicas that start identical stay bit-identical; there is no table exchange.
+ * The update rule differs from the reference's (one step per occurrence): the oracle's fwo_learn_sparse restates it.
+ * Models without a deep head.  Predictions: host buffer (may be NULL) / the batch's own. */
+int fwgpu_dist_learn_sparse(fwgpu_dist *d, const fwgpu_translator_config *t, const uint32_t *records, const uint64_t *rec_off,
+                            uint32_t n, float *predictions);
+int fwgpu_dist_learn_sparse_batch(fwgpu_dist *d, const fwgpu_translator_config *t, fwgpu_batch *b);
+/* in-process group: rank j brings n[j] records */
+int fwgpu_dist_group_learn_sparse(fwgpu_dist_group *g, const fwgpu_translator_config *t, const uint32_t *const *records,
+                                  const uint64_t *const *rec_off, const uint32_t *n, float *const *predictions);
 
 
 /* ---------------------------------------------------------------- HogwildTrainer replacement

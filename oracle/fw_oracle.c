@@ -1197,3 +1197,162 @@ void fwo_learn_minibatch(fwo_model *m, const fwo_translator *t, const uint32_t *
     free(ffm);
     scratch_free(&s);
 }
+
+/* ---- row-sparse gradient buckets: the update rule of the library's multi-GPU "sparse" mode (fwumious_wabbit_amd/csrc/sparse.hip).
+ * Not a reference code path: the reference has one shared table and steps per occurrence (hogwild.rs:24-103, block_ffm.rs:265-288).
+ * Here all examples of the global batch are scored against the weights as they are; every table row (FFM row of R floats, LR
+ * entry) then takes ONE optimizer step (optimizer.rs) with the gradient summed over all its occurrences.  The summation order is
+ * the library's, so that the results can be compared bit for bit: per part (= rank) the occurrences are sorted by (row, example,
+ * entry) and summed inside 64-element blocks of that sorted list (one bucket row per block and row); the bucket rows of a row are
+ * then added in (part, bucket) order.  FFM rows are applied in ascending row order within hash / R blocks, even blocks first, then
+ * odd ones (rows are R long from any start, so neighbours overlap: block_ffm.rs:92-94). */
+typedef struct {
+    uint32_t hash, ex, ent;
+} sp_occ;
+static int sp_occ_cmp(const void *a, const void *b) {
+    const sp_occ *x = (const sp_occ *)a, *y = (const sp_occ *)b;
+    if (x->hash != y->hash) return x->hash < y->hash ? -1 : 1;
+    if (x->ex != y->ex) return x->ex < y->ex ? -1 : 1;
+    return x->ent < y->ent ? -1 : (x->ent > y->ent);
+}
+typedef struct {
+    uint32_t hash;
+    uint64_t seq; /* arrival order: part, then position */
+    float *row;
+} sp_bucket;
+static int sp_bucket_cmp(const void *a, const void *b) {
+    const sp_bucket *x = (const sp_bucket *)a, *y = (const sp_bucket *)b;
+    if (x->hash != y->hash) return x->hash < y->hash ? -1 : 1;
+    return x->seq < y->seq ? -1 : (x->seq > y->seq);
+}
+
+void fwo_learn_sparse(fwo_model *m, const fwo_translator *t, const uint32_t *records, const uint64_t *rec_off, uint64_t n,
+                      const uint64_t *part_end, uint32_t n_parts, float *preds) {
+    const fwo_config *c = &m->cfg;
+    const uint32_t F = c->ffm_k ? c->ffm_num_fields : 0, k = c->ffm_k, C = c->num_combos, T = F * (F + 1) / 2, R = F * k;
+    const int has_lr = c->wiring != FWO_WIRING_FFM_ONLY;
+    fwo_scratch s;
+    scratch_init(&s, c);
+    mb_example *ex = (mb_example *)calloc(n ? n : 1, sizeof(mb_example));
+    fwo_lr_entry *lr = (fwo_lr_entry *)malloc(sizeof(fwo_lr_entry) * FWO_EX_CAP);
+    fwo_ffm_entry *ffm = (fwo_ffm_entry *)malloc(sizeof(fwo_ffm_entry) * FWO_EX_CAP);
+    uint64_t tot_ffm = 0, tot_lr = 0;
+    /* ---- pass 1: every example against the weights of the batch start; its per-entry gradient rows are kept */
+    for (uint64_t e = 0; e < n; e++) {
+        mb_example *x = &ex[e];
+        float label, imp;
+        fwo_translate(t, records + rec_off[e], lr, FWO_EX_CAP, &x->n_lr, ffm, FWO_EX_CAP, &x->n_ffm, &label, &imp);
+        x->lr = (fwo_lr_entry *)malloc(sizeof(fwo_lr_entry) * (x->n_lr + 1));
+        x->ffm = (fwo_ffm_entry *)malloc(sizeof(fwo_ffm_entry) * (x->n_ffm + 1));
+        memcpy(x->lr, lr, sizeof(fwo_lr_entry) * x->n_lr);
+        memcpy(x->ffm, ffm, sizeof(fwo_ffm_entry) * x->n_ffm);
+        x->update = imp != 0.0f; /* regressor.rs:366 */
+        lr_forward(m, lr, x->n_lr, s.lr_out);
+        x->G = NULL;
+        if (F) {
+            ensure_grads(&s, x->n_ffm * F * k);
+            ffm_fb_forward(m, ffm, x->n_ffm, &s);
+            x->G = (float *)malloc(sizeof(float) * ((size_t)x->n_ffm * R + 1));
+            memcpy(x->G, s.grads, sizeof(float) * (size_t)x->n_ffm * R);
+            fwo_triangle_forward(s.ffm_out, F, s.tri);
+        }
+        float p;
+        if (c->wiring == FWO_WIRING_FFM_ONLY)
+            p = sigmoid_block(s.ffm_out, F * F, NULL, 0, label, imp, &x->g);
+        else
+            p = sigmoid_block(s.lr_out, C, s.tri, T, label, imp, &x->g);
+        if (preds) preds[e] = p;
+        if (x->update) {
+            /* occurrence gradients: general gradient (uniform g without a head) x the cached feature gradient, block_ffm.rs:278 */
+            for (size_t i = 0; i < (size_t)x->n_ffm * R; i++) x->G[i] = x->g * x->G[i];
+            tot_ffm += x->n_ffm;
+            tot_lr += x->n_lr;
+        }
+    }
+    /* ---- pass 2: bucket rows per part */
+    for (int side = 0; side < 2; side++) {
+        const int is_ffm = side == 0;
+        if (is_ffm ? !F : !has_lr) continue;
+        const uint32_t W = is_ffm ? R : 1;
+        const uint64_t tot = is_ffm ? tot_ffm : tot_lr;
+        sp_occ *occ = (sp_occ *)malloc(sizeof(sp_occ) * (tot + 1));
+        sp_bucket *bk = (sp_bucket *)malloc(sizeof(sp_bucket) * (tot + 1));
+        uint64_t nb = 0, lo = 0;
+        for (uint32_t part = 0; part < n_parts; part++) {
+            const uint64_t hi = part_end[part];
+            uint64_t no = 0;
+            for (uint64_t e = lo; e < hi; e++) {
+                mb_example *x = &ex[e];
+                if (!x->update) continue;
+                const uint32_t cnt = is_ffm ? x->n_ffm : x->n_lr;
+                for (uint32_t i = 0; i < cnt; i++) {
+                    occ[no].hash = is_ffm ? x->ffm[i].hash : x->lr[i].hash;
+                    occ[no].ex = (uint32_t)e;
+                    occ[no].ent = i;
+                    no++;
+                }
+            }
+            qsort(occ, no, sizeof(sp_occ), sp_occ_cmp);
+            for (uint64_t j = 0; j < no;) {
+                const uint64_t blk_end = (j / 64 + 1) * 64 < no ? (j / 64 + 1) * 64 : no;
+                uint64_t j2 = j;
+                float *row = (float *)calloc(W, sizeof(float));
+                while (j2 < blk_end && occ[j2].hash == occ[j].hash) {
+                    const mb_example *x = &ex[occ[j2].ex];
+                    if (is_ffm) {
+                        const float *g = x->G + (size_t)occ[j2].ent * R;
+                        for (uint32_t q = 0; q < R; q++) row[q] = row[q] + g[q];
+                    } else {
+                        row[0] = row[0] + x->g * x->lr[occ[j2].ent].value; /* block_lr.rs:141 */
+                    }
+                    j2++;
+                }
+                bk[nb].hash = occ[j].hash;
+                bk[nb].seq = nb;
+                bk[nb].row = row;
+                nb++;
+                j = j2;
+            }
+            lo = hi;
+        }
+        /* ---- pass 3: one step per row */
+        qsort(bk, nb, sizeof(sp_bucket), sp_bucket_cmp);
+        float *Gs = (float *)malloc(sizeof(float) * W);
+        for (int parity = 0; parity < (is_ffm ? 2 : 1); parity++) {
+            for (uint64_t j = 0; j < nb;) {
+                uint64_t j2 = j;
+                while (j2 < nb && bk[j2].hash == bk[j].hash) j2++;
+                const uint32_t h = bk[j].hash;
+                if (!is_ffm || (int)((h / R) & 1u) == parity) {
+                    for (uint32_t q = 0; q < W; q++) Gs[q] = 0.0f;
+                    for (uint64_t b = j; b < j2; b++)
+                        for (uint32_t q = 0; q < W; q++) Gs[q] = Gs[q] + bk[b].row[q];
+                    if (is_ffm) {
+                        for (uint32_t q = 0; q < R; q++) {
+                            if (Gs[q] == 0.0f) continue;
+                            const float upd = opt_step(c->optimizer, c->ffm_learning_rate, c->ffm_power_t, m->lut_ffm, Gs[q], &m->ffm_acc[h + q]);
+                            m->ffm_w[h + q] -= upd;
+                        }
+                    } else if (Gs[0] != 0.0f) {
+                        const float upd = opt_step(c->optimizer, c->learning_rate, c->power_t, m->lut_lr, Gs[0], &m->lr[2 * (size_t)h + 1]);
+                        m->lr[2 * (size_t)h] -= upd;
+                    }
+                }
+                j = j2;
+            }
+        }
+        for (uint64_t b = 0; b < nb; b++) free(bk[b].row);
+        free(Gs);
+        free(bk);
+        free(occ);
+    }
+    for (uint64_t e = 0; e < n; e++) {
+        free(ex[e].lr);
+        free(ex[e].ffm);
+        free(ex[e].G);
+    }
+    free(ex);
+    free(lr);
+    free(ffm);
+    scratch_free(&s);
+}

@@ -171,6 +171,11 @@ double fwo_run_stream(fwo_model *m, const fwo_translator *t, const uint32_t *rec
  * (mini-batch AdaGrad), input gradients come from the frozen weights.  preds: the n predictions. */
 void fwo_learn_minibatch(fwo_model *m, const fwo_translator *t, const uint32_t *records, const uint64_t *rec_off, uint64_t n,
                          float *preds);
+/* Row-sparse gradient buckets: update rule of the library's multi-GPU "sparse" mode (one optimizer step per table row and batch,
+ * gradient summed over the row's occurrences; parts = the ranks' micro-batches, examples [part_end[p-1], part_end[p])).
+ * Models without a deep head. */
+void fwo_learn_sparse(fwo_model *m, const fwo_translator *t, const uint32_t *records, const uint64_t *rec_off, uint64_t n,
+                      const uint64_t *part_end, uint32_t n_parts, float *preds);
 
 #ifdef __cplusplus
 }

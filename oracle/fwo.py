@@ -149,6 +149,8 @@ def lib(native=False):
     L.fwo_translate.argtypes = [C.POINTER(Translator), vp, vp, C.c_uint32, u32p, vp, C.c_uint32, u32p, f32p, f32p]
     L.fwo_learn_minibatch.restype = None
     L.fwo_learn_minibatch.argtypes = [vp, C.POINTER(Translator), vp, vp, C.c_uint64, vp]
+    L.fwo_learn_sparse.restype = None
+    L.fwo_learn_sparse.argtypes = [vp, C.POINTER(Translator), vp, vp, C.c_uint64, vp, C.c_uint32, vp]
     L.fwo_run_stream.restype = C.c_double
     L.fwo_run_stream.argtypes = [vp, C.POINTER(Translator), vp, vp, C.c_uint64, C.c_uint64, C.c_int, vp]
     _lib_cache[native] = L
@@ -311,6 +313,18 @@ class Model:
         n = len(rec_off) - 1
         preds = np.zeros(n, dtype=np.float32)
         self.L.fwo_learn_minibatch(self.h, C.byref(tspec.c), _ptr(records), _ptr(rec_off), n, _ptr(preds))
+        return preds
+
+    def learn_sparse(self, tspec, records, rec_off, part_end=None):
+        """row-sparse gradient buckets (fw_oracle.h): one optimizer step per row with the gradient summed over the batch;
+        part_end = cumulative example counts of the ranks' micro-batches (default: one part)"""
+        records = np.ascontiguousarray(records, dtype=np.uint32)
+        rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
+        n = len(rec_off) - 1
+        pe = np.ascontiguousarray([n] if part_end is None else part_end, dtype=np.uint64)
+        assert int(pe[-1]) == n
+        preds = np.zeros(n, dtype=np.float32)
+        self.L.fwo_learn_sparse(self.h, C.byref(tspec.c), _ptr(records), _ptr(rec_off), n, _ptr(pe), len(pe), _ptr(preds))
         return preds
 
     def run_stream(self, tspec, records, rec_off, holdout_after=0, nthreads=1, want_preds=True):

@@ -175,3 +175,80 @@ def test_rccl_rank_single_process():
     sp.close()
     re_a.close()
     re_b.close()
+
+
+def _run_sparse(n_ranks, mi, recs, off, per_rank, n_steps):
+    regs = [fw.Regressor(mi) for _ in range(n_ranks)]
+    fbt = fw.FeatureBufferTranslator(mi)
+    g = DistGroup(regs)
+    total = sum(per_rank)
+    preds = np.zeros(n_steps * total, dtype=np.float32)
+    for s in range(n_steps):
+        base = s * total
+        rr, oo, a = [], [], base
+        for j in range(n_ranks):
+            b = a + per_rank[j]
+            rr.append(recs[int(off[a]):int(off[b])])
+            oo.append(off[a:b + 1] - off[a])
+            a = b
+        outs = g.learn_sparse(fbt, rr, oo)
+        a = base
+        for j in range(n_ranks):
+            preds[a:a + per_rank[j]] = outs[j]
+            a += per_rank[j]
+    tables = [[r.table_read(t) for t in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)] for r in regs]
+    g.close()
+    for r in regs:
+        r.close()
+    return preds, tables
+
+
+@pytest.mark.parametrize("n_ns,k,bits,ffm_bits,extra,ids,opt", [
+    (10, 4, 14, 14, 0.0, 3000, fw.Optimizer.AdagradLUT),     # tiny tables: most rows overlap a neighbour, hot rows span several 64-blocks
+    (30, 8, 16, 18, 3.0, 50000, fw.Optimizer.AdagradLUT),    # config C's shape
+    (12, 2, 15, 15, 1.0, 5000, fw.Optimizer.AdagradFlex),
+    (8, 4, 14, 14, 0.0, 2000, fw.Optimizer.SGD)])
+def test_sparse_bucket_step_matches_the_oracle(n_ns, k, bits, ffm_bits, extra, ids, opt):
+    """Row-sparse gradient buckets (fwgpu_dist_group_learn_sparse) on 1, 2 and 3 ranks (uneven micro-batches) == the oracle's
+    fwo_learn_sparse with the same partition: predictions and all three tables to f32 rounding; the replicas of a job bit-identical."""
+    mi, ocfg, ots = make_pair(n_ns, k, bits, ffm_bits, opt, lr=0.05, ffm_lr=0.05)
+    steps, gb = 5, 200
+    recs, off = fw.synth_records(n_ns, extra, 1.1, ids, 0.1, 83, 0, steps * gb)
+    y = record_labels(recs, off)
+    for parts in ([gb], [gb // 2, gb // 2], [90, 70, 40]):
+        om = fwo.Model(ocfg)
+        pe = np.cumsum(parts)
+        p_ref = np.concatenate([om.learn_sparse(ots, recs[int(off[s * gb]):int(off[(s + 1) * gb])], off[s * gb:(s + 1) * gb + 1] - off[s * gb], pe)
+                                for s in range(steps)])
+        ref_tabs = [om.lr_table, om.ffm_weights, om.ffm_acc]
+        preds, tables = _run_sparse(len(parts), mi, recs, off, parts, steps)
+        assert np.abs(logloss(preds, y) - logloss(p_ref, y)).max() < 1e-5, parts
+        for tabs in tables:
+            for t in range(3):
+                a, b = np.asarray(tabs[t]), np.asarray(ref_tabs[t])[:len(tabs[t])]
+                # the general gradients differ from the oracle's in the last bits (the forward sums are taken in another order),
+                # so the tables agree to f32 rounding, plus the odd AdagradLUT bucket edge (see `close` above)
+                bad = np.abs(a - b) > 3e-5 + 1e-5 * np.abs(b)
+                assert int(bad.sum()) <= max(3, a.size // 10000) and float(np.abs(a - b).max()) < 5e-3, (parts, t, int(bad.sum()), float(np.abs(a - b).max()))
+                # ... but the replicas of one job are the same bits: every rank applied the same buckets in the same order
+                assert np.array_equal(a, np.asarray(tables[0][t])), (parts, t)
+
+
+def test_sparse_bucket_step_empty_and_single_micro_batch():
+    """an empty micro-batch is a no-op; a single step scores against the initial weights"""
+    mi, ocfg, ots = make_pair(8, 4, 14, 14, fw.Optimizer.AdagradLUT, lr=0.05, ffm_lr=0.05)
+    recs, off = fw.synth_records(8, 0.0, 1.1, 2000, 0.1, 85, 0, 64)
+    regs = [fw.Regressor(mi)]
+    before = [regs[0].table_read(t) for t in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)]
+    g = DistGroup(regs)
+    fbt = fw.FeatureBufferTranslator(mi)
+    out = g.learn_sparse(fbt, [recs[:0]], [off[:1]])  # empty micro-batch
+    assert len(out[0]) == 0
+    out = g.learn_sparse(fbt, [recs], [off])
+    after = [regs[0].table_read(t) for t in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)]
+    assert any(not np.array_equal(a, b) for a, b in zip(before, after))
+    om = fwo.Model(ocfg)
+    p_ref = om.learn_sparse(ots, recs, off)
+    assert np.abs(out[0] - p_ref).max() < 1e-6
+    g.close()
+    regs[0].close()
