@@ -407,7 +407,13 @@ def main():
     kernel_ms = [ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(K)]
     if sharded_main:  # the step runs on the library's own stream and is host-synchronous: the step time is the wall time
         kernel_ms = [1e3 * elapsed / K] * K
-        if not sparse_main:
+        if sparse_main:
+            rows_f, rows_l = dist_rank.sparse_last_rows()
+            lb = batches[W + K - 1]
+            sparse_exchange = {"ffm_occurrences": int(lb.n_ffm), "ffm_bucket_rows": rows_f, "lr_occurrences": int(lb.n_lr), "lr_bucket_entries": rows_l,
+                               "bytes_sent_per_example": (rows_f * (args.fields * args.k * 4 + 4) + rows_l * 8) / B,
+                               "what": "last timed step of rank 0: occurrences (entries of the micro-batch) vs deduplicated bucket rows put on the wire"}
+        else:
             dist_rank.gather_tables()  # every rank gets the whole model back for the hold-out pass
     avg_kernel_ms = float(np.mean(kernel_ms))
     alg_bytes = float(np.mean([algorithmic_bytes(args, batches[W + i], words[W + i]) for i in range(K)]))
@@ -459,6 +465,8 @@ def main():
         dist.barrier()
         tsp = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device="cuda")
         dist.all_reduce(tsp, op=dist.ReduceOp.MAX)
+        sp_rows = dist_rank.sparse_last_rows()
+        sp_occ = (int(pb[-1].n_ffm), int(pb[-1].n_lr)) if hasattr(pb[-1], "n_ffm") else None
         for x in pb:
             x.close()
         del precs_
@@ -478,6 +486,8 @@ def main():
         dp_modes = {"replica": "the timed mode of this line",
                     "sparse": {"value": world * Kp * Bp / float(tsp.item()), "unit": "examples/sec", "steps": Kp,
                                "examples_per_step_per_gpu": Bp, "ms_per_step": 1e3 * float(tsp.item()) / Kp,
+                               "bucket_rows_last_step": {"ffm": sp_rows[0], "lr": sp_rows[1]},
+                               "bytes_sent_per_example": (sp_rows[0] * (args.fields * args.k * 4 + 4) + sp_rows[1] * 8) / Bp,
                                "what": "full replicas, per-micro-batch all-gather of deduplicated row gradients, every rank applies all of "
                                        "them: one summed-gradient AdaGrad step per row (fwgpu_dist_learn_sparse_batch)"},
                     "sharded": {"value": world * Ks * Bs / float(tsh.item()), "unit": "examples/sec", "steps": Ks,
@@ -556,6 +566,8 @@ def main():
             out["pcie_inclusive"] = pcie
         if dp_modes is not None:
             out["dp_modes"] = dp_modes
+        if sparse_main:
+            out["sparse_exchange"] = sparse_exchange
         if args.cpu and world == 1:
             n_cpu = args.cpu_examples or 20000
             try:

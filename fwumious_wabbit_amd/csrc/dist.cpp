@@ -14,6 +14,13 @@
 //   taken in another order: 1e-7 relative).  Rows that straddle an ownership boundary (R floats out of table/N) see the next
 //   owner's copy of their tail diverge: 6e-6 of the rows at config C with 8 ranks.
 //
+// Mode "sparse" = full replicas, row-sparse gradient buckets (north_star's wording; sparse.hip has the kernels and the rule):
+//     P1  FWD + MID over the rank's OWN micro-batch against its replica; every entry is listed as an occurrence (row, slot)
+//     P2  radix sort + segment reduction: one bucket row per row hash (per 64 sorted occurrences)
+//     X1  all-gather of the bucket counts, then of {keys, gradient rows} padded to the largest rank
+//     P3  merge (sort by hash, rank, index) + apply: one optimizer step per row with the summed gradient, same order everywhere
+//   Replicas that start identical stay bit-identical; no table ever crosses the links.
+//
 // RCCL is resolved at run time (dlopen librccl.so.1): a process that never calls fwgpu_dist_init does not load it, and a
 // Python process that already holds torch's copy reuses it.
 #include <dlfcn.h>
@@ -123,6 +130,7 @@ struct fwgpu_dist {
     uint64_t ob_wcap = 0;
     fwgpu_batch *cur = nullptr;      // the batch this sparse step runs on
     uint32_t occ_max_ffm = 0, occ_max_lr = 0;
+    uint32_t last_rows[2] = {0, 0};  // bucket rows {ffm, lr} this rank sent in its last sparse step
     ~fwgpu_dist() {
         sf.release();
         sl.release();
@@ -690,6 +698,8 @@ static int rccl_sparse_step(fwgpu_dist *d, uint32_t shape[4], float *preds) {
     std::vector<uint32_t> counts((size_t)2 * N);
     FWGPU_HIP(hipMemcpyAsync(counts.data(), all_counts, counts.size() * 4, hipMemcpyDeviceToHost, d->stream));
     FWGPU_HIP(hipStreamSynchronize(d->stream));
+    d->last_rows[0] = counts[2 * d->rank];
+    d->last_rows[1] = counts[2 * d->rank + 1];
     for (int side = 0; side < 2; side++) {
         fwgpu_dist::SparseSide &s = side == 0 ? d->sf : d->sl;
         if (!s.occ_cap) continue;
@@ -730,6 +740,14 @@ int fwgpu_dist_learn_sparse(fwgpu_dist *d, const fwgpu_translator_config *t, con
     int rc = sparse_begin(d, t, records, rec_off, n, nullptr, shape);
     if (rc) return rc;
     return rccl_sparse_step(d, shape, preds);
+}
+
+// what the rank's last sparse step put on the wire: bucket rows of R floats (+ 4-byte key) and LR buckets (key + float)
+int fwgpu_dist_sparse_last_rows(const fwgpu_dist *d, uint32_t *ffm_rows, uint32_t *lr_rows) {
+    if (!d) return fail(FWGPU_ERR_INVALID, "NULL dist");
+    if (ffm_rows) *ffm_rows = d->last_rows[0];
+    if (lr_rows) *lr_rows = d->last_rows[1];
+    return FWGPU_OK;
 }
 
 // the rank's micro-batch already in HBM (fwgpu_record_batch_create); predictions land in the batch
@@ -866,6 +884,8 @@ int fwgpu_dist_group_learn_sparse(fwgpu_dist_group *g, const fwgpu_translator_co
         fwgpu_dist *d = g->ranks[j].get();
         FWGPU_HIP(hipMemcpyAsync(&counts[2 * j], d->d_counts, 8, hipMemcpyDeviceToHost, d->stream));
         FWGPU_HIP(hipStreamSynchronize(d->stream));
+        d->last_rows[0] = counts[2 * j];
+        d->last_rows[1] = counts[2 * j + 1];
     }
     for (int side = 0; side < 2; side++) {
         uint32_t stride = 0;

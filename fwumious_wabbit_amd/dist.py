@@ -60,6 +60,12 @@ class DistRank:
     def learn_sparse_batch(self, translator, batch):
         check(capi.lib().fwgpu_dist_learn_sparse_batch(self.h, C.byref(translator.c), batch.h))
 
+    def sparse_last_rows(self):
+        """(FFM bucket rows, LR bucket entries) this rank sent in its last sparse step"""
+        a, b = C.c_uint32(), C.c_uint32()
+        check(capi.lib().fwgpu_dist_sparse_last_rows(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def gather_tables(self):
         check(capi.lib().fwgpu_dist_gather_tables(self.h))
 

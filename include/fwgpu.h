@@ -303,6 +303,8 @@ int fwgpu_dist_group_gather_tables(fwgpu_dist_group *g);
 int fwgpu_dist_learn_sparse(fwgpu_dist *d, const fwgpu_translator_config *t, const uint32_t *records, const uint64_t *rec_off,
                             uint32_t n, float *predictions);
 int fwgpu_dist_learn_sparse_batch(fwgpu_dist *d, const fwgpu_translator_config *t, fwgpu_batch *b);
+/* bucket rows the rank sent in its last sparse step: FFM rows (4-byte key + R floats each) and LR entries (key + float) */
+int fwgpu_dist_sparse_last_rows(const fwgpu_dist *d, uint32_t *ffm_rows, uint32_t *lr_rows);
 /* in-process group: rank j brings n[j] records */
 int fwgpu_dist_group_learn_sparse(fwgpu_dist_group *g, const fwgpu_translator_config *t, const uint32_t *const *records,
                                   const uint64_t *const *rec_off, const uint32_t *n, float *const *predictions);

@@ -1,4 +1,5 @@
-"""world_size 2 and 4 gloo tests of the owner-sharded step's PROTOCOL (fwumious_wabbit_amd/csrc/dist.cpp), on CPU.
+"""world_size 2 and 4 gloo tests of the multi-GPU steps' PROTOCOLS (fwumious_wabbit_amd/csrc/dist.cpp: owner-sharded step,
+row-sparse gradient buckets), on CPU.
 
 The library has no CPU compute path, so what runs here is a miniature of the step with the oracle's arithmetic in numpy (LR block
 + AdagradLUT, block_lr.rs:28-47 / 135-150, optimizer.rs:101-156) and the real collectives over torch.distributed: all-gather of
@@ -156,6 +157,113 @@ def test_sharded_protocol_world2_and_world4_equal_one_learner():
         assert np.count_nonzero(w_ref) > 100  # it did learn something
 
 
+# ------------------------------------------------------------------ row-sparse gradient buckets (sparse.hip / dist.cpp)
+def _buckets(idx, val, g):
+    """one rank's micro-batch -> deduplicated (key, gradient) buckets: occurrences sorted by (key, example, entry), summed in
+    order inside 64-element blocks of the sorted list (sparse_reduce_lr_kernel)"""
+    occ = sorted((int(idx[e, j]), e, j) for e in range(idx.shape[0]) for j in range(idx.shape[1]))
+    keys, vals = [], []
+    for b0 in range(0, len(occ), 64):
+        cur, acc = None, np.float32(0.0)
+        for h, e, j in occ[b0:b0 + 64]:
+            if h != cur:
+                if cur is not None:
+                    keys.append(cur)
+                    vals.append(acc)
+                cur, acc = h, np.float32(0.0)
+            acc = np.float32(acc + np.float32(g[e] * val[e, j]))
+        keys.append(cur)
+        vals.append(acc)
+    return np.array(keys, dtype=np.int64), np.array(vals, dtype=np.float32)
+
+
+def _apply_buckets(w, acc, lut, bucket_lists):
+    """all ranks' buckets, merged by (key, rank, index): one optimizer step per key with the summed gradient (sparse_apply_lr_kernel)"""
+    merged = sorted((int(k), r, i, v) for r, (ks, vs) in enumerate(bucket_lists) for i, (k, v) in enumerate(zip(ks, vs)))
+    i = 0
+    while i < len(merged):
+        h, G = merged[i][0], np.float32(0.0)
+        while i < len(merged) and merged[i][0] == h:
+            G = np.float32(G + merged[i][3])
+            i += 1
+        if G != 0.0:
+            acc[h] = np.float32(acc[h] + G * G)
+            key = int(np.float32(acc[h]).view(np.uint32)) >> 20
+            w[h] = np.float32(w[h] - G * lut[key])
+
+
+def _forward(w, idx, val, y):
+    ps, gs = [], []
+    for e in range(len(y)):
+        wsum = np.float32(0.0)
+        for h, v in zip(idx[e], val[e]):
+            wsum = np.float32(wsum + w[h] * v)
+        p, g = _sigmoid_grad(wsum, y[e])
+        ps.append(p)
+        gs.append(g)
+    return np.array(ps, dtype=np.float32), np.array(gs, dtype=np.float32)
+
+
+def _single_sparse_learner(n_ranks):
+    lut = _make_lut()
+    w = np.zeros(1 << BITS, dtype=np.float32)
+    acc = np.zeros(1 << BITS, dtype=np.float32)
+    preds = []
+    for s in range(STEPS):
+        idx, val, y = _examples(s, n_ranks * B)
+        p, g = _forward(w, idx, val, y)
+        preds.append(p)
+        _apply_buckets(w, acc, lut, [_buckets(idx[r * B:(r + 1) * B], val[r * B:(r + 1) * B], g[r * B:(r + 1) * B]) for r in range(n_ranks)])
+    return w, acc, np.concatenate(preds)
+
+
+def _sparse_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lut = _make_lut()
+    w = np.zeros(1 << BITS, dtype=np.float32)  # a full replica on every rank
+    acc = np.zeros(1 << BITS, dtype=np.float32)
+    preds = []
+    for s in range(STEPS):
+        idx_all, val_all, y_all = _examples(s, world * B)
+        mine = slice(rank * B, (rank + 1) * B)
+        p, g = _forward(w, idx_all[mine], val_all[mine], y_all[mine])  # own examples only: no record exchange in this mode
+        preds.append(p)
+        keys, vals = _buckets(idx_all[mine], val_all[mine], g)
+        # X1: bucket counts, then the buckets padded to the largest (ncclAllGather needs equal counts)
+        cnt = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(cnt, torch.tensor([len(keys)], dtype=torch.int64))
+        stride = int(max(c.item() for c in cnt))
+        pk, pv = np.zeros(stride, dtype=np.int64), np.zeros(stride, dtype=np.float32)
+        pk[:len(keys)], pv[:len(keys)] = keys, vals
+        gk = [torch.zeros(stride, dtype=torch.int64) for _ in range(world)]
+        gv = [torch.zeros(stride, dtype=torch.float32) for _ in range(world)]
+        dist.all_gather(gk, torch.from_numpy(pk))
+        dist.all_gather(gv, torch.from_numpy(pv))
+        lists = [(gk[r].numpy()[:int(cnt[r].item())], gv[r].numpy()[:int(cnt[r].item())]) for r in range(world)]
+        _apply_buckets(w, acc, lut, lists)  # every rank applies every rank's buckets, in the same order
+    out[rank] = (w.copy(), acc.copy(), np.concatenate(preds))
+    dist.destroy_process_group()
+
+
+def test_sparse_bucket_protocol_world2_and_world4_equal_one_learner():
+    """replicas + all-gathered deduplicated gradients == one learner taking one summed-gradient step per key and global batch,
+    bit for bit, and the replicas never drift apart (no table exchange at all)"""
+    for world in (2, 4):
+        w_ref, acc_ref, p_ref = _single_sparse_learner(world)
+        port = _free_port()
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_sparse_worker, args=(world, port, out), nprocs=world, join=True)
+        for r in range(world):
+            w, acc, preds = out[r]
+            assert np.array_equal(w, w_ref) and np.array_equal(acc, acc_ref), (world, r)
+            mine = np.concatenate([p_ref[s * world * B + r * B: s * world * B + (r + 1) * B] for s in range(STEPS)])
+            assert np.array_equal(preds, mine), (world, r)
+        assert np.count_nonzero(w_ref) > 100
+
+
 def test_dist_symbols_are_exported_without_loading_rccl():
     """the library resolves librccl only inside fwgpu_dist_init / fwgpu_dist_unique_id: importing it on a box without a GPU
     (this one) must not need RCCL, and the multi-GPU entry points must be there"""
@@ -165,6 +273,7 @@ def test_dist_symbols_are_exported_without_loading_rccl():
     L = capi.lib()
     for name in ("fwgpu_dist_unique_id", "fwgpu_dist_init", "fwgpu_dist_learn_sharded", "fwgpu_dist_gather_tables",
                  "fwgpu_dist_all_reduce_sum", "fwgpu_dist_group_create", "fwgpu_dist_group_learn_sharded",
+                 "fwgpu_dist_learn_sparse", "fwgpu_dist_learn_sparse_batch", "fwgpu_dist_group_learn_sparse",
                  "fwgpu_learn_batch_sync", "fwgpu_split_create"):
         assert hasattr(L, name)
     with open("/proc/self/maps") as f:
