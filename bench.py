@@ -196,7 +196,7 @@ def main():
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=None,
-                    help="examples per step per GPU (default 65536; --dp-mode sharded: 2048 / n_gpus, the synchronous step is stable "
+                    help="examples per step per GPU (default 65536; --dp-mode sharded: 2048 / n_gpus, --dp-mode sparse: 8192 / n_gpus; the synchronous step is stable "
                          "up to a GLOBAL micro-batch of ~2048 examples at these hyper-parameters, profiles/r02_sync_batch_stability.txt)")
     ap.add_argument("--fields", type=int, default=30)
     ap.add_argument("--k", type=int, default=8)
@@ -284,7 +284,7 @@ def main():
     if args.batch is None:
         # synchronous micro-batches are stable up to ~2048 examples at these hyper-parameters (profiles/r02_sync_batch_stability.txt)
         args.batch = (max(64, 2048 // world) if (use_dist and args.dp_mode == "sharded") else
-                      16384 if (use_dist and args.dp_mode == "sparse") else (2048 if sync_steps else 65536))
+                      max(256, 8192 // world) if (use_dist and args.dp_mode == "sparse") else (2048 if sync_steps else 65536))
     K, W, B = args.steps, args.warmup, args.batch
     # every rank trains on its own shard of the stream: examples [rank*(W+K)*B, ...)
     t0 = time.time()
@@ -452,7 +452,7 @@ def main():
     dp_modes = None
     if use_dist and dist_rank is not None and not sharded_main:
         # row-sparse gradient buckets first (it keeps the replicas whole)
-        Kp, Bp = min(K, 8), 16384
+        Kp, Bp = min(K, 16), max(256, 8192 // world)  # global micro-batch of 8192 examples: the summed-gradient rule's stable range
         precs_, poff_ = gen_records(fw, args, 2_500_000_000 + rank * Kp * Bp, Kp * Bp)
         pb = [re.record_batch(fbt, precs_[int(poff_[j * Bp]):int(poff_[(j + 1) * Bp])], poff_[j * Bp:(j + 1) * Bp + 1] - poff_[j * Bp]) for j in range(Kp)]
         dist_rank.learn_sparse_batch(fbt, pb[0])
@@ -520,6 +520,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "final_logloss": final_ll,
+            # what "learned" means on this hold-out tail: the loss of always predicting its positive rate (the untrained model reads ln 2)
+            "holdout_prior_logloss": logloss(np.full(len(hy), float(np.mean(hy == 1)), dtype=np.float64), hy),
             "saturated_fraction_last_step": saturated,
             "config": {
                 "hyperparameters": f"AdagradLUT lr={LR} power_t={POWER_T} init_acc_gradient={INIT_ACC} (run_one.sh)",

@@ -252,3 +252,37 @@ def test_sparse_bucket_step_empty_and_single_micro_batch():
     assert np.abs(out[0] - p_ref).max() < 1e-6
     g.close()
     regs[0].close()
+
+
+def test_sparse_bucket_step_importance_weights_and_models_without_ffm():
+    """importance 0 examples are scored but list no occurrence (regressor.rs:366), other importances scale the gradient;
+    an LR-only model (no FFM block) runs the LR side alone"""
+    for n_ns, k in ((8, 4), (6, 0)):
+        mi, ocfg, ots = make_pair(n_ns, k, 14, 14, fw.Optimizer.AdagradLUT, lr=0.05, ffm_lr=0.05)
+        recs, off = fw.synth_records(n_ns, 1.0, 1.1, 2000, 0.1, 87, 0, 240)
+        recs = recs.copy()
+        imp = np.array([0.0, 1.0, 2.5, 0.25], dtype=np.float32)
+        for i in range(240):
+            recs[int(off[i]) + 2] = imp[i % 4].view(np.uint32)  # record word 2: importance (parser.rs:57-74)
+        om = fwo.Model(ocfg)
+        p_ref = np.concatenate([om.learn_sparse(ots, recs[int(off[s * 120]):int(off[(s + 1) * 120])], off[s * 120:(s + 1) * 120 + 1] - off[s * 120], [50, 120])
+                                for s in range(2)])
+        ref_tabs = [om.lr_table, om.ffm_weights, om.ffm_acc]
+        preds, tables = _run_sparse(2, mi, recs, off, [50, 70], 2)
+        assert np.abs(preds - p_ref).max() < 1e-5
+        for t in range(3):
+            a, b = np.asarray(tables[0][t]), np.asarray(ref_tabs[t])[:len(tables[0][t])]
+            bad = np.abs(a - b) > 3e-5 + 1e-5 * np.abs(b)
+            assert int(bad.sum()) <= 3 and (a.size == 0 or float(np.abs(a - b).max()) < 5e-3), (k, t)
+            assert np.array_equal(a, np.asarray(tables[1][t]))
+        # the zero-importance examples changed nothing: a run without them ends with the same tables
+        keep = [i for i in range(240) if i % 4 != 0]
+        recs2 = np.concatenate([recs[int(off[i]):int(off[i + 1])] for i in keep])
+        off2 = np.concatenate([[0], np.cumsum([int(off[i + 1] - off[i]) for i in keep])]).astype(np.uint64)
+        om2 = fwo.Model(ocfg)
+        for s in range(2):
+            om2.learn_sparse(ots, recs2[int(off2[s * 90]):int(off2[(s + 1) * 90])], off2[s * 90:(s + 1) * 90 + 1] - off2[s * 90])
+        om3 = fwo.Model(ocfg)
+        for s in range(2):
+            om3.learn_sparse(ots, recs[int(off[s * 120]):int(off[(s + 1) * 120])], off[s * 120:(s + 1) * 120 + 1] - off[s * 120])
+        assert np.array_equal(np.asarray(om2.lr_table), np.asarray(om3.lr_table))
