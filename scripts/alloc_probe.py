@@ -32,8 +32,8 @@ for rep in range(int(os.environ.get("REPS", 8))):
         re.learn_batch(batches[i % 2], capi.MODE_HOGWILD, True)
     batches[1].predictions()
     dt = (time.perf_counter() - t0) / 16
-    ptrs = [hex(re.table_ptr(t)) if hasattr(re, "table_ptr") else "?" for t in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)]
-    print(f"regressor #{rep}: {dt * 1e3:.3f} ms/launch  tables at {ptrs}", flush=True)
+    ptrs = [hex(re.table_device_ptr(t)) for t in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)]
+    print(f"regressor #{rep}: {dt * 1e3:.3f} ms/launch  tables (lr, w, acc) at {ptrs}", flush=True)
     for b in batches:
         b.close()
     re.close()
