@@ -519,6 +519,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "table_placement": dict(zip(("candidates_tried", "pair_probe_ms_kept", "pair_probe_ms_slowest"), re.placement())),
             "final_logloss": final_ll,
             # what "learned" means on this hold-out tail: the loss of always predicting its positive rate (the untrained model reads ln 2)
             "holdout_prior_logloss": logloss(np.full(len(hy), float(np.mean(hy == 1)), dtype=np.float64), hy),

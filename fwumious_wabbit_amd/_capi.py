@@ -176,6 +176,7 @@ def lib():
         "fwgpu_delta_start": [vp, vp, vp, vp, u64, f32, vp],
         "fwgpu_delta_finish": [vp, vp, vp, vp, u64, vp],
         "fwgpu_debug_phase_ticks": [vp, i32, vp],
+        "fwgpu_debug_placement": [vp, P(i32), P(C.c_float), P(C.c_float)],
         "fwgpu_debug_set_kernel_version": [vp, i32],
         "fwgpu_debug_set_option": [vp, i32, i32],
         "fwgpu_debug_coherence_probe": [i32, i32, u32, P(u32), P(u32)],

@@ -181,6 +181,7 @@ struct SparseApplyArgs {
 size_t sparse_tmp_bytes(uint32_t n_max);
 hipError_t sparse_reduce(const SparseReduceArgs &a, hipStream_t stream);
 hipError_t sparse_apply(const SparseApplyArgs &a, int optimizer, hipStream_t stream);
+hipError_t pair_probe_ms(float *a, float *b, size_t bytes, uint32_t nrows, int reps, float *ms_out);  // sparse.hip: table placement probe
 hipError_t launch_ffm_init(float *w, float *acc, uint64_t len, uint32_t k, float init_width, float init_zero_band,
                            float init_center, float acc0, hipStream_t stream);
 hipError_t launch_fill(float *p, uint64_t n, float v, hipStream_t stream);
@@ -238,6 +239,9 @@ struct fwgpu_regressor {
     uint64_t lr_len = 0;   // entries
     uint64_t ffm_len = 0;  // floats
     float *d_lr = nullptr, *d_ffm_w = nullptr, *d_ffm_acc = nullptr;
+    int placement_tries = 0;                     // candidate allocations timed for d_ffm_acc (regressor.cpp: place_ffm_acc)
+    float placement_ms_lo = 0, placement_ms_hi = 0;  // fastest / slowest pair probe among them
+    float placement_ms_single = 0;                    // the same probe on the weight table alone
     float *d_lut_lr = nullptr, *d_lut_ffm = nullptr;
     uint32_t lr_hash_mask = 0, ffm_hash_mask = 0;
     fwgpu::LaunchConfig launch;

@@ -399,6 +399,75 @@ extern "C" {
 const char *fwgpu_last_error(void) { return g_last_error.c_str(); }
 int fwgpu_abi_version(void) { return FWGPU_ABI_VERSION; }
 
+// Where the accumulator table goes relative to the weight table.  Device memory on MI355X falls into groups (tools/placement.hip,
+// profiles/r02_placement.txt): the FFM update's pattern -- whole-line read-modify-write of w[h..] and acc[h..] at once -- runs 17 %
+// slower when both tables come from the same group (2.45 ms vs 2.04 ms per 3.3 M rows), whatever their addresses.  hipMalloc hands
+// out consecutive allocations from one group for several GB, so for tables beyond the Infinity Cache a few candidate allocations
+// are tried and timed against w with that very pattern (a fraction of a millisecond each); the fastest is kept, the rest freed.
+// FWGPU_PLACEMENT=0 switches the search off (the first allocation is used, as for small tables).
+static int place_ffm_acc(fwgpu_regressor *r, size_t fbytes) {
+    const char *env = std::getenv("FWGPU_PLACEMENT");
+    const bool search = fbytes > (256u << 20) && !(env && env[0] == '0');
+    std::vector<float *> cand;
+    float single = 0.0f, lo = 1e30f, hi = 0.0f;
+    int best = 0;
+    if (search) {
+        // the weight table alone, until two consecutive readings agree (the first launches of a process run on ramping clocks)
+        float prev = 0.0f;
+        for (int i = 0; i < 24; i++) {
+            if (pair_probe_ms(r->d_ffm_w, nullptr, fbytes, 400000, 2, &single) != hipSuccess) {
+                (void)hipGetLastError();
+                single = 0.0f;
+                break;
+            }
+            if (prev > 0.0f && std::fabs(single - prev) < 0.02f * prev) break;
+            prev = single;
+        }
+    }
+    // the pair costs 1.8x the single table when the two do not contend, 2.2x when they do (profiles/r02_placement.txt)
+    const float fast_below = 1.96f * single;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+        (void)hipGetLastError();
+        free_b = 0;
+    }
+    // Candidates are allocations of the table's own size, held until the search ends so that hipMalloc keeps walking forward.
+    // (Large "spacer" allocations to skip ahead do not work: they are assembled from elsewhere and the next table-sized block
+    // still comes from the same stretch.)  A stretch of contending memory is up to ~72 table-GB long (tools/placement scan of
+    // 200 x 1 GiB, profiles/r02_placement.txt), a probe costs about a millisecond.
+    const size_t budget = std::min<size_t>(free_b / 2, 128ull << 30);
+    const int max_tries = search && single > 0.0f ? (int)std::max<size_t>(2, std::min<size_t>(112, budget / fbytes)) : 1;
+    for (int t = 0; t < max_tries; t++) {
+        float *c = nullptr;
+        if (hipMalloc((void **)&c, fbytes) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        cand.push_back(c);
+        if (max_tries == 1) break;
+        float t_ms = 0.0f;
+        if (pair_probe_ms(r->d_ffm_w, c, fbytes, 400000, 2, &t_ms) != hipSuccess) {
+            (void)hipGetLastError();
+            break;  // (keep what there is; the probe is an optimisation)
+        }
+        hi = std::max(hi, t_ms);
+        if (t_ms < lo) {
+            lo = t_ms;
+            best = t;
+        }
+        if (t_ms < fast_below) break;  // does not contend with w: done
+    }
+    if (cand.empty()) return fail(FWGPU_ERR_DEVICE, "out of device memory (FFM accumulators)");
+    r->d_ffm_acc = cand[best];
+    for (size_t i = 0; i < cand.size(); i++)
+        if ((int)i != best) (void)hipFree(cand[i]);
+    r->placement_tries = (int)cand.size();
+    r->placement_ms_lo = hi > 0.0f ? lo : 0.0f;
+    r->placement_ms_hi = hi;
+    r->placement_ms_single = single;
+    return FWGPU_OK;
+}
+
 int fwgpu_create(const fwgpu_config *cfg, fwgpu_regressor **out) {
     if (!cfg || !out) return fail(FWGPU_ERR_INVALID, "fwgpu_create: NULL argument");
     *out = nullptr;
@@ -433,14 +502,17 @@ int fwgpu_create(const fwgpu_config *cfg, fwgpu_regressor **out) {
     r->ffm_len = cfg->ffm_k ? (1ull << cfg->ffm_bit_precision) + (uint64_t)cfg->ffm_num_fields * cfg->ffm_k : 0;
     r->lr_hash_mask = lr_hash_mask(cfg->bit_precision);
     r->ffm_hash_mask = ffm_hash_mask(cfg->ffm_bit_precision, cfg->ffm_k);
+    // (where the LR table lands relative to the FFM tables was measured not to matter: 3.55 ms per launch either way)
     FWGPU_HIP(hipMalloc((void **)&r->d_lr, r->lr_len * 2 * sizeof(float)));
     FWGPU_HIP(hipMemset(r->d_lr, 0, r->lr_len * 2 * sizeof(float)));
     if (r->ffm_len) {
         // +64 floats of slack so that a 16 B vector at the very end of the spill-over tail stays in the allocation
-        FWGPU_HIP(hipMalloc((void **)&r->d_ffm_w, (r->ffm_len + 64) * sizeof(float)));
-        FWGPU_HIP(hipMalloc((void **)&r->d_ffm_acc, (r->ffm_len + 64) * sizeof(float)));
-        FWGPU_HIP(hipMemset(r->d_ffm_w, 0, (r->ffm_len + 64) * sizeof(float)));
-        FWGPU_HIP(hipMemset(r->d_ffm_acc, 0, (r->ffm_len + 64) * sizeof(float)));
+        const size_t fbytes = (r->ffm_len + 64) * sizeof(float);
+        FWGPU_HIP(hipMalloc((void **)&r->d_ffm_w, fbytes));
+        int rc = place_ffm_acc(r.get(), fbytes);
+        if (rc) return rc;
+        FWGPU_HIP(hipMemset(r->d_ffm_w, 0, fbytes));
+        FWGPU_HIP(hipMemset(r->d_ffm_acc, 0, fbytes));
     }
     // each block owns its optimizer instance: block_lr.rs:63-65, block_ffm.rs:86-91
     std::vector<float> lut(kLutSize);
@@ -1104,6 +1176,14 @@ int fwgpu_delta_finish(void *table, void *snapshot, const void *local_delta, con
     FWGPU_HIP(launch_delta_finish(static_cast<float *>(table), static_cast<float *>(snapshot),
                                   static_cast<const float *>(local_delta), static_cast<const float *>(summed_delta),
                                   n_floats, static_cast<hipStream_t>(stream)));
+    return FWGPU_OK;
+}
+
+int fwgpu_debug_placement(const fwgpu_regressor *r, int *tries, float *ms_fastest, float *ms_slowest) {
+    if (!r) return fail(FWGPU_ERR_INVALID, "NULL regressor");
+    if (tries) *tries = r->placement_tries;
+    if (ms_fastest) *ms_fastest = r->placement_ms_lo;
+    if (ms_slowest) *ms_slowest = r->placement_ms_hi;
     return FWGPU_OK;
 }
 

@@ -308,6 +308,60 @@ static hipError_t sparse_apply_t(const SparseApplyArgs &a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ table placement probe (regressor.cpp: place_ffm_tables)
+// Random 1 KiB whole-line read-modify-write on two buffers at once -- the FFM update's access pattern on (w, acc).  Values are
+// written back unchanged.  tools/placement.hip measured that the same pattern runs 2.04 ms or 2.45 ms depending only on WHICH two
+// allocations are paired (profiles/r02_placement.txt): device memory falls into groups, and two tables of one group contend.
+namespace {
+__device__ __forceinline__ uint32_t probe_mix(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+__global__ __launch_bounds__(256) void pair_probe_kernel(float *a, float *b, uint32_t lines, uint32_t nrows, uint32_t seed) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < nrows; r += (gridDim.x * blockDim.x) >> 6) {
+        const uint32_t line = probe_mix(r * 2654435761u + seed) % (lines - 8);
+        __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(a + (size_t)line * 32, 0, 1024, 0x00020000);
+        __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(b + (size_t)line * 32, 0, 1024, 0x00020000);
+        const u4 x = __builtin_amdgcn_raw_buffer_load_b128(ra, lane * 16, 0, 16);
+        u4 y = x;
+        if (b) y = __builtin_amdgcn_raw_buffer_load_b128(rb, lane * 16, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(x, ra, lane * 16, 0, 16);
+        if (b) __builtin_amdgcn_raw_buffer_store_b128(y, rb, lane * 16, 0, 16);
+    }
+}
+}  // namespace
+
+// milliseconds of the pair pattern over `nrows` random windows of two buffers of `bytes` each (best of `reps`); b == NULL: a alone
+hipError_t pair_probe_ms(float *a, float *b, size_t bytes, uint32_t nrows, int reps, float *ms_out) {
+    hipEvent_t e0, e1;
+    hipError_t e = hipEventCreate(&e0);
+    if (e != hipSuccess) return e;
+    e = hipEventCreate(&e1);
+    if (e != hipSuccess) return e;
+    const uint32_t lines = (uint32_t)std::min<size_t>(bytes / 128, 0xffffffffu);
+    float best = 1e30f;
+    for (int i = 0; i <= reps; i++) {  // (the first one warms up)
+        (void)hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(pair_probe_kernel, dim3(256 * 12), dim3(256), 0, 0, a, b, lines, nrows, 17u + (uint32_t)i);
+        (void)hipEventRecord(e1, 0);
+        e = hipEventSynchronize(e1);
+        if (e != hipSuccess) break;
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (i > 0) best = std::min(best, ms);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_out = best;
+    return e;
+}
+
 hipError_t sparse_apply(const SparseApplyArgs &a, int optimizer, hipStream_t stream) {
     switch (optimizer) {
     case FWGPU_OPT_SGD: return sparse_apply_t<FWGPU_OPT_SGD>(a, stream);

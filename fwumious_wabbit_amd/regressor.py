@@ -420,6 +420,12 @@ class Regressor:
         check(self.L.fwgpu_table_device_ptr(self.h, which, C.byref(p)))
         return p.value
 
+    def placement(self):
+        """(candidate allocations tried for the FFM accumulators, fastest, slowest pair-probe ms) -- fwgpu_debug_placement"""
+        n, lo, hi = C.c_int32(), C.c_float(), C.c_float()
+        check(self.L.fwgpu_debug_placement(self.h, C.byref(n), C.byref(lo), C.byref(hi)))
+        return n.value, lo.value, hi.value
+
     def table_as_torch(self, which):
         """Zero-copy torch view of a table (device memory stays owned by the library)."""
         import torch

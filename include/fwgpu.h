@@ -366,6 +366,10 @@ int fwgpu_delta_finish(void *table, void *snapshot, const void *local_delta, con
  * [3] dot + LR forward + sigmoid, [4] LR update, [5] FFM update, [6] wait for the slowest wave, [7] examples.
  * out16 (may be NULL) receives the counters accumulated so far. */
 int fwgpu_debug_phase_ticks(fwgpu_regressor *r, int enable, uint64_t *out16);
+/* How the FFM accumulator table was placed relative to the weight table (fwgpu_create tries a few candidate allocations for
+ * tables beyond the Infinity Cache and times the update's access pattern on each pair; FWGPU_PLACEMENT=0 disables it):
+ * candidates tried (1: no search), fastest and slowest pair probe in milliseconds (0 when nothing was timed). */
+int fwgpu_debug_placement(const fwgpu_regressor *r, int *tries, float *ms_fastest, float *ms_slowest);
 /* 0 = automatic kernel choice, 1 = force the generic kernel (v1), 2 = register-resident rows (v2) where applicable. */
 int fwgpu_debug_set_kernel_version(fwgpu_regressor *r, int version);
 /* Tuning switches for experiments. option 1: value 1 = read the AdaGrad LUT from global memory instead of an LDS copy. */
