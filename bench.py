@@ -46,7 +46,7 @@ def build_model_instance(fw, args, device):
     return fw.ModelInstance(
         learning_rate=LR, ffm_learning_rate=LR, power_t=POWER_T, ffm_power_t=POWER_T, init_acc_gradient=INIT_ACC,
         ffm_init_acc_gradient=INIT_ACC, bit_precision=args.bits, ffm_bit_precision=args.ffm_bits, ffm_k=args.k,
-        add_constant_feature=True, optimizer=fw.Optimizer.AdagradLUT,
+        add_constant_feature=not os.environ.get("FWGPU_BENCH_NO_CONSTANT"), optimizer=fw.Optimizer.AdagradLUT,  # (experiment switch: the constant feature is the one LR entry every example writes)
         feature_combo_descs=[fw.FeatureComboDesc([fw.NamespaceDescriptor(i)]) for i in range(F)],
         ffm_fields=[[fw.NamespaceDescriptor(i)] for i in range(F)], device=device,
         # config E: `--nn_layers 2 --nn 0:width:256 --nn 0:activation:relu ...`, topology "one" 
