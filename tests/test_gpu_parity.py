@@ -992,3 +992,33 @@ def test_one_example_in_flight_is_the_sequential_mode():
         assert re_a.table_checksum(t) == re_b.table_checksum(t)
     for x in (b, tr, re_a, re_b):
         x.close()
+
+
+@pytest.mark.gpu
+def test_table_placement_search_is_transparent(monkeypatch):
+    """fwgpu_create looks for an accumulator allocation that does not contend with the weight table (tables beyond the
+    Infinity Cache only; regressor.cpp place_ffm_acc).  Whatever it picks, the model is the same model: same initial tables,
+    same sequential-mode results as with the search switched off; small tables are never searched."""
+    mi, ocfg, ots = make_pair(6, 8, 18, 27, fw.Optimizer.AdagradLUT, lr=0.05, ffm_lr=0.05)  # 2^27 floats = 512 MiB per FFM table
+    recs, off = fw.synth_records(6, 0.5, 1.1, 5000, 0.1, 97, 0, 64)
+    outs = []
+    for env in (None, "0"):
+        if env is None:
+            monkeypatch.delenv("FWGPU_PLACEMENT", raising=False)
+        else:
+            monkeypatch.setenv("FWGPU_PLACEMENT", env)
+        re = fw.Regressor(mi)
+        tries, lo, hi = re.placement()
+        if env == "0":
+            assert tries == 1 and lo == 0.0
+        else:
+            assert tries >= 1 and lo > 0.0 and hi >= lo
+        b = re.record_batch(fw.FeatureBufferTranslator(mi), recs, off)
+        re.learn_batch(b, capi.MODE_SEQUENTIAL, True)
+        outs.append((b.predictions().copy(), re.table_checksum(capi.TABLE_FFM_W), re.table_checksum(capi.TABLE_FFM_ACC), re.table_checksum(capi.TABLE_LR)))
+        b.close()
+        re.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1:] == outs[1][1:]
+    small = fw.Regressor(make_pair(4, 4, 14, 14, fw.Optimizer.AdagradLUT)[0])
+    assert small.placement() == (1, 0.0, 0.0)
+    small.close()
