@@ -54,6 +54,42 @@ __global__ void rmw_rows(float *a, float *b, uint32_t lines, uint32_t nrows, uin
     }
 }
 
+// the update pattern with the tables striped over several allocations: row r uses pair (r mod npairs)
+struct PairSet {
+    float *a[8];
+    float *b[8];
+    int n;
+};
+__global__ void rmw_rows_multi(PairSet ps, uint32_t lines, uint32_t nrows, uint32_t seed) {
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < nrows; r += (gridDim.x * blockDim.x) >> 6) {
+        const uint32_t hsh = mix(r * 2654435761u + seed);
+        const uint32_t line = hsh % (lines - 8);
+        const int q = (int)((hsh >> 7) % (uint32_t)ps.n);
+        __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(ps.a[q] + (size_t)line * 32, 0, 1024, 0x00020000);
+        __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(ps.b[q] + (size_t)line * 32, 0, 1024, 0x00020000);
+        u4 x = __builtin_amdgcn_raw_buffer_load_b128(ra, lane * 16, 0, 16);
+        u4 y = __builtin_amdgcn_raw_buffer_load_b128(rb, lane * 16, 0, 16);
+        x.x += 1;
+        y.y += x.x;
+        __builtin_amdgcn_raw_buffer_store_b128(x, ra, lane * 16, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(y, rb, lane * 16, 0, 16);
+    }
+}
+__global__ void read_rows_multi(PairSet ps, uint32_t lines, uint32_t nrows, uint32_t seed, float *sink) {
+    const uint32_t lane = threadIdx.x & 63;
+    float acc = 0.f;
+    for (uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < nrows; r += (gridDim.x * blockDim.x) >> 6) {
+        const uint32_t hsh = mix(r * 2654435761u + seed);
+        const uint32_t start = (hsh % (lines - 8)) * 32 + (mix(r + seed) & 3) * 8;
+        const int q = (int)((hsh >> 7) % (uint32_t)ps.n);
+        __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(ps.a[q] + start, 0, 960, 0x00020000);
+        u4 x = __builtin_amdgcn_raw_buffer_load_b128(ra, lane * 16, 0, 16);
+        acc += __uint_as_float(x.x);
+    }
+    if (acc == 123.456f) sink[0] = acc;
+}
+
 __global__ void read_rows(const float *a, uint32_t lines, uint32_t nrows, uint32_t seed, float *sink) {
     const uint32_t lane = threadIdx.x & 63;
     float acc = 0.f;
@@ -114,6 +150,78 @@ int main(int argc, char **argv) {
             printf("pass %d buffer %d at %p: window RMW %.3f ms (%.2f TB/s)  row read %.3f ms (%.2f TB/s)  8 B RMW %.3f ms\n", rep, i, (void *)buf[i], t_rmw,
                    2.0 * nrows * 1024 / t_rmw / 1e9, t_rd, nrows * 960.0 / t_rd / 1e9, t_lr);
         }
+    if (argc > 3 && argv[3][0] == 'r') {  // regions: classify the buffers, then stripe the tables over 1 / 2 / 3 / 4 regions
+        std::vector<int> rep, cls(K, -1);
+        std::vector<std::vector<int>> members;
+        float fast = 1e9f, slow = 0.f;
+        for (int j = 0; j < K; j++) {
+            for (size_t c = 0; c < rep.size() && cls[j] < 0; c++) {
+                const float t = time_ms([&] { hipLaunchKernelGGL(rmw_rows<true>, grid, block, 0, 0, buf[rep[c]], buf[j], lines, 600000u, 17u); }, 2);
+                if (t > 0.415f) cls[j] = (int)c;
+                fast = t < fast ? t : fast;
+                slow = t > slow ? t : slow;
+            }
+            if (cls[j] < 0) {
+                cls[j] = (int)rep.size();
+                rep.push_back(j);
+                members.emplace_back();
+            }
+            members[cls[j]].push_back(j);
+        }
+        printf("regions found among %d buffers: %zu (pair probe %.3f - %.3f ms); classes: ", K, rep.size(), fast, slow);
+        for (int j = 0; j < K; j++) printf("%d", cls[j]);
+        printf("\n");
+        std::vector<int> big;  // regions with at least 2 members
+        for (size_t c = 0; c < members.size(); c++)
+            if (members[c].size() >= 2) big.push_back((int)c);
+        printf("regions with >= 2 buffers: %zu\n", big.size());
+        auto run = [&](const char *name, std::vector<std::pair<int, int>> pairs) {
+            PairSet ps;
+            ps.n = (int)pairs.size();
+            for (int q = 0; q < ps.n; q++) {
+                ps.a[q] = buf[pairs[q].first];
+                ps.b[q] = buf[pairs[q].second];
+            }
+            const float t = time_ms([&] { hipLaunchKernelGGL(rmw_rows_multi, grid, block, 0, 0, ps, lines, nrows, 17u); }, 4);
+            const float tr = time_ms([&] { hipLaunchKernelGGL(read_rows_multi, grid, block, 0, 0, ps, lines, nrows, 29u, sink); }, 4);
+            printf("%-64s two-table RMW %.3f ms (%.2f TB/s)   row reads of the first table %.3f ms (%.2f TB/s)\n", name, t, 4.0 * nrows * 1024 / t / 1e9, tr,
+                   nrows * 960.0 / tr / 1e9);
+        };
+        if (big.size() >= 2) {
+            const int A0 = members[big[0]][0], A1 = members[big[0]][1], B0 = members[big[1]][0], B1 = members[big[1]][1];
+            run("same region (w = A0, acc = A1)", {{A0, A1}});
+            run("two regions (w = A0, acc = B0)", {{A0, B0}});
+            run("two regions, balanced ((A0,B0), (B1,A1))", {{A0, B0}, {B1, A1}});
+            if (big.size() >= 3) {
+                const int C0 = members[big[2]][0], C1 = members[big[2]][1];
+                run("three regions ((A0,B0), (B1,C0), (C1,A1))", {{A0, B0}, {B1, C0}, {C1, A1}});
+                if (big.size() >= 4) {
+                    const int D0 = members[big[3]][0], D1 = members[big[3]][1];
+                    run("four regions ((A0,B0), (B1,C0), (C1,D0), (D1,A1))", {{A0, B0}, {B1, C0}, {C1, D0}, {D1, A1}});
+                    run("four regions, w in A+C, acc in B+D ((A0,B0), (C0,D0))", {{A0, B0}, {C0, D0}});
+                }
+            }
+        }
+        return 0;
+    }
+    if (argc > 3 && argv[3][0] == 'p') {  // pads: both tables in ONE allocation, the second `pad` bytes behind the end of the first
+        float *blk;
+        const size_t maxpad = 3ull << 30;
+        CK(hipMalloc((void **)&blk, 2 * bytes + maxpad));
+        CK(hipMemset(blk, 0, 2 * bytes + maxpad));
+        const size_t pads[] = {0, 128, 256, 4096, 4096 + 128, 37 * 128, 65536, 65536 + 128 * 3, 1 << 20, (1 << 20) + 128 * 5, 2 << 20, (2 << 20) + 4096 + 128,
+                               16 << 20, (16 << 20) + 128 * 77, 1ull << 30, (1ull << 30) + 128 * 1237, (1ull << 30) + (1 << 20), 0x12345680ull, 0x7654300ull,
+                               3 * 4096, 5 * 65536, 7ull << 20, 11ull << 20, 513ull << 20, 1500ull << 20, 2047ull << 20};
+        for (size_t pad : pads) {
+            float *b2 = (float *)((char *)blk + bytes + pad);
+            const float t = time_ms([&] { hipLaunchKernelGGL(rmw_rows<true>, grid, block, 0, 0, blk, b2, lines, 600000u, 17u); }, 3);
+            printf("pad %12zu (0x%zx): %.3f ms\n", pad, pad, t);
+        }
+        const float t1 = time_ms([&] { hipLaunchKernelGGL(rmw_rows<true>, grid, block, 0, 0, blk, buf[0], lines, 600000u, 17u); }, 3);
+        const float t2 = time_ms([&] { hipLaunchKernelGGL(rmw_rows<true>, grid, block, 0, 0, blk, buf[K - 1], lines, 600000u, 17u); }, 3);
+        printf("block vs buffer 0: %.3f ms, vs buffer %d: %.3f ms\n", t1, K - 1, t2);
+        return 0;
+    }
     if (argc > 3) {  // scan: every buffer against a few reference buffers only
         for (int ref : {0, K / 3, (2 * K) / 3, K - 1}) {
             printf("vs buffer %2d:", ref);
