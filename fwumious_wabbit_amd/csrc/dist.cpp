@@ -488,6 +488,7 @@ int sparse_apply_side(fwgpu_dist *d, fwgpu_dist::SparseSide &s, bool ffm, const 
     a.tmp_bytes = d->sp_tmp_bytes;
     if (ffm) {
         a.R = s.width;
+        a.k4 = r->cfg.ffm_k % 4 == 0;
         a.w = r->d_ffm_w;
         a.acc = r->d_ffm_acc;
         a.rate = r->cfg.ffm_learning_rate;

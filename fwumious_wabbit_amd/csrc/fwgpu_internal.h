@@ -174,6 +174,7 @@ struct SparseApplyArgs {
     void *tmp;
     size_t tmp_bytes;
     uint32_t R;                       // 0: LR entries ({w, acc} pairs in `w`)
+    int32_t k4;                       // FFM: ffm_k % 4 == 0 (rows start on 16 B boundaries, a lane's float4 lies in one field slot)
     float *w, *acc;
     float rate, minus_power_t;
     const float *lut;

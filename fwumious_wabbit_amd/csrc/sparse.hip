@@ -130,6 +130,82 @@ __global__ __launch_bounds__(256) void sparse_reduce_ffm_kernel(const unsigned l
     }
 }
 
+// The same for rows of 16-byte aligned float4s (k % 4 == 0: every row starts on a 16 B boundary and a lane's four floats lie in one
+// field slot): one 16 B load per lane and occurrence instead of four 4 B loads.  Same arithmetic, same order.
+__global__ __launch_bounds__(256) void sparse_reduce_ffm4_kernel(const unsigned long long *keys, uint32_t n, const uint32_t *pos,
+                                                                 const uint2 *desc, uint32_t max_ffm, const float *split,
+                                                                 uint32_t split_len, const float *selfw, uint32_t selfw_stride,
+                                                                 const float *gbuf, uint32_t R, uint32_t k, uint32_t *bk_key,
+                                                                 float *bk_rows) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const uint32_t lane = threadIdx.x & 63, base = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 64;
+    if (base >= n) return;
+    const uint32_t i = base + lane;
+    const unsigned long long key = i < n ? keys[i] : kNoKey;
+    const bool valid = key != kNoKey;
+    const int cnt = __popcll(__ballot(valid));
+    if (!cnt) return;
+    const uint32_t m_h = (uint32_t)(key >> 32);
+    uint32_t m_ex = 0, m_ii = 0, m_f = 0, m_out = 0;
+    float m_v = 0.0f, m_g = 0.0f;
+    if (valid) {
+        const uint32_t slot = (uint32_t)key;
+        m_ex = slot / max_ffm;
+        m_ii = slot - m_ex * max_ffm;
+        const uint2 d = desc[slot];
+        m_v = __uint_as_float(d.x);
+        m_f = d.y;
+        m_g = gbuf[m_ex];
+        m_out = pos[i];
+    }
+    for (uint32_t c0 = 0; c0 < R; c0 += 256) {
+        const uint32_t e = c0 + lane * 4;  // this lane's four floats [e, e + 4)
+        const bool on = e < R;
+        const uint32_t z = e / k, kk = e - z * k;
+        f4 sum = {0.0f, 0.0f, 0.0f, 0.0f};
+        uint32_t cur_h = __shfl(m_h, 0, 64), cur_out = __shfl(m_out, 0, 64);
+        auto flush = [&]() {
+            if (on) *reinterpret_cast<f4 *>(bk_rows + (size_t)cur_out * R + e) = sum;
+            sum = f4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (lane == 0 && c0 == 0) bk_key[cur_out] = cur_h;
+        };
+        for (int t0 = 0; t0 < cnt; t0 += 4) {
+            f4 tv[4];
+            float sw[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int t = min(t0 + q, cnt - 1);
+                const uint32_t ex = __shfl(m_ex, t, 64), ii = __shfl(m_ii, t, 64), f = __shfl(m_f, t, 64);
+                const float *trow = split + (size_t)ex * split_len + f * R;
+                tv[q] = on ? *reinterpret_cast<const f4 *>(trow + e) : f4{0.0f, 0.0f, 0.0f, 0.0f};
+                const uint32_t es = f * k + (lane < k ? lane : 0);
+                sw[q] = (lane < k && es >= c0 && es < c0 + 256) ? selfw[(size_t)ex * selfw_stride + ii * k + lane] : 0.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int t = t0 + q;
+                if (t >= cnt) break;
+                const uint32_t h = __shfl(m_h, t, 64), f = __shfl(m_f, t, 64);
+                const float v = __shfl(m_v, t, 64), g = __shfl(m_g, t, 64);
+                if (h != cur_h) {
+                    flush();
+                    cur_h = h;
+                    cur_out = __shfl(m_out, t, 64);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float swx = __shfl(sw[q], (kk + j) & 63u, 64);  // (taken by all lanes)
+                    float x = tv[q][j];
+                    if (z == f) x = __fsub_rn(x, __fmul_rn(swx, v));  // block_ffm.rs:238
+                    const float G = __fmul_rn(v, x);                  // block_ffm.rs:239, 249
+                    sum[j] = __fadd_rn(sum[j], __fmul_rn(g, G));      // block_ffm.rs:278
+                }
+            }
+        }
+        flush();
+    }
+}
+
 // LR: one wave per 64 sorted occurrences (gradient = g * value, block_lr.rs:135-150).  Every lane fetches its own occurrence;
 // the run heads then add their run in order (lane broadcasts), so the sums do not depend on how the work is spread.
 __global__ __launch_bounds__(256) void sparse_reduce_lr_kernel(const unsigned long long *keys, uint32_t n, const uint32_t *pos,
@@ -226,6 +302,78 @@ __global__ __launch_bounds__(256) void sparse_apply_ffm_kernel(const unsigned lo
     }
 }
 
+// The same with 16 B accesses (k % 4 == 0): device-scope (sc1) buffer loads / stores of float4, as the example kernels use.
+// One wave per 64 consecutive elements of the merged list: the lanes find the block heads of this parity among them, the wave then
+// applies those blocks one after the other (a launch with one wave per ELEMENT spends most of its time starting waves that exit).
+template <int OPT>
+__global__ __launch_bounds__(256) void sparse_apply_ffm4_kernel(const unsigned long long *keys, uint32_t n, const float *rows,
+                                                                uint32_t R, uint32_t parity, float *ffm_w, float *ffm_acc,
+                                                                float rate, float minus_power_t, const float *lut) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const uint32_t lane = threadIdx.x & 63, base = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 64;
+    if (base >= n) return;
+    const uint32_t i = base + lane;
+    bool head = false;
+    if (i < n) {
+        const unsigned long long ki = keys[i];
+        if (ki != kNoKey) {
+            const uint32_t blk = (uint32_t)(ki >> 32) / R;
+            head = (blk & 1u) == parity && (i == 0 || (uint32_t)(keys[i - 1] >> 32) / R != blk);
+        }
+    }
+    unsigned long long heads = __ballot(head);
+    while (heads) {
+        const uint32_t first = (uint32_t)__builtin_ctzll(heads);
+        heads &= heads - 1;
+        uint32_t j = base + first;
+        const uint32_t blk = (uint32_t)(keys[j] >> 32) / R;
+        while (j < n) {
+            const unsigned long long kj = keys[j];
+            if (kj == kNoKey) break;
+            const uint32_t h = (uint32_t)(kj >> 32);
+            if (h / R != blk) break;
+            uint32_t j2 = j + 1;
+            while (j2 < n && (uint32_t)(keys[j2] >> 32) == h) ++j2;
+            __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(ffm_w + h, 0, (int)(R * 4), 0x00020000);
+            __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(ffm_acc + h, 0, (int)(R * 4), 0x00020000);
+            for (uint32_t c0 = 0; c0 < R; c0 += 256) {
+                const uint32_t e = c0 + lane * 4;
+                const bool on = e < R;
+                // (the table loads do not depend on the bucket rows: issued first, they overlap them)
+                f4 w = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(e * 4), 0, 16));
+                f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (OPT != FWGPU_OPT_SGD) acc = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(e * 4), 0, 16));
+                f4 G = {0.0f, 0.0f, 0.0f, 0.0f};
+                for (uint32_t t = j; t < j2; ++t) {
+                    const float *row = rows + (size_t)(uint32_t)keys[t] * R;
+                    const f4 x = on ? *reinterpret_cast<const f4 *>(row + e) : f4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) G[q] = __fadd_rn(G[q], x[q]);
+                }
+                // (lanes beyond the row read zeros and their stores are dropped: raw buffer of 4R bytes)
+                bool any = false;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (G[q] != 0.0f) {  // (a zero gradient changes nothing in any of the optimizers)
+                        float a = acc[q];
+                        const float upd = opt_step<OPT>(G[q], a, rate, minus_power_t, lut);
+                        acc[q] = a;
+                        w[q] = w[q] - upd;  // block_ffm.rs:282
+                        any = true;
+                    }
+                }
+                if (on && any) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, w), rw, (int)(e * 4), 0, 16);
+                    if (OPT != FWGPU_OPT_SGD) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc), ra, (int)(e * 4), 0, 16);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next row of the block may overlap this one (see the scalar kernel)
+            j = j2;
+        }
+    }
+}
+
 // LR apply: one thread per element; the thread of a hash's first element sums the run and takes the step.
 template <int OPT>
 __global__ void sparse_apply_lr_kernel(const unsigned long long *keys, uint32_t n, const float *vals, float *lr, float rate,
@@ -277,8 +425,12 @@ hipError_t sparse_reduce(const SparseReduceArgs &a, hipStream_t stream) {
     if (e != hipSuccess) return e;
     const uint32_t blocks64 = (a.n + 63) / 64;
     if (a.R) {
-        hipLaunchKernelGGL(sparse_reduce_ffm_kernel, dim3((blocks64 + 3) / 4), dim3(256), 0, stream, a.keys_sorted, a.n, a.pos, a.desc,
-                           a.max_entries, a.split, a.split_len, a.selfw, a.selfw_stride, a.gbuf, a.R, a.k, a.bk_key, a.bk_rows);
+        if (a.k % 4 == 0 && a.split_len % 4 == 0)
+            hipLaunchKernelGGL(sparse_reduce_ffm4_kernel, dim3((blocks64 + 3) / 4), dim3(256), 0, stream, a.keys_sorted, a.n, a.pos, a.desc,
+                               a.max_entries, a.split, a.split_len, a.selfw, a.selfw_stride, a.gbuf, a.R, a.k, a.bk_key, a.bk_rows);
+        else
+            hipLaunchKernelGGL(sparse_reduce_ffm_kernel, dim3((blocks64 + 3) / 4), dim3(256), 0, stream, a.keys_sorted, a.n, a.pos, a.desc,
+                               a.max_entries, a.split, a.split_len, a.selfw, a.selfw_stride, a.gbuf, a.R, a.k, a.bk_key, a.bk_rows);
     } else {
         hipLaunchKernelGGL(sparse_reduce_lr_kernel, dim3((blocks64 + 3) / 4), dim3(256), 0, stream, a.keys_sorted, a.n, a.pos, a.desc,
                            a.max_entries, a.gbuf, a.bk_key, a.bk_rows);
@@ -299,8 +451,12 @@ static hipError_t sparse_apply_t(const SparseApplyArgs &a, hipStream_t stream) {
     }
     if (a.R) {
         for (uint32_t parity = 0; parity < 2; ++parity)
-            hipLaunchKernelGGL(sparse_apply_ffm_kernel<OPT>, dim3((n + 3) / 4), dim3(256), 0, stream, a.keys_sorted, n, a.all_rows, a.R, parity,
-                               a.w, a.acc, a.rate, a.minus_power_t, a.lut);
+            if (a.k4)
+                hipLaunchKernelGGL(sparse_apply_ffm4_kernel<OPT>, dim3(((n + 63) / 64 + 3) / 4), dim3(256), 0, stream, a.keys_sorted, n, a.all_rows, a.R, parity,
+                                   a.w, a.acc, a.rate, a.minus_power_t, a.lut);
+            else
+                hipLaunchKernelGGL(sparse_apply_ffm_kernel<OPT>, dim3((n + 3) / 4), dim3(256), 0, stream, a.keys_sorted, n, a.all_rows, a.R, parity,
+                                   a.w, a.acc, a.rate, a.minus_power_t, a.lut);
     } else {
         hipLaunchKernelGGL(sparse_apply_lr_kernel<OPT>, dim3((n + 255) / 256), dim3(256), 0, stream, a.keys_sorted, n, a.all_rows, a.w, a.rate,
                            a.minus_power_t, a.lut);
