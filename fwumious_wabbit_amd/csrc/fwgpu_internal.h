@@ -228,6 +228,15 @@ struct fwgpu_batch {
     uint64_t n_words = 0;
     uint64_t words_cap = 0;
     uint32_t n_cap = 0;
+    // single-request batches (serving.cpp): records / offsets / predictions live in host memory mapped into the device's
+    // address space (the kernel reads the request and writes the prediction over PCIe: no copy calls), and every launch takes
+    // the next counter of a zeroed ring instead of a memset of `work`
+    void *host_block = nullptr;
+    uint32_t *h_records = nullptr;
+    uint64_t *h_rec_off = nullptr;
+    float *h_pred = nullptr;
+    uint32_t *work_ring = nullptr;
+    uint32_t work_next = 0;
     void *tr_dev = nullptr;  // device blob holding the DevTranslator arrays
     fwgpu::DevTranslator tr{};
 };
@@ -298,7 +307,10 @@ int check_translator(const fwgpu_regressor *r, const fwgpu_translator_config *t)
 int count_record(const fwgpu_translator_config *t, const uint32_t *rec, uint32_t rec_len, uint32_t *n_lr, uint32_t *n_ffm);
 // device-resident raw-record batch (translation happens inside the example kernel)
 int record_batch_alloc(fwgpu_regressor *r, const fwgpu_translator_config *t, uint32_t n_cap, uint64_t words_cap,
-                       fwgpu_batch **out);
+                       fwgpu_batch **out, bool host_mapped = false);
+// next launch of a host-mapped batch: points b->work at a fresh zero counter (re-zeroing the ring when it wraps)
+int mapped_batch_next_counter(fwgpu_batch *b, hipStream_t stream);
+constexpr uint32_t kWorkRing = 1024;
 struct RecordStats {  // what the host learns about a slice of records without translating them
     uint32_t max_lr = 0, max_ffm = 0, max_rec = 0;
     uint64_t tot_lr = 0, tot_ffm = 0;

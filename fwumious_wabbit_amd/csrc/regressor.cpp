@@ -130,8 +130,18 @@ int batch_alloc(fwgpu_regressor *r, uint32_t n, uint64_t n_lr, uint64_t n_ffm, f
 
 static size_t up256b(size_t x) { return (x + 255) & ~(size_t)255; }
 
+int mapped_batch_next_counter(fwgpu_batch *b, hipStream_t stream) {
+    if (!b->work_ring) return fail(FWGPU_ERR_INVALID, "not a host-mapped batch");
+    if (b->work_next == kWorkRing) {  // every counter has been used once (a 1-example launch leaves 2 in its counter)
+        FWGPU_HIP(hipMemsetAsync(b->work_ring, 0, kWorkRing * sizeof(uint32_t), stream));
+        b->work_next = 0;
+    }
+    b->work = b->work_ring + b->work_next++;
+    return FWGPU_OK;
+}
+
 int record_batch_alloc(fwgpu_regressor *r, const fwgpu_translator_config *t, uint32_t n_cap, uint64_t words_cap,
-                       fwgpu_batch **out) {
+                       fwgpu_batch **out, bool host_mapped) {
     int rc = check_translator(r, t);
     if (rc) return rc;
     if (t->n_fields > 255) return fail(FWGPU_ERR_INVALID, "translator: more than 255 fields");
@@ -146,9 +156,24 @@ int record_batch_alloc(fwgpu_regressor *r, const fwgpu_translator_config *t, uin
     const size_t o_off = o; o = up256b(o + 8 * ((size_t)n_cap + 1));
     const size_t o_pred = o; o = up256b(o + 4 * (size_t)n_cap);
     b->dev_bytes = std::max<size_t>(o, 256);
-    FWGPU_HIP(hipMalloc(&b->dev, b->dev_bytes));
-    FWGPU_HIP(hipMalloc((void **)&b->work, 64));
-    unsigned char *base = static_cast<unsigned char *>(b->dev);
+    unsigned char *base = nullptr;
+    if (host_mapped) {
+        FWGPU_HIP(hipHostMalloc(&b->host_block, b->dev_bytes, hipHostMallocMapped | hipHostMallocCoherent));
+        void *dv = nullptr;
+        FWGPU_HIP(hipHostGetDevicePointer(&dv, b->host_block, 0));
+        base = static_cast<unsigned char *>(dv);
+        unsigned char *hb = static_cast<unsigned char *>(b->host_block);
+        b->h_records = reinterpret_cast<uint32_t *>(hb + o_rec);
+        b->h_rec_off = reinterpret_cast<uint64_t *>(hb + o_off);
+        b->h_pred = reinterpret_cast<float *>(hb + o_pred);
+        FWGPU_HIP(hipMalloc((void **)&b->work_ring, kWorkRing * sizeof(uint32_t)));
+        FWGPU_HIP(hipMemset(b->work_ring, 0, kWorkRing * sizeof(uint32_t)));
+        b->work = b->work_ring;
+    } else {
+        FWGPU_HIP(hipMalloc(&b->dev, b->dev_bytes));
+        FWGPU_HIP(hipMalloc((void **)&b->work, 64));
+        base = static_cast<unsigned char *>(b->dev);
+    }
     b->records = reinterpret_cast<uint32_t *>(base + o_rec);
     b->rec_off = reinterpret_cast<uint64_t *>(base + o_off);
     b->pred = reinterpret_cast<float *>(base + o_pred);
@@ -384,7 +409,13 @@ static int run_batch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, h
     int rc = prepare_launch(r, b, mode, update, p, threads);
     if (rc) return rc;
     const uint32_t grid = pick_grid(r, p, mode, threads);
-    FWGPU_HIP(hipMemsetAsync(b->work, 0, sizeof(uint32_t), stream));
+    if (b->work_ring) {
+        rc = mapped_batch_next_counter(b, stream);
+        if (rc) return rc;
+        p.work = b->work;
+    } else {
+        FWGPU_HIP(hipMemsetAsync(b->work, 0, sizeof(uint32_t), stream));
+    }
     // An updating launch always uses device-scope (sc1) accesses; read-only launches use cached loads.
     FWGPU_HIP(launch_example_kernel(p, r->cfg.optimizer, update != 0, grid, threads, stream));
     return FWGPU_OK;
@@ -1039,7 +1070,11 @@ int fwgpu_batch_free(fwgpu_batch *b) {
     if (!b) return FWGPU_OK;
     if (b->dev) (void)hipFree(b->dev);
     if (b->tr_dev) (void)hipFree(b->tr_dev);
-    if (b->work) (void)hipFree(b->work);
+    if (b->host_block) (void)hipHostFree(b->host_block);
+    if (b->work_ring)
+        (void)hipFree(b->work_ring);
+    else if (b->work)
+        (void)hipFree(b->work);
     delete b;
     return FWGPU_OK;
 }

@@ -31,8 +31,10 @@ struct SharedModel {  // what clone_lite shares: the immutable regressor and the
     fwgpu_translator_config tr{};
     std::mutex mu;  // the regressor's single-example staging buffers are shared
     fwgpu_batch *batch = nullptr;  // device buffers of fwgpu_predictor_predict_batch, grown on demand and reused
+    fwgpu_batch *one = nullptr;    // single requests: a host-mapped batch (no copy calls, no memset: launch + one synchronisation)
     ~SharedModel() {
         if (batch) fwgpu_batch_free(batch);
+        if (one) fwgpu_batch_free(one);
         if (re) fwgpu_free(re);
         if (vw) fwgpu_vwmap_free(vw);
         if (mi) fwgpu_mi_free(mi);
@@ -117,17 +119,33 @@ float predict_line(FfiPredictor *p, const char *prefix, size_t prefix_len, const
             return kExceptionErrorCode;
         return out;
     }
-    if (!m.batch || m.batch->words_cap < n_words) {
-        if (m.batch) fwgpu_batch_free(m.batch);
-        m.batch = nullptr;
-        if (record_batch_alloc(m.re, &m.tr, 256, std::max<uint64_t>(2 * (uint64_t)n_words, 1 << 16), &m.batch) != FWGPU_OK) return kExceptionErrorCode;
+    // The request goes into host memory the device has mapped; the kernel reads it over PCIe in its stage phase and writes the
+    // prediction back the same way.  Per call: one kernel launch and one synchronisation (before: two copies in, a memset, the
+    // launch, a copy out and the synchronisation).
+    if (!m.one || m.one->words_cap < n_words) {
+        if (m.one) fwgpu_batch_free(m.one);
+        m.one = nullptr;
+        if (record_batch_alloc(m.re, &m.tr, 1, std::max<uint64_t>(2 * (uint64_t)n_words, 1 << 14), &m.one, /*host_mapped=*/true) != FWGPU_OK)
+            return kExceptionErrorCode;
     }
-    const uint64_t off[2] = {0, n_words};
-    if (record_batch_upload(m.batch, &m.tr, p->record.data(), off, 1, 0) != FWGPU_OK) return kExceptionErrorCode;
-    if (fwgpu_learn_batch(m.re, m.batch, FWGPU_MODE_SEQUENTIAL, /*update=*/0, nullptr) != FWGPU_OK) return kExceptionErrorCode;
-    float out = 0.0f;
-    if (fwgpu_batch_predictions(m.batch, &out, 1, nullptr) != FWGPU_OK) return kExceptionErrorCode;
-    return out;
+    fwgpu_batch *b = m.one;
+    uint32_t c_lr = 0, c_ffm = 0;
+    if (count_record(&m.tr, p->record.data(), n_words, &c_lr, &c_ffm) != FWGPU_OK) return kExceptionErrorCode;  // validates the record
+    std::memcpy(b->h_records, p->record.data(), (size_t)n_words * 4);
+    b->h_rec_off[0] = 0;
+    b->h_rec_off[1] = n_words;
+    b->n = 1;
+    b->n_lr = c_lr;
+    b->n_ffm = c_ffm;
+    b->n_words = n_words;
+    b->max_lr = m.re->cfg.wiring == FWGPU_WIRING_FFM_ONLY ? 0 : c_lr;
+    b->max_ffm = c_ffm;
+    b->max_rec = n_words;
+    b->aligned4 = true;
+    b->h_pred[0] = kExceptionErrorCode;  // (a launch that processed nothing must not return the previous request's answer)
+    if (fwgpu_learn_batch(m.re, b, FWGPU_MODE_SEQUENTIAL, /*update=*/0, nullptr) != FWGPU_OK) return kExceptionErrorCode;
+    if (hipStreamSynchronize(nullptr) != hipSuccess) return kExceptionErrorCode;
+    return b->h_pred[0];
 }
 
 }  // namespace

@@ -52,6 +52,12 @@ for name, fn in (("concatenation (whole lines, device translation)", lambda: pr.
     for _ in range(5):
         t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
     print(f"text route, {name}: {np.median(ts) * 1e3:.2f} ms per request = {N / np.median(ts):,.0f} candidates/s")
+enc = [t.encode() for t in full[:300]]
+pr.L.fw_predict(pr.p, enc[0])
+t0 = time.perf_counter()
+for t in enc:
+    pr.L.fw_predict(pr.p, t)
+print(f"fw_predict, one whole line per call: {(time.perf_counter() - t0) / 300 * 1e6:.0f} us per call")
 t0 = time.perf_counter()
 for c in cands[:300]:
     pr.predict_with_cache(c)

@@ -305,3 +305,20 @@ def test_trainer_digests_a_cache_file_natively(tmp_path):
         assert abs(gpu_hold - ref_hold) < 0.03, (gpu_hold, ref_hold)
         for x in (c, tr, re, hb):
             x.close()
+
+
+def test_fw_predict_many_calls_reuse_the_mapped_request_buffer(tmp_path):
+    """fw_predict keeps the request in device-mapped host memory and takes a fresh work counter from a ring of 1024 per launch:
+    2500 calls (the ring wraps twice) alternating between lines of different lengths all return their own prediction"""
+    from fwumious_wabbit_amd.serving import Predictor
+    vw = VwNamespaceMap(VW6)
+    mi, re, recs, off = _trained(fw.Optimizer.AdagradLUT, seed=63)
+    path = str(tmp_path / "model.fw")
+    P.save_regressor_to_filename(path, mi, vw, re)
+    pr = Predictor(f"fw -i {path} -t --foreground")
+    lines = ["|A0 1 2 |A1 5\n", "|A2 7 |A3 9:0.5 |A0 3 |A5 1 2 3 4 5 6 7\n", "|A4 11\n"]
+    want = pr.predict_batch(lines)
+    assert len(set(want.tolist())) == 3
+    for i in range(2500):
+        assert pr.predict(lines[i % 3]) == want[i % 3], i
+    pr.close()
