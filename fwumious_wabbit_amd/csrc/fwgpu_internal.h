@@ -232,6 +232,7 @@ struct fwgpu_batch {
     // address space (the kernel reads the request and writes the prediction over PCIe: no copy calls), and every launch takes
     // the next counter of a zeroed ring instead of a memset of `work`
     void *host_block = nullptr;
+    ptrdiff_t host_delta = 0;  // host address of a mapped array = its device address + host_delta
     uint32_t *h_records = nullptr;
     uint64_t *h_rec_off = nullptr;
     float *h_pred = nullptr;
@@ -295,7 +296,7 @@ struct HostBatch {  // SoA staging of a CSR batch on the host
     void clear();
     uint32_t size() const { return (uint32_t)label.size(); }
 };
-int batch_alloc(fwgpu_regressor *r, uint32_t n, uint64_t n_lr, uint64_t n_ffm, fwgpu_batch **out);
+int batch_alloc(fwgpu_regressor *r, uint32_t n, uint64_t n_lr, uint64_t n_ffm, fwgpu_batch **out, bool host_mapped = false);
 int batch_upload(fwgpu_batch *b, const HostBatch &hb, hipStream_t stream);
 int append_example(const fwgpu_regressor *r, HostBatch &hb, const fwgpu_lr_entry *lr, uint32_t n_lr,
                    const fwgpu_ffm_entry *ffm, uint32_t n_ffm, float label, float importance);

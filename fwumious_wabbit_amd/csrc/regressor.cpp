@@ -90,7 +90,7 @@ int append_example(const fwgpu_regressor *r, HostBatch &hb, const fwgpu_lr_entry
 
 static size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-int batch_alloc(fwgpu_regressor *r, uint32_t n, uint64_t n_lr, uint64_t n_ffm, fwgpu_batch **out) {
+int batch_alloc(fwgpu_regressor *r, uint32_t n, uint64_t n_lr, uint64_t n_ffm, fwgpu_batch **out, bool host_mapped) {
     std::unique_ptr<fwgpu_batch> b(new fwgpu_batch());
     b->owner = r;
     b->n = n;
@@ -110,9 +110,23 @@ int batch_alloc(fwgpu_regressor *r, uint32_t n, uint64_t n_lr, uint64_t n_ffm, f
     off[10] = o; o = up256(o + 2 * n_lr);
     b->dev_bytes = std::max<size_t>(o, 256);
     FWGPU_HIP(hipSetDevice(r->device));
-    FWGPU_HIP(hipMalloc(&b->dev, b->dev_bytes));
-    FWGPU_HIP(hipMalloc((void **)&b->work, 64));
-    unsigned char *base = static_cast<unsigned char *>(b->dev);
+    unsigned char *base = nullptr;
+    if (host_mapped) {
+        // single-example batches (fwgpu_learn / fwgpu_predict / predict_with_cache): the entries live in host memory the device
+        // has mapped; the kernel's stage phase reads them over PCIe and the prediction comes back the same way -- no copy calls
+        FWGPU_HIP(hipHostMalloc(&b->host_block, b->dev_bytes, hipHostMallocMapped | hipHostMallocCoherent));
+        void *dv = nullptr;
+        FWGPU_HIP(hipHostGetDevicePointer(&dv, b->host_block, 0));
+        base = static_cast<unsigned char *>(dv);
+        b->host_delta = static_cast<unsigned char *>(b->host_block) - base;
+        FWGPU_HIP(hipMalloc((void **)&b->work_ring, kWorkRing * sizeof(uint32_t)));
+        FWGPU_HIP(hipMemset(b->work_ring, 0, kWorkRing * sizeof(uint32_t)));
+        b->work = b->work_ring;
+    } else {
+        FWGPU_HIP(hipMalloc(&b->dev, b->dev_bytes));
+        FWGPU_HIP(hipMalloc((void **)&b->work, 64));
+        base = static_cast<unsigned char *>(b->dev);
+    }
     b->ffm_hash = reinterpret_cast<uint32_t *>(base + off[0]);
     b->ffm_val = reinterpret_cast<float *>(base + off[1]);
     b->ffm_fld = reinterpret_cast<uint8_t *>(base + off[2]);
@@ -279,9 +293,13 @@ int batch_upload(fwgpu_batch *b, const HostBatch &hb, hipStream_t stream) {
     const uint32_t n = hb.size();
     if (n > b->n || hb.ffm_hash.size() > b->n_ffm || hb.lr_hash.size() > b->n_lr)
         return fail(FWGPU_ERR_RANGE, "batch_upload: host batch larger than the device allocation");
-#define UP(dst, vec)                                                                                          \
-    if (!(vec).empty())                                                                                       \
-    FWGPU_HIP(hipMemcpyAsync((dst), (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice, stream))
+#define UP(dst, vec)                                                                                              \
+    if (!(vec).empty()) {                                                                                         \
+        if (b->host_block)                                                                                        \
+            memcpy(reinterpret_cast<unsigned char *>(dst) + b->host_delta, (vec).data(), (vec).size() * sizeof((vec)[0])); \
+        else                                                                                                      \
+            FWGPU_HIP(hipMemcpyAsync((dst), (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice, stream)); \
+    }
     UP(b->ffm_hash, hb.ffm_hash);
     UP(b->ffm_val, hb.ffm_val);
     UP(b->ffm_fld, hb.ffm_fld);
@@ -740,7 +758,14 @@ static int ensure_one(fwgpu_regressor *r, uint32_t n_lr, uint32_t n_ffm) {
         fwgpu_batch_free(r->one);
         r->one = nullptr;
     }
-    return batch_alloc(r, 1, std::max<uint32_t>(n_lr * 2, 256), std::max<uint32_t>(n_ffm * 2, 256), &r->one);
+    return batch_alloc(r, 1, std::max<uint32_t>(n_lr * 2, 256), std::max<uint32_t>(n_ffm * 2, 256), &r->one, /*host_mapped=*/true);
+}
+
+// the single example's prediction, once the launch has finished
+static int one_prediction(fwgpu_regressor *r, float *prediction) {
+    FWGPU_HIP(hipStreamSynchronize(0));
+    *prediction = *reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(r->one->pred) + r->one->host_delta);
+    return FWGPU_OK;
 }
 
 static int learn_one(fwgpu_regressor *r, const fwgpu_lr_entry *lr, uint32_t n_lr, const fwgpu_ffm_entry *ffm,
@@ -758,8 +783,7 @@ static int learn_one(fwgpu_regressor *r, const fwgpu_lr_entry *lr, uint32_t n_lr
     if (rc) return rc;
     rc = run_batch(r, r->one, FWGPU_MODE_SEQUENTIAL, update, 0);
     if (rc) return rc;
-    FWGPU_HIP(hipMemcpy(prediction, r->one->pred, sizeof(float), hipMemcpyDeviceToHost));
-    return FWGPU_OK;
+    return one_prediction(r, prediction);
 }
 
 int fwgpu_learn(fwgpu_regressor *r, const fwgpu_lr_entry *lr, uint32_t n_lr, const fwgpu_ffm_entry *ffm, uint32_t n_ffm,
@@ -995,8 +1019,7 @@ int fwgpu_setup_cache(fwgpu_regressor *r, const fwgpu_lr_entry *lr, uint32_t n_l
         rc = run_batch(r, r->one, FWGPU_MODE_SEQUENTIAL, 0, 0);
         r->one->emit_T = r->one->emit_dcf = nullptr;
     }
-    if (rc == FWGPU_OK && hipMemcpy(&pred, r->one->pred, sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
-        rc = fail(FWGPU_ERR_DEVICE, "setup_cache: launch failed");
+    if (rc == FWGPU_OK && one_prediction(r, &pred) != FWGPU_OK) rc = fail(FWGPU_ERR_DEVICE, "setup_cache: launch failed");
     if (rc != FWGPU_OK) {
         if (!*cache) {
             (void)hipFree(c->d_T);
@@ -1052,8 +1075,7 @@ int fwgpu_predict_with_cache(fwgpu_regressor *r, const fwgpu_block_cache *c, con
     rc = run_batch(r, r->one, FWGPU_MODE_SEQUENTIAL, 0, 0);
     r->one->cache = nullptr;
     if (rc) return rc;
-    FWGPU_HIP(hipMemcpy(prediction, r->one->pred, sizeof(float), hipMemcpyDeviceToHost));
-    return FWGPU_OK;
+    return one_prediction(r, prediction);
 }
 
 // Predict-only launches of this batch start every example's field sums from the cache (NULL detaches it): the batch must
