@@ -196,8 +196,8 @@ def main():
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=None,
-                    help="examples per step per GPU (default 65536; --dp-mode sharded: 2048 / n_gpus, --dp-mode sparse: 8192 / n_gpus; the synchronous step is stable "
-                         "up to a GLOBAL micro-batch of ~2048 examples at these hyper-parameters, profiles/r02_sync_batch_stability.txt)")
+                    help="examples per step per GPU (default 65536; --dp-mode sharded: 1024 / n_gpus, --dp-mode sparse: 8192 / n_gpus; the synchronous step is stable "
+                         "up to a GLOBAL micro-batch of ~1024 examples at these hyper-parameters: 2048 degrades and diverges in longer runs, profiles/r02_sync_batch_stability.txt, r02_group_modes.txt)")
     ap.add_argument("--fields", type=int, default=30)
     ap.add_argument("--k", type=int, default=8)
     ap.add_argument("--bits", type=int, default=28)
@@ -282,9 +282,9 @@ def main():
 
     sync_steps = args.sync or (args.nn_layers > 0 and args.head == "minibatch")
     if args.batch is None:
-        # synchronous micro-batches are stable up to ~2048 examples at these hyper-parameters (profiles/r02_sync_batch_stability.txt)
-        args.batch = (max(64, 2048 // world) if (use_dist and args.dp_mode == "sharded") else
-                      max(256, 8192 // world) if (use_dist and args.dp_mode == "sparse") else (2048 if sync_steps else 65536))
+        # synchronous micro-batches with per-occurrence steps are stable up to ~1024 examples at these hyper-parameters (profiles/r02_sync_batch_stability.txt)
+        args.batch = (max(64, 1024 // world) if (use_dist and args.dp_mode == "sharded") else
+                      max(256, 8192 // world) if (use_dist and args.dp_mode == "sparse") else (1024 if sync_steps else 65536))
     K, W, B = args.steps, args.warmup, args.batch
     # every rank trains on its own shard of the stream: examples [rank*(W+K)*B, ...)
     t0 = time.time()
@@ -470,7 +470,7 @@ def main():
         for x in pb:
             x.close()
         del precs_
-        Ks, Bs = min(K, 24), max(64, 2048 // world)  # global synchronous micro-batch of 2048 examples (stability limit, see --batch)
+        Ks, Bs = min(K, 48), max(64, 1024 // world)  # global synchronous micro-batch of 1024 examples (2048 is already marginal, see --batch)
         srecs, soff = gen_records(fw, args, 2_000_000_000 + rank * Ks * Bs, Ks * Bs)
         sb = [re.record_batch(fbt, srecs[int(soff[j * Bs]):int(soff[(j + 1) * Bs])], soff[j * Bs:(j + 1) * Bs + 1] - soff[j * Bs]) for j in range(Ks)]
         dist_rank.learn_sharded_batch(fbt, sb[0])  # warm-up: buffers, communicator channels

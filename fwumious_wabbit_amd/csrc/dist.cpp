@@ -26,6 +26,9 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -878,8 +881,10 @@ int fwgpu_dist_group_learn_sparse(fwgpu_dist_group *g, const fwgpu_translator_co
     int rc;
     for (int j = 0; j < N; j++)
         if ((rc = sparse_begin(g->ranks[j].get(), t, records[j], rec_off[j], n[j], nullptr, &shapes[4 * j]))) return rc;
-    for (int j = 0; j < N; j++)
+    for (int j = 0; j < N; j++) {
         if ((rc = sparse_local(g->ranks[j].get(), shapes.data()))) return rc;
+        FWGPU_HIP(hipStreamSynchronize(g->ranks[j]->stream));  // (one rank at a time: see below)
+    }
     std::vector<uint32_t> counts((size_t)2 * N);
     for (int j = 0; j < N; j++) {
         fwgpu_dist *d = g->ranks[j].get();
@@ -915,6 +920,9 @@ int fwgpu_dist_group_learn_sparse(fwgpu_dist_group *g, const fwgpu_translator_co
             fwgpu_dist::SparseSide &s = side == 0 ? dst->sf : dst->sl;
             if (!s.occ_cap) continue;
             if ((rc = sparse_apply_side(dst, s, side == 0, s.all_key, s.all_rows, s.flags, (uint32_t)N, stride))) return rc;
+            // the ranks of an in-process group share one GPU: their phases run one after the other (the group exists for tests and
+            // single-box emulation; with concurrent rank streams the step was observed to be non-reproducible on some boxes)
+            FWGPU_HIP(hipStreamSynchronize(dst->stream));
         }
     }
     for (int j = 0; j < N; j++) {

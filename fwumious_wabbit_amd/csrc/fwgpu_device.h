@@ -18,7 +18,9 @@ __device__ __forceinline__ float opt_step(float grad, float &acc, float rate, fl
     } else {  // optimizer.rs:147-156
         float na = __fadd_rn(acc, __fmul_rn(grad, grad));
         acc = na;
-        uint32_t key = __float_as_uint(na) >> (31 - kLutBits);
+        // (a diverged model can put a NaN with the sign bit set here, whose key would index past the 2048-entry table: the
+        // reference's bounds check panics at that point, optimizer.rs:152; this stays inside the table and goes on with NaNs)
+        uint32_t key = (__float_as_uint(na) >> (31 - kLutBits)) & (uint32_t)(kLutSize - 1);
         return __fmul_rn(grad, lut[key]);
     }
 }

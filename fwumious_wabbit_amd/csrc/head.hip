@@ -209,7 +209,7 @@ __global__ void head_apply_kernel(float *__restrict__ w, float *__restrict__ acc
                 upd = __fmul_rn(__fmul_rn(g, rate), powf(na, minus_power_t));
                 if (isnan(upd) || isinf(upd)) upd = 0.0f;
             } else {
-                upd = __fmul_rn(g, lut[__float_as_uint(na) >> (31 - kLutBits)]);
+                upd = __fmul_rn(g, lut[(__float_as_uint(na) >> (31 - kLutBits)) & (uint32_t)(kLutSize - 1)]);  // (masked: see opt_step)
             }
         }
         w[i] -= upd;

@@ -61,7 +61,9 @@ float fwo_step_lut(const float *lut, float g, float *acc) {
     float gradient_squared = g * g;
     float new_acc = *acc + gradient_squared;
     *acc = new_acc;
-    uint32_t key = f2u(new_acc) >> (31 - FWO_LUT_BITS);
+    /* (a NaN with the sign bit set -- a diverged model -- would index past the table: the reference's bounds check panics there,
+     * the restatement stays inside the table like the library does) */
+    uint32_t key = (f2u(new_acc) >> (31 - FWO_LUT_BITS)) & (uint32_t)(FWO_LUT_SIZE - 1);
     return g * lut[key];
 }
 
