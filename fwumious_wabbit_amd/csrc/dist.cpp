@@ -883,7 +883,15 @@ int fwgpu_dist_group_learn_sparse(fwgpu_dist_group *g, const fwgpu_translator_co
         if ((rc = sparse_begin(g->ranks[j].get(), t, records[j], rec_off[j], n[j], nullptr, &shapes[4 * j]))) return rc;
     for (int j = 0; j < N; j++) {
         if ((rc = sparse_local(g->ranks[j].get(), shapes.data()))) return rc;
-        FWGPU_HIP(hipStreamSynchronize(g->ranks[j]->stream));  // (one rank at a time: see below)
+        // One rank's local phase at a time.  With all ranks' FWD / MID / sort / reduce work enqueued at once on their streams the step
+        // was not reproducible at full table size and faulted once in ten runs (scripts/group_repro.py with FWGPU_GROUP_CONCURRENT=local);
+        // any single host synchronisation inside the local phase, or this one after it, makes it exact again.  Every buffer is per
+        // rank and every dependency is ordered on the rank's stream, so this looks like a runtime limit with that many kernels of
+        // that many streams in flight rather than a data race of the step; the RCCL path has one rank per process.
+        {
+            const char *cc = std::getenv("FWGPU_GROUP_CONCURRENT");  // (debug switch: "local" / "apply" / "all" bring the overlap back)
+            if (!(cc && (cc[0] == 'l' || (cc[0] == 'a' && cc[1] == 'l')))) FWGPU_HIP(hipStreamSynchronize(g->ranks[j]->stream));
+        }
     }
     std::vector<uint32_t> counts((size_t)2 * N);
     for (int j = 0; j < N; j++) {
@@ -922,7 +930,10 @@ int fwgpu_dist_group_learn_sparse(fwgpu_dist_group *g, const fwgpu_translator_co
             if ((rc = sparse_apply_side(dst, s, side == 0, s.all_key, s.all_rows, s.flags, (uint32_t)N, stride))) return rc;
             // the ranks of an in-process group share one GPU: their phases run one after the other (the group exists for tests and
             // single-box emulation; with concurrent rank streams the step was observed to be non-reproducible on some boxes)
-            FWGPU_HIP(hipStreamSynchronize(dst->stream));
+            {
+                const char *cc = std::getenv("FWGPU_GROUP_CONCURRENT");
+                if (!(cc && cc[0] == 'a')) FWGPU_HIP(hipStreamSynchronize(dst->stream));
+            }
         }
     }
     for (int j = 0; j < N; j++) {
