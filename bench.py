@@ -224,6 +224,10 @@ def main():
     ap.add_argument("--sync-every", dest="sync_every", type=int, default=0, help="N>1: steps between delta all-reduces")
     ap.add_argument("--combine", choices=["mean", "sum"], default="mean",
                     help="N>1: the agreed model moves by the mean (default) or the sum of the replicas' deltas")
+    ap.add_argument("--no-other-modes", dest="other_modes", action="store_false",
+                    help="N>1 replica run: skip the short sparse / sharded legs that are reported as dp_modes")
+    ap.add_argument("--other-modes-timeout", dest="other_modes_timeout", type=float, default=240.0,
+                    help="seconds after which the dp_modes legs are given up and the line is printed without them")
     ap.add_argument("--dp-mode", dest="dp_mode", choices=["replica", "sharded", "sparse"], default="replica",
                     help="N>1: 'replica' = full replicas + overlapped RCCL all-reduce of the table deltas every --sync-every steps "
                          "(the timed mode of a multi-GPU run); 'sharded' = owner-sharded tables, synchronous step with all-gather / "
@@ -447,11 +451,10 @@ def main():
         except Exception as e:
             pcie = {"value": None, "what": f"failed: {e!r}"}
 
-    # ---- the OTHER multi-GPU mode, timed on a short leg of its own (a replica run reports both; the owner-sharded step leaves
-    # every rank with only its own range current, so it comes last)
-    dp_modes = None
-    if use_dist and dist_rank is not None and not sharded_main:
-        # row-sparse gradient buckets first (it keeps the replicas whole)
+    # ---- the OTHER multi-GPU modes, timed on short legs of their own AFTER the line's figures are settled (a replica run reports
+    # them as dp_modes; the owner-sharded step leaves every rank with only its own range current, so it comes last).  They have
+    # never run on more than one GPU: a watchdog prints the line without them if they do not come back.
+    def run_other_modes():
         Kp, Bp = min(K, 16), max(256, 8192 // world)  # global micro-batch of 8192 examples: the summed-gradient rule's stable range
         precs_, poff_ = gen_records(fw, args, 2_500_000_000 + rank * Kp * Bp, Kp * Bp)
         pb = [re.record_batch(fbt, precs_[int(poff_[j * Bp]):int(poff_[(j + 1) * Bp])], poff_[j * Bp:(j + 1) * Bp + 1] - poff_[j * Bp]) for j in range(Kp)]
@@ -466,7 +469,6 @@ def main():
         tsp = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device="cuda")
         dist.all_reduce(tsp, op=dist.ReduceOp.MAX)
         sp_rows = dist_rank.sparse_last_rows()
-        sp_occ = (int(pb[-1].n_ffm), int(pb[-1].n_lr)) if hasattr(pb[-1], "n_ffm") else None
         for x in pb:
             x.close()
         del precs_
@@ -483,19 +485,19 @@ def main():
         dist.barrier()
         tsh = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device="cuda")
         dist.all_reduce(tsh, op=dist.ReduceOp.MAX)
-        dp_modes = {"replica": "the timed mode of this line",
-                    "sparse": {"value": world * Kp * Bp / float(tsp.item()), "unit": "examples/sec", "steps": Kp,
-                               "examples_per_step_per_gpu": Bp, "ms_per_step": 1e3 * float(tsp.item()) / Kp,
-                               "bucket_rows_last_step": {"ffm": sp_rows[0], "lr": sp_rows[1]},
-                               "bytes_sent_per_example": (sp_rows[0] * (args.fields * args.k * 4 + 4) + sp_rows[1] * 8) / Bp,
-                               "what": "full replicas, per-micro-batch all-gather of deduplicated row gradients, every rank applies all of "
-                                       "them: one summed-gradient AdaGrad step per row (fwgpu_dist_learn_sparse_batch)"},
-                    "sharded": {"value": world * Ks * Bs / float(tsh.item()), "unit": "examples/sec", "steps": Ks,
-                                "examples_per_step_per_gpu": Bs, "ms_per_step": 1e3 * float(tsh.item()) / Ks,
-                                "what": "owner-sharded tables, synchronous step of n_gpus x examples_per_step_per_gpu examples: all-gather of "
-                                        "records, reduce-scatter + all-gather of field sums, owner-side AdaGrad (fwgpu_dist_learn_sharded_batch)"}}
         for x in sb:
             x.close()
+        return {"replica": "the timed mode of this line",
+                "sparse": {"value": world * Kp * Bp / float(tsp.item()), "unit": "examples/sec", "steps": Kp,
+                           "examples_per_step_per_gpu": Bp, "ms_per_step": 1e3 * float(tsp.item()) / Kp,
+                           "bucket_rows_last_step": {"ffm": sp_rows[0], "lr": sp_rows[1]},
+                           "bytes_sent_per_example": (sp_rows[0] * (args.fields * args.k * 4 + 4) + sp_rows[1] * 8) / Bp,
+                           "what": "full replicas, per-micro-batch all-gather of deduplicated row gradients, every rank applies all of "
+                                   "them: one summed-gradient AdaGrad step per row (fwgpu_dist_learn_sparse_batch)"},
+                "sharded": {"value": world * Ks * Bs / float(tsh.item()), "unit": "examples/sec", "steps": Ks,
+                            "examples_per_step_per_gpu": Bs, "ms_per_step": 1e3 * float(tsh.item()) / Ks,
+                            "what": "owner-sharded tables, synchronous step of n_gpus x examples_per_step_per_gpu examples: all-gather of "
+                                    "records, reduce-scatter + all-gather of field sums, owner-side AdaGrad (fwgpu_dist_learn_sharded_batch)"}}
 
     # HBM traffic per launch: PMC counters cannot be read from inside this process; the figure is the rocprofv3
     # measurement of this very command (separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 correction on the
@@ -567,8 +569,6 @@ def main():
         }
         if pcie is not None:
             out["pcie_inclusive"] = pcie
-        if dp_modes is not None:
-            out["dp_modes"] = dp_modes
         if sparse_main:
             out["sparse_exchange"] = sparse_exchange
         if args.cpu and world == 1:
@@ -578,9 +578,29 @@ def main():
             except Exception as e:  # the baseline is a reported side figure; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "examples/sec", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}
-        result_line = json.dumps(out)
     else:
-        result_line = None
+        out = None
+    if use_dist and dist_rank is not None and not sharded_main and args.other_modes:
+        import threading
+
+        def bail():  # the legs hang (a collective that never completes): the line as it stands, then out -- on every rank
+            if out is not None:
+                out["dp_modes"] = {"replica": "the timed mode of this line", "error": f"the sparse / sharded legs did not finish within {args.other_modes_timeout} s"}
+                sys.stdout.flush()
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.other_modes_timeout, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            dp_modes = run_other_modes()
+        except Exception as e:  # a reported side figure: never lose the line over it
+            dp_modes = {"replica": "the timed mode of this line", "error": f"failed: {e!r}"}
+        dog.cancel()
+        if out is not None:
+            out["dp_modes"] = dp_modes
+    result_line = json.dumps(out) if out is not None else None
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
