@@ -18,7 +18,7 @@ python3 scripts/rocprof_summary.py $(find $OUT/${TAG}_trace $OUT/${TAG}_fetch $O
 head -40 $OUT/${TAG}_kernel_rocprofv3.txt
 # the multi-GPU code paths with ONE rank over RCCL (library communicator): replica exchange + sharded leg, then the sharded step as the timed mode
 MASTER_ADDR=127.0.0.1 MASTER_PORT=29544 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 600 python3 bench.py --force-dist --no-cpu-baseline --no-traffic > $OUT/${TAG}_bench_dist1_replica.json 2> $OUT/${TAG}_bench_dist1_replica.err
-MASTER_ADDR=127.0.0.1 MASTER_PORT=29545 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 600 python3 bench.py --force-dist --dp-mode sharded --steps 96 --no-cpu-baseline --no-traffic > $OUT/${TAG}_bench_dist1_sharded.json 2> $OUT/${TAG}_bench_dist1_sharded.err
+MASTER_ADDR=127.0.0.1 MASTER_PORT=29545 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 600 python3 bench.py --force-dist --dp-mode sharded --steps 192 --no-cpu-baseline --no-traffic > $OUT/${TAG}_bench_dist1_sharded.json 2> $OUT/${TAG}_bench_dist1_sharded.err
 tail -c 700 $OUT/${TAG}_bench_dist1_replica.json; echo; tail -c 400 $OUT/${TAG}_bench_dist1_sharded.json; echo
 # config E (configs[4]): exact head (the default) and the mini-batched MFMA head
 timeout 600 python3 bench.py --k 16 --nn-layers 2 --batch 8192 --steps 24 --warmup 2 > $OUT/${TAG}_configE_exact.json 2> $OUT/${TAG}_configE_exact.err
