@@ -216,7 +216,8 @@ def main():
                          "reference's per-example head inside the fused kernel")
     ap.add_argument("--sync", action="store_true", help="run the steps as synchronous micro-batches (fwgpu_learn_batch_sync) also without a deep head")
     ap.add_argument("--whole-lines", dest="whole_lines", type=int, default=None, choices=[0, 1, 2],
-                    help="FFM row updates as whole 128 B lines + duplicate-row chains: 0 off, 1 auto (default), 2 always (A/B runs)")
+                    help="update path: 0 = round-1 path (float-granular, repeated rows serialised), 1 = auto (default: duplicate-row chains; whole 128 B lines only "
+                         "when the accumulator table could not be placed away from the weight table), 2 = chains + whole lines always (A/B runs)")
     ap.add_argument("--threads", type=int, default=0, help="workgroup size override")
     ap.add_argument("--wgs-per-cu", dest="wgs", type=int, default=0)
     ap.add_argument("--max-in-flight", dest="max_in_flight", type=int, default=0,
@@ -551,7 +552,7 @@ def main():
                 "bound": "hbm",
                 "kernel": ("FWD / MID / " + ("head GEMMs (v_mfma_f32_32x32x2_f32) / " if args.nn_layers else "") + "UPD kernels of the synchronous micro-batch (generic row kernel)"
                            if sync_steps or sharded_main else
-                           "fw_example_kernel_r<AdagradLUT, coherent, MAXR=0, whole-line updates + duplicate-row chains> (3 workgroups x 512 threads per CU)"
+                           "fw_example_kernel_r<AdagradLUT, coherent, MAXR=0, duplicate-row chains> (3 workgroups x 512 threads per CU; whole-line row accesses only when w and acc contend for one memory region)"
                            if args.k % 4 == 0 and args.fields * args.k <= 256 and not args.nn_layers else
                            "fw_example_kernel<VEC=4, AdagradLUT, coherent> (generic rows, duplicate-row chains" + (" + per-example deep head)" if args.nn_layers else ")")),
                 "achieved": achieved,

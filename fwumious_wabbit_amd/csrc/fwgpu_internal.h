@@ -88,7 +88,8 @@ struct KernelParams {
     int32_t has_lr;            // wiring REGRESSOR: LR block participates
     int32_t update;
     int32_t aligned4;          // every FFM row of the batch starts on a 16-byte boundary
-    int32_t window;            // FFM rows are updated as the whole 128 B lines they touch (v2 kernel; kernels.hip update_rows_win)
+    int32_t window;            // the v2 kernel's update takes the window path (kernels.hip update_rows_win: duplicate-row chains, no resident rows)
+    int32_t line_pass;         // ... and reads / writes back the WHOLE 128 B lines a row touches (0: float-granular accesses)
     uint32_t k_log2;           // log2(k) when k is a power of two, else 0xff
     int32_t no_chain;          // debug option 3: duplicate rows are serialised in phase B instead of chained (A/B runs)
     int32_t chain;             // rows of the same hash inside one example are chained to the first and applied from registers (set with window)
@@ -253,6 +254,7 @@ struct fwgpu_regressor {
     int placement_tries = 0;                     // candidate allocations timed for d_ffm_acc (regressor.cpp: place_ffm_acc)
     float placement_ms_lo = 0, placement_ms_hi = 0;  // fastest / slowest pair probe among them
     float placement_ms_single = 0;                    // the same probe on the weight table alone
+    bool placement_contended = false;                 // the search ran and every candidate contended with the weight table
     float *d_lut_lr = nullptr, *d_lut_ffm = nullptr;
     uint32_t lr_hash_mask = 0, ffm_hash_mask = 0;
     fwgpu::LaunchConfig launch;

@@ -963,11 +963,7 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
             hh[u] = __builtin_amdgcn_readfirstlane(s.e_hash[idx[u]]);
             sb[u] = (hh[u] * 4u) & 127u;                          // row start within its first line, bytes
             nb[u] = (sb[u] + R * 4u + 127u) & ~127u;              // whole lines covered, bytes
-#ifdef FW_WIN_NOPASS  // A/B: float-granular accesses for every row (chains stay)
-            if (true) {
-#else
-            if (nb[u] > (uint32_t)NCH * 1024u) {                  // (wave-uniform) more lines than NCH chunks hold:
-#endif
+            if (!p.line_pass || nb[u] > (uint32_t)NCH * 1024u) {  // (wave-uniform) float-granular launch, or more lines than NCH chunks hold:
                 sb[u] = 0;                                        // this row keeps float-granular accesses
                 nb[u] = R * 4u;
             }

@@ -351,6 +351,11 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
     // where concurrent examples would meet on a line most often, so they keep float-granular writes.
     // (launch_example_kernel keeps the flag only where the whole-line path exists.)
     p.window = r->launch.window == 2 || (r->launch.window == 1 && r->ffm_len * 8ull > (256ull << 20)) ? 1 : 0;
+    // Whole-line accesses pay when w and acc contend for one region of the device memory (partial-line writes are what is slow
+    // then: -6.5 %); with the accumulator table placed away from the weights they buy nothing (4.64 vs 4.60 M examples/s) and
+    // only widen hogwild's race from the float to the line, so they are used when asked for (option 2 = 2) or when the placement
+    // search found no partner that does not contend.
+    p.line_pass = r->launch.window == 2 || (p.window && r->placement_contended) ? 1 : 0;
     p.no_chain = r->launch.no_chain;
     p.k_log2 = 0xffu;
     for (uint32_t l = 0; l < 16; l++)
@@ -510,6 +515,8 @@ static int place_ffm_acc(fwgpu_regressor *r, size_t fbytes) {
     r->d_ffm_acc = cand[best];
     for (size_t i = 0; i < cand.size(); i++)
         if ((int)i != best) (void)hipFree(cand[i]);
+    // (no search, or no candidate that does not contend: the launches assume contention and use whole-line accesses)
+    r->placement_contended = fbytes > (256u << 20) && !(search && single > 0.0f && lo < fast_below);
     r->placement_tries = (int)cand.size();
     r->placement_ms_lo = hi > 0.0f ? lo : 0.0f;
     r->placement_ms_hi = hi;

@@ -383,8 +383,9 @@ class Regressor:
         check(self.L.fwgpu_set_launch(self.h, threads, workgroups_per_cu))
 
     def set_whole_line_updates(self, mode):
-        """FFM rows written back as the whole 128 B lines they touch: 0 off, 1 auto (tables larger than the Infinity
-        Cache; the default), 2 always (kernels.hip update_rows_win)"""
+        """update path of large models (fwgpu_debug_set_option 2): 0 = round-1 path (float-granular, repeated rows serialised);
+        1 = auto, the default (tables beyond the Infinity Cache: duplicate-row chains, whole 128 B lines only when w and acc
+        contend for one memory region); 2 = chains + whole-line accesses always (kernels.hip update_rows_win)"""
         check(self.L.fwgpu_debug_set_option(self.h, 2, int(mode)))
 
     # ---- tables

@@ -372,7 +372,12 @@ int fwgpu_debug_phase_ticks(fwgpu_regressor *r, int enable, uint64_t *out16);
 int fwgpu_debug_placement(const fwgpu_regressor *r, int *tries, float *ms_fastest, float *ms_slowest);
 /* 0 = automatic kernel choice, 1 = force the generic kernel (v1), 2 = register-resident rows (v2) where applicable. */
 int fwgpu_debug_set_kernel_version(fwgpu_regressor *r, int version);
-/* Tuning switches for experiments. option 1: value 1 = read the AdaGrad LUT from global memory instead of an LDS copy. */
+/* Tuning switches for experiments.  option 1: value 1 = read the AdaGrad LUT from global memory instead of an LDS copy.
+ * option 2: the update path of large models (k % 4 == 0, rows of at most 256 floats): 0 = float-granular row updates, rows repeated
+ *   inside an example serialised on one wave (the round-1 path); 1 = automatic (default): tables beyond the Infinity Cache take the
+ *   chained path (repeated rows applied by their first occurrence's wave, from registers), with whole-128-byte-line accesses only
+ *   when the accumulator table could not be placed away from the weight table; 2 = chained path with whole-line accesses, always.
+ * option 3: value 1 = no duplicate-row chains (A/B runs). */
 int fwgpu_debug_set_option(fwgpu_regressor *r, int option, int value);
 /* an f32 as serde_json / ryu prints it in the embedded JSON documents ("0.1", "1.0", "1e-7"); NUL-terminated */
 int fwgpu_debug_format_f32(float v, char *buf, uint32_t cap);
