@@ -939,6 +939,10 @@ __device__ __forceinline__ void update_rows(const KernelParams &p, const Lds &s,
 // carry the neighbouring weights through unchanged.  In the in-order mode this is exact; between concurrent examples it
 // widens hogwild's unsynchronised read-modify-write from "the same float" to "the same 128 B line" for the (at most two)
 // edge lines of a row.  Rows whose WINDOWS intersect inside one example are serialised like overlapping rows.
+// KernelParams::line_pass selects it per launch: the whole lines pay (-6.5 %) while w and acc contend for one region of the
+// device memory; with acc placed away from w (regressor.cpp place_ffm_acc) the float-granular accesses of the same code path
+// (sb = 0, nb = 4R: exactly the row) are as fast, and the race stays at the float.  The duplicate-row chains below are what
+// this path keeps in both cases.
 template <int OPT, int AUX, int U, int NCH>
 __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds &s, const uint32_t (&idx)[U], float g,
                                                 int lane, uint32_t nf, const float *gpair = nullptr) {
