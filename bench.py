@@ -554,6 +554,8 @@ def main():
                            if sync_steps or sharded_main else
                            "fw_example_kernel_r<AdagradLUT, coherent, MAXR=0, duplicate-row chains> (3 workgroups x 512 threads per CU; whole-line row accesses only when w and acc contend for one memory region)"
                            if args.k % 4 == 0 and args.fields * args.k <= 256 and not args.nn_layers else
+                           "fw_example_kernel_r<AdagradLUT, coherent, MAXR=0, duplicate-row chains, NC=2> (two 16-byte chunks per lane and row; 2 workgroups x 512 threads per CU)"
+                           if args.k % 4 == 0 and args.fields * args.k <= 512 and 256 % args.k == 0 and not args.nn_layers else
                            "fw_example_kernel<VEC=4, AdagradLUT, coherent> (generic rows, duplicate-row chains" + (" + per-example deep head)" if args.nn_layers else ")")),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

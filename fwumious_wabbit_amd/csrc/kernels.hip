@@ -1631,8 +1631,11 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #ifndef FW_LB_WAVES
 #define FW_LB_WAVES 6
 #endif
-template <int OPT, bool COH, int MAXR, bool WIN>
-__global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_r(const KernelParams p) {
+// NC = 16-byte chunks per lane and row: 1 for rows of up to 256 floats (config C: 240), 2 for rows of up to 512 floats (k = 16 with 30
+// fields: 480).  Two-chunk rows keep T alone at 57.6 KB of LDS, so two workgroups share a CU and the register budget is 128 VGPRs.
+template <int OPT, bool COH, int MAXR, bool WIN, int NC = 1>
+__global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? FW_LB_WAVES : 4) fw_example_kernel_r(const KernelParams p) {
+    static_assert(NC == 1 || MAXR == 0, "resident rows are a single-chunk feature");
     typedef f4 V;
     constexpr int VEC = 4;
     constexpr int AUX = COH ? kAuxSc1 : kAuxPlain;
@@ -1675,11 +1678,18 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = bd >> 6;
     const uint32_t F = p.F, k = p.k, R = p.R;
-    // this lane's 4 floats of a row: elements [e0, e0+4) = slot z, offset kk0
-    const uint32_t e0 = lane * VEC;
-    const bool inb = e0 < R;
-    const uint32_t z = inb ? e0 / k : 0xfffffffeu;
-    const uint32_t kk0 = inb ? e0 - z * k : 0;
+    // this lane's 4 floats of a row's chunk c: elements [e0, e0+4) = slot z, offset kk0
+    uint32_t e0c[NC], zc[NC], kkc[NC];
+    bool inbc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        e0c[c] = (c * 64 + lane) * VEC;
+        inbc[c] = e0c[c] < R;
+        zc[c] = inbc[c] ? e0c[c] / k : 0xfffffffeu;
+        kkc[c] = inbc[c] ? e0c[c] - zc[c] * k : 0;
+    }
+    const uint32_t e0 = e0c[0], z = zc[0], kk0 = kkc[0];  // (chunk 0: what the resident-row code, NC == 1 only, works on)
+    const bool inb = inbc[0];
 
     const float *lut_lr = p.lut_lr;  // 201 lookups per example: read through L1 (an LDS copy measured no faster)
     if (use_lut)
@@ -1742,54 +1752,69 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
             }
         }
         {
-            V acc = Vec<VEC>::zero();
+            V acc[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] = Vec<VEC>::zero();
             float dc = 0.0f;
             uint32_t cur = 0xffffffffu;
-            // consume one row (buffer order): field switch -> flush the finished field's sum, transposed, into T
+            // consume one row (buffer order; ROW = its NC chunks): field switch -> flush the finished field's sum, transposed, into T
 #define FW_CONSUME(ROW, IDX)                                                                                  \
     {                                                                                                         \
         const uint32_t f_ = __builtin_amdgcn_readfirstlane(s.e_fld[(IDX)] & kFldMask);                         \
         const float v_ = s.e_val[(IDX)];                                                                      \
         if (f_ != cur) {                                                                                      \
             if (cur != 0xffffffffu) {                                                                         \
-                if (inb) Vec<VEC>::lds_store(s.T + z * R + cur * k + kk0, acc);                                \
+                _Pragma("unroll") for (int c = 0; c < NC; ++c)                                                \
+                    if (inbc[c]) Vec<VEC>::lds_store(s.T + zc[c] * R + cur * k + kkc[c], acc[c]);              \
                 dc = wave_sum(dc);                                                                            \
                 if (!COH && p.ctx_dcf) dc += p.ctx_dcf[cur];                                                  \
                 s.dcf[cur] = dc;                                                                              \
             }                                                                                                 \
-            acc = Vec<VEC>::zero();                                                                           \
-            if (!COH && p.ctx_T && inb) /* context cache: the cached features of the field come first */      \
-                acc = *reinterpret_cast<const f4 *>(p.ctx_T + z * R + f_ * k + kk0);                           \
+            _Pragma("unroll") for (int c = 0; c < NC; ++c) {                                                  \
+                acc[c] = Vec<VEC>::zero();                                                                    \
+                if (!COH && p.ctx_T && inbc[c]) /* context cache: the cached features of the field come first */ \
+                    acc[c] = *reinterpret_cast<const f4 *>(p.ctx_T + zc[c] * R + f_ * k + kkc[c]);             \
+            }                                                                                                 \
             dc = 0.0f;                                                                                        \
             cur = f_;                                                                                         \
         }                                                                                                     \
-        float ss_ = 0.0f;                                                                                     \
-        _Pragma("unroll") for (int j = 0; j < VEC; ++j) {                                                     \
-            const float w_ = (ROW)[j];                                                                        \
-            acc[j] = __fadd_rn(acc[j], __fmul_rn(w_, v_)); /* block_ffm.rs:205 */                             \
-            ss_ += w_ * w_;                                                                                   \
-        }                                                                                                     \
-        if (z == f_) {                                                                                        \
-            dc += ss_ * v_ * v_;                                                                              \
-            Vec<VEC>::lds_store(s.selfw + (IDX)*k + kk0, (ROW));                                               \
+        _Pragma("unroll") for (int c = 0; c < NC; ++c) {                                                      \
+            float ss_ = 0.0f;                                                                                 \
+            _Pragma("unroll") for (int j = 0; j < VEC; ++j) {                                                 \
+                const float w_ = (ROW)[c][j];                                                                 \
+                acc[c][j] = __fadd_rn(acc[c][j], __fmul_rn(w_, v_)); /* block_ffm.rs:205 */                   \
+                ss_ += w_ * w_;                                                                               \
+            }                                                                                                 \
+            if (zc[c] == f_) {                                                                                \
+                dc += ss_ * v_ * v_;                                                                          \
+                Vec<VEC>::lds_store(s.selfw + (IDX)*k + kkc[c], (ROW)[c]);                                     \
+            }                                                                                                 \
         }                                                                                                     \
     }
 #pragma unroll
             for (int sl = 0; sl < MAXR; ++sl)
-                if ((uint32_t)sl < cnt) FW_CONSUME(rows[sl], lo + sl)
+                if ((uint32_t)sl < cnt) {
+                    V one[NC];
+                    one[0] = rows[sl];
+                    FW_CONSUME(one, lo + sl)
+                }
             // overflow rows of this range: transient (they are re-read in the update phase)
             for (uint32_t i = lo + MAXR; i < hi; i += FW_UG) {
-                V r[FW_UG];
+                V r[FW_UG][NC];
 #pragma unroll
                 for (int u = 0; u < FW_UG; ++u) {
-                    r[u] = Vec<VEC>::zero();
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) r[u][c] = Vec<VEC>::zero();
                     if (i + u < hi) {
                         const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[i + u]);
-    #ifdef FW_ABL_PLAIN_GATHER
-                        r[u] = Vec<VEC>::template load<kAuxPlain>(make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+#ifdef FW_ABL_PLAIN_GATHER
+                            r[u][c] = Vec<VEC>::template load<kAuxPlain>(make_rsrc(p.ffm_w + h, R * 4), e0c[c] * 4);
 #else
-                        r[u] = Vec<VEC>::template load<AUX>(make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
+                            r[u][c] = Vec<VEC>::template load<AUX>(make_rsrc(p.ffm_w + h, R * 4), e0c[c] * 4);
 #endif
+                        }
                     }
                 }
 #pragma unroll
@@ -1797,7 +1822,9 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
                     if (i + u < hi) FW_CONSUME(r[u], i + u)
             }
             if (cur != 0xffffffffu) {
-                if (inb) Vec<VEC>::lds_store(s.T + z * R + cur * k + kk0, acc);
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    if (inbc[c]) Vec<VEC>::lds_store(s.T + zc[c] * R + cur * k + kkc[c], acc[c]);
                 dc = wave_sum(dc);
                 if (!COH && p.ctx_dcf) dc += p.ctx_dcf[cur];
                 s.dcf[cur] = dc;
@@ -1935,7 +1962,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
                     idx[u] = (i < hi && !(s.e_fld[i] & (kRowDep | kRowChained))) ? i : 0xffffffffu;
                 }
                 if (WIN)
-                    update_rows_win<OPT, AUX, UO, FW_WIN_NCH>(p, s, idx, g, lane, nf);
+                    update_rows_win<OPT, AUX, UO, (NC > FW_WIN_NCH ? NC : FW_WIN_NCH)>(p, s, idx, g, lane, nf);
                 else
                     update_rows<VEC, OPT, AUX, UO>(p, s, idx, g, lane);
             }
@@ -1948,7 +1975,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
                         if (s.e_fld[i] & kRowDep) {
                             uint32_t idx[1] = {i};
                             if (WIN)
-                                update_rows_win<OPT, AUX, 1, FW_WIN_NCH>(p, s, idx, g, lane, nf);
+                                update_rows_win<OPT, AUX, 1, (NC > FW_WIN_NCH ? NC : FW_WIN_NCH)>(p, s, idx, g, lane, nf);
                             else
                                 update_rows<VEC, OPT, AUX, 1>(p, s, idx, g, lane);
                             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -1972,6 +1999,10 @@ __global__ void __launch_bounds__(FW_LB_THREADS, FW_LB_WAVES) fw_example_kernel_
 #endif
 template <int OPT, bool COH>
 static hipError_t launch_r(const KernelParams &p, uint32_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
+    if (p.R > 64 * 4) {  // two-chunk rows (k = 16 at config E's 30 fields): no resident rows
+        if (p.window) return launch_persistent(fw_example_kernel_r<OPT, COH, 0, true, 2>, p, grid, threads, lds, stream);
+        return launch_persistent(fw_example_kernel_r<OPT, COH, 0, false, 2>, p, grid, threads, lds, stream);
+    }
     if (p.window) return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR_WIN, true>, p, grid, threads, lds, stream);
     return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR, false>, p, grid, threads, lds, stream);
 }
@@ -1994,7 +2025,9 @@ static hipError_t launch_resident(const KernelParams &p, int optimizer, bool coh
 
 // Does this launch run on the register-resident kernel (v2)?  16 B-aligned single-chunk rows, no deep head.
 static bool uses_resident_kernel(const KernelParams &p, uint32_t threads) {
-    return p.k % 4 == 0 && p.aligned4 && p.R <= 64 * 4 && p.kernel_version != 1 && p.nn.n_layers == 0 && threads <= FW_LB_THREADS;
+    // rows of up to 256 floats (one 16-byte chunk per lane) or up to 512 (two chunks; a field slot must not straddle the chunks)
+    const bool fits = p.R <= 64 * 4 || (p.R <= 64 * 4 * 2 && p.k != 0 && 256 % p.k == 0);
+    return p.k % 4 == 0 && p.aligned4 && fits && p.kernel_version != 1 && p.nn.n_layers == 0 && threads <= FW_LB_THREADS;
 }
 // Whole-line updates and duplicate-row chains exist in the v2 kernel's update path only, and only updating launches need them.
 void resolve_row_mode(KernelParams &p, uint32_t threads) {

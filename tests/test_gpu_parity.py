@@ -139,9 +139,15 @@ def test_sequential_stream_sgd_and_flex():
                    init_acc=1.0, ffm_init_acc=1.0, weight_tol=5e-5)
 
 
-def test_sequential_stream_k16_two_chunk_rows():
-    # R = 30*16 = 480 floats: two 64-lane chunks per row
-    _stream_parity(30, 16, 16, 18, fw.Optimizer.AdagradLUT, n=120, mean_extra=1.0, p_weighted=0.1, ids=20000, seed=6)
+@pytest.mark.parametrize("whole_lines", [None, 0, 2])
+def test_sequential_stream_k16_two_chunk_rows(whole_lines):
+    """R = 30*16 = 480 floats: two 16-byte chunks per lane and row, on the v2 kernel's two-chunk instantiation (static wave ranges,
+    duplicate-row chains; whole_lines = 2: 2 KiB windows of whole lines); R = 40*8 = 320: a partly filled second chunk, rows that
+    start at all four 32-byte phases of a line; heavy collisions on tiny tables"""
+    _stream_parity(30, 16, 16, 18, fw.Optimizer.AdagradLUT, n=120, mean_extra=1.0, p_weighted=0.1, ids=20000, seed=6, whole_lines=whole_lines)
+    _stream_parity(40, 8, 14, 14, fw.Optimizer.AdagradLUT, n=150, mean_extra=1.0, p_weighted=0.1, ids=3000, seed=46, whole_lines=whole_lines)
+    _stream_parity(30, 16, 13, 13, fw.Optimizer.AdagradFlex, n=100, mean_extra=0.5, p_weighted=0.2, ids=800, seed=47, init_acc=1.0,
+                   ffm_init_acc=1.0, weight_tol=5e-5, whole_lines=whole_lines)
 
 
 def test_lr_only_model():
