@@ -291,14 +291,20 @@ int fwgpu_trainer_digest_text(fwgpu_trainer *tr, fwgpu_parser *parser, fwgpu_cac
             words_cap = cap;
         }
     };
-    std::vector<Slice> sl(T);
-    uint64_t pos = 0;
+    // Two stages, pipelined over chunks of the text: chunk i+1 is parsed (T threads) while chunk i's records are digested (staging
+    // copy, upload, learn launches) on a helper thread, in order.  One pass over the whole buffer (parse everything, then digest
+    // everything) left the GPU idle while parsing and the parsers idle while learning: 1.3 M lines/s on 16 threads.
+    auto parse_range = [&](uint64_t r_begin, uint64_t r_end, std::vector<Slice> &sl) {
+    sl.clear();
+    sl.resize(T);
+    uint64_t pos = r_begin;
+    const uint64_t rlen = r_end - r_begin;
     for (unsigned k = 0; k < T; k++) {  // slice k ends at the first line break at or after its proportional share
         sl[k].begin = pos;
-        uint64_t e = k + 1 == T ? len : std::max<uint64_t>(pos, len * (k + 1) / T);
-        if (e < len) {
-            const void *nl = memchr(text + e, '\n', len - e);
-            e = nl ? (uint64_t)(static_cast<const char *>(nl) - text) + 1 : len;
+        uint64_t e = k + 1 == T ? r_end : std::max<uint64_t>(pos, r_begin + rlen * (k + 1) / T);
+        if (e < r_end) {
+            const void *nl = memchr(text + e, '\n', r_end - e);
+            e = nl ? (uint64_t)(static_cast<const char *>(nl) - text) + 1 : r_end;
         }
         sl[k].end = pos = e;
     }
@@ -354,26 +360,70 @@ int fwgpu_trainer_digest_text(fwgpu_trainer *tr, fwgpu_parser *parser, fwgpu_cac
         work(0);
         for (auto &x : th) x.join();
     }
+    };
     uint64_t done = 0, used = 0;
+    // digests the slices of one chunk in order; false: stop (rc says why: an error, or a command line reached)
+    auto digest_slices = [&](std::vector<Slice> &sl, int &rc, std::string &msg) -> bool {
+        for (unsigned k = 0; k < T && rc == FWGPU_OK; k++) {
+            Slice &s = sl[k];
+            uint64_t i = 0;
+            while (i < s.nr && rc == FWGPU_OK) {
+                const uint32_t take = (uint32_t)std::min<uint64_t>(s.nr - i, 1u << 30);
+                // offsets are relative to the slice's first word
+                rc = fwgpu_digest_records(tr, s.words.get(), s.off.data() + i, take);
+                i += take;
+            }
+            if (rc == FWGPU_OK && cache && s.nw) rc = fwgpu_cache_push_records(cache, s.words.get(), s.nw);
+            if (rc != FWGPU_OK) {
+                msg = fwgpu_last_error();  // (thread-local: carried back to the caller's thread)
+                return false;
+            }
+            done += s.nr;
+            used = s.begin + s.used;
+            if (s.rc != FWGPU_OK) {  // a command or a bad line stopped this slice: stop here, in order
+                rc = s.rc;
+                msg = s.msg;
+                return false;
+            }
+        }
+        return rc == FWGPU_OK;
+    };
+    // chunks of at least 4 MB of text per parser thread, at most 64 MB in all, cut at line breaks
+    const uint64_t chunk_target = std::min<uint64_t>(std::max<uint64_t>((uint64_t)T * (4u << 20), 16u << 20), 64u << 20);
+    std::vector<Slice> cur, next;
     int rc = FWGPU_OK;
-    for (unsigned k = 0; k < T && rc == FWGPU_OK; k++) {
-        Slice &s = sl[k];
-        uint64_t i = 0;
-        while (i < s.nr && rc == FWGPU_OK) {
-            const uint32_t take = (uint32_t)std::min<uint64_t>(s.nr - i, 1u << 30);
-            // offsets are relative to the slice's first word
-            rc = fwgpu_digest_records(tr, s.words.get(), s.off.data() + i, take);
-            i += take;
+    std::string msg;
+    uint64_t pos = 0;
+    auto chunk_end = [&](uint64_t from) {
+        uint64_t e = std::min<uint64_t>(len, from + chunk_target);
+        if (e < len) {
+            const void *nl = memchr(text + e, '\n', len - e);
+            e = nl ? (uint64_t)(static_cast<const char *>(nl) - text) + 1 : len;
         }
-        if (rc == FWGPU_OK && cache && s.nw) rc = fwgpu_cache_push_records(cache, s.words.get(), s.nw);
-        if (rc != FWGPU_OK) break;
-        done += s.nr;
-        used = s.begin + s.used;
-        if (s.rc != FWGPU_OK) {  // a command or a bad line stopped this slice: stop here, in order
-            rc = (s.rc == FWGPU_PARSE_FLUSH || s.rc == FWGPU_PARSE_HOGWILD_LOAD) ? s.rc : fail(s.rc, s.msg);
-            break;
-        }
+        return e;
+    };
+    bool have = false;
+    if (len) {
+        const uint64_t e = chunk_end(0);
+        parse_range(0, e, cur);
+        pos = e;
+        have = true;
     }
+    while (have) {
+        bool go_on = true;
+        std::thread dg([&] { go_on = digest_slices(cur, rc, msg); });
+        bool parsed_next = false;
+        if (pos < len) {
+            const uint64_t e = chunk_end(pos);
+            parse_range(pos, e, next);
+            pos = e;
+            parsed_next = true;
+        }
+        dg.join();
+        if (!go_on || !parsed_next) break;  // (a chunk parsed past a command line or an error is dropped: `consumed` says where to resume)
+        cur.swap(next);
+    }
+    if (rc != FWGPU_OK && rc != FWGPU_PARSE_FLUSH && rc != FWGPU_PARSE_HOGWILD_LOAD) rc = fail(rc, msg);
     if (n_examples) *n_examples = done;
     if (consumed) *consumed = used;
     return rc;
