@@ -295,8 +295,12 @@ int fwgpu_trainer_digest_text(fwgpu_trainer *tr, fwgpu_parser *parser, fwgpu_cac
     // copy, upload, learn launches) on a helper thread, in order.  One pass over the whole buffer (parse everything, then digest
     // everything) left the GPU idle while parsing and the parsers idle while learning: 1.3 M lines/s on 16 threads.
     auto parse_range = [&](uint64_t r_begin, uint64_t r_end, std::vector<Slice> &sl) {
-    sl.clear();
-    sl.resize(T);
+    if (sl.size() != T) sl.resize(T);
+    for (Slice &q : sl) {  // (the record buffers of the previous chunk are kept: first-touch page faults of 16 threads at once do not scale)
+        q.begin = q.end = q.used = q.nr = q.nw = 0;
+        q.rc = FWGPU_OK;
+        q.msg.clear();
+    }
     uint64_t pos = r_begin;
     const uint64_t rlen = r_end - r_begin;
     for (unsigned k = 0; k < T; k++) {  // slice k ends at the first line break at or after its proportional share
@@ -328,7 +332,7 @@ int fwgpu_trainer_digest_text(fwgpu_trainer *tr, fwgpu_parser *parser, fwgpu_cac
         }
         // a feature token takes >= 2 bytes of text and <= 2 words of record; the per-line header depends on the namespace
         // map, so the buffer grows whenever a pass stops short without an error
-        s.grow(n + lines * 64 + 4096);
+        if (s.words_cap < n + lines * 64 + 4096) s.grow(n + lines * 64 + 4096);
         s.off.assign(lines + 1, 0);
         std::vector<uint64_t> tmp(lines + 1);
         while (s.used < n) {

@@ -72,9 +72,11 @@ if gpu:
     print(f"fw_predict (one request per call, ~200 features): {dt1 * 1e6:.0f} us per call")
 if gpu:
     big = text * 8  # 160 000 lines, ~295 MB of text
-    for th in (1, 8, 16):
+    for th in (1, 8, 16, 32):
         re2 = fw.Regressor(mi)
         tr = fw.HogwildTrainer(re2, mi, micro_batch=16384)
+        tr.digest_text(p, text, threads=th)  # warm-up: the trainer's pinned staging and device buffers are allocated on first use
+        tr.block_until_workers_finished()
         t0 = time.perf_counter()
         n, used, rc = tr.digest_text(p, big, threads=th)
         tr.block_until_workers_finished()
