@@ -189,6 +189,9 @@ def lib():
         "fwgpu_parser_create": [vp, P(vp)],
         "fwgpu_parser_parse_line": [vp, C.c_char_p, u64, vp, u32, P(u32)],
         "fwgpu_parser_parse_with_prefix": [vp, C.c_char_p, u64, C.c_char_p, u64, vp, u32, P(u32)],
+        "fwgpu_parse_prefix_create": [vp, C.c_char_p, u64, P(vp)],
+        "fwgpu_parse_prefix_resumable": [vp],
+        "fwgpu_parser_parse_after_prefix": [vp, vp, C.c_char_p, u64, vp, u32, P(u32)],
         "fwgpu_parser_parse_buffer": [vp, C.c_char_p, u64, vp, u64, vp, u64, P(u64), P(u64), P(u64)],
         "fwgpu_mi_from_json": [C.c_char_p, u64, P(vp)],
         "fwgpu_mi_to_json": [vp, vp, u64, P(u64)],
@@ -215,7 +218,7 @@ def lib():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = i32
-    for name in ("fwgpu_vwmap_free", "fwgpu_parser_free", "fwgpu_cache_free", "fwgpu_mi_free", "fwgpu_input_close"):
+    for name in ("fwgpu_vwmap_free", "fwgpu_parser_free", "fwgpu_parse_prefix_free", "fwgpu_cache_free", "fwgpu_mi_free", "fwgpu_input_close"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = None
     for name in ("fwgpu_vwmap_num_namespaces", "fwgpu_vwmap_num_entries"):

@@ -103,6 +103,7 @@ struct KernelParams {
     // ---- serving context cache (regressor.rs:397-423, block_ffm.rs:442-782): the context features' field sums, in T's layout
     const float *ctx_T;                 // [F*R] T[z][f][k] partial sums of the cached features (NULL: none); read-only launches only
     const float *ctx_dcf;               // [F]   their self-pair corrections
+    const uint32_t *ctx_cover;          // record batches: bit per namespace slot whose FFM features the cache already holds (the stage phase skips them)
     float *emit_T;                      // setup_cache: example 0's T and dcf are written here after the gather
     float *emit_dcf;
     // ---- synchronous micro-batch ("split") pipeline: FWD -> [exchange] -> MID -> [head / exchange] -> UPD  (kernels.hip)
@@ -284,6 +285,11 @@ struct fwgpu_block_cache {
     float *d_T = nullptr;    // [F*R] + [F] (dcf) in one allocation
     float *d_dcf = nullptr;
     std::vector<uint64_t> present;  // sorted (hash << 32 | contra_field_index) of the cached FFM features (features_present)
+    // record batches (fwgpu_block_cache_cover_record): the context's record decides which namespace slots are covered
+    uint32_t *d_cover = nullptr;           // device copy of `cover`
+    std::vector<uint32_t> cover;           // bit per namespace slot
+    std::vector<uint32_t> ctx_slots;       // the context record's slot words (a request that rewrites a covered slot is not covered)
+    std::vector<uint64_t> present_bits;    // 4096-bit filter in front of `present`
 };
 
 namespace fwgpu {

@@ -389,7 +389,11 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
             uint32_t carry = 0;
             for (uint32_t b0 = 0; b0 < NP; b0 += 64) {
                 const uint32_t j = b0 + lane;
-                const bool on = j < NP && k_nonzero(p.k);
+                bool on = j < NP && k_nonzero(p.k);
+                if (CTX && p.ctx_cover && on) {  // features the context cache holds are not gathered again (block_ffm.rs:548, 600)
+                    const uint32_t ns = t.pair_ns[j];
+                    on = !((p.ctx_cover[ns >> 5] >> (ns & 31)) & 1u);
+                }
                 const uint32_t cnt = on ? slot_count(s.rec, t.pair_ns[j]) : 0;
                 const uint32_t inc = wave_scan_incl(cnt, lane);
                 if (j < NP) ffm_base[j] = carry + inc - cnt;
@@ -1688,7 +1692,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? FW_LB_WAVES : 4) fw_e
         zc[c] = inbc[c] ? e0c[c] / k : 0xfffffffeu;
         kkc[c] = inbc[c] ? e0c[c] - zc[c] * k : 0;
     }
-    const uint32_t e0 = e0c[0], z = zc[0], kk0 = kkc[0];  // (chunk 0: what the resident-row code, NC == 1 only, works on)
+    const uint32_t e0 = e0c[0], z = zc[0];  // (chunk 0: what the resident-row code, NC == 1 only, works on)
     const bool inb = inbc[0];
 
     const float *lut_lr = p.lut_lr;  // 201 lookups per example: read through L1 (an LDS copy measured no faster)

@@ -188,26 +188,34 @@ static inline uint32_t f32_bits(float f) {
     return u;
 }
 
-// parser.rs:214-461 next_vowpal_to_size.  `p[0..size)` is the line as read by read_until('\n') (newline included when
-// present).  Mirrors the reference's scanning literally, including `rowlen = size - 1` whether or not the last byte is
-// a newline.  The buffer is padded so the reference's one-past reads (`*p.add(i_end)` with i_end == rowlen) are defined.
-static int parse_line(fwgpu_parser *ps, const char *line, size_t size) {
+// The scanner's namespace state between two tokens of the feature loop (parser.rs:318-326)
+struct NsState {
+    uint32_t ns_seed = 0;
+    size_t ns_slot = kHeaderLen;
+    bool ns_f32 = false;
+    size_t ns_start = 0;
+    float ns_weight = 1.0f;
+    uint32_t ns_count = 0;
+};
+
+static int parse_float_or_error(const unsigned char *p, size_t a, size_t b, const char *what, float *out) {
+    if (b - a == 4 && std::memcmp(p + a, "NONE", 4) == 0) {  // parser.rs:123-130
+        *out = std::nanf("");
+        return FWGPU_OK;
+    }
+    if (!parse_f32_rust(reinterpret_cast<const char *>(p + a), b - a, out))
+        return fail(FWGPU_ERR_PARSE, std::string(what) + ": " + std::string(reinterpret_cast<const char *>(p + a), b - a));
+    return FWGPU_OK;
+}
+
+// Label, importance and the scan to the first '|' (parser.rs:226-316).  `rowlen` bounds every scan; on FWGPU_OK *pos is
+// where the feature loop starts.
+static int parse_head(fwgpu_parser *ps, const unsigned char *p, size_t size, size_t rowlen, size_t *pos) {
     const fwgpu_vwmap &vw = ps->vw_copy;
     std::vector<uint32_t> &ob = ps->out;
     const size_t bufpos = vw.num_namespaces + kHeaderLen;
     ob.assign(bufpos, kNoFeatures);
-    // `line` has at least one readable byte after `size` (callers copy the rare line that does not)
-    const unsigned char *p = reinterpret_cast<const unsigned char *>(line);
     size_t i_start, i_end = 0;
-    auto parse_float_or_error = [&](size_t a, size_t b, const char *what, float *out) -> int {
-        if (b - a == 4 && std::memcmp(p + a, "NONE", 4) == 0) {  // parser.rs:123-130
-            *out = std::nanf("");
-            return FWGPU_OK;
-        }
-        if (!parse_f32_rust(reinterpret_cast<const char *>(p + a), b - a, out))
-            return fail(FWGPU_ERR_PARSE, std::string(what) + ": " + std::string(reinterpret_cast<const char *>(p + a), b - a));
-        return FWGPU_OK;
-    };
 
     switch (p[0]) {
     case 0x31: ob[kLabelOffset] = 1; break;
@@ -239,7 +247,6 @@ static int parse_line(fwgpu_parser *ps, const char *line, size_t size) {
         return fail(FWGPU_ERR_PARSE, "Cannot parse an example");
     }
 
-    const size_t rowlen = size - 1;  // "ignore last newline byte"
     if (ob[kLabelOffset] == kNoLabel) {
         ob[kImportanceOffset] = kFloatOne;
     } else {
@@ -251,7 +258,7 @@ static int parse_line(fwgpu_parser *ps, const char *line, size_t size) {
             i_start = i_end;
             while (p[i_end] != 0x20 && i_end < rowlen) i_end++;
             float imp;
-            int rc = parse_float_or_error(i_start, i_end, "Failed parsing example importance", &imp);
+            int rc = parse_float_or_error(p, i_start, i_end, "Failed parsing example importance", &imp);
             if (rc) return rc;
             if (imp < 0.0f) {
                 // Rust prints the f32 with {:?}: shortest round-trip digits
@@ -261,14 +268,23 @@ static int parse_line(fwgpu_parser *ps, const char *line, size_t size) {
         }
     }
     while (p[i_end] != 0x7c && i_end < rowlen) i_end++;
+    *pos = i_end;
+    return FWGPU_OK;
+}
 
-    uint32_t ns_seed = 0;
-    size_t ns_slot = kHeaderLen;
-    bool ns_f32 = false;
-    size_t ns_start = 0;
-    float ns_weight = 1.0f;
-    uint32_t ns_count = 0;
-    while (i_end < rowlen) {
+// The feature loop (parser.rs:318-457) from token boundary `i_end` while i_end < stop; scans are bounded by `rowlen`.
+// Positions are only ever used relative to `p`, so the loop can go on in another buffer that holds the rest of the line.
+static int parse_body(fwgpu_parser *ps, const unsigned char *p, size_t rowlen, size_t i_end, size_t stop, NsState &st) {
+    const fwgpu_vwmap &vw = ps->vw_copy;
+    std::vector<uint32_t> &ob = ps->out;
+    uint32_t &ns_seed = st.ns_seed;
+    size_t &ns_slot = st.ns_slot;
+    bool &ns_f32 = st.ns_f32;
+    size_t &ns_start = st.ns_start;
+    float &ns_weight = st.ns_weight;
+    uint32_t &ns_count = st.ns_count;
+    size_t i_start;
+    while (i_end < stop) {
         while (p[i_end] == 0x20 && i_end < rowlen) i_end++;
         i_start = i_end;
         while (p[i_end] != 0x20 && p[i_end] != 0x3a && i_end < rowlen) i_end++;
@@ -278,7 +294,7 @@ static int parse_line(fwgpu_parser *ps, const char *line, size_t size) {
         if (p[i_start] == 0x7c) {
             i_start += 1;
             if (i_end_first != i_end) {
-                int rc = parse_float_or_error(i_end_first + 1, i_end, "Failed parsing namespace weight", &ns_weight);
+                int rc = parse_float_or_error(p, i_end_first + 1, i_end, "Failed parsing namespace weight", &ns_weight);
                 if (rc) return rc;
             } else {
                 ns_weight = 1.0f;
@@ -297,7 +313,7 @@ static int parse_line(fwgpu_parser *ps, const char *line, size_t size) {
             const uint32_t h = murmur3_32(p + i_start, i_end_first - i_start, ns_seed) & kMask31;
             float fw = 1.0f;
             if (i_end_first != i_end) {
-                int rc = parse_float_or_error(i_end_first + 1, i_end, "Failed parsing feature weight", &fw);
+                int rc = parse_float_or_error(p, i_end_first + 1, i_end, "Failed parsing feature weight", &fw);
                 if (rc) return rc;
             }
             if (ns_count == 0 && !ns_f32 && ns_weight == 1.0f && fw == 1.0f) {
@@ -316,7 +332,7 @@ static int parse_line(fwgpu_parser *ps, const char *line, size_t size) {
                         return fail(FWGPU_ERR_PARSE, "Failed parsing feature value to float (for float namespace): feature name "
                                                      "shorter than _namespace_skip_prefix");
                     if (i_end_first != fs) {
-                        int rc = parse_float_or_error(fs, i_end_first, "Failed parsing feature value to float (for float namespace)", &v);
+                        int rc = parse_float_or_error(p, fs, i_end_first, "Failed parsing feature value to float (for float namespace)", &v);
                         if (rc) return rc;
                     } else {
                         v = std::nanf("");
@@ -335,9 +351,39 @@ static int parse_line(fwgpu_parser *ps, const char *line, size_t size) {
         }
         i_end += 1;
     }
-    ob[0] = (uint32_t)ob.size();
     return FWGPU_OK;
 }
+
+// parser.rs:214-461 next_vowpal_to_size.  `p[0..size)` is the line as read by read_until('\n') (newline included when
+// present).  Mirrors the reference's scanning literally, including `rowlen = size - 1` whether or not the last byte is
+// a newline.  The buffer is padded so the reference's one-past reads (`*p.add(i_end)` with i_end == rowlen) are defined.
+static int parse_line(fwgpu_parser *ps, const char *line, size_t size) {
+    // `line` has at least one readable byte after `size` (callers copy the rare line that does not)
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(line);
+    const size_t rowlen = size - 1;  // "ignore last newline byte"
+    size_t pos = 0;
+    int rc = parse_head(ps, p, size, rowlen, &pos);
+    if (rc != FWGPU_OK) return rc;
+    NsState st;
+    rc = parse_body(ps, p, rowlen, pos, rowlen, st);
+    if (rc != FWGPU_OK) return rc;
+    ps->out[0] = (uint32_t)ps->out.size();
+    return FWGPU_OK;
+}
+
+}  // namespace fwgpu
+
+// A context line scanned once (fw_setup_cache), up to the last token boundary before its end: the record built so far and the
+// scanner's state there.  Requests then scan only `tail` + their own bytes.
+struct fwgpu_parse_prefix {
+    std::string text;           // the whole prefix (the fallback concatenates, like next_vowpal_with_cache)
+    bool resumable = false;
+    std::string tail;           // prefix bytes from the resume point on
+    std::vector<uint32_t> ob;   // output buffer at the resume point
+    fwgpu::NsState st;
+};
+
+namespace fwgpu {
 
 bool vwmap_source_equal(const fwgpu_vwmap *a, const fwgpu_vwmap *b) {  // VwNamespaceMapSource: derive(PartialEq)
     if (a->skip_prefix != b->skip_prefix || a->entries.size() != b->entries.size()) return false;
@@ -499,6 +545,86 @@ int fwgpu_parser_parse_with_prefix(fwgpu_parser *p, const char *prefix, uint64_t
     std::string s(prefix ? prefix : "", prefix ? prefix_len : 0);
     s.append(line ? line : "", line ? len : 0);
     return fwgpu_parser_parse_line(p, s.data(), s.size(), out, cap, n_words);
+}
+
+// next_vowpal_with_cache (parser.rs:195-211) without scanning the context again for every request.  The scanner is a
+// left-to-right state machine over tokens that end at a space, and everything it knows between two tokens is `NsState` + the
+// output buffer; so the context is scanned once up to its last token boundary whose token ended at a space INSIDE the context
+// (a last token that runs to the context's end may continue in the request), and a request resumes from there over the
+// context's remaining bytes + its own.  Contexts the head of the scanner does not leave inside the context (no '|', a
+// command, an error) are not resumable and take the concatenating route; so does an empty request.
+int fwgpu_parse_prefix_create(fwgpu_parser *p, const char *prefix, uint64_t len, fwgpu_parse_prefix **out) {
+    if (!p || !out || (!prefix && len)) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    auto px = std::make_unique<fwgpu_parse_prefix>();
+    px->text.assign(prefix ? prefix : "", len);
+    *out = nullptr;
+    if (len && (prefix[0] == 0x31 || prefix[0] == 0x2d || prefix[0] == 0x7c)) {
+        p->scratch.assign(prefix, len);
+        p->scratch.push_back('\0');
+        const unsigned char *q = reinterpret_cast<const unsigned char *>(p->scratch.data());
+        const size_t rowlen = len;  // as if more bytes followed: the request's
+        size_t pos = 0;
+        int rc = FWGPU_ERR_PARSE;
+        try {
+            rc = parse_head(p, q, len, rowlen, &pos);
+        } catch (const std::exception &) {
+        }
+        if (rc == FWGPU_OK && pos < len && q[pos] == 0x7c) {
+            // token boundaries of the feature loop: the last one whose token (and every one before it) ended at a space
+            size_t top = pos, i = pos;
+            for (;;) {
+                while (q[i] == 0x20 && i < rowlen) i++;
+                while (q[i] != 0x20 && i < rowlen) i++;
+                if (i >= rowlen) break;
+                i += 1;
+                top = i;
+            }
+            fwgpu::NsState st;
+            try {
+                rc = parse_body(p, q, rowlen, pos, top, st);
+            } catch (const std::exception &) {
+                rc = FWGPU_ERR_PARSE;
+            }
+            if (rc == FWGPU_OK) {
+                px->resumable = true;
+                px->tail.assign(prefix + top, len - top);
+                px->ob = p->out;
+                px->st = st;
+            }
+        }
+    }
+    *out = px.release();
+    return FWGPU_OK;
+}
+
+void fwgpu_parse_prefix_free(fwgpu_parse_prefix *px) { delete px; }
+
+int fwgpu_parse_prefix_resumable(const fwgpu_parse_prefix *px) { return px && px->resumable; }
+
+int fwgpu_parser_parse_after_prefix(fwgpu_parser *p, const fwgpu_parse_prefix *px, const char *line, uint64_t len, uint32_t *out,
+                                    uint32_t cap, uint32_t *n_words) {
+    if (!p || !px || !n_words || (!line && len)) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    if (!px->resumable || len == 0) return fwgpu_parser_parse_with_prefix(p, px->text.data(), px->text.size(), line, len, out, cap, n_words);
+    *n_words = 0;
+    p->scratch.assign(px->tail);
+    p->scratch.append(line, len);
+    p->scratch.push_back('\0');
+    const size_t size = px->tail.size() + len;
+    p->out = px->ob;
+    fwgpu::NsState st = px->st;
+    int rc;
+    try {
+        rc = parse_body(p, reinterpret_cast<const unsigned char *>(p->scratch.data()), size - 1, 0, size - 1, st);
+    } catch (const std::exception &e) {
+        return fail(FWGPU_ERR_PARSE, std::string("Cannot parse an example: ") + e.what());
+    }
+    if (rc != FWGPU_OK) return rc;
+    p->out[0] = (uint32_t)p->out.size();
+    *n_words = (uint32_t)p->out.size();
+    if (!out) return FWGPU_OK;
+    if (cap < p->out.size()) return fail(FWGPU_ERR_RANGE, "record buffer too small");
+    std::memcpy(out, p->out.data(), p->out.size() * 4);
+    return FWGPU_OK;
 }
 
 int fwgpu_debug_format_f32(float v, char *buf, uint32_t cap) {

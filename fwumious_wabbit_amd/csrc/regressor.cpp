@@ -368,6 +368,7 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
     if (!update && b->cache) {  // predict_with_cache: the field sums start from the cached features' (regressor.rs:397-407)
         p.ctx_T = b->cache->d_T;
         p.ctx_dcf = b->cache->d_dcf;
+        if (b->records) p.ctx_cover = b->cache->d_cover;
     }
     if (!update) {
         p.emit_T = b->emit_T;
@@ -1044,6 +1045,7 @@ int fwgpu_setup_cache(fwgpu_regressor *r, const fwgpu_lr_entry *lr, uint32_t n_l
 
 int fwgpu_block_cache_free(fwgpu_block_cache *c) {
     if (!c) return FWGPU_OK;
+    if (c->d_cover) (void)hipFree(c->d_cover);
     if (c->d_T) (void)hipFree(c->d_T);
     delete c;
     return FWGPU_OK;
@@ -1085,12 +1087,79 @@ int fwgpu_predict_with_cache(fwgpu_regressor *r, const fwgpu_block_cache *c, con
     return one_prediction(r, prediction);
 }
 
-// Predict-only launches of this batch start every example's field sums from the cache (NULL detaches it): the batch must
-// then hold only the entries fwgpu_block_cache_filter leaves.
+static inline uint32_t present_bit(uint64_t key) { return (uint32_t)((key * 0x9e3779b97f4a7c15ULL) >> 52); }  // 12 bits
+
+// Record batches with a context cache.  `record` is the context's own record (what fw_setup_cache parsed): the namespace
+// slots it fills are the covered ones.  A request's record (context + candidate, parser.rs:195-211) then goes to the device
+// whole, and the stage phase leaves out the FFM features of covered slots -- which are exactly the features
+// fwgpu_block_cache_filter drops, PROVIDED the request passes fwgpu_block_cache_record_ok.
+int fwgpu_block_cache_cover_record(fwgpu_block_cache *c, const fwgpu_translator_config *t, const uint32_t *record, uint32_t len) {
+    if (!c || !t || !record) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    uint32_t nl = 0, nf = 0;
+    int rc = count_record(t, record, len, &nl, &nf);
+    if (rc) return rc;
+    uint32_t max_ns = 0;
+    for (uint32_t m = 0; m < t->field_off[t->n_fields]; m++) max_ns = std::max(max_ns, t->field_ns[m]);
+    const uint32_t n_slots = std::min<uint32_t>(len > 3 ? len - 3 : 0, max_ns + 1);
+    c->cover.assign((max_ns + 32) / 32, 0);
+    c->ctx_slots.assign(record + 3, record + 3 + n_slots);
+    for (uint32_t ns = 0; ns < n_slots; ns++)
+        if (record[3 + ns] != 0x80000000u) c->cover[ns >> 5] |= 1u << (ns & 31);  // NO_FEATURES (parser.rs:19)
+    FWGPU_HIP(hipSetDevice(c->owner->device));
+    if (c->d_cover) (void)hipFree(c->d_cover);
+    c->d_cover = nullptr;
+    FWGPU_HIP(hipMalloc((void **)&c->d_cover, c->cover.size() * 4));
+    FWGPU_HIP(hipMemcpy(c->d_cover, c->cover.data(), c->cover.size() * 4, hipMemcpyHostToDevice));
+    c->present_bits.assign(64, 0);
+    for (uint64_t key : c->present) {
+        const uint32_t b = present_bit(key);
+        c->present_bits[b >> 6] |= 1ull << (b & 63);
+    }
+    return FWGPU_OK;
+}
+
+// 1 when leaving out the covered slots of this request's record is what fwgpu_block_cache_filter would do with its
+// translation: the request has not rewritten a covered slot (a namespace named again replaces the context's features in the
+// record, parser.rs:318-326, while the cache still holds them), and none of its own FFM features equals a cached one
+// (hash and field: the filter would drop it).  0: take the entry route (translate, filter) for this request.
+int fwgpu_block_cache_record_ok(const fwgpu_block_cache *c, const fwgpu_translator_config *t, const uint32_t *record, uint32_t len) {
+    if (!c || !t || !record || !c->d_cover) return 0;
+    const uint32_t n_slots = (uint32_t)c->ctx_slots.size();
+    if (len < 3 + n_slots) return 0;
+    for (uint32_t ns = 0; ns < n_slots; ns++)
+        if (((c->cover[ns >> 5] >> (ns & 31)) & 1u) && record[3 + ns] != c->ctx_slots[ns]) return 0;
+    const uint32_t ffm_mask = ffm_hash_mask(t->ffm_bit_precision, t->ffm_k);
+    for (uint32_t f = 0; f < t->n_fields; f++)
+        for (uint32_t m = t->field_off[f]; m < t->field_off[f + 1]; m++) {
+            const uint32_t ns = t->field_ns[m];
+            if (3 + ns >= len) return 0;
+            if (ns < n_slots && ((c->cover[ns >> 5] >> (ns & 31)) & 1u)) continue;
+            const uint32_t w = record[3 + ns];
+            auto hit = [&](uint32_t hash) {
+                const uint64_t key = ((uint64_t)(hash & ffm_mask) << 32) | (f * t->ffm_k);
+                const uint32_t b = present_bit(key);
+                return ((c->present_bits[b >> 6] >> (b & 63)) & 1ull) && std::binary_search(c->present.begin(), c->present.end(), key);
+            };
+            if (!(w & 0x80000000u)) {
+                if (hit(w)) return 0;
+                continue;
+            }
+            const uint32_t start = (w >> 16) & 0x3fff, end = w & 0xffff;
+            if (end > len || end < start) return 0;
+            for (uint32_t o = start; o + 1 < end; o += 2)
+                if (hit(record[o])) return 0;
+        }
+    return 1;
+}
+
+// Predict-only launches of this batch start every example's field sums from the cache (NULL detaches it): an entry batch must
+// then hold only the entries fwgpu_block_cache_filter leaves; a record batch holds whole requests that pass
+// fwgpu_block_cache_record_ok, and the cache must know the context's record (fwgpu_block_cache_cover_record).
 int fwgpu_batch_set_cache(fwgpu_batch *b, const fwgpu_block_cache *c) {
     if (!b) return fail(FWGPU_ERR_INVALID, "NULL batch");
     if (c && c->owner != b->owner) return fail(FWGPU_ERR_INVALID, "cache belongs to another regressor");
-    if (c && b->records) return fail(FWGPU_ERR_INVALID, "a context cache needs an entry batch (records are translated whole on the device)");
+    if (c && b->records && !c->d_cover)
+        return fail(FWGPU_ERR_INVALID, "a record batch needs a context cache that knows the context's record (fwgpu_block_cache_cover_record)");
     b->cache = c;
     return FWGPU_OK;
 }

@@ -2,11 +2,15 @@
 // fw_predict, fw_predict_with_cache, fw_setup_cache, free_predictor -- a binary that links libfw.so can link this library
 // instead.  Each call parses the VW text, translates the record and runs the example kernel on the device.
 //
-// Context cache (lib.rs:88-148, block_ffm.rs:442-782, block_lr.rs:165-255): fw_setup_cache translates the context line and
-// has the device compute its features' field sums once (fwgpu_setup_cache); fw_predict_with_cache parses context + candidate
-// (the very line the reference reassembles in next_vowpal_with_cache, parser.rs:195-211), translates it on the host and ships
-// only the entries that are not in the cache; fwgpu_predictor_predict_batch does that for all candidates of a request in one
-// launch.  Models with a deep head keep the uncached route (whole line scored), which gives the same result.
+// Context cache (lib.rs:88-148, block_ffm.rs:442-782, block_lr.rs:165-255): fw_setup_cache scans the context line once
+// (fwgpu_parse_prefix: a request's scan resumes at the context's last token boundary instead of going over the context's text
+// again, and gives the very record next_vowpal_with_cache builds from context + candidate, parser.rs:195-211), translates it
+// and has the device compute its features' field sums once (fwgpu_setup_cache).  fw_predict_with_cache translates the request's
+// record on the host and ships only the entries that are not in the cache.  fwgpu_predictor_predict_batch sends all candidates
+// of a request in one launch, as records: the kernel's own translation leaves out the namespaces the cache covers
+// (fwgpu_block_cache_cover_record); a request in which some candidate names a context namespace again, or carries a feature
+// equal to a cached one, takes the entry route (host translation + fwgpu_block_cache_filter), which is the reference's rule
+// for those.  Models with a deep head keep the uncached route (whole line scored), which gives the same result.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -74,16 +78,46 @@ std::vector<std::string> shell_split(const char *s) {
 
 }  // namespace
 
+// one parser thread's share of a batched request (kept between requests: no fresh pages to fault in, no parser to build)
+struct Part {
+    std::vector<uint32_t> words;
+    std::vector<uint64_t> len;
+    std::vector<uint32_t> slot;
+    // entry route: translated on the host, filtered (forward_with_cache gathers only what features_present lacks)
+    HostBatch hb;
+    bool hb_ok = true;
+    RecordStats stats;  // record route: what record_batch_upload would otherwise count again, serially
+    bool stats_ok = true;
+    bool entry_route = false;  // some candidate of this slice is not covered record-wise (fwgpu_block_cache_record_ok)
+    fwgpu_parser *parser = nullptr;  // VowpalParser is not thread safe (clone_lite's reason): one per thread
+    std::vector<uint32_t> rec;
+    void reset() {
+        words.clear();
+        len.clear();
+        slot.clear();
+        hb.clear();
+        hb_ok = stats_ok = true;
+        entry_route = false;
+        stats = RecordStats();
+    }
+    ~Part() {
+        if (parser) fwgpu_parser_free(parser);
+    }
+};
+
 struct FfiPredictor {
     std::shared_ptr<SharedModel> model;
+    std::vector<std::unique_ptr<Part>> parts;
     fwgpu_parser *parser = nullptr;
     std::string cached_text;  // PredictorCache.input_buffer_size bytes of the context line (lib.rs:64-67)
+    fwgpu_parse_prefix *prefix = nullptr;  // the same bytes, scanned
     bool has_cache = false;
     fwgpu_block_cache *cache = nullptr;  // PredictorCache.blocks: the context's field sums, on the device
     std::vector<uint32_t> record;
     std::vector<fwgpu_lr_entry> lr;
     std::vector<fwgpu_ffm_entry> ffm;
     ~FfiPredictor() {
+        if (prefix) fwgpu_parse_prefix_free(prefix);
         if (parser) fwgpu_parser_free(parser);
         if (cache) fwgpu_block_cache_free(cache);
     }
@@ -100,7 +134,9 @@ float predict_line(FfiPredictor *p, const char *prefix, size_t prefix_len, const
     p->record.resize(std::max<size_t>(p->record.size(), 4096));
     int rc;
     for (;;) {
-        rc = fwgpu_parser_parse_with_prefix(p->parser, prefix, prefix_len, text, len, p->record.data(), (uint32_t)p->record.size(), &n_words);
+        rc = prefix && p->prefix
+                 ? fwgpu_parser_parse_after_prefix(p->parser, p->prefix, text, len, p->record.data(), (uint32_t)p->record.size(), &n_words)
+                 : fwgpu_parser_parse_with_prefix(p->parser, prefix, prefix_len, text, len, p->record.data(), (uint32_t)p->record.size(), &n_words);
         if (rc == FWGPU_ERR_RANGE && p->record.size() < (1u << 24)) {
             p->record.resize(p->record.size() * 4);
             continue;
@@ -206,6 +242,9 @@ float fw_setup_cache(FfiPredictor *ptr, const char *input_buffer) {  // lib.rs:2
     if (len && input_buffer[len - 1] == '\n') len -= 1;  // "ignore last newline byte" (parser.rs:184-193)
     ptr->cached_text.assign(input_buffer, len);
     ptr->has_cache = true;
+    if (ptr->prefix) fwgpu_parse_prefix_free(ptr->prefix);
+    ptr->prefix = nullptr;
+    if (fwgpu_parse_prefix_create(ptr->parser, ptr->cached_text.data(), ptr->cached_text.size(), &ptr->prefix) != FWGPU_OK) return kExceptionErrorCode;
     SharedModel &m = *ptr->model;
     if (m.re->nn.n_layers == 0 && m.re->cfg.ffm_k != 0) {
         // translate_and_filter(buffer, 0, Some(Primitive)) + Regressor::setup_cache (lib.rs:133-146); every namespace this
@@ -215,6 +254,7 @@ float fw_setup_cache(FfiPredictor *ptr, const char *input_buffer) {  // lib.rs:2
         if (translate_record(&m.tr, ptr->record.data(), n_words, ptr->lr, ptr->ffm, &label, &imp) != FWGPU_OK) return kExceptionErrorCode;
         if (fwgpu_setup_cache(m.re, ptr->lr.data(), (uint32_t)ptr->lr.size(), ptr->ffm.data(), (uint32_t)ptr->ffm.size(), &ptr->cache) != FWGPU_OK)
             return kExceptionErrorCode;
+        if (fwgpu_block_cache_cover_record(ptr->cache, &m.tr, ptr->record.data(), n_words) != FWGPU_OK) return kExceptionErrorCode;
     }
     return 0.0f;
 }
@@ -232,25 +272,17 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
     if (!ptr || (!inputs && n) || (!out && n)) return fail(FWGPU_ERR_INVALID, "NULL argument");
     SharedModel &m = *ptr->model;
     // parse on a few host threads (each with its own parser: VowpalParser is not thread safe, clone_lite's reason)
-    // (FWGPU_SERVING_THREADS overrides; by default one thread per 512 lines, up to the cores there are and at most 32)
+    // (FWGPU_SERVING_THREADS overrides; by default one thread per 128 lines, up to the cores there are and at most 32)
     unsigned T = 1;
     if (n >= 256) {
         const char *env = std::getenv("FWGPU_SERVING_THREADS");
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        T = env && std::atoi(env) > 0 ? (unsigned)std::atoi(env) : std::min<unsigned>(std::min<unsigned>(32, hw), std::max<unsigned>(1, n / 512));
+        T = env && std::atoi(env) > 0 ? (unsigned)std::atoi(env) : std::min<unsigned>(std::min<unsigned>(32, hw), std::max<unsigned>(1, n / 128));
         T = std::min<unsigned>(T, 64);
     }
     const bool cached = with_cache && ptr->cache;  // candidates reduced to the entries the context cache does not cover
-    struct Part {
-        std::vector<uint32_t> words;
-        std::vector<uint64_t> len;
-        std::vector<uint32_t> slot;
-        // cached route: translated on the host, filtered (forward_with_cache gathers only what features_present lacks)
-        HostBatch hb;
-        bool hb_ok = true;
-        RecordStats stats;  // uncached route: what record_batch_upload would otherwise count again, serially
-        bool stats_ok = true;
-    };
+    // records + the kernel's own translation, unless a candidate turns out to need the entry route (FWGPU_SERVING_ENTRY_ROUTE=1 forces that one)
+    bool by_record = cached && !std::getenv("FWGPU_SERVING_ENTRY_ROUTE");
     const bool timing = std::getenv("FWGPU_SERVING_TIMING") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -258,18 +290,17 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
             std::fprintf(stderr, "[predict_batch] %-10s %.3f ms since entry\n", what,
                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     };
-    std::vector<Part> parts(T);
+    while (ptr->parts.size() < T) ptr->parts.push_back(std::make_unique<Part>());
+    std::vector<Part *> parts(T);
+    for (unsigned k = 0; k < T; k++) parts[k] = ptr->parts[k].get();
     for (uint32_t i = 0; i < n; i++) out[i] = kExceptionErrorCode;  // a worker that cannot start leaves its slice marked
     auto work = [&](unsigned k) {
-        fwgpu_parser *parser = ptr->parser;
-        fwgpu_parser *own = nullptr;
-        if (k > 0) {
-            if (fwgpu_parser_create(m.vw, &own) != FWGPU_OK) return;
-            parser = own;
-        }
-        Part &pt = parts[k];
-        pt.hb.clear();
-        std::vector<uint32_t> rec(4096);
+        Part &pt = *parts[k];
+        pt.reset();
+        if (!pt.parser && fwgpu_parser_create(m.vw, &pt.parser) != FWGPU_OK) return;
+        fwgpu_parser *parser = pt.parser;
+        std::vector<uint32_t> &rec = pt.rec;
+        if (rec.size() < 4096) rec.resize(4096);
         std::vector<fwgpu_lr_entry> t_lr;
         std::vector<fwgpu_ffm_entry> t_ffm;
         const uint32_t a = (uint32_t)((uint64_t)n * k / T), e = (uint32_t)((uint64_t)n * (k + 1) / T);
@@ -279,9 +310,11 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
             uint32_t nw = 0;
             int rc;
             for (;;) {
-                rc = fwgpu_parser_parse_with_prefix(parser, with_cache ? ptr->cached_text.data() : nullptr,
-                                                    with_cache ? ptr->cached_text.size() : 0, inputs[i], std::strlen(inputs[i]),
-                                                    rec.data(), (uint32_t)rec.size(), &nw);
+                rc = with_cache && ptr->prefix
+                         ? fwgpu_parser_parse_after_prefix(parser, ptr->prefix, inputs[i], std::strlen(inputs[i]), rec.data(), (uint32_t)rec.size(), &nw)
+                         : fwgpu_parser_parse_with_prefix(parser, with_cache ? ptr->cached_text.data() : nullptr,
+                                                          with_cache ? ptr->cached_text.size() : 0, inputs[i], std::strlen(inputs[i]),
+                                                          rec.data(), (uint32_t)rec.size(), &nw);
                 if (rc == FWGPU_ERR_RANGE && rec.size() < (1u << 24)) {
                     rec.resize(rec.size() * 4);
                     continue;
@@ -293,7 +326,11 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
                 continue;
             }
             rec[1] = 0;  // a request carries no label (NO_LABEL = 0xff); the prediction does not depend on it
-            if (cached) {
+            if (by_record && !fwgpu_block_cache_record_ok(ptr->cache, &m.tr, rec.data(), nw)) {
+                pt.entry_route = true;
+                break;  // the whole request goes again, by entries
+            }
+            if (cached && !by_record) {
                 float label, imp;
                 if (translate_record(&m.tr, rec.data(), nw, t_lr, t_ffm, &label, &imp) != FWGPU_OK) continue;
                 uint32_t kept = 0;
@@ -319,64 +356,47 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
             pt.len.push_back(nw);
             pt.slot.push_back(i);
         }
-        if (own) fwgpu_parser_free(own);
     };
-    {
+    for (;;) {
         std::vector<std::thread> th;
         for (unsigned k = 1; k < T; k++) th.emplace_back(work, k);
         work(0);
         for (auto &x : th) x.join();
+        bool again = false;
+        for (const Part *pt : parts) again = again || pt->entry_route;
+        if (!again) break;
+        by_record = false;
     }
     lap("parsed");
-    std::vector<uint32_t> words;
     std::vector<uint64_t> off(1, 0);
     std::vector<uint32_t> slot;  // which input each record belongs to
     RecordStats stats;
     bool stats_ok = true;
-    {
-        size_t tw = 0;
-        for (const Part &pt : parts) tw += pt.words.size();
-        words.reserve(tw);
-    }
-    {
-        std::vector<size_t> wbase(parts.size());
-        size_t tw = 0;
-        for (size_t q = 0; q < parts.size(); q++) {
-            wbase[q] = tw;
-            tw += parts[q].words.size();
-        }
-        words.resize(tw);
-        std::vector<std::thread> th;
-        auto copy = [&](size_t q) {
-            if (!parts[q].words.empty()) std::memcpy(words.data() + wbase[q], parts[q].words.data(), parts[q].words.size() * 4);
-        };
-        if (tw) {
-            for (size_t q = 1; q < parts.size(); q++) th.emplace_back(copy, q);
-            copy(0);
-            for (auto &x : th) x.join();
-        }
-    }
-    for (const Part &pt : parts) {
+    std::vector<size_t> wbase(parts.size() + 1, 0);
+    for (size_t q = 0; q < parts.size(); q++) {
+        const Part &pt = *parts[q];
+        wbase[q + 1] = wbase[q] + pt.words.size();
         for (uint64_t l : pt.len) off.push_back(off.back() + l);
         slot.insert(slot.end(), pt.slot.begin(), pt.slot.end());
         stats.merge(pt.stats);
         stats_ok = stats_ok && pt.stats_ok;
     }
+    const size_t total_words = wbase[parts.size()];
     lap("merged");
     if (slot.empty()) return FWGPU_OK;
     std::lock_guard<std::mutex> g(m.mu);
     const uint32_t nrec = (uint32_t)slot.size();
-    if (cached) {  // one entry batch, every example starting from the cached field sums
+    if (cached && !by_record) {  // one entry batch, every example starting from the cached field sums
         HostBatch hb;
         hb.clear();
         {   // the parts' SoA arrays land in one host batch at their offsets (copied by one thread per part), example offsets rebased
             const size_t P = parts.size();
             std::vector<size_t> fb(P + 1, 0), lb(P + 1, 0), eb_(P + 1, 0);
             for (size_t q = 0; q < P; q++) {
-                if (!parts[q].hb_ok) return fail(FWGPU_ERR_RANGE, "predict_batch: a candidate's entries were refused (see append_example)");
-                fb[q + 1] = fb[q] + parts[q].hb.ffm_hash.size();
-                lb[q + 1] = lb[q] + parts[q].hb.lr_hash.size();
-                eb_[q + 1] = eb_[q] + parts[q].hb.label.size();
+                if (!parts[q]->hb_ok) return fail(FWGPU_ERR_RANGE, "predict_batch: a candidate's entries were refused (see append_example)");
+                fb[q + 1] = fb[q] + parts[q]->hb.ffm_hash.size();
+                lb[q + 1] = lb[q] + parts[q]->hb.lr_hash.size();
+                eb_[q + 1] = eb_[q] + parts[q]->hb.label.size();
             }
             hb.ffm_hash.resize(fb[P]);
             hb.ffm_val.resize(fb[P]);
@@ -390,7 +410,7 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
             hb.lr_off.resize(eb_[P] + 1);
             hb.ffm_off[0] = hb.lr_off[0] = 0;
             auto put = [&](size_t q) {
-                const HostBatch &src = parts[q].hb;
+                const HostBatch &src = parts[q]->hb;
                 auto cp = [](auto &dst, size_t at, const auto &from) {
                     if (!from.empty()) std::memcpy(dst.data() + at, from.data(), from.size() * sizeof(from[0]));
                 };
@@ -409,10 +429,10 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
             for (size_t q = 1; q < P; q++) th.emplace_back(put, q);
             put(0);
             for (auto &x : th) x.join();
-            for (const Part &pt : parts) {
-                hb.max_lr = std::max(hb.max_lr, pt.hb.max_lr);
-                hb.max_ffm = std::max(hb.max_ffm, pt.hb.max_ffm);
-                hb.aligned4 = hb.aligned4 && pt.hb.aligned4;
+            for (const Part *pt : parts) {
+                hb.max_lr = std::max(hb.max_lr, pt->hb.max_lr);
+                hb.max_ffm = std::max(hb.max_ffm, pt->hb.max_ffm);
+                hb.aligned4 = hb.aligned4 && pt->hb.aligned4;
             }
         }
         lap("batched");
@@ -430,19 +450,44 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
         lap("predicted");
         return FWGPU_OK;
     }
-    if (!m.batch || m.batch->n_cap < nrec || m.batch->words_cap < words.size()) {
+    if (!m.batch || m.batch->n_cap < nrec || m.batch->words_cap < total_words) {
         if (m.batch) fwgpu_batch_free(m.batch);
         m.batch = nullptr;
-        int rc0 = record_batch_alloc(m.re, &m.tr, std::max<uint32_t>(nrec * 2, 256), std::max<uint64_t>(words.size() * 2, 1 << 16), &m.batch);
+        int rc0 = record_batch_alloc(m.re, &m.tr, std::max<uint32_t>(nrec * 2, 256), std::max<uint64_t>(total_words * 2, 1 << 16), &m.batch);
         if (rc0 != FWGPU_OK) return rc0;
     }
     fwgpu_batch *b = m.batch;
-    int rc = record_batch_upload(b, &m.tr, words.data(), off.data(), nrec, 0, stats_ok ? &stats : nullptr);
+    int rc = FWGPU_OK;
+    if (stats_ok) {
+        // every thread's records go to the device from where the thread left them (no merged host copy); the threads
+        // counted and validated their records as they parsed (what record_batch_upload would do again, serially)
+        for (size_t q = 0; q < parts.size() && rc == FWGPU_OK; q++)
+            if (!parts[q]->words.empty() &&
+                hipMemcpyAsync(b->records + wbase[q], parts[q]->words.data(), parts[q]->words.size() * 4, hipMemcpyHostToDevice, nullptr) != hipSuccess)
+                rc = fail(FWGPU_ERR_DEVICE, "predict_batch: copy to the device failed");
+        if (rc == FWGPU_OK && hipMemcpyAsync(b->rec_off, off.data(), ((size_t)nrec + 1) * 8, hipMemcpyHostToDevice, nullptr) != hipSuccess)
+            rc = fail(FWGPU_ERR_DEVICE, "predict_batch: copy to the device failed");
+        b->n = nrec;
+        b->n_lr = stats.tot_lr;
+        b->n_ffm = stats.tot_ffm;
+        b->n_words = total_words;
+        b->max_lr = m.re->cfg.wiring == FWGPU_WIRING_FFM_ONLY ? 0 : stats.max_lr;
+        b->max_ffm = stats.max_ffm;
+        b->max_rec = stats.max_rec;
+        b->aligned4 = true;
+    } else {  // some record did not validate: one host copy, and record_batch_upload says which and why
+        std::vector<uint32_t> words(total_words);
+        for (size_t q = 0; q < parts.size(); q++)
+            if (!parts[q]->words.empty()) std::memcpy(words.data() + wbase[q], parts[q]->words.data(), parts[q]->words.size() * 4);
+        rc = record_batch_upload(b, &m.tr, words.data(), off.data(), nrec, 0, nullptr);
+    }
     if (rc != FWGPU_OK) return rc;
     lap("uploaded");
-    rc = fwgpu_learn_batch(m.re, b, FWGPU_MODE_HOGWILD, /*update=*/0, nullptr);
+    if (by_record) rc = fwgpu_batch_set_cache(b, ptr->cache);  // the kernel's translation leaves the covered namespaces out
+    if (rc == FWGPU_OK) rc = fwgpu_learn_batch(m.re, b, FWGPU_MODE_HOGWILD, /*update=*/0, nullptr);
     std::vector<float> preds(slot.size());
     if (rc == FWGPU_OK) rc = fwgpu_batch_predictions(b, preds.data(), (uint32_t)preds.size(), nullptr);
+    (void)fwgpu_batch_set_cache(b, nullptr);
     if (rc != FWGPU_OK) return rc;
     for (size_t j = 0; j < slot.size(); j++) out[slot[j]] = preds[j];
     lap("predicted");

@@ -98,6 +98,16 @@ class VowpalParser:
                                                    self._buf.size, C.byref(n))
         return self._result(rc, n)
 
+    def scan_context(self, cached: bytes) -> "ParsePrefix":
+        """The context line scanned once; `next_vowpal_after` then equals next_vowpal_with_cache(cached, line)."""
+        return ParsePrefix(self, cached)
+
+    def next_vowpal_after(self, prefix: "ParsePrefix", line: bytes) -> np.ndarray:
+        n = C.c_uint32()
+        rc = self.L.fwgpu_parser_parse_after_prefix(self.h, prefix.h, line, len(line), capi.ptr(self._buf), self._buf.size,
+                                                    C.byref(n))
+        return self._result(rc, n)
+
     def parse_buffer(self, text: bytes, max_records=1 << 20, words_cap=None):
         """Many lines -> (records u32[], rec_off u64[n+1], bytes consumed, status).  Stops at the first line that is
         not an example; status is OK / PARSE_FLUSH / PARSE_HOGWILD_LOAD / ERR_PARSE."""
@@ -112,6 +122,28 @@ class VowpalParser:
     def close(self):
         if self.h:
             self.L.fwgpu_parser_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ParsePrefix:
+    def __init__(self, parser: VowpalParser, cached: bytes):
+        self.L = capi.lib()
+        self.h = C.c_void_p()
+        capi.check(self.L.fwgpu_parse_prefix_create(parser.h, cached, len(cached), C.byref(self.h)))
+
+    @property
+    def resumable(self) -> bool:
+        return bool(self.L.fwgpu_parse_prefix_resumable(self.h))
+
+    def close(self):
+        if self.h:
+            self.L.fwgpu_parse_prefix_free(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

@@ -135,6 +135,14 @@ int fwgpu_predict_with_cache(fwgpu_regressor *r, const fwgpu_block_cache *cache,
 int fwgpu_block_cache_filter(const fwgpu_block_cache *cache, const fwgpu_ffm_entry *ffm, uint32_t n_ffm, fwgpu_ffm_entry *out,
                        uint32_t *n_out);
 int fwgpu_block_cache_free(fwgpu_block_cache *cache);
+/* Record batches with the cache: the context's own record marks its namespace slots as covered; the record of a request
+ * (context + candidate, parser.rs:195-211) then goes to the device whole and the example kernel's translation leaves the
+ * covered slots' FFM features out.  That equals fwgpu_block_cache_filter on the request's translation whenever
+ * fwgpu_block_cache_record_ok returns 1 (the request has not named a covered namespace again, and none of its own features
+ * has the hash and field of a cached one); a request for which it returns 0 takes the entry route. */
+struct fwgpu_translator_config;
+int fwgpu_block_cache_cover_record(fwgpu_block_cache *cache, const struct fwgpu_translator_config *t, const uint32_t *record, uint32_t len);
+int fwgpu_block_cache_record_ok(const fwgpu_block_cache *cache, const struct fwgpu_translator_config *t, const uint32_t *record, uint32_t len);
 
 /* ---------------------------------------------------------------- deep head (BASELINE config E)
  * fwgpu_set_nn <= the `--nn_layers / --nn N:width:W / --nn N:activation:relu / --nn N:init:hu / --nn_topology` part of
@@ -206,7 +214,8 @@ typedef struct fwgpu_split fwgpu_split;
 int fwgpu_split_create(fwgpu_regressor *r, uint32_t n_examples, uint32_t max_ffm_per_example, fwgpu_split **out);
 int fwgpu_split_free(fwgpu_split *sp);
 int fwgpu_learn_batch_sync(fwgpu_regressor *r, fwgpu_batch *b, fwgpu_split *sp, int mode, void *hip_stream);
-/* predict-only launches of an ENTRY batch start every example's field sums from this context cache (NULL detaches it) */
+/* predict-only launches of this batch start every example's field sums from this context cache (NULL detaches it); a record
+ * batch needs a cache that went through fwgpu_block_cache_cover_record */
 int fwgpu_batch_set_cache(fwgpu_batch *b, const fwgpu_block_cache *cache);
 /* Enqueue one pass over the batch on `stream`: for every example, Regressor::learn(fb, update)
  * (update=0: Regressor::predict).  Predictions land in the batch's device buffer. Asynchronous. */
@@ -414,6 +423,15 @@ void fwgpu_parser_free(fwgpu_parser *p);
 int fwgpu_parser_parse_line(fwgpu_parser *p, const char *line, uint64_t len, uint32_t *out, uint32_t cap, uint32_t *n_words);
 int fwgpu_parser_parse_with_prefix(fwgpu_parser *p, const char *prefix, uint64_t prefix_len, const char *line, uint64_t len,
                                    uint32_t *out, uint32_t cap, uint32_t *n_words);
+/* The same result as fwgpu_parser_parse_with_prefix(prefix, line) for every line, without scanning the context again per
+ * request (lib.rs:88-108 scans context + candidate every time): the context is scanned once up to its last token boundary,
+ * requests resume there.  Contexts that cannot be resumed (fwgpu_parse_prefix_resumable == 0) take the concatenating route. */
+typedef struct fwgpu_parse_prefix fwgpu_parse_prefix;
+int fwgpu_parse_prefix_create(fwgpu_parser *p, const char *prefix, uint64_t len, fwgpu_parse_prefix **out);
+void fwgpu_parse_prefix_free(fwgpu_parse_prefix *px);
+int fwgpu_parse_prefix_resumable(const fwgpu_parse_prefix *px);
+int fwgpu_parser_parse_after_prefix(fwgpu_parser *p, const fwgpu_parse_prefix *px, const char *line, uint64_t len, uint32_t *out,
+                                    uint32_t cap, uint32_t *n_words);
 const char *fwgpu_parser_command_argument(const fwgpu_parser *p);
 int fwgpu_parser_parse_buffer(fwgpu_parser *p, const char *text, uint64_t len, uint32_t *words, uint64_t words_cap,
                               uint64_t *rec_off, uint64_t max_records, uint64_t *n_records, uint64_t *n_words,

@@ -46,7 +46,7 @@ print(f"context {len(ctx.split()) - NCTX} features, candidates ~{np.mean([len(c.
       f"max |cached - concatenated| = {np.abs(got - want).max():.2e}; fw_setup_cache {t_setup * 1e6:.0f} us")
 full_c, cands_c = pr.encode_batch(full), pr.encode_batch(cands)  # the char** of a C / Rust caller (Python's str -> bytes is not the library's time)
 for name, fn in (("concatenation (whole lines, device translation)", lambda: pr.predict_batch(full_c)),
-                 ("device context cache (host translation + filter)", lambda: pr.predict_batch(cands_c, with_cache=True))):
+                 ("device context cache (context scanned once, records, kernel skips the cached namespaces)", lambda: pr.predict_batch(cands_c, with_cache=True))):
     fn()
     ts = []
     for _ in range(5):

@@ -44,6 +44,102 @@ def test_parser_reference_kats(group):
                 assert len(line.rstrip(b"\n")) == case["size"]
 
 
+def _parse_outcome(fn):
+    try:
+        return ("ok", fn().tolist())
+    except capi.FwgpuError as e:
+        return ("error", e.code, e.message)
+    except FlushCommand:
+        return ("flush",)
+    except HogwildLoadCommand as e:
+        return ("hogwild_load", e.filename)
+
+
+def test_scanned_context_equals_concatenation_reference_kats():
+    """next_vowpal_with_cache's cases (parser.rs:1142-1183) through the scan-once route."""
+    for group in KATS["groups"]:
+        rr = VowpalParser(VwNamespaceMap(group["vwmap"]))
+        for case in group["cases"]:
+            if "cached" in case and "record" in case:
+                px = rr.scan_context(case["cached"].encode())
+                assert rr.next_vowpal_after(px, case["line"].encode()).tolist() == case["record"], case
+
+
+def test_scanned_context_equals_concatenation_at_every_split():
+    """Every way of cutting a line into context + request gives what the concatenating parser gives: records, error messages
+    and commands alike (tokens cut in the middle, weights cut at the colon, cuts inside runs of spaces, before the first bar,
+    repeated namespaces on either side, float namespaces, a context that is itself an error)."""
+    vw = VwNamespaceMap("A,featureA\nB,featureB\nC,featureC,f32\nDD,featureD\n_namespace_skip_prefix,2\n")
+    rr = VowpalParser(vw)
+    lines = [
+        b"1 |A a b:2.5 c |B x  y |C  yy3.5 |DD:0.5 q r:3 \n",
+        b"-1 0.25 |B only |A  a:0.1  |A again |DD z\n",
+        b"|A a |B b |C zz1 zz2\n",
+        b"1 |A a:1.0e-3 |B:2 b c:4|x |DD  \n",
+        b"-1 3 |A |B |DD d\n",
+        b"1 |A a |Q nope |B b\n",          # unknown namespace: error wherever the cut is
+        b"1 |A a:notanumber |B b\n",       # bad weight
+        b"1 |C zzbad |A a\n",              # bad float in a float namespace
+        b"1 |C:2 zz1 |A a\n",              # weighted float namespace
+        b"1 abc |A a\n",                   # bad importance
+        b"1 -2 |A a\n",                    # negative importance
+        b"flush\n",
+        b"hogwild_load some/file.fw\n",
+        b"two tokens\n",
+        b"1 no bar at all\n",
+        b"1 |A a",                          # no newline: the last byte is dropped (parser.rs:264)
+        b"1 |A  a   ",
+    ]
+    resumable = 0
+    for line in lines:
+        for cut in range(len(line) + 1):
+            ctx, rest = line[:cut], line[cut:]
+            want = _parse_outcome(lambda: rr.next_vowpal_with_cache(ctx, rest))
+            px = rr.scan_context(ctx)
+            resumable += px.resumable
+            got = _parse_outcome(lambda: rr.next_vowpal_after(px, rest))
+            assert got == want, (line, cut, px.resumable)
+            # one scanned context serves many requests, and another parser of the same map
+            other = VowpalParser(vw)
+            assert _parse_outcome(lambda: other.next_vowpal_after(px, rest)) == want
+            assert _parse_outcome(lambda: rr.next_vowpal_after(px, rest)) == want
+    assert resumable > 100  # (the scan-once route is what most cuts take)
+
+
+def test_scanned_context_equals_concatenation_random_lines():
+    rng = np.random.default_rng(11)
+    names = ["A", "B", "C", "DD"]
+    vw = VwNamespaceMap("A,featureA\nB,featureB\nC,featureC,f32\nDD,featureD\n_namespace_skip_prefix,2\n")
+    rr = VowpalParser(vw)
+
+    def feature(ns):
+        if ns == "C":
+            return "zz%g" % rng.normal()
+        f = "f%d" % rng.integers(0, 50)
+        return f + (":%g" % rng.uniform(0.1, 3)) * bool(rng.random() < 0.3)
+
+    def part(nss):
+        out = ""
+        for ns in nss:
+            w = ":%g" % rng.uniform(0.5, 2) if (ns != "C" and rng.random() < 0.2) else ""
+            out += "|" + ns + w + " " * int(rng.integers(1, 3))
+            out += "".join(feature(ns) + " " * int(rng.integers(1, 3)) for _ in range(rng.integers(0, 5)))
+        return out
+
+    for _ in range(300):
+        order = list(rng.permutation(names))
+        k = int(rng.integers(0, 5))
+        ctx = (rng.choice(["1 ", "-1 ", "1 0.5 ", ""]) + part(order[:k])).encode()
+        if rng.random() < 0.3:
+            ctx = ctx.rstrip()  # the request then continues the context's last token
+        px = rr.scan_context(ctx)
+        for _ in range(4):
+            extra = list(rng.permutation(names))[: int(rng.integers(0, 4))]  # may repeat a namespace of the context
+            cand = (rng.choice(["", " ", "x "]) + part(order[k:] + extra) + rng.choice(["\n", ""])).encode()
+            want = _parse_outcome(lambda: rr.next_vowpal_with_cache(ctx, cand))
+            assert _parse_outcome(lambda: rr.next_vowpal_after(px, cand)) == want, (ctx, cand)
+
+
 def test_vwmap_reference_kats():
     for k in KATS["vwmap"]:
         if "error" in k:

@@ -242,6 +242,28 @@ def test_serving_ffi_matches_the_regressor(tmp_path):
     assert np.abs(with_cache - whole).max() < 2e-6
     assert np.abs(pr.predict_batch(cands, with_cache=True) - whole).max() < 2e-6
     assert np.array_equal(pr.predict_batch(cands, with_cache=True), with_cache)  # batched == single, same route
+    # the batched call sends records and lets the kernel's translation skip the cached namespaces; the entry route
+    # (host translation + features_present filter, what the single call does) gives the same numbers
+    os.environ["FWGPU_SERVING_ENTRY_ROUTE"] = "1"
+    try:
+        assert np.array_equal(pr.predict_batch(cands, with_cache=True), with_cache)
+    finally:
+        del os.environ["FWGPU_SERVING_ENTRY_ROUTE"]
+    big = [f"|A2 {i} {i + 1}:0.5 |A3 {i * 7}:1.5 |A4 {i % 11} |A5 {i % 3}\n" for i in range(3000)]  # several parser threads
+    assert np.array_equal(pr.predict_batch(big, with_cache=True), np.array([pr.predict_with_cache(c) for c in big], dtype=np.float32))
+    assert np.abs(pr.predict_batch(big, with_cache=True) - pr.predict_batch([ctx + c for c in big])).max() < 2e-6
+    # requests the record route must hand to the entry route: a candidate that names a context namespace again (its
+    # features replace the context's in the record while the cache still holds the context's, parser.rs:318-326) ...
+    again = cands[:5] + ["|A1 5 |A2 3\n"] + cands[5:10]
+    assert np.array_equal(pr.predict_batch(again, with_cache=True), np.array([pr.predict_with_cache(c) for c in again], dtype=np.float32))
+    # ... and a context whose last token the candidates continue ("|A1 9" + "9 |A2 ..." is the feature 99)
+    assert pr.setup_cache("|A0 17 23:0.5 |A1 9\n") == 0.0  # (the cached text ends before the newline, lib.rs:64-67)
+    glued = [f"9 |A2 {i} |A3 {i * 7}:1.5\n" for i in range(12)] + [" |A2 1\n", "|A2 1\n"]
+    single = np.array([pr.predict_with_cache(c) for c in glued], dtype=np.float32)
+    assert np.array_equal(pr.predict_batch(glued, with_cache=True), single)
+    assert abs(pr.predict_with_cache(glued[-2]) - pr.predict("|A0 17 23:0.5 |A1 9 |A2 1\n")) < 2e-6
+    assert pr.setup_cache(ctx + "\n") == 0.0
+    assert np.array_equal(pr.predict_batch(cands, with_cache=True), with_cache)
     # a clone shares the weights, has its own (empty) cache
     cl = pr.clone_lite()
     assert cl.predict(lines[0]) == want[0] and cl.predict_with_cache(cands[0]) == pr.predict(cands[0])
