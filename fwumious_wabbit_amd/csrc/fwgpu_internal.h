@@ -92,6 +92,8 @@ struct KernelParams {
     int32_t line_pass;         // ... and reads / writes back the WHOLE 128 B lines a row touches (0: float-granular accesses)
     uint32_t k_log2;           // log2(k) when k is a power of two, else 0xff
     int32_t no_chain;          // debug option 3: duplicate rows are serialised in phase B instead of chained (A/B runs)
+    uint32_t hot_lr_hash;      // hogwild launches: the LR entry every example holds (the constant feature's), see hot_lr_flush (kernels.hip)
+    uint32_t hot_lr_every;     // its pending steps reach the table every this many examples of a workgroup (0: off, plain read-modify-writes)
     int32_t chain;             // rows of the same hash inside one example are chained to the first and applied from registers (set with window)
     float lr_rate, lr_minus_power_t;    // SGD / AdagradFlex parameters of the LR block
     float ffm_rate, ffm_minus_power_t;  // ... of the FFM block
@@ -130,6 +132,7 @@ struct LaunchConfig {
     int32_t lut_global = 0;
     int32_t window = 1;              // whole-line FFM row updates: 0 off, 1 auto (tables > Infinity Cache), 2 always (debug option 2)
     int32_t no_chain = 0;            // debug option 3
+    uint32_t hot_lr_every = 32;      // debug option 4
     bool threads_set = false;
     uint32_t max_in_flight = 0;  // cap on the persistent grid = examples processed concurrently (0: what the device holds)  // fwgpu_set_launch chose the workgroup size: no automatic choice
 };

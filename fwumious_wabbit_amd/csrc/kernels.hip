@@ -131,7 +131,7 @@ struct Lds {
     uint32_t *tcnt;           // per (field,namespace) pair and per combo: entry count, then exclusive offset
     uint32_t *l_combo;        // combo slot of each LR entry (deep head only)
     float *nn;                // deep-head scratch: x[X], xg[X], h[sum_width], m[sum_width], l_prod[max_lr]
-    uint32_t *ctr;            // 8
+    uint32_t *ctr;            // 8 counters, then 3 floats: the hot LR entry's acc snapshot, pending weight delta, pending acc delta
 };
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -219,7 +219,7 @@ __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t ma
     off[8] = o; o = align16(o + 4 * (size_t)F);
     off[9] = o; o = align16(o + 4 * (size_t)F);
     off[10] = o; o = align16(o + 4 * 3 * 16);
-    off[11] = o; o = align16(o + 4 * 8);
+    off[11] = o; o = align16(o + 4 * 16);  // ctr[8] + hot LR entry state (hot_lr_*)
     off[12] = o; o = align16(o + 4 * (size_t)F);
     // The record copy and the two hash sets are only alive during the stage phase, T only from the end of the stage phase on:
     // when they fit they live INSIDE T's region (config C: 6.4 KB of 28.8 KB), which is what lets a third workgroup fit a CU.
@@ -833,13 +833,63 @@ __device__ __forceinline__ void nn_backward(const KernelParams &p, const Lds &s,
 // buffer order, on one register copy of {w, acc}: duplicates chain exactly like the reference's loop (regressor.rs:629-655
 // pins this).  The entry is read again here rather than kept from the forward pass: keeping it saved no time and widened
 // the hogwild read-modify-write window of hot entries (constant feature) by two phases.
+// The hot LR entry of a hogwild launch (the constant feature's: it is in every example, feature_buffer.rs:270-276).  Every
+// workgroup's read-modify-write of that one 8-byte entry goes to the memory side and they serialise there (measured: 60-80 ns
+// per write, which capped a 10-field model at 16 M examples/s and cost the headline config 1.6 %), and of the ~10 that overlap
+// at any moment only the last write survives.  So a workgroup keeps its steps on that entry in LDS -- optimizer steps taken
+// one by one on (acc snapshot + own pending acc), exactly the per-example arithmetic -- and every `hot_lr_every` examples the
+// thread that has just stepped it adds the pending deltas to the table with two float atomics (nothing is lost: the entry's
+// accumulator ends a launch at acc0 + the sum of all examples' g^2, which a test checks) and takes a fresh acc snapshot;
+// thread 0 flushes the rest when the workgroup leaves.  In-order launches (one workgroup, the bit-exact mode) and the phases of
+// the synchronous pipeline do not use it.  Measured (scripts/hot_lr_ab.sh): 10-field model 16 -> 49 M examples/s, LR-only
+// 11.8 -> 22 M, headline config +1.5 %, hold-out loss unchanged.
+// (The switch and the entry's hash sit in LDS next to the state, ctr[13] / ctr[12], so that nothing of this stays live in
+// scalar registers across the example loop: the v2 kernel has none to spare.)
+__device__ __forceinline__ float *hot_lr_state(const Lds &s) { return reinterpret_cast<float *>(s.ctr + 8); }
+__device__ __forceinline__ bool hot_lr_is(const Lds &s, uint32_t h) { return s.ctr[13] != 0 && h == s.ctr[12]; }
+template <bool COH>
+__device__ __forceinline__ void hot_lr_init(const KernelParams &p, const Lds &s, bool fused) {  // thread 0, before the example loop
+    const bool on = fused && COH && p.hot_lr_every != 0 && p.has_lr && p.update && gridDim.x > 1;
+    s.ctr[13] = on ? p.hot_lr_every : 0;
+    s.ctr[12] = p.hot_lr_hash;
+    s.ctr[7] = 0;
+    float *hot = hot_lr_state(s);
+    hot[0] = on ? lr_load<true>(p.lr, p.hot_lr_hash).y : 0.0f;
+    hot[1] = hot[2] = 0.0f;
+}
+// The pending deltas go to the table (taken out of LDS by exchange: a step another thread adds meanwhile stays pending).
+// Called by the thread that has just stepped the entry, every ctr[13] examples, and by thread 0 after the example loop.
+__device__ __forceinline__ void hot_lr_flush(const KernelParams &p, const Lds &s) {
+    float *hot = hot_lr_state(s);
+    const float dw = atomicExch(hot + 1, 0.0f), dacc = atomicExch(hot + 2, 0.0f);
+    s.ctr[7] = 0;
+    if (dw == 0.0f && dacc == 0.0f) return;
+    float *entry = p.lr + 2 * (size_t)s.ctr[12];
+    __hip_atomic_fetch_add(entry, dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    hot[0] = __hip_atomic_fetch_add(entry + 1, dacc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + dacc;
+}
+
 template <int OPT, bool COH>
 __device__ __forceinline__ void lr_update(const KernelParams &p, const Lds &s, uint32_t nl, float g, const float *gx,
                                           const float *lut_lr, int tid, int bd, uint32_t lo = 0, uint32_t hi = 0xffffffffu) {
     for (uint32_t t = tid; t < nl; t += bd) {
         const uint32_t fl = s.l_flag[t];
-        if (fl & kRowChained) continue;
         const uint32_t h = s.l_hash[t];
+        if (COH && hot_lr_is(s, h)) {  // (every entry of that hash steps from the same snapshot; chains are for the table route)
+            float *hot = hot_lr_state(s);
+            const float a0 = hot[0] + hot[2];
+            float acc = a0;
+            const float upd = opt_step<OPT>((gx ? gx[s.l_combo[t]] : g) * s.l_val[t], acc, p.lr_rate, p.lr_minus_power_t, lut_lr);
+            atomicAdd(hot + 1, -upd);
+            atomicAdd(hot + 2, acc - a0);
+            if (!(fl & kRowChained)) {  // (one entry of that hash per example is not chained)
+                const uint32_t n = s.ctr[7] + 1;
+                s.ctr[7] = n;
+                if (n >= s.ctr[13]) hot_lr_flush(p, s);
+            }
+            continue;
+        }
+        if (fl & kRowChained) continue;
         if (h < lo || h >= hi) continue;  // sharded tables: another rank's entry
         float2 wa = lr_load<COH>(p.lr, h);
         {
@@ -1149,7 +1199,10 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
     // kernel -- RCCL during a replica exchange -- holds its slot, or the grid was over-subscribed) finds the work already
     // done instead of running its whole share alone after everyone else has finished.  One workgroup gets 0, 1, 2, ...
     // (the in-order mode).  The next ticket is requested one example ahead, so its latency is never waited for.
-    if (tid == 0) s.ctr[6] = atomicAdd(p.work, 1u);
+    if (tid == 0) {
+        s.ctr[6] = atomicAdd(p.work, 1u);
+        hot_lr_init<COH>(p, s, PH == 0);
+    }
     for (;;) {
         // Previous example's LDS reads are done.  A workgroup-scope barrier does not drain vmcnt on this target,
         // so in the in-order (single workgroup) mode every wave first waits for its own table stores to be
@@ -1328,7 +1381,11 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         } else {
         float lrs = 0.0f;
         if (p.has_lr)
-            for (uint32_t i = tid; i < nl; i += bd) lrs += lr_load<COH>(p.lr, s.l_hash[i]).x * s.l_val[i];
+            for (uint32_t i = tid; i < nl; i += bd) {
+                float w = lr_load<COH>(p.lr, s.l_hash[i]).x;
+                if (COH && hot_lr_is(s, s.l_hash[i])) w += hot_lr_state(s)[1];  // this workgroup's pending steps
+                lrs += w * s.l_val[i];
+            }
         dot = wave_sum(dot);
         lrs = wave_sum(lrs);
         if (lane == 0) {
@@ -1415,6 +1472,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         }
         if (tid == 0) s.ctr[6] = next_ticket;  // published by the loop-top barrier
     }
+    if (COH && tid == 0 && s.ctr[13]) hot_lr_flush(p, s);  // (every thread's steps are in: the loop ends on a barrier)
     if (timing)
         for (int i = 0; i < 8; ++i) atomicAdd(p.ticks + i, tk[i]);
 #undef FW_TICK
@@ -1711,7 +1769,10 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? FW_LB_WAVES : 4) fw_e
     }
     if (timing) tk_last = __builtin_amdgcn_s_memtime();
 
-    if (tid == 0) s.ctr[6] = atomicAdd(p.work, 1u);  // examples come from a device counter: see fw_example_kernel
+    if (tid == 0) {
+        s.ctr[6] = atomicAdd(p.work, 1u);  // examples come from a device counter: see fw_example_kernel
+        hot_lr_init<COH>(p, s, true);
+    }
     for (;;) {
         if (gridDim.x == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in-order mode: see fw_example_kernel
         __syncthreads();
@@ -1858,7 +1919,11 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? FW_LB_WAVES : 4) fw_e
         }
         float lrs = 0.0f;
         if (p.has_lr)
-            for (uint32_t i = tid; i < nl; i += bd) lrs += lr_load<COH>(p.lr, s.l_hash[i]).x * s.l_val[i];
+            for (uint32_t i = tid; i < nl; i += bd) {
+                float w = lr_load<COH>(p.lr, s.l_hash[i]).x;
+                if (COH && hot_lr_is(s, s.l_hash[i])) w += hot_lr_state(s)[1];  // this workgroup's pending steps
+                lrs += w * s.l_val[i];
+            }
         dot = wave_sum(dot);
         lrs = wave_sum(lrs);
         if (lane == 0) {
@@ -1992,6 +2057,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? FW_LB_WAVES : 4) fw_e
         }
         if (tid == 0) s.ctr[6] = next_ticket;  // published by the loop-top barrier
     }
+    if (COH && tid == 0 && s.ctr[13]) hot_lr_flush(p, s);  // (every thread's steps are in: the loop ends on a barrier)
 #undef FW_TICK
 }
 

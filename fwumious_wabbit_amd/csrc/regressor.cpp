@@ -357,6 +357,12 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
     // search found no partner that does not contend.
     p.line_pass = r->launch.window == 2 || (p.window && r->placement_contended) ? 1 : 0;
     p.no_chain = r->launch.no_chain;
+    p.hot_lr_hash = 11650396u & lr_hash_mask(r->cfg.bit_precision);  // feature_buffer.rs:8, 270-276
+    p.hot_lr_every = r->launch.hot_lr_every;
+    {
+        static const char *env = getenv("FWGPU_HOT_LR_EVERY");  // A/B runs: 0 = plain read-modify-writes
+        if (env) p.hot_lr_every = (uint32_t)atoi(env);
+    }
     p.k_log2 = 0xffu;
     for (uint32_t l = 0; l < 16; l++)
         if ((1u << l) == r->cfg.ffm_k) p.k_log2 = l;
@@ -743,6 +749,10 @@ int fwgpu_debug_set_option(fwgpu_regressor *r, int option, int value) {
     switch (option) {
     case 1: r->launch.lut_global = value ? 1 : 0; return FWGPU_OK;
     case 3: r->launch.no_chain = value ? 1 : 0; return FWGPU_OK;  // duplicate-row chains off (A/B runs)
+    case 4:  // hogwild launches: the constant feature's LR entry is stepped in LDS and reaches the table every `value` examples (0: off)
+        if (value < 0 || value > 1024) return fail(FWGPU_ERR_INVALID, "hot LR entry option: 0 .. 1024 examples");
+        r->launch.hot_lr_every = (uint32_t)value;
+        return FWGPU_OK;
     case 2:  // whole-line FFM row updates: 0 off, 1 auto (tables larger than the Infinity Cache; default), 2 always
         if (value < 0 || value > 2) return fail(FWGPU_ERR_INVALID, "window option: 0, 1 or 2");
         r->launch.window = value;

@@ -388,6 +388,12 @@ class Regressor:
         contend for one memory region); 2 = chains + whole-line accesses always (kernels.hip update_rows_win)"""
         check(self.L.fwgpu_debug_set_option(self.h, 2, int(mode)))
 
+    def set_hot_lr_entry(self, every):
+        """HOGWILD launches (fwgpu_debug_set_option 4): a workgroup steps the constant feature's LR entry in LDS and adds its
+        pending deltas to the table every `every` examples with float atomics (default 32; 0 = plain read-modify-writes
+        per example, which serialise on that entry and lose most of the concurrent ones)"""
+        check(self.L.fwgpu_debug_set_option(self.h, 4, int(every)))
+
     # ---- tables
     def set_max_in_flight(self, n):
         """cap on the examples a HOGWILD launch processes concurrently (16 = hogwild.rs's default thread count; 0 = no cap)"""

@@ -386,7 +386,10 @@ int fwgpu_debug_set_kernel_version(fwgpu_regressor *r, int version);
  *   inside an example serialised on one wave (the round-1 path); 1 = automatic (default): tables beyond the Infinity Cache take the
  *   chained path (repeated rows applied by their first occurrence's wave, from registers), with whole-128-byte-line accesses only
  *   when the accumulator table could not be placed away from the weight table; 2 = chained path with whole-line accesses, always.
- * option 3: value 1 = no duplicate-row chains (A/B runs). */
+ * option 3: value 1 = no duplicate-row chains (A/B runs).
+ * option 4: HOGWILD launches step the constant feature's LR entry (in every example, feature_buffer.rs:270-276) in LDS and add
+ *   the pending deltas to the table every `value` examples of a workgroup with float atomics (default 32; 0 = plain per-example
+ *   read-modify-writes, which serialise on that one entry and overwrite each other).  SEQUENTIAL launches never use it. */
 int fwgpu_debug_set_option(fwgpu_regressor *r, int option, int value);
 /* an f32 as serde_json / ryu prints it in the embedded JSON documents ("0.1", "1.0", "1e-7"); NUL-terminated */
 int fwgpu_debug_format_f32(float v, char *buf, uint32_t cap);

@@ -658,6 +658,37 @@ def test_hogwild_mode_reaches_reference_holdout_loss():
     re.close()
 
 
+@pytest.mark.parametrize("shape", ["ffm_k4", "lr_only", "ffm_k8_generic_kernel"])
+def test_hogwild_steps_on_the_constant_features_entry_are_all_applied(shape):
+    """The hot LR entry (kernels.hip hot_lr_flush): whatever the interleaving, the entry's accumulator after a hogwild launch is
+    acc0 + the sum over ALL examples of g^2, g = -(label - prediction) * importance being what each example's sigmoid produced
+    (block_loss_functions.rs:141, block_lr.rs:135-150 with value 1.0) -- computable from the launch's own predictions.  With
+    plain per-example read-modify-writes (option 0) concurrent steps overwrite each other and most of the sum is missing."""
+    n = 30000
+    k = {"ffm_k4": 4, "lr_only": 0, "ffm_k8_generic_kernel": 8}[shape]
+    mi, ocfg, ots = make_pair(10, k, 18, 18, fw.Optimizer.AdagradLUT)
+    recs, off = fw.synth_records(10, 0.0, 1.1, 100000, 0.0, 7, 0, n)
+    y = record_labels(recs, off)
+    label = (y == 1).astype(np.float64)
+    h = 11650396 & ((1 << 18) - 1)  # feature_buffer.rs:8, 270-276
+    got = {}
+    for every in (32, 5, 0):
+        re = fw.Regressor(mi)
+        if shape == "ffm_k8_generic_kernel":
+            capi.check(re.L.fwgpu_debug_set_kernel_version(re.h, 1))
+        re.set_hot_lr_entry(every)
+        b = re.record_batch(fw.FeatureBufferTranslator(mi), recs, off)
+        re.learn_batch(b, capi.MODE_HOGWILD, True)
+        p = b.predictions().astype(np.float64)
+        w, acc = re.table_read(capi.TABLE_LR, 2 * h, 2)
+        got[every] = (float(acc) - 1.0) / float(((label - p) ** 2).sum())
+        assert np.isfinite(w) and w != 0.0
+        b.close()
+        re.close()
+    assert abs(got[32] - 1.0) < 2e-3 and abs(got[5] - 1.0) < 2e-3, got  # (f32 sums in another order)
+    assert got[0] < 0.9, got  # the plain route loses concurrent steps (measured: 0.1-0.5 of the sum survives)
+
+
 @pytest.mark.parametrize("whole_lines", [1, 2])
 def test_hogwild_two_chunk_rows_reach_the_sequential_holdout_loss(whole_lines):
     """k = 16 at 30 fields (R = 480: the v2 kernel's two-chunk instantiation) with all examples of a launch in flight, chained duplicate
