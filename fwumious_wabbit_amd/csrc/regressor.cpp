@@ -1111,15 +1111,18 @@ int fwgpu_block_cache_cover_record(fwgpu_block_cache *c, const fwgpu_translator_
     uint32_t max_ns = 0;
     for (uint32_t m = 0; m < t->field_off[t->n_fields]; m++) max_ns = std::max(max_ns, t->field_ns[m]);
     const uint32_t n_slots = std::min<uint32_t>(len > 3 ? len - 3 : 0, max_ns + 1);
-    c->cover.assign((max_ns + 32) / 32, 0);
+    const size_t cover_words = (max_ns + 32) / 32;
+    FWGPU_HIP(hipSetDevice(c->owner->device));
+    if (c->d_cover && c->cover.size() != cover_words) {  // (a refilled cache keeps its allocation: fw_setup_cache runs once per request)
+        (void)hipFree(c->d_cover);
+        c->d_cover = nullptr;
+    }
+    c->cover.assign(cover_words, 0);
     c->ctx_slots.assign(record + 3, record + 3 + n_slots);
     for (uint32_t ns = 0; ns < n_slots; ns++)
         if (record[3 + ns] != 0x80000000u) c->cover[ns >> 5] |= 1u << (ns & 31);  // NO_FEATURES (parser.rs:19)
-    FWGPU_HIP(hipSetDevice(c->owner->device));
-    if (c->d_cover) (void)hipFree(c->d_cover);
-    c->d_cover = nullptr;
-    FWGPU_HIP(hipMalloc((void **)&c->d_cover, c->cover.size() * 4));
-    FWGPU_HIP(hipMemcpy(c->d_cover, c->cover.data(), c->cover.size() * 4, hipMemcpyHostToDevice));
+    if (!c->d_cover) FWGPU_HIP(hipMalloc((void **)&c->d_cover, cover_words * 4));
+    FWGPU_HIP(hipMemcpy(c->d_cover, c->cover.data(), cover_words * 4, hipMemcpyHostToDevice));
     c->present_bits.assign(64, 0);
     for (uint64_t key : c->present) {
         const uint32_t b = present_bit(key);
