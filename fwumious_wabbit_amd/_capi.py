@@ -192,6 +192,8 @@ def lib():
         "fwgpu_parse_prefix_create": [vp, C.c_char_p, u64, P(vp)],
         "fwgpu_parse_prefix_resumable": [vp],
         "fwgpu_parser_parse_after_prefix": [vp, vp, C.c_char_p, u64, vp, u32, P(u32)],
+        "fwgpu_parse_prefix_is_record": [vp, vp, u32],
+        "fwgpu_parser_parse_candidate": [vp, vp, C.c_char_p, u64, vp, u32, P(u32), P(i32)],
         "fwgpu_parser_parse_buffer": [vp, C.c_char_p, u64, vp, u64, vp, u64, P(u64), P(u64), P(u64)],
         "fwgpu_mi_from_json": [C.c_char_p, u64, P(vp)],
         "fwgpu_mi_to_json": [vp, vp, u64, P(u64)],

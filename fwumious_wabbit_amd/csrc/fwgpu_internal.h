@@ -105,6 +105,8 @@ struct KernelParams {
     // ---- serving context cache (regressor.rs:397-423, block_ffm.rs:442-782): the context features' field sums, in T's layout
     const float *ctx_T;                 // [F*R] T[z][f][k] partial sums of the cached features (NULL: none); read-only launches only
     const float *ctx_dcf;               // [F]   their self-pair corrections
+    const uint32_t *ctx_rec;            // candidate-only record batches: the context's record (namespaces a candidate's record lacks come from it)
+    uint32_t ctx_rec_len;
     const uint32_t *ctx_cover;          // record batches: bit per namespace slot whose FFM features the cache already holds (the stage phase skips them)
     float *emit_T;                      // setup_cache: example 0's T and dcf are written here after the gather
     float *emit_dcf;
@@ -230,6 +232,7 @@ struct fwgpu_batch {
     uint64_t *rec_off = nullptr;
     uint32_t max_rec = 0;
     bool rec_self_len = false;
+    bool delta_records = false;  // serving: records hold the candidate's namespaces only, the rest come from the context cache's record
     uint64_t n_words = 0;
     uint64_t words_cap = 0;
     uint32_t n_cap = 0;
@@ -289,7 +292,10 @@ struct fwgpu_block_cache {
     float *d_dcf = nullptr;
     std::vector<uint64_t> present;  // sorted (hash << 32 | contra_field_index) of the cached FFM features (features_present)
     // record batches (fwgpu_block_cache_cover_record): the context's record decides which namespace slots are covered
-    uint32_t *d_cover = nullptr;           // device copy of `cover`
+    uint32_t *d_cover = nullptr;           // device copy of `cover`, followed by the context's record
+    uint32_t *d_ctx_rec = nullptr;         // (inside d_cover's allocation)
+    std::vector<uint32_t> ctx_rec;         // the context's record
+    size_t ctx_rec_cap = 0;                // words of the allocation behind d_ctx_rec
     std::vector<uint32_t> cover;           // bit per namespace slot
     std::vector<uint32_t> ctx_slots;       // the context record's slot words (a request that rewrites a covered slot is not covered)
     std::vector<uint64_t> present_bits;    // 4096-bit filter in front of `present`
@@ -317,6 +323,10 @@ int translate_record(const fwgpu_translator_config *t, const uint32_t *rec, uint
 int check_translator(const fwgpu_regressor *r, const fwgpu_translator_config *t);
 // validates one record against the translator and counts the entries its translation produces
 int count_record(const fwgpu_translator_config *t, const uint32_t *rec, uint32_t rec_len, uint32_t *n_lr, uint32_t *n_ffm);
+int block_cache_record_ok(const fwgpu_block_cache *c, const fwgpu_translator_config *t, const uint32_t *record, uint32_t len, bool delta);
+// the same for a candidate-only record on top of its context's record (ctx may be NULL)
+int count_record(const fwgpu_translator_config *t, const uint32_t *rec, uint32_t rec_len, const uint32_t *ctx, uint32_t ctx_len,
+                 uint32_t *n_lr, uint32_t *n_ffm);
 // device-resident raw-record batch (translation happens inside the example kernel)
 int record_batch_alloc(fwgpu_regressor *r, const fwgpu_translator_config *t, uint32_t n_cap, uint64_t words_cap,
                        fwgpu_batch **out, bool host_mapped = false);

@@ -267,14 +267,21 @@ struct StageOut {
 };
 
 // record slot decoding, feature_reader! (feature_buffer.rs:47-108) on the LDS copy of the record
-__device__ __forceinline__ uint32_t slot_count(const uint32_t *rec, uint32_t ns) {
-    const uint32_t w = rec[3 + ns];
+// `ctx` (or NULL): the serving context's record, which a candidate-only record inherits every namespace from that it does
+// not hold itself (fwgpu_parser_parse_after_prefix, delta form)
+__device__ __forceinline__ uint32_t slot_count(const uint32_t *rec, const uint32_t *ctx, uint32_t ns) {
+    uint32_t w = rec[3 + ns];
+    if (ctx && w == 0x80000000u) w = ctx[3 + ns];
     if (!(w & 0x80000000u)) return 1;                      // single feature, value 1.0 (parser.rs:62-66)
     return ((w & 0xffffu) - ((w >> 16) & 0x3fffu)) >> 1;   // NO_FEATURES = 0x80000000 -> 0
 }
-__device__ __forceinline__ void slot_get(const uint32_t *rec, uint32_t ns, bool is_f32, uint32_t q, uint32_t &hash,
+__device__ __forceinline__ void slot_get(const uint32_t *rec, const uint32_t *ctx, uint32_t ns, bool is_f32, uint32_t q, uint32_t &hash,
                                          float &val) {
-    const uint32_t w = rec[3 + ns];
+    uint32_t w = rec[3 + ns];
+    if (ctx && w == 0x80000000u) {
+        rec = ctx;
+        w = rec[3 + ns];
+    }
     if (!(w & 0x80000000u)) {
         hash = w;
         val = 1.0f;
@@ -377,6 +384,11 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
         const DevTranslator &t = p.tr;
         const uint32_t NP = t.n_pairs, NC = t.n_combos;
         for (uint32_t i = tid; i < rec_len; i += bd) s.rec[i] = grec[i];
+        const uint32_t *ctx_rec = nullptr;
+        if (CTX && p.ctx_rec) {  // candidate-only records: the context's record sits behind the candidate's in LDS
+            ctx_rec = s.rec + rec_len;
+            for (uint32_t i = tid; i < p.ctx_rec_len; i += bd) s.rec[rec_len + i] = p.ctx_rec[i];
+        }
         __syncthreads();
         tk.stamp(8);
         // Two steps.  (1) wave 0 counts the features of every (field, namespace) pair, wave 1 the entries of every LR
@@ -394,7 +406,7 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
                     const uint32_t ns = t.pair_ns[j];
                     on = !((p.ctx_cover[ns >> 5] >> (ns & 31)) & 1u);
                 }
-                const uint32_t cnt = on ? slot_count(s.rec, t.pair_ns[j]) : 0;
+                const uint32_t cnt = on ? slot_count(s.rec, ctx_rec, t.pair_ns[j]) : 0;
                 const uint32_t inc = wave_scan_incl(cnt, lane);
                 if (j < NP) ffm_base[j] = carry + inc - cnt;
                 carry += (uint32_t)__shfl((int)inc, 63, 64);
@@ -411,7 +423,7 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
                 const bool on = c < NC && p.has_lr;
                 const uint32_t m0 = on ? t.combo_off[c] : 0, m1 = on ? t.combo_off[c + 1] : 0;
                 uint32_t total = on ? 1 : 0;
-                for (uint32_t m = m0; m < m1; ++m) total *= slot_count(s.rec, t.combo_ns[m]);
+                for (uint32_t m = m0; m < m1; ++m) total *= slot_count(s.rec, ctx_rec, t.combo_ns[m]);
                 const uint32_t inc = wave_scan_incl(total, lane);
                 if (c < NC) lr_base[c] = carry + inc - total;
                 carry += (uint32_t)__shfl((int)inc, 63, 64);
@@ -440,7 +452,7 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
             const uint32_t j = lo_;
             uint32_t h;
             float v;
-            slot_get(s.rec, t.pair_ns[j], t.pair_f32[j] != 0, e - ffm_base[j], h, v);
+            slot_get(s.rec, ctx_rec, t.pair_ns[j], t.pair_f32[j] != 0, e - ffm_base[j], h, v);
             s.e_hash[e] = h & t.ffm_mask;
             s.e_val[e] = v;
             s.e_fld[e] = t.pair_field[j];
@@ -462,13 +474,13 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
             uint32_t hash = 0;
             float val = 1.0f;
             for (uint32_t m = m0; m < m1; ++m) {
-                const uint32_t cm = slot_count(s.rec, t.combo_ns[m]);
+                const uint32_t cm = slot_count(s.rec, ctx_rec, t.combo_ns[m]);
                 div /= cm;
                 const uint32_t q = rem / div;
                 rem -= q * div;
                 uint32_t h;
                 float v;
-                slot_get(s.rec, t.combo_ns[m], t.combo_f32[m] != 0, q, h, v);
+                slot_get(s.rec, ctx_rec, t.combo_ns[m], t.combo_f32[m] != 0, q, h, v);
                 if (m == m0) {
                     hash = h;
                     val = v;

@@ -45,6 +45,7 @@ struct fwgpu_parser {
     std::vector<uint32_t> seed;  // murmur3::hash32(vwname) per entry (parser.rs:83)
     std::vector<uint32_t> out;   // output_buffer
     std::string scratch;         // padded copy of a line that has no readable byte after it
+    std::vector<uint32_t> delta; // candidate-only form of the last record (fwgpu_parser_parse_candidate)
     std::string cmd_arg;         // filename of the last hogwild_load command
     // vwname -> entry: the reference walks a 256-ary radix tree (radix_tree.rs); a small open-addressing table on the
     // name's bytes does the same exact-match lookup without allocating
@@ -624,6 +625,58 @@ int fwgpu_parser_parse_after_prefix(fwgpu_parser *p, const fwgpu_parse_prefix *p
     if (!out) return FWGPU_OK;
     if (cap < p->out.size()) return fail(FWGPU_ERR_RANGE, "record buffer too small");
     std::memcpy(out, p->out.data(), p->out.size() * 4);
+    return FWGPU_OK;
+}
+
+// 1 when the scanned part of the context is the whole of it: the context's own record (what fw_setup_cache parsed, `record`)
+// is word for word the output buffer at the resume point.  Requests can then be returned as candidate-only records.
+int fwgpu_parse_prefix_is_record(const fwgpu_parse_prefix *px, const uint32_t *record, uint32_t len) {
+    if (!px || !px->resumable || !record || len != px->ob.size() || len < kHeaderLen) return 0;
+    return std::memcmp(record + 1, px->ob.data() + 1, ((size_t)len - 1) * 4) == 0;  // (word 0 is the length, written last)
+}
+
+// fwgpu_parser_parse_after_prefix, but what comes back (*is_delta = 1) holds only what the request ADDED to the context's
+// record: the header, a slot word for every namespace the request filled (feature ranges relocated to this record; every other
+// slot NO_FEATURES = "as in the context") and the request's feature words.  The context's record + this one carry the same
+// information as the merged record; a request that goes on inside a namespace the context began cannot be split that way and
+// comes back merged (*is_delta = 0), as does everything when the context is not resumable.
+int fwgpu_parser_parse_candidate(fwgpu_parser *p, const fwgpu_parse_prefix *px, const char *line, uint64_t len, uint32_t *out,
+                                 uint32_t cap, uint32_t *n_words, int *is_delta) {
+    if (!is_delta) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    *is_delta = 0;
+    int rc = fwgpu_parser_parse_after_prefix(p, px, line, len, nullptr, 0, n_words);
+    if (rc != FWGPU_OK || *n_words == 0) return rc;
+    const std::vector<uint32_t> &m = p->out;
+    const size_t L0 = px->ob.size(), H = kHeaderLen + p->vw_copy.num_namespaces;
+    bool delta = px->resumable && len != 0 && m.size() >= L0 && L0 >= H;
+    std::vector<uint32_t> &d = p->delta;
+    if (delta) {
+        d.resize(H + (m.size() - L0));
+        d[kLabelOffset] = m[kLabelOffset];
+        d[kImportanceOffset] = m[kImportanceOffset];
+        for (size_t sl = kHeaderLen; sl < H && delta; sl++) {
+            const uint32_t w = m[sl];
+            if (w == px->ob[sl]) {
+                d[sl] = kNoFeatures;
+            } else if (!(w & kNotSingle)) {
+                d[sl] = w;
+            } else {
+                const uint32_t start = (w >> 16) & 0x3fff, end = w & 0xffff;
+                if (start < L0 || end < start) delta = false;  // the namespace began in the context
+                else d[sl] = kNotSingle | (uint32_t)(((start - L0 + H) << 16) + (end - L0 + H));
+            }
+        }
+        if (delta) {
+            std::memcpy(d.data() + H, m.data() + L0, (m.size() - L0) * 4);
+            d[0] = (uint32_t)d.size();
+        }
+    }
+    const std::vector<uint32_t> &res = delta ? d : m;
+    *is_delta = delta ? 1 : 0;
+    *n_words = (uint32_t)res.size();
+    if (!out) return FWGPU_OK;
+    if (cap < res.size()) return fail(FWGPU_ERR_RANGE, "record buffer too small");
+    std::memcpy(out, res.data(), res.size() * 4);
     return FWGPU_OK;
 }
 

@@ -375,6 +375,10 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
         p.ctx_T = b->cache->d_T;
         p.ctx_dcf = b->cache->d_dcf;
         if (b->records) p.ctx_cover = b->cache->d_cover;
+        if (b->records && b->delta_records) {
+            p.ctx_rec = b->cache->d_ctx_rec;
+            p.ctx_rec_len = (uint32_t)b->cache->ctx_rec.size();
+        }
     }
     if (!update) {
         p.emit_T = b->emit_T;
@@ -1113,16 +1117,22 @@ int fwgpu_block_cache_cover_record(fwgpu_block_cache *c, const fwgpu_translator_
     const uint32_t n_slots = std::min<uint32_t>(len > 3 ? len - 3 : 0, max_ns + 1);
     const size_t cover_words = (max_ns + 32) / 32;
     FWGPU_HIP(hipSetDevice(c->owner->device));
-    if (c->d_cover && c->cover.size() != cover_words) {  // (a refilled cache keeps its allocation: fw_setup_cache runs once per request)
+    if (c->d_cover && (c->cover.size() != cover_words || c->ctx_rec_cap < len)) {
+        // (a refilled cache keeps its allocation when the new context fits: fw_setup_cache runs once per request)
         (void)hipFree(c->d_cover);
         c->d_cover = nullptr;
     }
+    if (!c->d_cover) c->ctx_rec_cap = (size_t)len * 2;
     c->cover.assign(cover_words, 0);
     c->ctx_slots.assign(record + 3, record + 3 + n_slots);
     for (uint32_t ns = 0; ns < n_slots; ns++)
         if (record[3 + ns] != 0x80000000u) c->cover[ns >> 5] |= 1u << (ns & 31);  // NO_FEATURES (parser.rs:19)
-    if (!c->d_cover) FWGPU_HIP(hipMalloc((void **)&c->d_cover, cover_words * 4));
-    FWGPU_HIP(hipMemcpy(c->d_cover, c->cover.data(), cover_words * 4, hipMemcpyHostToDevice));
+    if (!c->d_cover) FWGPU_HIP(hipMalloc((void **)&c->d_cover, (cover_words + c->ctx_rec_cap) * 4));
+    c->d_ctx_rec = c->d_cover + cover_words;
+    c->ctx_rec.assign(record, record + len);
+    std::vector<uint32_t> up(c->cover);
+    up.insert(up.end(), record, record + len);
+    FWGPU_HIP(hipMemcpy(c->d_cover, up.data(), up.size() * 4, hipMemcpyHostToDevice));
     c->present_bits.assign(64, 0);
     for (uint64_t key : c->present) {
         const uint32_t b = present_bit(key);
@@ -1136,11 +1146,18 @@ int fwgpu_block_cache_cover_record(fwgpu_block_cache *c, const fwgpu_translator_
 // record, parser.rs:318-326, while the cache still holds them), and none of its own FFM features equals a cached one
 // (hash and field: the filter would drop it).  0: take the entry route (translate, filter) for this request.
 int fwgpu_block_cache_record_ok(const fwgpu_block_cache *c, const fwgpu_translator_config *t, const uint32_t *record, uint32_t len) {
+    return block_cache_record_ok(c, t, record, len, false);
+}
+
+}  // extern "C"
+namespace fwgpu {
+// delta: `record` holds the candidate's namespaces only (a covered slot it does not touch reads NO_FEATURES there)
+int block_cache_record_ok(const fwgpu_block_cache *c, const fwgpu_translator_config *t, const uint32_t *record, uint32_t len, bool delta) {
     if (!c || !t || !record || !c->d_cover) return 0;
     const uint32_t n_slots = (uint32_t)c->ctx_slots.size();
     if (len < 3 + n_slots) return 0;
     for (uint32_t ns = 0; ns < n_slots; ns++)
-        if (((c->cover[ns >> 5] >> (ns & 31)) & 1u) && record[3 + ns] != c->ctx_slots[ns]) return 0;
+        if (((c->cover[ns >> 5] >> (ns & 31)) & 1u) && record[3 + ns] != (delta ? 0x80000000u : c->ctx_slots[ns])) return 0;
     const uint32_t ffm_mask = ffm_hash_mask(t->ffm_bit_precision, t->ffm_k);
     for (uint32_t f = 0; f < t->n_fields; f++)
         for (uint32_t m = t->field_off[f]; m < t->field_off[f + 1]; m++) {
@@ -1164,6 +1181,8 @@ int fwgpu_block_cache_record_ok(const fwgpu_block_cache *c, const fwgpu_translat
         }
     return 1;
 }
+}  // namespace fwgpu
+extern "C" {
 
 // Predict-only launches of this batch start every example's field sums from the cache (NULL detaches it): an entry batch must
 // then hold only the entries fwgpu_block_cache_filter leaves; a record batch holds whole requests that pass

@@ -12,6 +12,8 @@
 // equal to a cached one, takes the entry route (host translation + fwgpu_block_cache_filter), which is the reference's rule
 // for those.  Models with a deep head keep the uncached route (whole line scored), which gives the same result.
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -78,6 +80,70 @@ std::vector<std::string> shell_split(const char *s) {
 
 }  // namespace
 
+// The parser threads of a predictor's batched requests, kept between requests: starting 31 threads costs more than scanning
+// a 20 000-candidate request on them takes.  run(n, fn) calls fn(0) on the caller and fn(1 .. n-1) on the workers.
+class Workers {
+public:
+    ~Workers() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    template <class F>
+    void run(unsigned n, F &&fn) {
+        if (n <= 1) {
+            fn(0u);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            while (threads_.size() + 1 < n) {
+                const unsigned id = (unsigned)threads_.size() + 1;
+                threads_.emplace_back([this, id] { loop(id); });
+            }
+            job_ = [&fn](unsigned k) { fn(k); };
+            active_ = n;
+            remaining_ = n - 1;
+            generation_++;
+        }
+        cv_.notify_all();
+        fn(0u);
+        std::unique_lock<std::mutex> g(mu_);
+        done_.wait(g, [this] { return remaining_ == 0; });
+        job_ = nullptr;
+    }
+
+private:
+    void loop(unsigned id) {
+        uint64_t seen = 0;
+        for (;;) {
+            std::function<void(unsigned)> job;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return stop_ || (generation_ != seen && id < active_); });
+                if (stop_) return;
+                seen = generation_;
+                job = job_;
+            }
+            job(id);
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                if (--remaining_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> threads_;
+    std::function<void(unsigned)> job_;
+    uint64_t generation_ = 0;
+    unsigned active_ = 0, remaining_ = 0;
+    bool stop_ = false;
+};
+
 // one parser thread's share of a batched request (kept between requests: no fresh pages to fault in, no parser to build)
 struct Part {
     std::vector<uint32_t> words;
@@ -108,10 +174,12 @@ struct Part {
 struct FfiPredictor {
     std::shared_ptr<SharedModel> model;
     std::vector<std::unique_ptr<Part>> parts;
+    Workers workers;
     fwgpu_parser *parser = nullptr;
     std::string cached_text;  // PredictorCache.input_buffer_size bytes of the context line (lib.rs:64-67)
     fwgpu_parse_prefix *prefix = nullptr;  // the same bytes, scanned
     bool has_cache = false;
+    bool delta_ok = false;  // the scanned context is the context's own record: requests can travel as candidate-only records
     fwgpu_block_cache *cache = nullptr;  // PredictorCache.blocks: the context's field sums, on the device
     std::vector<uint32_t> record;
     std::vector<fwgpu_lr_entry> lr;
@@ -242,6 +310,7 @@ float fw_setup_cache(FfiPredictor *ptr, const char *input_buffer) {  // lib.rs:2
     if (len && input_buffer[len - 1] == '\n') len -= 1;  // "ignore last newline byte" (parser.rs:184-193)
     ptr->cached_text.assign(input_buffer, len);
     ptr->has_cache = true;
+    ptr->delta_ok = false;
     if (ptr->prefix) fwgpu_parse_prefix_free(ptr->prefix);
     ptr->prefix = nullptr;
     if (fwgpu_parse_prefix_create(ptr->parser, ptr->cached_text.data(), ptr->cached_text.size(), &ptr->prefix) != FWGPU_OK) return kExceptionErrorCode;
@@ -255,6 +324,7 @@ float fw_setup_cache(FfiPredictor *ptr, const char *input_buffer) {  // lib.rs:2
         if (fwgpu_setup_cache(m.re, ptr->lr.data(), (uint32_t)ptr->lr.size(), ptr->ffm.data(), (uint32_t)ptr->ffm.size(), &ptr->cache) != FWGPU_OK)
             return kExceptionErrorCode;
         if (fwgpu_block_cache_cover_record(ptr->cache, &m.tr, ptr->record.data(), n_words) != FWGPU_OK) return kExceptionErrorCode;
+        ptr->delta_ok = fwgpu_parse_prefix_is_record(ptr->prefix, ptr->record.data(), n_words) != 0;
     }
     return 0.0f;
 }
@@ -283,6 +353,10 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
     const bool cached = with_cache && ptr->cache;  // candidates reduced to the entries the context cache does not cover
     // records + the kernel's own translation, unless a candidate turns out to need the entry route (FWGPU_SERVING_ENTRY_ROUTE=1 forces that one)
     bool by_record = cached && !std::getenv("FWGPU_SERVING_ENTRY_ROUTE");
+    // ... and of those records only what the candidate adds to the context's record, which the device already holds
+    // (FWGPU_SERVING_MERGED_RECORDS=1: whole context + candidate records instead)
+    const bool delta_wanted = ptr->delta_ok && !std::getenv("FWGPU_SERVING_MERGED_RECORDS");
+    bool delta = false;
     const bool timing = std::getenv("FWGPU_SERVING_TIMING") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -309,8 +383,10 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
             if (!inputs[i]) continue;
             uint32_t nw = 0;
             int rc;
+            int is_delta = 0;
             for (;;) {
-                rc = with_cache && ptr->prefix
+                rc = delta ? fwgpu_parser_parse_candidate(parser, ptr->prefix, inputs[i], std::strlen(inputs[i]), rec.data(), (uint32_t)rec.size(), &nw, &is_delta)
+                     : with_cache && ptr->prefix
                          ? fwgpu_parser_parse_after_prefix(parser, ptr->prefix, inputs[i], std::strlen(inputs[i]), rec.data(), (uint32_t)rec.size(), &nw)
                          : fwgpu_parser_parse_with_prefix(parser, with_cache ? ptr->cached_text.data() : nullptr,
                                                           with_cache ? ptr->cached_text.size() : 0, inputs[i], std::strlen(inputs[i]),
@@ -326,7 +402,7 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
                 continue;
             }
             rec[1] = 0;  // a request carries no label (NO_LABEL = 0xff); the prediction does not depend on it
-            if (by_record && !fwgpu_block_cache_record_ok(ptr->cache, &m.tr, rec.data(), nw)) {
+            if (by_record && ((delta && !is_delta) || !block_cache_record_ok(ptr->cache, &m.tr, rec.data(), nw, delta))) {
                 pt.entry_route = true;
                 break;  // the whole request goes again, by entries
             }
@@ -343,12 +419,17 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
                 continue;
             }
             uint32_t c_lr = 0, c_ffm = 0;
-            if (count_record(&m.tr, rec.data(), nw, &c_lr, &c_ffm) != FWGPU_OK) {
+            const uint32_t ctx_len = delta ? (uint32_t)ptr->cache->ctx_rec.size() : 0;
+            if (count_record(&m.tr, rec.data(), nw, delta ? ptr->cache->ctx_rec.data() : nullptr, ctx_len, &c_lr, &c_ffm) != FWGPU_OK) {
+                if (delta) {
+                    pt.entry_route = true;
+                    break;
+                }
                 pt.stats_ok = false;  // (the upload validates again and reports)
             } else {
                 pt.stats.max_lr = std::max(pt.stats.max_lr, c_lr);
                 pt.stats.max_ffm = std::max(pt.stats.max_ffm, c_ffm);
-                pt.stats.max_rec = std::max(pt.stats.max_rec, nw);
+                pt.stats.max_rec = std::max(pt.stats.max_rec, nw + ctx_len);  // (LDS holds the context's record behind the candidate's)
                 pt.stats.tot_lr += c_lr;
                 pt.stats.tot_ffm += c_ffm;
             }
@@ -358,10 +439,8 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
         }
     };
     for (;;) {
-        std::vector<std::thread> th;
-        for (unsigned k = 1; k < T; k++) th.emplace_back(work, k);
-        work(0);
-        for (auto &x : th) x.join();
+        delta = by_record && delta_wanted;
+        ptr->workers.run(T, work);
         bool again = false;
         for (const Part *pt : parts) again = again || pt->entry_route;
         if (!again) break;
@@ -425,10 +504,7 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
                 for (size_t j = 1; j < src.ffm_off.size(); j++) hb.ffm_off[eb_[q] + j] = src.ffm_off[j] + (uint32_t)fb[q];
                 for (size_t j = 1; j < src.lr_off.size(); j++) hb.lr_off[eb_[q] + j] = src.lr_off[j] + (uint32_t)lb[q];
             };
-            std::vector<std::thread> th;
-            for (size_t q = 1; q < P; q++) th.emplace_back(put, q);
-            put(0);
-            for (auto &x : th) x.join();
+            ptr->workers.run((unsigned)P, [&](unsigned q) { put(q); });
             for (const Part *pt : parts) {
                 hb.max_lr = std::max(hb.max_lr, pt->hb.max_lr);
                 hb.max_ffm = std::max(hb.max_ffm, pt->hb.max_ffm);
@@ -484,10 +560,12 @@ int fwgpu_predictor_predict_batch(FfiPredictor *ptr, const char *const *inputs, 
     if (rc != FWGPU_OK) return rc;
     lap("uploaded");
     if (by_record) rc = fwgpu_batch_set_cache(b, ptr->cache);  // the kernel's translation leaves the covered namespaces out
+    b->delta_records = delta;
     if (rc == FWGPU_OK) rc = fwgpu_learn_batch(m.re, b, FWGPU_MODE_HOGWILD, /*update=*/0, nullptr);
     std::vector<float> preds(slot.size());
     if (rc == FWGPU_OK) rc = fwgpu_batch_predictions(b, preds.data(), (uint32_t)preds.size(), nullptr);
     (void)fwgpu_batch_set_cache(b, nullptr);
+    b->delta_records = false;
     if (rc != FWGPU_OK) return rc;
     for (size_t j = 0; j < slot.size(); j++) out[slot[j]] = preds[j];
     lap("predicted");

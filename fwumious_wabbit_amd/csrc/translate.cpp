@@ -96,16 +96,26 @@ int translate_record(const fwgpu_translator_config *t, const uint32_t *rec, uint
 }
 
 int count_record(const fwgpu_translator_config *t, const uint32_t *rec, uint32_t rec_len, uint32_t *n_lr, uint32_t *n_ffm) {
-    if (rec_len < kHeaderLen) return fail(FWGPU_ERR_FORMAT, "record shorter than its header");
+    return count_record(t, rec, rec_len, nullptr, 0, n_lr, n_ffm);
+}
+
+int count_record(const fwgpu_translator_config *t, const uint32_t *rec, uint32_t rec_len, const uint32_t *ctx, uint32_t ctx_len,
+                 uint32_t *n_lr, uint32_t *n_ffm) {
+    if (rec_len < kHeaderLen || (ctx && ctx_len < kHeaderLen)) return fail(FWGPU_ERR_FORMAT, "record shorter than its header");
     auto cnt = [&](uint32_t ns, uint32_t *c) -> int {
         if (ns + kHeaderLen >= rec_len) return fail(FWGPU_ERR_FORMAT, "record: namespace slot beyond the record");
-        const uint32_t w = rec[ns + kHeaderLen];
+        uint32_t w = rec[ns + kHeaderLen], len = rec_len;
+        if (ctx && w == kNoFeatures) {  // a candidate-only record inherits the namespace from its context's record
+            if (ns + kHeaderLen >= ctx_len) return fail(FWGPU_ERR_FORMAT, "record: namespace slot beyond the context's record");
+            w = ctx[ns + kHeaderLen];
+            len = ctx_len;
+        }
         if ((w & kIsNotSingleMask) == 0) {
             *c = 1;
             return FWGPU_OK;
         }
         const uint32_t start = (w >> 16) & 0x3fff, end = w & 0xffff;
-        if (end < start || end > rec_len || ((end - start) & 1) || (end > start && start < kHeaderLen))
+        if (end < start || end > len || ((end - start) & 1) || (end > start && start < kHeaderLen))
             return fail(FWGPU_ERR_FORMAT, "record: malformed feature range");
         *c = (end - start) / 2;
         return FWGPU_OK;

@@ -108,6 +108,14 @@ class VowpalParser:
                                                     C.byref(n))
         return self._result(rc, n)
 
+    def next_vowpal_candidate(self, prefix: "ParsePrefix", line: bytes):
+        """(record, is_delta): the candidate-only form of next_vowpal_after's record when the request can be split off the
+        context's record (fwgpu_parser_parse_candidate), else the merged record"""
+        n, d = C.c_uint32(), C.c_int32()
+        rc = self.L.fwgpu_parser_parse_candidate(self.h, prefix.h, line, len(line), capi.ptr(self._buf), self._buf.size,
+                                                 C.byref(n), C.byref(d))
+        return self._result(rc, n), bool(d.value)
+
     def parse_buffer(self, text: bytes, max_records=1 << 20, words_cap=None):
         """Many lines -> (records u32[], rec_off u64[n+1], bytes consumed, status).  Stops at the first line that is
         not an example; status is OK / PARSE_FLUSH / PARSE_HOGWILD_LOAD / ERR_PARSE."""
@@ -140,6 +148,11 @@ class ParsePrefix:
     @property
     def resumable(self) -> bool:
         return bool(self.L.fwgpu_parse_prefix_resumable(self.h))
+
+    def is_record(self, record: np.ndarray) -> bool:
+        """the scanned part of the context is all of it: `record` (the context line parsed on its own) is the state requests resume from"""
+        r = np.ascontiguousarray(record, dtype=np.uint32)
+        return bool(self.L.fwgpu_parse_prefix_is_record(self.h, capi.ptr(r), len(r)))
 
     def close(self):
         if self.h:

@@ -435,6 +435,13 @@ void fwgpu_parse_prefix_free(fwgpu_parse_prefix *px);
 int fwgpu_parse_prefix_resumable(const fwgpu_parse_prefix *px);
 int fwgpu_parser_parse_after_prefix(fwgpu_parser *p, const fwgpu_parse_prefix *px, const char *line, uint64_t len, uint32_t *out,
                                     uint32_t cap, uint32_t *n_words);
+/* Candidate-only records.  When the scanned part of the context is all of it (fwgpu_parse_prefix_is_record: its output buffer
+ * equals the context's own record), fwgpu_parser_parse_candidate returns what the request ADDED to that record (*is_delta = 1):
+ * header, a slot word per namespace the request filled (every other slot NO_FEATURES = "as in the context"), the request's
+ * feature words.  A request that continues a namespace the context began comes back merged (*is_delta = 0). */
+int fwgpu_parse_prefix_is_record(const fwgpu_parse_prefix *px, const uint32_t *record, uint32_t len);
+int fwgpu_parser_parse_candidate(fwgpu_parser *p, const fwgpu_parse_prefix *px, const char *line, uint64_t len, uint32_t *out,
+                                 uint32_t cap, uint32_t *n_words, int *is_delta);
 const char *fwgpu_parser_command_argument(const fwgpu_parser *p);
 int fwgpu_parser_parse_buffer(fwgpu_parser *p, const char *text, uint64_t len, uint32_t *words, uint64_t words_cap,
                               uint64_t *rec_off, uint64_t max_records, uint64_t *n_records, uint64_t *n_words,

@@ -140,6 +140,67 @@ def test_scanned_context_equals_concatenation_random_lines():
             assert _parse_outcome(lambda: rr.next_vowpal_after(px, cand)) == want, (ctx, cand)
 
 
+def _namespaces(rec, n_ns, base=None):
+    """record -> per namespace slot the list of (hash, value bits); slots reading NO_FEATURES come from `base` (a context's record)"""
+    out = []
+    for ns in range(n_ns):
+        r, w = rec, int(rec[3 + ns])
+        if w == 0x80000000 and base is not None:
+            r, w = base, int(base[3 + ns])
+        if not (w & 0x80000000):
+            out.append([(w, 0x3f800000)])
+        else:
+            a, b = (w >> 16) & 0x3fff, w & 0xffff
+            out.append([(int(r[o]), int(r[o + 1])) for o in range(a, b - 1, 2)])
+    return out
+
+
+def test_candidate_only_records_carry_what_the_merged_record_carries():
+    """fwgpu_parser_parse_candidate: context record + candidate-only record == the record of context + candidate, namespace by
+    namespace (hashes and value bits), incl. candidates that name a context namespace again; a candidate that continues the
+    context's last namespace comes back merged"""
+    rng = np.random.default_rng(5)
+    names = ["A", "B", "C", "DD", "E"]
+    vw = VwNamespaceMap("A,fa\nB,fb\nC,fc,f32\nDD,fd\nE,fe\n_namespace_skip_prefix,2\n")
+    rr = VowpalParser(vw)
+    n_ns = vw.num_namespaces
+
+    def part(nss):
+        out = ""
+        for ns in nss:
+            feats = ["zz%g" % rng.normal() if ns == "C" else "f%d" % rng.integers(0, 50) + (":%g" % rng.uniform(0.1, 3)) * bool(rng.random() < 0.3)
+                     for _ in range(rng.integers(0, 4))]
+            out += "|" + ns + (":2" if ns != "C" and rng.random() < 0.15 else "") + " " + "".join(f + " " for f in feats)
+        return out
+
+    seen = {True: 0, False: 0}
+    for _ in range(200):
+        order = list(rng.permutation(names))
+        k = int(rng.integers(1, 4))
+        ctx = (rng.choice(["1 ", "-1 0.5 ", ""]) + part(order[:k])).encode()
+        px = rr.scan_context(ctx)
+        ctx_rec = rr.next_vowpal(ctx)
+        assert px.is_record(ctx_rec)  # (every context here ends with a space: the scan reaches its end)
+        for _ in range(4):
+            extra = list(rng.permutation(order[:k]))[: int(rng.integers(0, 2))]  # sometimes a context namespace again
+            lead = rng.choice(["", "", "f7 "])                                     # sometimes a feature that continues the context's last namespace
+            cand = (lead + part(order[k:] + extra) + "\n").encode()
+            merged = rr.next_vowpal_with_cache(ctx, cand)
+            got, is_delta = rr.next_vowpal_candidate(px, cand)
+            seen[is_delta] += 1
+            if not is_delta:
+                assert got.tolist() == merged.tolist() and lead
+                continue
+            # (a lead feature can still split off when the context's last namespace left no feature words behind)
+            assert got[0] == len(got) and got[1] == merged[1] and got[2] == merged[2]
+            assert len(got) <= len(merged) - len(ctx_rec) + 3 + n_ns
+            assert _namespaces(got, n_ns, base=ctx_rec) == _namespaces(merged, n_ns)
+    assert seen[True] > 300 and seen[False] > 30
+    # a context whose last token the request continues is not the context's own record: no candidate-only form
+    px = rr.scan_context(b"1 |A f1 |B f2")
+    assert not px.is_record(rr.next_vowpal(b"1 |A f1 |B f2"))
+
+
 def test_vwmap_reference_kats():
     for k in KATS["vwmap"]:
         if "error" in k:

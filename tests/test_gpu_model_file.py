@@ -249,6 +249,13 @@ def test_serving_ffi_matches_the_regressor(tmp_path):
         assert np.array_equal(pr.predict_batch(cands, with_cache=True), with_cache)
     finally:
         del os.environ["FWGPU_SERVING_ENTRY_ROUTE"]
+    # by default the records hold only what a candidate adds to the context's record (the device keeps that one); whole
+    # context + candidate records are the same numbers
+    os.environ["FWGPU_SERVING_MERGED_RECORDS"] = "1"
+    try:
+        assert np.array_equal(pr.predict_batch(cands, with_cache=True), with_cache)
+    finally:
+        del os.environ["FWGPU_SERVING_MERGED_RECORDS"]
     big = [f"|A2 {i} {i + 1}:0.5 |A3 {i * 7}:1.5 |A4 {i % 11} |A5 {i % 3}\n" for i in range(3000)]  # several parser threads
     assert np.array_equal(pr.predict_batch(big, with_cache=True), np.array([pr.predict_with_cache(c) for c in big], dtype=np.float32))
     assert np.abs(pr.predict_batch(big, with_cache=True) - pr.predict_batch([ctx + c for c in big])).max() < 2e-6
