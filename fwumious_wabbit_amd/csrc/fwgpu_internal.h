@@ -6,6 +6,10 @@
 #include <stdint.h>
 
 #include <string>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "fwgpu.h"
@@ -300,6 +304,74 @@ struct fwgpu_block_cache {
     std::vector<uint32_t> ctx_slots;       // the context record's slot words (a request that rewrites a covered slot is not covered)
     std::vector<uint64_t> present_bits;    // 4096-bit filter in front of `present`
 };
+
+namespace fwgpu {
+// Host worker threads kept between calls (serving requests, trainer chunks): starting a few dozen std::threads costs as much as
+// the work a call gives them.  run(n, fn) calls fn(0) on the caller and fn(1 .. n-1) on the workers; one run at a time.
+class Workers {
+public:
+    ~Workers() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    template <class F>
+    void run(unsigned n, F &&fn) {
+        if (n <= 1) {
+            fn(0u);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            while (threads_.size() + 1 < n) {
+                const unsigned id = (unsigned)threads_.size() + 1;
+                threads_.emplace_back([this, id] { loop(id); });
+            }
+            job_ = [&fn](unsigned k) { fn(k); };
+            active_ = n;
+            remaining_ = n - 1;
+            generation_++;
+        }
+        cv_.notify_all();
+        fn(0u);
+        std::unique_lock<std::mutex> g(mu_);
+        done_.wait(g, [this] { return remaining_ == 0; });
+        job_ = nullptr;
+    }
+
+private:
+    void loop(unsigned id) {
+        uint64_t seen = 0;
+        for (;;) {
+            std::function<void(unsigned)> job;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return stop_ || (generation_ != seen && id < active_); });
+                if (stop_) return;
+                seen = generation_;
+                job = job_;
+            }
+            job(id);
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                if (--remaining_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> threads_;
+    std::function<void(unsigned)> job_;
+    uint64_t generation_ = 0;
+    unsigned active_ = 0, remaining_ = 0;
+    bool stop_ = false;
+};
+
+
+}  // namespace fwgpu
 
 namespace fwgpu {
 // host helpers implemented in regressor.cpp / translate.cpp

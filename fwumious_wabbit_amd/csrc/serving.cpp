@@ -12,8 +12,6 @@
 // equal to a cached one, takes the entry route (host translation + fwgpu_block_cache_filter), which is the reference's rule
 // for those.  Models with a deep head keep the uncached route (whole line scored), which gives the same result.
 #include <chrono>
-#include <condition_variable>
-#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -80,70 +78,6 @@ std::vector<std::string> shell_split(const char *s) {
 
 }  // namespace
 
-// The parser threads of a predictor's batched requests, kept between requests: starting 31 threads costs more than scanning
-// a 20 000-candidate request on them takes.  run(n, fn) calls fn(0) on the caller and fn(1 .. n-1) on the workers.
-class Workers {
-public:
-    ~Workers() {
-        {
-            std::lock_guard<std::mutex> g(mu_);
-            stop_ = true;
-        }
-        cv_.notify_all();
-        for (auto &t : threads_) t.join();
-    }
-    template <class F>
-    void run(unsigned n, F &&fn) {
-        if (n <= 1) {
-            fn(0u);
-            return;
-        }
-        {
-            std::lock_guard<std::mutex> g(mu_);
-            while (threads_.size() + 1 < n) {
-                const unsigned id = (unsigned)threads_.size() + 1;
-                threads_.emplace_back([this, id] { loop(id); });
-            }
-            job_ = [&fn](unsigned k) { fn(k); };
-            active_ = n;
-            remaining_ = n - 1;
-            generation_++;
-        }
-        cv_.notify_all();
-        fn(0u);
-        std::unique_lock<std::mutex> g(mu_);
-        done_.wait(g, [this] { return remaining_ == 0; });
-        job_ = nullptr;
-    }
-
-private:
-    void loop(unsigned id) {
-        uint64_t seen = 0;
-        for (;;) {
-            std::function<void(unsigned)> job;
-            {
-                std::unique_lock<std::mutex> g(mu_);
-                cv_.wait(g, [&] { return stop_ || (generation_ != seen && id < active_); });
-                if (stop_) return;
-                seen = generation_;
-                job = job_;
-            }
-            job(id);
-            {
-                std::lock_guard<std::mutex> g(mu_);
-                if (--remaining_ == 0) done_.notify_one();
-            }
-        }
-    }
-    std::mutex mu_;
-    std::condition_variable cv_, done_;
-    std::vector<std::thread> threads_;
-    std::function<void(unsigned)> job_;
-    uint64_t generation_ = 0;
-    unsigned active_ = 0, remaining_ = 0;
-    bool stop_ = false;
-};
-
 // one parser thread's share of a batched request (kept between requests: no fresh pages to fault in, no parser to build)
 struct Part {
     std::vector<uint32_t> words;
@@ -174,7 +108,7 @@ struct Part {
 struct FfiPredictor {
     std::shared_ptr<SharedModel> model;
     std::vector<std::unique_ptr<Part>> parts;
-    Workers workers;
+    Workers workers;  // the parser threads of batched requests, kept between requests: starting 31 threads costs more than scanning a 20 000-candidate request on them takes
     fwgpu_parser *parser = nullptr;
     std::string cached_text;  // PredictorCache.input_buffer_size bytes of the context line (lib.rs:64-67)
     fwgpu_parse_prefix *prefix = nullptr;  // the same bytes, scanned

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <memory>
+#include <chrono>
 #include <thread>
 
 #include "fwgpu_internal.h"
@@ -49,6 +50,9 @@ struct fwgpu_trainer {
     std::unique_ptr<uint32_t[]> cache_words[2];
     std::unique_ptr<uint64_t[]> cache_off[2];
     uint64_t cache_off_cap = 0;
+    // host threads kept between calls: staging copies of fwgpu_digest_records, parser threads of
+    // fwgpu_trainer_digest_text.  Two pools: a chunk of text is parsed while the previous chunk's records are digested.
+    Workers copy_pool, parse_pool;
 };
 
 static bool predict_mode(const fwgpu_trainer *tr) {  // for the NEXT example (number seen + 1)
@@ -79,7 +83,7 @@ static int flush(fwgpu_trainer *tr, bool predict = false) {
     if (!b || b->n_cap < n || b->words_cap < words) {
         if (b) fwgpu_batch_free(b);
         tr->dev[c] = nullptr;
-        int rc = record_batch_alloc(r, &tr->t, std::max(n, tr->micro_batch), words * 5 / 4 + 4096, &tr->dev[c]);
+        int rc = record_batch_alloc(r, &tr->t, std::max(n, tr->micro_batch), words * 3 / 2 + 4096, &tr->dev[c]);
         if (rc) return rc;
         b = tr->dev[c];
     }
@@ -173,7 +177,8 @@ int fwgpu_digest_records(fwgpu_trainer *tr, const uint32_t *records, const uint6
         const uint64_t w0 = rec_off[i], w1 = rec_off[i + take];
         const uint64_t base = tr->rec_used[c];
         if (base + (w1 - w0) > tr->rec_cap[c]) {
-            const uint64_t ncap = std::max<uint64_t>((base + (w1 - w0)) * 3 / 2, 1u << 20);
+            // (pinning memory is slow, 0.3-0.5 ms per MB: grow generously, a micro-batch a few percent larger than the last must not pin again)
+            const uint64_t ncap = std::max<uint64_t>((base + (w1 - w0)) * 2, 1u << 20);
             uint32_t *nbuf = nullptr;
             FWGPU_HIP(hipSetDevice(tr->r->device));
             FWGPU_HIP(hipHostMalloc((void **)&nbuf, ncap * 4, hipHostMallocDefault));
@@ -194,10 +199,7 @@ int fwgpu_digest_records(fwgpu_trainer *tr, const uint32_t *records, const uint6
                 rcs[k] = count_records(&tr->t, records, rec_off + a, e - a, &st[k]);
                 if (rcs[k]) msgs[k] = fwgpu_last_error();
             };
-            std::vector<std::thread> th;
-            for (unsigned k = 1; k < T; k++) th.emplace_back(work, k);
-            work(0);
-            for (auto &x : th) x.join();
+            tr->copy_pool.run(T, work);
             for (unsigned k = 0; k < T; k++) {
                 if (rcs[k]) return fail(rcs[k], msgs[k]);
                 tr->stats[c].merge(st[k]);
@@ -291,6 +293,12 @@ int fwgpu_trainer_digest_text(fwgpu_trainer *tr, fwgpu_parser *parser, fwgpu_cac
             words_cap = cap;
         }
     };
+    struct Clones {  // one parser clone per extra thread (VowpalParser is not thread safe), for the length of this call
+        std::vector<fwgpu_parser *> p;
+        ~Clones() {
+            for (fwgpu_parser *q : p) fwgpu_parser_free(q);
+        }
+    } clones;
     // Two stages, pipelined over chunks of the text: chunk i+1 is parsed (T threads) while chunk i's records are digested (staging
     // copy, upload, learn launches) on a helper thread, in order.  One pass over the whole buffer (parse everything, then digest
     // everything) left the GPU idle while parsing and the parsers idle while learning: 1.3 M lines/s on 16 threads.
@@ -316,15 +324,7 @@ int fwgpu_trainer_digest_text(fwgpu_trainer *tr, fwgpu_parser *parser, fwgpu_cac
         Slice &s = sl[k];
         const uint64_t n = s.end - s.begin;
         if (!n) return;
-        fwgpu_parser *p = parser, *own = nullptr;
-        if (k > 0) {
-            s.rc = fwgpu_parser_clone(parser, &own);
-            if (s.rc) {
-                s.msg = fwgpu_last_error();
-                return;
-            }
-            p = own;
-        }
+        fwgpu_parser *p = k > 0 ? clones.p[k - 1] : parser;
         uint64_t lines = 0;
         for (const char *q = text + s.begin, *e = text + s.end; q < e; lines++) {
             const void *nl = memchr(q, '\n', (size_t)(e - q));
@@ -356,15 +356,15 @@ int fwgpu_trainer_digest_text(fwgpu_trainer *tr, fwgpu_parser *parser, fwgpu_cac
                 s.grow(s.words_cap * 2);
             }
         }
-        if (own) fwgpu_parser_free(own);
     };
-    {
-        std::vector<std::thread> th;
-        for (unsigned k = 1; k < T; k++) th.emplace_back(work, k);
-        work(0);
-        for (auto &x : th) x.join();
+    tr->parse_pool.run(T, work);
+    };
+    for (unsigned k = 1; k < T; k++) {
+        fwgpu_parser *c = nullptr;
+        const int crc = fwgpu_parser_clone(parser, &c);
+        if (crc) return crc;
+        clones.p.push_back(c);
     }
-    };
     uint64_t done = 0, used = 0;
     // digests the slices of one chunk in order; false: stop (rc says why: an error, or a command line reached)
     auto digest_slices = [&](std::vector<Slice> &sl, int &rc, std::string &msg) -> bool {
@@ -392,8 +392,11 @@ int fwgpu_trainer_digest_text(fwgpu_trainer *tr, fwgpu_parser *parser, fwgpu_cac
         }
         return rc == FWGPU_OK;
     };
-    // chunks of at least 4 MB of text per parser thread, at most 64 MB in all, cut at line breaks
-    const uint64_t chunk_target = std::min<uint64_t>(std::max<uint64_t>((uint64_t)T * (4u << 20), 16u << 20), 64u << 20);
+    // chunks of about 1 MB of text per parser thread (the threads are a pool: a chunk costs no thread start), 8 to 64 MB in all
+    // (FWGPU_TEXT_CHUNK_MB overrides), cut at line breaks
+    uint64_t chunk_target = std::min<uint64_t>(std::max<uint64_t>((uint64_t)T * (1u << 20), 8u << 20), 64u << 20);
+    if (const char *env = getenv("FWGPU_TEXT_CHUNK_MB"))
+        if (atoi(env) > 0) chunk_target = (uint64_t)atoi(env) << 20;
     std::vector<Slice> cur, next;
     int rc = FWGPU_OK;
     std::string msg;
@@ -413,9 +416,19 @@ int fwgpu_trainer_digest_text(fwgpu_trainer *tr, fwgpu_parser *parser, fwgpu_cac
         pos = e;
         have = true;
     }
+    const bool timing = getenv("FWGPU_TRAINER_TIMING") != nullptr;  // per chunk: parse of the next chunk / digest of this one, ms
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
     while (have) {
         bool go_on = true;
-        std::thread dg([&] { go_on = digest_slices(cur, rc, msg); });
+        double t_digest = 0.0;
+        const auto t0 = now();
+        std::thread dg([&] {
+            go_on = digest_slices(cur, rc, msg);
+            t_digest = ms(t0, now());
+        });
         bool parsed_next = false;
         if (pos < len) {
             const uint64_t e = chunk_end(pos);
@@ -423,7 +436,9 @@ int fwgpu_trainer_digest_text(fwgpu_trainer *tr, fwgpu_parser *parser, fwgpu_cac
             pos = e;
             parsed_next = true;
         }
+        const double t_parse = ms(t0, now());
         dg.join();
+        if (timing) fprintf(stderr, "[digest_text] chunk: parse of the next %.2f ms, digest of this one %.2f ms, both %.2f ms\n", t_parse, t_digest, ms(t0, now()));
         if (!go_on || !parsed_next) break;  // (a chunk parsed past a command line or an error is dropped: `consumed` says where to resume)
         cur.swap(next);
     }

@@ -71,7 +71,7 @@ if gpu:
         print(f"predict_batch({nb}): {dtb * 1e3:.2f} ms = {nb / dtb:,.0f} predictions/s")
     print(f"fw_predict (one request per call, ~200 features): {dt1 * 1e6:.0f} us per call")
 if gpu:
-    big = text * 8  # 160 000 lines, ~295 MB of text
+    big = text * 24  # 480 000 lines, ~885 MB of text (long enough that the trainer's staging buffers have stopped growing)
     for th in (1, 8, 16, 32):
         re2 = fw.Regressor(mi)
         tr = fw.HogwildTrainer(re2, mi, micro_batch=16384)
