@@ -700,10 +700,25 @@ __device__ __forceinline__ float nn_forward(const KernelParams &p, const Lds &s,
 #define FW_NN_FJU 4
 #endif
         constexpr int JU = FW_NN_FJU;
+        // hogwild launches: the same dot products from 16-byte device-scope loads (4-byte ones run at a third of the rate);
+        // the order of the sum differs, which only the in-order mode promises
+        const bool vec16 = COH && gridDim.x > 1 && (in & 3u) == 0 && (n.off[l] & 3u) == 0 && ((uintptr_t)in_vec & 15u) == 0;
         for (uint32_t j0 = wave * JU; j0 < out; j0 += nw * JU) {
             float dot[JU];
 #pragma unroll
             for (int u = 0; u < JU; ++u) dot[u] = 0.0f;
+            if (vec16) {
+                const __amdgpu_buffer_rsrc_t rw = make_rsrc(W, in * out * 4);
+                for (uint32_t q = lane; q < (in >> 2); q += 64) {
+                    f4 w[JU];
+#pragma unroll
+                    for (int u = 0; u < JU; ++u)
+                        w[u] = j0 + u < out ? Vec<4>::load<kAuxSc1>(rw, ((j0 + u) * in + 4 * q) * 4) : Vec<4>::zero();
+                    const f4 xv = Vec<4>::lds_load(in_vec + 4 * q);
+#pragma unroll
+                    for (int u = 0; u < JU; ++u) dot[u] += w[u][0] * xv[0] + w[u][1] * xv[1] + w[u][2] * xv[2] + w[u][3] * xv[3];
+                }
+            } else
             for (uint32_t i = lane; i < in; i += 64) {
                 float w[JU];
 #pragma unroll
@@ -805,6 +820,109 @@ __device__ __forceinline__ void nn_layer_backward(const DevNN &n, uint32_t l, co
     }
 }
 
+// The same layer backward for HOGWILD launches, where no order is promised: 16-byte device-scope accesses instead of 4-byte
+// ones (a scalar sc1 store is a fabric write of its own, about 6x the time per byte of a 16-byte one: at config E the head
+// issued 388 k of them per example, against 13 k for the whole FFM update), and every thread of the workgroup busy: thread
+// (q, grp) owns input columns 4q .. 4q+3 for the neurons of group grp; the groups' shares of the input gradient meet in LDS.
+// Needs 16-byte aligned rows (in % 4 == 0, layer offset % 4 == 0) and in / 4 <= workgroup size; otherwise the caller keeps
+// nn_layer_backward.  Contains barriers: called by every thread.
+#ifndef FW_NN_VJU
+#define FW_NN_VJU 4
+#endif
+template <int OPT>
+__device__ __forceinline__ void nn_layer_backward_vec(const DevNN &n, uint32_t l, const float *og, const float *in_a,
+                                                      uint32_t split, const float *in_b, float *grad_a, float *grad_b,
+                                                      int tid, int bd) {
+    const uint32_t in = n.in[l], out = n.out[l], nq = in >> 2;
+    float *W = n.w + n.off[l], *A = n.acc + n.off[l];
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(W, in * out * 4), ra = make_rsrc(A, in * out * 4);
+    uint32_t G = (uint32_t)bd / nq;
+    G = G > out ? out : G;
+    const uint32_t q = (uint32_t)tid % nq, grp = (uint32_t)tid / nq;
+    const bool active = grp < G;
+    const uint32_t jn = (out + G - 1) / G, jlo = grp * jn, jhi = jlo + jn < out ? jlo + jn : out;
+    f4 xi = Vec<4>::zero(), oe = Vec<4>::zero();
+    if (active) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t i = 4 * q + c;
+            xi[c] = i < split ? in_a[i] : in_b[i - split];
+        }
+        constexpr int JU = FW_NN_VJU;  // neurons in flight per thread: 2 x JU x 16 bytes
+        for (uint32_t j0 = jlo; j0 < jhi; j0 += JU) {
+            f4 w[JU], a[JU];
+            float gg[JU];
+#pragma unroll
+            for (int u = 0; u < JU; ++u) {
+                const uint32_t j = j0 + u;
+                gg[u] = j < jhi ? og[j] : 0.0f;
+                w[u] = Vec<4>::zero();
+                a[u] = Vec<4>::zero();
+                if (gg[u] != 0.0f) {  // block_neural.rs:275-277
+                    const uint32_t bo = (j * in + 4 * q) * 4;
+                    w[u] = Vec<4>::load<kAuxSc1>(rw, bo);
+                    if (OPT != FWGPU_OPT_SGD) a[u] = Vec<4>::load<kAuxSc1>(ra, bo);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < JU; ++u) {
+                if (gg[u] == 0.0f) continue;
+                const uint32_t bo = ((j0 + u) * in + 4 * q) * 4;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float acc = a[u][c];
+                    const float upd = opt_step<OPT>(gg[u] * xi[c], acc, n.rate, n.minus_power_t, n.lut);
+                    oe[c] += w[u][c] * gg[u];
+                    w[u][c] = w[u][c] - upd;
+                    a[u][c] = acc;
+                }
+                Vec<4>::store<kAuxSc1>(w[u], rw, bo);
+                if (OPT != FWGPU_OPT_SGD) Vec<4>::store<kAuxSc1>(a[u], ra, bo);
+            }
+        }
+    }
+    __syncthreads();  // every thread has read its inputs: the gradients may overwrite them (in_vals and in_grad alias)
+    if (active && grp == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t i = 4 * q + c;
+            if (i < split) grad_a[i] = oe[c];
+            else grad_b[i - split] = oe[c];
+        }
+    }
+    __syncthreads();
+    if (active && grp != 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t i = 4 * q + c;
+            atomicAdd(i < split ? &grad_a[i] : &grad_b[i - split], oe[c]);
+        }
+    }
+    for (uint32_t j = tid; j < out; j += bd) {  // bias terms (block_neural.rs:296-306)
+        const float gg = og[j];
+        if (gg != 0.0f) {
+            const size_t ix = (size_t)in * out + j;
+            const float w = nn_ld<true>(W + ix);
+            float acc = OPT == FWGPU_OPT_SGD ? 0.0f : nn_ld<true>(A + ix);
+            const float upd = opt_step<OPT>(gg, acc, n.rate, n.minus_power_t, n.lut);
+            nn_st<true>(W + ix, w - upd);
+            if (OPT != FWGPU_OPT_SGD) nn_st<true>(A + ix, acc);
+        }
+    }
+}
+
+// one layer's backward: the 16-byte form in hogwild launches where the layer's shape allows it (uniform across the workgroup)
+template <int OPT, bool COH>
+__device__ __forceinline__ void nn_layer_backward_any(const DevNN &n, uint32_t l, const float *og, const float *in_a,
+                                                      uint32_t split, const float *in_b, float *grad_a, float *grad_b,
+                                                      int tid, int bd) {
+    const uint32_t in = n.in[l];
+    if (COH && gridDim.x > 1 && in >= 4 && (in & 3u) == 0 && (n.off[l] & 3u) == 0 && (in >> 2) <= (uint32_t)bd)
+        nn_layer_backward_vec<OPT>(n, l, og, in_a, split, in_b, grad_a, grad_b, tid, bd);
+    else
+        nn_layer_backward<OPT, COH>(n, l, og, in_a, split, in_b, grad_a, grad_b, tid, bd);
+}
+
 // The unwinding of the head: final neuron, then [ReLU mask, layer] from last to first, BlockCopy summing both branches.
 // Leaves d logit/d x in xg[] (LR slot gradients first, then the triangle gradients).
 template <int OPT, bool COH>
@@ -816,7 +934,7 @@ __device__ __forceinline__ void nn_backward(const KernelParams &p, const Lds &s,
     if (tid == 0) b.fg[0] = g;  // og of the single final neuron
     __syncthreads();
     // final neuron: inputs [h_last | x], input gradients -> [h_last (in place) | xg]
-    nn_layer_backward<OPT, COH>(n, L, b.fg, b.h + hoff_last, wl, b.x, b.h + hoff_last, b.xg, tid, bd);
+    nn_layer_backward_any<OPT, COH>(n, L, b.fg, b.h + hoff_last, wl, b.x, b.h + hoff_last, b.xg, tid, bd);
     if (n.topology != 1)
         for (uint32_t i = tid; i < X; i += bd) b.xg[i] = 0.0f;
     __syncthreads();
@@ -828,12 +946,12 @@ __device__ __forceinline__ void nn_backward(const KernelParams &p, const Lds &s,
         __syncthreads();
         if (l > 0) {
             const uint32_t pin = n.out[l - 1];
-            nn_layer_backward<OPT, COH>(n, l, b.m + hoff, b.h + hoff - pin, pin, b.h + hoff - pin, b.h + hoff - pin,
+            nn_layer_backward_any<OPT, COH>(n, l, b.m + hoff, b.h + hoff - pin, pin, b.h + hoff - pin, b.h + hoff - pin,
                                             b.h + hoff - pin, tid, bd);
             hoff -= pin;
         } else {
             // first layer: inputs x; its input gradient is ADDED to the copy branch (BlockCopy, block_misc.rs:456-475)
-            nn_layer_backward<OPT, COH>(n, 0, b.m + hoff, b.x, X, b.x, b.fg, b.fg, tid, bd);
+            nn_layer_backward_any<OPT, COH>(n, 0, b.m + hoff, b.x, X, b.x, b.fg, b.fg, tid, bd);
             __syncthreads();
             for (uint32_t i = tid; i < X; i += bd) b.xg[i] = b.fg[i] + b.xg[i];
         }
