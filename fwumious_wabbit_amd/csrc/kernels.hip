@@ -359,6 +359,7 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
         s.ctr[1] = 0;  // some FFM rows of this example overlap an earlier row (exact)
         s.ctr[2] = 0;  // pre-filter: rows MAY overlap
         s.ctr[3] = 0;  // duplicate LR hashes in this example
+        s.ctr[14] = 0;  // deep head: LR entries not grouped by combo slot (nn_forward)
     }
     if (do_update) {
         for (uint32_t i = tid; i < g.setf_n; i += bd) {
@@ -656,12 +657,29 @@ __device__ __forceinline__ float nn_forward(const KernelParams &p, const Lds &s,
     const NnBuf b = nn_buf(p, s);
     const DevNN &n = p.nn;
     const uint32_t F = p.F, k = p.k, R = p.R, C = p.num_combos;
-    for (uint32_t i = tid; i < nl; i += bd) b.prod[i] = lr_load<COH>(p.lr, s.l_hash[i]).x * s.l_val[i];
+    for (uint32_t i = tid; i < nl; i += bd) {
+        b.prod[i] = lr_load<COH>(p.lr, s.l_hash[i]).x * s.l_val[i];
+        if (i + 1 < nl && s.l_combo[i] > s.l_combo[i + 1]) s.ctr[14] = 1;  // (zeroed by the stage phase)
+    }
     __syncthreads();
-    for (uint32_t c = tid; c < C; c += bd) {  // each combo slot sums its entries in buffer order
+    // Each combo slot sums its entries in buffer order.  The translator emits the entries combo by combo (feature_buffer.rs:194-267),
+    // so slot c's entries are one run, found by bisection; a batch of entries in any other order takes the full scan (the scan
+    // by 31 threads over 200 entries each was 30 us of an example's 210).
+    const bool by_combo = s.ctr[14] == 0;
+    for (uint32_t c = tid; c < C; c += bd) {
         float acc = 0.0f;
-        for (uint32_t i = 0; i < nl; ++i)
-            if (s.l_combo[i] == c) acc += b.prod[i];
+        if (by_combo) {
+            uint32_t lo_ = 0, hi_ = nl;  // first entry with l_combo >= c
+            while (lo_ < hi_) {
+                const uint32_t mid = (lo_ + hi_) >> 1;
+                if (s.l_combo[mid] < c) lo_ = mid + 1;
+                else hi_ = mid;
+            }
+            for (uint32_t i = lo_; i < nl && s.l_combo[i] == c; ++i) acc += b.prod[i];
+        } else {
+            for (uint32_t i = 0; i < nl; ++i)
+                if (s.l_combo[i] == c) acc += b.prod[i];
+        }
         b.x[c] = acc;
     }
     const uint32_t T = F * (F + 1) / 2;
@@ -848,7 +866,8 @@ __device__ __forceinline__ void nn_layer_backward_vec(const DevNN &n, uint32_t l
             const uint32_t i = 4 * q + c;
             xi[c] = i < split ? in_a[i] : in_b[i - split];
         }
-        constexpr int JU = FW_NN_VJU;  // neurons in flight per thread: 2 x JU x 16 bytes
+        constexpr int JU = FW_NN_VJU;  // neurons in flight per thread: 2 x JU x 16 bytes (8 in flight, and loading the next batch
+                                       // while this one is stepped, both measured slower: registers)
         for (uint32_t j0 = jlo; j0 < jhi; j0 += JU) {
             f4 w[JU], a[JU];
             float gg[JU];

@@ -9,7 +9,7 @@ import bench
 
 class A: pass
 args = A(); args.fields, args.k, args.bits, args.ffm_bits = int(os.environ.get("FIELDS", 30)), int(os.environ.get("K", 8)), 28, 28
-args.nn_layers, args.nn_width = 0, 256
+args.nn_layers, args.nn_width = int(os.environ.get("NN_LAYERS", 0)), 256
 args.mean_extra, args.zipf, args.ids, args.p_weighted, args.seed = 5.67, 1.05, 10_000_000, 0.1, 20240612
 B = int(os.environ.get("B", 16384)); NB = 3
 mi = bench.build_model_instance(fw, args, 0)
