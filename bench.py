@@ -247,6 +247,11 @@ def main():
                     help="run the RCCL replica-sync path even with one rank (smoke test of the N>1 code on one GPU)")
     ap.add_argument("--no-traffic", dest="traffic", action="store_false",
                     help="skip the live HBM-traffic measurement (two short rocprofv3 --pmc child runs of this very command)")
+    ap.add_argument("--curve-every", dest="curve_every", type=int, default=0,
+                    help="hold-out log-loss checkpoints: a predict-only pass over the hold-out tail after every this many timed steps, queued on the "
+                         "stream between steps and read after the timed region (0 = about 5 checkpoints per run; each costs ~0.3 ms of the timed wall time)")
+    ap.add_argument("--target-logloss", dest="target_logloss", type=float, default=None,
+                    help="seconds_to_logloss target (default: 0.985 x the loss of always predicting the hold-out's positive rate)")
     ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
     ap.add_argument("--cpu-examples", dest="cpu_examples", type=int, default=0)
     args = ap.parse_args()
@@ -295,16 +300,21 @@ def main():
     t0 = time.time()
     first = rank * (W + K) * B
     recs, off = gen_records(fw, args, first, (W + K) * B)
-    batches, words = [], []
+    batches, words, blabels = [], [], []
     for s in range(W + K):
         lo, hi = s * B, (s + 1) * B
         sub = recs[int(off[lo]):int(off[hi])]
         # raw records in HBM; FeatureBufferTranslator::translate (a2) runs inside the kernel's stage phase
         batches.append(re.record_batch(fbt, sub, off[lo:hi + 1] - off[lo]))
         words.append(len(sub))
+        blabels.append(sub[(off[lo:hi] - off[lo]).astype(np.int64) + 1].astype(np.float32))
     hrecs, hoff = gen_records(fw, args, 1_000_000_000, args.holdout)  # same hold-out tail on every rank
     hbatch = re.record_batch(fbt, hrecs, hoff)
     hy = hrecs[hoff[:-1].astype(np.int64) + 1].astype(np.float32)
+    # loss-vs-examples curve: hold-out passes between timed steps, each into a batch object of its own (predictions are read after the run)
+    curve_every = args.curve_every or max(1, K // 5)
+    curve_steps = [i for i in range(K) if (i + 1) % curve_every == 0 and i + 1 < K]
+    curve_batches = {i: re.record_batch(fbt, hrecs, hoff) for i in curve_steps}
     del recs
     prep_s = time.time() - t0
 
@@ -397,6 +407,8 @@ def main():
         ev[2 * i + 1].record(stream)
         if use_dist and not sharded_main and (i + 1) % sync_every == 0 and i <= last_sync_step:
             sync_replicas()
+        if i in curve_batches and not sharded_main:  # hold-out checkpoint (predict-only, main.rs:238-241), inside the wall time, outside the step's events
+            re.learn_batch(curve_batches[i], capi.MODE_HOGWILD, False, sptr)
     if use_dist and not sharded_main:
         syncer.finish()  # the exchange still in flight lands INSIDE the timed region
     torch.cuda.synchronize()
@@ -426,6 +438,18 @@ def main():
     # ---- final hold-out log-loss (main.rs:238-241 --holdout_after semantics: predicted, never learned)
     re.learn_batch(hbatch, capi.MODE_HOGWILD, False, sptr)
     final_ll = logloss(hbatch.predictions(sptr), hy)
+    # time to quality (benchmark/calc_loss.py:5-25 on the hold-out tail): loss after n learned examples (warm-up steps learn too), and the
+    # wall time this run needs to reach a stated target at its measured rate
+    prior_ll = logloss(np.full(len(hy), float(np.mean(hy == 1)), dtype=np.float64), hy)
+    curve = {}
+    if not sharded_main:
+        for i in curve_steps:
+            curve[(W + i + 1) * B * world] = logloss(curve_batches[i].predictions(sptr), hy)
+    curve[(W + K) * B * world] = final_ll
+    # progressive validation on the training stream itself (the prediction every example got BEFORE it was learned), per timed step
+    progressive = [] if sharded_main else [round(logloss(batches[W + i].predictions(sptr), blabels[W + i]), 5) for i in range(K)]
+    target_ll = args.target_logloss if args.target_logloss is not None else 0.985 * prior_ll
+    reached = [n for n, v in sorted(curve.items()) if v <= target_ll]
     # guard: a saturated sigmoid (|logit| > 50, block_loss_functions.rs:125-133) skips the update; report how many of
     # the last timed step's examples were in that state (healthy training: 0)
     p_last = batches[W + K - 1].predictions(sptr)
@@ -526,7 +550,12 @@ def main():
             "table_placement": dict(zip(("candidates_tried", "pair_probe_ms_kept", "pair_probe_ms_slowest"), re.placement())),
             "final_logloss": final_ll,
             # what "learned" means on this hold-out tail: the loss of always predicting its positive rate (the untrained model reads ln 2)
-            "holdout_prior_logloss": logloss(np.full(len(hy), float(np.mean(hy == 1)), dtype=np.float64), hy),
+            "holdout_prior_logloss": prior_ll,
+            "logloss_after_examples": {str(n): v for n, v in sorted(curve.items())},
+            "progressive_logloss_per_step": progressive,
+            "seconds_to_logloss": {"target": target_ll, "examples": reached[0] if reached else None,
+                                   "seconds": (reached[0] / (world * K * B / elapsed)) if reached else None,
+                                   "what": "first hold-out checkpoint at or below the target; seconds = examples learned so far (warm-up included) / this run's examples/sec"},
             "saturated_fraction_last_step": saturated,
             "config": {
                 "hyperparameters": f"AdagradLUT lr={LR} power_t={POWER_T} init_acc_gradient={INIT_ACC} (run_one.sh)",
@@ -592,7 +621,7 @@ def main():
                 out["dp_modes"] = {"replica": "the timed mode of this line", "error": f"the sparse / sharded legs did not finish within {args.other_modes_timeout} s"}
                 sys.stdout.flush()
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)  # a hung collective is a failure: the line is out, the exit status says so (no re-exec, no restart from here)
 
         dog = threading.Timer(args.other_modes_timeout, bail)
         dog.daemon = True

@@ -138,7 +138,7 @@ struct LaunchConfig {
     int32_t lut_global = 0;
     int32_t window = 1;              // whole-line FFM row updates: 0 off, 1 auto (tables > Infinity Cache), 2 always (debug option 2)
     int32_t no_chain = 0;            // debug option 3
-    uint32_t hot_lr_every = 32;      // debug option 4
+    uint32_t hot_lr_every = 1;       // debug option 4: hot LR entry route (0 off, 1 atomics per example, n>1 weight deltas pending n examples)
     bool threads_set = false;
     uint32_t max_in_flight = 0;  // cap on the persistent grid = examples processed concurrently (0: what the device holds)  // fwgpu_set_launch chose the workgroup size: no automatic choice
 };

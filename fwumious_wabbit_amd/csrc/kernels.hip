@@ -204,6 +204,57 @@ __device__ __forceinline__ bool set_contains(const uint32_t *tab, uint32_t mask,
     }
 }
 
+// The hot LR entry of a hogwild launch (the constant feature's: it is in every example, feature_buffer.rs:270-276).  Every
+// workgroup's read-modify-write of that one 8-byte entry goes to the memory side and they serialise there (measured: 60-80 ns
+// per write, which capped a 10-field model at 16 M examples/s), and of the ~10 that overlap at any moment only the last write
+// survives.  So in hogwild launches this one entry is stepped with fire-and-forget atomics instead of load + store:
+//   * the step is taken at (the accumulator this example's FORWARD pass read) + g^2 -- the forward pass loads the entry's
+//     {w, acc} pair anyway, so the accumulator is as fresh as the weight the prediction was made with: stale by at most the
+//     examples in flight, which is hogwild's own staleness (hogwild.rs:89-103: a thread reads, steps, writes back);
+//     `acc += g^2` then goes to the table as an atomic add, so every example's g^2 arrives whatever the interleaving.
+//     (Round 2 stepped on a per-WORKGROUP snapshot of the accumulator refreshed every 32 of the workgroup's examples: with short
+//     launches every workgroup took all its steps at the launch-start accumulator, i.e. at the largest step size, and the entry
+//     overshot -- GPUTEST_r02.  The step SIZE must follow the global accumulator; only the weight delta tolerates batching.)
+//   * the weight delta is added with an atomic as well; `hot_lr_every` (ctr[13]) > 1 keeps a workgroup's deltas pending in LDS
+//     for that many of its examples first (its own forward passes see them), 1 sends every step at once.
+// Nothing is lost: the entry's accumulator ends a launch at acc0 + the sum of all examples' g^2, which a test checks.
+// In-order launches (one workgroup, the bit-exact mode) and the phases of the synchronous pipeline do not use it.
+// (The switch and the entry's hash sit in LDS next to the state, ctr[13] / ctr[12], so that nothing of this stays live in
+// scalar registers across the example loop: the v2 kernel has none to spare.  State: hot[0] = the accumulator the forward pass
+// read, hot[1] = pending weight delta.)
+__device__ __forceinline__ float *hot_lr_state(const Lds &s) { return reinterpret_cast<float *>(s.ctr + 8); }
+__device__ __forceinline__ bool hot_lr_is(const Lds &s, uint32_t h) { return s.ctr[13] != 0 && h == s.ctr[12]; }
+template <bool COH>
+__device__ __forceinline__ void hot_lr_init(const KernelParams &p, const Lds &s, bool fused) {  // thread 0, before the example loop
+    const bool on = fused && COH && p.hot_lr_every != 0 && p.has_lr && p.update && gridDim.x > 1;
+    s.ctr[13] = on ? p.hot_lr_every : 0;
+    s.ctr[12] = p.hot_lr_hash;
+    s.ctr[7] = 0;
+    float *hot = hot_lr_state(s);
+    hot[0] = hot[1] = hot[2] = 0.0f;
+}
+// The pending weight delta goes to the table (taken out of LDS by exchange: a step another thread adds meanwhile stays pending).
+// Called by the thread that has just stepped the entry, every ctr[13] examples, and by thread 0 after the example loop.
+__device__ __forceinline__ void hot_lr_flush(const KernelParams &p, const Lds &s) {
+    float *hot = hot_lr_state(s);
+    const float dw = atomicExch(hot + 1, 0.0f);
+    s.ctr[7] = 0;
+    if (dw == 0.0f) return;
+    __hip_atomic_fetch_add(p.lr + 2 * (size_t)s.ctr[12], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// The weight of LR entry `h` as the forward pass sees it (block_lr.rs:36-45); for the hot entry: + this workgroup's pending
+// delta, and the accumulator that came with it is kept for the update phase.
+template <bool COH>
+__device__ __forceinline__ float lr_forward_weight(const KernelParams &p, const Lds &s, uint32_t h) {
+    const float2 wa = lr_load<COH>(p.lr, h);
+    if (COH && hot_lr_is(s, h)) {
+        float *hot = hot_lr_state(s);
+        hot[0] = wa.y;
+        return wa.x + hot[1];
+    }
+    return wa.x;
+}
+
 __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t max_ffm, uint32_t max_lr, uint32_t n_luts,
                                              uint32_t max_rec, uint32_t tr_items, uint32_t nn_floats, bool chain, size_t *off /*[23]*/) {
     size_t o = 0;
@@ -658,7 +709,7 @@ __device__ __forceinline__ float nn_forward(const KernelParams &p, const Lds &s,
     const DevNN &n = p.nn;
     const uint32_t F = p.F, k = p.k, R = p.R, C = p.num_combos;
     for (uint32_t i = tid; i < nl; i += bd) {
-        b.prod[i] = lr_load<COH>(p.lr, s.l_hash[i]).x * s.l_val[i];
+        b.prod[i] = lr_forward_weight<COH>(p, s, s.l_hash[i]) * s.l_val[i];
         if (i + 1 < nl && s.l_combo[i] > s.l_combo[i + 1]) s.ctr[14] = 1;  // (zeroed by the stage phase)
     }
     __syncthreads();
@@ -982,59 +1033,28 @@ __device__ __forceinline__ void nn_backward(const KernelParams &p, const Lds &s,
 // buffer order, on one register copy of {w, acc}: duplicates chain exactly like the reference's loop (regressor.rs:629-655
 // pins this).  The entry is read again here rather than kept from the forward pass: keeping it saved no time and widened
 // the hogwild read-modify-write window of hot entries (constant feature) by two phases.
-// The hot LR entry of a hogwild launch (the constant feature's: it is in every example, feature_buffer.rs:270-276).  Every
-// workgroup's read-modify-write of that one 8-byte entry goes to the memory side and they serialise there (measured: 60-80 ns
-// per write, which capped a 10-field model at 16 M examples/s and cost the headline config 1.6 %), and of the ~10 that overlap
-// at any moment only the last write survives.  So a workgroup keeps its steps on that entry in LDS -- optimizer steps taken
-// one by one on (acc snapshot + own pending acc), exactly the per-example arithmetic -- and every `hot_lr_every` examples the
-// thread that has just stepped it adds the pending deltas to the table with two float atomics (nothing is lost: the entry's
-// accumulator ends a launch at acc0 + the sum of all examples' g^2, which a test checks) and takes a fresh acc snapshot;
-// thread 0 flushes the rest when the workgroup leaves.  In-order launches (one workgroup, the bit-exact mode) and the phases of
-// the synchronous pipeline do not use it.  Measured (scripts/hot_lr_ab.sh): 10-field model 16 -> 49 M examples/s, LR-only
-// 11.8 -> 22 M, headline config +1.5 %, hold-out loss unchanged.
-// (The switch and the entry's hash sit in LDS next to the state, ctr[13] / ctr[12], so that nothing of this stays live in
-// scalar registers across the example loop: the v2 kernel has none to spare.)
-__device__ __forceinline__ float *hot_lr_state(const Lds &s) { return reinterpret_cast<float *>(s.ctr + 8); }
-__device__ __forceinline__ bool hot_lr_is(const Lds &s, uint32_t h) { return s.ctr[13] != 0 && h == s.ctr[12]; }
-template <bool COH>
-__device__ __forceinline__ void hot_lr_init(const KernelParams &p, const Lds &s, bool fused) {  // thread 0, before the example loop
-    const bool on = fused && COH && p.hot_lr_every != 0 && p.has_lr && p.update && gridDim.x > 1;
-    s.ctr[13] = on ? p.hot_lr_every : 0;
-    s.ctr[12] = p.hot_lr_hash;
-    s.ctr[7] = 0;
-    float *hot = hot_lr_state(s);
-    hot[0] = on ? lr_load<true>(p.lr, p.hot_lr_hash).y : 0.0f;
-    hot[1] = hot[2] = 0.0f;
-}
-// The pending deltas go to the table (taken out of LDS by exchange: a step another thread adds meanwhile stays pending).
-// Called by the thread that has just stepped the entry, every ctr[13] examples, and by thread 0 after the example loop.
-__device__ __forceinline__ void hot_lr_flush(const KernelParams &p, const Lds &s) {
-    float *hot = hot_lr_state(s);
-    const float dw = atomicExch(hot + 1, 0.0f), dacc = atomicExch(hot + 2, 0.0f);
-    s.ctr[7] = 0;
-    if (dw == 0.0f && dacc == 0.0f) return;
-    float *entry = p.lr + 2 * (size_t)s.ctr[12];
-    __hip_atomic_fetch_add(entry, dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    hot[0] = __hip_atomic_fetch_add(entry + 1, dacc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + dacc;
-}
-
 template <int OPT, bool COH>
 __device__ __forceinline__ void lr_update(const KernelParams &p, const Lds &s, uint32_t nl, float g, const float *gx,
                                           const float *lut_lr, int tid, int bd, uint32_t lo = 0, uint32_t hi = 0xffffffffu) {
     for (uint32_t t = tid; t < nl; t += bd) {
         const uint32_t fl = s.l_flag[t];
         const uint32_t h = s.l_hash[t];
-        if (COH && hot_lr_is(s, h)) {  // (every entry of that hash steps from the same snapshot; chains are for the table route)
+        if (COH && hot_lr_is(s, h)) {  // (every entry of that hash steps from the accumulator the forward pass read; chains are for the table route)
+            float *entry = p.lr + 2 * (size_t)h;
             float *hot = hot_lr_state(s);
-            const float a0 = hot[0] + hot[2];
-            float acc = a0;
-            const float upd = opt_step<OPT>((gx ? gx[s.l_combo[t]] : g) * s.l_val[t], acc, p.lr_rate, p.lr_minus_power_t, lut_lr);
-            atomicAdd(hot + 1, -upd);
-            atomicAdd(hot + 2, acc - a0);
-            if (!(fl & kRowChained)) {  // (one entry of that hash per example is not chained)
-                const uint32_t n = s.ctr[7] + 1;
-                s.ctr[7] = n;
-                if (n >= s.ctr[13]) hot_lr_flush(p, s);
+            const float grad = (gx ? gx[s.l_combo[t]] : g) * s.l_val[t];
+            float acc = hot[0];
+            const float upd = opt_step<OPT>(grad, acc, p.lr_rate, p.lr_minus_power_t, lut_lr);  // (acc += g^2 first: optimizer.rs:76-77, 147-149)
+            if (OPT != FWGPU_OPT_SGD) __hip_atomic_fetch_add(entry + 1, grad * grad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (s.ctr[13] == 1) {
+                __hip_atomic_fetch_add(entry, -upd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                atomicAdd(hot + 1, -upd);
+                if (!(fl & kRowChained)) {  // (one entry of that hash per example is not chained)
+                    const uint32_t n = s.ctr[7] + 1;
+                    s.ctr[7] = n;
+                    if (n >= s.ctr[13]) hot_lr_flush(p, s);
+                }
             }
             continue;
         }
@@ -1531,9 +1551,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         float lrs = 0.0f;
         if (p.has_lr)
             for (uint32_t i = tid; i < nl; i += bd) {
-                float w = lr_load<COH>(p.lr, s.l_hash[i]).x;
-                if (COH && hot_lr_is(s, s.l_hash[i])) w += hot_lr_state(s)[1];  // this workgroup's pending steps
-                lrs += w * s.l_val[i];
+                lrs += lr_forward_weight<COH>(p, s, s.l_hash[i]) * s.l_val[i];
             }
         dot = wave_sum(dot);
         lrs = wave_sum(lrs);
@@ -2069,9 +2087,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? FW_LB_WAVES : 4) fw_e
         float lrs = 0.0f;
         if (p.has_lr)
             for (uint32_t i = tid; i < nl; i += bd) {
-                float w = lr_load<COH>(p.lr, s.l_hash[i]).x;
-                if (COH && hot_lr_is(s, s.l_hash[i])) w += hot_lr_state(s)[1];  // this workgroup's pending steps
-                lrs += w * s.l_val[i];
+                lrs += lr_forward_weight<COH>(p, s, s.l_hash[i]) * s.l_val[i];
             }
         dot = wave_sum(dot);
         lrs = wave_sum(lrs);

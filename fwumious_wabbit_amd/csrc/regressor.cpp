@@ -470,9 +470,14 @@ int fwgpu_abi_version(void) { return FWGPU_ABI_VERSION; }
 // out consecutive allocations from one group for several GB, so for tables beyond the Infinity Cache a few candidate allocations
 // are tried and timed against w with that very pattern (a fraction of a millisecond each); the fastest is kept, the rest freed.
 // FWGPU_PLACEMENT=0 switches the search off (the first allocation is used, as for small tables).
+// The search is BOUNDED: at most 8 candidates and at most a tenth of the free device memory held at once (other regressors,
+// ranks or tenants of the device must not run out of memory because this one is probing), and only two candidates when more
+// than half of the device is already in use by anyone.  FWGPU_PLACEMENT=wide asks for the round-2 scan (up to 112 candidates,
+// half of the free memory) for single-tenant benchmark boxes.
 static int place_ffm_acc(fwgpu_regressor *r, size_t fbytes) {
     const char *env = std::getenv("FWGPU_PLACEMENT");
     const bool search = fbytes > (256u << 20) && !(env && env[0] == '0');
+    const bool wide = env && env[0] == 'w';
     std::vector<float *> cand;
     float single = 0.0f, lo = 1e30f, hi = 0.0f;
     int best = 0;
@@ -500,8 +505,10 @@ static int place_ffm_acc(fwgpu_regressor *r, size_t fbytes) {
     // (Large "spacer" allocations to skip ahead do not work: they are assembled from elsewhere and the next table-sized block
     // still comes from the same stretch.)  A stretch of contending memory is up to ~72 table-GB long (tools/placement scan of
     // 200 x 1 GiB, profiles/r02_placement.txt), a probe costs about a millisecond.
-    const size_t budget = std::min<size_t>(free_b / 2, 128ull << 30);
-    const int max_tries = search && single > 0.0f ? (int)std::max<size_t>(2, std::min<size_t>(112, budget / fbytes)) : 1;
+    const bool crowded = total_b && free_b < total_b / 2;  // someone else (another process, other regressors) holds half the device
+    const size_t budget = wide ? std::min<size_t>(free_b / 2, 128ull << 30) : free_b / 10;
+    const size_t cap = wide ? 112 : (crowded ? 2 : 8);
+    const int max_tries = search && single > 0.0f ? (int)std::max<size_t>(2, std::min<size_t>(cap, budget / fbytes)) : 1;
     for (int t = 0; t < max_tries; t++) {
         float *c = nullptr;
         if (hipMalloc((void **)&c, fbytes) != hipSuccess) {

@@ -21,7 +21,8 @@
 //
 // All of this is HBM-bound row traffic (960 B rows at config C): coalesced lane-per-float accesses, no LDS, no MFMA.
 #include "fwgpu_device.h"
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 
 namespace fwgpu {
 
@@ -400,15 +401,15 @@ __global__ void sparse_apply_lr_kernel(const unsigned long long *keys, uint32_t 
 hipError_t sort_keys(void *tmp, size_t tmp_bytes, const unsigned long long *in, unsigned long long *out, uint32_t n, int end_bit,
                      hipStream_t stream) {
     size_t need = tmp_bytes;
-    return hipcub::DeviceRadixSort::SortKeys(tmp, need, in, out, (int)n, 0, end_bit, stream);
+    return rocprim::radix_sort_keys(tmp, need, in, out, (size_t)n, 0u, (unsigned)end_bit, stream);
 }
 
 }  // namespace
 
 size_t sparse_tmp_bytes(uint32_t n_max) {
     size_t a = 0, b = 0;
-    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, a, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (int)n_max, 0, 64, 0);
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_max + 1, 0);
+    (void)rocprim::radix_sort_keys(nullptr, a, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (size_t)n_max, 0u, 64u, (hipStream_t)0);
+    (void)rocprim::exclusive_scan(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (size_t)n_max + 1, rocprim::plus<uint32_t>(), (hipStream_t)0);
     return (std::max(a, b) + 255) & ~(size_t)255;
 }
 
@@ -419,7 +420,7 @@ hipError_t sparse_reduce(const SparseReduceArgs &a, hipStream_t stream) {
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(sparse_flags_kernel, dim3((a.n + 256) / 256), dim3(256), 0, stream, a.keys_sorted, a.n, a.flags);
     size_t need = a.tmp_bytes;
-    e = hipcub::DeviceScan::ExclusiveSum(a.tmp, need, a.flags, a.pos, (int)a.n + 1, stream);
+    e = rocprim::exclusive_scan(a.tmp, need, a.flags, a.pos, 0u, (size_t)a.n + 1, rocprim::plus<uint32_t>(), stream);
     if (e != hipSuccess) return e;
     e = hipMemcpyAsync(a.d_count, a.pos + a.n, 4, hipMemcpyDeviceToDevice, stream);
     if (e != hipSuccess) return e;
@@ -499,7 +500,10 @@ hipError_t pair_probe_ms(float *a, float *b, size_t bytes, uint32_t nrows, int r
     hipError_t e = hipEventCreate(&e0);
     if (e != hipSuccess) return e;
     e = hipEventCreate(&e1);
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess) {
+        (void)hipEventDestroy(e0);
+        return e;
+    }
     const uint32_t lines = (uint32_t)std::min<size_t>(bytes / 128, 0xffffffffu);
     float best = 1e30f;
     for (int i = 0; i <= reps; i++) {  // (the first one warms up)

@@ -389,9 +389,10 @@ class Regressor:
         check(self.L.fwgpu_debug_set_option(self.h, 2, int(mode)))
 
     def set_hot_lr_entry(self, every):
-        """HOGWILD launches (fwgpu_debug_set_option 4): a workgroup steps the constant feature's LR entry in LDS and adds its
-        pending deltas to the table every `every` examples with float atomics (default 32; 0 = plain read-modify-writes
-        per example, which serialise on that entry and lose most of the concurrent ones)"""
+        """HOGWILD launches (fwgpu_debug_set_option 4): the constant feature's LR entry is stepped with atomics -- the step size
+        always from the GLOBAL accumulator (returning atomic add of g^2), the weight delta by a fire-and-forget atomic, sent at
+        once (`every` = 1, the default) or kept pending in LDS for `every` examples of the workgroup; 0 = plain
+        read-modify-writes per example, which serialise on that entry and lose most of the concurrent ones"""
         check(self.L.fwgpu_debug_set_option(self.h, 4, int(every)))
 
     # ---- tables

@@ -1,26 +1,25 @@
-"""Spread of the hogwild hold-out loss of tests/test_gpu_parity.py's trainer and hogwild tests over repeated runs."""
-import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import numpy as np
-import fwumious_wabbit_amd as fw
-from fwumious_wabbit_amd import capi
-from helpers import make_pair, logloss, record_labels
-import test_gpu_parity as T
+"""Spread of |gpu hogwild hold-out loss - sequential oracle's| for every scenario of tests/test_zz_gpu_hogwild_quality.py, over repeated
+runs and for the routes of the hot LR entry (kernels.hip hot_lr_flush): 0 = plain read-modify-writes, 1 = atomics per example (default),
+32 = weight deltas pending 32 examples of a workgroup.  HOLDOUT_TOL of the tests rests on this table.
+usage: python scripts/holdout_spread.py [reps=8] [scenario ...]"""
+import os
+import sys
 
-n_train, n_hold = 12000, 2000
-mi, ocfg, ots = make_pair(10, 4, 18, 18, fw.Optimizer.AdagradLUT)
-recs, off = fw.synth_records(10, 0.0, 1.1, 100000, 0.0, 77, 0, n_train + n_hold)
-y = record_labels(recs, off)
-ref_hold, _ = T._holdout_loss_oracle(ocfg, ots, recs, off, n_train)
-vals = []
-for rep in range(12):
-    re = fw.Regressor(mi)
-    tr = fw.HogwildTrainer(re, mi, micro_batch=1024)
-    tr.digest_records(recs[:int(off[n_train])], off[:n_train + 1])
-    tr.block_until_workers_finished()
-    hb = re.batch_from_records(fw.FeatureBufferTranslator(mi), recs[int(off[n_train]):], off[n_train:] - off[n_train])
-    re.learn_batch(hb, capi.MODE_HOGWILD, False)
-    vals.append(float(logloss(hb.predictions(), y[n_train:]).mean()))
-    tr.close(); re.close()
-print("oracle sequential", ref_hold, "gpu hogwild", np.round(vals, 4), "max gap", max(abs(v - ref_hold) for v in vals))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+import test_zz_gpu_hogwild_quality as Q  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+names = sys.argv[2:] or list(Q.SCENARIOS)
+print(f"{'scenario':16s} {'hot_lr':>6s} {'oracle':>8s} {'gpu min':>8s} {'gpu max':>8s} {'max gap':>8s}")
+for name in names:
+    for hot in (0, 1, 32):
+        vals, ref = [], None
+        for _ in range(reps):
+            g, ref = Q.SCENARIOS[name](hot_lr=hot)
+            vals.append(g)
+        v = np.array(vals)
+        print(f"{name:16s} {hot:6d} {ref:8.4f} {v.min():8.4f} {v.max():8.4f} {np.abs(v - ref).max():8.4f}", flush=True)

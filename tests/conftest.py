@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "statistical: compares a concurrent (hogwild) run with a tolerance on a final loss / accuracy; "
+                                       "collected LAST so that a tolerance miss under -x cannot hide an exact-parity test")
     # a fresh checkout has no built artefacts: build them once (hipcc cross-compiles gfx950 without a GPU)
     lib = os.path.join(ROOT, "fwumious_wabbit_amd", "lib", "libfwgpu.so")
     if not os.path.exists(lib):
@@ -28,6 +30,8 @@ def _have_gpu():
 
 
 def pytest_collection_modifyitems(config, items):
+    # exact-parity tests first, statistical ones last (stable: the order inside each group is the collection order)
+    items.sort(key=lambda it: 1 if "statistical" in it.keywords else 0)
     # gpu-marked tests are only meaningful on the GPU box; skip (not fail) them elsewhere so that a
     # plain `pytest tests/` in the authoring container stays green.
     if _have_gpu():

@@ -178,6 +178,7 @@ def test_reference_example_datasets_lr(tmp_path, name, interactions, power_t, op
     assert len(np.unique(out[0][0][200:])) > 50  # and it is not predicting a constant
 
 
+@pytest.mark.statistical
 def test_text_to_trainer_natively_with_cache_writing(tmp_path):
     """fwgpu_trainer_digest_text: the reference's training loop over VW text with `-c` (main.rs:213-270), all in native
     code: several parser threads, records learned in file order (hogwild on the device), cache written on the way"""
@@ -219,6 +220,7 @@ def test_text_to_trainer_natively_with_cache_writing(tmp_path):
         x.close()
 
 
+@pytest.mark.statistical
 def test_gz_input_file_to_trainer_then_cache_pass(tmp_path):
     """`fw --data train.vw.gz -c`: gzip text in (buffer_handler.rs:19-23), LZ4 cache out (cache.rs:73), everything native;
     the second pass trains from the cache alone"""

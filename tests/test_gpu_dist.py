@@ -84,6 +84,7 @@ def test_sharded_step_equals_the_single_gpu_synchronous_step(n_ns, k, bits, ffm_
                 assert np.array_equal(tabs[t], tables[0][t])
 
 
+@pytest.mark.statistical
 def test_sharded_boundary_rows_are_a_small_documented_deviation():
     """With rows that straddle ownership boundaries left in, N ranks still track the single-table result closely: hold-out
     predictions of the final models agree to 1e-3 on these tiny tables (R / (table / N) = 0.2-0.4 %)."""
