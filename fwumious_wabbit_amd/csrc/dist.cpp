@@ -54,9 +54,16 @@ struct RcclApi {
     bool ok = false;
     bool load() {
         std::call_once(once, [this] {
+            // FWGPU_RCCL_LIBRARY names the library that provides the seven entry points below, e.g. another RCCL build -- or the
+            // shared-memory stand-in of tests/fake_rccl, which lets the process-per-rank path run with N > 1 on ONE GPU
+            // (RTLD_LOCAL: its nccl* symbols must not shadow a real RCCL the process also holds)
+            if (const char *over = std::getenv("FWGPU_RCCL_LIBRARY")) {
+                if (over[0]) lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+                if (!lib) return;
+            }
             for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-                lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
                 if (lib) break;
+                lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             }
             if (!lib) return;
 #define SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(lib, name))
@@ -881,7 +888,17 @@ int fwgpu_dist_group_learn_sparse(fwgpu_dist_group *g, const fwgpu_translator_co
     int rc;
     for (int j = 0; j < N; j++)
         if ((rc = sparse_begin(g->ranks[j].get(), t, records[j], rec_off[j], n[j], nullptr, &shapes[4 * j]))) return rc;
+    // debug switches for the concurrent schedule (scripts/group_repro.py): FWGPU_DBG_GROUP_CHAIN=1 orders rank j's local phase behind
+    // rank j-1's ON THE DEVICE (event wait, no host synchronisation)
+    static const bool dbg_chain = std::getenv("FWGPU_DBG_GROUP_CHAIN") != nullptr;
     for (int j = 0; j < N; j++) {
+        if (dbg_chain && j > 0) {
+            hipEvent_t ev;
+            FWGPU_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            FWGPU_HIP(hipEventRecord(ev, g->ranks[j - 1]->stream));
+            FWGPU_HIP(hipStreamWaitEvent(g->ranks[j]->stream, ev, 0));
+            FWGPU_HIP(hipEventDestroy(ev));
+        }
         if ((rc = sparse_local(g->ranks[j].get(), shapes.data()))) return rc;
         // One rank's local phase at a time.  With all ranks' FWD / MID / sort / reduce work enqueued at once on their streams the step
         // was not reproducible at full table size and faulted once in ten runs (scripts/group_repro.py with FWGPU_GROUP_CONCURRENT=local);

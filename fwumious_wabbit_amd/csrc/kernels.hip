@@ -28,6 +28,7 @@
 // plain cached loads.
 #include "fwgpu_internal.h"
 #include "fwgpu_device.h"
+#include <cstdlib>
 
 namespace fwgpu {
 
@@ -1715,7 +1716,12 @@ static hipError_t launch_phase_v(const KernelParams &p, int optimizer, int phase
         default: return launch_persistent(fw_example_kernel<VEC, FWGPU_OPT_ADAGRAD_LUT, true, 3, true>, p, grid, threads, lds, stream);
         }
     }
-    if (phase == 1) return launch_persistent(fw_example_kernel<VEC, FWGPU_OPT_SGD, false, 1, false>, p, grid, threads, lds, stream);
+    if (phase == 1) {
+        // debug (scripts/group_repro.py): FWD with device-scope (sc1) table loads instead of cached ones
+        static const bool dbg_coh = std::getenv("FWGPU_DBG_FWD_COH") != nullptr;
+        if (dbg_coh && VEC == 4) return launch_persistent(fw_example_kernel<4, FWGPU_OPT_SGD, true, 1, false>, p, grid, threads, lds, stream);
+        return launch_persistent(fw_example_kernel<VEC, FWGPU_OPT_SGD, false, 1, false>, p, grid, threads, lds, stream);
+    }
     switch (optimizer) {
     case FWGPU_OPT_SGD: return launch_persistent(fw_example_kernel<VEC, FWGPU_OPT_SGD, true, 3, false>, p, grid, threads, lds, stream);
     case FWGPU_OPT_ADAGRAD_FLEX: return launch_persistent(fw_example_kernel<VEC, FWGPU_OPT_ADAGRAD_FLEX, true, 3, false>, p, grid, threads, lds, stream);

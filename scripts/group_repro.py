@@ -20,8 +20,12 @@ args.nn_layers, args.nn_width = 0, 256
 args.mean_extra, args.zipf, args.ids, args.p_weighted, args.seed = 5.67, 1.05, 10_000_000, 0.1, 20240612
 mi = bench.build_model_instance(fw, args, 0)
 n, per, steps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+in_flight = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # cap on each rank's persistent grid (n x in_flight <= 768: all ranks' workgroups co-resident)
 recs, off = bench.gen_records(fw, args, 0, n * per * steps)
 regs = [fw.Regressor(mi) for _ in range(n)]
+if in_flight:
+    for r in regs:
+        r.set_max_in_flight(in_flight)
 fbt = fw.FeatureBufferTranslator(mi)
 g = DistGroup(regs)
 for s in range(steps):

@@ -1,0 +1,89 @@
+"""One RANK of a process-per-rank job of the library's multi-GPU path (fwgpu_dist_init + fwgpu_dist_learn_sharded / _sparse,
+dist.cpp), started N times by tests/test_gpu_dist_procs.py on ONE GPU with FWGPU_RCCL_LIBRARY pointing at the shared-memory
+stand-in of tests/fake_rccl.  Reads the job description (an .npz written by the test), runs its share, writes its predictions
+and final tables.
+usage: python dist_rank_worker.py <job.npz> <rank> <out.npz>"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+import fwumious_wabbit_amd as fw  # noqa: E402
+from fwumious_wabbit_amd import _capi as capi  # noqa: E402
+from fwumious_wabbit_amd.dist import DistRank, unique_id  # noqa: E402
+from helpers import make_pair  # noqa: E402
+
+
+def main():
+    job = np.load(sys.argv[1], allow_pickle=False)
+    rank = int(sys.argv[2])
+    n_ranks = int(job["n_ranks"])
+    mode = str(job["mode"])
+    n_ns, k, bits, ffm_bits, opt = (int(job[x]) for x in ("n_ns", "k", "bits", "ffm_bits", "optimizer"))
+    mi, _, _ = make_pair(n_ns, k, bits, ffm_bits, opt, lr=float(job["lr"]), ffm_lr=float(job["lr"]))
+    recs, off = job["recs"], job["off"]
+    parts = job["parts"]  # [steps, n_ranks] records per rank and step
+    id_file = str(job["id_file"])
+    if rank == 0:  # ncclGetUniqueId on one rank, handed to the others by the launcher's own means (here: a file)
+        uid = unique_id()
+        with open(id_file + ".tmp", "wb") as f:
+            f.write(uid)
+        os.replace(id_file + ".tmp", id_file)
+    else:
+        t0 = time.time()
+        while not os.path.exists(id_file):
+            if time.time() - t0 > 120:
+                raise SystemExit("unique id never arrived")
+            time.sleep(0.01)
+        uid = open(id_file, "rb").read()
+    re = fw.Regressor(mi)
+    fbt = fw.FeatureBufferTranslator(mi)
+    d = DistRank(re, uid, rank, n_ranks)
+    if mode == "sharded":
+        d.set_mode(capi.MODE_SEQUENTIAL)
+    preds = []
+    pos = 0
+    for s in range(parts.shape[0]):
+        a = pos + int(parts[s, :rank].sum())
+        b = a + int(parts[s, rank])
+        sub, so = recs[int(off[a]):int(off[b])], off[a:b + 1] - off[a]
+        if mode == "sharded":
+            if s % 2 == 0:
+                preds.append(d.learn_sharded(fbt, sub, so))
+            else:  # the device-resident form of the same call
+                ba = re.record_batch(fbt, sub, so)
+                d.learn_sharded_batch(fbt, ba)
+                preds.append(ba.predictions().copy())
+                ba.close()
+        elif mode == "sparse":
+            preds.append(d.learn_sparse(fbt, sub, so))
+        else:
+            raise SystemExit("unknown mode " + mode)
+        pos += int(parts[s].sum())
+    ranges = np.array(d.ranges(), dtype=np.uint64)
+    if mode == "sharded":
+        d.gather_tables()
+    # the replica mode's exchange: all-reduce (sum) of a device buffer through the same communicator
+    t = re.table_as_torch(capi.TABLE_FFM_W) if int(job["allreduce"]) else None
+    ar = None
+    if t is not None:
+        import torch
+        x = torch.full((1 << 20,), float(rank + 1), dtype=torch.float32, device=t.device)
+        x[:8] = torch.arange(8, dtype=torch.float32, device=t.device) * (rank + 1)
+        torch.cuda.synchronize()
+        d.all_reduce_sum(x.data_ptr(), x.numel())
+        torch.cuda.synchronize()
+        ar = x[:16].cpu().numpy()
+    tabs = [np.asarray(re.table_read(tt)) for tt in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)]
+    np.savez(sys.argv[3], preds=np.concatenate(preds) if preds else np.zeros(0, np.float32), lr=tabs[0], ffm_w=tabs[1], ffm_acc=tabs[2],
+             ranges=ranges, allreduce=ar if ar is not None else np.zeros(0, np.float32))
+    d.close()
+    re.close()
+
+
+if __name__ == "__main__":
+    main()

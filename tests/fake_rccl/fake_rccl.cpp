@@ -1,0 +1,222 @@
+// TEST INFRASTRUCTURE, not product: an in-tree stand-in for the seven RCCL entry points libfwgpu resolves at run time
+// (fwumious_wabbit_amd/csrc/dist.cpp, struct RcclApi), so that the library's process-per-rank path -- shape / count exchange,
+// padding to the largest rank, owner ranges, in-place gathers of the tables -- runs under pytest with 2-4 PROCESSES on one GPU.
+// Selected with FWGPU_RCCL_LIBRARY=<this .so> before the first fwgpu_dist_* call; nothing in the product links or loads it otherwise.
+//
+// Transport: a POSIX shared-memory segment named by the "unique id"; every collective is host-synchronous --
+//   stream sync, device -> segment slot of this rank, barrier, every rank combines the slots it needs (sums in rank order: the
+//   same bits on every rank), host -> device, barrier.  Large messages go through in slot-sized chunks.
+// Semantics follow nccl.h: AllGather(send, recv, sendcount), ReduceScatter(send, recv, recvcount), AllReduce(send, recv, count),
+// in-place forms included.
+#include <fcntl.h>
+#include <hip/hip_runtime.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+extern "C" {
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef struct FakeComm *ncclComm_t;
+typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6, ncclFloat32 = 7, ncclFloat64 = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+}
+
+namespace {
+constexpr size_t kSlot = 16u << 20;  // bytes per rank and chunk
+struct Header {
+    std::atomic<uint32_t> magic, arrived, generation, attached;
+    uint32_t nranks;
+};
+}  // namespace
+
+struct FakeComm {
+    int rank = 0, n = 1;
+    char name[128] = {0};
+    Header *hdr = nullptr;
+    unsigned char *slots = nullptr;
+    size_t bytes = 0;
+    bool barrier() {
+        const uint32_t gen = hdr->generation.load(std::memory_order_acquire);
+        if (hdr->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)n) {
+            hdr->arrived.store(0, std::memory_order_relaxed);
+            hdr->generation.store(gen + 1, std::memory_order_release);
+            return true;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        while (hdr->generation.load(std::memory_order_acquire) == gen) {
+            std::this_thread::yield();
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) return false;  // a rank died: fail, do not hang the test
+        }
+        return true;
+    }
+    unsigned char *slot(int r) { return slots + (size_t)r * kSlot; }
+};
+
+static size_t esize(ncclDataType_t t) {
+    switch (t) {
+    case ncclInt8: case ncclUint8: return 1;
+    case ncclFloat16: return 2;
+    case ncclInt32: case ncclUint32: case ncclFloat32: return 4;
+    default: return 8;
+    }
+}
+
+template <typename T>
+static void sum_into(std::vector<unsigned char> &acc, const unsigned char *src, size_t n, bool first) {
+    T *a = reinterpret_cast<T *>(acc.data());
+    const T *b = reinterpret_cast<const T *>(src);
+    for (size_t i = 0; i < n; i++) a[i] = first ? b[i] : (T)(a[i] + b[i]);
+}
+static ncclResult_t sum_any(std::vector<unsigned char> &acc, const unsigned char *src, size_t n, ncclDataType_t t, bool first) {
+    switch (t) {
+    case ncclFloat32: sum_into<float>(acc, src, n, first); return ncclSuccess;
+    case ncclFloat64: sum_into<double>(acc, src, n, first); return ncclSuccess;
+    case ncclInt32: sum_into<int32_t>(acc, src, n, first); return ncclSuccess;
+    case ncclUint32: sum_into<uint32_t>(acc, src, n, first); return ncclSuccess;
+    case ncclInt64: sum_into<int64_t>(acc, src, n, first); return ncclSuccess;
+    case ncclUint64: sum_into<uint64_t>(acc, src, n, first); return ncclSuccess;
+    default: return ncclInvalidArgument;
+    }
+}
+
+extern "C" {
+
+const char *ncclGetErrorString(ncclResult_t r) {
+    switch (r) {
+    case ncclSuccess: return "no error";
+    case ncclUnhandledCudaError: return "fake rccl: HIP call failed";
+    case ncclSystemError: return "fake rccl: shared memory / barrier failure (did a rank die?)";
+    case ncclInvalidArgument: return "fake rccl: unsupported datatype or operation";
+    default: return "fake rccl: internal error";
+    }
+}
+
+ncclResult_t ncclGetUniqueId(ncclUniqueId *id) {
+    static std::atomic<unsigned> ctr{0};
+    memset(id->internal, 0, sizeof(id->internal));
+    snprintf(id->internal, sizeof(id->internal), "/fwgpu_fakerccl_%d_%u_%ld", (int)getpid(), ctr++,
+             (long)std::chrono::steady_clock::now().time_since_epoch().count());
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int rank) {
+    FakeComm *c = new FakeComm();
+    c->rank = rank;
+    c->n = nranks;
+    memcpy(c->name, id.internal, sizeof(c->name));
+    c->name[sizeof(c->name) - 1] = 0;
+    c->bytes = 4096 + (size_t)nranks * kSlot;
+    int fd = -1;
+    if (rank == 0) {
+        fd = shm_open(c->name, O_CREAT | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)c->bytes) != 0) return ncclSystemError;
+    } else {
+        for (int i = 0; i < 60000 && fd < 0; i++) {  // rank 0 creates the segment
+            fd = shm_open(c->name, O_RDWR, 0600);
+            struct stat st;
+            if (fd >= 0 && (fstat(fd, &st) != 0 || (size_t)st.st_size < c->bytes)) {
+                close(fd);
+                fd = -1;
+            }
+            if (fd < 0) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+        if (fd < 0) return ncclSystemError;
+    }
+    void *m = mmap(nullptr, c->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return ncclSystemError;
+    c->hdr = reinterpret_cast<Header *>(m);
+    c->slots = reinterpret_cast<unsigned char *>(m) + 4096;
+    if (rank == 0) {
+        c->hdr->nranks = (uint32_t)nranks;
+        c->hdr->arrived.store(0);
+        c->hdr->generation.store(0);
+        c->hdr->attached.store(0);
+        c->hdr->magic.store(0x46574743u, std::memory_order_release);
+    } else {
+        for (int i = 0; i < 60000 && c->hdr->magic.load(std::memory_order_acquire) != 0x46574743u; i++)
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        if (c->hdr->magic.load() != 0x46574743u) return ncclSystemError;
+    }
+    c->hdr->attached.fetch_add(1);
+    if (!c->barrier()) return ncclSystemError;
+    *out = c;
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommDestroy(ncclComm_t c) {
+    if (!c) return ncclSuccess;
+    const uint32_t left = c->hdr->attached.fetch_sub(1) - 1;
+    munmap(reinterpret_cast<void *>(c->hdr), c->bytes);
+    if (left == 0) shm_unlink(c->name);
+    delete c;
+    return ncclSuccess;
+}
+
+#define HIPOK(x) do { if ((x) != hipSuccess) return ncclUnhandledCudaError; } while (0)
+
+ncclResult_t ncclAllGather(const void *send, void *recv, size_t count, ncclDataType_t t, ncclComm_t c, hipStream_t s) {
+    const size_t es = esize(t), total = count * es;
+    HIPOK(hipStreamSynchronize(s));
+    for (size_t off = 0; off < total || (total == 0 && off == 0); off += kSlot) {
+        const size_t m = total - off < kSlot ? total - off : kSlot;
+        if (m) HIPOK(hipMemcpy(c->slot(c->rank), (const char *)send + off, m, hipMemcpyDeviceToHost));
+        if (!c->barrier()) return ncclSystemError;
+        for (int r = 0; r < c->n && m; r++) HIPOK(hipMemcpy((char *)recv + (size_t)r * total + off, c->slot(r), m, hipMemcpyHostToDevice));
+        if (!c->barrier()) return ncclSystemError;
+        if (total == 0) break;
+    }
+    return ncclSuccess;
+}
+
+ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, ncclDataType_t t, ncclRedOp_t op, ncclComm_t c, hipStream_t s) {
+    if (op != ncclSum) return ncclInvalidArgument;
+    const size_t es = esize(t), total = count * es;
+    HIPOK(hipStreamSynchronize(s));
+    std::vector<unsigned char> acc(kSlot);
+    for (size_t off = 0; off < total; off += kSlot) {
+        const size_t m = total - off < kSlot ? total - off : kSlot;
+        HIPOK(hipMemcpy(c->slot(c->rank), (const char *)send + off, m, hipMemcpyDeviceToHost));
+        if (!c->barrier()) return ncclSystemError;
+        for (int r = 0; r < c->n; r++) {
+            ncclResult_t e = sum_any(acc, c->slot(r), m / es, t, r == 0);
+            if (e != ncclSuccess) return e;
+        }
+        HIPOK(hipMemcpy((char *)recv + off, acc.data(), m, hipMemcpyHostToDevice));
+        if (!c->barrier()) return ncclSystemError;
+    }
+    return ncclSuccess;
+}
+
+// send: n * recvcount elements; rank d receives the sum over ranks of send[d * recvcount ...]
+ncclResult_t ncclReduceScatter(const void *send, void *recv, size_t recvcount, ncclDataType_t t, ncclRedOp_t op, ncclComm_t c, hipStream_t s) {
+    if (op != ncclSum) return ncclInvalidArgument;
+    const size_t es = esize(t), total = recvcount * es;
+    const size_t sub = (kSlot / (size_t)c->n) & ~(size_t)63;  // a rank's slot holds one sub-slot per destination
+    HIPOK(hipStreamSynchronize(s));
+    std::vector<unsigned char> acc(sub);
+    for (size_t off = 0; off < total; off += sub) {
+        const size_t m = total - off < sub ? total - off : sub;
+        for (int d = 0; d < c->n; d++)
+            HIPOK(hipMemcpy(c->slot(c->rank) + (size_t)d * sub, (const char *)send + (size_t)d * total + off, m, hipMemcpyDeviceToHost));
+        if (!c->barrier()) return ncclSystemError;
+        for (int r = 0; r < c->n; r++) {
+            ncclResult_t e = sum_any(acc, c->slot(r) + (size_t)c->rank * sub, m / es, t, r == 0);
+            if (e != ncclSuccess) return e;
+        }
+        HIPOK(hipMemcpy((char *)recv + off, acc.data(), m, hipMemcpyHostToDevice));
+        if (!c->barrier()) return ncclSystemError;
+    }
+    return ncclSuccess;
+}
+
+}  // extern "C"
