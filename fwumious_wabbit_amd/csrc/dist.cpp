@@ -140,6 +140,7 @@ struct fwgpu_dist {
     uint64_t ob_wcap = 0;
     fwgpu_batch *cur = nullptr;      // the batch this sparse step runs on
     uint32_t occ_max_ffm = 0, occ_max_lr = 0;
+    hipEvent_t dbg_ev[3] = {nullptr, nullptr, nullptr};  // debug (scripts/group_bisect.sh): recorded behind FWD / MID / the FFM reduction of sparse_local
     uint32_t last_rows[2] = {0, 0};  // bucket rows {ffm, lr} this rank sent in its last sparse step
     ~fwgpu_dist() {
         sf.release();
@@ -430,8 +431,10 @@ int sparse_local(fwgpu_dist *d, const uint32_t *shapes /*[n*4]*/) {
     SplitRanges rg;  // full replica: every row is this rank's, every example of the launch is its own
     rc = split_forward(r, d->cur, d->sp, FWGPU_MODE_HOGWILD, rg, d->stream, &occ, &d->occ_max_ffm, &d->occ_max_lr);
     if (rc) return rc;
+    if (d->dbg_ev[0]) FWGPU_HIP(hipEventRecord(d->dbg_ev[0], d->stream));
     rc = split_mid(r, d->sp, 0, n, d->cur->pred, false, d->stream);
     if (rc) return rc;
+    if (d->dbg_ev[1]) FWGPU_HIP(hipEventRecord(d->dbg_ev[1], d->stream));
     if (has_ffm) {
         SparseReduceArgs a{};
         a.keys = d->sf.key;
@@ -457,6 +460,7 @@ int sparse_local(fwgpu_dist *d, const uint32_t *shapes /*[n*4]*/) {
         if (a.n > d->sf.occ_cap) return fail(FWGPU_ERR_RANGE, "sparse step: occurrence buffers too small");
         FWGPU_HIP(sparse_reduce(a, d->stream));
     }
+    if (d->dbg_ev[2]) FWGPU_HIP(hipEventRecord(d->dbg_ev[2], d->stream));
     if (has_lr) {
         SparseReduceArgs a{};
         a.keys = d->sl.key;
@@ -890,14 +894,22 @@ int fwgpu_dist_group_learn_sparse(fwgpu_dist_group *g, const fwgpu_translator_co
         if ((rc = sparse_begin(g->ranks[j].get(), t, records[j], rec_off[j], n[j], nullptr, &shapes[4 * j]))) return rc;
     // debug switches for the concurrent schedule (scripts/group_repro.py): FWGPU_DBG_GROUP_CHAIN=1 orders rank j's local phase behind
     // rank j-1's ON THE DEVICE (event wait, no host synchronisation)
-    static const bool dbg_chain = std::getenv("FWGPU_DBG_GROUP_CHAIN") != nullptr;
+    // FWGPU_DBG_GROUP_CHAIN = fwd | mid | red: ... behind rank j-1's FWD / MID / FFM reduction only (the rest overlaps freely)
+    static const char *dbg_chain = std::getenv("FWGPU_DBG_GROUP_CHAIN");
+    const int chain_at = !dbg_chain ? -1 : dbg_chain[0] == 'f' ? 0 : dbg_chain[0] == 'm' ? 1 : dbg_chain[0] == 'r' ? 2 : 3;
     for (int j = 0; j < N; j++) {
-        if (dbg_chain && j > 0) {
+        fwgpu_dist *dj = g->ranks[j].get();
+        if (chain_at >= 0 && chain_at < 3)
+            for (int e = 0; e < 3; e++)
+                if (!dj->dbg_ev[e]) FWGPU_HIP(hipEventCreateWithFlags(&dj->dbg_ev[e], hipEventDisableTiming));
+        if (chain_at == 3 && j > 0) {
             hipEvent_t ev;
             FWGPU_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             FWGPU_HIP(hipEventRecord(ev, g->ranks[j - 1]->stream));
             FWGPU_HIP(hipStreamWaitEvent(g->ranks[j]->stream, ev, 0));
             FWGPU_HIP(hipEventDestroy(ev));
+        } else if (chain_at >= 0 && j > 0) {
+            FWGPU_HIP(hipStreamWaitEvent(dj->stream, g->ranks[j - 1]->dbg_ev[chain_at], 0));
         }
         if ((rc = sparse_local(g->ranks[j].get(), shapes.data()))) return rc;
         // One rank's local phase at a time.  With all ranks' FWD / MID / sort / reduce work enqueued at once on their streams the step

@@ -52,6 +52,12 @@ struct DevNN {
     uint32_t X;          // length of x = LR slots + triangle
     uint32_t sum_width;  // sum of the hidden widths
     uint32_t max_in;     // largest layer input (LDS scratch)
+    uint32_t defer;      // hogwild launches: a workgroup keeps the dense steps of this many examples pending (their rank-1 factors in LDS)
+                         // and applies them in example order in ONE pass over the weights (kernels.hip nn_flush); 0 = step per example
+    uint32_t slot;       // floats per pending example: x[X], h[sum_width], output gradients[sum_width], g
+    uint32_t defer_sum;  // 1: the pending examples' gradients of a weight are SUMMED and take one optimizer step (the mini-batch rule of
+                         // head.hip at workgroup scale); 0: one step per pending example, in example order (the reference's rule per weight)
+    uint32_t plain_reads; // 1: the forward pass and the input gradients read the dense weights through the XCD's L2 (plain loads)
     float rate, minus_power_t;
     float *w, *acc;      // all layers back to back: per layer W[j*in+i] then the biases (block_neural.rs:86-88)
     const float *lut;
@@ -138,6 +144,9 @@ struct LaunchConfig {
     int32_t lut_global = 0;
     int32_t window = 1;              // whole-line FFM row updates: 0 off, 1 auto (tables > Infinity Cache), 2 always (debug option 2)
     int32_t no_chain = 0;            // debug option 3
+    int32_t nn_defer = 8;            // debug option 7: deep head, hogwild launches: pending examples per workgroup (0 / 1: step per example)
+    int32_t nn_defer_sum = 1;        // debug option 8
+    int32_t nn_plain_reads = 0;      // debug option 9
     uint32_t hot_lr_every = 1;       // debug option 4: hot LR entry route (0 off, 1 atomics per example, n>1 weight deltas pending n examples)
     bool threads_set = false;
     uint32_t max_in_flight = 0;  // cap on the persistent grid = examples processed concurrently (0: what the device holds)  // fwgpu_set_launch chose the workgroup size: no automatic choice

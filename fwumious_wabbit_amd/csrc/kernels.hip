@@ -141,7 +141,7 @@ __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t
 // input gradient, and one product per LR entry
 __host__ __device__ inline uint32_t nn_lds_floats(const KernelParams &p) {
     if (!p.nn.n_layers) return 0;
-    return 2 * p.nn.X + 2 * p.nn.sum_width + p.nn.max_in + p.max_lr + 16;
+    return 2 * p.nn.X + 2 * p.nn.sum_width + p.nn.max_in + p.max_lr + 16 + p.nn.defer * p.nn.slot;
 }
 
 // size of the open-addressing sets: power of two >= 2*n (load factor <= 0.5)
@@ -673,6 +673,7 @@ struct NnBuf {
     float *m;    // [sum_width] ReLU 0/1 masks, then the layers' output gradients
     float *fg;   // [max_in] final neuron's input gradient / per-layer scratch
     float *prod; // [max_lr] w*v of every LR entry
+    float *ring; // [defer * slot] pending examples' factors (nn_backward_deferred / nn_flush)
 };
 __device__ __forceinline__ NnBuf nn_buf(const KernelParams &p, const Lds &s) {
     NnBuf b;
@@ -682,6 +683,7 @@ __device__ __forceinline__ NnBuf nn_buf(const KernelParams &p, const Lds &s) {
     b.m = b.h + p.nn.sum_width;
     b.fg = b.m + p.nn.sum_width;
     b.prod = b.fg + p.nn.max_in;
+    b.ring = b.prod + ((p.max_lr + 15) & ~3u);
     return b;
 }
 template <bool COH>
@@ -783,7 +785,9 @@ __device__ __forceinline__ float nn_forward(const KernelParams &p, const Lds &s,
                     f4 w[JU];
 #pragma unroll
                     for (int u = 0; u < JU; ++u)
-                        w[u] = j0 + u < out ? Vec<4>::load<kAuxSc1>(rw, ((j0 + u) * in + 4 * q) * 4) : Vec<4>::zero();
+                        w[u] = j0 + u >= out ? Vec<4>::zero()
+                               : n.plain_reads ? Vec<4>::load<kAuxPlain>(rw, ((j0 + u) * in + 4 * q) * 4)
+                                               : Vec<4>::load<kAuxSc1>(rw, ((j0 + u) * in + 4 * q) * 4);
                     const f4 xv = Vec<4>::lds_load(in_vec + 4 * q);
 #pragma unroll
                     for (int u = 0; u < JU; ++u) dot[u] += w[u][0] * xv[0] + w[u][1] * xv[1] + w[u][2] * xv[2] + w[u][3] * xv[3];
@@ -1028,6 +1032,250 @@ __device__ __forceinline__ void nn_backward(const KernelParams &p, const Lds &s,
         }
         __syncthreads();
     }
+}
+
+// ---- deferred dense steps (hogwild launches, DevNN::defer > 1).
+// The exact head read-modify-writes all 194 k dense weights of config E for EVERY example: 20 B x 194 k = 3.9 MB per example
+// through the fabric, and of the ~256 concurrent writers of a weight one survives.  A dense layer's gradient is rank 1 --
+// d W[j][i] = og[j] * in[i] -- so a workgroup keeps the FACTORS of its last `defer` examples in LDS (x, the hidden activations,
+// the layers' output gradients: 6 KB per example at config E) and, every `defer` examples, walks the weights ONCE: load {w, acc},
+// apply the pending examples' AdaGrad steps one after the other in example order (exactly the per-example sequence of
+// block_neural.rs:275-306 on that weight, gradients taken with the weights of the workgroup's last pass), store.  The input
+// gradients of a pending example are formed with the weights as they are (block_neural.rs:283: the pre-update weight).
+// Traffic per example: the forward and input-gradient reads + 16 B x 194 k / defer; no step is dropped inside a workgroup.
+// Between workgroups it is hogwild as before.  In-order launches keep the per-example path (bit-exact mode).
+constexpr int kNnDeferMax = 8;
+struct NnRing {
+    float *x, *h, *og, *g;
+};
+__device__ __forceinline__ NnRing nn_ring_slot(const KernelParams &p, const NnBuf &b, uint32_t e) {
+    NnRing r;
+    r.x = b.ring + (size_t)e * p.nn.slot;
+    r.h = r.x + p.nn.X;
+    r.og = r.h + p.nn.sum_width;
+    r.g = r.og + p.nn.sum_width;
+    return r;
+}
+// input gradient of layer l with the weights as they are: grad[i] = sum_j W[j][i] * og[j]  (16-byte device-scope loads; thread
+// (q, grp) owns columns 4q .. 4q+3 for the neurons of group grp).  Contains barriers: called by every thread.
+__device__ __forceinline__ void nn_layer_ingrad_vec(const DevNN &n, uint32_t l, const float *og, uint32_t split, float *grad_a,
+                                                    float *grad_b, int tid, int bd) {
+    const uint32_t in = n.in[l], out = n.out[l], nq = in >> 2;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(n.w + n.off[l], in * out * 4);
+    uint32_t G = (uint32_t)bd / nq;
+    G = G > out ? out : G;
+    const uint32_t q = (uint32_t)tid % nq, grp = (uint32_t)tid / nq;
+    const bool active = grp < G;
+    const uint32_t jn = (out + G - 1) / G, jlo = grp * jn, jhi = jlo + jn < out ? jlo + jn : out;
+    f4 oe = Vec<4>::zero();
+    if (active) {
+        constexpr int JU = 8;
+        for (uint32_t j0 = jlo; j0 < jhi; j0 += JU) {
+            f4 w[JU];
+            float gg[JU];
+#pragma unroll
+            for (int u = 0; u < JU; ++u) {
+                const uint32_t j = j0 + u;
+                gg[u] = j < jhi ? og[j] : 0.0f;
+                w[u] = Vec<4>::zero();
+                if (gg[u] != 0.0f)
+                    w[u] = n.plain_reads ? Vec<4>::load<kAuxPlain>(rw, (j * in + 4 * q) * 4) : Vec<4>::load<kAuxSc1>(rw, (j * in + 4 * q) * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < JU; ++u)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) oe[c] += w[u][c] * gg[u];
+        }
+    }
+    __syncthreads();
+    if (active && grp == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t i = 4 * q + c;
+            if (i < split) grad_a[i] = oe[c];
+            else grad_b[i - split] = oe[c];
+        }
+    }
+    __syncthreads();
+    if (active && grp != 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t i = 4 * q + c;
+            atomicAdd(i < split ? &grad_a[i] : &grad_b[i - split], oe[c]);
+        }
+    }
+}
+
+// The pending examples' dense steps, one pass over the weights.  Called by every thread (barriers), count = s.ctr[15] > 0.
+template <int OPT>
+__device__ __forceinline__ void nn_flush(const KernelParams &p, const Lds &s, int tid, int bd) {
+    const NnBuf b = nn_buf(p, s);
+    const DevNN &n = p.nn;
+    const uint32_t cnt = s.ctr[15];
+    const uint32_t L = n.n_layers, X = n.X, wl = n.out[L - 1];
+    uint32_t hoff = 0;
+    for (uint32_t l = 0; l <= L; ++l) {
+        const uint32_t in = n.in[l], out = n.out[l], nq = in >> 2;
+        // layer l: inputs = x (l = 0), the previous layer's activations, or [h_last | x] (final neuron, topology one);
+        // output gradients = the layer's og, or g for the final neuron
+        const uint32_t in_h = l == 0 ? 0u : (l == L ? wl : in);      // leading inputs that come from h
+        const uint32_t in_hoff = l == 0 ? 0u : (l == L ? n.sum_width - wl : hoff - n.out[l - 1]);
+        float *W = n.w + n.off[l], *A = n.acc + n.off[l];
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(W, in * out * 4), ra = make_rsrc(A, in * out * 4);
+        uint32_t G = (uint32_t)bd / nq;
+        G = G > out ? out : G;
+        const uint32_t q = (uint32_t)tid % nq, grp = (uint32_t)tid / nq;
+        const uint32_t jn = (out + G - 1) / G, jlo = grp * jn, jhi = jlo + jn < out ? jlo + jn : out;
+        if (grp < G) {
+            f4 xi[kNnDeferMax];
+#pragma unroll
+            for (int e = 0; e < kNnDeferMax; ++e) {
+                xi[e] = Vec<4>::zero();
+                if ((uint32_t)e < cnt) {
+                    const NnRing r = nn_ring_slot(p, b, e);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const uint32_t i = 4 * q + c;
+                        xi[e][c] = i < in_h ? r.h[in_hoff + i] : r.x[i - in_h];
+                    }
+                }
+            }
+            constexpr int JU = 2;
+            for (uint32_t j0 = jlo; j0 < jhi; j0 += JU) {
+                f4 w[JU], a[JU];
+                bool any[JU];
+#pragma unroll
+                for (int u = 0; u < JU; ++u) {
+                    const uint32_t j = j0 + u;
+                    any[u] = false;
+                    if (j < jhi)
+                        for (uint32_t e = 0; e < cnt; ++e) {
+                            const NnRing r = nn_ring_slot(p, b, e);
+                            any[u] = any[u] || (l == L ? r.g[0] : r.og[hoff + j]) != 0.0f;
+                        }
+                    w[u] = Vec<4>::zero();
+                    a[u] = Vec<4>::zero();
+                    if (any[u]) {  // block_neural.rs:275-277: weights of a neuron without upstream gradient are not touched
+                        const uint32_t bo = (j * in + 4 * q) * 4;
+                        w[u] = Vec<4>::load<kAuxSc1>(rw, bo);
+                        if (OPT != FWGPU_OPT_SGD) a[u] = Vec<4>::load<kAuxSc1>(ra, bo);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < JU; ++u) {
+                    if (!any[u]) continue;
+                    const uint32_t j = j0 + u;
+                    f4 G = Vec<4>::zero();
+#pragma unroll
+                    for (int e = 0; e < kNnDeferMax; ++e) {
+                        if ((uint32_t)e >= cnt) break;
+                        const NnRing r = nn_ring_slot(p, b, e);
+                        const float gg = l == L ? r.g[0] : r.og[hoff + j];
+                        if (gg == 0.0f) continue;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            if (n.defer_sum) {
+                                G[c] += gg * xi[e][c];
+                            } else {
+                                float acc = a[u][c];
+                                const float upd = opt_step<OPT>(gg * xi[e][c], acc, n.rate, n.minus_power_t, n.lut);
+                                w[u][c] = w[u][c] - upd;
+                                a[u][c] = acc;
+                            }
+                        }
+                    }
+                    if (n.defer_sum) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            float acc = a[u][c];
+                            const float upd = opt_step<OPT>(G[c], acc, n.rate, n.minus_power_t, n.lut);
+                            w[u][c] = w[u][c] - upd;
+                            a[u][c] = acc;
+                        }
+                    }
+                    const uint32_t bo = (j * in + 4 * q) * 4;
+                    Vec<4>::store<kAuxSc1>(w[u], rw, bo);
+                    if (OPT != FWGPU_OPT_SGD) Vec<4>::store<kAuxSc1>(a[u], ra, bo);
+                }
+            }
+        }
+        for (uint32_t j = tid; j < out; j += bd) {  // bias terms (block_neural.rs:296-306)
+            const size_t ix = (size_t)in * out + j;
+            float w = 0.0f, acc = 0.0f;
+            bool loaded = false;
+            float Gb = 0.0f;
+            for (uint32_t e = 0; e < cnt; ++e) {
+                const NnRing r = nn_ring_slot(p, b, e);
+                const float gg = l == L ? r.g[0] : r.og[hoff + j];
+                if (gg == 0.0f) continue;
+                if (!loaded) {
+                    w = nn_ld<true>(W + ix);
+                    acc = OPT == FWGPU_OPT_SGD ? 0.0f : nn_ld<true>(A + ix);
+                    loaded = true;
+                }
+                if (n.defer_sum) Gb += gg;
+                else w -= opt_step<OPT>(gg, acc, n.rate, n.minus_power_t, n.lut);
+            }
+            if (loaded && n.defer_sum) w -= opt_step<OPT>(Gb, acc, n.rate, n.minus_power_t, n.lut);
+            if (loaded) {
+                nn_st<true>(W + ix, w);
+                if (OPT != FWGPU_OPT_SGD) nn_st<true>(A + ix, acc);
+            }
+        }
+        if (l < L) hoff += out;
+    }
+    (void)X;
+    __syncthreads();  // the ring may be overwritten
+    if (tid == 0) s.ctr[15] = 0;
+}
+
+// The unwinding of the head with the dense steps left pending: this example's factors go to the ring, the input gradients are
+// formed with the weights as they are; d logit / d x ends in xg[] as in nn_backward.  Flushes when the ring is full.
+template <int OPT>
+__device__ __forceinline__ void nn_backward_deferred(const KernelParams &p, const Lds &s, float g, int tid, int bd) {
+    const NnBuf b = nn_buf(p, s);
+    const DevNN &n = p.nn;
+    const uint32_t L = n.n_layers, X = n.X, wl = n.out[L - 1];
+    const uint32_t e = s.ctr[15];
+    const NnRing r = nn_ring_slot(p, b, e);
+    for (uint32_t i = tid; i < X; i += bd) r.x[i] = b.x[i];
+    for (uint32_t i = tid; i < n.sum_width; i += bd) r.h[i] = b.h[i];
+    if (tid == 0) {
+        r.g[0] = g;
+        b.fg[0] = g;
+    }
+    __syncthreads();
+    const uint32_t hoff_last = n.sum_width - wl;
+    // final neuron: inputs [h_last | x] -> input gradients [h_last (in place) | xg]
+    nn_layer_ingrad_vec(n, L, b.fg, wl, b.h + hoff_last, b.xg, tid, bd);
+    if (n.topology != 1)
+        for (uint32_t i = tid; i < X; i += bd) b.xg[i] = 0.0f;
+    __syncthreads();
+    uint32_t hoff = hoff_last;
+    for (int l = (int)L - 1; l >= 0; --l) {
+        const uint32_t out = n.out[l];
+        // BlockRELU backward (block_relu.rs:105-110): mask * upstream gradient -> this layer's output gradient
+        for (uint32_t j = tid; j < out; j += bd) {
+            const float og = b.m[hoff + j] * b.h[hoff + j];
+            b.m[hoff + j] = og;
+            r.og[hoff + j] = og;
+        }
+        __syncthreads();
+        if (l > 0) {
+            const uint32_t pin = n.out[l - 1];
+            nn_layer_ingrad_vec(n, l, b.m + hoff, pin, b.h + hoff - pin, b.h + hoff - pin, tid, bd);
+            hoff -= pin;
+        } else {
+            // first layer: its input gradient is ADDED to the copy branch (BlockCopy, block_misc.rs:456-475)
+            nn_layer_ingrad_vec(n, 0, b.m + hoff, X, b.fg, b.fg, tid, bd);
+            __syncthreads();
+            for (uint32_t i = tid; i < X; i += bd) b.xg[i] = b.fg[i] + b.xg[i];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) s.ctr[15] = e + 1;
+    __syncthreads();
+    if (e + 1 >= n.defer) nn_flush<OPT>(p, s, tid, bd);
 }
 
 // LR update (block_lr.rs:135-150).  Entries with the same hash are applied by the thread owning the FIRST occurrence, in
@@ -1372,6 +1620,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
     if (tid == 0) {
         s.ctr[6] = atomicAdd(p.work, 1u);
         hot_lr_init<COH>(p, s, PH == 0);
+        s.ctr[15] = 0;  // deep head: examples whose dense steps are pending (nn_backward_deferred)
     }
     for (;;) {
         // Previous example's LDS reads are done.  A workgroup-scope barrier does not drain vmcnt on this target,
@@ -1602,7 +1851,10 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                 gx = p.dxbuf + (size_t)ex * p.nn.X;
                 gpair = gx + p.num_combos;
             } else if (NN && p.nn.n_layers) {
-                nn_backward<OPT, COH>(p, s, g, tid, bd);
+                if (COH && PH == 0 && p.nn.defer > 1 && gridDim.x > 1)
+                    nn_backward_deferred<OPT>(p, s, g, tid, bd);
+                else
+                    nn_backward<OPT, COH>(p, s, g, tid, bd);
                 gx = nn_buf(p, s).xg;
                 gpair = gx + p.num_combos;
             }
@@ -1641,6 +1893,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         if (tid == 0) s.ctr[6] = next_ticket;  // published by the loop-top barrier
     }
     if (COH && tid == 0 && s.ctr[13]) hot_lr_flush(p, s);  // (every thread's steps are in: the loop ends on a barrier)
+    if (NN && COH && PH == 0 && p.nn.defer > 1 && gridDim.x > 1 && s.ctr[15]) nn_flush<OPT>(p, s, tid, bd);  // (uniform: read behind the loop's barrier)
     if (timing)
         for (int i = 0; i < 8; ++i) atomicAdd(p.ticks + i, tk[i]);
 #undef FW_TICK

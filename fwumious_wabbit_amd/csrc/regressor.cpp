@@ -433,6 +433,32 @@ static int prepare_launch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int upda
     }
     if (lds > r->lds_per_cu)
         return fail(FWGPU_ERR_RANGE, "example does not fit the 160 KiB LDS (k*F^2 or features per example too large)");
+    // Deep head, hogwild training: the dense steps of `defer` examples stay pending per workgroup (kernels.hip nn_flush) when the
+    // layers have the 16-byte shape and the LDS left over by the example itself holds at least two examples' factors
+    // (one workgroup per CU at config E: T alone is 57.6 KB).
+    p.nn.defer = 0;
+    if (p.nn.n_layers && update && mode == FWGPU_MODE_HOGWILD) {
+        int want = r->launch.nn_defer;
+        static const char *env = getenv("FWGPU_NN_DEFER");  // A/B runs
+        if (env) want = atoi(env);
+        bool shape_ok = true;
+        for (uint32_t l = 0; l <= p.nn.n_layers; l++)
+            shape_ok = shape_ok && p.nn.in[l] >= 4 && (p.nn.in[l] & 3u) == 0 && (p.nn.off[l] & 3u) == 0 && (p.nn.in[l] >> 2) <= threads;
+        p.nn.slot = (p.nn.X + 2 * p.nn.sum_width + 4 + 3) & ~3u;
+        const size_t spare = r->lds_per_cu > lds + 256 ? r->lds_per_cu - lds - 256 : 0;
+        // (a second workgroup per CU is worth more than the ring: only LDS that one workgroup per CU leaves unused anyway)
+        const bool one_per_cu = 2 * lds > r->lds_per_cu;
+        const uint32_t fit = (uint32_t)std::min<size_t>(8, spare / (4 * (size_t)p.nn.slot));
+        if (want > 1 && shape_ok && one_per_cu && fit >= 2) {
+            p.nn.defer = std::min<uint32_t>((uint32_t)want, fit);
+            lds = example_kernel_lds_bytes(p, r->cfg.optimizer);
+        }
+        p.nn.defer_sum = r->launch.nn_defer_sum ? 1u : 0u;
+        p.nn.plain_reads = r->launch.nn_plain_reads ? 1u : 0u;
+        static const char *env_sum = getenv("FWGPU_NN_DEFER_SUM"), *env_plain = getenv("FWGPU_NN_PLAIN");  // A/B runs
+        if (env_sum) p.nn.defer_sum = atoi(env_sum) ? 1u : 0u;
+        if (env_plain) p.nn.plain_reads = atoi(env_plain) ? 1u : 0u;
+    }
     return FWGPU_OK;
 }
 
@@ -470,7 +496,7 @@ int fwgpu_abi_version(void) { return FWGPU_ABI_VERSION; }
 // out consecutive allocations from one group for several GB, so for tables beyond the Infinity Cache a few candidate allocations
 // are tried and timed against w with that very pattern (a fraction of a millisecond each); the fastest is kept, the rest freed.
 // FWGPU_PLACEMENT=0 switches the search off (the first allocation is used, as for small tables).
-// The search is BOUNDED: at most 8 candidates and at most a tenth of the free device memory held at once (other regressors,
+// The search is BOUNDED: at most 64 candidates (24 found no partner on one box in two: -10 % examples/s) and at most a quarter of the free device memory held at once (other regressors,
 // ranks or tenants of the device must not run out of memory because this one is probing), and only two candidates when more
 // than half of the device is already in use by anyone.  FWGPU_PLACEMENT=wide asks for the round-2 scan (up to 112 candidates,
 // half of the free memory) for single-tenant benchmark boxes.
@@ -506,8 +532,8 @@ static int place_ffm_acc(fwgpu_regressor *r, size_t fbytes) {
     // still comes from the same stretch.)  A stretch of contending memory is up to ~72 table-GB long (tools/placement scan of
     // 200 x 1 GiB, profiles/r02_placement.txt), a probe costs about a millisecond.
     const bool crowded = total_b && free_b < total_b / 2;  // someone else (another process, other regressors) holds half the device
-    const size_t budget = wide ? std::min<size_t>(free_b / 2, 128ull << 30) : free_b / 10;
-    const size_t cap = wide ? 112 : (crowded ? 2 : 8);
+    const size_t budget = wide ? std::min<size_t>(free_b / 2, 128ull << 30) : free_b / 4;
+    const size_t cap = wide ? 112 : (crowded ? 2 : 64);
     const int max_tries = search && single > 0.0f ? (int)std::max<size_t>(2, std::min<size_t>(cap, budget / fbytes)) : 1;
     for (int t = 0; t < max_tries; t++) {
         float *c = nullptr;
@@ -763,6 +789,12 @@ int fwgpu_debug_set_option(fwgpu_regressor *r, int option, int value) {
     case 4:  // hogwild launches: the constant feature's LR entry is stepped in LDS and reaches the table every `value` examples (0: off)
         if (value < 0 || value > 1024) return fail(FWGPU_ERR_INVALID, "hot LR entry option: 0 .. 1024 examples");
         r->launch.hot_lr_every = (uint32_t)value;
+        return FWGPU_OK;
+    case 8: r->launch.nn_defer_sum = value ? 1 : 0; return FWGPU_OK;    // pending dense gradients summed into one step (1) or stepped one by one (0)
+    case 9: r->launch.nn_plain_reads = value ? 1 : 0; return FWGPU_OK;  // dense weights read through L2 in the forward / input-gradient passes
+    case 7:  // deep head, hogwild launches: examples whose dense steps stay pending per workgroup (0 / 1: step per example)
+        if (value < 0 || value > 8) return fail(FWGPU_ERR_INVALID, "nn_defer option: 0 .. 8 examples");
+        r->launch.nn_defer = value;
         return FWGPU_OK;
     case 2:  // whole-line FFM row updates: 0 off, 1 auto (tables larger than the Infinity Cache; default), 2 always
         if (value < 0 || value > 2) return fail(FWGPU_ERR_INVALID, "window option: 0, 1 or 2");

@@ -18,6 +18,11 @@ variants = [
     ("in_flight_256", ["--max-in-flight", "256"], {}),
     ("round1_path", ["--whole-lines", "0"], {}),
     ("round1_path_512", ["--whole-lines", "0", "--max-in-flight", "512"], {}),
+    ("maxr2win", [], {"FWGPU_LIBRARY": os.path.join(ROOT, "build", "variants", "libfwgpu_maxr2win.so")}),
+    ("maxr2win_nochain", [], {"FWGPU_LIBRARY": os.path.join(ROOT, "build", "variants", "libfwgpu_maxr2win.so"), "FWGPU_BENCH_NO_CHAIN": "1"}),
+    ("whole_lines_2", ["--whole-lines", "2"], {}),
+    ("placement_off", [], {"FWGPU_PLACEMENT": "0"}),
+    ("no_chain", [], {"FWGPU_BENCH_NO_CHAIN": "1"}),
     ("hot_lr_plain", [], {"FWGPU_HOT_LR_EVERY": "0"}),
     ("hot_lr_every32", [], {"FWGPU_HOT_LR_EVERY": "32"}),
 ]
@@ -26,9 +31,9 @@ if os.environ.get("PARETO_ONLY"):
     variants = [v for v in variants if v[0] in keep]
 print(f"{'variant':18s} {'ex/s (M)':>24s} {'final hold-out':>26s} {'s to target':>22s}  curve of the last run")
 for name, flags, env in variants:
-    vals, lls, secs, curve = [], [], [], None
+    vals, lls, secs, curve, place = [], [], [], None, []
     for _ in range(reps):
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps, "--warmup", warm, "--no-traffic", "--no-cpu-baseline"] + flags,
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps, "--warmup", warm, "--no-traffic", "--no-cpu-baseline", "--target-logloss", os.environ.get("PARETO_TARGET", "0.655")] + flags,
                              env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if not line:
@@ -39,5 +44,6 @@ for name, flags, env in variants:
         lls.append(d["final_logloss"])
         secs.append(d["seconds_to_logloss"]["seconds"])
         curve = {k: round(v, 4) for k, v in d["logloss_after_examples"].items()}
+        place.append(d["table_placement"]["candidates_tried"])
     print(f"{name:18s} {' '.join(f'{v:.3f}' for v in vals):>24s} {' '.join(f'{v:.4f}' for v in lls):>26s} "
-          f"{' '.join('-' if v is None else f'{v:.3f}' for v in secs):>22s}  {curve}", flush=True)
+          f"{' '.join('-' if v is None else f'{v:.3f}' for v in secs):>22s}  placement tries {place}  {curve}", flush=True)

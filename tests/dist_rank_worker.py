@@ -67,20 +67,15 @@ def main():
     ranges = np.array(d.ranges(), dtype=np.uint64)
     if mode == "sharded":
         d.gather_tables()
-    # the replica mode's exchange: all-reduce (sum) of a device buffer through the same communicator
-    t = re.table_as_torch(capi.TABLE_FFM_W) if int(job["allreduce"]) else None
-    ar = None
-    if t is not None:
-        import torch
-        x = torch.full((1 << 20,), float(rank + 1), dtype=torch.float32, device=t.device)
-        x[:8] = torch.arange(8, dtype=torch.float32, device=t.device) * (rank + 1)
-        torch.cuda.synchronize()
-        d.all_reduce_sum(x.data_ptr(), x.numel())
-        torch.cuda.synchronize()
-        ar = x[:16].cpu().numpy()
     tabs = [np.asarray(re.table_read(tt)) for tt in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)]
+    # the replica mode's exchange: all-reduce (sum) of a device buffer through the same communicator -- here the rank's FFM
+    # accumulator table scaled by nothing: after gather_tables every rank holds the same table, so the sum is n_ranks x the table
+    ar = np.zeros(0, np.float32)
+    if int(job["allreduce"]):
+        d.all_reduce_sum(re.table_device_ptr(capi.TABLE_FFM_ACC), re.table_len(capi.TABLE_FFM_ACC))
+        ar = np.asarray(re.table_read(capi.TABLE_FFM_ACC))
     np.savez(sys.argv[3], preds=np.concatenate(preds) if preds else np.zeros(0, np.float32), lr=tabs[0], ffm_w=tabs[1], ffm_acc=tabs[2],
-             ranges=ranges, allreduce=ar if ar is not None else np.zeros(0, np.float32))
+             ranges=ranges, allreduce=ar)
     d.close()
     re.close()
 

@@ -90,9 +90,8 @@ def test_process_per_rank_sharded_step_matches_the_oracle(tmp_path, n_ranks):
         # owner ranges partition the tables
         lo, hi = int(o["ranges"][0]), int(o["ranges"][1])
         assert lo == r * ((1 << ffm_bits) // n_ranks) and (hi == 0xFFFFFFFF if r == n_ranks - 1 else hi == (r + 1) * ((1 << ffm_bits) // n_ranks))
-        # all-reduce (sum) through the same communicator: sum over ranks of (rank + 1) * i for the first 8, of (rank + 1) after
-        tot = n_ranks * (n_ranks + 1) / 2
-        assert np.array_equal(o["allreduce"][:8], np.arange(8, dtype=np.float32) * tot) and np.all(o["allreduce"][8:] == tot)
+        # all-reduce (sum) through the same communicator: every rank held the same accumulator table
+        assert np.array_equal(o["allreduce"], o["ffm_acc"] * np.float32(n_ranks))
 
 
 @pytest.mark.parametrize("n_ranks,opt", [(2, fw.Optimizer.AdagradLUT), (4, fw.Optimizer.AdagradLUT), (3, fw.Optimizer.AdagradFlex)])
