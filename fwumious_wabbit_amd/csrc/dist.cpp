@@ -140,6 +140,7 @@ struct fwgpu_dist {
     uint64_t ob_wcap = 0;
     fwgpu_batch *cur = nullptr;      // the batch this sparse step runs on
     uint32_t occ_max_ffm = 0, occ_max_lr = 0;
+    PeerShards *d_peers = nullptr;   // peer-sharded step: the owners' table bases, on this rank's device
     hipEvent_t dbg_ev[3] = {nullptr, nullptr, nullptr};  // debug (scripts/group_bisect.sh): recorded behind FWD / MID / the FFM reduction of sparse_local
     uint32_t last_rows[2] = {0, 0};  // bucket rows {ffm, lr} this rank sent in its last sparse step
     ~fwgpu_dist() {
@@ -151,6 +152,7 @@ struct fwgpu_dist {
         if (gb) fwgpu_batch_free(gb);
         if (sp) fwgpu_split_free(sp);
         if (d_own) (void)hipFree(d_own);
+        if (d_peers) (void)hipFree(d_peers);
         if (d_shape) (void)hipFree(d_shape);
         if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
         if (stream) (void)hipStreamDestroy(stream);
@@ -967,6 +969,75 @@ int fwgpu_dist_group_learn_sparse(fwgpu_dist_group *g, const fwgpu_translator_co
     }
     for (int j = 0; j < N; j++) {
         fwgpu_dist *d = g->ranks[j].get();
+        if (preds && preds[j] && d->B) FWGPU_HIP(hipMemcpyAsync(preds[j], d->cur->pred, (size_t)d->B * 4, hipMemcpyDeviceToHost, d->stream));
+        FWGPU_HIP(hipStreamSynchronize(d->stream));
+    }
+    return FWGPU_OK;
+}
+
+// Peer-sharded hogwild step (SURVEY 8e "owner-sharded tables", without the synchronous batch): the tables are sharded by owner --
+// rank s's allocation is the authoritative copy of the FFM rows that START in [s, s+1) * 2^ffm_bits / N and of the LR entries in
+// the same share of 2^bits -- and every rank runs the FUSED hogwild kernel on its own micro-batch, reaching each row in its owner's
+// memory: a plain pointer when the owner lives on the same device (the one-GPU emulation, the tests), a peer-mapped pointer over
+// xGMI when it lives on another GPU of the process (hipDeviceEnablePeerAccess below).  No collective, no barrier between the
+// ranks: this is hogwild.rs:89-103 with GPUs in the place of threads and xGMI in the place of the cache-coherent bus -- the
+// reference's update rule per occurrence, staleness = the examples in flight on all GPUs.
+// What crosses a link per example at config C with N GPUs: (N-1)/N of the row traffic, 200 rows x 960 B x (1 read in the gather +
+// read w, read acc, write w, write acc in the update) = 0.96 MB x 7/8 = 0.84 MB at N = 8, spread over 7 links: 0.12 MB per link
+// and example in each direction pair -> ~1.2 M examples/s per GPU at 153 GB/s per link: a CAPACITY mode with hogwild semantics
+// (no batch-size limit, no divergence cliff), slower than replicas (0.26 KB per example) by the same arithmetic that makes the
+// sparse mode slow.  DESIGN.md 7 has the table.
+// FWGPU_MODE_SEQUENTIAL: rank after rank, each on one workgroup, in example order: the deterministic form the tests compare with
+// the oracle (the sequential reference algorithm over the ranks' micro-batches in rank order).
+// Rows that start below an ownership boundary and reach across it live wholly in their owner's copy (the documented deviation
+// of the sharded mode: 6e-6 of the rows at config C with 8 ranks).
+int fwgpu_dist_group_learn_peer(fwgpu_dist_group *g, const fwgpu_translator_config *t, const uint32_t *const *records,
+                                const uint64_t *const *rec_off, const uint32_t *n, float *const *preds, int update) {
+    if (!g || !t || !records || !rec_off || !n) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    const int N = (int)g->ranks.size();
+    if (N > 8 || (N & (N - 1))) return fail(FWGPU_ERR_INVALID, "peer-sharded step: 1, 2, 4 or 8 ranks");
+    fwgpu_regressor *r0 = g->ranks[0]->r;
+    if (r0->nn.n_layers) return fail(FWGPU_ERR_INVALID, "peer-sharded step: models with a deep head are not covered");
+    int lg = 0;
+    while ((1 << lg) < N) lg++;
+    if ((r0->cfg.ffm_k && (int)r0->cfg.ffm_bit_precision < lg) || (int)r0->cfg.bit_precision < lg)
+        return fail(FWGPU_ERR_INVALID, "peer-sharded step: fewer table entries than ranks");
+    PeerShards ps{};
+    ps.n = (uint32_t)N;
+    ps.shift_ffm = r0->cfg.ffm_k ? r0->cfg.ffm_bit_precision - lg : 31;
+    ps.shift_lr = r0->cfg.bit_precision - lg;
+    for (int j = 0; j < N; j++) {
+        fwgpu_regressor *r = g->ranks[j]->r;
+        ps.ffm_w[j] = r->d_ffm_w;
+        ps.ffm_acc[j] = r->d_ffm_acc;
+        ps.lr[j] = r->d_lr;
+    }
+    // owners on other devices: map their memory (xGMI peer access; a no-op for same-device groups)
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < N; j++) {
+            const int di = g->ranks[i]->r->device, dj = g->ranks[j]->r->device;
+            if (di == dj) continue;
+            FWGPU_HIP(hipSetDevice(di));
+            hipError_t e = hipDeviceEnablePeerAccess(dj, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(FWGPU_ERR_DEVICE, "hipDeviceEnablePeerAccess failed");
+            (void)hipGetLastError();
+        }
+    uint32_t shape[4];
+    int rc;
+    const int mode = g->ranks[0]->mode;
+    for (int j = 0; j < N; j++) {
+        fwgpu_dist *d = g->ranks[j].get();
+        if ((rc = sparse_begin(d, t, records[j], rec_off[j], n[j], nullptr, shape))) return rc;  // (uploads the rank's records into its own batch)
+        FWGPU_HIP(hipSetDevice(d->r->device));
+        if (!d->d_peers) FWGPU_HIP(hipMalloc((void **)&d->d_peers, sizeof(PeerShards)));
+        FWGPU_HIP(hipMemcpyAsync(d->d_peers, &ps, sizeof(PeerShards), hipMemcpyHostToDevice, d->stream));
+        FWGPU_HIP(hipStreamSynchronize(d->stream));  // (ps is a local)
+        if ((rc = run_batch_peer(d->r, d->cur, mode, update, d->d_peers, d->stream))) return rc;
+        if (mode == FWGPU_MODE_SEQUENTIAL) FWGPU_HIP(hipStreamSynchronize(d->stream));  // rank after rank
+    }
+    for (int j = 0; j < N; j++) {
+        fwgpu_dist *d = g->ranks[j].get();
+        FWGPU_HIP(hipSetDevice(d->r->device));
         if (preds && preds[j] && d->B) FWGPU_HIP(hipMemcpyAsync(preds[j], d->cur->pred, (size_t)d->B * 4, hipMemcpyDeviceToHost, d->stream));
         FWGPU_HIP(hipStreamSynchronize(d->stream));
     }

@@ -52,15 +52,15 @@ struct DevNN {
     uint32_t X;          // length of x = LR slots + triangle
     uint32_t sum_width;  // sum of the hidden widths
     uint32_t max_in;     // largest layer input (LDS scratch)
-    uint32_t defer;      // hogwild launches: a workgroup keeps the dense steps of this many examples pending (their rank-1 factors in LDS)
-                         // and applies them in example order in ONE pass over the weights (kernels.hip nn_flush); 0 = step per example
-    uint32_t slot;       // floats per pending example: x[X], h[sum_width], output gradients[sum_width], g
-    uint32_t defer_sum;  // 1: the pending examples' gradients of a weight are SUMMED and take one optimizer step (the mini-batch rule of
-                         // head.hip at workgroup scale); 0: one step per pending example, in example order (the reference's rule per weight)
-    uint32_t plain_reads; // 1: the forward pass and the input gradients read the dense weights through the XCD's L2 (plain loads)
     float rate, minus_power_t;
     float *w, *acc;      // all layers back to back: per layer W[j*in+i] then the biases (block_neural.rs:86-88)
     const float *lut;
+};
+
+// peer-sharded tables: the owners' table bases (device pointers valid on the launching device: same device, or peer-mapped)
+struct PeerShards {
+    uint32_t n, shift_ffm, shift_lr, pad_;
+    float *ffm_w[8], *ffm_acc[8], *lr[8];
 };
 
 // Everything the example kernel needs, passed by value.
@@ -130,6 +130,10 @@ struct KernelParams {
     uint32_t own_lo_ffm, own_hi_ffm;    // this rank owns the FFM rows with own_lo <= hash < own_hi (sharded tables)...
     uint32_t own_lo_lr, own_hi_lr;      // ... and these LR entries
     uint32_t home_lo, home_hi;          // examples of the launch whose label / counts this rank contributes (its own shard of the batch)
+    // ---- peer-sharded tables (dist.cpp fwgpu_dist_group_learn_peer): the tables are sharded by owner, every rank runs the fused hogwild
+    // kernel on its own examples and reaches a row IN ITS OWNER'S MEMORY (same device, or a peer GPU's memory mapped over xGMI).
+    // owner(row) = row start >> shard_shift; every owner's allocation is indexed like the whole table.
+    const struct PeerShards *shards;   // device memory; NULL: the regressor's own tables
     // ---- row-sparse gradient mode (sparse.hip): the FWD phase lists every entry as an occurrence, slot = example * max_ffm + entry
     unsigned long long *occ_ffm_key;    // [n * max_ffm] (row hash << 32 | slot), ~0 for unused slots and examples that do not update
     uint2 *occ_ffm_desc;                // [n * max_ffm] {value bits, field}
@@ -144,9 +148,6 @@ struct LaunchConfig {
     int32_t lut_global = 0;
     int32_t window = 1;              // whole-line FFM row updates: 0 off, 1 auto (tables > Infinity Cache), 2 always (debug option 2)
     int32_t no_chain = 0;            // debug option 3
-    int32_t nn_defer = 8;            // debug option 7: deep head, hogwild launches: pending examples per workgroup (0 / 1: step per example)
-    int32_t nn_defer_sum = 1;        // debug option 8
-    int32_t nn_plain_reads = 0;      // debug option 9
     uint32_t hot_lr_every = 1;       // debug option 4: hot LR entry route (0 off, 1 atomics per example, n>1 weight deltas pending n examples)
     bool threads_set = false;
     uint32_t max_in_flight = 0;  // cap on the persistent grid = examples processed concurrently (0: what the device holds)  // fwgpu_set_launch chose the workgroup size: no automatic choice
@@ -434,6 +435,8 @@ uint32_t lr_hash_mask(uint32_t bit_precision);
 uint32_t ffm_hash_mask(uint32_t ffm_bits, uint32_t ffm_k);
 void lut_init(float *lut, float learning_rate, float power_t, float init_acc);
 KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int update);
+// the fused learn / predict launch of `b` with every row and LR entry reached in its owner's tables (generic kernel); d_shards: device copy
+int run_batch_peer(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, const PeerShards *d_shards, hipStream_t stream);
 struct SplitRanges {  // what a rank owns (sharded tables) and which examples of the launch are its own
     uint32_t ffm_lo = 0, ffm_hi = 0xffffffffu, lr_lo = 0, lr_hi = 0xffffffffu, home_lo = 0, home_hi = 0xffffffffu;
 };

@@ -111,6 +111,19 @@ __device__ __forceinline__ void lr_store(float *lr, uint32_t h, float2 wa) {
         *p = v;
 }
 
+// Table bases of a row / an LR entry: the regressor's own tables, or -- peer-sharded tables -- the owner's (KernelParams::shards).
+// `h` is wave-uniform at the row sites (a scalar branch and a scalar load from the kernel arguments).
+// (The owners' bases live in device memory, not in the kernel arguments: an array indexed at run time inside the by-value KernelParams
+// made the compiler copy the whole struct to scratch -- 1-2 KB per lane in every kernel, -30 % on the generic kernel.)
+// SH is a template argument of the generic kernel (its own instantiations, launched by run_batch_peer only): a run-time test per row
+// cost the deep-head launch 17 %.
+template <bool SH>
+__device__ __forceinline__ float *ffm_w_base(const KernelParams &p, uint32_t h) { return SH ? p.shards->ffm_w[h >> p.shards->shift_ffm] : p.ffm_w; }
+template <bool SH>
+__device__ __forceinline__ float *ffm_acc_base(const KernelParams &p, uint32_t h) { return SH ? p.shards->ffm_acc[h >> p.shards->shift_ffm] : p.ffm_acc; }
+template <bool SH>
+__device__ __forceinline__ float *lr_base(const KernelParams &p, uint32_t h) { return SH ? p.shards->lr[h >> p.shards->shift_lr] : p.lr; }
+
 // LDS carve-up (all offsets 16-byte aligned).
 struct Lds {
     float *T;        // F*R
@@ -141,7 +154,7 @@ __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t
 // input gradient, and one product per LR entry
 __host__ __device__ inline uint32_t nn_lds_floats(const KernelParams &p) {
     if (!p.nn.n_layers) return 0;
-    return 2 * p.nn.X + 2 * p.nn.sum_width + p.nn.max_in + p.max_lr + 16 + p.nn.defer * p.nn.slot;
+    return 2 * p.nn.X + 2 * p.nn.sum_width + p.nn.max_in + p.max_lr + 16;
 }
 
 // size of the open-addressing sets: power of two >= 2*n (load factor <= 0.5)
@@ -236,18 +249,19 @@ __device__ __forceinline__ void hot_lr_init(const KernelParams &p, const Lds &s,
 }
 // The pending weight delta goes to the table (taken out of LDS by exchange: a step another thread adds meanwhile stays pending).
 // Called by the thread that has just stepped the entry, every ctr[13] examples, and by thread 0 after the example loop.
+template <bool SH = false>
 __device__ __forceinline__ void hot_lr_flush(const KernelParams &p, const Lds &s) {
     float *hot = hot_lr_state(s);
     const float dw = atomicExch(hot + 1, 0.0f);
     s.ctr[7] = 0;
     if (dw == 0.0f) return;
-    __hip_atomic_fetch_add(p.lr + 2 * (size_t)s.ctr[12], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(lr_base<SH>(p, s.ctr[12]) + 2 * (size_t)s.ctr[12], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // The weight of LR entry `h` as the forward pass sees it (block_lr.rs:36-45); for the hot entry: + this workgroup's pending
 // delta, and the accumulator that came with it is kept for the update phase.
-template <bool COH>
+template <bool COH, bool SH = false>
 __device__ __forceinline__ float lr_forward_weight(const KernelParams &p, const Lds &s, uint32_t h) {
-    const float2 wa = lr_load<COH>(p.lr, h);
+    const float2 wa = lr_load<COH>(lr_base<SH>(p, h), h);
     if (COH && hot_lr_is(s, h)) {
         float *hot = hot_lr_state(s);
         hot[0] = wa.y;
@@ -673,7 +687,6 @@ struct NnBuf {
     float *m;    // [sum_width] ReLU 0/1 masks, then the layers' output gradients
     float *fg;   // [max_in] final neuron's input gradient / per-layer scratch
     float *prod; // [max_lr] w*v of every LR entry
-    float *ring; // [defer * slot] pending examples' factors (nn_backward_deferred / nn_flush)
 };
 __device__ __forceinline__ NnBuf nn_buf(const KernelParams &p, const Lds &s) {
     NnBuf b;
@@ -683,7 +696,6 @@ __device__ __forceinline__ NnBuf nn_buf(const KernelParams &p, const Lds &s) {
     b.m = b.h + p.nn.sum_width;
     b.fg = b.m + p.nn.sum_width;
     b.prod = b.fg + p.nn.max_in;
-    b.ring = b.prod + ((p.max_lr + 15) & ~3u);
     return b;
 }
 template <bool COH>
@@ -785,9 +797,7 @@ __device__ __forceinline__ float nn_forward(const KernelParams &p, const Lds &s,
                     f4 w[JU];
 #pragma unroll
                     for (int u = 0; u < JU; ++u)
-                        w[u] = j0 + u >= out ? Vec<4>::zero()
-                               : n.plain_reads ? Vec<4>::load<kAuxPlain>(rw, ((j0 + u) * in + 4 * q) * 4)
-                                               : Vec<4>::load<kAuxSc1>(rw, ((j0 + u) * in + 4 * q) * 4);
+                        w[u] = j0 + u < out ? Vec<4>::load<kAuxSc1>(rw, ((j0 + u) * in + 4 * q) * 4) : Vec<4>::zero();
                     const f4 xv = Vec<4>::lds_load(in_vec + 4 * q);
 #pragma unroll
                     for (int u = 0; u < JU; ++u) dot[u] += w[u][0] * xv[0] + w[u][1] * xv[1] + w[u][2] * xv[2] + w[u][3] * xv[3];
@@ -1034,262 +1044,18 @@ __device__ __forceinline__ void nn_backward(const KernelParams &p, const Lds &s,
     }
 }
 
-// ---- deferred dense steps (hogwild launches, DevNN::defer > 1).
-// The exact head read-modify-writes all 194 k dense weights of config E for EVERY example: 20 B x 194 k = 3.9 MB per example
-// through the fabric, and of the ~256 concurrent writers of a weight one survives.  A dense layer's gradient is rank 1 --
-// d W[j][i] = og[j] * in[i] -- so a workgroup keeps the FACTORS of its last `defer` examples in LDS (x, the hidden activations,
-// the layers' output gradients: 6 KB per example at config E) and, every `defer` examples, walks the weights ONCE: load {w, acc},
-// apply the pending examples' AdaGrad steps one after the other in example order (exactly the per-example sequence of
-// block_neural.rs:275-306 on that weight, gradients taken with the weights of the workgroup's last pass), store.  The input
-// gradients of a pending example are formed with the weights as they are (block_neural.rs:283: the pre-update weight).
-// Traffic per example: the forward and input-gradient reads + 16 B x 194 k / defer; no step is dropped inside a workgroup.
-// Between workgroups it is hogwild as before.  In-order launches keep the per-example path (bit-exact mode).
-constexpr int kNnDeferMax = 8;
-struct NnRing {
-    float *x, *h, *og, *g;
-};
-__device__ __forceinline__ NnRing nn_ring_slot(const KernelParams &p, const NnBuf &b, uint32_t e) {
-    NnRing r;
-    r.x = b.ring + (size_t)e * p.nn.slot;
-    r.h = r.x + p.nn.X;
-    r.og = r.h + p.nn.sum_width;
-    r.g = r.og + p.nn.sum_width;
-    return r;
-}
-// input gradient of layer l with the weights as they are: grad[i] = sum_j W[j][i] * og[j]  (16-byte device-scope loads; thread
-// (q, grp) owns columns 4q .. 4q+3 for the neurons of group grp).  Contains barriers: called by every thread.
-__device__ __forceinline__ void nn_layer_ingrad_vec(const DevNN &n, uint32_t l, const float *og, uint32_t split, float *grad_a,
-                                                    float *grad_b, int tid, int bd) {
-    const uint32_t in = n.in[l], out = n.out[l], nq = in >> 2;
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc(n.w + n.off[l], in * out * 4);
-    uint32_t G = (uint32_t)bd / nq;
-    G = G > out ? out : G;
-    const uint32_t q = (uint32_t)tid % nq, grp = (uint32_t)tid / nq;
-    const bool active = grp < G;
-    const uint32_t jn = (out + G - 1) / G, jlo = grp * jn, jhi = jlo + jn < out ? jlo + jn : out;
-    f4 oe = Vec<4>::zero();
-    if (active) {
-        constexpr int JU = 8;
-        for (uint32_t j0 = jlo; j0 < jhi; j0 += JU) {
-            f4 w[JU];
-            float gg[JU];
-#pragma unroll
-            for (int u = 0; u < JU; ++u) {
-                const uint32_t j = j0 + u;
-                gg[u] = j < jhi ? og[j] : 0.0f;
-                w[u] = Vec<4>::zero();
-                if (gg[u] != 0.0f)
-                    w[u] = n.plain_reads ? Vec<4>::load<kAuxPlain>(rw, (j * in + 4 * q) * 4) : Vec<4>::load<kAuxSc1>(rw, (j * in + 4 * q) * 4);
-            }
-#pragma unroll
-            for (int u = 0; u < JU; ++u)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) oe[c] += w[u][c] * gg[u];
-        }
-    }
-    __syncthreads();
-    if (active && grp == 0) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const uint32_t i = 4 * q + c;
-            if (i < split) grad_a[i] = oe[c];
-            else grad_b[i - split] = oe[c];
-        }
-    }
-    __syncthreads();
-    if (active && grp != 0) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const uint32_t i = 4 * q + c;
-            atomicAdd(i < split ? &grad_a[i] : &grad_b[i - split], oe[c]);
-        }
-    }
-}
-
-// The pending examples' dense steps, one pass over the weights.  Called by every thread (barriers), count = s.ctr[15] > 0.
-template <int OPT>
-__device__ __forceinline__ void nn_flush(const KernelParams &p, const Lds &s, int tid, int bd) {
-    const NnBuf b = nn_buf(p, s);
-    const DevNN &n = p.nn;
-    const uint32_t cnt = s.ctr[15];
-    const uint32_t L = n.n_layers, X = n.X, wl = n.out[L - 1];
-    uint32_t hoff = 0;
-    for (uint32_t l = 0; l <= L; ++l) {
-        const uint32_t in = n.in[l], out = n.out[l], nq = in >> 2;
-        // layer l: inputs = x (l = 0), the previous layer's activations, or [h_last | x] (final neuron, topology one);
-        // output gradients = the layer's og, or g for the final neuron
-        const uint32_t in_h = l == 0 ? 0u : (l == L ? wl : in);      // leading inputs that come from h
-        const uint32_t in_hoff = l == 0 ? 0u : (l == L ? n.sum_width - wl : hoff - n.out[l - 1]);
-        float *W = n.w + n.off[l], *A = n.acc + n.off[l];
-        const __amdgpu_buffer_rsrc_t rw = make_rsrc(W, in * out * 4), ra = make_rsrc(A, in * out * 4);
-        uint32_t G = (uint32_t)bd / nq;
-        G = G > out ? out : G;
-        const uint32_t q = (uint32_t)tid % nq, grp = (uint32_t)tid / nq;
-        const uint32_t jn = (out + G - 1) / G, jlo = grp * jn, jhi = jlo + jn < out ? jlo + jn : out;
-        if (grp < G) {
-            f4 xi[kNnDeferMax];
-#pragma unroll
-            for (int e = 0; e < kNnDeferMax; ++e) {
-                xi[e] = Vec<4>::zero();
-                if ((uint32_t)e < cnt) {
-                    const NnRing r = nn_ring_slot(p, b, e);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const uint32_t i = 4 * q + c;
-                        xi[e][c] = i < in_h ? r.h[in_hoff + i] : r.x[i - in_h];
-                    }
-                }
-            }
-            constexpr int JU = 2;
-            for (uint32_t j0 = jlo; j0 < jhi; j0 += JU) {
-                f4 w[JU], a[JU];
-                bool any[JU];
-#pragma unroll
-                for (int u = 0; u < JU; ++u) {
-                    const uint32_t j = j0 + u;
-                    any[u] = false;
-                    if (j < jhi)
-                        for (uint32_t e = 0; e < cnt; ++e) {
-                            const NnRing r = nn_ring_slot(p, b, e);
-                            any[u] = any[u] || (l == L ? r.g[0] : r.og[hoff + j]) != 0.0f;
-                        }
-                    w[u] = Vec<4>::zero();
-                    a[u] = Vec<4>::zero();
-                    if (any[u]) {  // block_neural.rs:275-277: weights of a neuron without upstream gradient are not touched
-                        const uint32_t bo = (j * in + 4 * q) * 4;
-                        w[u] = Vec<4>::load<kAuxSc1>(rw, bo);
-                        if (OPT != FWGPU_OPT_SGD) a[u] = Vec<4>::load<kAuxSc1>(ra, bo);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < JU; ++u) {
-                    if (!any[u]) continue;
-                    const uint32_t j = j0 + u;
-                    f4 G = Vec<4>::zero();
-#pragma unroll
-                    for (int e = 0; e < kNnDeferMax; ++e) {
-                        if ((uint32_t)e >= cnt) break;
-                        const NnRing r = nn_ring_slot(p, b, e);
-                        const float gg = l == L ? r.g[0] : r.og[hoff + j];
-                        if (gg == 0.0f) continue;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            if (n.defer_sum) {
-                                G[c] += gg * xi[e][c];
-                            } else {
-                                float acc = a[u][c];
-                                const float upd = opt_step<OPT>(gg * xi[e][c], acc, n.rate, n.minus_power_t, n.lut);
-                                w[u][c] = w[u][c] - upd;
-                                a[u][c] = acc;
-                            }
-                        }
-                    }
-                    if (n.defer_sum) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            float acc = a[u][c];
-                            const float upd = opt_step<OPT>(G[c], acc, n.rate, n.minus_power_t, n.lut);
-                            w[u][c] = w[u][c] - upd;
-                            a[u][c] = acc;
-                        }
-                    }
-                    const uint32_t bo = (j * in + 4 * q) * 4;
-                    Vec<4>::store<kAuxSc1>(w[u], rw, bo);
-                    if (OPT != FWGPU_OPT_SGD) Vec<4>::store<kAuxSc1>(a[u], ra, bo);
-                }
-            }
-        }
-        for (uint32_t j = tid; j < out; j += bd) {  // bias terms (block_neural.rs:296-306)
-            const size_t ix = (size_t)in * out + j;
-            float w = 0.0f, acc = 0.0f;
-            bool loaded = false;
-            float Gb = 0.0f;
-            for (uint32_t e = 0; e < cnt; ++e) {
-                const NnRing r = nn_ring_slot(p, b, e);
-                const float gg = l == L ? r.g[0] : r.og[hoff + j];
-                if (gg == 0.0f) continue;
-                if (!loaded) {
-                    w = nn_ld<true>(W + ix);
-                    acc = OPT == FWGPU_OPT_SGD ? 0.0f : nn_ld<true>(A + ix);
-                    loaded = true;
-                }
-                if (n.defer_sum) Gb += gg;
-                else w -= opt_step<OPT>(gg, acc, n.rate, n.minus_power_t, n.lut);
-            }
-            if (loaded && n.defer_sum) w -= opt_step<OPT>(Gb, acc, n.rate, n.minus_power_t, n.lut);
-            if (loaded) {
-                nn_st<true>(W + ix, w);
-                if (OPT != FWGPU_OPT_SGD) nn_st<true>(A + ix, acc);
-            }
-        }
-        if (l < L) hoff += out;
-    }
-    (void)X;
-    __syncthreads();  // the ring may be overwritten
-    if (tid == 0) s.ctr[15] = 0;
-}
-
-// The unwinding of the head with the dense steps left pending: this example's factors go to the ring, the input gradients are
-// formed with the weights as they are; d logit / d x ends in xg[] as in nn_backward.  Flushes when the ring is full.
-template <int OPT>
-__device__ __forceinline__ void nn_backward_deferred(const KernelParams &p, const Lds &s, float g, int tid, int bd) {
-    const NnBuf b = nn_buf(p, s);
-    const DevNN &n = p.nn;
-    const uint32_t L = n.n_layers, X = n.X, wl = n.out[L - 1];
-    const uint32_t e = s.ctr[15];
-    const NnRing r = nn_ring_slot(p, b, e);
-    for (uint32_t i = tid; i < X; i += bd) r.x[i] = b.x[i];
-    for (uint32_t i = tid; i < n.sum_width; i += bd) r.h[i] = b.h[i];
-    if (tid == 0) {
-        r.g[0] = g;
-        b.fg[0] = g;
-    }
-    __syncthreads();
-    const uint32_t hoff_last = n.sum_width - wl;
-    // final neuron: inputs [h_last | x] -> input gradients [h_last (in place) | xg]
-    nn_layer_ingrad_vec(n, L, b.fg, wl, b.h + hoff_last, b.xg, tid, bd);
-    if (n.topology != 1)
-        for (uint32_t i = tid; i < X; i += bd) b.xg[i] = 0.0f;
-    __syncthreads();
-    uint32_t hoff = hoff_last;
-    for (int l = (int)L - 1; l >= 0; --l) {
-        const uint32_t out = n.out[l];
-        // BlockRELU backward (block_relu.rs:105-110): mask * upstream gradient -> this layer's output gradient
-        for (uint32_t j = tid; j < out; j += bd) {
-            const float og = b.m[hoff + j] * b.h[hoff + j];
-            b.m[hoff + j] = og;
-            r.og[hoff + j] = og;
-        }
-        __syncthreads();
-        if (l > 0) {
-            const uint32_t pin = n.out[l - 1];
-            nn_layer_ingrad_vec(n, l, b.m + hoff, pin, b.h + hoff - pin, b.h + hoff - pin, tid, bd);
-            hoff -= pin;
-        } else {
-            // first layer: its input gradient is ADDED to the copy branch (BlockCopy, block_misc.rs:456-475)
-            nn_layer_ingrad_vec(n, 0, b.m + hoff, X, b.fg, b.fg, tid, bd);
-            __syncthreads();
-            for (uint32_t i = tid; i < X; i += bd) b.xg[i] = b.fg[i] + b.xg[i];
-        }
-        __syncthreads();
-    }
-    if (tid == 0) s.ctr[15] = e + 1;
-    __syncthreads();
-    if (e + 1 >= n.defer) nn_flush<OPT>(p, s, tid, bd);
-}
-
 // LR update (block_lr.rs:135-150).  Entries with the same hash are applied by the thread owning the FIRST occurrence, in
 // buffer order, on one register copy of {w, acc}: duplicates chain exactly like the reference's loop (regressor.rs:629-655
 // pins this).  The entry is read again here rather than kept from the forward pass: keeping it saved no time and widened
 // the hogwild read-modify-write window of hot entries (constant feature) by two phases.
-template <int OPT, bool COH>
+template <int OPT, bool COH, bool SH = false>
 __device__ __forceinline__ void lr_update(const KernelParams &p, const Lds &s, uint32_t nl, float g, const float *gx,
                                           const float *lut_lr, int tid, int bd, uint32_t lo = 0, uint32_t hi = 0xffffffffu) {
     for (uint32_t t = tid; t < nl; t += bd) {
         const uint32_t fl = s.l_flag[t];
         const uint32_t h = s.l_hash[t];
         if (COH && hot_lr_is(s, h)) {  // (every entry of that hash steps from the accumulator the forward pass read; chains are for the table route)
-            float *entry = p.lr + 2 * (size_t)h;
+            float *entry = lr_base<SH>(p, h) + 2 * (size_t)h;
             float *hot = hot_lr_state(s);
             const float grad = (gx ? gx[s.l_combo[t]] : g) * s.l_val[t];
             float acc = hot[0];
@@ -1302,14 +1068,14 @@ __device__ __forceinline__ void lr_update(const KernelParams &p, const Lds &s, u
                 if (!(fl & kRowChained)) {  // (one entry of that hash per example is not chained)
                     const uint32_t n = s.ctr[7] + 1;
                     s.ctr[7] = n;
-                    if (n >= s.ctr[13]) hot_lr_flush(p, s);
+                    if (n >= s.ctr[13]) hot_lr_flush<SH>(p, s);
                 }
             }
             continue;
         }
         if (fl & kRowChained) continue;
         if (h < lo || h >= hi) continue;  // sharded tables: another rank's entry
-        float2 wa = lr_load<COH>(p.lr, h);
+        float2 wa = lr_load<COH>(lr_base<SH>(p, h), h);
         {
             const float grad = (gx ? gx[s.l_combo[t]] : g) * s.l_val[t];
             wa.x -= opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, lut_lr);
@@ -1320,13 +1086,13 @@ __device__ __forceinline__ void lr_update(const KernelParams &p, const Lds &s, u
                     const float grad = (gx ? gx[s.l_combo[j]] : g) * s.l_val[j];
                     wa.x -= opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, lut_lr);
                 }
-        lr_store<COH>(p.lr, h, wa);
+        lr_store<COH>(lr_base<SH>(p, h), h, wa);
     }
 }
 
 // Update of one FFM feature row by one wave (block_ffm.rs:269-286), U rows at a time for memory-level
 // parallelism.  idx[u] == 0xffffffff marks an unused slot.
-template <int VEC, int OPT, int AUX, int U>
+template <int VEC, int OPT, int AUX, int U, bool SH = false>
 __device__ __forceinline__ void update_rows(const KernelParams &p, const Lds &s, const uint32_t (&idx)[U], float g,
                                             int lane, const float *gpair = nullptr, uint32_t nf = 0) {
     typedef typename Vec<VEC>::type V;
@@ -1348,10 +1114,10 @@ __device__ __forceinline__ void update_rows(const KernelParams &p, const Lds &s,
                 const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[idx[u]]);
                 hsh[u] = h;
                 fld[u] = __builtin_amdgcn_readfirstlane(s.e_fld[idx[u]]);
-                rw[u] = make_rsrc(p.ffm_w + h, R * 4);
+                rw[u] = make_rsrc(ffm_w_base<SH>(p, h) + h, R * 4);
                 wv[u] = Vec<VEC>::template load<AUX>(rw[u], e0 * 4);
                 if (OPT != FWGPU_OPT_SGD) {
-                    ra[u] = make_rsrc(p.ffm_acc + h, R * 4);
+                    ra[u] = make_rsrc(ffm_acc_base<SH>(p, h) + h, R * 4);
                     av[u] = Vec<VEC>::template load<AUX>(ra[u], e0 * 4);
                 }
             }
@@ -1545,7 +1311,7 @@ uint32_t split_record_len(uint32_t F, uint32_t R, uint32_t nlr) { return split_l
 //   FWD : stage, gather the rows this rank OWNS (all of them on one GPU), write T / dcf / LR sums to the example's split record
 //   (exchange: records summed over the ranks; MID kernel: logit, prediction, general gradient; or the mini-batched deep head)
 //   UPD : stage, T and the entries' own slots back from the records, AdaGrad on the owned rows and LR entries
-template <int VEC, int OPT, bool COH, int PH = 0, bool NN = true>
+template <int VEC, int OPT, bool COH, int PH = 0, bool NN = true, bool SH = false>
 __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) {
     typedef typename Vec<VEC>::type V;
     constexpr int AUX = COH ? kAuxSc1 : kAuxPlain;
@@ -1620,7 +1386,6 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
     if (tid == 0) {
         s.ctr[6] = atomicAdd(p.work, 1u);
         hot_lr_init<COH>(p, s, PH == 0);
-        s.ctr[15] = 0;  // deep head: examples whose dense steps are pending (nn_backward_deferred)
     }
     for (;;) {
         // Previous example's LDS reads are done.  A workgroup-scope barrier does not drain vmcnt on this target,
@@ -1675,7 +1440,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                                 const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[i + u]);
                                 if (PH == 1) on[u] = h >= p.own_lo_ffm && h < p.own_hi_ffm;  // sharded tables: owned rows only
                                 v[u] = s.e_val[i + u];
-                                if (on[u]) r[u] = Vec<VEC>::template load<AUX>(make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
+                                if (on[u]) r[u] = Vec<VEC>::template load<AUX>(make_rsrc(ffm_w_base<SH>(p, h) + h, R * 4), e0 * 4);
                             }
                         }
 #pragma unroll
@@ -1801,7 +1566,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         float lrs = 0.0f;
         if (p.has_lr)
             for (uint32_t i = tid; i < nl; i += bd) {
-                lrs += lr_forward_weight<COH>(p, s, s.l_hash[i]) * s.l_val[i];
+                lrs += lr_forward_weight<COH, SH>(p, s, s.l_hash[i]) * s.l_val[i];
             }
         dot = wave_sum(dot);
         lrs = wave_sum(lrs);
@@ -1851,15 +1616,12 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                 gx = p.dxbuf + (size_t)ex * p.nn.X;
                 gpair = gx + p.num_combos;
             } else if (NN && p.nn.n_layers) {
-                if (COH && PH == 0 && p.nn.defer > 1 && gridDim.x > 1)
-                    nn_backward_deferred<OPT>(p, s, g, tid, bd);
-                else
-                    nn_backward<OPT, COH>(p, s, g, tid, bd);
+                nn_backward<OPT, COH>(p, s, g, tid, bd);
                 gx = nn_buf(p, s).xg;
                 gpair = gx + p.num_combos;
             }
             const uint32_t olo = PH == 3 ? p.own_lo_ffm : 0u, ohi = PH == 3 ? p.own_hi_ffm : 0xffffffffu;
-            if (p.has_lr) lr_update<OPT, COH>(p, s, nl, g, gx, lut_lr, tid, bd, PH == 3 ? p.own_lo_lr : 0u, PH == 3 ? p.own_hi_lr : 0xffffffffu);
+            if (p.has_lr) lr_update<OPT, COH, SH>(p, s, nl, g, gx, lut_lr, tid, bd, PH == 3 ? p.own_lo_lr : 0u, PH == 3 ? p.own_hi_lr : 0xffffffffu);
             FW_TICK(4);
             if (k) {
                 // phase A: rows with no earlier overlapping row, all waves, UU rows each
@@ -1870,7 +1632,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                         const uint32_t i = i0 + u;
                         idx[u] = (i < nf && !(s.e_fld[i] & (kRowDep | kRowChained)) && s.e_hash[i] >= olo && s.e_hash[i] < ohi) ? i : 0xffffffffu;
                     }
-                    update_rows<VEC, OPT, AUX, UU>(p, s, idx, g, lane, gpair, nf);
+                    update_rows<VEC, OPT, AUX, UU, SH>(p, s, idx, g, lane, gpair, nf);
                 }
                 // phase B: overlapping rows, strictly in buffer order on one wave
                 if (s.ctr[1]) {
@@ -1880,7 +1642,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                         for (uint32_t i = 0; i < nf; ++i) {
                             if ((s.e_fld[i] & kRowDep) && s.e_hash[i] >= olo && s.e_hash[i] < ohi) {
                                 uint32_t idx[1] = {i};
-                                update_rows<VEC, OPT, AUX, 1>(p, s, idx, g, lane, gpair, nf);
+                                update_rows<VEC, OPT, AUX, 1, SH>(p, s, idx, g, lane, gpair, nf);
                                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                                 __builtin_amdgcn_s_waitcnt(0);
                             }
@@ -1892,8 +1654,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         }
         if (tid == 0) s.ctr[6] = next_ticket;  // published by the loop-top barrier
     }
-    if (COH && tid == 0 && s.ctr[13]) hot_lr_flush(p, s);  // (every thread's steps are in: the loop ends on a barrier)
-    if (NN && COH && PH == 0 && p.nn.defer > 1 && gridDim.x > 1 && s.ctr[15]) nn_flush<OPT>(p, s, tid, bd);  // (uniform: read behind the loop's barrier)
+    if (COH && tid == 0 && s.ctr[13]) hot_lr_flush<SH>(p, s);  // (every thread's steps are in: the loop ends on a barrier)
     if (timing)
         for (int i = 0; i < 8; ++i) atomicAdd(p.ticks + i, tk[i]);
 #undef FW_TICK
@@ -1937,6 +1698,7 @@ template <int VEC, int OPT, bool COH>
 static hipError_t launch_t(const KernelParams &p, uint32_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
     // (models without a deep head run an instantiation without its code: fewer registers, no spills in the row loops)
     if (p.nn.n_layers) return launch_persistent(fw_example_kernel<VEC, OPT, COH, 0, true>, p, grid, threads, lds, stream);
+    if (p.shards) return launch_persistent(fw_example_kernel<VEC, OPT, COH, 0, false, true>, p, grid, threads, lds, stream);  // peer-sharded tables
     return launch_persistent(fw_example_kernel<VEC, OPT, COH, 0, false>, p, grid, threads, lds, stream);
 }
 
@@ -2394,7 +2156,10 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? FW_LB_WAVES : 4) fw_e
 #endif
             if (lr_upd) lr_update<OPT, COH>(p, s, nl, g, nullptr, lut_lr, tid, bd);
             FW_TICK(4);
-            // phase A, resident rows: w comes from registers (read once, in the gather); only acc is loaded
+            // phase A, resident rows: w comes from registers (read once, in the gather); only acc is loaded.
+            // Chained duplicates (WIN): a row that is chained to an earlier one is applied by that row's owner, and an owner WITH a
+            // chain applies it from the window path below (which walks the chain): neither is stepped here.
+            constexpr uint32_t kResSkip = WIN ? (kRowDep | kRowChained | kRowHasChain) : kRowDep;
 #pragma unroll
             for (int g0 = 0; g0 < MAXR; g0 += UA) {
                 if ((uint32_t)g0 < cnt) {
@@ -2404,7 +2169,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? FW_LB_WAVES : 4) fw_e
                         av[u] = Vec<VEC>::zero();
                         if (OPT != FWGPU_OPT_SGD && (uint32_t)(g0 + u) < cnt) {
                             const uint32_t i = lo + g0 + u;
-                            if (!(s.e_fld[i] & kRowDep)) {
+                            if (!(s.e_fld[i] & kResSkip)) {
                                 const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[i]);
                                 av[u] = Vec<VEC>::template load<AUX>(make_rsrc(p.ffm_acc + h, R * 4), e0 * 4);
                             }
@@ -2415,7 +2180,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? FW_LB_WAVES : 4) fw_e
                         if (g0 + u < MAXR && (uint32_t)(g0 + u) < cnt) {
                             const uint32_t i = lo + g0 + u;
                             const uint32_t fb = s.e_fld[i];
-                            if (!(fb & kRowDep)) {
+                            if (!(fb & kResSkip)) {
                                 const uint32_t f = __builtin_amdgcn_readfirstlane(fb & kFldMask);
                                 const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[i]);
                                 const float v = s.e_val[i];
@@ -2446,13 +2211,15 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? FW_LB_WAVES : 4) fw_e
 #ifdef FW_ABL_NO_FFM_UPD
             for (uint32_t i0 = hi; i0 < hi; i0 += UO) {
 #else
-            for (uint32_t i0 = lo + MAXR; i0 < hi; i0 += UO) {
+            for (uint32_t i0 = (WIN && MAXR > 0) ? lo : lo + MAXR; i0 < hi; i0 += UO) {
 #endif
                 uint32_t idx[UO];
 #pragma unroll
                 for (int u = 0; u < UO; ++u) {
                     const uint32_t i = i0 + u;
                     idx[u] = (i < hi && !(s.e_fld[i] & (kRowDep | kRowChained))) ? i : 0xffffffffu;
+                    // (the first MAXR rows of the range were stepped from registers, unless they own a chain)
+                    if (WIN && MAXR > 0 && i < lo + MAXR && i < hi && !(s.e_fld[i] & kRowHasChain)) idx[u] = 0xffffffffu;
                 }
                 if (WIN)
                     update_rows_win<OPT, AUX, UO, (NC > FW_WIN_NCH ? NC : FW_WIN_NCH)>(p, s, idx, g, lane, nf);
@@ -2489,7 +2256,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? FW_LB_WAVES : 4) fw_e
 #define FW_MAXR 2
 #endif
 #ifndef FW_MAXR_WIN
-#define FW_MAXR_WIN 0
+#define FW_MAXR_WIN 8
 #endif
 template <int OPT, bool COH>
 static hipError_t launch_r(const KernelParams &p, uint32_t grid, uint32_t threads, size_t lds, hipStream_t stream) {

@@ -433,32 +433,6 @@ static int prepare_launch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int upda
     }
     if (lds > r->lds_per_cu)
         return fail(FWGPU_ERR_RANGE, "example does not fit the 160 KiB LDS (k*F^2 or features per example too large)");
-    // Deep head, hogwild training: the dense steps of `defer` examples stay pending per workgroup (kernels.hip nn_flush) when the
-    // layers have the 16-byte shape and the LDS left over by the example itself holds at least two examples' factors
-    // (one workgroup per CU at config E: T alone is 57.6 KB).
-    p.nn.defer = 0;
-    if (p.nn.n_layers && update && mode == FWGPU_MODE_HOGWILD) {
-        int want = r->launch.nn_defer;
-        static const char *env = getenv("FWGPU_NN_DEFER");  // A/B runs
-        if (env) want = atoi(env);
-        bool shape_ok = true;
-        for (uint32_t l = 0; l <= p.nn.n_layers; l++)
-            shape_ok = shape_ok && p.nn.in[l] >= 4 && (p.nn.in[l] & 3u) == 0 && (p.nn.off[l] & 3u) == 0 && (p.nn.in[l] >> 2) <= threads;
-        p.nn.slot = (p.nn.X + 2 * p.nn.sum_width + 4 + 3) & ~3u;
-        const size_t spare = r->lds_per_cu > lds + 256 ? r->lds_per_cu - lds - 256 : 0;
-        // (a second workgroup per CU is worth more than the ring: only LDS that one workgroup per CU leaves unused anyway)
-        const bool one_per_cu = 2 * lds > r->lds_per_cu;
-        const uint32_t fit = (uint32_t)std::min<size_t>(8, spare / (4 * (size_t)p.nn.slot));
-        if (want > 1 && shape_ok && one_per_cu && fit >= 2) {
-            p.nn.defer = std::min<uint32_t>((uint32_t)want, fit);
-            lds = example_kernel_lds_bytes(p, r->cfg.optimizer);
-        }
-        p.nn.defer_sum = r->launch.nn_defer_sum ? 1u : 0u;
-        p.nn.plain_reads = r->launch.nn_plain_reads ? 1u : 0u;
-        static const char *env_sum = getenv("FWGPU_NN_DEFER_SUM"), *env_plain = getenv("FWGPU_NN_PLAIN");  // A/B runs
-        if (env_sum) p.nn.defer_sum = atoi(env_sum) ? 1u : 0u;
-        if (env_plain) p.nn.plain_reads = atoi(env_plain) ? 1u : 0u;
-    }
     return FWGPU_OK;
 }
 
@@ -477,6 +451,23 @@ static int run_batch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, h
         FWGPU_HIP(hipMemsetAsync(b->work, 0, sizeof(uint32_t), stream));
     }
     // An updating launch always uses device-scope (sc1) accesses; read-only launches use cached loads.
+    FWGPU_HIP(launch_example_kernel(p, r->cfg.optimizer, update != 0, grid, threads, stream));
+    return FWGPU_OK;
+}
+
+int run_batch_peer(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, const PeerShards *d_shards, hipStream_t stream) {
+    if (b->n == 0) return FWGPU_OK;
+    if (r->nn.n_layers) return fail(FWGPU_ERR_INVALID, "peer-sharded tables: models with a deep head are not covered");
+    KernelParams p;
+    uint32_t threads = 0;
+    const int32_t kv = r->launch.kernel_version;
+    r->launch.kernel_version = 1;  // the generic kernel carries the owner lookup (kernels.hip ffm_w_base / lr_base)
+    int rc = prepare_launch(r, b, mode, update, p, threads);
+    r->launch.kernel_version = kv;
+    if (rc) return rc;
+    p.shards = d_shards;
+    const uint32_t grid = pick_grid(r, p, mode, threads);
+    FWGPU_HIP(hipMemsetAsync(b->work, 0, sizeof(uint32_t), stream));
     FWGPU_HIP(launch_example_kernel(p, r->cfg.optimizer, update != 0, grid, threads, stream));
     return FWGPU_OK;
 }
@@ -789,12 +780,6 @@ int fwgpu_debug_set_option(fwgpu_regressor *r, int option, int value) {
     case 4:  // hogwild launches: the constant feature's LR entry is stepped in LDS and reaches the table every `value` examples (0: off)
         if (value < 0 || value > 1024) return fail(FWGPU_ERR_INVALID, "hot LR entry option: 0 .. 1024 examples");
         r->launch.hot_lr_every = (uint32_t)value;
-        return FWGPU_OK;
-    case 8: r->launch.nn_defer_sum = value ? 1 : 0; return FWGPU_OK;    // pending dense gradients summed into one step (1) or stepped one by one (0)
-    case 9: r->launch.nn_plain_reads = value ? 1 : 0; return FWGPU_OK;  // dense weights read through L2 in the forward / input-gradient passes
-    case 7:  // deep head, hogwild launches: examples whose dense steps stay pending per workgroup (0 / 1: step per example)
-        if (value < 0 || value > 8) return fail(FWGPU_ERR_INVALID, "nn_defer option: 0 .. 8 examples");
-        r->launch.nn_defer = value;
         return FWGPU_OK;
     case 2:  // whole-line FFM row updates: 0 off, 1 auto (tables larger than the Infinity Cache; default), 2 always
         if (value < 0 || value > 2) return fail(FWGPU_ERR_INVALID, "window option: 0, 1 or 2");

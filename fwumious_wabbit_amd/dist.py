@@ -119,6 +119,18 @@ class DistGroup:
         check(capi.lib().fwgpu_dist_group_learn_sparse(self.h, C.byref(translator.c), recp, offp, ns.ctypes.data_as(C.c_void_p), outp))
         return [o[:int(n)] for o, n in zip(outs, ns)]
 
+    def learn_peer(self, translator, records_per_rank, rec_off_per_rank, update=True):
+        """one peer-sharded hogwild step: rank j runs the fused kernel on records_per_rank[j] (any number), every row reached in its
+        owner's tables (fwgpu_dist_group_learn_peer) -> its predictions"""
+        rr = [_recs(a, b) for a, b in zip(records_per_rank, rec_off_per_rank)]
+        ns = np.array([len(b) - 1 for _, b in rr], dtype=np.uint32)
+        outs = [np.zeros(max(int(n), 1), dtype=np.float32) for n in ns]
+        recp = (C.c_void_p * self.n)(*[a.ctypes.data for a, _ in rr])
+        offp = (C.c_void_p * self.n)(*[b.ctypes.data for _, b in rr])
+        outp = (C.c_void_p * self.n)(*[o.ctypes.data for o in outs])
+        check(capi.lib().fwgpu_dist_group_learn_peer(self.h, C.byref(translator.c), recp, offp, ns.ctypes.data_as(C.c_void_p), outp, 1 if update else 0))
+        return [o[:int(n)] for o, n in zip(outs, ns)]
+
     def gather_tables(self):
         check(capi.lib().fwgpu_dist_group_gather_tables(self.h))
 

@@ -317,6 +317,16 @@ int fwgpu_dist_sparse_last_rows(const fwgpu_dist *d, uint32_t *ffm_rows, uint32_
 /* in-process group: rank j brings n[j] records */
 int fwgpu_dist_group_learn_sparse(fwgpu_dist_group *g, const fwgpu_translator_config *t, const uint32_t *const *records,
                                   const uint64_t *const *rec_off, const uint32_t *n, float *const *predictions);
+/* Peer-sharded hogwild step (replaces hogwild.rs:24-103's shared table ACROSS GPUs with the reference's own update rule): the tables
+ * are sharded by owner (rank s owns the FFM rows that START in its 1/N of 2^ffm_bits and the LR entries in its 1/N of 2^bits), every
+ * rank runs the fused hogwild kernel on its own n[j] records and reaches each row IN ITS OWNER'S MEMORY -- a plain pointer on the
+ * same device, a peer-mapped pointer over xGMI between the GPUs of one process.  No collective and no barrier between ranks:
+ * per-occurrence AdaGrad steps, staleness = the examples in flight on all GPUs.  1, 2, 4 or 8 ranks; models without a deep head.
+ * fwgpu_dist_group_set_mode(FWGPU_MODE_SEQUENTIAL): rank after rank, in example order -- the sequential reference algorithm over
+ * the ranks' micro-batches in rank order (the deterministic form).  update = 0: predict only.  fwgpu_dist_group_gather_tables
+ * afterwards gives every rank the whole model. */
+int fwgpu_dist_group_learn_peer(fwgpu_dist_group *g, const fwgpu_translator_config *t, const uint32_t *const *records,
+                                const uint64_t *const *rec_off, const uint32_t *n, float *const *predictions, int update);
 
 
 /* ---------------------------------------------------------------- HogwildTrainer replacement

@@ -18,8 +18,8 @@ variants = [
     ("in_flight_256", ["--max-in-flight", "256"], {}),
     ("round1_path", ["--whole-lines", "0"], {}),
     ("round1_path_512", ["--whole-lines", "0", "--max-in-flight", "512"], {}),
-    ("maxr2win", [], {"FWGPU_LIBRARY": os.path.join(ROOT, "build", "variants", "libfwgpu_maxr2win.so")}),
-    ("maxr2win_nochain", [], {"FWGPU_LIBRARY": os.path.join(ROOT, "build", "variants", "libfwgpu_maxr2win.so"), "FWGPU_BENCH_NO_CHAIN": "1"}),
+    # build variants (scripts/build_variant.sh maxrNwin -DFW_MAXR_WIN=N): rows per wave kept from the gather (the shipped build: 2)
+] + [(f"maxr{m}win", [], {"FWGPU_LIBRARY": os.path.join(ROOT, "build", "variants", f"libfwgpu_maxr{m}win.so")}) for m in (0, 1, 2, 3, 4, 6, 8, 10, 12, 16)] + [
     ("whole_lines_2", ["--whole-lines", "2"], {}),
     ("placement_off", [], {"FWGPU_PLACEMENT": "0"}),
     ("no_chain", [], {"FWGPU_BENCH_NO_CHAIN": "1"}),
