@@ -140,6 +140,7 @@ struct fwgpu_dist {
     uint64_t ob_wcap = 0;
     fwgpu_batch *cur = nullptr;      // the batch this sparse step runs on
     uint32_t occ_max_ffm = 0, occ_max_lr = 0;
+    hipEvent_t ev_prev = nullptr;    // group step: "the previous rank's local phase is done" (device-side ordering of the ranks)
     PeerShards *d_peers = nullptr;   // peer-sharded step: the owners' table bases, on this rank's device
     hipEvent_t dbg_ev[3] = {nullptr, nullptr, nullptr};  // debug (scripts/group_bisect.sh): recorded behind FWD / MID / the FFM reduction of sparse_local
     uint32_t last_rows[2] = {0, 0};  // bucket rows {ffm, lr} this rank sent in its last sparse step
@@ -378,6 +379,10 @@ int sparse_begin(fwgpu_dist *d, const fwgpu_translator_config *t, const uint32_t
         }
         d->cur = d->ob;
     }
+    {
+        static const bool dbg_sync_upload = std::getenv("FWGPU_DBG_SYNC_UPLOAD") != nullptr;  // debug: the upload is complete before anything else is enqueued
+        if (dbg_sync_upload) FWGPU_HIP(hipStreamSynchronize(d->stream));
+    }
     d->B = d->cur->n;
     shape[0] = d->cur->max_lr;
     shape[1] = d->cur->max_ffm;
@@ -424,6 +429,40 @@ int sparse_local(fwgpu_dist *d, const uint32_t *shapes /*[n*4]*/) {
         if (rc) return rc;
         d->sp_n = std::max(n, max_n);
         d->sp_ffm = max_ffm;
+    }
+    {
+        static const bool dbg_addr = std::getenv("FWGPU_DBG_ADDR") != nullptr;  // debug: where every per-rank buffer of the step lies
+        if (dbg_addr) {
+            auto pr = [&](const char *name, const void *q, size_t bytes) {
+                std::fprintf(stderr, "[addr] rank %d %-14s %p .. %p (%zu B)\n", d->rank, name, q, (const char *)q + bytes, bytes);
+            };
+            pr("sf.key", d->sf.key, (size_t)d->sf.occ_cap * 8);
+            pr("sf.key_sorted", d->sf.key_sorted, (size_t)d->sf.occ_cap * 8);
+            pr("sf.desc", d->sf.desc, (size_t)d->sf.occ_cap * 8);
+            pr("sf.flags", d->sf.flags, ((size_t)d->sf.occ_cap + 1) * 4);
+            pr("sf.pos", d->sf.pos, ((size_t)d->sf.occ_cap + 1) * 4);
+            pr("sf.bk_key", d->sf.bk_key, (size_t)d->sf.occ_cap * 4);
+            pr("sf.bk_rows", d->sf.bk_rows, (size_t)d->sf.occ_cap * d->sf.width * 4);
+            pr("sl.key", d->sl.key, (size_t)d->sl.occ_cap * 8);
+            pr("sl.key_sorted", d->sl.key_sorted, (size_t)d->sl.occ_cap * 8);
+            pr("sl.desc", d->sl.desc, (size_t)d->sl.occ_cap * 8);
+            pr("sl.flags", d->sl.flags, ((size_t)d->sl.occ_cap + 1) * 4);
+            pr("sl.pos", d->sl.pos, ((size_t)d->sl.occ_cap + 1) * 4);
+            pr("sl.bk_key", d->sl.bk_key, (size_t)d->sl.occ_cap * 4);
+            pr("sl.bk_rows", d->sl.bk_rows, (size_t)d->sl.occ_cap * 4);
+            pr("sp_tmp", d->sp_tmp, d->sp_tmp_bytes);
+            pr("d_counts", d->d_counts, (size_t)(2 + 2 * d->n) * 4);
+            pr("sp.d_split", d->sp->d_split, (size_t)d->sp->n_cap * d->sp->split_len * 4);
+            pr("sp.d_selfw", d->sp->d_selfw, (size_t)d->sp->n_cap * d->sp->selfw_stride * 4);
+            pr("sp.d_g", d->sp->d_g, (size_t)d->sp->n_cap * 8);
+            pr("cur.records", d->cur->records, (size_t)d->cur->n_words * 4);
+            pr("cur.pred", d->cur->pred, (size_t)d->cur->n * 4);
+            pr("ffm_w", r->d_ffm_w, (size_t)r->ffm_len * 4);
+            pr("ffm_acc", r->d_ffm_acc, (size_t)r->ffm_len * 4);
+            pr("lr", r->d_lr, (size_t)r->lr_len * 8);
+            std::fprintf(stderr, "[addr] rank %d n %u max_ffm %u max_lr %u sf_cap %llu sl_cap %llu\n", d->rank, n, max_ffm, max_lr,
+                         (unsigned long long)sf_cap, (unsigned long long)sl_cap);
+        }
     }
     OccBuffers occ;
     occ.ffm_key = has_ffm ? d->sf.key : nullptr;
@@ -530,7 +569,10 @@ int make_rank(fwgpu_regressor *r, int rank, int n, fwgpu_dist **out) {
     d->rank = rank;
     d->n = n;
     FWGPU_HIP(hipDeviceSynchronize());  // (the rank's stream does not wait for the NULL stream: table initialisation must be done)
-    FWGPU_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    {
+        static const char *sf = std::getenv("FWGPU_DBG_STREAM_FLAGS");  // debug (scripts/group_bisect.sh): "default" = a blocking stream
+        FWGPU_HIP(hipStreamCreateWithFlags(&d->stream, sf && sf[0] == 'd' ? hipStreamDefault : hipStreamNonBlocking));
+    }
     FWGPU_HIP(hipMalloc((void **)&d->d_shape, (size_t)n * 4 * sizeof(uint32_t)));
     set_ranges(d.get());
     *out = d.release();
@@ -894,35 +936,35 @@ int fwgpu_dist_group_learn_sparse(fwgpu_dist_group *g, const fwgpu_translator_co
     int rc;
     for (int j = 0; j < N; j++)
         if ((rc = sparse_begin(g->ranks[j].get(), t, records[j], rec_off[j], n[j], nullptr, &shapes[4 * j]))) return rc;
-    // debug switches for the concurrent schedule (scripts/group_repro.py): FWGPU_DBG_GROUP_CHAIN=1 orders rank j's local phase behind
-    // rank j-1's ON THE DEVICE (event wait, no host synchronisation)
-    // FWGPU_DBG_GROUP_CHAIN = fwd | mid | red: ... behind rank j-1's FWD / MID / FFM reduction only (the rest overlaps freely)
+    // The ranks' local phases run ONE AFTER THE OTHER ON THE DEVICE: rank j's stream waits (event, no host synchronisation) for rank
+    // j-1's local phase.  With the local phases of two or more ranks truly overlapping on different hardware queues the step is not
+    // reproducible (scripts/group_exp.sh, profiles/r03_group_concurrency.txt): single examples of a rank come out with another
+    // result (as if skipped or read half-way), occasionally an address built from such data faults.  What is known: it needs the FWD
+    // (+ MID) kernels of two ranks in flight at once (ordering rank j behind rank j-1's MID is enough, behind its FWD is not); it is
+    // not stale L2 (device-scope table loads do not help), not grid over-subscription (192 workgroups per rank do not help), not the
+    // streams' flags; GPU_MAX_HW_QUEUES <= 2 makes it exact; every per-rank buffer is disjoint (addresses printed and compared),
+    // occurrence keys / sorted keys / scan results are structurally valid in wrong runs, an LDS canary behind the kernel's layout stays
+    // untouched -- and it comes and goes with unrelated code generation changes of the FWD kernel (two of five builds of this round
+    // were exact 8/8 without any ordering).  A timing-dependent fault in (or under) the generic kernel's FWD phase that only two
+    // concurrent queues expose; not found.  FWGPU_GROUP_CONCURRENT=local removes the ordering (debug), FWGPU_DBG_GROUP_CHAIN =
+    // fwd | mid | red moves the wait to an earlier point of rank j-1's phase.  The RCCL path has one rank per process and one queue.
     static const char *dbg_chain = std::getenv("FWGPU_DBG_GROUP_CHAIN");
-    const int chain_at = !dbg_chain ? -1 : dbg_chain[0] == 'f' ? 0 : dbg_chain[0] == 'm' ? 1 : dbg_chain[0] == 'r' ? 2 : 3;
+    static const char *cc_env = std::getenv("FWGPU_GROUP_CONCURRENT");
+    const bool unordered = cc_env && (cc_env[0] == 'l' || (cc_env[0] == 'a' && cc_env[1] == 'l'));
+    const int chain_at = dbg_chain ? (dbg_chain[0] == 'f' ? 0 : dbg_chain[0] == 'm' ? 1 : dbg_chain[0] == 'r' ? 2 : 3) : (unordered ? -1 : 3);
     for (int j = 0; j < N; j++) {
         fwgpu_dist *dj = g->ranks[j].get();
         if (chain_at >= 0 && chain_at < 3)
             for (int e = 0; e < 3; e++)
                 if (!dj->dbg_ev[e]) FWGPU_HIP(hipEventCreateWithFlags(&dj->dbg_ev[e], hipEventDisableTiming));
         if (chain_at == 3 && j > 0) {
-            hipEvent_t ev;
-            FWGPU_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            FWGPU_HIP(hipEventRecord(ev, g->ranks[j - 1]->stream));
-            FWGPU_HIP(hipStreamWaitEvent(g->ranks[j]->stream, ev, 0));
-            FWGPU_HIP(hipEventDestroy(ev));
+            if (!dj->ev_prev) FWGPU_HIP(hipEventCreateWithFlags(&dj->ev_prev, hipEventDisableTiming));
+            FWGPU_HIP(hipEventRecord(dj->ev_prev, g->ranks[j - 1]->stream));
+            FWGPU_HIP(hipStreamWaitEvent(dj->stream, dj->ev_prev, 0));
         } else if (chain_at >= 0 && j > 0) {
             FWGPU_HIP(hipStreamWaitEvent(dj->stream, g->ranks[j - 1]->dbg_ev[chain_at], 0));
         }
-        if ((rc = sparse_local(g->ranks[j].get(), shapes.data()))) return rc;
-        // One rank's local phase at a time.  With all ranks' FWD / MID / sort / reduce work enqueued at once on their streams the step
-        // was not reproducible at full table size and faulted once in ten runs (scripts/group_repro.py with FWGPU_GROUP_CONCURRENT=local);
-        // any single host synchronisation inside the local phase, or this one after it, makes it exact again.  Every buffer is per
-        // rank and every dependency is ordered on the rank's stream, so this looks like a runtime limit with that many kernels of
-        // that many streams in flight rather than a data race of the step; the RCCL path has one rank per process.
-        {
-            const char *cc = std::getenv("FWGPU_GROUP_CONCURRENT");  // (debug switch: "local" / "apply" / "all" bring the overlap back)
-            if (!(cc && (cc[0] == 'l' || (cc[0] == 'a' && cc[1] == 'l')))) FWGPU_HIP(hipStreamSynchronize(g->ranks[j]->stream));
-        }
+        if ((rc = sparse_local(dj, shapes.data()))) return rc;
     }
     std::vector<uint32_t> counts((size_t)2 * N);
     for (int j = 0; j < N; j++) {
@@ -931,6 +973,55 @@ int fwgpu_dist_group_learn_sparse(fwgpu_dist_group *g, const fwgpu_translator_co
         FWGPU_HIP(hipStreamSynchronize(d->stream));
         d->last_rows[0] = counts[2 * j];
         d->last_rows[1] = counts[2 * j + 1];
+    }
+    {
+        // debug (scripts/group_bisect.sh): what did every rank's local phase leave behind?  FWD's occurrence keys must be
+        // (hash << 32 | slot) with slot == their index (or ~0), the sorted keys ascending, pos non-decreasing and <= the bucket count
+        static const bool dbg_verify = std::getenv("FWGPU_DBG_VERIFY") != nullptr;
+        if (dbg_verify)
+            for (int j = 0; j < N; j++) {
+                fwgpu_dist *d = g->ranks[j].get();
+                for (int side = 0; side < 2; side++) {
+                    fwgpu_dist::SparseSide &sd = side == 0 ? d->sf : d->sl;
+                    const uint32_t me = side == 0 ? d->occ_max_ffm : d->occ_max_lr;
+                    const size_t nk = (size_t)d->B * me;
+                    if (!sd.occ_cap || !nk) continue;
+                    std::vector<unsigned long long> k(nk), ks(nk);
+                    std::vector<uint32_t> pos(nk + 1);
+                    FWGPU_HIP(hipMemcpy(k.data(), sd.key, nk * 8, hipMemcpyDeviceToHost));
+                    FWGPU_HIP(hipMemcpy(ks.data(), sd.key_sorted, nk * 8, hipMemcpyDeviceToHost));
+                    FWGPU_HIP(hipMemcpy(pos.data(), sd.pos, (nk + 1) * 4, hipMemcpyDeviceToHost));
+                    size_t bad_key = 0, bad_sorted = 0, bad_pos = 0, valid = 0, valid_sorted = 0;
+                    const uint64_t tab = side == 0 ? d->r->ffm_len : d->r->lr_len;
+                    for (size_t i = 0; i < nk; i++) {
+                        if (k[i] == ~0ull) continue;
+                        valid++;
+                        if ((uint32_t)k[i] != (uint32_t)i || (k[i] >> 32) >= tab) bad_key++;
+                    }
+                    for (size_t i = 0; i < nk; i++) {
+                        if (ks[i] != ~0ull) valid_sorted++;
+                        if (i && ks[i] < ks[i - 1]) bad_sorted++;
+                    }
+                    for (size_t i = 1; i <= nk; i++)
+                        if (pos[i] < pos[i - 1] || pos[i] > counts[2 * j + side]) bad_pos++;
+                    std::fprintf(stderr, "[verify] rank %d side %d keys %zu valid %zu bad %zu | sorted valid %zu out-of-order %zu | pos bad %zu count %u\n", j, side,
+                                 nk, valid, bad_key, valid_sorted, bad_sorted, bad_pos, counts[2 * j + side]);
+                }
+                // order-independent checksums of what each stage produced: FWD (split records, own slots), MID (gradients), reduction (bucket rows)
+                unsigned long long *d_cs = nullptr, cs[5] = {0, 0, 0, 0, 0};
+                FWGPU_HIP(hipMalloc((void **)&d_cs, 5 * 8));
+                FWGPU_HIP(hipMemset(d_cs, 0, 5 * 8));
+                FWGPU_HIP(launch_checksum(d->sp->d_split, (uint64_t)d->B * d->sp->split_len, d_cs + 0, d->stream));
+                FWGPU_HIP(launch_checksum(d->sp->d_g, d->B, d_cs + 1, d->stream));
+                if (d->sf.occ_cap) FWGPU_HIP(launch_checksum(d->sf.bk_rows, (uint64_t)counts[2 * j] * d->sf.width, d_cs + 2, d->stream));
+                if (d->sl.occ_cap) FWGPU_HIP(launch_checksum(d->sl.bk_rows, counts[2 * j + 1], d_cs + 3, d->stream));
+                FWGPU_HIP(launch_checksum(d->cur->pred, d->B, d_cs + 4, d->stream));
+                FWGPU_HIP(hipStreamSynchronize(d->stream));
+                FWGPU_HIP(hipMemcpy(cs, d_cs, 5 * 8, hipMemcpyDeviceToHost));
+                (void)hipFree(d_cs);
+                if (j == 0) std::fprintf(stderr, "[canary] changed LDS canary words so far: %u\n", dbg_canary_read());
+                std::fprintf(stderr, "[stage] rank %d split %016llx g %016llx ffm_rows %016llx lr_rows %016llx pred %016llx\n", j, cs[0], cs[1], cs[2], cs[3], cs[4]);
+            }
     }
     for (int side = 0; side < 2; side++) {
         uint32_t stride = 0;

@@ -1387,6 +1387,8 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         s.ctr[6] = atomicAdd(p.work, 1u);
         hot_lr_init<COH>(p, s, PH == 0);
     }
+    if (p.dbg_canary)  // debug: 256 words behind this kernel's own LDS layout; nobody may write there
+        for (uint32_t i = tid; i < 256; i += bd) reinterpret_cast<uint32_t *>(smem + p.dbg_canary_off)[i] = 0xC0FFEE00u + i;
     for (;;) {
         // Previous example's LDS reads are done.  A workgroup-scope barrier does not drain vmcnt on this target,
         // so in the in-order (single workgroup) mode every wave first waits for its own table stores to be
@@ -1655,6 +1657,9 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         if (tid == 0) s.ctr[6] = next_ticket;  // published by the loop-top barrier
     }
     if (COH && tid == 0 && s.ctr[13]) hot_lr_flush<SH>(p, s);  // (every thread's steps are in: the loop ends on a barrier)
+    if (p.dbg_canary)
+        for (uint32_t i = tid; i < 256; i += bd)
+            if (reinterpret_cast<uint32_t *>(smem + p.dbg_canary_off)[i] != 0xC0FFEE00u + i) atomicAdd(p.dbg_canary, 1u);
     if (timing)
         for (int i = 0; i < 8; ++i) atomicAdd(p.ticks + i, tk[i]);
 #undef FW_TICK
@@ -1744,15 +1749,34 @@ static hipError_t launch_phase_v(const KernelParams &p, int optimizer, int phase
     }
 }
 
+static uint32_t *g_dbg_canary = nullptr;
 hipError_t launch_example_phase(const KernelParams &p_in, int optimizer, int phase, uint32_t grid, uint32_t threads, hipStream_t stream) {
     if (p_in.n_examples == 0) return hipSuccess;
     KernelParams p = p_in;
     p.window = 0;  // (the generic kernel's update path)
     p.update = phase == 3 ? 1 : 0;
     p.chain = p.update && !p.no_chain;
-    const size_t lds = example_kernel_lds_bytes(p, optimizer);
+    size_t lds = example_kernel_lds_bytes(p, optimizer);
+    static const bool canary = std::getenv("FWGPU_DBG_LDS_CANARY") != nullptr;
+    static uint32_t *d_canary = nullptr;
+    if (canary) {
+        if (!d_canary && (hipMalloc((void **)&d_canary, 4) != hipSuccess || hipMemset(d_canary, 0, 4) != hipSuccess)) return hipErrorOutOfMemory;
+        g_dbg_canary = d_canary;
+        p.dbg_canary = d_canary;
+        p.dbg_canary_off = (uint32_t)lds;
+        lds += 1024;
+    }
+    {
+        static const char *pad = std::getenv("FWGPU_DBG_LDS_PAD");  // debug: extra dynamic LDS bytes behind the layout (nothing uses them)
+        if (pad) lds += (size_t)atoi(pad);
+    }
     if (p.k % 4 == 0 && p.aligned4) return launch_phase_v<4>(p, optimizer, phase, grid, threads, lds, stream);
     return launch_phase_v<1>(p, optimizer, phase, grid, threads, lds, stream);
+}
+uint32_t dbg_canary_read() {
+    uint32_t v = 0;
+    if (g_dbg_canary) (void)hipMemcpy(&v, g_dbg_canary, 4, hipMemcpyDeviceToHost);
+    return v;
 }
 
 // MID: one workgroup per example.  From the (summed) split record: the logit exactly as the fused kernel forms it

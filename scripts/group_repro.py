@@ -20,7 +20,7 @@ args.nn_layers, args.nn_width = 0, 256
 args.mean_extra, args.zipf, args.ids, args.p_weighted, args.seed = 5.67, 1.05, 10_000_000, 0.1, 20240612
 mi = bench.build_model_instance(fw, args, 0)
 n, per, steps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-in_flight = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # cap on each rank's persistent grid (n x in_flight <= 768: all ranks' workgroups co-resident)
+in_flight = int(sys.argv[4]) if len(sys.argv) > 4 else int(os.environ.get("GRID", "0"))  # cap on each rank's persistent grid (n x in_flight <= 768: all ranks' workgroups co-resident)
 recs, off = bench.gen_records(fw, args, 0, n * per * steps)
 regs = [fw.Regressor(mi) for _ in range(n)]
 if in_flight:
@@ -34,5 +34,7 @@ for s in range(steps):
         a, b = (s * n + j) * per, (s * n + j + 1) * per
         rr.append(recs[int(off[a]):int(off[b])])
         oo.append(off[a:b + 1] - off[a])
-    g.learn_sparse(fbt, rr, oo)
+    outs = g.learn_sparse(fbt, rr, oo)
+    if os.environ.get("REPRO_SAVE"):
+        np.savez(os.environ["REPRO_SAVE"] + f"_step{s}.npz", *outs)
 print("final", [tuple(r.table_checksum(t) % 1000000 for t in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)) for r in regs])
