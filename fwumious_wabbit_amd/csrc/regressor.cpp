@@ -487,10 +487,12 @@ int fwgpu_abi_version(void) { return FWGPU_ABI_VERSION; }
 // out consecutive allocations from one group for several GB, so for tables beyond the Infinity Cache a few candidate allocations
 // are tried and timed against w with that very pattern (a fraction of a millisecond each); the fastest is kept, the rest freed.
 // FWGPU_PLACEMENT=0 switches the search off (the first allocation is used, as for small tables).
-// The search is BOUNDED: at most 64 candidates (24 found no partner on one box in two: -10 % examples/s) and at most a quarter of the free device memory held at once (other regressors,
-// ranks or tenants of the device must not run out of memory because this one is probing), and only two candidates when more
-// than half of the device is already in use by anyone.  FWGPU_PLACEMENT=wide asks for the round-2 scan (up to 112 candidates,
-// half of the free memory) for single-tenant benchmark boxes.
+// The search is BOUNDED by who else is on the device: alone (more than 85 % of the device memory free -- a training box) it may hold
+// up to 112 candidates / half of the free memory for the few milliseconds it takes (a contending stretch of the allocator is up to
+// ~72 table-GB long, profiles/r02_placement.txt; 24 and 64 candidates each left whole boxes on a contending pair this round:
+// -10 % examples/s); with other tenants present at most 16 candidates and a tenth of the free memory, and only two candidates when
+// more than half of the device is in use (other regressors, ranks, serving replicas must not run out of memory because this
+// one is probing).  FWGPU_PLACEMENT=wide forces the wide scan, =0 switches the search off.
 static int place_ffm_acc(fwgpu_regressor *r, size_t fbytes) {
     const char *env = std::getenv("FWGPU_PLACEMENT");
     const bool search = fbytes > (256u << 20) && !(env && env[0] == '0');
@@ -523,8 +525,9 @@ static int place_ffm_acc(fwgpu_regressor *r, size_t fbytes) {
     // still comes from the same stretch.)  A stretch of contending memory is up to ~72 table-GB long (tools/placement scan of
     // 200 x 1 GiB, profiles/r02_placement.txt), a probe costs about a millisecond.
     const bool crowded = total_b && free_b < total_b / 2;  // someone else (another process, other regressors) holds half the device
-    const size_t budget = wide ? std::min<size_t>(free_b / 2, 128ull << 30) : free_b / 4;
-    const size_t cap = wide ? 112 : (crowded ? 2 : 64);
+    const bool alone = total_b && free_b > total_b / 100 * 85;
+    const size_t budget = (wide || alone) ? std::min<size_t>(free_b / 2, 128ull << 30) : free_b / 10;
+    const size_t cap = (wide || alone) ? 112 : (crowded ? 2 : 16);
     const int max_tries = search && single > 0.0f ? (int)std::max<size_t>(2, std::min<size_t>(cap, budget / fbytes)) : 1;
     for (int t = 0; t < max_tries; t++) {
         float *c = nullptr;
