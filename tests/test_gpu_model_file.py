@@ -241,6 +241,24 @@ def test_serving_ffi_matches_the_regressor(tmp_path):
     # (the reference's own *_with_cache tests use assert_epsilon!, 5e-6: block_helpers.rs:30-40)
     assert np.abs(with_cache - whole).max() < 2e-6
     assert np.abs(pr.predict_batch(cands, with_cache=True) - whole).max() < 2e-6
+    # ... and a THIRD party: the CPU oracle's Regressor::predict (regressor.rs:381-395, block_ffm.rs:316-440 numerics) of the whole
+    # line on the same weights -- the cached route, the whole-line route and the batched route against the reference algorithm
+    # itself (assert_epsilon! 5e-6, block_helpers.rs:30-40), not only against each other
+    from oracle import fwo
+    _, ocfg, _ = make_pair(6, 4, 12, 12, fw.Optimizer.AdagradLUT, lr=0.05, ffm_lr=0.05)
+    om = fwo.Model(ocfg)
+    om.lr_table[:] = np.asarray(re.table_read(capi.TABLE_LR))
+    om.ffm_weights[:] = np.asarray(re.table_read(capi.TABLE_FFM_W))[: len(om.ffm_weights)]
+    om.ffm_acc[:] = np.asarray(re.table_read(capi.TABLE_FFM_ACC))[: len(om.ffm_acc)]
+
+    def oracle_predict(line):
+        fb = fbt.translate(parser.next_vowpal(line.encode()))
+        return om.predict(np.asarray(fb.lr_buffer), np.asarray(fb.ffm_buffer))
+
+    oracle = np.array([oracle_predict(ctx + c) for c in cands], dtype=np.float32)
+    assert np.abs(with_cache - oracle).max() < 5e-6 and np.abs(whole - oracle).max() < 5e-6
+    assert np.abs(pr.predict_batch(cands, with_cache=True) - oracle).max() < 5e-6
+    assert np.abs(got - np.array([oracle_predict(l) for l in lines], dtype=np.float32)).max() < 5e-6
     assert np.array_equal(pr.predict_batch(cands, with_cache=True), with_cache)  # batched == single, same route
     # the batched call sends records and lets the kernel's translation skip the cached namespaces; the entry route
     # (host translation + features_present filter, what the single call does) gives the same numbers
