@@ -112,8 +112,13 @@ struct KernelParams {
     uint32_t host_cus, host_wgs_cap, host_grid_cap;    // host side only: persistent grid = occupancy x CUs (capped), when launched with grid 0
     int32_t kernel_version;             // 0 = auto, 1 = force the v1 kernel, 2 = v2 where applicable
     unsigned long long *ticks;          // optional [8] per-phase shader-clock accumulators (debug), else NULL
+#ifndef FW_KP_NO_CANARY                 // (debug builds of scripts/kp_size_exp.sh drop the two fields: sizeof(KernelParams) 744 -> 728)
     uint32_t *dbg_canary;               // debug (FWGPU_DBG_LDS_CANARY): device counter of LDS canary words found changed, else NULL
     uint32_t dbg_canary_off;            // ... byte offset of the 1 KiB canary behind the kernel's own LDS layout
+#endif
+#ifdef FW_KP_PAD                        // debug builds (scripts/kp_size_exp.sh): the struct's size as a variable of the group-concurrency fault
+    unsigned char kp_pad[FW_KP_PAD];
+#endif
     // ---- serving context cache (regressor.rs:397-423, block_ffm.rs:442-782): the context features' field sums, in T's layout
     const float *ctx_T;                 // [F*R] T[z][f][k] partial sums of the cached features (NULL: none); read-only launches only
     const float *ctx_dcf;               // [F]   their self-pair corrections
@@ -164,7 +169,10 @@ hipError_t launch_example_kernel(const KernelParams &p, int optimizer, bool cohe
 // records and the gradients); the MID step (records -> logit -> prediction, general gradient / deep-head input) is its own kernel
 hipError_t launch_example_phase(const KernelParams &p, int optimizer, int phase, uint32_t grid, uint32_t threads, hipStream_t stream);
 hipError_t launch_split_mid(const KernelParams &p, uint32_t n_examples, hipStream_t stream);
-uint32_t dbg_canary_read();  // debug: LDS canary words found changed so far (phase launches under FWGPU_DBG_LDS_CANARY)
+uint32_t dbg_canary_read();
+#ifdef FW_DBG_KERNARG_CHECK
+unsigned dbg_kernarg_changed_read(unsigned *checked);
+#endif  // debug: LDS canary words found changed so far (phase launches under FWGPU_DBG_LDS_CANARY)
 uint32_t split_record_len(uint32_t F, uint32_t R, uint32_t nlr);
 // row-sparse gradient buckets (sparse.hip)
 struct SparseReduceArgs {

@@ -1311,6 +1311,28 @@ uint32_t split_record_len(uint32_t F, uint32_t R, uint32_t nlr) { return split_l
 //   FWD : stage, gather the rows this rank OWNS (all of them on one GPU), write T / dcf / LR sums to the example's split record
 //   (exchange: records summed over the ranks; MID kernel: logit, prediction, general gradient; or the mini-batched deep head)
 //   UPD : stage, T and the entries' own slots back from the records, AdaGrad on the owned rows and LR entries
+#ifdef FW_DBG_KERNARG_CHECK  // debug build (scripts/kp_size_exp.sh): does a running kernel's argument block change under it?
+__device__ unsigned g_dbg_kernarg_changed[4];  // [0] workgroups whose kernarg checksum differed between entry and exit, [1] workgroups checked,
+                                               // [2] workgroups whose arguments, as loaded by the kernel, differ from the argument block in memory
+unsigned dbg_kernarg_changed_read(unsigned *checked) {
+    unsigned v[4] = {0, 0, 0, 0};
+    (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(g_dbg_kernarg_changed), sizeof(v));
+    if (checked) {
+        checked[0] = v[1];
+        checked[1] = v[2];
+    }
+    return v[0];
+}
+__device__ __forceinline__ unsigned dbg_kernarg_sum() {
+    // (read through the flat address of the segment with device-scope loads: not the scalar cache's copy)
+    unsigned long long a = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("; kernarg address laundered" : "+v"(a));  // (the constant address space must not follow the pointer)
+    const unsigned *ka = reinterpret_cast<const unsigned *>(a);
+    unsigned x = 0;
+    for (unsigned i = 0; i < sizeof(KernelParams) / 4; i++) x = x * 31u + __hip_atomic_load(ka + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return x;
+}
+#endif
 template <int VEC, int OPT, bool COH, int PH = 0, bool NN = true, bool SH = false>
 __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) {
     typedef typename Vec<VEC>::type V;
@@ -1387,8 +1409,21 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         s.ctr[6] = atomicAdd(p.work, 1u);
         hot_lr_init<COH>(p, s, PH == 0);
     }
+#ifdef FW_DBG_KERNARG_CHECK
+    unsigned ka_sum0 = 0;
+    if (tid == 0) {
+        ka_sum0 = dbg_kernarg_sum();
+        // the same sum over the arguments AS THE KERNEL SEES THEM (scalar loads from the kernarg segment, through the scalar cache / L2)
+        const unsigned *q = reinterpret_cast<const unsigned *>(&p);
+        unsigned xs = 0;
+        for (unsigned i = 0; i < sizeof(KernelParams) / 4; i++) xs = xs * 31u + q[i];
+        if (xs != ka_sum0) atomicAdd(&g_dbg_kernarg_changed[2], 1u);
+    }
+#endif
+#ifndef FW_KP_NO_CANARY
     if (p.dbg_canary)  // debug: 256 words behind this kernel's own LDS layout; nobody may write there
         for (uint32_t i = tid; i < 256; i += bd) reinterpret_cast<uint32_t *>(smem + p.dbg_canary_off)[i] = 0xC0FFEE00u + i;
+#endif
     for (;;) {
         // Previous example's LDS reads are done.  A workgroup-scope barrier does not drain vmcnt on this target,
         // so in the in-order (single workgroup) mode every wave first waits for its own table stores to be
@@ -1657,9 +1692,17 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         if (tid == 0) s.ctr[6] = next_ticket;  // published by the loop-top barrier
     }
     if (COH && tid == 0 && s.ctr[13]) hot_lr_flush<SH>(p, s);  // (every thread's steps are in: the loop ends on a barrier)
+#ifdef FW_DBG_KERNARG_CHECK
+    if (tid == 0) {
+        atomicAdd(&g_dbg_kernarg_changed[1], 1u);
+        if (dbg_kernarg_sum() != ka_sum0) atomicAdd(&g_dbg_kernarg_changed[0], 1u);
+    }
+#endif
+#ifndef FW_KP_NO_CANARY
     if (p.dbg_canary)
         for (uint32_t i = tid; i < 256; i += bd)
             if (reinterpret_cast<uint32_t *>(smem + p.dbg_canary_off)[i] != 0xC0FFEE00u + i) atomicAdd(p.dbg_canary, 1u);
+#endif
     if (timing)
         for (int i = 0; i < 8; ++i) atomicAdd(p.ticks + i, tk[i]);
 #undef FW_TICK
@@ -1759,6 +1802,7 @@ hipError_t launch_example_phase(const KernelParams &p_in, int optimizer, int pha
     size_t lds = example_kernel_lds_bytes(p, optimizer);
     static const bool canary = std::getenv("FWGPU_DBG_LDS_CANARY") != nullptr;
     static uint32_t *d_canary = nullptr;
+#ifndef FW_KP_NO_CANARY
     if (canary) {
         if (!d_canary && (hipMalloc((void **)&d_canary, 4) != hipSuccess || hipMemset(d_canary, 0, 4) != hipSuccess)) return hipErrorOutOfMemory;
         g_dbg_canary = d_canary;
@@ -1766,6 +1810,10 @@ hipError_t launch_example_phase(const KernelParams &p_in, int optimizer, int pha
         p.dbg_canary_off = (uint32_t)lds;
         lds += 1024;
     }
+#else
+    (void)canary;
+    (void)d_canary;
+#endif
     {
         static const char *pad = std::getenv("FWGPU_DBG_LDS_PAD");  // debug: extra dynamic LDS bytes behind the layout (nothing uses them)
         if (pad) lds += (size_t)atoi(pad);
