@@ -46,6 +46,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
@@ -70,6 +71,7 @@ struct RcclApi {
             SYM(GetUniqueId, "ncclGetUniqueId");
             SYM(CommInitRank, "ncclCommInitRank");
             SYM(CommDestroy, "ncclCommDestroy");
+            SYM(CommAbort, "ncclCommAbort");
             SYM(AllReduce, "ncclAllReduce");
             SYM(AllGather, "ncclAllGather");
             SYM(ReduceScatter, "ncclReduceScatter");
@@ -90,6 +92,12 @@ RcclApi g_rccl;
     } while (0)
 
 }  // namespace
+
+struct fwgpu_dist;
+// A collective step that fails on ONE rank (out of memory, a phase error, an RCCL error) would leave the other ranks waiting in
+// their next collective for good: the failing rank aborts the communicator (ncclCommAbort, where the library has it), which makes
+// the peers' pending and later collectives return an error instead of hanging.  The rank is unusable afterwards.
+static int abort_on_failure(fwgpu_dist *d, int rc);
 
 // One rank of the job.
 struct fwgpu_dist {
@@ -182,6 +190,10 @@ int check_shardable(const fwgpu_dist *d) {
     const fwgpu_regressor *r = d->r;
     if (r->cfg.ffm_k && (((1ull << r->cfg.ffm_bit_precision) / d->n) % 64 != 0 || (1ull << r->cfg.ffm_bit_precision) % d->n != 0))
         return fail(FWGPU_ERR_INVALID, "sharded step: the FFM table does not split into n ranges of whole 256 B blocks");
+    // the LR table is gathered as n equal ranges too (fwgpu_dist_gather_tables): a rank count that does not divide 2^bits would leave
+    // the last rank's tail owned but never gathered
+    if (r->cfg.wiring != FWGPU_WIRING_FFM_ONLY && r->lr_len % (uint64_t)d->n != 0)
+        return fail(FWGPU_ERR_INVALID, "sharded step: the LR table does not split into n equal ranges (n must divide 2^bit_precision)");
     return FWGPU_OK;
 }
 
@@ -610,6 +622,16 @@ int fwgpu_dist_init(fwgpu_regressor *r, const uint8_t *unique_id, int rank, int 
     return FWGPU_OK;
 }
 
+static int abort_on_failure(fwgpu_dist *d, int rc) {
+    if (rc != FWGPU_OK && d && d->comm && d->n > 1 && g_rccl.CommAbort) {
+        const std::string msg = fwgpu_last_error();
+        (void)g_rccl.CommAbort(d->comm);
+        d->comm = nullptr;
+        set_error(msg + " (the communicator was aborted so that the other ranks do not wait; this rank cannot continue)");
+    }
+    return rc;
+}
+
 int fwgpu_dist_free(fwgpu_dist *d) {
     delete d;
     return FWGPU_OK;
@@ -649,7 +671,7 @@ int fwgpu_dist_learn_sharded(fwgpu_dist *d, const fwgpu_translator_config *t, co
     uint32_t shape[4];
     int rc = step_begin(d, t, records, rec_off, n, shape);
     if (rc) return rc;
-    return rccl_step(d, records, rec_off, n, shape, preds, nullptr);
+    return abort_on_failure(d, rccl_step(d, records, rec_off, n, shape, preds, nullptr));
 }
 
 // The same step with the rank's micro-batch already in HBM (a record batch of this regressor); the predictions land in the
@@ -659,7 +681,7 @@ int fwgpu_dist_learn_sharded_batch(fwgpu_dist *d, const fwgpu_translator_config 
     uint32_t shape[4];
     int rc = step_begin_batch(d, t, b, shape);
     if (rc) return rc;
-    return rccl_step(d, nullptr, nullptr, b->n, shape, nullptr, b->pred);
+    return abort_on_failure(d, rccl_step(d, nullptr, nullptr, b->n, shape, nullptr, b->pred));
 }
 
 static int rccl_step(fwgpu_dist *d, const uint32_t *records, const uint64_t *rec_off, uint32_t n, uint32_t shape[4], float *preds,
@@ -698,6 +720,7 @@ static int rccl_step(fwgpu_dist *d, const uint32_t *records, const uint64_t *rec
 // Every rank's owned range into every rank's tables (before saving the model, or before predicting on one GPU).
 int fwgpu_dist_gather_tables(fwgpu_dist *d) {
     if (!d || !d->comm) return fail(FWGPU_ERR_INVALID, "not an RCCL rank (fwgpu_dist_init)");
+    if (int rc0 = check_shardable(d)) return rc0;
     fwgpu_regressor *r = d->r;
     FWGPU_HIP(hipSetDevice(r->device));
     if (r->cfg.ffm_k) {
@@ -798,7 +821,7 @@ int fwgpu_dist_learn_sparse(fwgpu_dist *d, const fwgpu_translator_config *t, con
     uint32_t shape[4];
     int rc = sparse_begin(d, t, records, rec_off, n, nullptr, shape);
     if (rc) return rc;
-    return rccl_sparse_step(d, shape, preds);
+    return abort_on_failure(d, rccl_sparse_step(d, shape, preds));
 }
 
 // what the rank's last sparse step put on the wire: bucket rows of R floats (+ 4-byte key) and LR buckets (key + float)
@@ -815,7 +838,7 @@ int fwgpu_dist_learn_sparse_batch(fwgpu_dist *d, const fwgpu_translator_config *
     uint32_t shape[4];
     int rc = sparse_begin(d, t, nullptr, nullptr, 0, b, shape);
     if (rc) return rc;
-    return rccl_sparse_step(d, shape, nullptr);
+    return abort_on_failure(d, rccl_sparse_step(d, shape, nullptr));
 }
 
 // ------------------------------------------------------------------ in-process group: the same step, collectives by copies

@@ -33,7 +33,7 @@ typedef enum { ncclSum = 0 } ncclRedOp_t;
 namespace {
 constexpr size_t kSlot = 16u << 20;  // bytes per rank and chunk
 struct Header {
-    std::atomic<uint32_t> magic, arrived, generation, attached;
+    std::atomic<uint32_t> magic, arrived, generation, attached, aborted;
     uint32_t nranks;
 };
 }  // namespace
@@ -53,6 +53,7 @@ struct FakeComm {
         }
         const auto t0 = std::chrono::steady_clock::now();
         while (hdr->generation.load(std::memory_order_acquire) == gen) {
+            if (hdr->aborted.load(std::memory_order_acquire)) return false;  // a rank called ncclCommAbort
             std::this_thread::yield();
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) return false;  // a rank died: fail, do not hang the test
         }
@@ -141,6 +142,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
         c->hdr->arrived.store(0);
         c->hdr->generation.store(0);
         c->hdr->attached.store(0);
+        c->hdr->aborted.store(0);
         c->hdr->magic.store(0x46574743u, std::memory_order_release);
     } else {
         for (int i = 0; i < 60000 && c->hdr->magic.load(std::memory_order_acquire) != 0x46574743u; i++)
@@ -160,6 +162,13 @@ ncclResult_t ncclCommDestroy(ncclComm_t c) {
     if (left == 0) shm_unlink(c->name);
     delete c;
     return ncclSuccess;
+}
+
+// a failing rank tears the job down: its peers' pending and later collectives return an error instead of waiting
+ncclResult_t ncclCommAbort(ncclComm_t c) {
+    if (!c) return ncclSuccess;
+    c->hdr->aborted.store(1, std::memory_order_release);
+    return ncclCommDestroy(c);
 }
 
 #define HIPOK(x) do { if ((x) != hipSuccess) return ncclUnhandledCudaError; } while (0)
