@@ -19,8 +19,6 @@ variants = [
     ("round1_path", ["--whole-lines", "0"], {}),
     ("round1_path_512", ["--whole-lines", "0", "--max-in-flight", "512"], {}),
     # build variants (scripts/build_variant.sh maxrNwin -DFW_MAXR_WIN=N): rows per wave kept from the gather (the shipped build: 2)
-    ("lb384m8", ["--threads", "384", "--wgs-per-cu", "3"], {"FWGPU_LIBRARY": os.path.join(ROOT, "build", "variants", "libfwgpu_lb384m8.so")}),
-    ("lb384m12", ["--threads", "384", "--wgs-per-cu", "3"], {"FWGPU_LIBRARY": os.path.join(ROOT, "build", "variants", "libfwgpu_lb384m12.so")}),
 ] + [(f"maxr{m}win", [], {"FWGPU_LIBRARY": os.path.join(ROOT, "build", "variants", f"libfwgpu_maxr{m}win.so")}) for m in (0, 1, 2, 3, 4, 6, 8, 10, 12, 16)] + [
     ("whole_lines_2", ["--whole-lines", "2"], {}),
     ("placement_off", [], {"FWGPU_PLACEMENT": "0"}),
