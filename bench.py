@@ -243,6 +243,9 @@ def main():
     ap.add_argument("--dist-backend", dest="dist_backend", default="nccl",
                     help="torch.distributed backend; 'gloo' + --same-device lets the N>1 path be exercised on a one-GPU box")
     ap.add_argument("--same-device", dest="same_device", action="store_true", help="debug: every rank uses cuda:0")
+    ap.add_argument("--library-comm", dest="library_comm", action="store_true",
+                    help="use the library's own communicator (fwgpu_dist_*) whatever the torch backend: with --dist-backend gloo --same-device and "
+                         "FWGPU_RCCL_LIBRARY=tests/fake_rccl/libfwgpu_fakerccl.so the whole N > 1 flow of this script runs with N processes on ONE GPU")
     ap.add_argument("--force-dist", dest="force_dist", action="store_true",
                     help="run the RCCL replica-sync path even with one rank (smoke test of the N>1 code on one GPU)")
     ap.add_argument("--no-traffic", dest="traffic", action="store_false",
@@ -331,7 +334,7 @@ def main():
     if use_dist:
         from fwumious_wabbit_amd.dist_sync import DeltaAllReduce
 
-        if args.dist_backend == "nccl" and not args.same_device and not args.nn_layers:
+        if ((args.dist_backend == "nccl" and not args.same_device) or args.library_comm) and not args.nn_layers:
             # the library's own RCCL communicator (C ABI): rank 0 draws the id, torch.distributed is only the side channel
             from fwumious_wabbit_amd.dist import DistRank, unique_id
 
@@ -582,7 +585,7 @@ def main():
                 "bound": "hbm",
                 "kernel": ("FWD / MID / " + ("head GEMMs (v_mfma_f32_32x32x2_f32) / " if args.nn_layers else "") + "UPD kernels of the synchronous micro-batch (generic row kernel)"
                            if sync_steps or sharded_main else
-                           "fw_example_kernel_r<AdagradLUT, coherent, MAXR=0, duplicate-row chains> (3 workgroups x 512 threads per CU; whole-line row accesses only when w and acc contend for one memory region)"
+                           "fw_example_kernel_r<AdagradLUT, coherent, MAXR=8, duplicate-row chains> (3 workgroups x 512 threads per CU; 8 rows per wave kept from the gather and written back as w_gather - step; whole-line row accesses only when w and acc contend for one memory region)"
                            if args.k % 4 == 0 and args.fields * args.k <= 256 and not args.nn_layers else
                            "fw_example_kernel_r<AdagradLUT, coherent, MAXR=0, duplicate-row chains, NC=2> (two 16-byte chunks per lane and row; 2 workgroups x 512 threads per CU)"
                            if args.k % 4 == 0 and args.fields * args.k <= 512 and 256 % args.k == 0 and not args.nn_layers else
