@@ -1913,8 +1913,12 @@ hipError_t launch_split_mid(const KernelParams &p, uint32_t n, hipStream_t strea
 //     rest four at a time; field sums are accumulated in buffer order (bit-identical to the reference);
 //   * rows beyond MAXR, and rows that overlap an earlier row of the same example (rare), are re-read in the update
 //     (update_rows, UO rows in flight).
-// MAXR = 12 (128 VGPRs, two workgroups per CU) keeps half of the rows resident; the shipped MAXR = 2 (<= 85 VGPRs, three
-// workgroups per CU) re-reads almost every row and is faster: occupancy beats residency.
+// MAXR = 12 at 128 VGPRs (two workgroups per CU) keeps half of the rows resident and is slower than three workgroups per CU at 80
+// VGPRs: occupancy beats residency for SPEED.  Round 3: the kept rows decide the QUALITY of the concurrent mode -- a
+// kept row is written back as w_gather - step, which overwrites what other examples did to it during this example's lifetime, and
+// the hold-out loss falls monotonically with MAXR at equal examples/s (0.662 / 0.656 / 0.648 / 0.644 / 0.639 for 0 / 2 / 4 / 6 / 8
+// kept rows per wave, profiles/r03_pareto.txt).  The window path (tables beyond the Infinity Cache: config C) ships FW_MAXR_WIN = 8
+// (80 VGPRs, 30 of them spilled: part of the kept rows live in scratch); the small-table path keeps FW_MAXR = 2.
 // Only for 16 B-aligned single-chunk rows (k % 4 == 0, R <= 256 floats): BASELINE configs B and C.
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #pragma unroll
