@@ -1088,10 +1088,10 @@ int fwgpu_dist_group_learn_sparse(fwgpu_dist_group *g, const fwgpu_translator_co
     }
 #ifdef FW_DBG_KERNARG_CHECK
     {
-        unsigned checked[2] = {0, 0};
+        unsigned checked[3] = {0, 0, 0};
         const unsigned changed = dbg_kernarg_changed_read(checked);
-        std::fprintf(stderr, "[kernarg] of %u workgroups checked so far: argument block changed in memory while they ran: %u; arguments as LOADED BY THE KERNEL differ from the block in memory: %u\n",
-                     checked[0], changed, checked[1]);
+        std::fprintf(stderr, "[kernarg] of %u workgroups checked so far: argument block changed in memory while they ran: %u; arguments as LOADED BY THE KERNEL differ from the block in memory: %u (FWD), %u (MID workgroups)\n",
+                     checked[0], changed, checked[1], checked[2]);
     }
 #endif
     return FWGPU_OK;

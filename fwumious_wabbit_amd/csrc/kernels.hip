@@ -1313,13 +1313,14 @@ uint32_t split_record_len(uint32_t F, uint32_t R, uint32_t nlr) { return split_l
 //   UPD : stage, T and the entries' own slots back from the records, AdaGrad on the owned rows and LR entries
 #ifdef FW_DBG_KERNARG_CHECK  // debug build (scripts/kp_size_exp.sh): does a running kernel's argument block change under it?
 __device__ unsigned g_dbg_kernarg_changed[4];  // [0] workgroups whose kernarg checksum differed between entry and exit, [1] workgroups checked,
-                                               // [2] workgroups whose arguments, as loaded by the kernel, differ from the argument block in memory
+                                               // [2] workgroups whose arguments, as loaded by the kernel, differ from the argument block in memory; [3] the same for the MID kernel
 unsigned dbg_kernarg_changed_read(unsigned *checked) {
     unsigned v[4] = {0, 0, 0, 0};
     (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(g_dbg_kernarg_changed), sizeof(v));
     if (checked) {
         checked[0] = v[1];
         checked[1] = v[2];
+        checked[2] = v[3];
     }
     return v[0];
 }
@@ -1831,9 +1832,22 @@ uint32_t dbg_canary_read() {
 // (LR sum + 0.5 * (sum_e T[e] * T[perm(e)] - sum_f dcf[f])), sigmoid / log-loss (block_loss_functions.rs:105-153) -> prediction and
 // general gradient; or, with a mini-batched deep head, the head's input x = [LR combo sums, triangle of the pair outputs]
 // (block_misc.rs:864-883; a field holding at most one feature has a diagonal of exactly 0, as in the reference's own form).
+#ifdef FW_DBG_MID_PAD  // debug build: two more by-value words lift this kernel's argument segment over the size class of the fault
+__global__ void __launch_bounds__(256) split_mid_kernel(const KernelParams p, uint32_t n, unsigned long long pad0, unsigned long long pad1) {
+#else
 __global__ void __launch_bounds__(256) split_mid_kernel(const KernelParams p, uint32_t n) {
+#endif
     __shared__ float red[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef FW_DBG_KERNARG_CHECK
+    if (tid == 0) {  // this kernel's arguments as it loads them against the argument block in memory
+        const unsigned mem = dbg_kernarg_sum();
+        const unsigned *q = reinterpret_cast<const unsigned *>(&p);
+        unsigned xs = 0;
+        for (unsigned i = 0; i < sizeof(KernelParams) / 4; i++) xs = xs * 31u + q[i];
+        if (xs != mem) atomicAdd(&g_dbg_kernarg_changed[3], 1u);
+    }
+#endif
     const uint32_t F = p.F, k = p.k, R = p.R, C = p.split_nlr;
     for (uint32_t ex = blockIdx.x; ex < n; ex += gridDim.x) {
         const float *rec = p.split + (size_t)ex * p.split_len;
@@ -1897,7 +1911,11 @@ __global__ void __launch_bounds__(256) split_mid_kernel(const KernelParams p, ui
 
 hipError_t launch_split_mid(const KernelParams &p, uint32_t n, hipStream_t stream) {
     if (!n) return hipSuccess;
+#ifdef FW_DBG_MID_PAD
+    hipLaunchKernelGGL(split_mid_kernel, dim3(n < 4096 ? n : 4096), dim3(256), 0, stream, p, n, 0ull, 0ull);
+#else
     hipLaunchKernelGGL(split_mid_kernel, dim3(n < 4096 ? n : 4096), dim3(256), 0, stream, p, n);
+#endif
     return hipGetLastError();
 }
 
