@@ -384,3 +384,35 @@ def test_peer_sharded_hogwild_reaches_the_sequential_oracles_holdout_loss(n_rank
         r.close()
     print(f"peer-sharded hogwild, {n_ranks} ranks: hold-out {gpu_hold:.4f}, sequential oracle {ref_hold:.4f}")
     assert gpu_hold < 0.6931 and abs(gpu_hold - ref_hold) < 0.02, (gpu_hold, ref_hold)
+
+
+def test_group_sparse_step_is_reproducible_at_scale():
+    """Regression test of the in-process group's schedule ("the concurrency fault"): the ranks' local phases are ordered
+    ON THE DEVICE by events, no host synchronisation between them; at a size where unordered ranks were seen to go wrong (2048
+    examples per rank, ~200 features each, 24-bit tables: thousands of workgroups per phase) three fresh 4-rank jobs must end with the
+    SAME BITS, replicas identical.  (A job with another partition of the same global batches sums the buckets in another order: equal to
+    f32 rounding only, which the oracle comparisons above cover.)"""
+    n_ns, k = 30, 8
+    mi, ocfg, ots = make_pair(n_ns, k, 24, 24, fw.Optimizer.AdagradLUT, lr=0.025, ffm_lr=0.025, power_t=0.38, ffm_power_t=0.38)
+    steps, per = 3, 2048
+    recs, off = fw.synth_records(n_ns, 5.67, 1.05, 1000000, 0.1, 97, 0, steps * 4 * per)
+    sums = []
+    for n_ranks in (4, 4, 4):
+        regs = [fw.Regressor(mi) for _ in range(n_ranks)]
+        fbt = fw.FeatureBufferTranslator(mi)
+        g = DistGroup(regs)
+        for s in range(steps):
+            rr, oo = [], []
+            for j in range(n_ranks):
+                a = (s * 4 + j * (4 // n_ranks)) * per
+                b = a + (4 // n_ranks) * per
+                rr.append(recs[int(off[a]):int(off[b])])
+                oo.append(off[a:b + 1] - off[a])
+            g.learn_sparse(fbt, rr, oo)
+        cs = [tuple(r.table_checksum(t) for t in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)) for r in regs]
+        assert all(c == cs[0] for c in cs), cs  # replicas bit-identical
+        sums.append(cs[0])
+        g.close()
+        for r in regs:
+            r.close()
+    assert sums[0] == sums[1] == sums[2], sums
