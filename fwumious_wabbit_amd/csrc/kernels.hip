@@ -1931,12 +1931,14 @@ hipError_t launch_split_mid(const KernelParams &p, uint32_t n, hipStream_t strea
 //     rest four at a time; field sums are accumulated in buffer order (bit-identical to the reference);
 //   * rows beyond MAXR, and rows that overlap an earlier row of the same example (rare), are re-read in the update
 //     (update_rows, UO rows in flight).
-// MAXR = 12 at 128 VGPRs (two workgroups per CU) keeps half of the rows resident and is slower than three workgroups per CU at 80
-// VGPRs: occupancy beats residency for SPEED.  Round 3: the kept rows decide the QUALITY of the concurrent mode -- a
-// kept row is written back as w_gather - step, which overwrites what other examples did to it during this example's lifetime, and
-// the hold-out loss falls monotonically with MAXR at equal examples/s (0.662 / 0.656 / 0.648 / 0.644 / 0.639 for 0 / 2 / 4 / 6 / 8
-// kept rows per wave, profiles/r03_pareto.txt).  The window path (tables beyond the Infinity Cache: config C) ships FW_MAXR_WIN = 8
-// (80 VGPRs, 30 of them spilled: part of the kept rows live in scratch); the small-table path keeps FW_MAXR = 2.
+// Rounds 1-2: three workgroups per CU at 80 VGPRs with 0-2 kept rows beat two workgroups at 128 VGPRs with 12: occupancy beat residency
+// for SPEED.  Round 3: the kept rows decide the QUALITY of the concurrent mode -- a kept row is written back as w_gather - step, which
+// overwrites what other examples did to it during this example's lifetime -- and the hold-out loss falls monotonically with MAXR at
+// equal examples/s (0.662 / 0.656 / 0.648 / 0.644 / 0.639 for 0 / 2 / 4 / 6 / 8 kept rows per wave at three workgroups per CU, where the
+// registers end at 8: profiles/r03_pareto.txt).  With duplicate-row chains, the placed accumulator table and kept rows that skip the
+// re-read of w, TWO workgroups per CU at 128 VGPRs (FW_LB_WAVES_WIN = 4) with FW_MAXR_WIN = 14 kept rows and no spill are now both faster
+// and better: 4.79 M examples/s at 0.6355 against 4.71 M at 0.641 (8 kept rows, three workgroups).  The small-table path keeps FW_MAXR = 2
+// at six waves per SIMD.
 // Only for 16 B-aligned single-chunk rows (k % 4 == 0, R <= 256 floats): BASELINE configs B and C.
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #pragma unroll
@@ -1978,7 +1980,10 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // NC = 16-byte chunks per lane and row: 1 for rows of up to 256 floats (config C: 240), 2 for rows of up to 512 floats (k = 16 with 30
 // fields: 480).  Two-chunk rows keep T alone at 57.6 KB of LDS, so two workgroups share a CU and the register budget is 128 VGPRs.
 template <int OPT, bool COH, int MAXR, bool WIN, int NC = 1>
-__global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? FW_LB_WAVES : 4) fw_example_kernel_r(const KernelParams p) {
+#ifndef FW_LB_WAVES_WIN  // the window path (config C's updating launches): FOUR waves per SIMD = two workgroups per CU, 128 registers -- room for
+#define FW_LB_WAVES_WIN 4  // 14 kept rows per wave without a spill; faster AND better than three workgroups with 8 kept rows
+#endif
+__global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WIN : FW_LB_WAVES) : 4) fw_example_kernel_r(const KernelParams p) {
     static_assert(NC == 1 || MAXR == 0, "resident rows are a single-chunk feature");
     typedef f4 V;
     constexpr int VEC = 4;
@@ -2350,7 +2355,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? FW_LB_WAVES : 4) fw_e
 #define FW_MAXR 2
 #endif
 #ifndef FW_MAXR_WIN
-#define FW_MAXR_WIN 8
+#define FW_MAXR_WIN 14
 #endif
 template <int OPT, bool COH>
 static hipError_t launch_r(const KernelParams &p, uint32_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
