@@ -20,11 +20,11 @@ pytestmark = [pytest.mark.gpu, pytest.mark.statistical]
 
 # 12-40k-example streams, loss still falling fast: the whole learnable gap of these streams is 0.04-0.09.  Spread of
 # |gpu hogwild - sequential oracle| on the round-3 build (scripts/holdout_spread.py, 8 runs per scenario and hot-LR route):
-# profiles/r03b_holdout_spread.txt -- hogwild_24k <= 0.0117, config_b <= 0.0097, two_chunk <= 0.0145, trainer <= 0.0083.
+# profiles/r03d_holdout_spread.txt -- hogwild_24k <= 0.0117, config_b <= 0.0097, two_chunk <= 0.0145, trainer <= 0.0083.
 HOLDOUT_TOL = 0.02
 # The two 2048-example-launch scenarios train on only 16 k examples in eight launches: the first launches run on fresh accumulators
 # with 768 examples (fused) or the whole 2048-example batch (synchronous) in flight, and their gap to the sequential result is the
-# widest of all: 0.0116 .. 0.0195 over 46 runs of the final builds (profiles/r03b_holdout_spread.txt and its two predecessors in
+# widest of all: 0.0116 .. 0.0195 over 46 runs of the final builds (profiles/r03d_holdout_spread.txt and its two predecessors in
 # gpurun history).  GPUTEST_r02's regression read 0.049 on the same scenario.
 SCENARIO_TOL = {"short_fused": 0.03, "short_sync": 0.03}
 
