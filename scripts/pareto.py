@@ -19,6 +19,7 @@ variants = [
     ("round1_path", ["--whole-lines", "0"], {}),
     ("round1_path_512", ["--whole-lines", "0", "--max-in-flight", "512"], {}),
     # build variants (scripts/build_variant.sh maxrNwin -DFW_MAXR_WIN=N): rows per wave kept from the gather (the shipped build: 2)
+    ("t1024m14", ["--threads", "1024", "--wgs-per-cu", "1"], {"FWGPU_LIBRARY": os.path.join(ROOT, "build", "variants", "libfwgpu_t1024m14.so")}),
     ("t640m10", ["--threads", "640", "--wgs-per-cu", "2"], {"FWGPU_LIBRARY": os.path.join(ROOT, "build", "variants", "libfwgpu_t640m10.so")}),
 ] + [(f"w4m{m}", [], {"FWGPU_LIBRARY": os.path.join(ROOT, "build", "variants", f"libfwgpu_w4m{m}.so")}) for m in (12, 14, 16, 20, 24)] + [(v, [], {"FWGPU_LIBRARY": os.path.join(ROOT, "build", "variants", f"libfwgpu_{v}.so")}) for v in ("w4m12uo2", "w4m12uo2ua4", "w4m12ug8", "w4m16uo2")] + [(f"maxr{m}win", [], {"FWGPU_LIBRARY": os.path.join(ROOT, "build", "variants", f"libfwgpu_maxr{m}win.so")}) for m in (0, 1, 2, 3, 4, 6, 8, 10, 12, 16)] + [
     ("whole_lines_2", ["--whole-lines", "2"], {}),
