@@ -38,6 +38,7 @@ typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 // aux (cache policy) bits of the raw buffer builtins on gfx940+: bit0 sc0, bit1 nt, bit4 sc1.
 constexpr int kAuxPlain = 0;
 constexpr int kAuxSc1 = 16;
+constexpr int kAuxSys = 17;  // sc0 sc1: system scope -- rows in a PEER GPU's memory (peer-sharded tables over xGMI)
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, uint32_t bytes) {
     // raw buffer (stride 0), num_records in bytes; out-of-range lanes load 0 and their stores are dropped.
@@ -91,21 +92,25 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-template <bool COH>
+template <bool COH, bool SYS = false>
 __device__ __forceinline__ float2 lr_load(const float *lr, uint32_t h) {
     const unsigned long long *p = reinterpret_cast<const unsigned long long *>(lr) + h;
     unsigned long long v;
-    if (COH)
+    if (COH && SYS)
+        v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else if (COH)
         v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else
         v = *p;
     return float2{__uint_as_float((uint32_t)v), __uint_as_float((uint32_t)(v >> 32))};
 }
-template <bool COH>
+template <bool COH, bool SYS = false>
 __device__ __forceinline__ void lr_store(float *lr, uint32_t h, float2 wa) {
     unsigned long long *p = reinterpret_cast<unsigned long long *>(lr) + h;
     unsigned long long v = (unsigned long long)__float_as_uint(wa.x) | ((unsigned long long)__float_as_uint(wa.y) << 32);
-    if (COH)
+    if (COH && SYS)
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else if (COH)
         __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else
         *p = v;
@@ -255,13 +260,13 @@ __device__ __forceinline__ void hot_lr_flush(const KernelParams &p, const Lds &s
     const float dw = atomicExch(hot + 1, 0.0f);
     s.ctr[7] = 0;
     if (dw == 0.0f) return;
-    __hip_atomic_fetch_add(lr_base<SH>(p, s.ctr[12]) + 2 * (size_t)s.ctr[12], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(lr_base<SH>(p, s.ctr[12]) + 2 * (size_t)s.ctr[12], dw, __ATOMIC_RELAXED, SH ? __HIP_MEMORY_SCOPE_SYSTEM : __HIP_MEMORY_SCOPE_AGENT);
 }
 // The weight of LR entry `h` as the forward pass sees it (block_lr.rs:36-45); for the hot entry: + this workgroup's pending
 // delta, and the accumulator that came with it is kept for the update phase.
 template <bool COH, bool SH = false>
 __device__ __forceinline__ float lr_forward_weight(const KernelParams &p, const Lds &s, uint32_t h) {
-    const float2 wa = lr_load<COH>(lr_base<SH>(p, h), h);
+    const float2 wa = lr_load<COH, SH>(lr_base<SH>(p, h), h);
     if (COH && hot_lr_is(s, h)) {
         float *hot = hot_lr_state(s);
         hot[0] = wa.y;
@@ -1060,9 +1065,9 @@ __device__ __forceinline__ void lr_update(const KernelParams &p, const Lds &s, u
             const float grad = (gx ? gx[s.l_combo[t]] : g) * s.l_val[t];
             float acc = hot[0];
             const float upd = opt_step<OPT>(grad, acc, p.lr_rate, p.lr_minus_power_t, lut_lr);  // (acc += g^2 first: optimizer.rs:76-77, 147-149)
-            if (OPT != FWGPU_OPT_SGD) __hip_atomic_fetch_add(entry + 1, grad * grad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (OPT != FWGPU_OPT_SGD) __hip_atomic_fetch_add(entry + 1, grad * grad, __ATOMIC_RELAXED, SH ? __HIP_MEMORY_SCOPE_SYSTEM : __HIP_MEMORY_SCOPE_AGENT);
             if (s.ctr[13] == 1) {
-                __hip_atomic_fetch_add(entry, -upd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(entry, -upd, __ATOMIC_RELAXED, SH ? __HIP_MEMORY_SCOPE_SYSTEM : __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 atomicAdd(hot + 1, -upd);
                 if (!(fl & kRowChained)) {  // (one entry of that hash per example is not chained)
@@ -1075,7 +1080,7 @@ __device__ __forceinline__ void lr_update(const KernelParams &p, const Lds &s, u
         }
         if (fl & kRowChained) continue;
         if (h < lo || h >= hi) continue;  // sharded tables: another rank's entry
-        float2 wa = lr_load<COH>(lr_base<SH>(p, h), h);
+        float2 wa = lr_load<COH, SH>(lr_base<SH>(p, h), h);
         {
             const float grad = (gx ? gx[s.l_combo[t]] : g) * s.l_val[t];
             wa.x -= opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, lut_lr);
@@ -1086,7 +1091,7 @@ __device__ __forceinline__ void lr_update(const KernelParams &p, const Lds &s, u
                     const float grad = (gx ? gx[s.l_combo[j]] : g) * s.l_val[j];
                     wa.x -= opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, lut_lr);
                 }
-        lr_store<COH>(lr_base<SH>(p, h), h, wa);
+        lr_store<COH, SH>(lr_base<SH>(p, h), h, wa);
     }
 }
 
@@ -1337,7 +1342,8 @@ __device__ __forceinline__ unsigned dbg_kernarg_sum() {
 template <int VEC, int OPT, bool COH, int PH = 0, bool NN = true, bool SH = false>
 __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) {
     typedef typename Vec<VEC>::type V;
-    constexpr int AUX = COH ? kAuxSc1 : kAuxPlain;
+    // (peer-sharded tables: a row may live in another GPU's memory -- system-scope accesses there, device scope otherwise)
+    constexpr int AUX = COH ? (SH ? kAuxSys : kAuxSc1) : kAuxPlain;
 #ifndef FW_V1_UG
 #define FW_V1_UG 8
 #endif
