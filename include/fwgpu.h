@@ -397,9 +397,13 @@ int fwgpu_debug_set_kernel_version(fwgpu_regressor *r, int version);
  *   chained path (repeated rows applied by their first occurrence's wave, from registers), with whole-128-byte-line accesses only
  *   when the accumulator table could not be placed away from the weight table; 2 = chained path with whole-line accesses, always.
  * option 3: value 1 = no duplicate-row chains (A/B runs).
- * option 4: HOGWILD launches step the constant feature's LR entry (in every example, feature_buffer.rs:270-276) in LDS and add
- *   the pending deltas to the table every `value` examples of a workgroup with float atomics (default 32; 0 = plain per-example
- *   read-modify-writes, which serialise on that one entry and overwrite each other).  SEQUENTIAL launches never use it. */
+ * option 4: HOGWILD launches step the constant feature's LR entry (in every example, feature_buffer.rs:270-276) with atomics: the
+ *   step is taken at the accumulator the example's forward pass read + its own g^2, `acc += g^2` and `w -= step` are added to the
+ *   table by float atomics.  value 1 (default): both per example; value n > 1: a workgroup's WEIGHT deltas stay pending in LDS for
+ *   n of its examples; 0 = plain per-example read-modify-writes, which serialise on that one entry and overwrite each other.
+ *   SEQUENTIAL launches never use it.
+ * (The update path of option 2 = 1 / 2 keeps the first 14 rows of every wave's share of an example from the gather and writes
+ *   them back as w_gather - step in HOGWILD launches: what the concurrent mode's hold-out loss rests on) */
 int fwgpu_debug_set_option(fwgpu_regressor *r, int option, int value);
 /* an f32 as serde_json / ryu prints it in the embedded JSON documents ("0.1", "1.0", "1e-7"); NUL-terminated */
 int fwgpu_debug_format_f32(float v, char *buf, uint32_t cap);
