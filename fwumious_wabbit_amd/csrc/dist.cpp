@@ -150,6 +150,8 @@ struct fwgpu_dist {
     uint32_t occ_max_ffm = 0, occ_max_lr = 0;
     hipEvent_t ev_prev = nullptr;    // group step: "the previous rank's local phase is done" (device-side ordering of the ranks)
     PeerShards *d_peers = nullptr;   // peer-sharded step: the owners' table bases, on this rank's device
+    bool peers_attached = false;     // process-per-rank peer mode: the other ranks' tables are mapped (hipIpcOpenMemHandle)
+    std::vector<void *> ipc_open;    // ... what to close again
     hipEvent_t dbg_ev[3] = {nullptr, nullptr, nullptr};  // debug (scripts/group_bisect.sh): recorded behind FWD / MID / the FFM reduction of sparse_local
     uint32_t last_rows[2] = {0, 0};  // bucket rows {ffm, lr} this rank sent in its last sparse step
     ~fwgpu_dist() {
@@ -161,6 +163,7 @@ struct fwgpu_dist {
         if (gb) fwgpu_batch_free(gb);
         if (sp) fwgpu_split_free(sp);
         if (d_own) (void)hipFree(d_own);
+        for (void *q : ipc_open) (void)hipIpcCloseMemHandle(q);
         if (d_peers) (void)hipFree(d_peers);
         if (d_shape) (void)hipFree(d_shape);
         if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
@@ -595,6 +598,8 @@ int make_rank(fwgpu_regressor *r, int rank, int n, fwgpu_dist **out) {
 
 extern "C" {
 
+int fwgpu_dist_barrier(fwgpu_dist *d);
+
 // ------------------------------------------------------------------ RCCL: one rank per process
 int fwgpu_dist_unique_id(uint8_t *id, uint64_t cap) {
     if (!id || cap < sizeof(ncclUniqueId)) return fail(FWGPU_ERR_INVALID, "unique id buffer must hold 128 bytes");
@@ -721,6 +726,8 @@ static int rccl_step(fwgpu_dist *d, const uint32_t *records, const uint64_t *rec
 int fwgpu_dist_gather_tables(fwgpu_dist *d) {
     if (!d || !d->comm) return fail(FWGPU_ERR_INVALID, "not an RCCL rank (fwgpu_dist_init)");
     if (int rc0 = check_shardable(d)) return rc0;
+    if (d->peers_attached)  // peer-sharded ranks run at their own pace and write into each other's tables: everybody is done first
+        if (int rcb = fwgpu_dist_barrier(d)) return rcb;
     fwgpu_regressor *r = d->r;
     FWGPU_HIP(hipSetDevice(r->device));
     if (r->cfg.ffm_k) {
@@ -745,6 +752,102 @@ int fwgpu_dist_gather_tables(fwgpu_dist *d) {
     }
     const uint64_t lper = r->lr_len / d->n;  // entries of 2 floats ({w, acc}; SGD keeps the same stride on the device)
     FWGPU_NCCL(g_rccl.AllGather(r->d_lr + 2 * lper * d->rank, r->d_lr, 2 * lper, ncclFloat, d->comm, d->stream));
+    FWGPU_HIP(hipStreamSynchronize(d->stream));
+    return FWGPU_OK;
+}
+
+// ------------------------------------------------------------------ peer-sharded hogwild, one PROCESS per rank
+// The process-per-rank form of fwgpu_dist_group_learn_peer: every rank exports IPC handles of its three tables
+// (hipIpcGetMemHandle), the handles travel through the job's own all-gather, every rank maps the other ranks' tables
+// (hipIpcOpenMemHandle: the owner's memory over xGMI, or the same device's memory when several ranks share a GPU) and from then on
+// runs the fused hogwild kernel on its own micro-batches with every row reached in its owner's allocation.  No collective per step.
+// fwgpu_dist_barrier orders the ranks where the caller needs it (before fwgpu_dist_gather_tables, before a hold-out pass; the tests
+// use it to run rank after rank = the sequential reference).
+int fwgpu_dist_barrier(fwgpu_dist *d) {
+    if (!d || !d->comm) return fail(FWGPU_ERR_INVALID, "not an RCCL rank (fwgpu_dist_init)");
+    FWGPU_HIP(hipSetDevice(d->r->device));
+    FWGPU_HIP(hipStreamSynchronize(d->stream));  // this rank's launches are done ...
+    FWGPU_HIP(hipMemsetAsync(d->d_shape, 0, 4, d->stream));
+    FWGPU_NCCL(g_rccl.AllReduce(d->d_shape, d->d_shape, 1, ncclFloat, ncclSum, d->comm, d->stream));
+    FWGPU_HIP(hipStreamSynchronize(d->stream));  // ... and so are everybody else's
+    return FWGPU_OK;
+}
+
+int fwgpu_dist_peer_attach(fwgpu_dist *d) {
+    if (!d || !d->comm) return fail(FWGPU_ERR_INVALID, "not an RCCL rank (fwgpu_dist_init)");
+    if (d->peers_attached) return FWGPU_OK;
+    fwgpu_regressor *r = d->r;
+    const int N = d->n;
+    if (N > 8 || (N & (N - 1))) return fail(FWGPU_ERR_INVALID, "peer-sharded step: 1, 2, 4 or 8 ranks");
+    if (r->nn.n_layers) return fail(FWGPU_ERR_INVALID, "peer-sharded step: models with a deep head are not covered");
+    int lg = 0;
+    while ((1 << lg) < N) lg++;
+    if ((r->cfg.ffm_k && (int)r->cfg.ffm_bit_precision < lg) || (int)r->cfg.bit_precision < lg)
+        return fail(FWGPU_ERR_INVALID, "peer-sharded step: fewer table entries than ranks");
+    FWGPU_HIP(hipSetDevice(r->device));
+    struct Handles {
+        hipIpcMemHandle_t w, acc, lr;
+        uint32_t has_ffm, pad[3];
+    };
+    static_assert(sizeof(Handles) % 4 == 0, "all-gathered as 32-bit words");
+    Handles mine{};
+    mine.has_ffm = r->cfg.ffm_k ? 1u : 0u;
+    if (r->cfg.ffm_k) {
+        FWGPU_HIP(hipIpcGetMemHandle(&mine.w, r->d_ffm_w));
+        FWGPU_HIP(hipIpcGetMemHandle(&mine.acc, r->d_ffm_acc));
+    }
+    FWGPU_HIP(hipIpcGetMemHandle(&mine.lr, r->d_lr));
+    Handles *d_all = nullptr;
+    FWGPU_HIP(hipMalloc((void **)&d_all, sizeof(Handles) * (size_t)N));
+    FWGPU_HIP(hipMemcpyAsync(d_all + d->rank, &mine, sizeof(Handles), hipMemcpyHostToDevice, d->stream));
+    FWGPU_HIP(hipStreamSynchronize(d->stream));
+    ncclResult_t e = N > 1 ? g_rccl.AllGather(d_all + d->rank, d_all, sizeof(Handles) / 4, ncclUint32, d->comm, d->stream) : ncclSuccess;
+    std::vector<Handles> all((size_t)N);
+    hipError_t he = hipStreamSynchronize(d->stream);
+    if (he == hipSuccess) he = hipMemcpy(all.data(), d_all, sizeof(Handles) * (size_t)N, hipMemcpyDeviceToHost);
+    (void)hipFree(d_all);
+    if (e != ncclSuccess) return fail(FWGPU_ERR_DEVICE, "peer attach: all-gather of the IPC handles failed");
+    if (he != hipSuccess) return fail(FWGPU_ERR_DEVICE, std::string("peer attach: ") + hipGetErrorString(he));
+    PeerShards ps{};
+    ps.n = (uint32_t)N;
+    ps.shift_ffm = r->cfg.ffm_k ? r->cfg.ffm_bit_precision - lg : 31;
+    ps.shift_lr = r->cfg.bit_precision - lg;
+    for (int j = 0; j < N; j++) {
+        if (j == d->rank) {
+            ps.ffm_w[j] = r->d_ffm_w;
+            ps.ffm_acc[j] = r->d_ffm_acc;
+            ps.lr[j] = r->d_lr;
+            continue;
+        }
+        auto open = [&](const hipIpcMemHandle_t &h, float **out) -> int {
+            void *q = nullptr;
+            FWGPU_HIP(hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess));
+            d->ipc_open.push_back(q);
+            *out = static_cast<float *>(q);
+            return FWGPU_OK;
+        };
+        int rc;
+        if (all[j].has_ffm && ((rc = open(all[j].w, &ps.ffm_w[j])) || (rc = open(all[j].acc, &ps.ffm_acc[j])))) return rc;
+        if ((rc = open(all[j].lr, &ps.lr[j]))) return rc;
+    }
+    if (!d->d_peers) FWGPU_HIP(hipMalloc((void **)&d->d_peers, sizeof(PeerShards)));
+    FWGPU_HIP(hipMemcpy(d->d_peers, &ps, sizeof(PeerShards), hipMemcpyHostToDevice));
+    d->peers_attached = true;
+    return fwgpu_dist_barrier(d);  // nobody launches before everybody has mapped everybody
+}
+
+// One peer-sharded step of THIS rank: its n records through the fused kernel (mode = fwgpu_dist_set_mode), rows reached in their owners'
+// tables.  Not a collective: ranks run at their own pace (hogwild across GPUs).  predictions: host buffer, may be NULL.
+int fwgpu_dist_learn_peer(fwgpu_dist *d, const fwgpu_translator_config *t, const uint32_t *records, const uint64_t *rec_off, uint32_t n,
+                          float *preds, int update) {
+    if (!d || !d->comm) return fail(FWGPU_ERR_INVALID, "not an RCCL rank (fwgpu_dist_init)");
+    if (!d->peers_attached) return fail(FWGPU_ERR_INVALID, "fwgpu_dist_peer_attach first");
+    uint32_t shape[4];
+    int rc = sparse_begin(d, t, records, rec_off, n, nullptr, shape);  // (uploads the rank's records into its own batch)
+    if (rc) return rc;
+    FWGPU_HIP(hipSetDevice(d->r->device));
+    if ((rc = run_batch_peer(d->r, d->cur, d->mode, update, d->d_peers, d->stream))) return rc;
+    if (preds && d->B) FWGPU_HIP(hipMemcpyAsync(preds, d->cur->pred, (size_t)d->B * 4, hipMemcpyDeviceToHost, d->stream));
     FWGPU_HIP(hipStreamSynchronize(d->stream));
     return FWGPU_OK;
 }

@@ -66,6 +66,21 @@ class DistRank:
         check(capi.lib().fwgpu_dist_sparse_last_rows(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def peer_attach(self):
+        """collective, once: map every other rank's tables (IPC handles through the job's all-gather)"""
+        check(capi.lib().fwgpu_dist_peer_attach(self.h))
+
+    def learn_peer(self, translator, records, rec_off, update=True) -> np.ndarray:
+        """peer-sharded hogwild: this rank's records through the fused kernel, rows reached in their owners' tables (not a collective)"""
+        records, rec_off = _recs(records, rec_off)
+        n = len(rec_off) - 1
+        out = np.zeros(max(n, 1), dtype=np.float32)
+        check(capi.lib().fwgpu_dist_learn_peer(self.h, C.byref(translator.c), ptr(records), rec_off.ctypes.data_as(C.c_void_p), n, ptr(out), 1 if update else 0))
+        return out[:n]
+
+    def barrier(self):
+        check(capi.lib().fwgpu_dist_barrier(self.h))
+
     def gather_tables(self):
         check(capi.lib().fwgpu_dist_gather_tables(self.h))
 

@@ -327,6 +327,16 @@ int fwgpu_dist_group_learn_sparse(fwgpu_dist_group *g, const fwgpu_translator_co
  * afterwards gives every rank the whole model. */
 int fwgpu_dist_group_learn_peer(fwgpu_dist_group *g, const fwgpu_translator_config *t, const uint32_t *const *records,
                                 const uint64_t *const *rec_off, const uint32_t *n, float *const *predictions, int update);
+/* The same mode with one PROCESS per rank (hogwild.rs:24-103 across the GPUs of a node, one process per GPU as RCCL jobs are launched):
+ * fwgpu_dist_peer_attach -- collective, once -- exports this rank's tables as IPC handles (hipIpcGetMemHandle), all-gathers the handles
+ * through the job's communicator and maps every other rank's tables (hipIpcOpenMemHandle: a peer GPU's memory over xGMI, or the same
+ * device's when ranks share a GPU); fwgpu_dist_learn_peer then runs THIS rank's n records through the fused kernel, each row reached
+ * in its owner's allocation -- not a collective, ranks run at their own pace; fwgpu_dist_barrier (collective) is where the caller
+ * orders them: before fwgpu_dist_gather_tables, before a hold-out pass, or between ranks for a deterministic rank-after-rank run. */
+int fwgpu_dist_peer_attach(fwgpu_dist *d);
+int fwgpu_dist_learn_peer(fwgpu_dist *d, const fwgpu_translator_config *t, const uint32_t *records, const uint64_t *rec_off, uint32_t n,
+                          float *predictions, int update);
+int fwgpu_dist_barrier(fwgpu_dist *d);
 
 
 /* ---------------------------------------------------------------- HogwildTrainer replacement

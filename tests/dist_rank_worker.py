@@ -43,8 +43,10 @@ def main():
     re = fw.Regressor(mi)
     fbt = fw.FeatureBufferTranslator(mi)
     d = DistRank(re, uid, rank, n_ranks)
-    if mode == "sharded":
+    if mode in ("sharded", "peer_seq"):
         d.set_mode(capi.MODE_SEQUENTIAL)
+    if mode in ("peer", "peer_seq"):
+        d.peer_attach()
     preds = []
     pos = 0
     for s in range(parts.shape[0]):
@@ -61,11 +63,18 @@ def main():
                 ba.close()
         elif mode == "sparse":
             preds.append(d.learn_sparse(fbt, sub, so))
+        elif mode == "peer":  # hogwild across the ranks: everybody at its own pace
+            preds.append(d.learn_peer(fbt, sub, so))
+        elif mode == "peer_seq":  # rank after rank, each in example order: the sequential reference over the ranks' micro-batches
+            for turn in range(n_ranks):
+                if turn == rank:
+                    preds.append(d.learn_peer(fbt, sub, so))
+                d.barrier()
         else:
             raise SystemExit("unknown mode " + mode)
         pos += int(parts[s].sum())
     ranges = np.array(d.ranges(), dtype=np.uint64)
-    if mode == "sharded":
+    if mode in ("sharded", "peer", "peer_seq"):
         d.gather_tables()
     tabs = [np.asarray(re.table_read(tt)) for tt in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)]
     # the replica mode's exchange: all-reduce (sum) of a device buffer through the same communicator -- here the rank's FFM

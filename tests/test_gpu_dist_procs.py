@@ -132,3 +132,81 @@ def test_process_per_rank_sparse_step_matches_the_oracle(tmp_path, n_ranks, opt)
         for name, ref in zip(("lr", "ffm_w", "ffm_acc"), ref_tabs):
             assert _close(o[name], ref[:len(o[name])]), (r, name, float(np.abs(o[name] - ref[:len(o[name])]).max()))
             assert np.array_equal(o[name], outs[0][name]), (r, name)  # replicas stay bit-identical
+
+
+def _no_straddle_stream(mi, n_ns, k, ffm_bits, n, seed):
+    """examples without rows that straddle an ownership boundary of 4 ranks (the sharded modes' documented deviation)"""
+    R = n_ns * k
+    recs0, off0 = fw.synth_records(n_ns, 1.0, 1.1, 3000, 0.1, seed, 0, 3 * n)
+    fbt0 = fw.FeatureBufferTranslator(mi)
+    bounds = [j * (1 << ffm_bits) // 4 for j in range(1, 4)]
+    keep = []
+    for i in range(len(off0) - 1):
+        h = np.asarray(fbt0.translate(recs0[int(off0[i]):int(off0[i + 1])]).ffm_buffer)["hash"].astype(np.int64)
+        if not any(((h < b) & (h + R > b)).any() for b in bounds):
+            keep.append(i)
+        if len(keep) == n:
+            break
+    recs = np.concatenate([recs0[int(off0[i]):int(off0[i + 1])] for i in keep])
+    off = np.concatenate([[0], np.cumsum([int(off0[i + 1] - off0[i]) for i in keep])]).astype(np.uint64)
+    return recs, off
+
+
+@pytest.mark.parametrize("n_ranks", [2, 4])
+def test_process_per_rank_peer_sharded_in_order_is_the_sequential_reference(tmp_path, n_ranks):
+    """fwgpu_dist_peer_attach (IPC handles of every rank's tables through the job's all-gather, hipIpcOpenMemHandle) +
+    fwgpu_dist_learn_peer with the ranks taking turns (fwgpu_dist_barrier) and each in example order: the job is the sequential
+    reference algorithm over the ranks' micro-batches in rank order -- per-example parity with the oracle and the gathered tables,
+    with every rank a PROCESS of its own that reaches the other processes' tables through mapped memory."""
+    n_ns, k, bits, ffm_bits = 10, 4, 14, 14
+    mi, ocfg, ots = make_pair(n_ns, k, bits, ffm_bits, fw.Optimizer.AdagradLUT, lr=0.05, ffm_lr=0.05)
+    steps = 3
+    parts = [{2: [70, 50], 4: [40, 30, 30, 20]}[n_ranks] for _ in range(steps)]
+    recs, off = _no_straddle_stream(mi, n_ns, k, ffm_bits, steps * 120, 191)
+    om = fwo.Model(ocfg)
+    _, p_ref = om.run_stream(ots, recs, off, holdout_after=0, nthreads=1)
+    outs = _run_job(tmp_path, "peer_seq", n_ranks, (n_ns, k, bits, ffm_bits, fw.Optimizer.AdagradLUT, 0.05), recs, off, parts)
+    preds = np.zeros(steps * 120, dtype=np.float32)
+    taken = [0] * n_ranks
+    for s in range(steps):
+        a = s * 120
+        for r in range(n_ranks):
+            preds[a:a + parts[s][r]] = outs[r]["preds"][taken[r]:taken[r] + parts[s][r]]
+            taken[r] += parts[s][r]
+            a += parts[s][r]
+    assert np.abs(preds - p_ref).max() < 1e-5
+    ref_tabs = [np.asarray(om.lr_table), np.asarray(om.ffm_weights), np.asarray(om.ffm_acc)]
+    for r, o in enumerate(outs):
+        for name, ref in zip(("lr", "ffm_w", "ffm_acc"), ref_tabs):
+            assert _close(o[name], ref[:len(o[name])]), (r, name)
+            assert np.array_equal(o[name], outs[0][name]), (r, name)
+
+
+@pytest.mark.statistical
+def test_process_per_rank_peer_sharded_hogwild_reaches_the_oracles_holdout_loss(tmp_path):
+    """the concurrent form: two processes, each running the fused hogwild kernel on its half of every step at its own pace, rows
+    reached in their owners' (the other process's) tables; the gathered model's hold-out loss against the sequential oracle's"""
+    n_train, n_hold = 24000, 4000
+    mi, ocfg, ots = make_pair(10, 4, 18, 18, fw.Optimizer.AdagradLUT)
+    recs, off = fw.synth_records(10, 0.0, 1.1, 100000, 0.0, 20240611, 0, n_train + n_hold)
+    y = record_labels(recs, off)
+    om = fwo.Model(ocfg)
+    _, p = om.run_stream(ots, recs, off, holdout_after=n_train + 1, nthreads=1)
+    ref_hold = float(logloss(p[n_train:], y[n_train:]).mean())
+    step = 2000
+    parts = [[step // 2, step // 2] for _ in range(n_train // step)]
+    outs = _run_job(tmp_path, "peer", 2, (10, 4, 18, 18, fw.Optimizer.AdagradLUT, 0.1), recs[: int(off[n_train])], off[: n_train + 1], parts)
+    assert np.array_equal(outs[0]["ffm_w"], outs[1]["ffm_w"])  # gather_tables: both processes hold the whole model
+    re = fw.Regressor(mi)
+    from fwumious_wabbit_amd import _capi as capi
+    re.table_write(capi.TABLE_LR, outs[0]["lr"])
+    re.table_write(capi.TABLE_FFM_W, outs[0]["ffm_w"])
+    re.table_write(capi.TABLE_FFM_ACC, outs[0]["ffm_acc"])
+    fbt = fw.FeatureBufferTranslator(mi)
+    hb = re.record_batch(fbt, recs[int(off[n_train]):], off[n_train:] - off[n_train])
+    re.learn_batch(hb, capi.MODE_HOGWILD, False)
+    gpu_hold = float(logloss(hb.predictions(), y[n_train:]).mean())
+    hb.close()
+    re.close()
+    print(f"process-per-rank peer-sharded hogwild: hold-out {gpu_hold:.4f}, sequential oracle {ref_hold:.4f}")
+    assert gpu_hold < 0.6931 and abs(gpu_hold - ref_hold) < 0.02, (gpu_hold, ref_hold)
