@@ -229,13 +229,14 @@ def main():
                     help="N>1 replica run: skip the short sparse / sharded legs that are reported as dp_modes")
     ap.add_argument("--other-modes-timeout", dest="other_modes_timeout", type=float, default=240.0,
                     help="seconds after which the dp_modes legs are given up and the line is printed without them")
-    ap.add_argument("--dp-mode", dest="dp_mode", choices=["replica", "sharded", "sparse"], default="replica",
+    ap.add_argument("--dp-mode", dest="dp_mode", choices=["replica", "sharded", "sparse", "peer"], default="replica",
                     help="N>1: 'replica' = full replicas + overlapped RCCL all-reduce of the table deltas every --sync-every steps "
                          "(the timed mode of a multi-GPU run); 'sharded' = owner-sharded tables, synchronous step with all-gather / "
                          "reduce-scatter of field sums (fwgpu_dist_learn_sharded_batch).  A replica run also times a short "
                          "sharded leg and reports it as dp_modes.sharded; 'sparse' = full replicas, per-micro-batch all-gather of "
                          "deduplicated row gradients, one summed-gradient step per row (fwgpu_dist_learn_sparse_batch), also timed "
-                         "as dp_modes.sparse on a replica run")
+                         "as dp_modes.sparse on a replica run; 'peer' = tables sharded by owner, every rank runs the fused hogwild kernel on its own batches and "
+                         "reaches each row in its owner's memory through IPC-mapped tables (fwgpu_dist_peer_attach / learn_peer_batch): no collective per step")
     ap.add_argument("--rccl", choices=["library", "torch"], default="library",
                     help="N>1 replica exchange: through the library's own RCCL communicator (C ABI, fwgpu_dist_all_reduce_sum) or torch.distributed")
     ap.add_argument("--blocking-sync", dest="blocking_sync", action="store_true",
@@ -258,6 +259,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
     ap.add_argument("--cpu-examples", dest="cpu_examples", type=int, default=0)
     args = ap.parse_args()
+    if os.environ.get("FWGPU_BENCH_DEBUG"):  # where is a hung run?  Python stacks of all threads to stderr after that many seconds
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["FWGPU_BENCH_DEBUG"]), exit=False)
 
     import torch
     import torch.distributed as dist
@@ -376,14 +381,20 @@ def main():
         re.learn_batch(hbatch, capi.MODE_HOGWILD, False, sptr)
     torch.cuda.synchronize()
     sparse_main = use_dist and args.dp_mode == "sparse"
-    sharded_main = (use_dist and args.dp_mode == "sharded") or sparse_main  # (both: synchronous steps inside the library, no replica exchange)
+    peer_main = use_dist and args.dp_mode == "peer"
+    sharded_main = (use_dist and args.dp_mode == "sharded") or sparse_main or peer_main  # (all: steps inside the library, no replica exchange)
     if sharded_main and dist_rank is None:
         raise SystemExit(f"--dp-mode {args.dp_mode} needs the RCCL backend (one rank per GPU) and a model without a deep head")
 
     split = re.split_buffers(B, 1024) if sync_steps else None
 
+    if peer_main:
+        dist_rank.peer_attach()
+
     def step(b):
-        if sparse_main:  # row-sparse gradient buckets: full replicas, all-gather of deduplicated row gradients, one step per row
+        if peer_main:  # peer-sharded hogwild: own batch, rows in their owners' tables, no collective
+            dist_rank.learn_peer_batch(fbt, b, True, sptr)
+        elif sparse_main:  # row-sparse gradient buckets: full replicas, all-gather of deduplicated row gradients, one step per row
             dist_rank.learn_sparse_batch(fbt, b)
         elif sharded_main:  # owner-sharded synchronous step: all-gather records, reduce-scatter field sums, owner-side updates
             dist_rank.learn_sharded_batch(fbt, b)
@@ -425,7 +436,9 @@ def main():
         elapsed = float(tmax.item())
 
     kernel_ms = [ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(K)]
-    if sharded_main:  # the step runs on the library's own stream and is host-synchronous: the step time is the wall time
+    if peer_main:
+        dist_rank.gather_tables()  # (barrier inside) every rank gets the whole model back for the hold-out pass
+    elif sharded_main:  # the step runs on the library's own stream and is host-synchronous: the step time is the wall time
         kernel_ms = [1e3 * elapsed / K] * K
         if sparse_main:
             rows_f, rows_l = dist_rank.sparse_last_rows()
@@ -571,6 +584,8 @@ def main():
                 "mode": ("synchronous micro-batches (every example sees the batch-start weights; FWD / MID / head on MFMA / UPD kernels)" if sync_steps
                          else "hogwild (device-wide concurrent examples, racy RMW, sc1 accesses)"),
                 "parallelism": ("1 GPU" if not use_dist else
+                                f"dp{world} peer: tables sharded by owner, every rank's fused hogwild kernel reaches each row in its owner's memory (IPC-mapped tables over xGMI), "
+                                f"no collective per step, {world} x {B} examples per step" if peer_main else
                                 f"dp{world} sparse: full replicas, per-micro-batch all-gather of deduplicated row gradients of {world} x {B} examples, "
                                 f"one summed-gradient AdaGrad step per row on every replica, RCCL inside the library" if sparse_main else
                                 f"dp{world} sharded: owner-sharded tables, synchronous step of {world} x {B} examples (records all-gathered, field sums "
@@ -583,7 +598,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("FWD / MID / " + ("head GEMMs (v_mfma_f32_32x32x2_f32) / " if args.nn_layers else "") + "UPD kernels of the synchronous micro-batch (generic row kernel)"
+                "kernel": ("fw_example_kernel<4, AdagradLUT, coherent, peer-sharded> (generic kernel with the owner lookup, system-scope row accesses)" if peer_main else
+                           "FWD / MID / " + ("head GEMMs (v_mfma_f32_32x32x2_f32) / " if args.nn_layers else "") + "UPD kernels of the synchronous micro-batch (generic row kernel)"
                            if sync_steps or sharded_main else
                            "fw_example_kernel_r<AdagradLUT, coherent, MAXR=14, duplicate-row chains> (2 workgroups x 512 threads per CU at 128 VGPRs; 14 rows per wave kept from the gather and written back as w_gather - step; whole-line row accesses only when w and acc contend for one memory region)"
                            if args.k % 4 == 0 and args.fields * args.k <= 256 and not args.nn_layers else

@@ -151,6 +151,8 @@ struct fwgpu_dist {
     hipEvent_t ev_prev = nullptr;    // group step: "the previous rank's local phase is done" (device-side ordering of the ranks)
     PeerShards *d_peers = nullptr;   // peer-sharded step: the owners' table bases, on this rank's device
     bool peers_attached = false;     // process-per-rank peer mode: the other ranks' tables are mapped (hipIpcOpenMemHandle)
+    float *lr_shard = nullptr;       // ... this rank's OWNED range of the LR table in an allocation of its own while the mode is on: what the
+    uint64_t lr_shard_lo = 0, lr_shard_n = 0;  // peers map (hipIpcOpenMemHandle hangs on allocations of 2 GiB and more: a `-b 28` LR table is 2 GiB)
     std::vector<void *> ipc_open;    // ... what to close again
     hipEvent_t dbg_ev[3] = {nullptr, nullptr, nullptr};  // debug (scripts/group_bisect.sh): recorded behind FWD / MID / the FFM reduction of sparse_local
     uint32_t last_rows[2] = {0, 0};  // bucket rows {ffm, lr} this rank sent in its last sparse step
@@ -164,6 +166,7 @@ struct fwgpu_dist {
         if (sp) fwgpu_split_free(sp);
         if (d_own) (void)hipFree(d_own);
         for (void *q : ipc_open) (void)hipIpcCloseMemHandle(q);
+        if (lr_shard) (void)hipFree(lr_shard);
         if (d_peers) (void)hipFree(d_peers);
         if (d_shape) (void)hipFree(d_shape);
         if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
@@ -726,8 +729,11 @@ static int rccl_step(fwgpu_dist *d, const uint32_t *records, const uint64_t *rec
 int fwgpu_dist_gather_tables(fwgpu_dist *d) {
     if (!d || !d->comm) return fail(FWGPU_ERR_INVALID, "not an RCCL rank (fwgpu_dist_init)");
     if (int rc0 = check_shardable(d)) return rc0;
-    if (d->peers_attached)  // peer-sharded ranks run at their own pace and write into each other's tables: everybody is done first
+    if (d->peers_attached) {  // peer-sharded ranks run at their own pace and write into each other's tables: everybody is done first
         if (int rcb = fwgpu_dist_barrier(d)) return rcb;
+        FWGPU_HIP(hipSetDevice(d->r->device));  // ... and the owned LR range comes back from its shard allocation
+        FWGPU_HIP(hipMemcpy(d->r->d_lr + 2 * d->lr_shard_lo, d->lr_shard, d->lr_shard_n * 8, hipMemcpyDeviceToDevice));
+    }
     fwgpu_regressor *r = d->r;
     FWGPU_HIP(hipSetDevice(r->device));
     if (r->cfg.ffm_k) {
@@ -790,19 +796,31 @@ int fwgpu_dist_peer_attach(fwgpu_dist *d) {
         uint32_t has_ffm, pad[3];
     };
     static_assert(sizeof(Handles) % 4 == 0, "all-gathered as 32-bit words");
+    static const bool dbg = std::getenv("FWGPU_DBG_PEER") != nullptr;
+#define PEER_DBG(...) do { if (dbg) { std::fprintf(stderr, "[peer %d] ", d->rank); std::fprintf(stderr, __VA_ARGS__); std::fprintf(stderr, "\n"); } } while (0)
     Handles mine{};
     mine.has_ffm = r->cfg.ffm_k ? 1u : 0u;
     if (r->cfg.ffm_k) {
         FWGPU_HIP(hipIpcGetMemHandle(&mine.w, r->d_ffm_w));
         FWGPU_HIP(hipIpcGetMemHandle(&mine.acc, r->d_ffm_acc));
     }
-    FWGPU_HIP(hipIpcGetMemHandle(&mine.lr, r->d_lr));
+    PEER_DBG("ffm handles exported");
+    // The LR table's owned range moves into an allocation of its own for as long as the mode is on (copied back by
+    // fwgpu_dist_gather_tables): 1/N of the table, so that what peers have to map stays below 2 GiB -- hipIpcOpenMemHandle hangs on an
+    // allocation of exactly 2^31 bytes (ROCm 7.x, measured: a `-b 28` LR table), the two 1.07 GB FFM tables open fine.
+    d->lr_shard_n = r->lr_len / (uint64_t)N;
+    d->lr_shard_lo = d->lr_shard_n * (uint64_t)d->rank;
+    FWGPU_HIP(hipMalloc((void **)&d->lr_shard, d->lr_shard_n * 8));
+    FWGPU_HIP(hipMemcpy(d->lr_shard, r->d_lr + 2 * d->lr_shard_lo, d->lr_shard_n * 8, hipMemcpyDeviceToDevice));
+    FWGPU_HIP(hipIpcGetMemHandle(&mine.lr, d->lr_shard));
+    PEER_DBG("lr handle exported (%llu bytes)", (unsigned long long)r->lr_len * 8);
     Handles *d_all = nullptr;
     FWGPU_HIP(hipMalloc((void **)&d_all, sizeof(Handles) * (size_t)N));
     FWGPU_HIP(hipMemcpyAsync(d_all + d->rank, &mine, sizeof(Handles), hipMemcpyHostToDevice, d->stream));
     FWGPU_HIP(hipStreamSynchronize(d->stream));
     ncclResult_t e = N > 1 ? g_rccl.AllGather(d_all + d->rank, d_all, sizeof(Handles) / 4, ncclUint32, d->comm, d->stream) : ncclSuccess;
     std::vector<Handles> all((size_t)N);
+    PEER_DBG("handles all-gathered");
     hipError_t he = hipStreamSynchronize(d->stream);
     if (he == hipSuccess) he = hipMemcpy(all.data(), d_all, sizeof(Handles) * (size_t)N, hipMemcpyDeviceToHost);
     (void)hipFree(d_all);
@@ -813,15 +831,19 @@ int fwgpu_dist_peer_attach(fwgpu_dist *d) {
     ps.shift_ffm = r->cfg.ffm_k ? r->cfg.ffm_bit_precision - lg : 31;
     ps.shift_lr = r->cfg.bit_precision - lg;
     for (int j = 0; j < N; j++) {
+        // (an owner's LR base is its shard allocation moved back by its range start: the kernel indexes it like the whole table, and the
+        // owner lookup only ever sends entries of that range there)
         if (j == d->rank) {
             ps.ffm_w[j] = r->d_ffm_w;
             ps.ffm_acc[j] = r->d_ffm_acc;
-            ps.lr[j] = r->d_lr;
+            ps.lr[j] = d->lr_shard - 2 * d->lr_shard_lo;
             continue;
         }
         auto open = [&](const hipIpcMemHandle_t &h, float **out) -> int {
             void *q = nullptr;
+            PEER_DBG("opening a handle of rank %d ...", j);
             FWGPU_HIP(hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess));
+            PEER_DBG("... opened at %p", q);
             d->ipc_open.push_back(q);
             *out = static_cast<float *>(q);
             return FWGPU_OK;
@@ -829,6 +851,7 @@ int fwgpu_dist_peer_attach(fwgpu_dist *d) {
         int rc;
         if (all[j].has_ffm && ((rc = open(all[j].w, &ps.ffm_w[j])) || (rc = open(all[j].acc, &ps.ffm_acc[j])))) return rc;
         if ((rc = open(all[j].lr, &ps.lr[j]))) return rc;
+        ps.lr[j] -= 2 * d->lr_shard_n * (uint64_t)j;
     }
     if (!d->d_peers) FWGPU_HIP(hipMalloc((void **)&d->d_peers, sizeof(PeerShards)));
     FWGPU_HIP(hipMemcpy(d->d_peers, &ps, sizeof(PeerShards), hipMemcpyHostToDevice));
@@ -850,6 +873,17 @@ int fwgpu_dist_learn_peer(fwgpu_dist *d, const fwgpu_translator_config *t, const
     if (preds && d->B) FWGPU_HIP(hipMemcpyAsync(preds, d->cur->pred, (size_t)d->B * 4, hipMemcpyDeviceToHost, d->stream));
     FWGPU_HIP(hipStreamSynchronize(d->stream));
     return FWGPU_OK;
+}
+
+// the same step with the rank's micro-batch already resident in HBM (a record batch of this rank's regressor); predictions land in the
+// batch; asynchronous on the rank's stream unless `hip_stream` is given (then launched there)
+int fwgpu_dist_learn_peer_batch(fwgpu_dist *d, const fwgpu_translator_config *t, fwgpu_batch *b, int update, void *hip_stream) {
+    if (!d || !d->comm) return fail(FWGPU_ERR_INVALID, "not an RCCL rank (fwgpu_dist_init)");
+    if (!d->peers_attached) return fail(FWGPU_ERR_INVALID, "fwgpu_dist_peer_attach first");
+    if (!t || !b || !b->records) return fail(FWGPU_ERR_INVALID, "peer step: a record batch is needed");
+    if (b->owner != d->r) return fail(FWGPU_ERR_INVALID, "peer step: batch belongs to another regressor");
+    FWGPU_HIP(hipSetDevice(d->r->device));
+    return run_batch_peer(d->r, b, d->mode, update, d->d_peers, hip_stream ? static_cast<hipStream_t>(hip_stream) : d->stream);
 }
 
 // Dense all-reduce of a device float buffer over the job (replica mode: table deltas; deep head: dense gradient sums)

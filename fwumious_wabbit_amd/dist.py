@@ -78,6 +78,10 @@ class DistRank:
         check(capi.lib().fwgpu_dist_learn_peer(self.h, C.byref(translator.c), ptr(records), rec_off.ctypes.data_as(C.c_void_p), n, ptr(out), 1 if update else 0))
         return out[:n]
 
+    def learn_peer_batch(self, translator, batch, update=True, stream=None):
+        """the same step with the records already in HBM (Regressor.record_batch); predictions: batch.predictions()"""
+        check(capi.lib().fwgpu_dist_learn_peer_batch(self.h, C.byref(translator.c), batch.h, 1 if update else 0, stream))
+
     def barrier(self):
         check(capi.lib().fwgpu_dist_barrier(self.h))
 

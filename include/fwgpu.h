@@ -332,10 +332,15 @@ int fwgpu_dist_group_learn_peer(fwgpu_dist_group *g, const fwgpu_translator_conf
  * through the job's communicator and maps every other rank's tables (hipIpcOpenMemHandle: a peer GPU's memory over xGMI, or the same
  * device's when ranks share a GPU); fwgpu_dist_learn_peer then runs THIS rank's n records through the fused kernel, each row reached
  * in its owner's allocation -- not a collective, ranks run at their own pace; fwgpu_dist_barrier (collective) is where the caller
- * orders them: before fwgpu_dist_gather_tables, before a hold-out pass, or between ranks for a deterministic rank-after-rank run. */
+ * orders them: before fwgpu_dist_gather_tables, before a hold-out pass, or between ranks for a deterministic rank-after-rank run.
+ * While the mode is on, a rank's OWNED range of the LR table lives in an allocation of its own (what the peers map: 1/N of the table --
+ * hipIpcOpenMemHandle hangs on a 2 GiB allocation on ROCm 7.2); fwgpu_dist_gather_tables copies it back before it assembles the
+ * tables, so fwgpu_predict / fwgpu_save on the rank's regressor see the trained LR weights only after that call. */
 int fwgpu_dist_peer_attach(fwgpu_dist *d);
 int fwgpu_dist_learn_peer(fwgpu_dist *d, const fwgpu_translator_config *t, const uint32_t *records, const uint64_t *rec_off, uint32_t n,
                           float *predictions, int update);
+/* ... with the rank's micro-batch already in HBM (a record batch of its regressor); launched on hip_stream, or on the rank's own stream */
+int fwgpu_dist_learn_peer_batch(fwgpu_dist *d, const fwgpu_translator_config *t, fwgpu_batch *b, int update, void *hip_stream);
 int fwgpu_dist_barrier(fwgpu_dist *d);
 
 
