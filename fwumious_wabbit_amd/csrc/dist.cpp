@@ -1097,17 +1097,15 @@ int fwgpu_dist_group_learn_sparse(fwgpu_dist_group *g, const fwgpu_translator_co
     for (int j = 0; j < N; j++)
         if ((rc = sparse_begin(g->ranks[j].get(), t, records[j], rec_off[j], n[j], nullptr, &shapes[4 * j]))) return rc;
     // The ranks' local phases run ONE AFTER THE OTHER ON THE DEVICE: rank j's stream waits (event, no host synchronisation) for rank
-    // j-1's local phase.  With the local phases of two or more ranks truly overlapping on different hardware queues the step is not
-    // reproducible (scripts/group_exp.sh, profiles/r03_group_concurrency.txt): single examples of a rank come out with another
-    // result (as if skipped or read half-way), occasionally an address built from such data faults.  What is known: it needs the FWD
-    // (+ MID) kernels of two ranks in flight at once (ordering rank j behind rank j-1's MID is enough, behind its FWD is not); it is
-    // not stale L2 (device-scope table loads do not help), not grid over-subscription (192 workgroups per rank do not help), not the
-    // streams' flags; GPU_MAX_HW_QUEUES <= 2 makes it exact; every per-rank buffer is disjoint (addresses printed and compared),
-    // occurrence keys / sorted keys / scan results are structurally valid in wrong runs, an LDS canary behind the kernel's layout stays
-    // untouched -- and it comes and goes with unrelated code generation changes of the FWD kernel (two of five builds of this round
-    // were exact 8/8 without any ordering).  A timing-dependent fault in (or under) the generic kernel's FWD phase that only two
-    // concurrent queues expose; not found.  FWGPU_GROUP_CONCURRENT=local removes the ordering (debug), FWGPU_DBG_GROUP_CHAIN =
-    // fwd | mid | red moves the wait to an earlier point of rank j-1's phase.  The RCCL path has one rank per process and one queue.
+    // j-1's local phase.  With the FWD (+ MID) kernels of two ranks overlapping on different hardware queues the step is not reproducible
+    // (scripts/group_repro.py, profiles/r03_group_concurrency.txt): single WORKGROUPS of a phase kernel come up with wrong
+    // loop-invariant state -- their examples read wrong, occasionally an address built from it faults.  It is not this library's memory
+    // accesses (buffers disjoint, keys / scans valid, LDS canary untouched, arguments intact) and not the size of the argument block, as a
+    // first pass concluded: it follows the register allocation the KernelParams layout happens to select, and it goes away -- 34 of 34 runs
+    // on every failing layout -- when the phase kernels keep their spilled scalar registers in scratch memory instead of VGPR lanes
+    // (`make PHASE_SGPR_SPILLS=scratch`, 0.55x the phase kernels' speed).  The default build keeps the fast spills and this ordering, which
+    // is exact on every build.  FWGPU_GROUP_CONCURRENT=local removes the ordering (debug), FWGPU_DBG_GROUP_CHAIN = fwd | mid | red moves the
+    // wait to an earlier point of rank j-1's phase.  The RCCL path has one rank per process and one queue.
     static const char *dbg_chain = std::getenv("FWGPU_DBG_GROUP_CHAIN");
     static const char *cc_env = std::getenv("FWGPU_GROUP_CONCURRENT");
     const bool unordered = cc_env && (cc_env[0] == 'l' || (cc_env[0] == 'a' && cc_env[1] == 'l'));

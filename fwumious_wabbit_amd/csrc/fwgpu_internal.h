@@ -127,6 +127,9 @@ struct KernelParams {
     const uint32_t *ctx_cover;          // record batches: bit per namespace slot whose FFM features the cache already holds (the stage phase skips them)
     float *emit_T;                      // setup_cache: example 0's T and dcf are written here after the gather
     float *emit_dcf;
+#if defined(FW_KP_PAD_POS) && FW_KP_PAD_POS == 1  // debug builds (scripts/kp_pos_exp.sh): 16 bytes HERE
+    unsigned char kp_pos_pad[16];
+#endif
     // ---- synchronous micro-batch ("split") pipeline: FWD -> [exchange] -> MID -> [head / exchange] -> UPD  (kernels.hip)
     float *split;                       // [n * split_len] per example: T[F*R], dcf[F], LR sums[split_nlr], field counts[F], label, importance
     uint32_t split_len, split_nlr;      // floats per example; LR sums kept: 1 (total) or num_combos (deep head)
@@ -134,18 +137,30 @@ struct KernelParams {
     uint32_t selfw_stride;
     float *gbuf;                        // [n] general gradient of every example (MID -> UPD)
     float *xbuf, *dxbuf;                // deep head, mini-batched: x and d logit/d x per example [n * nn.X]
+#if defined(FW_KP_PAD_POS) && FW_KP_PAD_POS == 2  // debug builds (scripts/kp_pos_exp.sh): 16 bytes HERE
+    unsigned char kp_pos_pad[16];
+#endif
     uint32_t own_lo_ffm, own_hi_ffm;    // this rank owns the FFM rows with own_lo <= hash < own_hi (sharded tables)...
     uint32_t own_lo_lr, own_hi_lr;      // ... and these LR entries
     uint32_t home_lo, home_hi;          // examples of the launch whose label / counts this rank contributes (its own shard of the batch)
+#if defined(FW_KP_PAD_POS) && FW_KP_PAD_POS == 3  // debug builds (scripts/kp_pos_exp.sh): 16 bytes HERE
+    unsigned char kp_pos_pad[16];
+#endif
     // ---- peer-sharded tables (dist.cpp fwgpu_dist_group_learn_peer): the tables are sharded by owner, every rank runs the fused hogwild
     // kernel on its own examples and reaches a row IN ITS OWNER'S MEMORY (same device, or a peer GPU's memory mapped over xGMI).
     // owner(row) = row start >> shard_shift; every owner's allocation is indexed like the whole table.
     const struct PeerShards *shards;   // device memory; NULL: the regressor's own tables
+#if defined(FW_KP_PAD_POS) && FW_KP_PAD_POS == 4  // debug builds (scripts/kp_pos_exp.sh): 16 bytes HERE
+    unsigned char kp_pos_pad[16];
+#endif
     // ---- row-sparse gradient mode (sparse.hip): the FWD phase lists every entry as an occurrence, slot = example * max_ffm + entry
     unsigned long long *occ_ffm_key;    // [n * max_ffm] (row hash << 32 | slot), ~0 for unused slots and examples that do not update
     uint2 *occ_ffm_desc;                // [n * max_ffm] {value bits, field}
     unsigned long long *occ_lr_key;     // [n * max_lr]
     uint2 *occ_lr_desc;                 // [n * max_lr]  {value bits, 0}
+#ifdef FW_KP_TAIL_PAD                   // debug builds: the same, BEHIND the last field (no other field moves: the kernels' code stays what it is)
+    unsigned char kp_tail_pad[FW_KP_TAIL_PAD];
+#endif
 };
 
 struct LaunchConfig {

@@ -677,11 +677,13 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
     return o;
 }
 
+#ifndef FW_PHASE_TU  // (host functions live in ONE of the two translation units of this file: see the Makefile)
 size_t example_kernel_lds_bytes(const KernelParams &p, int optimizer) {
     size_t off[23];
     return lds_layout(p.F, p.k, p.max_ffm, p.max_lr, (optimizer == FWGPU_OPT_ADAGRAD_LUT && p.update && !p.lut_global) ? 1 : 0,
                       p.records ? p.max_rec : 0, p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off);
 }
+#endif
 
 
 // ------------------------------------------------------------------ deep head (a18), per-example reference semantics
@@ -1309,7 +1311,9 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
 
 // split record of one example (floats): T[F*R] | dcf[F] | LR sums[nlr] | feature count per field[F] | label | importance | pad
 __host__ __device__ inline uint32_t split_len_of(uint32_t F, uint32_t R, uint32_t nlr) { return (F * R + F + nlr + F + 2 + 3) & ~3u; }
+#ifndef FW_PHASE_TU
 uint32_t split_record_len(uint32_t F, uint32_t R, uint32_t nlr) { return split_len_of(F, R, nlr); }
+#endif
 
 // PH = 0: the fused learn / predict step.  PH = 1 (FWD) and PH = 3 (UPD): the two table-touching halves of the synchronous
 // micro-batch pipeline -- every example of the batch sees the weights of the batch start, updates are applied afterwards:
@@ -1319,6 +1323,7 @@ uint32_t split_record_len(uint32_t F, uint32_t R, uint32_t nlr) { return split_l
 #ifdef FW_DBG_KERNARG_CHECK  // debug build (scripts/kp_size_exp.sh): does a running kernel's argument block change under it?
 __device__ unsigned g_dbg_kernarg_changed[4];  // [0] workgroups whose kernarg checksum differed between entry and exit, [1] workgroups checked,
                                                // [2] workgroups whose arguments, as loaded by the kernel, differ from the argument block in memory; [3] the same for the MID kernel
+#ifdef FW_PHASE_TU
 unsigned dbg_kernarg_changed_read(unsigned *checked) {
     unsigned v[4] = {0, 0, 0, 0};
     (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(g_dbg_kernarg_changed), sizeof(v));
@@ -1329,6 +1334,7 @@ unsigned dbg_kernarg_changed_read(unsigned *checked) {
     }
     return v[0];
 }
+#endif
 __device__ __forceinline__ unsigned dbg_kernarg_sum() {
     // (read through the flat address of the segment with device-scope loads: not the scalar cache's copy)
     unsigned long long a = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1344,6 +1350,8 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
     typedef typename Vec<VEC>::type V;
     // (peer-sharded tables: a row may live in another GPU's memory -- system-scope accesses there, device scope otherwise)
     constexpr int AUX = COH ? (SH ? kAuxSys : kAuxSc1) : kAuxPlain;
+    // a serving context cache (ctx_*, emit_*) only ever comes with read-only launches of the whole kernel, never with the phases of a split step
+    constexpr bool kCtx = !COH && PH == 0;
 #ifndef FW_V1_UG
 #define FW_V1_UG 8
 #endif
@@ -1442,7 +1450,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         if (ex >= p.n_examples) break;
         FW_TICK(6);
         if (timing) tk[7] += 1;
-        const StageOut so = stage_example<!COH>(p, s, geom, ex, tid, bd);
+        const StageOut so = stage_example<kCtx>(p, s, geom, ex, tid, bd);
         uint32_t next_ticket = 0;  // (every thread is past its read of ctr[6]: the stage phase has barriers)
         if (tid == 0) next_ticket = atomicAdd(p.work, 1u);
         const uint32_t nf = so.nf, nl = so.nl;
@@ -1467,7 +1475,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                     const uint32_t z = inb ? e0 / k : 0;
                     const bool self = inb && (z == f);
                     V acc = Vec<VEC>::zero();
-                    if (!COH && p.ctx_T && inb) {  // context cache: the cached features of this field come first (block_ffm.rs:548-556)
+                    if (kCtx && p.ctx_T && inb) {  // context cache: the cached features of this field come first (block_ffm.rs:548-556)
 #pragma unroll
                         for (int j = 0; j < VEC; ++j) Vec<VEC>::set(acc, j, p.ctx_T[z * R + f * k + (e0 - z * k) + j]);
                     }
@@ -1507,13 +1515,13 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
                     if (inb) Vec<VEC>::lds_store(s.T + z * R + f * k + (e0 - z * k), acc);
                 }
                 dc = wave_sum(dc);
-                if (!COH && p.ctx_dcf) dc += p.ctx_dcf[f];
+                if (kCtx && p.ctx_dcf) dc += p.ctx_dcf[f];
                 s.dcf[f] = dc;  // same value from all 64 lanes
             }
         }
         __syncthreads();
         FW_TICK(2);
-        if (!COH && p.emit_T && ex == 0) {  // setup_cache: keep this example's field sums (Regressor::setup_cache, regressor.rs:409-423)
+        if (kCtx && p.emit_T && ex == 0) {  // setup_cache: keep this example's field sums (Regressor::setup_cache, regressor.rs:409-423)
             for (uint32_t i = tid; i < F * R; i += bd) p.emit_T[i] = s.T[i];
             for (uint32_t f = tid; f < F; f += bd) p.emit_dcf[f] = s.dcf[f];
         }
@@ -1774,6 +1782,12 @@ static hipError_t launch_v(const KernelParams &p, int optimizer, bool coherent, 
     }
 }
 
+#ifdef FW_PHASE_TU
+// (This part is the file's SECOND translation unit, built with -DFW_PHASE_TU.  `make PHASE_SGPR_SPILLS=scratch` compiles it with
+// -mllvm -amdgpu-spill-sgpr-to-vgpr=0: the phase kernels then keep their spilled scalar registers in scratch memory, not in lanes of a vector
+// register.  With the spills in VGPR lanes, FWD / MID launches of two ranks that overlap on different hardware queues give single workgroups
+// wrong loop-invariant state -- DESIGN.md 7, profiles/r03_group_concurrency.txt.  The default build keeps the VGPR-lane form, 1.8x faster, and
+// dist.cpp orders the ranks of an in-process group on the device.)
 // ------------------------------------------------------------------ split pipeline: phase launches and the MID kernel
 template <int VEC>
 static hipError_t launch_phase_v(const KernelParams &p, int optimizer, int phase, uint32_t grid, uint32_t threads, size_t lds,
@@ -1924,6 +1938,8 @@ hipError_t launch_split_mid(const KernelParams &p, uint32_t n, hipStream_t strea
 #endif
     return hipGetLastError();
 }
+
+#endif  // FW_PHASE_TU
 
 // ------------------------------------------------------------------ v2: static wave ranges, occupancy-tuned
 //
@@ -2363,6 +2379,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
 #ifndef FW_MAXR_WIN
 #define FW_MAXR_WIN 14
 #endif
+#ifndef FW_PHASE_TU  // (the fused kernels' launchers and the small utility kernels: first translation unit only)
 template <int OPT, bool COH>
 static hipError_t launch_r(const KernelParams &p, uint32_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
     if (p.R > 64 * 4) {  // two-chunk rows (k = 16 at config E's 30 fields): no resident rows
@@ -2643,4 +2660,5 @@ hipError_t launch_coherence_probe(unsigned *scratch /* >= 256+1+64+2 words, zero
     return hipGetLastError();
 }
 
+#endif  // !FW_PHASE_TU
 }  // namespace fwgpu
