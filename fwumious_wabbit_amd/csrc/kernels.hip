@@ -1315,6 +1315,16 @@ __host__ __device__ inline uint32_t split_len_of(uint32_t F, uint32_t R, uint32_
 uint32_t split_record_len(uint32_t F, uint32_t R, uint32_t nlr) { return split_len_of(F, R, nlr); }
 #endif
 
+// The kernels take their parameters by value (one argument block, scalar loads).  Left alone, the compiler loads every field once in the
+// prologue of the persistent kernel and keeps ~180 scalars alive across the example loop -- 200 of them spilled to VGPR lanes, which in turn
+// pushed 8 vector registers of the config-C learn kernel to scratch.  kp_fresh() hands out the argument block's address through an empty
+// asm statement, so loads cannot move above the point of the call: called at the top of every example, the fields are (re)loaded where they
+// are used (scalar cache hits) and the pressure goes away: 200 -> 85 spilled scalars, 8 -> 1 spilled vector registers, 36 -> 8 B/lane of scratch.
+__device__ __forceinline__ const KernelParams &kp_fresh() {
+    const __attribute__((address_space(4))) char *k = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("; argument block address handed out" : "+s"(k));
+    return *(const KernelParams *)k;  // (KernelParams is the kernels' first and only explicit argument: offset 0 of the segment)
+}
 // PH = 0: the fused learn / predict step.  PH = 1 (FWD) and PH = 3 (UPD): the two table-touching halves of the synchronous
 // micro-batch pipeline -- every example of the batch sees the weights of the batch start, updates are applied afterwards:
 //   FWD : stage, gather the rows this rank OWNS (all of them on one GPU), write T / dcf / LR sums to the example's split record
@@ -1346,7 +1356,8 @@ __device__ __forceinline__ unsigned dbg_kernarg_sum() {
 }
 #endif
 template <int VEC, int OPT, bool COH, int PH = 0, bool NN = true, bool SH = false>
-__global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) {
+__global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* read through kp_fresh() */) {
+    const KernelParams &p = kp_fresh();
     typedef typename Vec<VEC>::type V;
     // (peer-sharded tables: a row may live in another GPU's memory -- system-scope accesses there, device scope otherwise)
     constexpr int AUX = COH ? (SH ? kAuxSys : kAuxSc1) : kAuxPlain;
@@ -1440,6 +1451,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams p) 
         for (uint32_t i = tid; i < 256; i += bd) reinterpret_cast<uint32_t *>(smem + p.dbg_canary_off)[i] = 0xC0FFEE00u + i;
 #endif
     for (;;) {
+        const KernelParams &p = kp_fresh();  // (shadows the prologue's: this example's loads start here)
         // Previous example's LDS reads are done.  A workgroup-scope barrier does not drain vmcnt on this target,
         // so in the in-order (single workgroup) mode every wave first waits for its own table stores to be
         // acknowledged: the next example must read what this one wrote.  Concurrent (hogwild) grids skip the
@@ -2005,7 +2017,8 @@ template <int OPT, bool COH, int MAXR, bool WIN, int NC = 1>
 #ifndef FW_LB_WAVES_WIN  // the window path (config C's updating launches): FOUR waves per SIMD = two workgroups per CU, 128 registers -- room for
 #define FW_LB_WAVES_WIN 4  // 14 kept rows per wave without a spill; faster AND better than three workgroups with 8 kept rows
 #endif
-__global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WIN : FW_LB_WAVES) : 4) fw_example_kernel_r(const KernelParams p) {
+__global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WIN : FW_LB_WAVES) : 4) fw_example_kernel_r(const KernelParams /* read through kp_fresh() */) {
+    const KernelParams &p = kp_fresh();
     static_assert(NC == 1 || MAXR == 0, "resident rows are a single-chunk feature");
     typedef f4 V;
     constexpr int VEC = 4;
@@ -2083,6 +2096,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         hot_lr_init<COH>(p, s, true);
     }
     for (;;) {
+        const KernelParams &p = kp_fresh();  // (shadows the prologue's: this example's loads start here)
         if (gridDim.x == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in-order mode: see fw_example_kernel
         __syncthreads();
         const uint32_t ex = s.ctr[6];

@@ -6,6 +6,8 @@ src = os.path.join(ROOT, "fwumious_wabbit_amd", "csrc")
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", f"-I{ROOT}/include", "-I.",
        "-Rpass-analysis=kernel-resource-usage", "-c", "kernels.hip", "-o", "/tmp/kernels_ru.o"]
 out = subprocess.run(cmd, cwd=src, capture_output=True, text=True).stderr
+# (kernels.hip is two translation units: the phase kernels -- FWD / UPD / MID -- are the second, see the Makefile)
+out += subprocess.run(cmd[:-4] + ["-DFW_PHASE_TU"] + cmd[-4:], cwd=src, capture_output=True, text=True).stderr
 rows, cur = [], None
 for line in out.splitlines():
     m = re.search(r"remark:\s+(.*?)(?: \[-Rpass)", line)
@@ -19,7 +21,7 @@ for line in out.splitlines():
         k, v = t.split(":", 1)
         cur[k.strip()] = v.strip()
 dem = subprocess.run(["c++filt"], input="\n".join(r["name"] for r in rows), capture_output=True, text=True).stdout.splitlines()
-print("# hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -Rpass-analysis=kernel-resource-usage -c kernels.hip   (scripts/kernel_resource_usage.py)")
+print("# hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -Rpass-analysis=kernel-resource-usage -c kernels.hip, then the same with -DFW_PHASE_TU   (scripts/kernel_resource_usage.py)")
 print("# template arguments: fw_example_kernel_r<OPT (100 SGD / 200 AdagradFlex / 300 AdagradLUT), COH (updating launch), MAXR, WIN (chained update path), NC (16-byte chunks per row)>")
 print("#                     fw_example_kernel<VEC, OPT, COH, PH (0 fused / 1 FWD / 3 UPD), NN (deep head)>")
 print("# kernel, VGPRs, AGPRs, scratch bytes/lane, occupancy waves/SIMD, SGPR spills (to VGPR lanes), VGPR spills, static LDS")
