@@ -2026,7 +2026,12 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
     constexpr int UA = FW_UA;  // accumulator rows in flight per wave in the update phase
     constexpr int UO = FW_UO;  // overflow rows (w + acc) in flight per wave
     extern __shared__ __align__(16) unsigned char smem[];
-    const bool use_lut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global;
+    // Single-chunk rows (configs B / C): the AdaGrad LUT is ALWAYS the LDS copy, decided at compile time -- s.lut is then an LDS pointer the
+    // compiler can see through (ds_read_b32).  As a run-time choice between the LDS copy and the global table the pointer was generic: every
+    // lookup a flat_load, and a flat access makes the wave wait for vmcnt(0) AND lgkmcnt(0) -- i.e. for the acknowledgement of every row
+    // store issued before it.  (launch_example_kernel clears lut_global for these launches so that the host sizes the LDS the same way.)
+    constexpr bool kLdsLut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && NC == 1;
+    const bool use_lut = kLdsLut || ((OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global);
     size_t off[23];
     lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut ? 1 : 0, p.records ? p.max_rec : 0,
                p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off);
@@ -2439,6 +2444,7 @@ hipError_t launch_example_kernel(const KernelParams &p_in, int optimizer, bool c
     if (p_in.n_examples == 0) return hipSuccess;
     KernelParams p = p_in;
     const bool v2 = uses_resident_kernel(p, threads);
+    if (v2 && p.R <= 64 * 4 && p.update) p.lut_global = 0;  // (the v2 kernel's single-chunk instantiations keep the LUT in LDS: see kLdsLut)
     resolve_row_mode(p, threads);  // (idempotent: run_batch has normally done it already, to size the LDS)
     const size_t lds = example_kernel_lds_bytes(p, optimizer);
     // 16-byte row vectors need k % 4 == 0: then R % 4 == 0 and hash & mask is a multiple of next_pow2(k) >= 4
