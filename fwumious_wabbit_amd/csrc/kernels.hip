@@ -30,6 +30,12 @@
 #include "fwgpu_device.h"
 #include <cstdlib>
 
+#ifndef FW_PLAIN_GATHER  // A/B builds: 1 = the v2 kernel's gather reads w through L2 (plain loads) in updating launches too
+#define FW_PLAIN_GATHER 0
+#endif
+#ifndef FW_PLAIN_UPD_LOADS  // A/B builds: 1 = the v2 kernel's update phase reads acc (and re-reads w) through L2 as well; stores stay device-scope
+#define FW_PLAIN_UPD_LOADS 0
+#endif
 namespace fwgpu {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -1223,9 +1229,9 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
             av[u][c] = wv[u][c];
             if (nb[u] > (uint32_t)c * 1024u) {                    // wave-uniform
                 const uint32_t fl = hh[u] - (sb[u] >> 2);         // float index of the window start
-                wv[u][c] = Vec<4>::template load<AUX>(make_rsrc(p.ffm_w + fl, nb[u]), c * 1024 + lane * 16);
+                wv[u][c] = Vec<4>::template load<(FW_PLAIN_UPD_LOADS ? kAuxPlain : AUX)>(make_rsrc(p.ffm_w + fl, nb[u]), c * 1024 + lane * 16);
                 if (OPT != FWGPU_OPT_SGD)
-                    av[u][c] = Vec<4>::template load<AUX>(make_rsrc(p.ffm_acc + fl, nb[u]), c * 1024 + lane * 16);
+                    av[u][c] = Vec<4>::template load<(FW_PLAIN_UPD_LOADS ? kAuxPlain : AUX)>(make_rsrc(p.ffm_acc + fl, nb[u]), c * 1024 + lane * 16);
             }
         }
     }
@@ -2141,7 +2147,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
             rows[sl] = Vec<VEC>::zero();
             if ((uint32_t)sl < cnt) {
                 const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[lo + sl]);
-                rows[sl] = Vec<VEC>::template load<AUX>(make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
+                rows[sl] = Vec<VEC>::template load<(FW_PLAIN_GATHER ? kAuxPlain : AUX)>(make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
             }
         }
         {
@@ -2205,7 +2211,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
 #ifdef FW_ABL_PLAIN_GATHER
                             r[u][c] = Vec<VEC>::template load<kAuxPlain>(make_rsrc(p.ffm_w + h, R * 4), e0c[c] * 4);
 #else
-                            r[u][c] = Vec<VEC>::template load<AUX>(make_rsrc(p.ffm_w + h, R * 4), e0c[c] * 4);
+                            r[u][c] = Vec<VEC>::template load<(FW_PLAIN_GATHER ? kAuxPlain : AUX)>(make_rsrc(p.ffm_w + h, R * 4), e0c[c] * 4);
 #endif
                         }
                     }
@@ -2311,7 +2317,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                             const uint32_t i = lo + g0 + u;
                             if (!(s.e_fld[i] & kResSkip)) {
                                 const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[i]);
-                                av[u] = Vec<VEC>::template load<AUX>(make_rsrc(p.ffm_acc + h, R * 4), e0 * 4);
+                                av[u] = Vec<VEC>::template load<(FW_PLAIN_UPD_LOADS ? kAuxPlain : AUX)>(make_rsrc(p.ffm_acc + h, R * 4), e0 * 4);
                             }
                         }
                     }
