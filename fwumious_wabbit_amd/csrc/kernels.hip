@@ -33,6 +33,9 @@
 #ifndef FW_PLAIN_GATHER  // A/B builds: 1 = the v2 kernel's gather reads w through L2 (plain loads) in updating launches too
 #define FW_PLAIN_GATHER 0
 #endif
+#ifndef FW_PLAIN_STORES  // A/B builds: 1 = the v2 kernel's row stores are plain (write-back L2, flushed at the end of the launch) instead of device-scope write-through
+#define FW_PLAIN_STORES 0
+#endif
 #ifndef FW_PLAIN_UPD_LOADS  // A/B builds: 1 = the v2 kernel's update phase reads acc (and re-reads w) through L2 as well; stores stay device-scope
 #define FW_PLAIN_UPD_LOADS 0
 #endif
@@ -1297,11 +1300,11 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
 #ifdef FW_ABL_NO_STORE
             if (wn[0] == 123.456f && an[1] == 654.321f)
 #endif
-            Vec<4>::template store<AUX>(wn, make_rsrc(p.ffm_w + fl, nb[u]), c * 1024 + lane * 16);
+            Vec<4>::template store<(FW_PLAIN_STORES ? kAuxPlain : AUX)>(wn, make_rsrc(p.ffm_w + fl, nb[u]), c * 1024 + lane * 16);
 #ifdef FW_ABL_NO_STORE
             if (wn[0] == 123.456f && an[1] == 654.321f)
 #endif
-            if (OPT != FWGPU_OPT_SGD) Vec<4>::template store<AUX>(an, make_rsrc(p.ffm_acc + fl, nb[u]), c * 1024 + lane * 16);
+            if (OPT != FWGPU_OPT_SGD) Vec<4>::template store<(FW_PLAIN_STORES ? kAuxPlain : AUX)>(an, make_rsrc(p.ffm_acc + fl, nb[u]), c * 1024 + lane * 16);
         }
     }
 #ifdef FW_PROF_UPD
@@ -2345,9 +2348,9 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                                     av[u][j] = acc;
                                     wv[j] = wv[j] - upd;  // block_ffm.rs:282
                                 }
-                                Vec<VEC>::template store<AUX>(wv, make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
+                                Vec<VEC>::template store<(FW_PLAIN_STORES ? kAuxPlain : AUX)>(wv, make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
                                 if (OPT != FWGPU_OPT_SGD)
-                                    Vec<VEC>::template store<AUX>(av[u], make_rsrc(p.ffm_acc + h, R * 4), e0 * 4);
+                                    Vec<VEC>::template store<(FW_PLAIN_STORES ? kAuxPlain : AUX)>(av[u], make_rsrc(p.ffm_acc + h, R * 4), e0 * 4);
                             }
                         }
                     }
