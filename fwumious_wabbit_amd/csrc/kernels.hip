@@ -30,13 +30,24 @@
 #include "fwgpu_device.h"
 #include <cstdlib>
 
-#ifndef FW_PLAIN_GATHER  // A/B builds: 1 = the v2 kernel's gather reads w through L2 (plain loads) in updating launches too
+// Cache policy of the v2 kernel's FFM row traffic in updating launches (A/B macros; profiles/r03_rejected.txt has every combination measured):
+//   * WEIGHT rows are stored PLAIN -- write-back through the XCD's L2, flushed when the launch ends -- since the end of round 3: the L2 combines the
+//     row's 64 B write-through requests into whole-line bursts, +9.5 % examples/s (5.32 against 4.86 M, roofline.frac 0.515), and the hold-out loss over
+//     9.8 M examples is the same or better (0.632 / 0.629 against 0.634 / 0.629).  Other XCDs see the row when the line leaves this XCD's L2; what a
+//     write-back clobbers is the lines the row touches rather than its floats -- for the weights that is more of the damping the kept rows already are.
+//   * ACCUMULATOR rows stay device-scope write-through: written back late they come out smaller than they are, the steps larger, and the loss suffers
+//     (0.638-0.639 against 0.629-0.634); the trainer protocol test that compares WHICH accumulators were touched fails on it as well.
+//   * loads stay device-scope (plain loads: +0.5 %, no better loss).
+#ifndef FW_PLAIN_STORES_W
+#define FW_PLAIN_STORES_W 1
+#endif
+#ifndef FW_PLAIN_STORES_ACC
+#define FW_PLAIN_STORES_ACC 0
+#endif
+#ifndef FW_PLAIN_GATHER  // 1 = the gather reads w through L2 (plain loads) in updating launches too
 #define FW_PLAIN_GATHER 0
 #endif
-#ifndef FW_PLAIN_STORES  // A/B builds: 1 = the v2 kernel's row stores are plain (write-back L2, flushed at the end of the launch) instead of device-scope write-through
-#define FW_PLAIN_STORES 0
-#endif
-#ifndef FW_PLAIN_UPD_LOADS  // A/B builds: 1 = the v2 kernel's update phase reads acc (and re-reads w) through L2 as well; stores stay device-scope
+#ifndef FW_PLAIN_UPD_LOADS  // 1 = the update phase reads acc (and re-reads w) through L2 as well
 #define FW_PLAIN_UPD_LOADS 0
 #endif
 namespace fwgpu {
@@ -1300,11 +1311,11 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
 #ifdef FW_ABL_NO_STORE
             if (wn[0] == 123.456f && an[1] == 654.321f)
 #endif
-            Vec<4>::template store<(FW_PLAIN_STORES ? kAuxPlain : AUX)>(wn, make_rsrc(p.ffm_w + fl, nb[u]), c * 1024 + lane * 16);
+            Vec<4>::template store<(FW_PLAIN_STORES_W ? kAuxPlain : AUX)>(wn, make_rsrc(p.ffm_w + fl, nb[u]), c * 1024 + lane * 16);
 #ifdef FW_ABL_NO_STORE
             if (wn[0] == 123.456f && an[1] == 654.321f)
 #endif
-            if (OPT != FWGPU_OPT_SGD) Vec<4>::template store<(FW_PLAIN_STORES ? kAuxPlain : AUX)>(an, make_rsrc(p.ffm_acc + fl, nb[u]), c * 1024 + lane * 16);
+            if (OPT != FWGPU_OPT_SGD) Vec<4>::template store<(FW_PLAIN_STORES_ACC ? kAuxPlain : AUX)>(an, make_rsrc(p.ffm_acc + fl, nb[u]), c * 1024 + lane * 16);
         }
     }
 #ifdef FW_PROF_UPD
@@ -2348,9 +2359,9 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                                     av[u][j] = acc;
                                     wv[j] = wv[j] - upd;  // block_ffm.rs:282
                                 }
-                                Vec<VEC>::template store<(FW_PLAIN_STORES ? kAuxPlain : AUX)>(wv, make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
+                                Vec<VEC>::template store<(FW_PLAIN_STORES_W ? kAuxPlain : AUX)>(wv, make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
                                 if (OPT != FWGPU_OPT_SGD)
-                                    Vec<VEC>::template store<(FW_PLAIN_STORES ? kAuxPlain : AUX)>(av[u], make_rsrc(p.ffm_acc + h, R * 4), e0 * 4);
+                                    Vec<VEC>::template store<(FW_PLAIN_STORES_ACC ? kAuxPlain : AUX)>(av[u], make_rsrc(p.ffm_acc + h, R * 4), e0 * 4);
                             }
                         }
                     }
