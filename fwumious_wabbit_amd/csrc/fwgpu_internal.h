@@ -108,6 +108,10 @@ struct KernelParams {
     float lr_rate, lr_minus_power_t;    // SGD / AdagradFlex parameters of the LR block
     float ffm_rate, ffm_minus_power_t;  // ... of the FFM block
     int32_t lut_global;                 // 1: AdaGrad LUT read from global memory (through L1) instead of an LDS copy
+    int32_t store_policy;               // hogwild launches of the v2 window kernel: how FFM row stores reach memory (kernels.hip "store policy"): 0 = both tables
+                                        // device-scope write-through, 1 = weights write-back through the XCD's L2, 2 = both tables write-back
+    uint32_t wb_flush_every;            // policies 1 / 2: a workgroup writes its XCD's dirty L2 lines back (buffer_wbl2 sc1) every this many of its examples (0: never)
+    int32_t prefetch;                   // record batches on the v2 kernel: example n+1's record is copied to LDS while example n is in its dot / update phases
     uint32_t *work;                     // next example to process (zeroed before every launch)
     uint32_t host_cus, host_wgs_cap, host_grid_cap;    // host side only: persistent grid = occupancy x CUs (capped), when launched with grid 0
     int32_t kernel_version;             // 0 = auto, 1 = force the v1 kernel, 2 = v2 where applicable
@@ -171,6 +175,9 @@ struct LaunchConfig {
     int32_t window = 1;              // whole-line FFM row updates: 0 off, 1 auto (tables > Infinity Cache), 2 always (debug option 2)
     int32_t no_chain = 0;            // debug option 3
     uint32_t hot_lr_every = 1;       // debug option 4: hot LR entry route (0 off, 1 atomics per example, n>1 weight deltas pending n examples)
+    int32_t store_policy = -1;       // debug option 5: FFM row store policy of hogwild launches (-1: the build's default, kDefaultStorePolicy)
+    int32_t wb_flush_every = -1;     // debug option 6: write-back interval of policies 1 / 2 in examples per workgroup (-1: default, 0: never)
+    int32_t prefetch = 1;            // debug option 7: next-record prefetch of the v2 kernel (A/B runs)
     bool threads_set = false;
     uint32_t max_in_flight = 0;  // cap on the persistent grid = examples processed concurrently (0: what the device holds)  // fwgpu_set_launch chose the workgroup size: no automatic choice
 };

@@ -30,25 +30,24 @@
 #include "fwgpu_device.h"
 #include <cstdlib>
 
-// Cache policy of the v2 kernel's FFM row traffic in updating launches (A/B macros; profiles/r03_rejected.txt has every combination measured):
-//   * WEIGHT rows are stored PLAIN -- write-back through the XCD's L2, flushed when the launch ends -- since the end of round 3: the L2 combines the
-//     row's 64 B write-through requests into whole-line bursts, +9.5 % examples/s (5.32 against 4.86 M, roofline.frac 0.515), and the hold-out loss over
-//     9.8 M examples is the same or better (0.632 / 0.629 against 0.634 / 0.629).  Other XCDs see the row when the line leaves this XCD's L2; what a
-//     write-back clobbers is the lines the row touches rather than its floats -- for the weights that is more of the damping the kept rows already are.
-//   * ACCUMULATOR rows stay device-scope write-through: written back late they come out smaller than they are, the steps larger, and the loss suffers
-//     (0.638-0.639 against 0.629-0.634); the trainer protocol test that compares WHICH accumulators were touched fails on it as well.
-//   * loads stay device-scope (plain loads: +0.5 %, no better loss).
-#ifndef FW_PLAIN_STORES_W
-#define FW_PLAIN_STORES_W 1
+// Store policy of the v2 kernel's FFM row traffic in HOGWILD launches (template argument POL of fw_example_kernel_r, chosen per launch from
+// KernelParams::store_policy; fwgpu_debug_set_option(r, 5, policy) / FWGPU_STORE_POLICY select it at run time, tests/test_gpu_conservation.py
+// measures what each policy does to the steps of rows that many concurrent examples hold):
+//   0  both tables device-scope write-through (buffer_store ... sc1): every 64 B request goes to the memory side and is acknowledged from there;
+//   1  WEIGHT rows write-back through the XCD's L2, accumulators write-through (round 3's shipped build: +9.5 % examples/s);
+//   2  BOTH tables write-back (the fastest; round 3 measured 0.55-0.56 of the HBM peak with it).
+// A write-back line is visible to the other seven XCDs when it leaves this XCD's L2.  Cold lines leave within microseconds (an XCD's 4 MB L2 turns
+// over every ~16 us at this kernel's write rate); a line that is re-touched before it is evicted -- the head rows of a Zipf field -- would stay
+// dirty for the whole launch, each XCD stepping a private copy.  KernelParams::wb_flush_every bounds that window: every that many examples a
+// workgroup issues ONE `buffer_wbl2 sc1` (write back all dirty lines of this XCD's L2; lines stay valid), staggered over the workgroups, so
+// that an XCD's L2 is written back every few microseconds whatever the rows' popularity.  All loads stay device-scope (sc1: L1 bypassed, served by
+// the L2 or, for lines another XCD has written through, by the memory side).
+// In-order launches (one workgroup = one XCD) are exact under every policy; the launch's end writes everything back.
+#ifndef FW_DEFAULT_STORE_POLICY
+#define FW_DEFAULT_STORE_POLICY 1
 #endif
-#ifndef FW_PLAIN_STORES_ACC
-#define FW_PLAIN_STORES_ACC 0
-#endif
-#ifndef FW_PLAIN_GATHER  // 1 = the gather reads w through L2 (plain loads) in updating launches too
-#define FW_PLAIN_GATHER 0
-#endif
-#ifndef FW_PLAIN_UPD_LOADS  // 1 = the update phase reads acc (and re-reads w) through L2 as well
-#define FW_PLAIN_UPD_LOADS 0
+#ifndef FW_DEFAULT_WB_FLUSH_EVERY
+#define FW_DEFAULT_WB_FLUSH_EVERY 0
 #endif
 namespace fwgpu {
 
@@ -170,8 +169,14 @@ struct Lds {
     uint32_t *tcnt;           // per (field,namespace) pair and per combo: entry count, then exclusive offset
     uint32_t *l_combo;        // combo slot of each LR entry (deep head only)
     float *nn;                // deep-head scratch: x[X], xg[X], h[sum_width], m[sum_width], l_prod[max_lr]
-    uint32_t *ctr;            // 8 counters, then 3 floats: the hot LR entry's acc snapshot, pending weight delta, pending acc delta
+    uint32_t *ctr;            // 8 counters, then 3 floats: the hot LR entry's acc snapshot, pending weight delta, pending acc delta; [16..] see kCtr*
+    uint32_t *rec_next;       // v2 kernel, record batches: the NEXT example's record, copied from HBM while this example is in its dot / update phases
 };
+// ctr[] slots of the v2 kernel's prefetch and write-back bookkeeping
+constexpr int kCtrNext = 16;      // the next example's ticket, published to all threads by the post-gather barrier
+constexpr int kCtrPfLen = 17;     // words of the next example's record that sit in rec_next (0: not prefetched)
+constexpr int kCtrWbCount = 18;   // examples of this workgroup since its last buffer_wbl2
+constexpr int kCtrWbEvery = 19;   // KernelParams::wb_flush_every, or 0 when this launch never writes back (in-order launches, policy 0)
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
@@ -296,7 +301,8 @@ __device__ __forceinline__ float lr_forward_weight(const KernelParams &p, const 
 }
 
 __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t max_ffm, uint32_t max_lr, uint32_t n_luts,
-                                             uint32_t max_rec, uint32_t tr_items, uint32_t nn_floats, bool chain, size_t *off /*[23]*/) {
+                                             uint32_t max_rec, uint32_t tr_items, uint32_t nn_floats, bool chain, size_t *off /*[23]*/,
+                                             uint32_t pf_words = 0) {
     size_t o = 0;
     size_t R = (size_t)F * k;
     off[0] = o; o = align16(o + 4 * F * R);
@@ -310,7 +316,7 @@ __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t ma
     off[8] = o; o = align16(o + 4 * (size_t)F);
     off[9] = o; o = align16(o + 4 * (size_t)F);
     off[10] = o; o = align16(o + 4 * 3 * 16);
-    off[11] = o; o = align16(o + 4 * 16);  // ctr[8] + hot LR entry state (hot_lr_*)
+    off[11] = o; o = align16(o + 4 * 32);  // ctr[8] + hot LR entry state (hot_lr_*) + the v2 kernel's prefetch / write-back slots (kCtr*)
     off[12] = o; o = align16(o + 4 * (size_t)F);
     // The record copy and the two hash sets are only alive during the stage phase, T only from the end of the stage phase on:
     // when they fit they live INSIDE T's region (config C: 6.4 KB of 28.8 KB), which is what lets a third workgroup fit a CU.
@@ -333,6 +339,7 @@ __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t ma
     off[21] = o; o = align16(o + 4 * (size_t)max_lr);
     off[17] = o; o = align16(o + (nn_floats ? 4 * (size_t)max_lr : 0));
     off[18] = o; o = align16(o + 4 * (size_t)nn_floats);
+    off[22] = o; o = align16(o + 4 * (size_t)pf_words);  // rec_next (outside T's region: it is written while T is alive)
     return o;
 }
 
@@ -410,14 +417,22 @@ struct StageTicker {
 // Must be called by every thread of the workgroup (it contains barriers).
 template <bool CTX = true>  // CTX: the launch may carry a serving context cache (read-only launches only)
 __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const Lds &s, const SetGeom &g, uint32_t ex,
-                                                  int tid, int bd, unsigned long long *tick_out = nullptr) {
+                                                  int tid, int bd, unsigned long long *tick_out = nullptr, uint32_t pf_len = 0) {
     StageTicker tk{tick_out, tick_out ? __builtin_amdgcn_s_memtime() : 0ull};
     const int lane = tid & 63, wave = tid >> 6;
     const uint32_t F = p.F, R = p.R;
     StageOut o;
     const uint32_t *grec = nullptr;
     uint32_t rec_len = 0, fo = 0, lo = 0;
-    if (p.records) {
+    if (p.records && pf_len) {
+        // (v2 kernel) the record is in LDS already: copied there during the previous example's dot phase, so that this stage phase starts
+        // without a memory round trip -- and without waiting for the previous example's row stores to be acknowledged, which the first
+        // vmcnt wait of a stage phase that loads from HBM does
+        rec_len = pf_len;
+        o.label = (float)s.rec_next[1];
+        o.imp = __uint_as_float(s.rec_next[2]);
+        o.nf = o.nl = 0;
+    } else if (p.records) {
         const uint64_t r0 = p.rec_off[ex];
         grec = p.records + r0;
         // gathered batches (sharded multi-GPU step) have gaps between the ranks' records: the record carries its own
@@ -446,11 +461,16 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
         s.fend[i] = 0;
     }
     if (tid == 0) {
-        s.ctr[0] = 0;  // next field to gather (v1)
-        s.ctr[1] = 0;  // some FFM rows of this example overlap an earlier row (exact)
-        s.ctr[2] = 0;  // pre-filter: rows MAY overlap
-        s.ctr[3] = 0;  // duplicate LR hashes in this example
-        s.ctr[14] = 0;  // deep head: LR entries not grouped by combo slot (nn_forward)
+        // (the zero is made opaque: left alone the compiler keeps a four-register zero vector alive across the whole example loop for this one
+        // ds_write_b128, spills it in the 128-register kernel and reloads it from scratch HERE -- behind an s_waitcnt vmcnt(0) that drains
+        // wave 0's row stores at the top of every stage phase)
+        uint32_t zero = 0;
+        asm volatile("" : "+v"(zero));
+        s.ctr[0] = zero;  // next field to gather (v1)
+        s.ctr[1] = zero;  // some FFM rows of this example overlap an earlier row (exact)
+        s.ctr[2] = zero;  // pre-filter: rows MAY overlap
+        s.ctr[3] = zero;  // duplicate LR hashes in this example
+        s.ctr[14] = zero;  // deep head: LR entries not grouped by combo slot (nn_forward)
     }
     if (do_update) {
         for (uint32_t i = tid; i < g.setf_n; i += bd) {
@@ -475,7 +495,10 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
     } else {
         const DevTranslator &t = p.tr;
         const uint32_t NP = t.n_pairs, NC = t.n_combos;
-        for (uint32_t i = tid; i < rec_len; i += bd) s.rec[i] = grec[i];
+        if (pf_len)
+            for (uint32_t i = tid; i < rec_len; i += bd) s.rec[i] = s.rec_next[i];
+        else
+            for (uint32_t i = tid; i < rec_len; i += bd) s.rec[i] = grec[i];
         const uint32_t *ctx_rec = nullptr;
         if (CTX && p.ctx_rec) {  // candidate-only records: the context's record sits behind the candidate's in LDS
             ctx_rec = s.rec + rec_len;
@@ -701,7 +724,8 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
 size_t example_kernel_lds_bytes(const KernelParams &p, int optimizer) {
     size_t off[23];
     return lds_layout(p.F, p.k, p.max_ffm, p.max_lr, (optimizer == FWGPU_OPT_ADAGRAD_LUT && p.update && !p.lut_global) ? 1 : 0,
-                      p.records ? p.max_rec : 0, p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off);
+                      p.records ? p.max_rec : 0, p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off,
+                      (p.records && p.prefetch) ? p.max_rec : 0);
 }
 #endif
 
@@ -1208,7 +1232,7 @@ __device__ __forceinline__ void update_rows(const KernelParams &p, const Lds &s,
 // device memory; with acc placed away from w (regressor.cpp place_ffm_acc) the float-granular accesses of the same code path
 // (sb = 0, nb = 4R: exactly the row) are as fast, and the race stays at the float.  The duplicate-row chains below are what
 // this path keeps in both cases.
-template <int OPT, int AUX, int U, int NCH>
+template <int OPT, int AUX, int U, int NCH, int AUX_SW = AUX, int AUX_SA = AUX>
 __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds &s, const uint32_t (&idx)[U], float g,
                                                 int lane, uint32_t nf, const float *gpair = nullptr) {
     const uint32_t R = p.R, k = p.k, ksh = p.k_log2;
@@ -1243,9 +1267,9 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
             av[u][c] = wv[u][c];
             if (nb[u] > (uint32_t)c * 1024u) {                    // wave-uniform
                 const uint32_t fl = hh[u] - (sb[u] >> 2);         // float index of the window start
-                wv[u][c] = Vec<4>::template load<(FW_PLAIN_UPD_LOADS ? kAuxPlain : AUX)>(make_rsrc(p.ffm_w + fl, nb[u]), c * 1024 + lane * 16);
+                wv[u][c] = Vec<4>::template load<AUX>(make_rsrc(p.ffm_w + fl, nb[u]), c * 1024 + lane * 16);
                 if (OPT != FWGPU_OPT_SGD)
-                    av[u][c] = Vec<4>::template load<(FW_PLAIN_UPD_LOADS ? kAuxPlain : AUX)>(make_rsrc(p.ffm_acc + fl, nb[u]), c * 1024 + lane * 16);
+                    av[u][c] = Vec<4>::template load<AUX>(make_rsrc(p.ffm_acc + fl, nb[u]), c * 1024 + lane * 16);
             }
         }
     }
@@ -1311,11 +1335,11 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
 #ifdef FW_ABL_NO_STORE
             if (wn[0] == 123.456f && an[1] == 654.321f)
 #endif
-            Vec<4>::template store<(FW_PLAIN_STORES_W ? kAuxPlain : AUX)>(wn, make_rsrc(p.ffm_w + fl, nb[u]), c * 1024 + lane * 16);
+            Vec<4>::template store<AUX_SW>(wn, make_rsrc(p.ffm_w + fl, nb[u]), c * 1024 + lane * 16);
 #ifdef FW_ABL_NO_STORE
             if (wn[0] == 123.456f && an[1] == 654.321f)
 #endif
-            if (OPT != FWGPU_OPT_SGD) Vec<4>::template store<(FW_PLAIN_STORES_ACC ? kAuxPlain : AUX)>(an, make_rsrc(p.ffm_acc + fl, nb[u]), c * 1024 + lane * 16);
+            if (OPT != FWGPU_OPT_SGD) Vec<4>::template store<AUX_SA>(an, make_rsrc(p.ffm_acc + fl, nb[u]), c * 1024 + lane * 16);
         }
     }
 #ifdef FW_PROF_UPD
@@ -1395,7 +1419,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
     const bool use_lut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global;
     size_t off[23];
     lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut ? 1 : 0, p.records ? p.max_rec : 0,
-               p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off);
+               p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off, (p.records && p.prefetch) ? p.max_rec : 0);
     Lds s;
     s.T = reinterpret_cast<float *>(smem + off[0]);
     s.selfw = reinterpret_cast<float *>(smem + off[1]);
@@ -1418,6 +1442,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
     s.tcnt = reinterpret_cast<uint32_t *>(smem + off[16]);
     s.l_combo = reinterpret_cast<uint32_t *>(smem + off[17]);
     s.nn = reinterpret_cast<float *>(smem + off[18]);
+    s.rec_next = reinterpret_cast<uint32_t *>(smem + off[22]);
     SetGeom geom;
     geom.setf_n = set_size(p.max_ffm);
     geom.setl_n = set_size(p.max_lr);
@@ -2033,7 +2058,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #endif
 // NC = 16-byte chunks per lane and row: 1 for rows of up to 256 floats (config C: 240), 2 for rows of up to 512 floats (k = 16 with 30
 // fields: 480).  Two-chunk rows keep T alone at 57.6 KB of LDS, so two workgroups share a CU and the register budget is 128 VGPRs.
-template <int OPT, bool COH, int MAXR, bool WIN, int NC = 1>
+template <int OPT, bool COH, int MAXR, bool WIN, int NC = 1, int POL = FW_DEFAULT_STORE_POLICY>
 #ifndef FW_LB_WAVES_WIN  // the window path (config C's updating launches): FOUR waves per SIMD = two workgroups per CU, 128 registers -- room for
 #define FW_LB_WAVES_WIN 4  // 14 kept rows per wave without a spill; faster AND better than three workgroups with 8 kept rows
 #endif
@@ -2043,6 +2068,8 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
     typedef f4 V;
     constexpr int VEC = 4;
     constexpr int AUX = COH ? kAuxSc1 : kAuxPlain;
+    constexpr int AUX_SW = (COH && POL < 1) ? kAuxSc1 : kAuxPlain;  // weight-row stores (store policy: top of this file)
+    constexpr int AUX_SA = (COH && POL < 2) ? kAuxSc1 : kAuxPlain;  // accumulator-row stores
     constexpr int UA = FW_UA;  // accumulator rows in flight per wave in the update phase
     constexpr int UO = FW_UO;  // overflow rows (w + acc) in flight per wave
     extern __shared__ __align__(16) unsigned char smem[];
@@ -2054,7 +2081,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
     const bool use_lut = kLdsLut || ((OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global);
     size_t off[23];
     lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut ? 1 : 0, p.records ? p.max_rec : 0,
-               p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off);
+               p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off, (p.records && p.prefetch) ? p.max_rec : 0);
     Lds s;
     s.T = reinterpret_cast<float *>(smem + off[0]);
     s.selfw = reinterpret_cast<float *>(smem + off[1]);
@@ -2077,6 +2104,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
     s.tcnt = reinterpret_cast<uint32_t *>(smem + off[16]);
     s.l_combo = reinterpret_cast<uint32_t *>(smem + off[17]);
     s.nn = reinterpret_cast<float *>(smem + off[18]);
+    s.rec_next = reinterpret_cast<uint32_t *>(smem + off[22]);
     SetGeom geom;
     geom.setf_n = set_size(p.max_ffm);
     geom.setl_n = set_size(p.max_lr);
@@ -2086,6 +2114,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
 
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = bd >> 6;
+    constexpr int kPfMax = 2;  // words of the next record a thread carries through the dot phase (records of up to kPfMax * blockDim words are prefetched)
     const uint32_t F = p.F, k = p.k, R = p.R;
     // this lane's 4 floats of a row's chunk c: elements [e0, e0+4) = slot z, offset kk0
     uint32_t e0c[NC], zc[NC], kkc[NC];
@@ -2106,6 +2135,10 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
     else
         s.lut = const_cast<float *>(p.lut_ffm);  // LUT read through L1 (the sc1 row traffic bypasses L1)
 
+    // Per-phase shader-clock stamps (fwgpu_debug_phase_ticks) exist in -DFW_TICKS builds only (scripts/perf_probe.py builds its own library): in the
+    // shipped kernel the stamps' atomics made the compiler drain every outstanding store at the top of every example (an s_waitcnt vmcnt(0) behind
+    // the loop-top barrier), which is exactly the wait the record prefetch below is there to remove.
+#ifdef FW_TICKS
     unsigned long long tk_last = 0;
     const bool timing = p.ticks != nullptr && tid == 0;
 #define FW_TICK(slot)                                                 \
@@ -2115,10 +2148,18 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         tk_last = now_;                                               \
     }
     if (timing) tk_last = __builtin_amdgcn_s_memtime();
+#else
+#define FW_TICK(slot)
+#endif
 
     if (tid == 0) {
         s.ctr[6] = atomicAdd(p.work, 1u);  // examples come from a device counter: see fw_example_kernel
         hot_lr_init<COH>(p, s, true);
+        s.ctr[kCtrPfLen] = 0;
+        // write-back policies: this workgroup's turn to write its XCD's L2 back comes every wb_flush_every examples, staggered by workgroup
+        const uint32_t every = (COH && POL >= 1 && gridDim.x > 1) ? p.wb_flush_every : 0u;
+        s.ctr[kCtrWbEvery] = every;
+        s.ctr[kCtrWbCount] = every ? blockIdx.x % every : 0u;
     }
     for (;;) {
         const KernelParams &p = kp_fresh();  // (shadows the prologue's: this example's loads start here)
@@ -2127,8 +2168,12 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         const uint32_t ex = s.ctr[6];
         if (ex >= p.n_examples) break;
         FW_TICK(6);
+#ifdef FW_TICKS
         if (timing) atomicAdd(p.ticks + 7, 1ull);
-        const StageOut so = stage_example<!COH>(p, s, geom, ex, tid, bd, timing ? p.ticks : nullptr);
+        const StageOut so = stage_example<!COH>(p, s, geom, ex, tid, bd, timing ? p.ticks : nullptr, s.ctr[kCtrPfLen]);
+#else
+        const StageOut so = stage_example<!COH>(p, s, geom, ex, tid, bd, nullptr, s.ctr[kCtrPfLen]);
+#endif
         uint32_t next_ticket = 0;
         if (tid == 0) next_ticket = atomicAdd(p.work, 1u);
         const uint32_t nf = so.nf, nl = so.nl;
@@ -2161,7 +2206,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
             rows[sl] = Vec<VEC>::zero();
             if ((uint32_t)sl < cnt) {
                 const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[lo + sl]);
-                rows[sl] = Vec<VEC>::template load<(FW_PLAIN_GATHER ? kAuxPlain : AUX)>(make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
+                rows[sl] = Vec<VEC>::template load<AUX>(make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
             }
         }
         {
@@ -2222,11 +2267,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                         const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[i + u]);
 #pragma unroll
                         for (int c = 0; c < NC; ++c) {
-#ifdef FW_ABL_PLAIN_GATHER
-                            r[u][c] = Vec<VEC>::template load<kAuxPlain>(make_rsrc(p.ffm_w + h, R * 4), e0c[c] * 4);
-#else
-                            r[u][c] = Vec<VEC>::template load<(FW_PLAIN_GATHER ? kAuxPlain : AUX)>(make_rsrc(p.ffm_w + h, R * 4), e0c[c] * 4);
-#endif
+                            r[u][c] = Vec<VEC>::template load<AUX>(make_rsrc(p.ffm_w + h, R * 4), e0c[c] * 4);
                         }
                     }
                 }
@@ -2244,8 +2285,31 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
             }
 #undef FW_CONSUME
         }
+        if (tid == 0) s.ctr[kCtrNext] = next_ticket;  // (its atomic was issued before this wave's row loads: it has returned)
         __syncthreads();
         FW_TICK(2);
+        // ---------------- the NEXT example's record: HBM -> registers now, -> LDS after the dot phase.  Its stage phase then needs no memory
+        // round trip, so the acknowledgements of this example's row stores are waited for under the next stage phase's LDS work, not before it.
+        // (LDS-direct loads: no register carries the words through the dot phase -- with 14 rows kept per wave there is none to spare)
+        uint32_t pf_len = 0;
+        if (p.records && p.prefetch) {
+            const uint32_t nt = s.ctr[kCtrNext];
+            if (nt < p.n_examples) {
+                const uint64_t r0 = p.rec_off[nt];
+                const uint32_t *grec = p.records + r0;
+                pf_len = p.rec_self_len ? grec[0] : (uint32_t)(p.rec_off[nt + 1] - r0);
+                pf_len = __builtin_amdgcn_readfirstlane(pf_len);
+                if (pf_len > (uint32_t)(kPfMax * bd)) pf_len = 0;  // (a longer record is fetched by its own stage phase)
+#pragma unroll
+                for (int j = 0; j < kPfMax; ++j) {
+                    const uint32_t i = (uint32_t)(tid + j * bd);
+                    // destination = wave-uniform LDS base + lane * 4: word i of the record lands in rec_next[i]
+                    if (i < pf_len)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(grec + i),
+                                                         (__attribute__((address_space(3))) void *)(s.rec_next + (i - lane)), 4, 0, 0);
+                }
+            }
+        }
         if (!COH && p.emit_T && ex == 0) {  // setup_cache: keep this example's field sums (Regressor::setup_cache, regressor.rs:409-423)
             for (uint32_t i = tid; i < F * R; i += bd) p.emit_T[i] = s.T[i];
             for (uint32_t f = tid; f < F; f += bd) p.emit_dcf[f] = s.dcf[f];
@@ -2275,6 +2339,10 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         if (lane == 0) {
             s.red[wave] = dot;
             s.red[32 + wave] = lrs;
+        }
+        if (p.records && p.prefetch) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next record has landed in rec_next (nothing else of this wave is in flight here)
+            if (tid == 0) s.ctr[kCtrPfLen] = pf_len;
         }
         __syncthreads();
         float dot_t = 0.0f, dc_t = 0.0f, lr_t = 0.0f;
@@ -2331,7 +2399,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                             const uint32_t i = lo + g0 + u;
                             if (!(s.e_fld[i] & kResSkip)) {
                                 const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[i]);
-                                av[u] = Vec<VEC>::template load<(FW_PLAIN_UPD_LOADS ? kAuxPlain : AUX)>(make_rsrc(p.ffm_acc + h, R * 4), e0 * 4);
+                                av[u] = Vec<VEC>::template load<AUX>(make_rsrc(p.ffm_acc + h, R * 4), e0 * 4);
                             }
                         }
                     }
@@ -2359,9 +2427,9 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                                     av[u][j] = acc;
                                     wv[j] = wv[j] - upd;  // block_ffm.rs:282
                                 }
-                                Vec<VEC>::template store<(FW_PLAIN_STORES_W ? kAuxPlain : AUX)>(wv, make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
+                                Vec<VEC>::template store<AUX_SW>(wv, make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
                                 if (OPT != FWGPU_OPT_SGD)
-                                    Vec<VEC>::template store<(FW_PLAIN_STORES_ACC ? kAuxPlain : AUX)>(av[u], make_rsrc(p.ffm_acc + h, R * 4), e0 * 4);
+                                    Vec<VEC>::template store<AUX_SA>(av[u], make_rsrc(p.ffm_acc + h, R * 4), e0 * 4);
                             }
                         }
                     }
@@ -2382,7 +2450,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                     if (WIN && MAXR > 0 && i < lo + MAXR && i < hi && !(s.e_fld[i] & kRowHasChain)) idx[u] = 0xffffffffu;
                 }
                 if (WIN)
-                    update_rows_win<OPT, AUX, UO, (NC > FW_WIN_NCH ? NC : FW_WIN_NCH)>(p, s, idx, g, lane, nf);
+                    update_rows_win<OPT, AUX, UO, (NC > FW_WIN_NCH ? NC : FW_WIN_NCH), AUX_SW, AUX_SA>(p, s, idx, g, lane, nf);
                 else
                     update_rows<VEC, OPT, AUX, UO>(p, s, idx, g, lane);
             }
@@ -2395,7 +2463,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                         if (s.e_fld[i] & kRowDep) {
                             uint32_t idx[1] = {i};
                             if (WIN)
-                                update_rows_win<OPT, AUX, 1, (NC > FW_WIN_NCH ? NC : FW_WIN_NCH)>(p, s, idx, g, lane, nf);
+                                update_rows_win<OPT, AUX, 1, (NC > FW_WIN_NCH ? NC : FW_WIN_NCH), AUX_SW, AUX_SA>(p, s, idx, g, lane, nf);
                             else
                                 update_rows<VEC, OPT, AUX, 1>(p, s, idx, g, lane);
                             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -2407,6 +2475,19 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
             FW_TICK(5);
         }
         if (tid == 0) s.ctr[6] = next_ticket;  // published by the loop-top barrier
+        if (COH && POL >= 1 && tid == bd - 1) {
+            // bounded staleness of the write-back policies: this workgroup's turn to write its XCD's dirty L2 lines back (one instruction, not
+            // waited for here: it completes under the next example's stage phase)
+            const uint32_t every = s.ctr[kCtrWbEvery];
+            if (every) {
+                uint32_t c = s.ctr[kCtrWbCount] + 1;
+                if (c >= every) {
+                    c = 0;
+                    asm volatile("buffer_wbl2 sc1" ::: "memory");
+                }
+                s.ctr[kCtrWbCount] = c;
+            }
+        }
     }
     if (COH && tid == 0 && s.ctr[13]) hot_lr_flush(p, s);  // (every thread's steps are in: the loop ends on a barrier)
 #undef FW_TICK
@@ -2425,7 +2506,12 @@ static hipError_t launch_r(const KernelParams &p, uint32_t grid, uint32_t thread
         if (p.window) return launch_persistent(fw_example_kernel_r<OPT, COH, 0, true, 2>, p, grid, threads, lds, stream);
         return launch_persistent(fw_example_kernel_r<OPT, COH, 0, false, 2>, p, grid, threads, lds, stream);
     }
-    if (p.window) return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR_WIN, true>, p, grid, threads, lds, stream);
+    if (p.window) {
+        // the config-C kernel: its store policy is a launch parameter (instantiations of their own, so that the shipped policy pays nothing for the others)
+        if (COH && p.store_policy == 0) return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR_WIN, true, 1, COH ? 0 : FW_DEFAULT_STORE_POLICY>, p, grid, threads, lds, stream);
+        if (COH && p.store_policy == 2) return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR_WIN, true, 1, COH ? 2 : FW_DEFAULT_STORE_POLICY>, p, grid, threads, lds, stream);
+        return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR_WIN, true, 1, COH ? 1 : FW_DEFAULT_STORE_POLICY>, p, grid, threads, lds, stream);
+    }
     return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR, false>, p, grid, threads, lds, stream);
 }
 
@@ -2457,6 +2543,9 @@ void resolve_row_mode(KernelParams &p, uint32_t threads) {
     // chained duplicate rows: the generic kernel's update path and the whole-line path apply them from registers; the
     // register-resident variant of the v2 kernel (window off) keeps the old route (duplicates serialised in phase B)
     p.chain = (p.update && !p.no_chain && (p.window || !uses_resident_kernel(p, threads))) ? 1 : 0;
+    // the next record is prefetched by the v2 kernel's updating launches (read-only launches have no store drain to hide, and their LDS is what lets
+    // three workgroups share a CU)
+    p.prefetch = (p.prefetch && p.records && p.update && uses_resident_kernel(p, threads)) ? 1 : 0;
 }
 
 hipError_t launch_example_kernel(const KernelParams &p_in, int optimizer, bool coherent, uint32_t grid, uint32_t threads,
@@ -2465,6 +2554,8 @@ hipError_t launch_example_kernel(const KernelParams &p_in, int optimizer, bool c
     KernelParams p = p_in;
     const bool v2 = uses_resident_kernel(p, threads);
     if (v2 && p.R <= 64 * 4 && p.update) p.lut_global = 0;  // (the v2 kernel's single-chunk instantiations keep the LUT in LDS: see kLdsLut)
+    if (p.store_policy < 0) p.store_policy = FW_DEFAULT_STORE_POLICY;  // (-1: the build's default; the host side does not know the -D flags of a variant build)
+    if (p.wb_flush_every == 0xffffffffu) p.wb_flush_every = FW_DEFAULT_WB_FLUSH_EVERY;
     resolve_row_mode(p, threads);  // (idempotent: run_batch has normally done it already, to size the LDS)
     const size_t lds = example_kernel_lds_bytes(p, optimizer);
     // 16-byte row vectors need k % 4 == 0: then R % 4 == 0 and hash & mask is a multiple of next_pow2(k) >= 4

@@ -350,7 +350,7 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
     // Cache (profiles/r02_rowceil.txt: cache-resident tables write partial lines at full rate).  Small tables also are
     // where concurrent examples would meet on a line most often, so they keep float-granular writes.
     // (launch_example_kernel keeps the flag only where the whole-line path exists.)
-    p.window = r->launch.window == 2 || (r->launch.window == 1 && r->ffm_len * 8ull > (256ull << 20)) ? 1 : 0;
+    p.window = r->launch.window >= 2 || (r->launch.window == 1 && r->ffm_len * 8ull > (256ull << 20)) ? 1 : 0;  // (3: the path of large tables on a table of any size, tests)
     // Whole-line accesses pay when w and acc contend for one region of the device memory (partial-line writes are what is slow
     // then: -6.5 %); with the accumulator table placed away from the weights they buy nothing (4.64 vs 4.60 M examples/s) and
     // only widen hogwild's race from the float to the line, so they are used when asked for (option 2 = 2) or when the placement
@@ -391,6 +391,12 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
     p.tr = b->tr;
     p.kernel_version = r->launch.kernel_version;
     p.lut_global = r->launch.lut_global;
+    {   // FFM row store policy of hogwild launches and its write-back interval (kernels.hip, "store policy"); -1 / ~0 = the kernels' build default
+        static const char *env_pol = getenv("FWGPU_STORE_POLICY"), *env_wb = getenv("FWGPU_WB_FLUSH_EVERY"), *env_pf = getenv("FWGPU_PREFETCH");
+        p.store_policy = r->launch.store_policy >= 0 ? r->launch.store_policy : (env_pol ? atoi(env_pol) : -1);
+        p.wb_flush_every = r->launch.wb_flush_every >= 0 ? (uint32_t)r->launch.wb_flush_every : (env_wb ? (uint32_t)atoi(env_wb) : 0xffffffffu);
+        p.prefetch = (r->launch.prefetch && !(env_pf && env_pf[0] == '0')) ? 1 : 0;
+    }
     p.work = b->work;
     p.host_cus = r->num_cus;
     p.host_wgs_cap = r->launch.workgroups_per_cu;
@@ -784,8 +790,17 @@ int fwgpu_debug_set_option(fwgpu_regressor *r, int option, int value) {
         if (value < 0 || value > 1024) return fail(FWGPU_ERR_INVALID, "hot LR entry option: 0 .. 1024 examples");
         r->launch.hot_lr_every = (uint32_t)value;
         return FWGPU_OK;
-    case 2:  // whole-line FFM row updates: 0 off, 1 auto (tables larger than the Infinity Cache; default), 2 always
-        if (value < 0 || value > 2) return fail(FWGPU_ERR_INVALID, "window option: 0, 1 or 2");
+    case 5:  // FFM row store policy of hogwild launches: 0 write-through, 1 weights write-back, 2 both tables write-back, -1 the build's default
+        if (value < -1 || value > 2) return fail(FWGPU_ERR_INVALID, "store policy option: -1, 0, 1 or 2");
+        r->launch.store_policy = value;
+        return FWGPU_OK;
+    case 6:  // write-back interval of policies 1 / 2: a workgroup issues buffer_wbl2 every `value` of its examples (0 never, -1 the build's default)
+        if (value < -1 || value > 65536) return fail(FWGPU_ERR_INVALID, "write-back interval option: -1 .. 65536 examples");
+        r->launch.wb_flush_every = value;
+        return FWGPU_OK;
+    case 7: r->launch.prefetch = value ? 1 : 0; return FWGPU_OK;  // next-record prefetch of the v2 kernel's updating launches
+    case 2:  // whole-line FFM row updates: 0 off, 1 auto (tables larger than the Infinity Cache; default), 2 always, 3 chained path always with float-granular accesses
+        if (value < 0 || value > 3) return fail(FWGPU_ERR_INVALID, "window option: 0, 1, 2 or 3");
         r->launch.window = value;
         return FWGPU_OK;
     }

@@ -385,8 +385,21 @@ class Regressor:
     def set_whole_line_updates(self, mode):
         """update path of large models (fwgpu_debug_set_option 2): 0 = round-1 path (float-granular, repeated rows serialised);
         1 = auto, the default (tables beyond the Infinity Cache: duplicate-row chains, whole 128 B lines only when w and acc
-        contend for one memory region); 2 = chains + whole-line accesses always (kernels.hip update_rows_win)"""
+        contend for one memory region); 2 = chains + whole-line accesses always (kernels.hip update_rows_win); 3 = chains with
+        float-granular accesses always (the path of large, well-placed tables on a table of any size)"""
         check(self.L.fwgpu_debug_set_option(self.h, 2, int(mode)))
+
+    def set_store_policy(self, policy, flush_every=-1):
+        """HOGWILD launches of the large-table update path (fwgpu_debug_set_option 5 / 6): how FFM row stores reach memory -- 0 both
+        tables device-scope write-through, 1 weight rows write-back through the XCD's L2, 2 both tables write-back, -1 the build's
+        default; with 1 / 2 a workgroup writes its XCD's dirty L2 lines back every `flush_every` of its examples (0 = only when the
+        launch ends, -1 = the build's default).  kernels.hip "store policy", tests/test_gpu_conservation.py"""
+        check(self.L.fwgpu_debug_set_option(self.h, 5, int(policy)))
+        check(self.L.fwgpu_debug_set_option(self.h, 6, int(flush_every)))
+
+    def set_prefetch(self, on):
+        """updating launches copy the next example's record to LDS during the current example (fwgpu_debug_set_option 7; default on)"""
+        check(self.L.fwgpu_debug_set_option(self.h, 7, int(bool(on))))
 
     def set_hot_lr_entry(self, every):
         """HOGWILD launches (fwgpu_debug_set_option 4): the constant feature's LR entry is stepped with atomics -- the step size

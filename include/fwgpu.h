@@ -410,13 +410,20 @@ int fwgpu_debug_set_kernel_version(fwgpu_regressor *r, int version);
  * option 2: the update path of large models (k % 4 == 0, rows of at most 256 floats): 0 = float-granular row updates, rows repeated
  *   inside an example serialised on one wave (the round-1 path); 1 = automatic (default): tables beyond the Infinity Cache take the
  *   chained path (repeated rows applied by their first occurrence's wave, from registers), with whole-128-byte-line accesses only
- *   when the accumulator table could not be placed away from the weight table; 2 = chained path with whole-line accesses, always.
+ *   when the accumulator table could not be placed away from the weight table; 2 = chained path with whole-line accesses, always;
+ *   3 = chained path with float-granular accesses, always (what large tables run when the placement search succeeded, on any table).
  * option 3: value 1 = no duplicate-row chains (A/B runs).
  * option 4: HOGWILD launches step the constant feature's LR entry (in every example, feature_buffer.rs:270-276) with atomics: the
  *   step is taken at the accumulator the example's forward pass read + its own g^2, `acc += g^2` and `w -= step` are added to the
  *   table by float atomics.  value 1 (default): both per example; value n > 1: a workgroup's WEIGHT deltas stay pending in LDS for
  *   n of its examples; 0 = plain per-example read-modify-writes, which serialise on that one entry and overwrite each other.
  *   SEQUENTIAL launches never use it.
+ * option 5: store policy of the FFM row stores in HOGWILD launches of that update path: 0 = both tables device-scope write-through,
+ *   1 = weight rows write-back through the XCD's L2, 2 = both tables write-back; -1 = the build's default.  option 6: with policy
+ *   1 / 2 a workgroup writes its XCD's dirty L2 lines back every `value` of its examples (0 = only when the launch ends; -1 = the
+ *   build's default) -- the bound on how long a popular row can stay private to one XCD (DESIGN.md 4.2,
+ *   tests/test_gpu_conservation.py).  SEQUENTIAL launches are exact under every policy.
+ * option 7: value 0 = the updating launches do not prefetch the next example's record (A/B runs; default 1).
  * (The update path of option 2 = 1 / 2 keeps the first 14 rows of every wave's share of an example from the gather and writes
  *   them back as w_gather - step in HOGWILD launches: what the concurrent mode's hold-out loss rests on) */
 int fwgpu_debug_set_option(fwgpu_regressor *r, int option, int value);
