@@ -39,6 +39,7 @@ struct DevTranslator {
     const uint8_t *pair_f32;
     const uint8_t *pair_field;   // field index of each pair
     uint32_t n_combos, n_pairs, add_const, lr_mask, ffm_mask;
+    uint32_t n_members;          // combo_off[n_combos]
 };
 
 // Deep head: BlockCopy -> [BlockNeuronLayer -> BlockRELU]* -> Join -> single neuron (regressor.rs:191-320)
@@ -111,6 +112,7 @@ struct KernelParams {
     int32_t store_policy;               // hogwild launches of the v2 window kernel: how FFM row stores reach memory (kernels.hip "store policy"): 0 = both tables
                                         // device-scope write-through, 1 = weights write-back through the XCD's L2, 2 = both tables write-back
     uint32_t wb_flush_every;            // policies 1 / 2: a workgroup writes its XCD's dirty L2 lines back (buffer_wbl2 sc1) every this many of its examples (0: never)
+    int32_t tr_lds;                     // record batches on the v2 kernel: the translator's tables are read from an LDS copy (kernels.hip TrLds)
     int32_t prefetch;                   // record batches on the v2 kernel: example n+1's record is copied to LDS while example n is in its dot / update phases
     uint32_t *work;                     // next example to process (zeroed before every launch)
     uint32_t host_cus, host_wgs_cap, host_grid_cap;    // host side only: persistent grid = occupancy x CUs (capped), when launched with grid 0

@@ -35,7 +35,7 @@
 // measures what each policy does to the steps of rows that many concurrent examples hold):
 //   0  both tables device-scope write-through (buffer_store ... sc1): every 64 B request goes to the memory side and is acknowledged from there;
 //   1  WEIGHT rows write-back through the XCD's L2, accumulators write-through (round 3's shipped build: +9.5 % examples/s);
-//   2  BOTH tables write-back (the fastest; round 3 measured 0.55-0.56 of the HBM peak with it).
+//   2  BOTH tables write-back (the fastest: 0.555-0.56 of the HBM peak, profiles/r04b_policy_ab.txt).
 // A write-back line is visible to the other seven XCDs when it leaves this XCD's L2.  Cold lines leave within microseconds (an XCD's 4 MB L2 turns
 // over every ~16 us at this kernel's write rate); a line that is re-touched before it is evicted -- the head rows of a Zipf field -- would stay
 // dirty for the whole launch, each XCD stepping a private copy.  KernelParams::wb_flush_every bounds that window: every that many examples a
@@ -47,7 +47,7 @@
 #define FW_DEFAULT_STORE_POLICY 1
 #endif
 #ifndef FW_DEFAULT_WB_FLUSH_EVERY
-#define FW_DEFAULT_WB_FLUSH_EVERY 0
+#define FW_DEFAULT_WB_FLUSH_EVERY 128
 #endif
 namespace fwgpu {
 
@@ -301,8 +301,8 @@ __device__ __forceinline__ float lr_forward_weight(const KernelParams &p, const 
 }
 
 __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t max_ffm, uint32_t max_lr, uint32_t n_luts,
-                                             uint32_t max_rec, uint32_t tr_items, uint32_t nn_floats, bool chain, size_t *off /*[23]*/,
-                                             uint32_t pf_words = 0) {
+                                             uint32_t max_rec, uint32_t tr_items, uint32_t nn_floats, bool chain, size_t *off /*[24]*/,
+                                             uint32_t pf_words = 0, uint32_t tr_words = 0) {
     size_t o = 0;
     size_t R = (size_t)F * k;
     off[0] = o; o = align16(o + 4 * F * R);
@@ -340,6 +340,7 @@ __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t ma
     off[17] = o; o = align16(o + (nn_floats ? 4 * (size_t)max_lr : 0));
     off[18] = o; o = align16(o + 4 * (size_t)nn_floats);
     off[22] = o; o = align16(o + 4 * (size_t)pf_words);  // rec_next (outside T's region: it is written while T is alive)
+    off[23] = o; o = align16(o + 4 * (size_t)tr_words);  // v2 kernel: the translator's tables (TrLds)
     return o;
 }
 
@@ -414,10 +415,39 @@ struct StageTicker {
     }
 };
 
+// The translator's tables (which namespaces feed which LR combo / FFM field) as the stage phase reads them: straight from HBM (TrGlobal), or
+// from a packed copy in LDS that the v2 kernel's prologue makes (TrLds).  Through TrGlobal every lookup is a global load followed by an
+// s_waitcnt vmcnt(0) -- half a dozen dependent round trips per stage phase, and each of those waits also waits for the acknowledgement of
+// every row store the previous example's update phase has in flight; through TrLds the stage phase of a prefetched record touches no memory.
+struct TrGlobal {
+    const DevTranslator &t;
+    __device__ __forceinline__ uint32_t pair_ns(uint32_t j) const { return t.pair_ns[j]; }
+    __device__ __forceinline__ bool pair_f32(uint32_t j) const { return t.pair_f32[j] != 0; }
+    __device__ __forceinline__ uint32_t pair_field(uint32_t j) const { return t.pair_field[j]; }
+    __device__ __forceinline__ uint32_t combo_off(uint32_t c) const { return t.combo_off[c]; }
+    __device__ __forceinline__ uint32_t combo_ns(uint32_t m) const { return t.combo_ns[m]; }
+    __device__ __forceinline__ bool combo_f32(uint32_t m) const { return t.combo_f32[m] != 0; }
+    __device__ __forceinline__ float combo_w(uint32_t c) const { return t.combo_w[c]; }
+};
+struct TrLds {
+    const uint32_t *pair;  // [n_pairs]      namespace | field << 16 | f32 << 31
+    const uint32_t *coff;  // [n_combos + 1] first member of every combo
+    const uint32_t *cm;    // [n_members]    namespace | f32 << 31
+    const float *cw;       // [n_combos]     combo weight
+    __device__ __forceinline__ uint32_t pair_ns(uint32_t j) const { return pair[j] & 0xffffu; }
+    __device__ __forceinline__ bool pair_f32(uint32_t j) const { return (pair[j] >> 31) != 0; }
+    __device__ __forceinline__ uint32_t pair_field(uint32_t j) const { return (pair[j] >> 16) & 0xffu; }
+    __device__ __forceinline__ uint32_t combo_off(uint32_t c) const { return coff[c]; }
+    __device__ __forceinline__ uint32_t combo_ns(uint32_t m) const { return cm[m] & 0x7fffffffu; }
+    __device__ __forceinline__ bool combo_f32(uint32_t m) const { return (cm[m] >> 31) != 0; }
+    __device__ __forceinline__ float combo_w(uint32_t c) const { return cw[c]; }
+};
+__host__ __device__ inline uint32_t tr_lds_words(const DevTranslator &t) { return t.n_pairs + (t.n_combos + 1) + t.n_members + t.n_combos; }
+
 // Must be called by every thread of the workgroup (it contains barriers).
-template <bool CTX = true>  // CTX: the launch may carry a serving context cache (read-only launches only)
+template <bool CTX = true, class TR = TrGlobal>  // CTX: the launch may carry a serving context cache (read-only launches only)
 __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const Lds &s, const SetGeom &g, uint32_t ex,
-                                                  int tid, int bd, unsigned long long *tick_out = nullptr, uint32_t pf_len = 0) {
+                                                  int tid, int bd, const TR &tr, unsigned long long *tick_out = nullptr, uint32_t pf_len = 0) {
     StageTicker tk{tick_out, tick_out ? __builtin_amdgcn_s_memtime() : 0ull};
     const int lane = tid & 63, wave = tid >> 6;
     const uint32_t F = p.F, R = p.R;
@@ -518,10 +548,10 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
                 const uint32_t j = b0 + lane;
                 bool on = j < NP && k_nonzero(p.k);
                 if (CTX && p.ctx_cover && on) {  // features the context cache holds are not gathered again (block_ffm.rs:548, 600)
-                    const uint32_t ns = t.pair_ns[j];
+                    const uint32_t ns = tr.pair_ns(j);
                     on = !((p.ctx_cover[ns >> 5] >> (ns & 31)) & 1u);
                 }
-                const uint32_t cnt = on ? slot_count(s.rec, ctx_rec, t.pair_ns[j]) : 0;
+                const uint32_t cnt = on ? slot_count(s.rec, ctx_rec, tr.pair_ns(j)) : 0;
                 const uint32_t inc = wave_scan_incl(cnt, lane);
                 if (j < NP) ffm_base[j] = carry + inc - cnt;
                 carry += (uint32_t)__shfl((int)inc, 63, 64);
@@ -536,9 +566,9 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
             for (uint32_t b0 = 0; b0 < NC; b0 += 64) {
                 const uint32_t c = b0 + lane;
                 const bool on = c < NC && p.has_lr;
-                const uint32_t m0 = on ? t.combo_off[c] : 0, m1 = on ? t.combo_off[c + 1] : 0;
+                const uint32_t m0 = on ? tr.combo_off(c) : 0, m1 = on ? tr.combo_off(c + 1) : 0;
                 uint32_t total = on ? 1 : 0;
-                for (uint32_t m = m0; m < m1; ++m) total *= slot_count(s.rec, ctx_rec, t.combo_ns[m]);
+                for (uint32_t m = m0; m < m1; ++m) total *= slot_count(s.rec, ctx_rec, tr.combo_ns(m));
                 const uint32_t inc = wave_scan_incl(total, lane);
                 if (c < NC) lr_base[c] = carry + inc - total;
                 carry += (uint32_t)__shfl((int)inc, 63, 64);
@@ -567,10 +597,10 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
             const uint32_t j = lo_;
             uint32_t h;
             float v;
-            slot_get(s.rec, ctx_rec, t.pair_ns[j], t.pair_f32[j] != 0, e - ffm_base[j], h, v);
+            slot_get(s.rec, ctx_rec, tr.pair_ns(j), tr.pair_f32(j), e - ffm_base[j], h, v);
             s.e_hash[e] = h & t.ffm_mask;
             s.e_val[e] = v;
-            s.e_fld[e] = t.pair_field[j];
+            s.e_fld[e] = tr.pair_field(j);
         }
         // lr_buffer (feature_buffer.rs:194-276): hash = (h_prev * 16777619) ^ h_next, values multiply.  Threads are
         // taken from the top of the workgroup so that the waves busy with the ffm_buffer above are not the same ones.
@@ -583,19 +613,19 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
                 else hi_ = mid;
             }
             const uint32_t c = lo_;
-            const uint32_t m0 = t.combo_off[c], m1 = t.combo_off[c + 1];
+            const uint32_t m0 = tr.combo_off(c), m1 = tr.combo_off(c + 1);
             // digits of the entry's index within the combo, first namespace most significant (the reference's loop nesting)
             uint32_t rem = e - lr_base[c], div = lr_base[c + 1] - lr_base[c];
             uint32_t hash = 0;
             float val = 1.0f;
             for (uint32_t m = m0; m < m1; ++m) {
-                const uint32_t cm = slot_count(s.rec, ctx_rec, t.combo_ns[m]);
+                const uint32_t cm = slot_count(s.rec, ctx_rec, tr.combo_ns(m));
                 div /= cm;
                 const uint32_t q = rem / div;
                 rem -= q * div;
                 uint32_t h;
                 float v;
-                slot_get(s.rec, ctx_rec, t.combo_ns[m], t.combo_f32[m] != 0, q, h, v);
+                slot_get(s.rec, ctx_rec, tr.combo_ns(m), tr.combo_f32(m), q, h, v);
                 if (m == m0) {
                     hash = h;
                     val = v;
@@ -605,7 +635,7 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
                 }
             }
             s.l_hash[e] = hash & t.lr_mask;
-            s.l_val[e] = val * t.combo_w[c];
+            s.l_val[e] = val * tr.combo_w(c);
             if (p.nn.n_layers) s.l_combo[e] = c;
         }
         __syncthreads();
@@ -722,10 +752,10 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
 
 #ifndef FW_PHASE_TU  // (host functions live in ONE of the two translation units of this file: see the Makefile)
 size_t example_kernel_lds_bytes(const KernelParams &p, int optimizer) {
-    size_t off[23];
+    size_t off[24];
     return lds_layout(p.F, p.k, p.max_ffm, p.max_lr, (optimizer == FWGPU_OPT_ADAGRAD_LUT && p.update && !p.lut_global) ? 1 : 0,
                       p.records ? p.max_rec : 0, p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off,
-                      (p.records && p.prefetch) ? p.max_rec : 0);
+                      (p.records && p.prefetch) ? p.max_rec : 0, (p.records && p.tr_lds) ? tr_lds_words(p.tr) : 0);
 }
 #endif
 
@@ -1417,9 +1447,10 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
     constexpr int UU = FW_V1_UU;  // feature rows in flight per wave in the update phase (x2 tables)
     extern __shared__ __align__(16) unsigned char smem[];
     const bool use_lut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global;
-    size_t off[23];
+    size_t off[24];
     lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut ? 1 : 0, p.records ? p.max_rec : 0,
-               p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off, (p.records && p.prefetch) ? p.max_rec : 0);
+               p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off, (p.records && p.prefetch) ? p.max_rec : 0,
+               (p.records && p.tr_lds) ? tr_lds_words(p.tr) : 0);
     Lds s;
     s.T = reinterpret_cast<float *>(smem + off[0]);
     s.selfw = reinterpret_cast<float *>(smem + off[1]);
@@ -1507,7 +1538,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
         if (ex >= p.n_examples) break;
         FW_TICK(6);
         if (timing) tk[7] += 1;
-        const StageOut so = stage_example<kCtx>(p, s, geom, ex, tid, bd);
+        const StageOut so = stage_example<kCtx>(p, s, geom, ex, tid, bd, TrGlobal{p.tr});
         uint32_t next_ticket = 0;  // (every thread is past its read of ctr[6]: the stage phase has barriers)
         if (tid == 0) next_ticket = atomicAdd(p.work, 1u);
         const uint32_t nf = so.nf, nl = so.nl;
@@ -1875,6 +1906,7 @@ hipError_t launch_example_phase(const KernelParams &p_in, int optimizer, int pha
     if (p_in.n_examples == 0) return hipSuccess;
     KernelParams p = p_in;
     p.window = 0;  // (the generic kernel's update path)
+    p.prefetch = p.tr_lds = 0;  // (v2-only LDS regions)
     p.update = phase == 3 ? 1 : 0;
     p.chain = p.update && !p.no_chain;
     size_t lds = example_kernel_lds_bytes(p, optimizer);
@@ -2079,9 +2111,10 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
     // store issued before it.  (launch_example_kernel clears lut_global for these launches so that the host sizes the LDS the same way.)
     constexpr bool kLdsLut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && NC == 1;
     const bool use_lut = kLdsLut || ((OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global);
-    size_t off[23];
+    size_t off[24];
     lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut ? 1 : 0, p.records ? p.max_rec : 0,
-               p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off, (p.records && p.prefetch) ? p.max_rec : 0);
+               p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off, (p.records && p.prefetch) ? p.max_rec : 0,
+               (p.records && p.tr_lds) ? tr_lds_words(p.tr) : 0);
     Lds s;
     s.T = reinterpret_cast<float *>(smem + off[0]);
     s.selfw = reinterpret_cast<float *>(smem + off[1]);
@@ -2135,6 +2168,23 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
     else
         s.lut = const_cast<float *>(p.lut_ffm);  // LUT read through L1 (the sc1 row traffic bypasses L1)
 
+    // the translator's tables, packed into LDS once per workgroup (record batches; visible to all threads behind the loop-top barrier)
+    TrLds trl;
+    {
+        uint32_t *tw = reinterpret_cast<uint32_t *>(smem + off[23]);
+        const DevTranslator &t = p.tr;
+        const uint32_t NP = t.n_pairs, NCB = t.n_combos, NM = t.n_members;
+        trl.pair = tw;
+        trl.coff = tw + NP;
+        trl.cm = tw + NP + NCB + 1;
+        trl.cw = reinterpret_cast<const float *>(tw + NP + NCB + 1 + NM);
+        if (p.records) {
+            for (uint32_t j = tid; j < NP; j += bd) tw[j] = t.pair_ns[j] | ((uint32_t)t.pair_field[j] << 16) | (t.pair_f32[j] ? 0x80000000u : 0u);
+            for (uint32_t c = tid; c <= NCB; c += bd) tw[NP + c] = t.combo_off[c];
+            for (uint32_t m = tid; m < NM; m += bd) tw[NP + NCB + 1 + m] = t.combo_ns[m] | (t.combo_f32[m] ? 0x80000000u : 0u);
+            for (uint32_t c = tid; c < NCB; c += bd) tw[NP + NCB + 1 + NM + c] = __float_as_uint(t.combo_w[c]);
+        }
+    }
     // Per-phase shader-clock stamps (fwgpu_debug_phase_ticks) exist in -DFW_TICKS builds only (scripts/perf_probe.py builds its own library): in the
     // shipped kernel the stamps' atomics made the compiler drain every outstanding store at the top of every example (an s_waitcnt vmcnt(0) behind
     // the loop-top barrier), which is exactly the wait the record prefetch below is there to remove.
@@ -2170,9 +2220,9 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         FW_TICK(6);
 #ifdef FW_TICKS
         if (timing) atomicAdd(p.ticks + 7, 1ull);
-        const StageOut so = stage_example<!COH>(p, s, geom, ex, tid, bd, timing ? p.ticks : nullptr, s.ctr[kCtrPfLen]);
+        const StageOut so = stage_example<!COH>(p, s, geom, ex, tid, bd, trl, timing ? p.ticks : nullptr, s.ctr[kCtrPfLen]);
 #else
-        const StageOut so = stage_example<!COH>(p, s, geom, ex, tid, bd, nullptr, s.ctr[kCtrPfLen]);
+        const StageOut so = stage_example<!COH>(p, s, geom, ex, tid, bd, trl, nullptr, s.ctr[kCtrPfLen]);
 #endif
         uint32_t next_ticket = 0;
         if (tid == 0) next_ticket = atomicAdd(p.work, 1u);
@@ -2302,11 +2352,11 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                 if (pf_len > (uint32_t)(kPfMax * bd)) pf_len = 0;  // (a longer record is fetched by its own stage phase)
 #pragma unroll
                 for (int j = 0; j < kPfMax; ++j) {
-                    const uint32_t i = (uint32_t)(tid + j * bd);
                     // destination = wave-uniform LDS base + lane * 4: word i of the record lands in rec_next[i]
+                    const uint32_t i0 = __builtin_amdgcn_readfirstlane((uint32_t)(wave * 64 + j * bd)), i = i0 + (uint32_t)lane;
                     if (i < pf_len)
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(grec + i),
-                                                         (__attribute__((address_space(3))) void *)(s.rec_next + (i - lane)), 4, 0, 0);
+                                                         (__attribute__((address_space(3))) void *)(s.rec_next + i0), 4, 0, 0);
                 }
             }
         }
@@ -2540,12 +2590,15 @@ static bool uses_resident_kernel(const KernelParams &p, uint32_t threads) {
 // Whole-line updates and duplicate-row chains exist in the v2 kernel's update path only, and only updating launches need them.
 void resolve_row_mode(KernelParams &p, uint32_t threads) {
     p.window = (p.window && uses_resident_kernel(p, threads) && p.update && p.k_log2 != 0xffu) ? 1 : 0;
+    if (p.store_policy < 0) p.store_policy = FW_DEFAULT_STORE_POLICY;  // (-1: the build's default; the host side does not know the -D flags of a variant build)
+    if (p.wb_flush_every == 0xffffffffu) p.wb_flush_every = FW_DEFAULT_WB_FLUSH_EVERY;
     // chained duplicate rows: the generic kernel's update path and the whole-line path apply them from registers; the
     // register-resident variant of the v2 kernel (window off) keeps the old route (duplicates serialised in phase B)
     p.chain = (p.update && !p.no_chain && (p.window || !uses_resident_kernel(p, threads))) ? 1 : 0;
     // the next record is prefetched by the v2 kernel's updating launches (read-only launches have no store drain to hide, and their LDS is what lets
     // three workgroups share a CU)
     p.prefetch = (p.prefetch && p.records && p.update && uses_resident_kernel(p, threads)) ? 1 : 0;
+    p.tr_lds = (p.records && uses_resident_kernel(p, threads)) ? 1 : 0;  // the v2 kernel reads the translator's tables from an LDS copy
 }
 
 hipError_t launch_example_kernel(const KernelParams &p_in, int optimizer, bool coherent, uint32_t grid, uint32_t threads,
@@ -2554,8 +2607,6 @@ hipError_t launch_example_kernel(const KernelParams &p_in, int optimizer, bool c
     KernelParams p = p_in;
     const bool v2 = uses_resident_kernel(p, threads);
     if (v2 && p.R <= 64 * 4 && p.update) p.lut_global = 0;  // (the v2 kernel's single-chunk instantiations keep the LUT in LDS: see kLdsLut)
-    if (p.store_policy < 0) p.store_policy = FW_DEFAULT_STORE_POLICY;  // (-1: the build's default; the host side does not know the -D flags of a variant build)
-    if (p.wb_flush_every == 0xffffffffu) p.wb_flush_every = FW_DEFAULT_WB_FLUSH_EVERY;
     resolve_row_mode(p, threads);  // (idempotent: run_batch has normally done it already, to size the LDS)
     const size_t lds = example_kernel_lds_bytes(p, optimizer);
     // 16-byte row vectors need k % 4 == 0: then R % 4 == 0 and hash & mask is a multiple of next_pow2(k) >= 4

@@ -229,6 +229,7 @@ int record_batch_alloc(fwgpu_regressor *r, const fwgpu_translator_config *t, uin
     b->tr.pair_field = reinterpret_cast<const uint8_t *>(tb + q_pfld);
     b->tr.n_combos = t->n_combos;
     b->tr.n_pairs = npr;
+    b->tr.n_members = ncm;
     b->tr.add_const = t->add_constant_feature ? 1 : 0;
     b->tr.lr_mask = r->lr_hash_mask;
     b->tr.ffm_mask = r->ffm_hash_mask;

@@ -14,6 +14,9 @@
 //   S3r the same after A has first READ the whole lines (so its L2 holds them valid before B's store).
 //   S4  eviction:     A plain-stores 1 to the lines, then streams 32 MB through its L2 with plain loads and stores (no write-back instruction);
 //                     B sc1-loads -> has the dirty data reached memory by eviction alone?
+//   S5  sc1 load of an own dirty line: A plain-stores 1, then sc1-loads the lines (no write-back);  B sc1-loads -> did A's load push the line out?
+//   S6  sc1 store into an own dirty line: A plain-stores chunk 0 = 1, then sc1-stores chunk 1 = 5 of the same lines (no write-back);
+//                     B sc1-loads -> chunk 1 is 5; is chunk 0 out as well (the write-through took the dirty bytes along) or still private to A?
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -53,7 +56,7 @@ __device__ __forceinline__ void pass_turn(unsigned *turn, unsigned next) {
 }
 
 constexpr unsigned kLines = 64, kLineBytes = 128, kRegion = kLines * kLineBytes;  // 8 KB per scenario
-constexpr int kScen = 6;
+constexpr int kScen = 8;
 
 struct Ctl {
     unsigned turn;       // scenario * 16 + step
@@ -179,6 +182,32 @@ __global__ void probe(Ctl *c, unsigned *data, unsigned *scratch, size_t scratch_
                 if (lane == 0) { res[0] = c0; res[1] = c1; res[2] = c1lost; }  // 64 lines each
                 pass_turn(turn, t0 + 16);
             }
+        } else if (sc == 6 || sc == 7) {  // S5 / S6
+            if (A) {
+                wait_turn(turn, t0 + 0);
+                for_lines([&](unsigned o) { if (sc == 6 || (lane & 7) == 0) st<kAuxPlain>(X, kRegion, o, 1u); });
+                drain();
+                if (sc == 6) {
+                    unsigned z = 0;
+                    for_lines([&](unsigned o) { z += ld<kAuxSc1>(X, kRegion, o); });
+                    if (z == 0x12345678u) res[7] = z;
+                } else {
+                    for_lines([&](unsigned o) { if ((lane & 7) == 1) st<kAuxSc1>(X, kRegion, o, 5u); });
+                }
+                drain();
+                pass_turn(turn, t0 + 1);
+            } else {
+                wait_turn(turn, t0 + 1);
+                unsigned c0 = 0, c1 = 0, all1 = 0;
+                for_lines([&](unsigned o) {
+                    const unsigned v = ld<kAuxSc1>(X, kRegion, o);
+                    all1 += count_eq(v, 1u);
+                    c0 += (unsigned)__popcll(__ballot((lane & 7) == 0 && v == 1u));
+                    c1 += (unsigned)__popcll(__ballot((lane & 7) == 1 && v == 5u));
+                });
+                if (lane == 0) { res[0] = all1; res[1] = c0; res[2] = c1; }
+                pass_turn(turn, t0 + 16);
+            }
         } else {  // S4
             if (A) {
                 wait_turn(turn, t0 + 0);
@@ -242,6 +271,8 @@ int main() {
         printf("  S3  partial line (A never read it)  : A's chunk arrived %u/64, B's chunk kept %u, B's chunk zeroed %u\n", h.res[3][0], h.res[3][1], h.res[3][2]);
         printf("  S3r partial line (A had read it)    : A's chunk arrived %u/64, B's chunk kept %u, B's chunk zeroed %u\n", h.res[4][0], h.res[4][1], h.res[4][2]);
         printf("  S4  eviction only (32 MB streamed)  : B sees A's data %u, still memory's %u (of 512)\n", h.res[5][0], h.res[5][1]);
+        printf("  S5  A sc1-loads its own dirty lines : B then sees A's data in %u of 512 chunks\n", h.res[6][0]);
+        printf("  S6  A sc1-stores into its dirty line: B sees the sc1-stored chunk in %u/64 lines, the plain-stored (dirty) chunk in %u/64\n", h.res[7][2], h.res[7][1]);
     }
     return ok_runs ? 0 : 2;
 }
