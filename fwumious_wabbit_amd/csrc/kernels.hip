@@ -2100,8 +2100,14 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
     typedef f4 V;
     constexpr int VEC = 4;
     constexpr int AUX = COH ? kAuxSc1 : kAuxPlain;
-    constexpr int AUX_SW = (COH && POL < 1) ? kAuxSc1 : kAuxPlain;  // weight-row stores (store policy: top of this file)
-    constexpr int AUX_SA = (COH && POL < 2) ? kAuxSc1 : kAuxPlain;  // accumulator-row stores
+#ifndef FW_WB_AUX_W  // cache-policy bits of the write-back stores (A/B builds: 2 = nt, the L2's streaming policy)
+#define FW_WB_AUX_W 0
+#endif
+#ifndef FW_WB_AUX_A
+#define FW_WB_AUX_A 0
+#endif
+    constexpr int AUX_SW = (COH && POL < 1) ? kAuxSc1 : (COH ? FW_WB_AUX_W : kAuxPlain);  // weight-row stores (store policy: top of this file)
+    constexpr int AUX_SA = (COH && POL < 2) ? kAuxSc1 : (COH ? FW_WB_AUX_A : kAuxPlain);  // accumulator-row stores
     constexpr int UA = FW_UA;  // accumulator rows in flight per wave in the update phase
     constexpr int UO = FW_UO;  // overflow rows (w + acc) in flight per wave
     extern __shared__ __align__(16) unsigned char smem[];

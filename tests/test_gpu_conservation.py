@@ -161,7 +161,7 @@ def test_in_order_launch_applies_every_step_under_every_policy():
 SHIPPED = (-1, -1)
 MEASURED = [(0, 0), (1, 0), (2, 0), (2, 64)]
 
-# Measured on MI355X (profiles/r04b_conservation.txt; rows in a third of all examples, ~170 concurrent holders):
+# Measured on MI355X (profiles/r04c_conservation.txt, r04b_conservation.txt; rows in a third of all examples, ~170 concurrent holders):
 #   weights, SGD      write-through 0.014-0.036 (row kept from the gather) / 0.22-0.46 (row re-read in the update); write-back 0.010-0.027 / 0.083-0.114,
 #                     whatever the write-back interval down to 8 examples: with the row dirty in eight L2s at once the last write-back wins, an eighth
 #                     of the within-XCD survival (tools/l2probe: S2), until the interval falls below the row's hit interval per XCD (interval 1: 0.16-0.27)
