@@ -92,6 +92,38 @@ def logloss(p, y):
     return float(np.mean(-np.where(y == 1, np.log(p), np.log(1 - p))))
 
 
+def oracle_reference_curve(args, world):
+    """Hold-out log-loss of the SEQUENTIAL reference algorithm on this very stream and hold-out tail after N examples: numbers produced by
+    scripts/make_bench_oracle_curve.py from the CPU oracle and committed as data (tests/golden/bench_oracle_curve.json).  Only for the default
+    single-GPU stream (with N > 1 every rank trains on its own shard: another example order); {} when the run's stream is another one."""
+    path = os.path.join(ROOT, "tests", "golden", "bench_oracle_curve.json")
+    if world != 1 or args.nn_layers or not os.path.exists(path):
+        return {}
+    d = json.load(open(path))
+    c = d["config"]
+    same = all(getattr(args, k) == v for k, v in c.items()) and d["hyper"] == {"lr": LR, "power_t": POWER_T, "init_acc": INIT_ACC}
+    return dict(zip(d["examples"], d["logloss"])) if same else {}
+
+
+def link_bytes_per_example(args, world, n_ffm, n_lr, rec_words, sync_every, table_bytes):
+    """What one example puts on the xGMI links of ONE rank (bytes sent + received), per multi-GPU mode, for this run's model and N
+    (analytic, from the modes' exchange steps -- the sparse mode's measured figure is dp_modes.sparse.bytes_sent_per_example)."""
+    N = world
+    if N <= 1:
+        return None
+    R4 = args.fields * args.k * 4            # one FFM row, bytes
+    SL4 = (args.fields * args.fields * args.k + 3 * args.fields + 8) * 4  # one split record (T, corrections, counts, LR sum, label, importance)
+    rows, f = n_ffm * R4, (N - 1) / N
+    return {
+        "replica": 2 * f * table_bytes / (sync_every * args.batch * 1.0),                    # ring all-reduce of the table deltas, once per sync_every steps
+        "sparse_upper_bound": (rows + n_ffm * 4 + n_lr * 8) * N,                               # undeduplicated row gradients: own bucket out, N - 1 buckets in
+        "sharded": 4 * rec_words * (N - 1) + 2 * SL4 * f + (SL4 + 4) * (N - 1),               # records all-gathered, field sums reduce-scattered, records + gradients all-gathered
+        "peer": (5 * rows + 4 * n_lr * 8) * f,                                                 # gather w; read w, acc; write w, acc -- all in the owner's memory
+        "owner_apply": (2 * rows + n_ffm * 8 + 2 * n_lr * 8) * f,                               # fetch w from the owner, push the gradient row to the owner (fwgpu_dist_*_owner)
+        "what": "bytes per example on one rank's links (sent + received), (N-1)/N of the rows being remote",
+    }
+
+
 def cpu_baseline(args, n_examples):
     """The CPU oracle (a C restatement of the reference algorithm; the Rust reference cannot be built here)
     timed on this box's host cores in hogwild mode on a bounded sample of the same stream."""
@@ -549,12 +581,15 @@ def main():
         traffic, traffic_src = measure_traffic(args)
 
     if rank == 0:
+        oracle_curve = oracle_reference_curve(args, world) if not (sync_steps or use_dist) else {}
         achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "examples/sec + final log-loss, 30-field k=8 FFM, at 1/2/4/8 MI355X",
             "value": world * K * B / elapsed,
             "unit": "examples/sec",
             "n_gpus": world,
+            # ranks of the job as the library's RCCL communicator counts them (ncclCommCount), not WORLD_SIZE; null when no communicator exists (N = 1)
+            "rccl_ranks": (dist_rank.comm_count() if dist_rank is not None else None),
             "steps": K,
             "warmup": W,
             "ms_per_step": 1e3 * elapsed / K,
@@ -568,6 +603,10 @@ def main():
             # what "learned" means on this hold-out tail: the loss of always predicting its positive rate (the untrained model reads ln 2)
             "holdout_prior_logloss": prior_ll,
             "logloss_after_examples": {str(n): v for n, v in sorted(curve.items())},
+            # the sequential CPU oracle (= the reference's single-thread algorithm) on the same stream, same hold-out tail, same number of examples:
+            # null where it was not precomputed (tests/golden/bench_oracle_curve.json holds multiples of 65 536 up to 3.4 M)
+            "oracle_logloss_after_examples": {str(n): oracle_curve.get(n) for n, v in sorted(curve.items())},
+            "oracle_final_logloss": oracle_curve.get((W + K) * B * world),
             "progressive_logloss_per_step": progressive,
             "seconds_to_logloss": {"target": target_ll, "examples": reached[0] if reached else None,
                                    "seconds": (reached[0] / (world * K * B / elapsed)) if reached else None,
@@ -619,6 +658,11 @@ def main():
                 "launch_ms_min_median_max": [float(np.min(kernel_ms)), float(np.median(kernel_ms)), float(np.max(kernel_ms))],
             },
         }
+        if use_dist:
+            nb = batches[W]
+            tb = 8.0 * ((1 << args.ffm_bits) + args.fields * args.k) + 8.0 * (1 << args.bits)
+            out["link_bytes_per_example"] = link_bytes_per_example(args, world, nb.n_ffm / max(nb.n, 1), nb.n_lr / max(nb.n, 1), words[W] / max(nb.n, 1),
+                                                                   sync_every, tb)
         if pcie is not None:
             out["pcie_inclusive"] = pcie
         if sparse_main:

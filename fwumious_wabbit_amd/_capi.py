@@ -130,6 +130,7 @@ def lib():
         "fwgpu_dist_set_mode": [vp, i32],
         "fwgpu_dist_group_set_mode": [vp, i32],
         "fwgpu_dist_rank": [vp, P(i32), P(i32)],
+        "fwgpu_dist_comm_count": [vp, P(i32)],
         "fwgpu_dist_ranges": [vp, P(u32), P(u32), P(u32), P(u32)],
         "fwgpu_dist_learn_sharded": [vp, P(TranslatorConfig), vp, vp, u32, vp],
         "fwgpu_dist_learn_sharded_batch": [vp, P(TranslatorConfig), vp],

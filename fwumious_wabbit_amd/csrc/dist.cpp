@@ -33,6 +33,8 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "fwgpu_internal.h"
@@ -47,6 +49,8 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;  // optional
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;              // optional
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
@@ -72,6 +76,8 @@ struct RcclApi {
             SYM(CommInitRank, "ncclCommInitRank");
             SYM(CommDestroy, "ncclCommDestroy");
             SYM(CommAbort, "ncclCommAbort");
+            SYM(CommGetAsyncError, "ncclCommGetAsyncError");
+            SYM(CommCount, "ncclCommCount");
             SYM(AllReduce, "ncclAllReduce");
             SYM(AllGather, "ncclAllGather");
             SYM(ReduceScatter, "ncclReduceScatter");
@@ -94,9 +100,17 @@ RcclApi g_rccl;
 }  // namespace
 
 struct fwgpu_dist;
-// A collective step that fails on ONE rank (out of memory, a phase error, an RCCL error) would leave the other ranks waiting in
-// their next collective for good: the failing rank aborts the communicator (ncclCommAbort, where the library has it), which makes
-// the peers' pending and later collectives return an error instead of hanging.  The rank is unusable afterwards.
+// Failure model of the collective steps (one rank per process).
+//  * A failure BEFORE the step's first exchange (bad records, a batch of another regressor, out of memory while sizing the buffers) is
+//    what a job actually meets: the failing rank still takes part in the first collective -- the all-gather of the batch shapes -- with
+//    a poisoned shape (kShapePoison in word 3), every rank sees it, and every rank returns from the step without having exchanged or applied
+//    anything: the failing rank with its own error, the others with FWGPU_ERR_PEER.  The job stays usable.
+//  * A failure AFTER the exchange has begun (a HIP or RCCL error mid-step) leaves this rank unable to finish its collectives.  It aborts its
+//    communicator (ncclCommAbort) so that its own stream does not hang; that abort is LOCAL -- the peers' collective kernels keep waiting
+//    for this rank.  They get out through wait_stream(): every wait behind a collective polls the stream and the communicator's
+//    asynchronous error state (ncclCommGetAsyncError, where the library has it) and, after FWGPU_DIST_TIMEOUT_MS (default 0 = wait for
+//    ever, as RCCL itself does), aborts the own communicator and returns FWGPU_ERR_PEER.  A job that wants to survive a dead rank sets it.
+constexpr uint32_t kShapePoison = 0xffffffffu;
 static int abort_on_failure(fwgpu_dist *d, int rc);
 
 // One rank of the job.
@@ -148,6 +162,9 @@ struct fwgpu_dist {
     uint64_t ob_wcap = 0;
     fwgpu_batch *cur = nullptr;      // the batch this sparse step runs on
     uint32_t occ_max_ffm = 0, occ_max_lr = 0;
+    hipEvent_t ev_peer_step = nullptr;  // recorded behind a peer-sharded step launched on a stream of the caller's (fwgpu_dist_barrier waits for it)
+    int begin_rc = FWGPU_OK;         // result of the current step's local preparation (failure model: dist.cpp top)
+    bool begin_failed = false;
     hipEvent_t ev_prev = nullptr;    // group step: "the previous rank's local phase is done" (device-side ordering of the ranks)
     PeerShards *d_peers = nullptr;   // peer-sharded step: the owners' table bases, on this rank's device
     bool peers_attached = false;     // process-per-rank peer mode: the other ranks' tables are mapped (hipIpcOpenMemHandle)
@@ -631,13 +648,57 @@ int fwgpu_dist_init(fwgpu_regressor *r, const uint8_t *unique_id, int rank, int 
 }
 
 static int abort_on_failure(fwgpu_dist *d, int rc) {
-    if (rc != FWGPU_OK && d && d->comm && d->n > 1 && g_rccl.CommAbort) {
+    if (rc != FWGPU_OK && rc != FWGPU_ERR_PEER && d && !d->begin_failed && d->comm && d->n > 1 && g_rccl.CommAbort) {
         const std::string msg = fwgpu_last_error();
         (void)g_rccl.CommAbort(d->comm);
         d->comm = nullptr;
-        set_error(msg + " (the communicator was aborted so that the other ranks do not wait; this rank cannot continue)");
+        set_error(msg + " (this rank's communicator was aborted: it cannot continue; peers leave their collective through FWGPU_DIST_TIMEOUT_MS)");
     }
     return rc;
+}
+
+// Wait for the rank's stream behind a collective.  Without a time-out this is hipStreamSynchronize; with FWGPU_DIST_TIMEOUT_MS it polls, so that
+// a rank whose peer has died leaves the collective with an error instead of waiting for ever.
+static int wait_stream(fwgpu_dist *d) {
+    static const long timeout_ms = [] {
+        const char *e = std::getenv("FWGPU_DIST_TIMEOUT_MS");
+        return e ? std::atol(e) : 0L;
+    }();
+    if (timeout_ms <= 0 || !d->comm || d->n <= 1) {
+        FWGPU_HIP(hipStreamSynchronize(d->stream));
+        return FWGPU_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(d->stream);
+        if (q == hipSuccess) return FWGPU_OK;
+        if (q != hipErrorNotReady) return fail(FWGPU_ERR_DEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+        ncclResult_t ae = ncclSuccess;
+        const bool async_err = g_rccl.CommGetAsyncError && g_rccl.CommGetAsyncError(d->comm, &ae) == ncclSuccess && ae != ncclSuccess && ae != ncclInProgress;
+        const bool late = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_ms;
+        if (async_err || late) {
+            if (g_rccl.CommAbort) (void)g_rccl.CommAbort(d->comm);
+            d->comm = nullptr;
+            return fail(FWGPU_ERR_PEER, async_err ? "a collective reported an asynchronous RCCL error: communicator aborted"
+                                                  : "a collective did not complete within FWGPU_DIST_TIMEOUT_MS (a peer rank is gone?): communicator aborted");
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+
+// after the all-gather of the batch shapes: did any rank poison its shape (a failure before the exchange)?
+static int check_shapes(fwgpu_dist *d, const std::vector<uint32_t> &shapes, bool same_n) {
+    for (int j = 0; j < d->n; j++)
+        if (shapes[4 * (size_t)j + 3] == kShapePoison) {
+            if (j == d->rank) return d->begin_rc;  // (this rank's own error; its message is in fwgpu_last_error())
+            return fail(FWGPU_ERR_PEER, "rank " + std::to_string(j) + " reported a failure before the step's exchange: nothing was exchanged or applied");
+        }
+    if (same_n)
+        for (int j = 0; j < d->n; j++)
+            if (shapes[4 * (size_t)j + 3] != shapes[3])
+                return fail(FWGPU_ERR_PEER, "sharded step: the ranks passed different micro-batch sizes (rank 0: " + std::to_string(shapes[3]) + ", rank " +
+                                                std::to_string(j) + ": " + std::to_string(shapes[4 * (size_t)j + 3]) + "): nothing was exchanged or applied");
+    return FWGPU_OK;
 }
 
 int fwgpu_dist_free(fwgpu_dist *d) {
@@ -648,6 +709,19 @@ int fwgpu_dist_free(fwgpu_dist *d) {
 int fwgpu_dist_set_mode(fwgpu_dist *d, int mode) {
     if (!d || (mode != FWGPU_MODE_SEQUENTIAL && mode != FWGPU_MODE_HOGWILD)) return fail(FWGPU_ERR_INVALID, "dist_set_mode: bad argument");
     d->mode = mode;
+    return FWGPU_OK;
+}
+
+// ranks of the job AS THE COMMUNICATOR COUNTS THEM (ncclCommCount), not as the launcher's environment says; 0 for a member of an in-process group
+int fwgpu_dist_comm_count(const fwgpu_dist *d, int *count) {
+    if (!d || !count) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    *count = 0;
+    if (!d->comm) return FWGPU_OK;
+    if (!g_rccl.CommCount) {
+        *count = d->n;
+        return FWGPU_OK;
+    }
+    FWGPU_NCCL(g_rccl.CommCount(d->comm, count));
     return FWGPU_OK;
 }
 
@@ -672,13 +746,21 @@ int fwgpu_dist_ranges(const fwgpu_dist *d, uint32_t *ffm_lo, uint32_t *ffm_hi, u
 // every rank of the job calls it with the same n.
 static int rccl_step(fwgpu_dist *d, const uint32_t *records, const uint64_t *rec_off, uint32_t n, uint32_t shape[4], float *preds,
                      float *d_preds);
+// a step's local preparation has run: on failure the rank still joins the shape exchange, with a poisoned shape (failure model above)
+static void begin_result(fwgpu_dist *d, int rc, uint32_t shape[4]) {
+    d->begin_rc = rc;
+    d->begin_failed = rc != FWGPU_OK;
+    if (rc) {
+        shape[0] = shape[1] = shape[2] = 0;
+        shape[3] = kShapePoison;
+    }
+}
 
 int fwgpu_dist_learn_sharded(fwgpu_dist *d, const fwgpu_translator_config *t, const uint32_t *records, const uint64_t *rec_off,
                              uint32_t n, float *preds) {
     if (!d || !d->comm) return fail(FWGPU_ERR_INVALID, "not an RCCL rank (fwgpu_dist_init)");
     uint32_t shape[4];
-    int rc = step_begin(d, t, records, rec_off, n, shape);
-    if (rc) return rc;
+    begin_result(d, step_begin(d, t, records, rec_off, n, shape), shape);
     return abort_on_failure(d, rccl_step(d, records, rec_off, n, shape, preds, nullptr));
 }
 
@@ -687,9 +769,8 @@ int fwgpu_dist_learn_sharded(fwgpu_dist *d, const fwgpu_translator_config *t, co
 int fwgpu_dist_learn_sharded_batch(fwgpu_dist *d, const fwgpu_translator_config *t, fwgpu_batch *b) {
     if (!d || !d->comm) return fail(FWGPU_ERR_INVALID, "not an RCCL rank (fwgpu_dist_init)");
     uint32_t shape[4];
-    int rc = step_begin_batch(d, t, b, shape);
-    if (rc) return rc;
-    return abort_on_failure(d, rccl_step(d, nullptr, nullptr, b->n, shape, nullptr, b->pred));
+    begin_result(d, step_begin_batch(d, t, b, shape), shape);
+    return abort_on_failure(d, rccl_step(d, nullptr, nullptr, b ? b->n : 0, shape, nullptr, b ? b->pred : nullptr));
 }
 
 static int rccl_step(fwgpu_dist *d, const uint32_t *records, const uint64_t *rec_off, uint32_t n, uint32_t shape[4], float *preds,
@@ -700,7 +781,8 @@ static int rccl_step(fwgpu_dist *d, const uint32_t *records, const uint64_t *rec
     FWGPU_NCCL(g_rccl.AllGather(d->d_shape + 4 * d->rank, d->d_shape, 4, ncclUint32, d->comm, d->stream));
     std::vector<uint32_t> shapes((size_t)d->n * 4);
     FWGPU_HIP(hipMemcpyAsync(shapes.data(), d->d_shape, shapes.size() * 4, hipMemcpyDeviceToHost, d->stream));
-    FWGPU_HIP(hipStreamSynchronize(d->stream));
+    if ((rc = wait_stream(d))) return rc;
+    if ((rc = check_shapes(d, shapes, true))) return rc;
     rc = step_upload(d, records, rec_off, shapes.data());
     if (rc) return rc;
     if (n == 0) return FWGPU_OK;
@@ -772,11 +854,12 @@ int fwgpu_dist_gather_tables(fwgpu_dist *d) {
 int fwgpu_dist_barrier(fwgpu_dist *d) {
     if (!d || !d->comm) return fail(FWGPU_ERR_INVALID, "not an RCCL rank (fwgpu_dist_init)");
     FWGPU_HIP(hipSetDevice(d->r->device));
+    // (a peer-sharded step may have been launched on a stream of the caller's: the barrier covers it through the event recorded behind it)
+    if (d->ev_peer_step) FWGPU_HIP(hipStreamWaitEvent(d->stream, d->ev_peer_step, 0));
     FWGPU_HIP(hipStreamSynchronize(d->stream));  // this rank's launches are done ...
     FWGPU_HIP(hipMemsetAsync(d->d_shape, 0, 4, d->stream));
     FWGPU_NCCL(g_rccl.AllReduce(d->d_shape, d->d_shape, 1, ncclFloat, ncclSum, d->comm, d->stream));
-    FWGPU_HIP(hipStreamSynchronize(d->stream));  // ... and so are everybody else's
-    return FWGPU_OK;
+    return wait_stream(d);  // ... and so are everybody else's
 }
 
 int fwgpu_dist_peer_attach(fwgpu_dist *d) {
@@ -790,6 +873,10 @@ int fwgpu_dist_peer_attach(fwgpu_dist *d) {
     while ((1 << lg) < N) lg++;
     if ((r->cfg.ffm_k && (int)r->cfg.ffm_bit_precision < lg) || (int)r->cfg.bit_precision < lg)
         return fail(FWGPU_ERR_INVALID, "peer-sharded step: fewer table entries than ranks");
+    // hipIpcOpenMemHandle hangs on an allocation of 2^31 bytes or more on this runtime (measured on the 2 GiB LR table of `-b 28`, which is why the
+    // LR table travels as per-rank shards below); an FFM table of that size -- ffm_bit_precision >= 29 -- would meet the same hang in the peers
+    if (r->cfg.ffm_k && r->ffm_len * 4ull >= (1ull << 31))
+        return fail(FWGPU_ERR_RANGE, "peer-sharded step: FFM tables of 2 GiB or more cannot be mapped by the peers (hipIpcOpenMemHandle); use ffm_bit_precision <= 28");
     FWGPU_HIP(hipSetDevice(r->device));
     struct Handles {
         hipIpcMemHandle_t w, acc, lr;
@@ -816,6 +903,10 @@ int fwgpu_dist_peer_attach(fwgpu_dist *d) {
     PEER_DBG("lr handle exported (%llu bytes)", (unsigned long long)r->lr_len * 8);
     Handles *d_all = nullptr;
     FWGPU_HIP(hipMalloc((void **)&d_all, sizeof(Handles) * (size_t)N));
+    struct FreeOnExit {  // (every early return below releases the staging buffer)
+        void *q;
+        ~FreeOnExit() { if (q) (void)hipFree(q); }
+    } free_d_all{d_all};
     FWGPU_HIP(hipMemcpyAsync(d_all + d->rank, &mine, sizeof(Handles), hipMemcpyHostToDevice, d->stream));
     FWGPU_HIP(hipStreamSynchronize(d->stream));
     ncclResult_t e = N > 1 ? g_rccl.AllGather(d_all + d->rank, d_all, sizeof(Handles) / 4, ncclUint32, d->comm, d->stream) : ncclSuccess;
@@ -823,7 +914,6 @@ int fwgpu_dist_peer_attach(fwgpu_dist *d) {
     PEER_DBG("handles all-gathered");
     hipError_t he = hipStreamSynchronize(d->stream);
     if (he == hipSuccess) he = hipMemcpy(all.data(), d_all, sizeof(Handles) * (size_t)N, hipMemcpyDeviceToHost);
-    (void)hipFree(d_all);
     if (e != ncclSuccess) return fail(FWGPU_ERR_DEVICE, "peer attach: all-gather of the IPC handles failed");
     if (he != hipSuccess) return fail(FWGPU_ERR_DEVICE, std::string("peer attach: ") + hipGetErrorString(he));
     PeerShards ps{};
@@ -883,7 +973,14 @@ int fwgpu_dist_learn_peer_batch(fwgpu_dist *d, const fwgpu_translator_config *t,
     if (!t || !b || !b->records) return fail(FWGPU_ERR_INVALID, "peer step: a record batch is needed");
     if (b->owner != d->r) return fail(FWGPU_ERR_INVALID, "peer step: batch belongs to another regressor");
     FWGPU_HIP(hipSetDevice(d->r->device));
-    return run_batch_peer(d->r, b, d->mode, update, d->d_peers, hip_stream ? static_cast<hipStream_t>(hip_stream) : d->stream);
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : d->stream;
+    int rc = run_batch_peer(d->r, b, d->mode, update, d->d_peers, st);
+    if (rc) return rc;
+    if (st != d->stream) {  // fwgpu_dist_barrier (and through it gather_tables) must cover this launch too
+        if (!d->ev_peer_step) FWGPU_HIP(hipEventCreateWithFlags(&d->ev_peer_step, hipEventDisableTiming));
+        FWGPU_HIP(hipEventRecord(d->ev_peer_step, st));
+    }
+    return FWGPU_OK;
 }
 
 // Dense all-reduce of a device float buffer over the job (replica mode: table deltas; deep head: dense gradient sums)
@@ -905,7 +1002,8 @@ static int rccl_sparse_step(fwgpu_dist *d, uint32_t shape[4], float *preds) {
     if (N > 1) FWGPU_NCCL(g_rccl.AllGather(d->d_shape + 4 * d->rank, d->d_shape, 4, ncclUint32, d->comm, d->stream));
     std::vector<uint32_t> shapes((size_t)N * 4);
     FWGPU_HIP(hipMemcpyAsync(shapes.data(), d->d_shape, shapes.size() * 4, hipMemcpyDeviceToHost, d->stream));
-    FWGPU_HIP(hipStreamSynchronize(d->stream));
+    if ((rc = wait_stream(d))) return rc;
+    if ((rc = check_shapes(d, shapes, false))) return rc;
     rc = sparse_local(d, shapes.data());
     if (rc) return rc;
     // bucket-row counts of every rank
@@ -916,7 +1014,7 @@ static int rccl_sparse_step(fwgpu_dist *d, uint32_t shape[4], float *preds) {
         FWGPU_HIP(hipMemcpyAsync(all_counts, d->d_counts, 8, hipMemcpyDeviceToDevice, d->stream));
     std::vector<uint32_t> counts((size_t)2 * N);
     FWGPU_HIP(hipMemcpyAsync(counts.data(), all_counts, counts.size() * 4, hipMemcpyDeviceToHost, d->stream));
-    FWGPU_HIP(hipStreamSynchronize(d->stream));
+    if ((rc = wait_stream(d))) return rc;
     d->last_rows[0] = counts[2 * d->rank];
     d->last_rows[1] = counts[2 * d->rank + 1];
     for (int side = 0; side < 2; side++) {
@@ -948,16 +1046,14 @@ static int rccl_sparse_step(fwgpu_dist *d, uint32_t shape[4], float *preds) {
         if (rc) return rc;
     }
     if (preds && d->B) FWGPU_HIP(hipMemcpyAsync(preds, d->cur->pred, (size_t)d->B * 4, hipMemcpyDeviceToHost, d->stream));
-    FWGPU_HIP(hipStreamSynchronize(d->stream));
-    return FWGPU_OK;
+    return wait_stream(d);
 }
 
 int fwgpu_dist_learn_sparse(fwgpu_dist *d, const fwgpu_translator_config *t, const uint32_t *records, const uint64_t *rec_off,
                             uint32_t n, float *preds) {
     if (!d || !d->comm) return fail(FWGPU_ERR_INVALID, "not an RCCL rank (fwgpu_dist_init)");
     uint32_t shape[4];
-    int rc = sparse_begin(d, t, records, rec_off, n, nullptr, shape);
-    if (rc) return rc;
+    begin_result(d, sparse_begin(d, t, records, rec_off, n, nullptr, shape), shape);
     return abort_on_failure(d, rccl_sparse_step(d, shape, preds));
 }
 
@@ -973,8 +1069,7 @@ int fwgpu_dist_sparse_last_rows(const fwgpu_dist *d, uint32_t *ffm_rows, uint32_
 int fwgpu_dist_learn_sparse_batch(fwgpu_dist *d, const fwgpu_translator_config *t, fwgpu_batch *b) {
     if (!d || !d->comm) return fail(FWGPU_ERR_INVALID, "not an RCCL rank (fwgpu_dist_init)");
     uint32_t shape[4];
-    int rc = sparse_begin(d, t, nullptr, nullptr, 0, b, shape);
-    if (rc) return rc;
+    begin_result(d, sparse_begin(d, t, nullptr, nullptr, 0, b, shape), shape);
     return abort_on_failure(d, rccl_sparse_step(d, shape, nullptr));
 }
 
@@ -1037,10 +1132,24 @@ int fwgpu_dist_group_learn_sharded(fwgpu_dist_group *g, const fwgpu_translator_c
             FWGPU_HIP(hipMemcpyAsync(dst->gb->rec_off + (size_t)B * j, src->gb->rec_off + (size_t)B * j, (size_t)B * 8, hipMemcpyDeviceToDevice, dst->stream));
         }
     }
+    // The ranks' phase kernels run ONE AFTER THE OTHER on the device (rank j's stream waits for an event behind rank j-1's phase): phase kernels of
+    // two hardware queues that overlap are not reproducible on this build (see fwgpu_dist_group_learn_sparse below).
+    // FWGPU_GROUP_CONCURRENT=local removes the ordering (debug).
+    static const char *cc_env = std::getenv("FWGPU_GROUP_CONCURRENT");
+    const bool ordered = !(cc_env && (cc_env[0] == 'l' || (cc_env[0] == 'a' && cc_env[1] == 'l')));
+    auto chain = [&](int j) -> int {
+        if (!ordered || j == 0) return FWGPU_OK;
+        fwgpu_dist *dj = g->ranks[j].get();
+        if (!dj->ev_prev) FWGPU_HIP(hipEventCreateWithFlags(&dj->ev_prev, hipEventDisableTiming));
+        FWGPU_HIP(hipEventRecord(dj->ev_prev, g->ranks[j - 1]->stream));
+        FWGPU_HIP(hipStreamWaitEvent(dj->stream, dj->ev_prev, 0));
+        return FWGPU_OK;
+    };
     int rc = sync_all();
     if (rc) return rc;
-    for (auto &d : g->ranks) {
-        rc = phase_fwd(d.get());
+    for (int j = 0; j < N; j++) {
+        if ((rc = chain(j))) return rc;
+        rc = phase_fwd(g->ranks[j].get());
         if (rc) return rc;
     }
     rc = sync_all();
@@ -1058,8 +1167,9 @@ int fwgpu_dist_group_learn_sharded(fwgpu_dist_group *g, const fwgpu_translator_c
     }
     rc = sync_all();
     if (rc) return rc;
-    for (auto &d : g->ranks) {
-        rc = phase_mid(d.get());
+    for (int j = 0; j < N; j++) {
+        if ((rc = chain(j))) return rc;
+        rc = phase_mid(g->ranks[j].get());
         if (rc) return rc;
     }
     rc = sync_all();
@@ -1076,8 +1186,9 @@ int fwgpu_dist_group_learn_sharded(fwgpu_dist_group *g, const fwgpu_translator_c
     }
     rc = sync_all();
     if (rc) return rc;
-    for (auto &d : g->ranks) {
-        rc = phase_upd(d.get());
+    for (int j = 0; j < N; j++) {
+        if ((rc = chain(j))) return rc;
+        rc = phase_upd(g->ranks[j].get());
         if (rc) return rc;
     }
     for (int j = 0; j < N; j++) {

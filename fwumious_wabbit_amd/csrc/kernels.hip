@@ -1389,6 +1389,48 @@ __host__ __device__ inline uint32_t split_len_of(uint32_t F, uint32_t R, uint32_
 uint32_t split_record_len(uint32_t F, uint32_t R, uint32_t nlr) { return split_len_of(F, R, nlr); }
 #endif
 
+// LDS carve-up of the example kernels (lds_layout), the overlap pre-filter's geometry and the LDS copy of the translator's tables
+__device__ __forceinline__ void bind_lds(const KernelParams &p, unsigned char *smem, bool use_lut, Lds &s, SetGeom &geom, TrLds &trl) {
+    size_t off[24];
+    lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut ? 1 : 0, p.records ? p.max_rec : 0,
+               p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off, (p.records && p.prefetch) ? p.max_rec : 0,
+               (p.records && p.tr_lds) ? tr_lds_words(p.tr) : 0);
+    s.T = reinterpret_cast<float *>(smem + off[0]);
+    s.selfw = reinterpret_cast<float *>(smem + off[1]);
+    s.lut = reinterpret_cast<float *>(smem + off[2]);
+    s.e_hash = reinterpret_cast<uint32_t *>(smem + off[3]);
+    s.e_val = reinterpret_cast<float *>(smem + off[4]);
+    s.e_fld = reinterpret_cast<uint32_t *>(smem + off[5]);
+    s.l_hash = reinterpret_cast<uint32_t *>(smem + off[6]);
+    s.l_val = reinterpret_cast<float *>(smem + off[7]);
+    s.fstart = reinterpret_cast<uint32_t *>(smem + off[8]);
+    s.fend = reinterpret_cast<uint32_t *>(smem + off[9]);
+    s.red = reinterpret_cast<float *>(smem + off[10]);
+    s.ctr = reinterpret_cast<uint32_t *>(smem + off[11]);
+    s.dcf = reinterpret_cast<float *>(smem + off[12]);
+    s.set_ffm = reinterpret_cast<uint32_t *>(smem + off[13]);
+    s.set_lr = reinterpret_cast<uint32_t *>(smem + off[14]);
+    s.rec = reinterpret_cast<uint32_t *>(smem + off[15]);
+    s.l_flag = reinterpret_cast<uint32_t *>(smem + off[21]);
+    s.set_blk = reinterpret_cast<uint32_t *>(smem + off[20]);
+    s.tcnt = reinterpret_cast<uint32_t *>(smem + off[16]);
+    s.l_combo = reinterpret_cast<uint32_t *>(smem + off[17]);
+    s.nn = reinterpret_cast<float *>(smem + off[18]);
+    s.rec_next = reinterpret_cast<uint32_t *>(smem + off[22]);
+    geom.setf_n = set_size(p.max_ffm);
+    geom.setl_n = set_size(p.max_lr);
+    geom.setf_shift = 32 - log2u(geom.setf_n);
+    geom.setl_shift = 32 - log2u(geom.setl_n);
+    geom.blk_shift = conflict_blk_shift(p);
+
+    if (!use_lut) s.lut = const_cast<float *>(p.lut_ffm);  // LUT read through L1 (the sc1 row traffic bypasses L1)
+    uint32_t *tw = reinterpret_cast<uint32_t *>(smem + off[23]);
+    trl.pair = tw;
+    trl.coff = tw + p.tr.n_pairs;
+    trl.cm = tw + p.tr.n_pairs + p.tr.n_combos + 1;
+    trl.cw = reinterpret_cast<const float *>(tw + p.tr.n_pairs + p.tr.n_combos + 1 + p.tr.n_members);
+}
+
 // The kernels take their parameters by value (one argument block, scalar loads).  Left alone, the compiler loads every field once in the
 // prologue of the persistent kernel and keeps ~180 scalars alive across the example loop -- 200 of them spilled to VGPR lanes, which in turn
 // pushed 8 vector registers of the config-C learn kernel to scratch.  kp_fresh() hands out the argument block's address through an empty
@@ -1447,39 +1489,10 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
     constexpr int UU = FW_V1_UU;  // feature rows in flight per wave in the update phase (x2 tables)
     extern __shared__ __align__(16) unsigned char smem[];
     const bool use_lut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global;
-    size_t off[24];
-    lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut ? 1 : 0, p.records ? p.max_rec : 0,
-               p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off, (p.records && p.prefetch) ? p.max_rec : 0,
-               (p.records && p.tr_lds) ? tr_lds_words(p.tr) : 0);
     Lds s;
-    s.T = reinterpret_cast<float *>(smem + off[0]);
-    s.selfw = reinterpret_cast<float *>(smem + off[1]);
-    s.lut = reinterpret_cast<float *>(smem + off[2]);
-    s.e_hash = reinterpret_cast<uint32_t *>(smem + off[3]);
-    s.e_val = reinterpret_cast<float *>(smem + off[4]);
-    s.e_fld = reinterpret_cast<uint32_t *>(smem + off[5]);
-    s.l_hash = reinterpret_cast<uint32_t *>(smem + off[6]);
-    s.l_val = reinterpret_cast<float *>(smem + off[7]);
-    s.fstart = reinterpret_cast<uint32_t *>(smem + off[8]);
-    s.fend = reinterpret_cast<uint32_t *>(smem + off[9]);
-    s.red = reinterpret_cast<float *>(smem + off[10]);
-    s.ctr = reinterpret_cast<uint32_t *>(smem + off[11]);
-    s.dcf = reinterpret_cast<float *>(smem + off[12]);
-    s.set_ffm = reinterpret_cast<uint32_t *>(smem + off[13]);
-    s.set_lr = reinterpret_cast<uint32_t *>(smem + off[14]);
-    s.rec = reinterpret_cast<uint32_t *>(smem + off[15]);
-    s.l_flag = reinterpret_cast<uint32_t *>(smem + off[21]);
-    s.set_blk = reinterpret_cast<uint32_t *>(smem + off[20]);
-    s.tcnt = reinterpret_cast<uint32_t *>(smem + off[16]);
-    s.l_combo = reinterpret_cast<uint32_t *>(smem + off[17]);
-    s.nn = reinterpret_cast<float *>(smem + off[18]);
-    s.rec_next = reinterpret_cast<uint32_t *>(smem + off[22]);
     SetGeom geom;
-    geom.setf_n = set_size(p.max_ffm);
-    geom.setl_n = set_size(p.max_lr);
-    geom.setf_shift = 32 - log2u(geom.setf_n);
-    geom.setl_shift = 32 - log2u(geom.setl_n);
-    geom.blk_shift = conflict_blk_shift(p);
+    TrLds trl_unused;
+    bind_lds(p, smem, use_lut, s, geom, trl_unused);
 
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = bd >> 6;
@@ -1489,8 +1502,6 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
     const float *lut_lr = p.lut_lr;  // 201 lookups per example: read through L1 (an LDS copy measured no faster)
     if (use_lut)
         for (int i = tid; i < kLutSize; i += bd) s.lut[i] = p.lut_ffm[i];
-    else
-        s.lut = const_cast<float *>(p.lut_ffm);  // LUT read through L1 (the sc1 row traffic bypasses L1)
 
     // debug phase timing (thread 0 of every workgroup; all stamps sit right after a barrier or at a phase end)
     unsigned long long tk_last = 0, tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1532,7 +1543,17 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
         // so in the in-order (single workgroup) mode every wave first waits for its own table stores to be
         // acknowledged: the next example must read what this one wrote.  Concurrent (hogwild) grids skip the
         // wait and let the stores drain under the next example's gather.
-        if (gridDim.x == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (the thread index is made opaque once per example, so that the lane masks derived from it are recomputed where they are used instead of
+        // living in scalar-register pairs across the whole example loop: see fw_example_kernel_r)
+        int tid_now = threadIdx.x, bd_now = blockDim.x;
+        uint32_t grid_now = gridDim.x;
+        asm volatile("; thread index, workgroup and grid size handed out" : "+v"(tid_now), "+s"(bd_now), "+s"(grid_now));
+        const int tid = tid_now, lane = tid & 63, wave = tid >> 6, bd = bd_now, nw = bd >> 6;
+        Lds s;
+        SetGeom geom;
+        TrLds trl_unused;
+        bind_lds(p, smem, use_lut, s, geom, trl_unused);
+        if (grid_now == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const uint32_t ex = s.ctr[6];
         if (ex >= p.n_examples) break;
@@ -2117,79 +2138,29 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
     // store issued before it.  (launch_example_kernel clears lut_global for these launches so that the host sizes the LDS the same way.)
     constexpr bool kLdsLut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && NC == 1;
     const bool use_lut = kLdsLut || ((OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global);
-    size_t off[24];
-    lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut ? 1 : 0, p.records ? p.max_rec : 0,
-               p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off, (p.records && p.prefetch) ? p.max_rec : 0,
-               (p.records && p.tr_lds) ? tr_lds_words(p.tr) : 0);
     Lds s;
-    s.T = reinterpret_cast<float *>(smem + off[0]);
-    s.selfw = reinterpret_cast<float *>(smem + off[1]);
-    s.lut = reinterpret_cast<float *>(smem + off[2]);
-    s.e_hash = reinterpret_cast<uint32_t *>(smem + off[3]);
-    s.e_val = reinterpret_cast<float *>(smem + off[4]);
-    s.e_fld = reinterpret_cast<uint32_t *>(smem + off[5]);
-    s.l_hash = reinterpret_cast<uint32_t *>(smem + off[6]);
-    s.l_val = reinterpret_cast<float *>(smem + off[7]);
-    s.fstart = reinterpret_cast<uint32_t *>(smem + off[8]);
-    s.fend = reinterpret_cast<uint32_t *>(smem + off[9]);
-    s.red = reinterpret_cast<float *>(smem + off[10]);
-    s.ctr = reinterpret_cast<uint32_t *>(smem + off[11]);
-    s.dcf = reinterpret_cast<float *>(smem + off[12]);
-    s.set_ffm = reinterpret_cast<uint32_t *>(smem + off[13]);
-    s.set_lr = reinterpret_cast<uint32_t *>(smem + off[14]);
-    s.rec = reinterpret_cast<uint32_t *>(smem + off[15]);
-    s.l_flag = reinterpret_cast<uint32_t *>(smem + off[21]);
-    s.set_blk = reinterpret_cast<uint32_t *>(smem + off[20]);
-    s.tcnt = reinterpret_cast<uint32_t *>(smem + off[16]);
-    s.l_combo = reinterpret_cast<uint32_t *>(smem + off[17]);
-    s.nn = reinterpret_cast<float *>(smem + off[18]);
-    s.rec_next = reinterpret_cast<uint32_t *>(smem + off[22]);
     SetGeom geom;
-    geom.setf_n = set_size(p.max_ffm);
-    geom.setl_n = set_size(p.max_lr);
-    geom.setf_shift = 32 - log2u(geom.setf_n);
-    geom.setl_shift = 32 - log2u(geom.setl_n);
-    geom.blk_shift = conflict_blk_shift(p);
+    TrLds trl;
+    bind_lds(p, smem, use_lut, s, geom, trl);
 
     const int tid = threadIdx.x, bd = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = bd >> 6;
     constexpr int kPfMax = 2;  // words of the next record a thread carries through the dot phase (records of up to kPfMax * blockDim words are prefetched)
     const uint32_t F = p.F, k = p.k, R = p.R;
-    // this lane's 4 floats of a row's chunk c: elements [e0, e0+4) = slot z, offset kk0
-    uint32_t e0c[NC], zc[NC], kkc[NC];
-    bool inbc[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        e0c[c] = (c * 64 + lane) * VEC;
-        inbc[c] = e0c[c] < R;
-        zc[c] = inbc[c] ? e0c[c] / k : 0xfffffffeu;
-        kkc[c] = inbc[c] ? e0c[c] - zc[c] * k : 0;
-    }
-    const uint32_t e0 = e0c[0], z = zc[0];  // (chunk 0: what the resident-row code, NC == 1 only, works on)
-    const bool inb = inbc[0];
 
     const float *lut_lr = p.lut_lr;  // 201 lookups per example: read through L1 (an LDS copy measured no faster)
     if (use_lut)
         for (int i = tid; i < kLutSize; i += bd) s.lut[i] = p.lut_ffm[i];
-    else
-        s.lut = const_cast<float *>(p.lut_ffm);  // LUT read through L1 (the sc1 row traffic bypasses L1)
 
     // the translator's tables, packed into LDS once per workgroup (record batches; visible to all threads behind the loop-top barrier)
-    TrLds trl;
-    {
-        uint32_t *tw = reinterpret_cast<uint32_t *>(smem + off[23]);
+    if (p.records) {
+        uint32_t *tw = const_cast<uint32_t *>(trl.pair);
         const DevTranslator &t = p.tr;
         const uint32_t NP = t.n_pairs, NCB = t.n_combos, NM = t.n_members;
-        trl.pair = tw;
-        trl.coff = tw + NP;
-        trl.cm = tw + NP + NCB + 1;
-        trl.cw = reinterpret_cast<const float *>(tw + NP + NCB + 1 + NM);
-        if (p.records) {
-            for (uint32_t j = tid; j < NP; j += bd) tw[j] = t.pair_ns[j] | ((uint32_t)t.pair_field[j] << 16) | (t.pair_f32[j] ? 0x80000000u : 0u);
-            for (uint32_t c = tid; c <= NCB; c += bd) tw[NP + c] = t.combo_off[c];
-            for (uint32_t m = tid; m < NM; m += bd) tw[NP + NCB + 1 + m] = t.combo_ns[m] | (t.combo_f32[m] ? 0x80000000u : 0u);
-            for (uint32_t c = tid; c < NCB; c += bd) tw[NP + NCB + 1 + NM + c] = __float_as_uint(t.combo_w[c]);
-        }
+        for (uint32_t j = tid; j < NP; j += bd) tw[j] = t.pair_ns[j] | ((uint32_t)t.pair_field[j] << 16) | (t.pair_f32[j] ? 0x80000000u : 0u);
+        for (uint32_t c = tid; c <= NCB; c += bd) tw[NP + c] = t.combo_off[c];
+        for (uint32_t m = tid; m < NM; m += bd) tw[NP + NCB + 1 + m] = t.combo_ns[m] | (t.combo_f32[m] ? 0x80000000u : 0u);
+        for (uint32_t c = tid; c < NCB; c += bd) tw[NP + NCB + 1 + NM + c] = __float_as_uint(t.combo_w[c]);
     }
     // Per-phase shader-clock stamps (fwgpu_debug_phase_ticks) exist in -DFW_TICKS builds only (scripts/perf_probe.py builds its own library): in the
     // shipped kernel the stamps' atomics made the compiler drain every outstanding store at the top of every example (an s_waitcnt vmcnt(0) behind
@@ -2219,7 +2190,33 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
     }
     for (;;) {
         const KernelParams &p = kp_fresh();  // (shadows the prologue's: this example's loads start here)
-        if (gridDim.x == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in-order mode: see fw_example_kernel
+        // The thread index is made opaque once per example, and everything that depends on it -- the lane's place in a row, and above all the
+        // dozen lane MASKS (tid == 0, tid < n, lane < 2 / 4 / ... of the wave scans) -- is derived inside the loop: left loop-invariant, every
+        // such mask is a pair of scalar registers that lives across the whole example loop, i.e. is spilled to a VGPR lane in the prologue
+        // and read back where it is used (~30 of the kernel's ~100 spilled scalars).
+        int tid_now = threadIdx.x, bd_now = blockDim.x;
+        uint32_t grid_now = gridDim.x;
+        asm volatile("; thread index, workgroup and grid size handed out" : "+v"(tid_now), "+s"(bd_now), "+s"(grid_now));
+        const int tid = tid_now, lane = tid & 63, wave = tid >> 6, bd = bd_now, nw = bd >> 6;
+        const uint32_t F = p.F, k = p.k, R = p.R;
+        // ... and so is the LDS carve-up: two dozen offsets that would otherwise live in scalar registers from the prologue on
+        Lds s;
+        SetGeom geom;
+        TrLds trl;
+        bind_lds(p, smem, use_lut, s, geom, trl);
+        // this lane's 4 floats of a row's chunk c: elements [e0, e0+4) = slot z, offset kk0
+        uint32_t e0c[NC], zc[NC], kkc[NC];
+        bool inbc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            e0c[c] = (c * 64 + lane) * VEC;
+            inbc[c] = e0c[c] < R;
+            zc[c] = inbc[c] ? e0c[c] / k : 0xfffffffeu;
+            kkc[c] = inbc[c] ? e0c[c] - zc[c] * k : 0;
+        }
+        const uint32_t e0 = e0c[0], z = zc[0];  // (chunk 0: what the resident-row code, NC == 1 only, works on)
+        const bool inb = inbc[0];
+        if (grid_now == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in-order mode: see fw_example_kernel
         __syncthreads();
         const uint32_t ex = s.ctr[6];
         if (ex >= p.n_examples) break;
@@ -2530,8 +2527,11 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
             }
             FW_TICK(5);
         }
-        if (tid == 0) s.ctr[6] = next_ticket;  // published by the loop-top barrier
-        if (COH && POL >= 1 && tid == bd - 1) {
+        // (the tail's lane tests start from a fresh thread index: `tid == 0` from the top of the example would be one more mask alive across the whole body)
+        int tid_tail = threadIdx.x;
+        asm volatile("; thread index handed out" : "+v"(tid_tail));
+        if (tid_tail == 0) s.ctr[6] = next_ticket;  // published by the loop-top barrier
+        if (COH && POL >= 1 && tid_tail == bd - 1) {
             // bounded staleness of the write-back policies: this workgroup's turn to write its XCD's dirty L2 lines back (one instruction, not
             // waited for here: it completes under the next example's stage phase)
             const uint32_t every = s.ctr[kCtrWbEvery];
@@ -2545,7 +2545,11 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
             }
         }
     }
-    if (COH && tid == 0 && s.ctr[13]) hot_lr_flush(p, s);  // (every thread's steps are in: the loop ends on a barrier)
+    {
+        int tid_end = threadIdx.x;
+        asm volatile("; thread index handed out" : "+v"(tid_end));
+        if (COH && tid_end == 0 && s.ctr[13]) hot_lr_flush(p, s);  // (every thread's steps are in: the loop ends on a barrier)
+    }
 #undef FW_TICK
 }
 

@@ -32,6 +32,12 @@ class DistRank:
     def set_mode(self, mode):
         check(capi.lib().fwgpu_dist_set_mode(self.h, mode))
 
+    def comm_count(self) -> int:
+        """ranks of the job as the communicator counts them (ncclCommCount)"""
+        n = C.c_int32(0)
+        check(capi.lib().fwgpu_dist_comm_count(self.h, C.byref(n)))
+        return n.value
+
     def ranges(self):
         v = [C.c_uint32() for _ in range(4)]
         check(capi.lib().fwgpu_dist_ranges(self.h, *[C.byref(x) for x in v]))

@@ -40,6 +40,7 @@ enum {
     FWGPU_ERR_FORMAT = 5,  /* malformed record, weight blob, cache or model file */
     FWGPU_ERR_PARSE = 6,   /* the text parser rejected a line; fwgpu_last_error() holds the reference's message */
     FWGPU_ERR_IO = 7,      /* file could not be opened / read / written */
+    FWGPU_ERR_PEER = 8,    /* multi-GPU step: ANOTHER rank of the job failed (or is gone); this rank exchanged and applied nothing in the step */
     /* not errors: commands the text parser hands back instead of a record (parser.rs:31-57) */
     FWGPU_PARSE_FLUSH = 100,
     FWGPU_PARSE_HOGWILD_LOAD = 101
@@ -290,6 +291,8 @@ int fwgpu_dist_free(fwgpu_dist *d);
 int fwgpu_dist_set_mode(fwgpu_dist *d, int mode);
 int fwgpu_dist_group_set_mode(fwgpu_dist_group *g, int mode);
 int fwgpu_dist_rank(const fwgpu_dist *d, int *rank, int *n_ranks);
+/* ranks of the job as the RCCL communicator itself counts them (ncclCommCount); 0 for a member of an in-process group */
+int fwgpu_dist_comm_count(const fwgpu_dist *d, int *count);
 int fwgpu_dist_ranges(const fwgpu_dist *d, uint32_t *ffm_lo, uint32_t *ffm_hi, uint32_t *lr_lo, uint32_t *lr_hi);
 int fwgpu_dist_learn_sharded(fwgpu_dist *d, const fwgpu_translator_config *t, const uint32_t *records, const uint64_t *rec_off,
                              uint32_t n, float *predictions);

@@ -49,6 +49,33 @@ def main():
         d.peer_attach()
     preds = []
     pos = 0
+    codes = []
+    if mode in ("sharded_fail", "sparse_fail"):
+        # Failure model of the collective steps (dist.cpp): a rank whose LOCAL preparation fails still joins the shape exchange with a
+        # poisoned shape; every rank returns from the step -- the culprit with its own error, the others with FWGPU_ERR_PEER -- nothing is
+        # exchanged or applied, nobody hangs, and the job goes on.  Step A: the last rank passes a record whose slot word points behind the
+        # record; step B (sharded only): rank 0 passes one example fewer than the others; then the ordinary steps below must still work.
+        learn = d.learn_sharded if mode == "sharded_fail" else d.learn_sparse
+        a, b = 0, int(parts[0, rank])
+        a += int(parts[0, :rank].sum())
+        b += int(parts[0, :rank].sum())
+        sub, so = recs[int(off[a]):int(off[b])].copy(), off[a:b + 1] - off[a]
+        bad = sub.copy()
+        if rank == n_ranks - 1:
+            bad[3] = 0x80000000 | (0x3ff0 << 16) | 0xfff0  # namespace 0: features at [0x3ff0, 0xfff0): far behind the record's end
+        try:
+            learn(fbt, bad, so)
+            codes.append(0)
+        except capi.FwgpuError as e:
+            codes.append(e.code)
+        if mode == "sharded_fail":
+            n_here = len(so) - 1 - (1 if rank == 0 else 0)
+            try:
+                learn(fbt, sub[:int(so[n_here])], so[:n_here + 1])
+                codes.append(0)
+            except capi.FwgpuError as e:
+                codes.append(e.code)
+        mode = mode.split("_")[0]
     for s in range(parts.shape[0]):
         a = pos + int(parts[s, :rank].sum())
         b = a + int(parts[s, rank])
@@ -84,7 +111,7 @@ def main():
         d.all_reduce_sum(re.table_device_ptr(capi.TABLE_FFM_ACC), re.table_len(capi.TABLE_FFM_ACC))
         ar = np.asarray(re.table_read(capi.TABLE_FFM_ACC))
     np.savez(sys.argv[3], preds=np.concatenate(preds) if preds else np.zeros(0, np.float32), lr=tabs[0], ffm_w=tabs[1], ffm_acc=tabs[2],
-             ranges=ranges, allreduce=ar)
+             ranges=ranges, allreduce=ar, codes=np.asarray(codes, dtype=np.int64))
     d.close()
     re.close()
 

@@ -164,6 +164,12 @@ ncclResult_t ncclCommDestroy(ncclComm_t c) {
     return ncclSuccess;
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t c, int *count) {
+    if (!c || !count) return ncclInvalidArgument;
+    *count = c->n;
+    return ncclSuccess;
+}
+
 // a failing rank tears the job down: its peers' pending and later collectives return an error instead of waiting
 ncclResult_t ncclCommAbort(ncclComm_t c) {
     if (!c) return ncclSuccess;

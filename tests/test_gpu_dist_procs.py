@@ -58,8 +58,20 @@ def _close(a, b):
     return int(bad.sum()) <= max(3, a.size // 10000) and float(np.abs(a - b).max()) < 5e-3
 
 
-@pytest.mark.parametrize("n_ranks", [2, 4])
-def test_process_per_rank_sharded_step_matches_the_oracle(tmp_path, n_ranks):
+def _check_failed_steps(outs, n_steps):
+    """the deliberately failed steps in front of a `*_fail` job (tests/dist_rank_worker.py): every rank came back from every one of them --
+    the culprit with its own error, the others with FWGPU_ERR_PEER -- and, as the caller's oracle comparison then shows, nothing was applied"""
+    PEER = 8
+    n = len(outs)
+    codes = np.stack([o["codes"] for o in outs])  # [rank, failed step]
+    assert codes.shape == (n, n_steps), codes
+    assert codes[n - 1, 0] not in (0, PEER) and np.all(codes[:n - 1, 0] == PEER), codes  # step A: the last rank's malformed record
+    if n_steps > 1:
+        assert np.all(codes[:, 1] == PEER), codes                                        # step B: micro-batch sizes differ: nobody is "the" culprit
+
+
+@pytest.mark.parametrize("n_ranks,fail", [(2, False), (4, False), (2, True)])
+def test_process_per_rank_sharded_step_matches_the_oracle(tmp_path, n_ranks, fail):
     assert os.path.exists(FAKE), "tests/fake_rccl is not built (__graft_entry__.build)"
     n_ns, k, bits, ffm_bits = 10, 4, 14, 14
     mi, ocfg, ots = make_pair(n_ns, k, bits, ffm_bits, fw.Optimizer.AdagradLUT, lr=0.05, ffm_lr=0.05)
@@ -84,7 +96,9 @@ def test_process_per_rank_sharded_step_matches_the_oracle(tmp_path, n_ranks):
                             for s in range(steps)])
     ref_tabs = [np.asarray(om.lr_table), np.asarray(om.ffm_weights), np.asarray(om.ffm_acc)]
     parts = [[gb // n_ranks] * n_ranks for _ in range(steps)]
-    outs = _run_job(tmp_path, "sharded", n_ranks, (n_ns, k, bits, ffm_bits, fw.Optimizer.AdagradLUT, 0.05), recs, off, parts, allreduce=1)
+    outs = _run_job(tmp_path, "sharded_fail" if fail else "sharded", n_ranks, (n_ns, k, bits, ffm_bits, fw.Optimizer.AdagradLUT, 0.05), recs, off, parts, allreduce=1)
+    if fail:
+        _check_failed_steps(outs, 2)
     per = gb // n_ranks
     preds = np.zeros(steps * gb, dtype=np.float32)
     for r, o in enumerate(outs):
@@ -102,8 +116,9 @@ def test_process_per_rank_sharded_step_matches_the_oracle(tmp_path, n_ranks):
         assert np.array_equal(o["allreduce"], o["ffm_acc"] * np.float32(n_ranks))
 
 
-@pytest.mark.parametrize("n_ranks,opt", [(2, fw.Optimizer.AdagradLUT), (4, fw.Optimizer.AdagradLUT), (3, fw.Optimizer.AdagradFlex)])
-def test_process_per_rank_sparse_step_matches_the_oracle(tmp_path, n_ranks, opt):
+@pytest.mark.parametrize("n_ranks,opt,fail", [(2, fw.Optimizer.AdagradLUT, False), (4, fw.Optimizer.AdagradLUT, False), (3, fw.Optimizer.AdagradFlex, False),
+                                              (3, fw.Optimizer.AdagradLUT, True)])
+def test_process_per_rank_sparse_step_matches_the_oracle(tmp_path, n_ranks, opt, fail):
     assert os.path.exists(FAKE), "tests/fake_rccl is not built (__graft_entry__.build)"
     n_ns, k, bits, ffm_bits = 12, 4, 15, 15
     mi, ocfg, ots = make_pair(n_ns, k, bits, ffm_bits, opt, lr=0.05, ffm_lr=0.05)
@@ -118,7 +133,9 @@ def test_process_per_rank_sparse_step_matches_the_oracle(tmp_path, n_ranks, opt)
     p_ref = np.concatenate([om.learn_sparse(ots, recs[int(off[s * gb]):int(off[(s + 1) * gb])], off[s * gb:(s + 1) * gb + 1] - off[s * gb],
                                             np.cumsum(parts[s])) for s in range(steps)])
     ref_tabs = [np.asarray(om.lr_table), np.asarray(om.ffm_weights), np.asarray(om.ffm_acc)]
-    outs = _run_job(tmp_path, "sparse", n_ranks, (n_ns, k, bits, ffm_bits, opt, 0.05), recs, off, parts)
+    outs = _run_job(tmp_path, "sparse_fail" if fail else "sparse", n_ranks, (n_ns, k, bits, ffm_bits, opt, 0.05), recs, off, parts)
+    if fail:
+        _check_failed_steps(outs, 1)
     preds = np.zeros(steps * gb, dtype=np.float32)
     taken = [0] * n_ranks
     for s in range(steps):
