@@ -222,6 +222,27 @@ def measure_traffic(args):
                    f"(3 steps; median per learn dispatch: FETCH_SIZE {kb['FETCH_SIZE']:.0f} KB x2 (gfx950 16 B/lane correction) + WRITE_SIZE {kb['WRITE_SIZE']:.0f} KB)")
 
 
+def config_e_leg(args):
+    """BASELINE configs[4] next to the headline line: a short child run of this script with k = 16 and the 2 x 256 ReLU head (exact
+    per-example head, hogwild), so that the driver's default invocation measures it too.  A reported side figure, never `value`."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--k", "16", "--nn-layers", "2", "--nn-width", "256", "--head", "exact", "--batch", "8192",
+           "--steps", "24", "--warmup", "4", "--holdout", str(args.holdout), "--no-cpu-baseline", "--no-traffic", "--no-config-e",
+           "--fields", str(args.fields), "--bits", str(args.bits), "--ffm-bits", str(args.ffm_bits)]
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=420, check=False)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not lines:
+            return {"value": None, "error": (p.stderr or p.stdout)[-300:]}
+        d = json.loads(lines[-1])
+        return {"value": d["value"], "unit": d["unit"], "final_logloss": d["final_logloss"], "ms_per_step": d["ms_per_step"],
+                "roofline_frac": d["roofline"]["frac"], "examples_learned": (d["steps"] + d["warmup"]) * 8192,
+                "workload": d["config"]["workload"], "kernel": d["roofline"]["kernel"]}
+    except Exception as e:  # a side measurement: never lose the bench line over it
+        return {"value": None, "error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -289,6 +310,8 @@ def main():
     ap.add_argument("--target-logloss", dest="target_logloss", type=float, default=None,
                     help="seconds_to_logloss target (default: 0.985 x the loss of always predicting the hold-out's positive rate)")
     ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
+    ap.add_argument("--no-config-e", dest="config_e", action="store_false",
+                    help="skip the short config-E leg (k = 16 + 2 x 256 ReLU head, a child run) that the default single-GPU line reports as `config_e`")
     ap.add_argument("--cpu-examples", dest="cpu_examples", type=int, default=0)
     args = ap.parse_args()
     if os.environ.get("FWGPU_BENCH_DEBUG"):  # where is a hung run?  Python stacks of all threads to stderr after that many seconds
@@ -663,6 +686,9 @@ def main():
             tb = 8.0 * ((1 << args.ffm_bits) + args.fields * args.k) + 8.0 * (1 << args.bits)
             out["link_bytes_per_example"] = link_bytes_per_example(args, world, nb.n_ffm / max(nb.n, 1), nb.n_lr / max(nb.n, 1), words[W] / max(nb.n, 1),
                                                                    sync_every, tb)
+        if args.config_e and world == 1 and not use_dist and not sync_steps and not args.nn_layers and args.k == 8 and args.cpu:
+            # (released first: the child allocates its own 28-bit tables)
+            out["config_e"] = "pending"
         if pcie is not None:
             out["pcie_inclusive"] = pcie
         if sparse_main:
@@ -696,6 +722,12 @@ def main():
         dog.cancel()
         if out is not None:
             out["dp_modes"] = dp_modes
+    if out is not None and out.get("config_e") == "pending":
+        for bb in batches:
+            bb.close()
+        hbatch.close()
+        re.close()
+        out["config_e"] = config_e_leg(args)
     result_line = json.dumps(out) if out is not None else None
     if use_dist:
         dist.barrier()

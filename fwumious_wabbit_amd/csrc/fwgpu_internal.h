@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <memory>
 #include <string>
 #include <condition_variable>
 #include <functional>
@@ -109,6 +110,7 @@ struct KernelParams {
     float lr_rate, lr_minus_power_t;    // SGD / AdagradFlex parameters of the LR block
     float ffm_rate, ffm_minus_power_t;  // ... of the FFM block
     int32_t lut_global;                 // 1: AdaGrad LUT read from global memory (through L1) instead of an LDS copy
+    int32_t lut_lds_forced;             // ... unless the launch runs a kernel that keeps it in LDS as a compile-time fact (resolve_row_mode)
     int32_t store_policy;               // hogwild launches of the v2 window kernel: how FFM row stores reach memory (kernels.hip "store policy"): 0 = both tables
                                         // device-scope write-through, 1 = weights write-back through the XCD's L2, 2 = both tables write-back
     uint32_t wb_flush_every;            // policies 1 / 2: a workgroup writes its XCD's dirty L2 lines back (buffer_wbl2 sc1) every this many of its examples (0: never)
@@ -253,6 +255,7 @@ hipError_t launch_coherence_probe(unsigned *scratch, int use_sc1, unsigned iters
 }  // namespace fwgpu
 
 struct fwgpu_block_cache;
+namespace fwgpu { struct HostBatch; }
 struct fwgpu_batch {
     fwgpu_regressor *owner = nullptr;
     const fwgpu_block_cache *cache = nullptr;  // context cache the next predict-only launch of this batch starts from
@@ -297,6 +300,7 @@ struct fwgpu_batch {
     uint32_t work_next = 0;
     void *tr_dev = nullptr;  // device blob holding the DevTranslator arrays
     fwgpu::DevTranslator tr{};
+    std::unique_ptr<fwgpu::HostBatch> host_copy;  // entry batches with an example of more than 4096 FFM features / LR entries: walked example by example (regressor.cpp)
 };
 
 struct fwgpu_regressor {
@@ -432,6 +436,7 @@ struct HostBatch {  // SoA staging of a CSR batch on the host
 };
 int batch_alloc(fwgpu_regressor *r, uint32_t n, uint64_t n_lr, uint64_t n_ffm, fwgpu_batch **out, bool host_mapped = false);
 int batch_upload(fwgpu_batch *b, const HostBatch &hb, hipStream_t stream);
+void keep_host_copy_if_oversize(fwgpu_batch *b, HostBatch &&hb);
 int append_example(const fwgpu_regressor *r, HostBatch &hb, const fwgpu_lr_entry *lr, uint32_t n_lr,
                    const fwgpu_ffm_entry *ffm, uint32_t n_ffm, float label, float importance);
 int translate_record(const fwgpu_translator_config *t, const uint32_t *rec, uint32_t rec_len,

@@ -753,7 +753,8 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
 #ifndef FW_PHASE_TU  // (host functions live in ONE of the two translation units of this file: see the Makefile)
 size_t example_kernel_lds_bytes(const KernelParams &p, int optimizer) {
     size_t off[24];
-    return lds_layout(p.F, p.k, p.max_ffm, p.max_lr, (optimizer == FWGPU_OPT_ADAGRAD_LUT && p.update && !p.lut_global) ? 1 : 0,
+    // (lut_lds_forced: the v2 kernel's single-chunk instantiations ALWAYS keep the AdaGrad LUT in LDS -- kLdsLut -- whatever option 1 says)
+    return lds_layout(p.F, p.k, p.max_ffm, p.max_lr, (optimizer == FWGPU_OPT_ADAGRAD_LUT && p.update && (!p.lut_global || p.lut_lds_forced)) ? 1 : 0,
                       p.records ? p.max_rec : 0, p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off,
                       (p.records && p.prefetch) ? p.max_rec : 0, (p.records && p.tr_lds) ? tr_lds_words(p.tr) : 0);
 }
@@ -1927,7 +1928,7 @@ hipError_t launch_example_phase(const KernelParams &p_in, int optimizer, int pha
     if (p_in.n_examples == 0) return hipSuccess;
     KernelParams p = p_in;
     p.window = 0;  // (the generic kernel's update path)
-    p.prefetch = p.tr_lds = 0;  // (v2-only LDS regions)
+    p.prefetch = p.tr_lds = p.lut_lds_forced = 0;  // (v2-only LDS regions / choices)
     p.update = phase == 3 ? 1 : 0;
     p.chain = p.update && !p.no_chain;
     size_t lds = example_kernel_lds_bytes(p, optimizer);
@@ -2135,7 +2136,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
     // Single-chunk rows (configs B / C): the AdaGrad LUT is ALWAYS the LDS copy, decided at compile time -- s.lut is then an LDS pointer the
     // compiler can see through (ds_read_b32).  As a run-time choice between the LDS copy and the global table the pointer was generic: every
     // lookup a flat_load, and a flat access makes the wave wait for vmcnt(0) AND lgkmcnt(0) -- i.e. for the acknowledgement of every row
-    // store issued before it.  (launch_example_kernel clears lut_global for these launches so that the host sizes the LDS the same way.)
+    // store issued before it.  (resolve_row_mode sets lut_lds_forced for these launches so that the host sizes the LDS the same way.)
     constexpr bool kLdsLut = (OPT == FWGPU_OPT_ADAGRAD_LUT) && NC == 1;
     const bool use_lut = kLdsLut || ((OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global);
     Lds s;
@@ -2609,6 +2610,9 @@ void resolve_row_mode(KernelParams &p, uint32_t threads) {
     // three workgroups share a CU)
     p.prefetch = (p.prefetch && p.records && p.update && uses_resident_kernel(p, threads)) ? 1 : 0;
     p.tr_lds = (p.records && uses_resident_kernel(p, threads)) ? 1 : 0;  // the v2 kernel reads the translator's tables from an LDS copy
+    // The v2 kernel's single-chunk updating instantiations keep the LUT in LDS as a compile-time fact (kLdsLut): settled HERE, so that the host's
+    // LDS size -- the occupancy choice and the 160 KiB check of prepare_launch -- is the size the launch really uses (debug option 1 does not apply to them).
+    p.lut_lds_forced = (uses_resident_kernel(p, threads) && p.R <= 64 * 4 && p.update) ? 1 : 0;
 }
 
 hipError_t launch_example_kernel(const KernelParams &p_in, int optimizer, bool coherent, uint32_t grid, uint32_t threads,
@@ -2616,8 +2620,8 @@ hipError_t launch_example_kernel(const KernelParams &p_in, int optimizer, bool c
     if (p_in.n_examples == 0) return hipSuccess;
     KernelParams p = p_in;
     const bool v2 = uses_resident_kernel(p, threads);
-    if (v2 && p.R <= 64 * 4 && p.update) p.lut_global = 0;  // (the v2 kernel's single-chunk instantiations keep the LUT in LDS: see kLdsLut)
     resolve_row_mode(p, threads);  // (idempotent: run_batch has normally done it already, to size the LDS)
+    (void)v2;
     const size_t lds = example_kernel_lds_bytes(p, optimizer);
     // 16-byte row vectors need k % 4 == 0: then R % 4 == 0 and hash & mask is a multiple of next_pow2(k) >= 4
     // floats (feature_buffer.rs:141-148), so every row starts 16-byte aligned.

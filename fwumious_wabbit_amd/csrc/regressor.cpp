@@ -428,7 +428,7 @@ static int prepare_launch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int upda
         // flight with the LUT read through L1 beat one example with the LUT in LDS (k = 16: 1.82 -> 1.93 M examples/s)
         KernelParams q = p;
         q.lut_global = 1;
-        const size_t lds_nolut = example_kernel_lds_bytes(q, r->cfg.optimizer);
+        const size_t lds_nolut = example_kernel_lds_bytes(q, r->cfg.optimizer);  // (== lds where the kernel keeps the LUT in LDS regardless: lut_lds_forced)
         if (!p.lut_global && 2 * lds_nolut <= r->lds_per_cu) {
             p.lut_global = 1;
             lds = lds_nolut;
@@ -443,8 +443,10 @@ static int prepare_launch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int upda
     return FWGPU_OK;
 }
 
+static int run_batch_by_example(fwgpu_regressor *r, fwgpu_batch *b, int update, hipStream_t stream);
 static int run_batch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, hipStream_t stream) {
     if (b->n == 0) return FWGPU_OK;
+    if (b->host_copy) return run_batch_by_example(r, b, update, stream);  // (an example beyond what the fused kernel stages: see learn_one_chunked)
     KernelParams p;
     uint32_t threads = 0;
     int rc = prepare_launch(r, b, mode, update, p, threads);
@@ -477,6 +479,11 @@ int run_batch_peer(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, con
     FWGPU_HIP(hipMemsetAsync(b->work, 0, sizeof(uint32_t), stream));
     FWGPU_HIP(launch_example_kernel(p, r->cfg.optimizer, update != 0, grid, threads, stream));
     return FWGPU_OK;
+}
+
+// a batch with an example beyond what the fused kernel stages keeps its entries on the host: it is walked example by example (run_batch)
+void keep_host_copy_if_oversize(fwgpu_batch *b, HostBatch &&hb) {
+    if (hb.max_ffm > 4096 || hb.max_lr > 4096) b->host_copy.reset(new HostBatch(std::move(hb)));
 }
 
 }  // namespace fwgpu
@@ -833,6 +840,119 @@ static int one_prediction(fwgpu_regressor *r, float *prediction) {
     return FWGPU_OK;
 }
 
+// ---- examples beyond the fused kernel's LDS budget.
+// The reference takes an example of any size (block_ffm.rs:294-312: the gradient cache moves to the heap beyond 170 393 floats, the algorithm
+// stays what it is).  The fused kernel stages an example's entries in LDS: 4096 FFM features / LR entries at most.  A larger example takes the
+// synchronous pipeline instead, CHUNK by chunk -- field sums and LR sums are additive over features:
+//   FWD   every chunk of <= kChunkEntries entries is a pseudo-example of a small batch: its partial field sums, self-pair corrections and LR sum
+//         go to its split record, its features' own slots to the selfw buffer (pre-update weights, as block_ffm.rs:219-261 uses them);
+//   sum   the chunks' records are added in chunk order and the total is copied back into every chunk's record;
+//   MID   logit, prediction and general gradient once, from the total;
+//   UPD   the chunks IN ORDER on one workgroup, each with the total record: AdaGrad per occurrence in buffer order, rows that repeat or
+//         overlap across chunks included (a later chunk re-reads what an earlier one wrote), exactly the reference's update loop (block_ffm.rs:265-288).
+// Only the order of the field sums' additions differs from the reference (chunk subtotals): ~1e-7 relative.  Models with a deep head are not covered.
+constexpr uint32_t kMaxStagedEntries = 4096;  // what one workgroup of the fused kernel stages (prepare_launch)
+constexpr uint32_t kChunkEntries = 2048;
+
+static int learn_one_chunked(fwgpu_regressor *r, const HostBatch &hb, uint32_t e, int update, float *prediction) {
+    if (r->nn.n_layers) return fail(FWGPU_ERR_RANGE, "an example has more than 4096 FFM features or LR entries: not covered for models with a deep head");
+    const uint32_t f0 = hb.ffm_off[e], f1 = hb.ffm_off[e + 1], l0 = hb.lr_off[e], l1 = hb.lr_off[e + 1];
+    const uint32_t nf = f1 - f0, nl = l1 - l0;
+    const uint32_t m = std::max<uint32_t>(1, std::max((nf + kChunkEntries - 1) / kChunkEntries, (nl + kChunkEntries - 1) / kChunkEntries));
+    HostBatch hc;
+    hc.clear();
+    hc.aligned4 = hb.aligned4;
+    for (uint32_t j = 0; j < m; j++) {
+        const uint32_t fa = std::min(nf, j * kChunkEntries), fb = std::min(nf, (j + 1) * kChunkEntries);
+        const uint32_t la = std::min(nl, j * kChunkEntries), lb = std::min(nl, (j + 1) * kChunkEntries);
+        hc.ffm_hash.insert(hc.ffm_hash.end(), hb.ffm_hash.begin() + f0 + fa, hb.ffm_hash.begin() + f0 + fb);
+        hc.ffm_val.insert(hc.ffm_val.end(), hb.ffm_val.begin() + f0 + fa, hb.ffm_val.begin() + f0 + fb);
+        hc.ffm_fld.insert(hc.ffm_fld.end(), hb.ffm_fld.begin() + f0 + fa, hb.ffm_fld.begin() + f0 + fb);
+        hc.lr_hash.insert(hc.lr_hash.end(), hb.lr_hash.begin() + l0 + la, hb.lr_hash.begin() + l0 + lb);
+        hc.lr_val.insert(hc.lr_val.end(), hb.lr_val.begin() + l0 + la, hb.lr_val.begin() + l0 + lb);
+        hc.lr_combo.insert(hc.lr_combo.end(), hb.lr_combo.begin() + l0 + la, hb.lr_combo.begin() + l0 + lb);
+        hc.ffm_off.push_back((uint32_t)hc.ffm_hash.size());
+        hc.lr_off.push_back((uint32_t)hc.lr_hash.size());
+        hc.label.push_back(hb.label[e]);
+        hc.importance.push_back(hb.importance[e]);
+        hc.max_ffm = std::max(hc.max_ffm, fb - fa);
+        hc.max_lr = std::max(hc.max_lr, lb - la);
+    }
+    fwgpu_batch *cb = nullptr;
+    fwgpu_split *sp = nullptr;
+    int rc = batch_alloc(r, m, hc.lr_hash.size(), hc.ffm_hash.size(), &cb);
+    if (rc == FWGPU_OK) rc = batch_upload(cb, hc, 0);
+    if (rc == FWGPU_OK) rc = fwgpu_split_create(r, m, kChunkEntries, &sp);
+    auto done = [&](int code) {
+        (void)hipStreamSynchronize(0);
+        if (cb) fwgpu_batch_free(cb);
+        if (sp) fwgpu_split_free(sp);
+        return code;
+    };
+    if (rc) return done(rc);
+    SplitRanges rg;
+    rg.home_lo = 0;
+    rg.home_hi = 1;  // the label and the importance enter the total once: chunk 0 contributes them
+    if ((rc = split_forward(r, cb, sp, FWGPU_MODE_HOGWILD, rg, 0))) return done(rc);
+    const size_t SL = sp->split_len;
+    for (uint32_t j = 1; j < m; j++)
+        if (launch_add(sp->d_split, sp->d_split + (size_t)j * SL, SL, 0) != hipSuccess) return done(fail(FWGPU_ERR_DEVICE, "chunked example: add failed"));
+    if ((rc = split_mid(r, sp, 0, 1, cb->pred, false, 0))) return done(rc);
+    const bool upd = update && hb.importance[e] != 0.0f;  // regressor.rs:366
+    if (upd) {
+        for (uint32_t j = 1; j < m; j++) {
+            if (hipMemcpyAsync(sp->d_split + (size_t)j * SL, sp->d_split, SL * 4, hipMemcpyDeviceToDevice, 0) != hipSuccess ||
+                hipMemcpyAsync(sp->d_g + j, sp->d_g, 4, hipMemcpyDeviceToDevice, 0) != hipSuccess)
+                return done(fail(FWGPU_ERR_DEVICE, "chunked example: copy failed"));
+        }
+        if ((rc = split_update(r, cb, sp, FWGPU_MODE_SEQUENTIAL, rg, false, 0))) return done(rc);
+    }
+    if (hipMemcpyAsync(prediction, cb->pred, 4, hipMemcpyDeviceToHost, 0) != hipSuccess) return done(fail(FWGPU_ERR_DEVICE, "chunked example: read-back failed"));
+    return done(FWGPU_OK);
+}
+
+// one example of a host batch through the single-example path (fused kernel in order, or chunk by chunk)
+static int learn_host_example(fwgpu_regressor *r, const HostBatch &hb, uint32_t e, int update, float *prediction) {
+    const uint32_t nf = hb.ffm_off[e + 1] - hb.ffm_off[e], nl = hb.lr_off[e + 1] - hb.lr_off[e];
+    if (nf > kMaxStagedEntries || nl > kMaxStagedEntries) return learn_one_chunked(r, hb, e, update, prediction);
+    HostBatch one;
+    one.clear();
+    one.aligned4 = hb.aligned4;
+    one.ffm_hash.assign(hb.ffm_hash.begin() + hb.ffm_off[e], hb.ffm_hash.begin() + hb.ffm_off[e + 1]);
+    one.ffm_val.assign(hb.ffm_val.begin() + hb.ffm_off[e], hb.ffm_val.begin() + hb.ffm_off[e + 1]);
+    one.ffm_fld.assign(hb.ffm_fld.begin() + hb.ffm_off[e], hb.ffm_fld.begin() + hb.ffm_off[e + 1]);
+    one.lr_hash.assign(hb.lr_hash.begin() + hb.lr_off[e], hb.lr_hash.begin() + hb.lr_off[e + 1]);
+    one.lr_val.assign(hb.lr_val.begin() + hb.lr_off[e], hb.lr_val.begin() + hb.lr_off[e + 1]);
+    one.lr_combo.assign(hb.lr_combo.begin() + hb.lr_off[e], hb.lr_combo.begin() + hb.lr_off[e + 1]);
+    one.ffm_off.push_back(nf);
+    one.lr_off.push_back(nl);
+    one.label.push_back(hb.label[e]);
+    one.importance.push_back(hb.importance[e]);
+    one.max_ffm = nf;
+    one.max_lr = nl;
+    int rc = ensure_one(r, nl, nf);
+    if (rc) return rc;
+    if ((rc = batch_upload(r->one, one, 0))) return rc;
+    rc = run_batch(r, r->one, FWGPU_MODE_SEQUENTIAL, update, 0);
+    if (rc == FWGPU_ERR_RANGE && !r->nn.n_layers) return learn_one_chunked(r, hb, e, update, prediction);
+    if (rc) return rc;
+    return one_prediction(r, prediction);
+}
+
+// A batch that holds an oversize example keeps its host copy (fwgpu_batch::host_copy) and is walked example by example, in order, whatever the
+// mode: the in-order result is one of the outcomes hogwild allows.  The rare path: three launches per chunked example.
+int fwgpu::run_batch_by_example(fwgpu_regressor *r, fwgpu_batch *b, int update, hipStream_t stream) {
+    FWGPU_HIP(hipStreamSynchronize(stream));
+    const HostBatch &hb = *b->host_copy;
+    std::vector<float> preds(hb.size());
+    for (uint32_t e = 0; e < hb.size(); e++) {
+        int rc = learn_host_example(r, hb, e, update, &preds[e]);
+        if (rc) return rc;
+    }
+    FWGPU_HIP(hipMemcpy(b->pred, preds.data(), preds.size() * 4, hipMemcpyHostToDevice));
+    return FWGPU_OK;
+}
+
 static int learn_one(fwgpu_regressor *r, const fwgpu_lr_entry *lr, uint32_t n_lr, const fwgpu_ffm_entry *ffm,
                      uint32_t n_ffm, float label, float importance, int update, float *prediction) {
     if (!r || !prediction) return fail(FWGPU_ERR_INVALID, "NULL argument");
@@ -842,11 +962,14 @@ static int learn_one(fwgpu_regressor *r, const fwgpu_lr_entry *lr, uint32_t n_lr
     hb.clear();
     int rc = append_example(r, hb, lr, n_lr, ffm, n_ffm, label, importance);
     if (rc) return rc;
+    if (hb.max_ffm > kMaxStagedEntries || hb.max_lr > kMaxStagedEntries) return learn_one_chunked(r, hb, 0, update, prediction);
     rc = ensure_one(r, (uint32_t)hb.lr_hash.size(), (uint32_t)hb.ffm_hash.size());
     if (rc) return rc;
     rc = batch_upload(r->one, hb, 0);
     if (rc) return rc;
     rc = run_batch(r, r->one, FWGPU_MODE_SEQUENTIAL, update, 0);
+    // (fewer than 4096 entries of each kind, but together more than the LDS holds: prepare_launch refuses before anything is launched)
+    if (rc == FWGPU_ERR_RANGE && !r->nn.n_layers) return learn_one_chunked(r, hb, 0, update, prediction);
     if (rc) return rc;
     return one_prediction(r, prediction);
 }
@@ -886,6 +1009,7 @@ int fwgpu_batch_create(fwgpu_regressor *r, const fwgpu_lr_entry *lr, const uint3
         fwgpu_batch_free(b);
         return rc;
     }
+    keep_host_copy_if_oversize(b, std::move(hb));
     *out = b;
     return FWGPU_OK;
 }
@@ -900,6 +1024,19 @@ int fwgpu_record_batch_create(fwgpu_regressor *r, const fwgpu_translator_config 
     if (rc) return rc;
     rc = record_batch_upload(b, t, records, rec_off, n, 0);
     if (rc == FWGPU_OK && hipStreamSynchronize(0) != hipSuccess) rc = fail(FWGPU_ERR_DEVICE, "upload failed");
+    if (rc == FWGPU_OK && (b->max_ffm > kMaxStagedEntries || b->max_lr > kMaxStagedEntries)) {
+        // a record that translates to more entries than a workgroup stages: the batch is translated on the host and walked example by example
+        HostBatch hb;
+        hb.clear();
+        std::vector<fwgpu_lr_entry> lr;
+        std::vector<fwgpu_ffm_entry> ffm;
+        for (uint32_t i = 0; i < n && rc == FWGPU_OK; i++) {
+            float label, imp;
+            rc = translate_record(t, records + rec_off[i], (uint32_t)(rec_off[i + 1] - rec_off[i]), lr, ffm, &label, &imp);
+            if (rc == FWGPU_OK) rc = append_example(r, hb, lr.data(), (uint32_t)lr.size(), ffm.data(), (uint32_t)ffm.size(), label, imp);
+        }
+        if (rc == FWGPU_OK) keep_host_copy_if_oversize(b, std::move(hb));
+    }
     if (rc) {
         fwgpu_batch_free(b);
         return rc;

@@ -285,6 +285,7 @@ int fwgpu_batch_from_records(fwgpu_regressor *r, const fwgpu_translator_config *
         fwgpu_batch_free(b);
         return rc;
     }
+    keep_host_copy_if_oversize(b, std::move(hb));
     *out = b;
     return FWGPU_OK;
 }

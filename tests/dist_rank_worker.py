@@ -43,7 +43,7 @@ def main():
     re = fw.Regressor(mi)
     fbt = fw.FeatureBufferTranslator(mi)
     d = DistRank(re, uid, rank, n_ranks)
-    if mode in ("sharded", "peer_seq"):
+    if mode in ("sharded", "sharded_fail", "peer_seq"):
         d.set_mode(capi.MODE_SEQUENTIAL)
     if mode in ("peer", "peer_seq"):
         d.peer_attach()

@@ -822,7 +822,7 @@ def test_cpp_host_mirror_reference_tests():
 
 def test_very_large_examples():
     """An example with thousands of features (1024-thread workgroups, the generic kernel) next to ordinary ones: same results
-    as the oracle in the in-order mode; more than 4096 FFM features in one example is refused, not mis-trained."""
+    as the oracle in the in-order mode, whatever their size."""
     k, F = 4, 5
     mi, ocfg, _ = make_pair(F, k, 16, 16, fw.Optimizer.AdagradLUT, lr=0.02, ffm_lr=0.02)
     rng = np.random.default_rng(31)
@@ -848,12 +848,18 @@ def test_very_large_examples():
     # the concurrent mode copes with the same batch (results are order dependent: only sanity is checked)
     re.learn_batch(b, capi.MODE_HOGWILD, True)
     assert np.all(np.isfinite(b.predictions()))
-    for too_big in ((4100, 1), (3900, 3900)):  # more than 4096 FFM features / does not fit the LDS: refused loudly
-        with pytest.raises(capi.FwgpuError):
-            lr, ffm = example(*too_big)
-            re.learn(fw.lr_and_ffm_vec(lr, ffm, 1.0, 1.0), None, True)
     b.close()
     re.close()
+    # more than a workgroup stages (4096 entries), or more than the LDS holds (3900 + 3900): the chunked path (regressor.cpp learn_one_chunked), same
+    # results as the oracle -- round 3 refused these with FWGPU_ERR_RANGE
+    om2, re2 = fwo.Model(ocfg), fw.Regressor(mi)
+    for n_ffm, n_lr in ((4100, 1), (3900, 3900), (30, 5000)):
+        lr, ffm = example(n_ffm, n_lr)
+        want = om2.learn(fwo.lr_entries(lr), fwo.ffm_entries(ffm), 1.0, 1.0, True)
+        got = re2.learn(fw.lr_and_ffm_vec(lr, ffm, 1.0, 1.0), None, True)
+        assert abs(got - want) < 2e-5, (n_ffm, n_lr, got, want)
+    assert np.abs(re2.table_read(capi.TABLE_FFM_W) - om2.ffm_weights).max() < 2e-5
+    re2.close()
 
 
 def test_trainer_holdout_and_testonly_protocol():
@@ -940,3 +946,57 @@ def test_table_placement_search_is_transparent(monkeypatch):
     small = fw.Regressor(make_pair(4, 4, 14, 14, fw.Optimizer.AdagradLUT)[0])
     assert small.placement() == (1, 0.0, 0.0)
     small.close()
+
+
+# ------------------------------------------------------------------ examples beyond what a workgroup stages (block_ffm.rs:294-312)
+@pytest.mark.parametrize("n_feat,opt", [(6000, fw.Optimizer.AdagradLUT), (20000, fw.Optimizer.AdagradFlex), (20000, fw.Optimizer.SGD)])
+def test_examples_beyond_4096_features_take_the_chunked_path(n_feat, opt):
+    """The reference takes an example of any size (its gradient cache moves to the heap beyond 170 393 floats, block_ffm.rs:294-312).  The fused
+    kernel stages at most 4096 entries; larger examples go through the synchronous pipeline chunk by chunk (regressor.cpp learn_one_chunked).
+    Against the oracle: predict, three learn calls on three different huge examples -- rows repeated across chunks, rows that overlap rows of
+    other chunks, LR hashes repeated across chunks included -- then an ordinary small example, per-call predictions and the final tables."""
+    F, k, bits, ffm_bits = 8, 4, 16, 16
+    mi, ocfg, _ = make_pair(F, k, bits, ffm_bits, opt, lr=0.01, ffm_lr=0.01)
+    om = fwo.Model(ocfg)
+    re = fw.Regressor(mi)
+    rng = np.random.default_rng(n_feat)
+    R = F * k
+
+    def example(n):
+        fld = np.sort(rng.integers(0, F, size=n))
+        h = (rng.integers(0, (1 << ffm_bits) // 4, size=n) * 4).astype(np.int64)
+        h[n // 2] = h[7]                    # the same row 3000+ entries apart (another chunk) ...
+        h[n - 5] = h[11] + 4                # ... and a row that overlaps a row of an early chunk
+        v = rng.uniform(0.002, 0.02, size=n)
+        ffm = [(int(h[i]), float(v[i]), int(fld[i]) * k) for i in range(n)]
+        lh = rng.integers(0, 1 << bits, size=n)
+        lh[n - 3] = lh[2]                   # a repeated LR hash across chunks
+        lr = [(int(lh[i]), float(v[i]), int(fld[i])) for i in range(n)] + [(11650396 & ((1 << bits) - 1), 1.0, F)]
+        return lr, ffm
+
+    worst = 0.0
+    for step in range(5):
+        lr, ffm = example(n_feat if step < 4 else 40)
+        label = float(step % 2)
+        fb = fw.lr_and_ffm_vec(lr, ffm, label=label)
+        if step == 0:
+            p_gpu, p_cpu = re.predict(fb), om.predict(fwo.lr_entries(lr), fwo.ffm_entries(ffm))
+        else:
+            p_gpu, p_cpu = re.learn(fb, None, True), om.learn(fwo.lr_entries(lr), fwo.ffm_entries(ffm), label, 1.0, True)
+        worst = max(worst, abs(p_gpu - p_cpu))
+    assert worst < 2e-5, worst
+    for which, ref in ((capi.TABLE_FFM_W, om.ffm_weights), (capi.TABLE_FFM_ACC, om.ffm_acc), (capi.TABLE_LR, om.lr_table)):
+        got, ref = re.table_read(which), np.asarray(ref).reshape(-1)
+        bad = np.abs(got - ref[:len(got)]) > 2e-5 + 1e-4 * np.abs(ref[:len(got)])
+        assert int(bad.sum()) <= 3, (which, int(bad.sum()), float(np.abs(got - ref[:len(got)]).max()))
+    # the same through a BATCH that holds one oversize example among ordinary ones (walked example by example, in order)
+    fbs, want = [], []
+    for step in range(3):
+        lr, ffm = example(n_feat if step == 1 else 30)
+        fbs.append(fw.lr_and_ffm_vec(lr, ffm, label=float(step % 2)))
+        want.append(om.learn(fwo.lr_entries(lr), fwo.ffm_entries(ffm), float(step % 2), 1.0, True))
+    b = re.batch(fbs)
+    re.learn_batch(b, capi.MODE_HOGWILD, True)
+    assert np.abs(b.predictions() - np.array(want, dtype=np.float32)).max() < 2e-5
+    b.close()
+    re.close()
