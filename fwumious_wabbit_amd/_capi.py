@@ -146,6 +146,9 @@ def lib():
         "fwgpu_dist_group_learn_sparse": [vp, P(TranslatorConfig), vp, vp, vp, vp],
         "fwgpu_dist_group_learn_peer": [vp, P(TranslatorConfig), vp, vp, vp, vp, i32],
         "fwgpu_dist_peer_attach": [vp],
+        "fwgpu_dist_owner_attach": [vp, u32, u32],
+        "fwgpu_dist_learn_owner": [vp, P(TranslatorConfig), vp, vp, u32, vp, i32],
+        "fwgpu_dist_group_learn_owner": [vp, P(TranslatorConfig), vp, vp, vp, vp, i32],
         "fwgpu_dist_learn_peer": [vp, P(TranslatorConfig), vp, vp, u32, vp, i32],
         "fwgpu_dist_learn_peer_batch": [vp, P(TranslatorConfig), vp, i32, vp],
         "fwgpu_dist_barrier": [vp],

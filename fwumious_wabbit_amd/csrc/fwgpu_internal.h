@@ -65,6 +65,16 @@ struct PeerShards {
     float *ffm_w[8], *ffm_acc[8], *lr[8];
 };
 
+// owner-side apply (dist.cpp fwgpu_dist_*_owner): where a SOURCE rank's kernel puts the gradient rows of its examples -- one region per owner, in
+// the OWNER's memory (same device, or peer / IPC mapped), written by this source only; positions come from counters in the source's own memory
+struct PushRings {
+    uint32_t n, cap_ffm, cap_lr, pad_;
+    uint32_t *cnt;  // [2n + 1] source-local: rows pushed to owner o, LR entries pushed to owner o (at n + o), then an overflow flag
+    uint32_t *ffm_key[8];  // per owner: row hash of every pushed gradient row ...
+    float *ffm_rows[8];    // ... and its R floats (block_ffm.rs:278: general gradient x gradient cache)
+    uint2 *lr_ent[8];      // per owner: {hash, gradient bits} of every pushed LR entry (block_lr.rs:140-147)
+};
+
 // Everything the example kernel needs, passed by value.
 struct KernelParams {
     // ---- tables (HBM) ----
@@ -158,6 +168,7 @@ struct KernelParams {
     // kernel on its own examples and reaches a row IN ITS OWNER'S MEMORY (same device, or a peer GPU's memory mapped over xGMI).
     // owner(row) = row start >> shard_shift; every owner's allocation is indexed like the whole table.
     const struct PeerShards *shards;   // device memory; NULL: the regressor's own tables
+    const struct PushRings *push;      // with shards: the update phase pushes gradient rows to their owners instead of stepping the rows itself (owner-side apply)
 #if defined(FW_KP_PAD_POS) && FW_KP_PAD_POS == 4  // debug builds (scripts/kp_pos_exp.sh): 16 bytes HERE
     unsigned char kp_pos_pad[16];
 #endif
@@ -476,7 +487,11 @@ uint32_t ffm_hash_mask(uint32_t ffm_bits, uint32_t ffm_k);
 void lut_init(float *lut, float learning_rate, float power_t, float init_acc);
 KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int update);
 // the fused learn / predict launch of `b` with every row and LR entry reached in its owner's tables (generic kernel); d_shards: device copy
-int run_batch_peer(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, const PeerShards *d_shards, hipStream_t stream);
+int run_batch_peer(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, const PeerShards *d_shards, hipStream_t stream,
+                   const PushRings *d_push = nullptr);
+// owner-side apply: the optimizer steps of `n_rows` pushed gradient rows / `n_lr` pushed LR gradients on this regressor's own tables
+hipError_t launch_owner_apply(const fwgpu_regressor *r, float *lr_base, const uint32_t *keys, const float *rows, uint32_t n_rows, const uint2 *lr_ent,
+                              uint32_t n_lr, bool in_order, hipStream_t stream);
 struct SplitRanges {  // what a rank owns (sharded tables) and which examples of the launch are its own
     uint32_t ffm_lo = 0, ffm_hi = 0xffffffffu, lr_lo = 0, lr_hi = 0xffffffffu, home_lo = 0, home_hi = 0xffffffffu;
 };

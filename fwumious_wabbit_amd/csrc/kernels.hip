@@ -1783,6 +1783,65 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
                 gpair = gx + p.num_combos;
             }
             const uint32_t olo = PH == 3 ? p.own_lo_ffm : 0u, ohi = PH == 3 ? p.own_hi_ffm : 0xffffffffu;
+            if (SH && p.push) {
+                // ---------------- owner-side apply: this example's gradients travel to the rows' owners, who run the optimizer on their own tables
+                // (dist.cpp fwgpu_dist_*_owner).  Every OCCURRENCE is pushed -- repeated and overlapping rows need no special care here: the owner
+                // applies what it receives one after the other.  In-order launches push in buffer order from one wave / one thread, so that the
+                // owner's sequence of steps is the reference's (block_ffm.rs:269-286, block_lr.rs:140-150).
+                const PushRings &pr = *p.push;
+                const bool in_order = gridDim.x == 1;
+                auto push_lr = [&](uint32_t t) {
+                    const uint32_t h = s.l_hash[t], o = h >> p.shards->shift_lr;
+                    const uint32_t pos = atomicAdd(&pr.cnt[pr.n + o], 1u);
+                    if (pos < pr.cap_lr) {
+                        const float grad = g * s.l_val[t];  // block_lr.rs:143
+                        __hip_atomic_store(reinterpret_cast<unsigned long long *>(pr.lr_ent[o] + pos), (unsigned long long)h | ((unsigned long long)__float_as_uint(grad) << 32),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    } else {
+                        pr.cnt[2 * pr.n] = 1;
+                    }
+                };
+                if (p.has_lr) {
+                    if (in_order) {
+                        if (tid == 0)
+                            for (uint32_t t = 0; t < nl; ++t) push_lr(t);
+                    } else {
+                        for (uint32_t t = tid; t < nl; t += bd) push_lr(t);
+                    }
+                }
+                if (k && (!in_order || wave == 0)) {
+                    for (uint32_t i = in_order ? 0u : (uint32_t)wave; i < nf; i += in_order ? 1u : (uint32_t)nw) {
+                        const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[i]);
+                        const uint32_t f = __builtin_amdgcn_readfirstlane(s.e_fld[i]) & kFldMask;
+                        const uint32_t o = h >> p.shards->shift_ffm;
+                        uint32_t pos = 0;
+                        if (lane == 0) pos = atomicAdd(&pr.cnt[o], 1u);
+                        pos = __builtin_amdgcn_readfirstlane(pos);
+                        if (pos >= pr.cap_ffm) {
+                            if (lane == 0) pr.cnt[2 * pr.n] = 1;
+                            continue;
+                        }
+                        if (lane == 0) __hip_atomic_store(pr.ffm_key[o] + pos, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        const __amdgpu_buffer_rsrc_t rr = make_rsrc(pr.ffm_rows[o] + (size_t)pos * R, R * 4);
+                        const float v = s.e_val[i];
+                        for (uint32_t c = 0; c < nchunk; ++c) {
+                            const uint32_t e0 = (c * 64 + lane) * VEC;
+                            if (e0 >= R) continue;
+                            const uint32_t z = e0 / k;
+                            V tv = Vec<VEC>::lds_load(s.T + f * R + e0), sw = Vec<VEC>::zero(), gv = Vec<VEC>::zero();
+                            const bool self = z == f;
+                            if (self) sw = Vec<VEC>::lds_load(s.selfw + i * k + (e0 - z * k));
+#pragma unroll
+                            for (int j = 0; j < VEC; ++j) {
+                                float t_ = Vec<VEC>::get(tv, j);
+                                if (self) t_ = __fsub_rn(t_, __fmul_rn(Vec<VEC>::get(sw, j), v));  // contra - w*v   block_ffm.rs:238
+                                Vec<VEC>::set(gv, j, __fmul_rn(g, __fmul_rn(v, t_)));               // block_ffm.rs:239, 278
+                            }
+                            Vec<VEC>::template store<kAuxSys>(gv, rr, e0 * 4);
+                        }
+                    }
+                }
+            } else {
             if (p.has_lr) lr_update<OPT, COH, SH>(p, s, nl, g, gx, lut_lr, tid, bd, PH == 3 ? p.own_lo_lr : 0u, PH == 3 ? p.own_hi_lr : 0xffffffffu);
             FW_TICK(4);
             if (k) {
@@ -1812,6 +1871,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
                     }
                 }
             }
+            }  // (not the owner-side-apply push)
             FW_TICK(5);
         }
         if (tid == 0) s.ctr[6] = next_ticket;  // published by the loop-top barrier
@@ -2632,6 +2692,58 @@ hipError_t launch_example_kernel(const KernelParams &p_in, int optimizer, bool c
         return launch_v<4>(p, optimizer, coherent, grid, threads, lds, stream);
     }
     return launch_v<1>(p, optimizer, coherent, grid, threads, lds, stream);
+}
+
+// ------------------------------------------------------------------ owner-side apply (dist.cpp fwgpu_dist_*_owner)
+// The owner's half of the step: one wave per pushed gradient row runs the optimizer on the owner's OWN tables (acc += grad^2; w -= step,
+// optimizer.rs), one thread per pushed LR gradient likewise.  in_order (one wave): everything in the order it was pushed -- with one source
+// pushing one example at a time that is the reference's sequence of updates.  Concurrently the steps race like any hogwild step, but only
+// inside the owner: no read-modify-write ever crosses a link, and the accumulators never leave their GPU.
+template <int OPT>
+__global__ void __launch_bounds__(256) owner_apply_kernel(float *w, float *acc, float *lr, const uint32_t *keys, const float *rows, uint32_t n_rows,
+                                                          const uint2 *lr_ent, uint32_t n_lr, uint32_t R, float ffm_rate, float ffm_mpt, const float *lut_ffm,
+                                                          float lr_rate, float lr_mpt, const float *lut_lr, int in_order) {
+    const uint32_t lane = threadIdx.x & 63, gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t i = gw; i < n_rows; i += nw) {
+        const uint32_t h = __hip_atomic_load(keys + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (uint32_t e = lane; e < R; e += 64) {
+            const float grad = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(rows + (size_t)i * R + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+            float a = OPT == FWGPU_OPT_SGD ? 0.0f : __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned *>(acc + h + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            float wv = __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned *>(w + h + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            wv -= opt_step<OPT>(grad, a, ffm_rate, ffm_mpt, lut_ffm);  // block_ffm.rs:279-282
+            __hip_atomic_store(reinterpret_cast<unsigned *>(w + h + e), __float_as_uint(wv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (OPT != FWGPU_OPT_SGD) __hip_atomic_store(reinterpret_cast<unsigned *>(acc + h + e), __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (in_order) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next row of the ring may be the same row, or overlap it
+    }
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    for (uint32_t j = in_order ? 0u : gt; j < n_lr; j += in_order ? 1u : nt) {
+        if (in_order && gt != 0) break;
+        const unsigned long long ent = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(lr_ent + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t h = (uint32_t)ent;
+        const float grad = __uint_as_float((uint32_t)(ent >> 32));
+        float2 wa = lr_load<true>(lr, h);  // ({w, acc} pairs on the device whatever the optimizer)
+        wa.x -= opt_step<OPT>(grad, wa.y, lr_rate, lr_mpt, lut_lr);  // block_lr.rs:145-147
+        lr_store<true>(lr, h, wa);
+    }
+}
+
+hipError_t launch_owner_apply(const fwgpu_regressor *r, float *lr_base, const uint32_t *keys, const float *rows, uint32_t n_rows, const uint2 *lr_ent,
+                              uint32_t n_lr, bool in_order, hipStream_t stream) {
+    if (!n_rows && !n_lr) return hipSuccess;
+    const uint32_t F = r->cfg.ffm_k ? r->cfg.ffm_num_fields : 0, R = F * r->cfg.ffm_k;
+    const uint32_t blocks = in_order ? 1u : std::min<uint32_t>(4096u, std::max<uint32_t>(1u, (n_rows + 3) / 4 + (n_lr + 255) / 256));
+    const dim3 grid(blocks), block(in_order ? 64 : 256);
+#define FW_APPLY(OPT)                                                                                                                              \
+    hipLaunchKernelGGL(owner_apply_kernel<OPT>, grid, block, 0, stream, r->d_ffm_w, r->d_ffm_acc, lr_base, keys, rows, n_rows, lr_ent, n_lr, R, \
+                       r->cfg.ffm_learning_rate, -r->cfg.ffm_power_t, r->d_lut_ffm, r->cfg.learning_rate, -r->cfg.power_t, r->d_lut_lr, in_order ? 1 : 0)
+    switch (r->cfg.optimizer) {
+    case FWGPU_OPT_SGD: FW_APPLY(FWGPU_OPT_SGD); break;
+    case FWGPU_OPT_ADAGRAD_FLEX: FW_APPLY(FWGPU_OPT_ADAGRAD_FLEX); break;
+    default: FW_APPLY(FWGPU_OPT_ADAGRAD_LUT); break;
+    }
+#undef FW_APPLY
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ init / fill / checksum

@@ -464,7 +464,8 @@ static int run_batch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, h
     return FWGPU_OK;
 }
 
-int run_batch_peer(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, const PeerShards *d_shards, hipStream_t stream) {
+int run_batch_peer(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, const PeerShards *d_shards, hipStream_t stream,
+                   const PushRings *d_push) {
     if (b->n == 0) return FWGPU_OK;
     if (r->nn.n_layers) return fail(FWGPU_ERR_INVALID, "peer-sharded tables: models with a deep head are not covered");
     KernelParams p;
@@ -475,6 +476,8 @@ int run_batch_peer(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, con
     r->launch.kernel_version = kv;
     if (rc) return rc;
     p.shards = d_shards;
+    p.push = d_push;
+    if (d_push) p.hot_lr_every = 0;  // (owner-side apply: every LR gradient travels to its owner, the constant feature's included)
     const uint32_t grid = pick_grid(r, p, mode, threads);
     FWGPU_HIP(hipMemsetAsync(b->work, 0, sizeof(uint32_t), stream));
     FWGPU_HIP(launch_example_kernel(p, r->cfg.optimizer, update != 0, grid, threads, stream));

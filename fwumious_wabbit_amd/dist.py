@@ -84,6 +84,19 @@ class DistRank:
         check(capi.lib().fwgpu_dist_learn_peer(self.h, C.byref(translator.c), ptr(records), rec_off.ctypes.data_as(C.c_void_p), n, ptr(out), 1 if update else 0))
         return out[:n]
 
+    def owner_attach(self, max_rows, max_lr):
+        """owner-side apply: maps tables and gradient rings (sized for steps of up to max_rows gradient rows / max_lr LR gradients per rank); collective"""
+        check(capi.lib().fwgpu_dist_owner_attach(self.h, int(max_rows), int(max_lr)))
+
+    def learn_owner(self, translator, records, rec_off, update=True) -> np.ndarray:
+        """one COLLECTIVE owner-side-apply step: this rank's records (possibly none) fetch their rows from the owners and push gradient rows to them;
+        this rank then applies what the others pushed here"""
+        records, rec_off = _recs(records, rec_off)
+        n = len(rec_off) - 1
+        out = np.zeros(max(n, 1), dtype=np.float32)
+        check(capi.lib().fwgpu_dist_learn_owner(self.h, C.byref(translator.c), ptr(records) if n else None, rec_off.ctypes.data_as(C.c_void_p), n, ptr(out), 1 if update else 0))
+        return out[:n]
+
     def learn_peer_batch(self, translator, batch, update=True, stream=None):
         """the same step with the records already in HBM (Regressor.record_batch); predictions: batch.predictions()"""
         check(capi.lib().fwgpu_dist_learn_peer_batch(self.h, C.byref(translator.c), batch.h, 1 if update else 0, stream))
@@ -154,6 +167,18 @@ class DistGroup:
         offp = (C.c_void_p * self.n)(*[b.ctypes.data for _, b in rr])
         outp = (C.c_void_p * self.n)(*[o.ctypes.data for o in outs])
         check(capi.lib().fwgpu_dist_group_learn_peer(self.h, C.byref(translator.c), recp, offp, ns.ctypes.data_as(C.c_void_p), outp, 1 if update else 0))
+        return [o[:int(n)] for o, n in zip(outs, ns)]
+
+    def learn_owner(self, translator, records_per_rank, rec_off_per_rank, update=True):
+        """one owner-side-apply step: rank j's records fetch their rows from the owners and push one gradient row per occurrence to them, every
+        owner applies what it received on its own tables (fwgpu_dist_group_learn_owner) -> predictions per rank"""
+        rr = [_recs(a, b) for a, b in zip(records_per_rank, rec_off_per_rank)]
+        ns = np.array([len(b) - 1 for _, b in rr], dtype=np.uint32)
+        outs = [np.zeros(max(int(n), 1), dtype=np.float32) for n in ns]
+        recp = (C.c_void_p * self.n)(*[a.ctypes.data for a, _ in rr])
+        offp = (C.c_void_p * self.n)(*[b.ctypes.data for _, b in rr])
+        outp = (C.c_void_p * self.n)(*[o.ctypes.data for o in outs])
+        check(capi.lib().fwgpu_dist_group_learn_owner(self.h, C.byref(translator.c), recp, offp, ns.ctypes.data_as(C.c_void_p), outp, 1 if update else 0))
         return [o[:int(n)] for o, n in zip(outs, ns)]
 
     def gather_tables(self):

@@ -290,6 +290,17 @@ int fwgpu_dist_free(fwgpu_dist *d);
  * workgroup (deterministic, for parity checks) */
 int fwgpu_dist_set_mode(fwgpu_dist *d, int mode);
 int fwgpu_dist_group_set_mode(fwgpu_dist_group *g, int mode);
+/* Owner-side apply: sharded hogwild whose read-modify-writes never cross a link (what hogwild.rs:89-103 does with threads on one shared table,
+ * with GPUs and owner-sharded tables): a rank FETCHES its examples' weight rows from their owners, and PUSHES one gradient row per occurrence
+ * into a ring in the owner's memory; the owner runs the optimizer on its own tables.  fwgpu_dist_owner_attach maps tables and rings (rings sized
+ * for steps of up to max_rows gradient rows / max_lr LR gradients per rank); fwgpu_dist_learn_owner is ONE COLLECTIVE STEP -- every rank calls
+ * it, n may be 0 -- of push, count exchange, apply.  FWGPU_MODE_SEQUENTIAL with one example per step, ranks taking turns, is the sequential
+ * reference.  The in-process group form takes every rank's micro-batch in one call. */
+int fwgpu_dist_owner_attach(fwgpu_dist *d, uint32_t max_rows, uint32_t max_lr);
+int fwgpu_dist_learn_owner(fwgpu_dist *d, const fwgpu_translator_config *t, const uint32_t *records, const uint64_t *rec_off, uint32_t n,
+                           float *predictions, int update);
+int fwgpu_dist_group_learn_owner(fwgpu_dist_group *g, const fwgpu_translator_config *t, const uint32_t *const *records,
+                                 const uint64_t *const *rec_off, const uint32_t *n, float *const *predictions, int update);
 int fwgpu_dist_rank(const fwgpu_dist *d, int *rank, int *n_ranks);
 /* ranks of the job as the RCCL communicator itself counts them (ncclCommCount); 0 for a member of an in-process group */
 int fwgpu_dist_comm_count(const fwgpu_dist *d, int *count);

@@ -47,6 +47,9 @@ def main():
         d.set_mode(capi.MODE_SEQUENTIAL)
     if mode in ("peer", "peer_seq"):
         d.peer_attach()
+    if mode == "owner_seq":
+        d.set_mode(capi.MODE_SEQUENTIAL)
+        d.owner_attach(4096, 4096)
     preds = []
     pos = 0
     codes = []
@@ -92,6 +95,17 @@ def main():
             preds.append(d.learn_sparse(fbt, sub, so))
         elif mode == "peer":  # hogwild across the ranks: everybody at its own pace
             preds.append(d.learn_peer(fbt, sub, so))
+        elif mode == "owner_seq":
+            # owner-side apply, one example per COLLECTIVE step, the ranks taking turns in rank order: the sequential reference.  Every rank calls
+            # every step; the ranks whose turn it is not pass no record.
+            mine = []
+            for turn in range(n_ranks):
+                for e in range(int(parts[s, turn])):
+                    if turn == rank:
+                        mine.append(d.learn_owner(fbt, sub[int(so[e]):int(so[e + 1])], so[e:e + 2] - so[e])[0])
+                    else:
+                        d.learn_owner(fbt, sub[:0], so[:1])
+            preds.append(np.asarray(mine, dtype=np.float32))
         elif mode == "peer_seq":  # rank after rank, each in example order: the sequential reference over the ranks' micro-batches
             for turn in range(n_ranks):
                 if turn == rank:
@@ -101,7 +115,7 @@ def main():
             raise SystemExit("unknown mode " + mode)
         pos += int(parts[s].sum())
     ranges = np.array(d.ranges(), dtype=np.uint64)
-    if mode in ("sharded", "peer", "peer_seq"):
+    if mode in ("sharded", "peer", "peer_seq", "owner_seq"):
         d.gather_tables()
     tabs = [np.asarray(re.table_read(tt)) for tt in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)]
     # the replica mode's exchange: all-reduce (sum) of a device buffer through the same communicator -- here the rank's FFM

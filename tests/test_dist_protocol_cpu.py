@@ -157,6 +157,81 @@ def test_sharded_protocol_world2_and_world4_equal_one_learner():
         assert np.count_nonzero(w_ref) > 100  # it did learn something
 
 
+# ------------------------------------------------------------------ owner-side apply (dist.cpp fwgpu_dist_learn_owner)
+def _owner_worker(rank, world, port, out):
+    """the owner-side-apply step's protocol: FETCH the weights of the own examples' entries from their owners, score, PUSH one (hash, gradient)
+    per occurrence to the entry's owner -- positions counted by the source, counts exchanged with the step's one collective -- and APPLY what
+    arrived, source after source, in push order.  N ranks == one learner running synchronous steps of N*B examples, bit for bit."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lut = _make_lut()
+    per = (1 << BITS) // world
+    lo, hi = per * rank, per * (rank + 1)
+    w = np.zeros(1 << BITS, dtype=np.float32)
+    acc = np.zeros(1 << BITS, dtype=np.float32)
+    preds = []
+    cap = B * NNZ
+    for s in range(STEPS):
+        idx_all, val_all, y_all = _examples(s, world * B)
+        idx, val, y = idx_all[rank * B:(rank + 1) * B], val_all[rank * B:(rank + 1) * B], y_all[rank * B:(rank + 1) * B]
+        # fetch: the owners' current ranges (the GPU path reads single rows over the link; what matters here is WHOSE copy is read)
+        parts = [torch.zeros(per, dtype=torch.float32) for _ in range(world)]
+        dist.all_gather(parts, torch.from_numpy(w[lo:hi].copy()))
+        w_seen = torch.cat(parts).numpy()
+        # score the own examples, push one gradient per occurrence to its owner, in buffer order
+        push_h = np.zeros((world, cap), dtype=np.int64)
+        push_g = np.zeros((world, cap), dtype=np.float32)
+        cnt = np.zeros(world, dtype=np.int64)
+        for e in range(B):
+            wsum = np.float32(0.0)
+            for h, v in zip(idx[e], val[e]):
+                wsum = np.float32(wsum + w_seen[h] * v)
+            p, g = _sigmoid_grad(wsum, y[e])
+            preds.append(p)
+            for h, v in zip(idx[e], val[e]):
+                o = int(h) // per
+                push_h[o, cnt[o]] = h
+                push_g[o, cnt[o]] = np.float32(g * v)
+                cnt[o] += 1
+        # the step's collective: counts and rings (the GPU path writes the rings straight into the owner's memory and gathers only the counts)
+        all_cnt = [torch.zeros(world, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(all_cnt, torch.from_numpy(cnt.copy()))
+        all_h = [torch.zeros(world, cap, dtype=torch.int64) for _ in range(world)]
+        all_g = [torch.zeros(world, cap, dtype=torch.float32) for _ in range(world)]
+        dist.all_gather(all_h, torch.from_numpy(push_h.copy()))
+        dist.all_gather(all_g, torch.from_numpy(push_g.copy()))
+        # apply: source after source, push order
+        for src in range(world):
+            n = int(all_cnt[src][rank])
+            hh, gg = all_h[src][rank].numpy(), all_g[src][rank].numpy()
+            for j in range(n):
+                h, grad = int(hh[j]), np.float32(gg[j])
+                assert lo <= h < hi
+                acc[h] = np.float32(acc[h] + grad * grad)
+                w[h] = np.float32(w[h] - grad * lut[int(np.float32(acc[h]).view(np.uint32)) >> 20])
+    for tab in (w, acc):
+        parts = [torch.zeros(per, dtype=torch.float32) for _ in range(world)]
+        dist.all_gather(parts, torch.from_numpy(tab[lo:hi].copy()))
+        tab[:] = torch.cat(parts).numpy()
+    out[rank] = (w.copy(), acc.copy(), np.array(preds, dtype=np.float32))
+    dist.destroy_process_group()
+
+
+def test_owner_side_apply_protocol_world2_and_world4_equal_one_learner():
+    for world in (2, 4):
+        w_ref, acc_ref, p_ref = _single_learner(world)
+        port = _free_port()
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_owner_worker, args=(world, port, out), nprocs=world, join=True)
+        for r in range(world):
+            w, acc, preds = out[r]
+            assert np.array_equal(w, w_ref) and np.array_equal(acc, acc_ref), (world, r)
+            mine = np.concatenate([p_ref[s * world * B + r * B: s * world * B + (r + 1) * B] for s in range(STEPS)])
+            assert np.array_equal(preds, mine), (world, r)
+
+
 # ------------------------------------------------------------------ row-sparse gradient buckets (sparse.hip / dist.cpp)
 def _buckets(idx, val, g):
     """one rank's micro-batch -> deduplicated (key, gradient) buckets: occurrences sorted by (key, example, entry), summed in

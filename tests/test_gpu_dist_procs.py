@@ -169,12 +169,14 @@ def _no_straddle_stream(mi, n_ns, k, ffm_bits, n, seed):
     return recs, off
 
 
-@pytest.mark.parametrize("n_ranks", [2, 4])
-def test_process_per_rank_peer_sharded_in_order_is_the_sequential_reference(tmp_path, n_ranks):
+@pytest.mark.parametrize("mode,n_ranks", [("peer_seq", 2), ("peer_seq", 4), ("owner_seq", 2), ("owner_seq", 4)])
+def test_process_per_rank_peer_sharded_in_order_is_the_sequential_reference(tmp_path, mode, n_ranks):
     """fwgpu_dist_peer_attach (IPC handles of every rank's tables through the job's all-gather, hipIpcOpenMemHandle) +
     fwgpu_dist_learn_peer with the ranks taking turns (fwgpu_dist_barrier) and each in example order: the job is the sequential
     reference algorithm over the ranks' micro-batches in rank order -- per-example parity with the oracle and the gathered tables,
-    with every rank a PROCESS of its own that reaches the other processes' tables through mapped memory."""
+    with every rank a PROCESS of its own that reaches the other processes' tables through mapped memory.
+    `owner_seq`: the same job with OWNER-SIDE APPLY (fwgpu_dist_owner_attach + fwgpu_dist_learn_owner, one example per collective step): weight
+    rows fetched from the owner process's tables, gradient rows pushed into a ring in the owner process's memory, the owner applying them."""
     n_ns, k, bits, ffm_bits = 10, 4, 14, 14
     mi, ocfg, ots = make_pair(n_ns, k, bits, ffm_bits, fw.Optimizer.AdagradLUT, lr=0.05, ffm_lr=0.05)
     steps = 3
@@ -182,7 +184,7 @@ def test_process_per_rank_peer_sharded_in_order_is_the_sequential_reference(tmp_
     recs, off = _no_straddle_stream(mi, n_ns, k, ffm_bits, steps * 120, 191)
     om = fwo.Model(ocfg)
     _, p_ref = om.run_stream(ots, recs, off, holdout_after=0, nthreads=1)
-    outs = _run_job(tmp_path, "peer_seq", n_ranks, (n_ns, k, bits, ffm_bits, fw.Optimizer.AdagradLUT, 0.05), recs, off, parts)
+    outs = _run_job(tmp_path, mode, n_ranks, (n_ns, k, bits, ffm_bits, fw.Optimizer.AdagradLUT, 0.05), recs, off, parts)
     preds = np.zeros(steps * 120, dtype=np.float32)
     taken = [0] * n_ranks
     for s in range(steps):
