@@ -1043,7 +1043,10 @@ __device__ __forceinline__ void nn_layer_backward_vec(const DevNN &n, uint32_t l
                     w[u][c] = w[u][c] - upd;
                     a[u][c] = acc;
                 }
-                Vec<4>::store<kAuxSc1>(w[u], rw, bo);
+#ifndef FW_NN_WB_W  // A/B build: the dense WEIGHT stores of hogwild launches write-back through the XCD's L2 (the FFM rows' policy 1 applied to the head)
+#define FW_NN_WB_W 0
+#endif
+                Vec<4>::store<(FW_NN_WB_W ? kAuxPlain : kAuxSc1)>(w[u], rw, bo);
                 if (OPT != FWGPU_OPT_SGD) Vec<4>::store<kAuxSc1>(a[u], ra, bo);
             }
         }
@@ -1522,6 +1525,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
     if (tid == 0) {
         s.ctr[6] = atomicAdd(p.work, 1u);
         hot_lr_init<COH>(p, s, PH == 0);
+        s.ctr[kCtrWbCount] = blockIdx.x & 15u;
     }
 #ifdef FW_DBG_KERNARG_CHECK
     unsigned ka_sum0 = 0;
@@ -1875,6 +1879,13 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
             FW_TICK(5);
         }
         if (tid == 0) s.ctr[6] = next_ticket;  // published by the loop-top barrier
+#if FW_NN_WB_W
+        if (COH && NN && gridDim.x > 1 && tid == bd - 1) {  // (A/B build) bound on the dense weights' dirty window: one L2 write-back per 16 examples of a workgroup
+            const uint32_t c = s.ctr[kCtrWbCount] + 1;
+            s.ctr[kCtrWbCount] = c & 15u;
+            if ((c & 15u) == 0) asm volatile("buffer_wbl2 sc1" ::: "memory");
+        }
+#endif
     }
     if (COH && tid == 0 && s.ctr[13]) hot_lr_flush<SH>(p, s);  // (every thread's steps are in: the loop ends on a barrier)
 #ifdef FW_DBG_KERNARG_CHECK
@@ -2129,7 +2140,7 @@ hipError_t launch_split_mid(const KernelParams &p, uint32_t n, hipStream_t strea
 // overwrites what other examples did to it during this example's lifetime -- and the hold-out loss falls monotonically with MAXR at
 // equal examples/s (0.662 / 0.656 / 0.648 / 0.644 / 0.639 for 0 / 2 / 4 / 6 / 8 kept rows per wave at three workgroups per CU, where the
 // registers end at 8: profiles/r03_pareto.txt).  With duplicate-row chains, the placed accumulator table and kept rows that skip the
-// re-read of w, TWO workgroups per CU at 128 VGPRs (FW_LB_WAVES_WIN = 4) with FW_MAXR_WIN = 14 kept rows and no spill are now both faster
+// re-read of w, TWO workgroups per CU at 128 VGPRs (FW_LB_WAVES_WIN = 4) with FW_MAXR_WIN = 14 kept rows and no spill are now both faster (round 4: 20 kept rows on the slimmed kernel, see FW_UG_WIN)
 // and better: 4.79 M examples/s at 0.6355 against 4.71 M at 0.641 (8 kept rows, three workgroups).  The small-table path keeps FW_MAXR = 2
 // at six waves per SIMD.
 // Only for 16 B-aligned single-chunk rows (k % 4 == 0, R <= 256 floats): BASELINE configs B and C.
@@ -2156,6 +2167,17 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #ifndef FW_UA
 #define FW_UA 2
 #endif
+// ... and in the config-C kernel (WIN, single-chunk rows), whose registers go to the rows kept from the gather: 20 kept rows, overflow rows two at a
+// time, accumulator rows one at a time = 128 VGPRs with one spilled; measured (profiles/r04_kept_rows_ab.txt, driver shape / 10 M examples):
+//   kept rows (UG, UA)   14 (4, 2)      16 (4, 2)      18 (2, 2)      20 (2, 1)      22 (2, 1)      24 (2, 1)
+//   examples/s           5.43-5.46 M    5.45-5.49 M    5.45-5.50 M    5.50-5.53 M    5.41-5.43 M    5.28-5.32 M
+//   hold-out after 10 M  0.6299         0.6291         0.6276         0.6233-0.6237  0.6227         0.6224
+#ifndef FW_UG_WIN
+#define FW_UG_WIN 2
+#endif
+#ifndef FW_UA_WIN
+#define FW_UA_WIN 1
+#endif
 #ifndef FW_WIN_NCH  // 1 KiB chunks per row in the whole-line update.  2 would give the k = 8 rows that span 9 lines their ninth line too: measured slower (3.96 vs 3.86 ms, the extra registers spill)
 #define FW_WIN_NCH 1
 #endif
@@ -2174,7 +2196,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // fields: 480).  Two-chunk rows keep T alone at 57.6 KB of LDS, so two workgroups share a CU and the register budget is 128 VGPRs.
 template <int OPT, bool COH, int MAXR, bool WIN, int NC = 1, int POL = FW_DEFAULT_STORE_POLICY>
 #ifndef FW_LB_WAVES_WIN  // the window path (config C's updating launches): FOUR waves per SIMD = two workgroups per CU, 128 registers -- room for
-#define FW_LB_WAVES_WIN 4  // 14 kept rows per wave without a spill; faster AND better than three workgroups with 8 kept rows
+#define FW_LB_WAVES_WIN 4  // 14 (round 4: 20) kept rows per wave; faster AND better than three workgroups with 8 kept rows
 #endif
 __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WIN : FW_LB_WAVES) : 4) fw_example_kernel_r(const KernelParams /* read through kp_fresh() */) {
     const KernelParams &p = kp_fresh();
@@ -2190,7 +2212,8 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
 #endif
     constexpr int AUX_SW = (COH && POL < 1) ? kAuxSc1 : (COH ? FW_WB_AUX_W : kAuxPlain);  // weight-row stores (store policy: top of this file)
     constexpr int AUX_SA = (COH && POL < 2) ? kAuxSc1 : (COH ? FW_WB_AUX_A : kAuxPlain);  // accumulator-row stores
-    constexpr int UA = FW_UA;  // accumulator rows in flight per wave in the update phase
+    constexpr int UA = (WIN && NC == 1) ? FW_UA_WIN : FW_UA;  // accumulator rows in flight per wave in the update phase
+    constexpr int UG = (WIN && NC == 1) ? FW_UG_WIN : FW_UG;  // overflow rows in flight per wave in the gather
     constexpr int UO = FW_UO;  // overflow rows (w + acc) in flight per wave
     extern __shared__ __align__(16) unsigned char smem[];
     // Single-chunk rows (configs B / C): the AdaGrad LUT is ALWAYS the LDS copy, decided at compile time -- s.lut is then an LDS pointer the
@@ -2209,7 +2232,6 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
     constexpr int kPfMax = 2;  // words of the next record a thread carries through the dot phase (records of up to kPfMax * blockDim words are prefetched)
     const uint32_t F = p.F, k = p.k, R = p.R;
 
-    const float *lut_lr = p.lut_lr;  // 201 lookups per example: read through L1 (an LDS copy measured no faster)
     if (use_lut)
         for (int i = tid; i < kLutSize; i += bd) s.lut[i] = p.lut_ffm[i];
 
@@ -2260,6 +2282,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         asm volatile("; thread index, workgroup and grid size handed out" : "+v"(tid_now), "+s"(bd_now), "+s"(grid_now));
         const int tid = tid_now, lane = tid & 63, wave = tid >> 6, bd = bd_now, nw = bd >> 6;
         const uint32_t F = p.F, k = p.k, R = p.R;
+        const float *lut_lr = p.lut_lr;  // 201 lookups per example: read through L1 (an LDS copy measured no faster)
         // ... and so is the LDS carve-up: two dozen offsets that would otherwise live in scalar registers from the prologue on
         Lds s;
         SetGeom geom;
@@ -2371,10 +2394,10 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                     FW_CONSUME(one, lo + sl)
                 }
             // overflow rows of this range: transient (they are re-read in the update phase)
-            for (uint32_t i = lo + MAXR; i < hi; i += FW_UG) {
-                V r[FW_UG][NC];
+            for (uint32_t i = lo + MAXR; i < hi; i += UG) {
+                V r[UG][NC];
 #pragma unroll
-                for (int u = 0; u < FW_UG; ++u) {
+                for (int u = 0; u < UG; ++u) {
 #pragma unroll
                     for (int c = 0; c < NC; ++c) r[u][c] = Vec<VEC>::zero();
                     if (i + u < hi) {
@@ -2386,7 +2409,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < FW_UG; ++u)
+                for (int u = 0; u < UG; ++u)
                     if (i + u < hi) FW_CONSUME(r[u], i + u)
             }
             if (cur != 0xffffffffu) {
@@ -2404,7 +2427,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         FW_TICK(2);
         // ---------------- the NEXT example's record: HBM -> registers now, -> LDS after the dot phase.  Its stage phase then needs no memory
         // round trip, so the acknowledgements of this example's row stores are waited for under the next stage phase's LDS work, not before it.
-        // (LDS-direct loads: no register carries the words through the dot phase -- with 14 rows kept per wave there is none to spare)
+        // (LDS-direct loads: no register carries the words through the dot phase -- with 20 rows kept per wave there is none to spare)
         uint32_t pf_len = 0;
         if (p.records && p.prefetch) {
             const uint32_t nt = s.ctr[kCtrNext];
@@ -2618,7 +2641,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
 #define FW_MAXR 2
 #endif
 #ifndef FW_MAXR_WIN
-#define FW_MAXR_WIN 14
+#define FW_MAXR_WIN 20
 #endif
 #ifndef FW_PHASE_TU  // (the fused kernels' launchers and the small utility kernels: first translation unit only)
 template <int OPT, bool COH>
@@ -2705,7 +2728,22 @@ __global__ void __launch_bounds__(256) owner_apply_kernel(float *w, float *acc, 
                                                           float lr_rate, float lr_mpt, const float *lut_lr, int in_order) {
     const uint32_t lane = threadIdx.x & 63, gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t i = gw; i < n_rows; i += nw) {
-        const uint32_t h = __hip_atomic_load(keys + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t h = __builtin_amdgcn_readfirstlane(__hip_atomic_load(keys + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        if (((R | h) & 3u) == 0) {  // 16-byte rows (k % 4 == 0): one 16 B access per lane and table, like the fused kernel's
+            const __amdgpu_buffer_rsrc_t rg = make_rsrc(rows + (size_t)i * R, R * 4), rw = make_rsrc(w + h, R * 4), ra = make_rsrc(acc + h, R * 4);
+            for (uint32_t e0 = lane * 4; e0 < R; e0 += 256) {
+                const f4 gv = Vec<4>::load<kAuxSys>(rg, e0 * 4);
+                f4 wv = Vec<4>::load<kAuxSc1>(rw, e0 * 4), av = OPT == FWGPU_OPT_SGD ? Vec<4>::zero() : Vec<4>::load<kAuxSc1>(ra, e0 * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float a = av[c];
+                    wv[c] = wv[c] - opt_step<OPT>(gv[c], a, ffm_rate, ffm_mpt, lut_ffm);  // block_ffm.rs:279-282
+                    av[c] = a;
+                }
+                Vec<4>::store<kAuxSc1>(wv, rw, e0 * 4);
+                if (OPT != FWGPU_OPT_SGD) Vec<4>::store<kAuxSc1>(av, ra, e0 * 4);
+            }
+        } else
         for (uint32_t e = lane; e < R; e += 64) {
             const float grad = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(rows + (size_t)i * R + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
             float a = OPT == FWGPU_OPT_SGD ? 0.0f : __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned *>(acc + h + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));

@@ -1,7 +1,7 @@
 """Two tenants on one GPU: two regressors learn at the same time on two HIP streams (two hardware queues), each in the in-order mode, and each
 must come out exactly as the sequential oracle says -- predictions per example and final tables.  Round 3 traced an irreproducibility of the
 PHASE kernels of two queues overlapping to scalar registers spilled to VGPR lanes; this holds the fused kernels -- the
-config-C kernel with its 14 kept rows among them -- to exactness under the same overlap, with a third stream running hogwild launches of a
+config-C kernel with its 20 kept rows among them -- to exactness under the same overlap, with a third stream running hogwild launches of a
 third model beside them to keep every CU busy."""
 import numpy as np
 import pytest
