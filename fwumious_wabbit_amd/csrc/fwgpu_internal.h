@@ -448,6 +448,8 @@ struct HostBatch {  // SoA staging of a CSR batch on the host
 int batch_alloc(fwgpu_regressor *r, uint32_t n, uint64_t n_lr, uint64_t n_ffm, fwgpu_batch **out, bool host_mapped = false);
 int batch_upload(fwgpu_batch *b, const HostBatch &hb, hipStream_t stream);
 void keep_host_copy_if_oversize(fwgpu_batch *b, HostBatch &&hb);
+int record_batch_host_copy_if_oversize(fwgpu_regressor *r, const fwgpu_translator_config *t, fwgpu_batch *b, const uint32_t *records,
+                                       const uint64_t *rec_off, uint32_t n);
 int append_example(const fwgpu_regressor *r, HostBatch &hb, const fwgpu_lr_entry *lr, uint32_t n_lr,
                    const fwgpu_ffm_entry *ffm, uint32_t n_ffm, float label, float importance);
 int translate_record(const fwgpu_translator_config *t, const uint32_t *rec, uint32_t rec_len,

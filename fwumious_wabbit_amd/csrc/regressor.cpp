@@ -488,6 +488,24 @@ int run_batch_peer(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, con
 void keep_host_copy_if_oversize(fwgpu_batch *b, HostBatch &&hb) {
     if (hb.max_ffm > 4096 || hb.max_lr > 4096) b->host_copy.reset(new HostBatch(std::move(hb)));
 }
+// ... a RECORD batch (just uploaded: max_ffm / max_lr are known) with a record that translates to more entries than that: translated on the host
+int record_batch_host_copy_if_oversize(fwgpu_regressor *r, const fwgpu_translator_config *t, fwgpu_batch *b, const uint32_t *records,
+                                       const uint64_t *rec_off, uint32_t n) {
+    b->host_copy.reset();
+    if (b->max_ffm <= 4096 && b->max_lr <= 4096) return FWGPU_OK;
+    HostBatch hb;
+    hb.clear();
+    std::vector<fwgpu_lr_entry> lr;
+    std::vector<fwgpu_ffm_entry> ffm;
+    for (uint32_t i = 0; i < n; i++) {
+        float label, imp;
+        int rc = translate_record(t, records + rec_off[i], (uint32_t)(rec_off[i + 1] - rec_off[i]), lr, ffm, &label, &imp);
+        if (rc == FWGPU_OK) rc = append_example(r, hb, lr.data(), (uint32_t)lr.size(), ffm.data(), (uint32_t)ffm.size(), label, imp);
+        if (rc) return rc;
+    }
+    keep_host_copy_if_oversize(b, std::move(hb));
+    return FWGPU_OK;
+}
 
 }  // namespace fwgpu
 
@@ -1027,19 +1045,7 @@ int fwgpu_record_batch_create(fwgpu_regressor *r, const fwgpu_translator_config 
     if (rc) return rc;
     rc = record_batch_upload(b, t, records, rec_off, n, 0);
     if (rc == FWGPU_OK && hipStreamSynchronize(0) != hipSuccess) rc = fail(FWGPU_ERR_DEVICE, "upload failed");
-    if (rc == FWGPU_OK && (b->max_ffm > kMaxStagedEntries || b->max_lr > kMaxStagedEntries)) {
-        // a record that translates to more entries than a workgroup stages: the batch is translated on the host and walked example by example
-        HostBatch hb;
-        hb.clear();
-        std::vector<fwgpu_lr_entry> lr;
-        std::vector<fwgpu_ffm_entry> ffm;
-        for (uint32_t i = 0; i < n && rc == FWGPU_OK; i++) {
-            float label, imp;
-            rc = translate_record(t, records + rec_off[i], (uint32_t)(rec_off[i + 1] - rec_off[i]), lr, ffm, &label, &imp);
-            if (rc == FWGPU_OK) rc = append_example(r, hb, lr.data(), (uint32_t)lr.size(), ffm.data(), (uint32_t)ffm.size(), label, imp);
-        }
-        if (rc == FWGPU_OK) keep_host_copy_if_oversize(b, std::move(hb));
-    }
+    if (rc == FWGPU_OK) rc = record_batch_host_copy_if_oversize(r, t, b, records, rec_off, n);
     if (rc) {
         fwgpu_batch_free(b);
         return rc;

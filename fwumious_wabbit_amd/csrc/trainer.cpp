@@ -91,6 +91,8 @@ static int flush(fwgpu_trainer *tr, bool predict = false) {
     // compute stream only waits for THIS buffer's copy (one stream for both cost the copy's 0.6 ms per 16 384 examples: 4.0 -> 4.6 M ex/s).
     int rc = record_batch_upload(b, &tr->t, tr->rec[c], tr->off[c].data(), n, tr->copy_stream, &tr->stats[c]);
     if (rc) return rc;
+    // (a record that translates to more entries than a workgroup stages: the micro-batch is walked example by example, regressor.cpp learn_one_chunked)
+    if ((rc = record_batch_host_copy_if_oversize(r, &tr->t, b, tr->rec[c], tr->off[c].data(), n))) return rc;
     FWGPU_HIP(hipEventRecord(tr->uploaded[c], tr->copy_stream));
     FWGPU_HIP(hipStreamWaitEvent(tr->stream, tr->uploaded[c], 0));
     rc = fwgpu_learn_batch(r, b, FWGPU_MODE_HOGWILD, predict ? 0 : 1, tr->stream);

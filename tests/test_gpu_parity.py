@@ -1000,3 +1000,51 @@ def test_examples_beyond_4096_features_take_the_chunked_path(n_feat, opt):
     assert np.abs(b.predictions() - np.array(want, dtype=np.float32)).max() < 2e-5
     b.close()
     re.close()
+
+
+def test_oversize_records_through_record_batches_and_the_trainer():
+    """Records that translate to more entries than a workgroup stages (two namespaces of 3000 features each: 6006 FFM features, 6007 LR entries)
+    between ordinary ones: a raw-record batch with such a record is translated on the host and walked in order, and so is the trainer's
+    micro-batch that holds it -- predictions against the oracle's run over the same records."""
+    F, k, bits, ffm_bits = 8, 4, 16, 16
+    mi, ocfg, ots = make_pair(F, k, bits, ffm_bits, fw.Optimizer.AdagradLUT, lr=0.01, ffm_lr=0.01)
+    rng = np.random.default_rng(77)
+
+    def record(n_big, label):
+        slots, tail = [], []
+        pos = 3 + F
+        for ns in range(F):
+            n = n_big if ns < 2 else 1
+            if n == 1:
+                slots.append(int(rng.integers(0, 1 << 31)))
+            else:
+                slots.append(0x80000000 | (pos << 16) | (pos + 2 * n))
+                for _ in range(n):
+                    tail += [int(rng.integers(0, 1 << 31)), int(np.float32(rng.uniform(0.002, 0.02)).view(np.uint32))]
+                pos += 2 * n
+        rec = [3 + F + len(tail), label, int(np.float32(1.0).view(np.uint32))] + slots + tail
+        return np.array(rec, dtype=np.uint32)
+
+    recs_l = [record(1, 1), record(3000, 0), record(1, 1), record(3000, 1), record(1, 0)]
+    recs = np.concatenate(recs_l)
+    off = np.concatenate([[0], np.cumsum([len(r) for r in recs_l])]).astype(np.uint64)
+    om = fwo.Model(ocfg)
+    _, p_ref = om.run_stream(ots, recs, off, holdout_after=0, nthreads=1)
+    fbt = fw.FeatureBufferTranslator(mi)
+    re = fw.Regressor(mi)
+    b = re.record_batch(fbt, recs, off)
+    re.learn_batch(b, capi.MODE_HOGWILD, True)
+    assert np.abs(b.predictions() - p_ref).max() < 2e-5, (b.predictions(), p_ref)
+    b.close()
+    assert np.abs(re.table_read(capi.TABLE_FFM_W) - om.ffm_weights).max() < 2e-5
+    re.close()
+    # the trainer (hogwild.rs:51-60): one worker's worth of concurrency, so that the result is the sequential one
+    re = fw.Regressor(mi)
+    re.set_max_in_flight(1)
+    tr = fw.HogwildTrainer(re, mi, micro_batch=4)
+    tr.digest_records(recs, off)
+    tr.block_until_workers_finished()
+    assert tr.examples_seen() == 5
+    assert np.abs(re.table_read(capi.TABLE_FFM_W) - om.ffm_weights).max() < 2e-5
+    tr.close()
+    re.close()
