@@ -2214,6 +2214,8 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
 #ifndef FW_WB_AUX_A
 #define FW_WB_AUX_A 0
 #endif
+    // (nt on the device-scope LOADS was measured and rejected: gather -2 %, accumulator loads -4 %, profiles/r04_nt_loads_and_flush256_ab.txt)
+    constexpr int AUX_G = AUX, AUX_LA = AUX;
     constexpr int AUX_SW = (COH && POL < 1) ? kAuxSc1 : (COH ? FW_WB_AUX_W : kAuxPlain);  // weight-row stores (store policy: top of this file)
     constexpr int AUX_SA = (COH && POL < 2) ? kAuxSc1 : (COH ? FW_WB_AUX_A : kAuxPlain);  // accumulator-row stores
     constexpr int UA = (WIN && NC == 1) ? FW_UA_WIN : FW_UA;  // accumulator rows in flight per wave in the update phase
@@ -2347,7 +2349,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
             rows[sl] = Vec<VEC>::zero();
             if ((uint32_t)sl < cnt) {
                 const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[lo + sl]);
-                rows[sl] = Vec<VEC>::template load<AUX>(make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
+                rows[sl] = Vec<VEC>::template load<AUX_G>(make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
             }
         }
         {
@@ -2408,7 +2410,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                         const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[i + u]);
 #pragma unroll
                         for (int c = 0; c < NC; ++c) {
-                            r[u][c] = Vec<VEC>::template load<AUX>(make_rsrc(p.ffm_w + h, R * 4), e0c[c] * 4);
+                            r[u][c] = Vec<VEC>::template load<AUX_G>(make_rsrc(p.ffm_w + h, R * 4), e0c[c] * 4);
                         }
                     }
                 }
@@ -2540,7 +2542,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                             const uint32_t i = lo + g0 + u;
                             if (!(s.e_fld[i] & kResSkip)) {
                                 const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[i]);
-                                av[u] = Vec<VEC>::template load<AUX>(make_rsrc(p.ffm_acc + h, R * 4), e0 * 4);
+                                av[u] = Vec<VEC>::template load<AUX_LA>(make_rsrc(p.ffm_acc + h, R * 4), e0 * 4);
                             }
                         }
                     }
