@@ -2531,6 +2531,61 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
             // Chained duplicates (WIN): a row that is chained to an earlier one is applied by that row's owner, and an owner WITH a
             // chain applies it from the window path below (which walks the chain): neither is stepped here.
             constexpr uint32_t kResSkip = WIN ? (kRowDep | kRowChained | kRowHasChain) : kRowDep;
+// The kept rows' update as branch-free straight-line code with the NEXT row's accumulator load issued before this row's stores (round 4's last
+// kernel change: 5.80-5.87 M examples/s against 5.63-5.69 M on one box, `roofline.frac` 0.561-0.568, same loss; profiles/r04_pipelined_update_ab.txt.
+// The same form for the ~5 overflow rows of a wave -- 5 / 8 / 12 static slots with fresh w and acc -- measured 0.6 % SLOWER and is not kept).
+#ifndef FW_PIPE_UPD
+#define FW_PIPE_UPD 1
+#endif
+            if (FW_PIPE_UPD && WIN && NC == 1 && MAXR > 0) {
+                // Every kept slot goes through the same instructions; a slot without a row (beyond the wave's range, or a row the window path
+                // applies) gets descriptors of zero length: its loads return 0, its stores are dropped.  With no branch between them the compiler
+                // counts the memory operations exactly (s_waitcnt vmcnt(n) instead of vmcnt(0)): waiting for row sl + 1's accumulators does not
+                // wait for the acknowledgement of row sl's stores any more.
+                auto slot = [&](int sl, uint32_t &h, uint32_t &f, bool &ok) {
+                    const uint32_t i = lo + (uint32_t)sl;
+                    const uint32_t fb = __builtin_amdgcn_readfirstlane(s.e_fld[i]);
+                    ok = (uint32_t)sl < cnt && !(fb & kResSkip);
+                    h = ok ? __builtin_amdgcn_readfirstlane(s.e_hash[i]) : 0u;
+                    f = ok ? (fb & kFldMask) : 0u;
+                };
+                uint32_t h0, f0;
+                bool ok0;
+                slot(0, h0, f0, ok0);
+                V a_cur = OPT != FWGPU_OPT_SGD ? Vec<VEC>::template load<AUX_LA>(make_rsrc(p.ffm_acc + h0, ok0 ? R * 4 : 0), e0 * 4) : Vec<VEC>::zero();
+#pragma unroll
+                for (int sl = 0; sl < MAXR; ++sl) {
+                    uint32_t h1 = 0, f1 = 0;
+                    bool ok1 = false;
+                    V a_nxt = Vec<VEC>::zero();
+                    if (sl + 1 < MAXR) {
+                        slot(sl + 1, h1, f1, ok1);
+                        if (OPT != FWGPU_OPT_SGD) a_nxt = Vec<VEC>::template load<AUX_LA>(make_rsrc(p.ffm_acc + h1, ok1 ? R * 4 : 0), e0 * 4);
+                    }
+                    const float v = s.e_val[lo + (uint32_t)sl];
+                    V wv = rows[sl];
+                    V tv = Vec<VEC>::zero();
+                    if (inb) tv = Vec<VEC>::lds_load(s.T + f0 * R + e0);
+                    const bool self = (z == f0);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        float t = tv[j];
+                        if (self) t = __fsub_rn(t, __fmul_rn(wv[j], v));  // contra - w*v  block_ffm.rs:238
+                        const float G = __fmul_rn(v, t);
+                        const float grad = __fmul_rn(g, G);
+                        float acc = a_cur[j];
+                        const float upd = opt_step<OPT>(grad, acc, p.ffm_rate, p.ffm_minus_power_t, s.lut);
+                        a_cur[j] = acc;
+                        wv[j] = wv[j] - upd;  // block_ffm.rs:282
+                    }
+                    Vec<VEC>::template store<AUX_SW>(wv, make_rsrc(p.ffm_w + h0, ok0 ? R * 4 : 0), e0 * 4);
+                    if (OPT != FWGPU_OPT_SGD) Vec<VEC>::template store<AUX_SA>(a_cur, make_rsrc(p.ffm_acc + h0, ok0 ? R * 4 : 0), e0 * 4);
+                    a_cur = a_nxt;
+                    h0 = h1;
+                    f0 = f1;
+                    ok0 = ok1;
+                }
+            } else
 #pragma unroll
             for (int g0 = 0; g0 < MAXR; g0 += UA) {
                 if ((uint32_t)g0 < cnt) {
