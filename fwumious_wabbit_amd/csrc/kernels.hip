@@ -300,6 +300,18 @@ __device__ __forceinline__ float lr_forward_weight(const KernelParams &p, const 
     return wa.x;
 }
 
+// the same, returning the whole {w, acc} pair: the v2 kernel keeps a thread's first entry from the forward pass for its update (lr_update `kept`)
+template <bool COH, bool SH = false>
+__device__ __forceinline__ float2 lr_forward_pair(const KernelParams &p, const Lds &s, uint32_t h) {
+    float2 wa = lr_load<COH, SH>(lr_base<SH>(p, h), h);
+    if (COH && hot_lr_is(s, h)) {
+        float *hot = hot_lr_state(s);
+        hot[0] = wa.y;
+        wa.x += hot[1];
+    }
+    return wa;
+}
+
 __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t max_ffm, uint32_t max_lr, uint32_t n_luts,
                                              uint32_t max_rec, uint32_t tr_items, uint32_t nn_floats, bool chain, size_t *off /*[24]*/,
                                              uint32_t pf_words = 0, uint32_t tr_words = 0) {
@@ -1133,9 +1145,13 @@ __device__ __forceinline__ void nn_backward(const KernelParams &p, const Lds &s,
 // buffer order, on one register copy of {w, acc}: duplicates chain exactly like the reference's loop (regressor.rs:629-655
 // pins this).  The entry is read again here rather than kept from the forward pass: keeping it saved no time and widened
 // the hogwild read-modify-write window of hot entries (constant feature) by two phases.
+// `kept`: the {w, acc} pair of entry `tid` as this thread's forward pass read it (v2 kernel): that entry is stepped without a second load -- the
+// load's round trip was 16 % of an example's time (profiles/r04_phase_ticks.txt) for 0.4 % of its bytes.  In order it is the same pair a reload would
+// return (nothing writes the entry between an example's forward pass and its update); concurrently the entry's read-modify-write window grows from the
+// update's round trip to the dot + sigmoid phases, ~6 of an example's ~100 us.
 template <int OPT, bool COH, bool SH = false>
 __device__ __forceinline__ void lr_update(const KernelParams &p, const Lds &s, uint32_t nl, float g, const float *gx,
-                                          const float *lut_lr, int tid, int bd, uint32_t lo = 0, uint32_t hi = 0xffffffffu) {
+                                          const float *lut_lr, int tid, int bd, uint32_t lo = 0, uint32_t hi = 0xffffffffu, const float2 *kept = nullptr) {
     for (uint32_t t = tid; t < nl; t += bd) {
         const uint32_t fl = s.l_flag[t];
         const uint32_t h = s.l_hash[t];
@@ -1160,7 +1176,7 @@ __device__ __forceinline__ void lr_update(const KernelParams &p, const Lds &s, u
         }
         if (fl & kRowChained) continue;
         if (h < lo || h >= hi) continue;  // sharded tables: another rank's entry
-        float2 wa = lr_load<COH, SH>(lr_base<SH>(p, h), h);
+        float2 wa = (kept && t == (uint32_t)tid) ? *kept : lr_load<COH, SH>(lr_base<SH>(p, h), h);
         {
             const float grad = (gx ? gx[s.l_combo[t]] : g) * s.l_val[t];
             wa.x -= opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, lut_lr);
@@ -2473,9 +2489,12 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
             }
         }
         float lrs = 0.0f;
+        float2 lr_kept = float2{0.0f, 0.0f};  // this thread's first LR entry as the forward pass read it (lr_update `kept`)
         if (p.has_lr)
             for (uint32_t i = tid; i < nl; i += bd) {
-                lrs += lr_forward_weight<COH>(p, s, s.l_hash[i]) * s.l_val[i];
+                const float2 wa = lr_forward_pair<COH>(p, s, s.l_hash[i]);
+                if (i == (uint32_t)tid) lr_kept = wa;
+                lrs += wa.x * s.l_val[i];
             }
         dot = wave_sum(dot);
         lrs = wave_sum(lrs);
@@ -2525,7 +2544,13 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
 #else
             const bool lr_upd = p.has_lr;
 #endif
-            if (lr_upd) lr_update<OPT, COH>(p, s, nl, g, nullptr, lut_lr, tid, bd);
+            // The pair kept from the forward pass saves the update's load round trip: +1.8 % examples/s at config C at the same loss.  Only for
+            // examples of at least FW_LR_KEEP_MIN LR entries: on streams of small examples (10-40 entries, ~15 us per example) the longer
+            // read-modify-write window of the hot LR entries costs 0.005-0.01 of hold-out loss (profiles/r04_lr_pair_kept_ab.txt; round 2 saw the same).
+#ifndef FW_LR_KEEP_MIN
+#define FW_LR_KEEP_MIN 128
+#endif
+            if (lr_upd) lr_update<OPT, COH>(p, s, nl, g, nullptr, lut_lr, tid, bd, 0u, 0xffffffffu, nl >= FW_LR_KEEP_MIN ? &lr_kept : nullptr);
             FW_TICK(4);
             // phase A, resident rows: w comes from registers (read once, in the gather); only acc is loaded.
             // Chained duplicates (WIN): a row that is chained to an earlier one is applied by that row's owner, and an owner WITH a
