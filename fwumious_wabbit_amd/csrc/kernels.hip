@@ -1145,13 +1145,14 @@ __device__ __forceinline__ void nn_backward(const KernelParams &p, const Lds &s,
 // buffer order, on one register copy of {w, acc}: duplicates chain exactly like the reference's loop (regressor.rs:629-655
 // pins this).  The entry is read again here rather than kept from the forward pass: keeping it saved no time and widened
 // the hogwild read-modify-write window of hot entries (constant feature) by two phases.
-// `kept`: the {w, acc} pair of entry `tid` as this thread's forward pass read it (v2 kernel): that entry is stepped without a second load -- the
+// `use_kept` / `kept`: the {w, acc} pair of entry `tid` as this thread's forward pass read it (v2 kernel): that entry is stepped without a second load -- the
 // load's round trip was 16 % of an example's time (profiles/r04_phase_ticks.txt) for 0.4 % of its bytes.  In order it is the same pair a reload would
 // return (nothing writes the entry between an example's forward pass and its update); concurrently the entry's read-modify-write window grows from the
 // update's round trip to the dot + sigmoid phases, ~6 of an example's ~100 us.
 template <int OPT, bool COH, bool SH = false>
 __device__ __forceinline__ void lr_update(const KernelParams &p, const Lds &s, uint32_t nl, float g, const float *gx,
-                                          const float *lut_lr, int tid, int bd, uint32_t lo = 0, uint32_t hi = 0xffffffffu, const float2 *kept = nullptr) {
+                                          const float *lut_lr, int tid, int bd, uint32_t lo = 0, uint32_t hi = 0xffffffffu, bool use_kept = false,
+                                          float2 kept = float2{0.0f, 0.0f}) {
     for (uint32_t t = tid; t < nl; t += bd) {
         const uint32_t fl = s.l_flag[t];
         const uint32_t h = s.l_hash[t];
@@ -1176,7 +1177,8 @@ __device__ __forceinline__ void lr_update(const KernelParams &p, const Lds &s, u
         }
         if (fl & kRowChained) continue;
         if (h < lo || h >= hi) continue;  // sharded tables: another rank's entry
-        float2 wa = (kept && t == (uint32_t)tid) ? *kept : lr_load<COH, SH>(lr_base<SH>(p, h), h);
+        float2 wa = kept;  // (by value: a pointer to the caller's pair would put it in scratch memory)
+        if (!(use_kept && t == (uint32_t)tid)) wa = lr_load<COH, SH>(lr_base<SH>(p, h), h);
         {
             const float grad = (gx ? gx[s.l_combo[t]] : g) * s.l_val[t];
             wa.x -= opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, lut_lr);
@@ -2188,6 +2190,12 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 //   kept rows (UG, UA)   14 (4, 2)      16 (4, 2)      18 (2, 2)      20 (2, 1)      22 (2, 1)      24 (2, 1)
 //   examples/s           5.43-5.46 M    5.45-5.49 M    5.45-5.50 M    5.50-5.53 M    5.41-5.43 M    5.28-5.32 M
 //   hold-out after 10 M  0.6299         0.6291         0.6276         0.6233-0.6237  0.6227         0.6224
+// The kept rows' update as branch-free straight-line code with the NEXT row's accumulator load issued before this row's stores (round 4's last
+// kernel change: 5.80-5.87 M examples/s against 5.63-5.69 M on one box, `roofline.frac` 0.561-0.568, same loss; profiles/r04_pipelined_update_ab.txt.
+// The same form for the ~5 overflow rows of a wave -- 5 / 8 / 12 static slots with fresh w and acc -- measured 0.6 % SLOWER and is not kept).
+#ifndef FW_PIPE_UPD
+#define FW_PIPE_UPD 1
+#endif
 #ifndef FW_UG_WIN
 #define FW_UG_WIN 2
 #endif
@@ -2359,13 +2367,30 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         if (cnt == 0) lo = 0;
 
         // ---------------- gather: all row loads up front, rows stay resident
+        // Which rows of the range are kept: the first MAXR -- or (-DFW_KEEP_LAST=1, config-C kernel) the LAST MAXR: the overflow rows then come FIRST in
+        // buffer order and are gathered first, eight at a time, in the registers the kept rows do not occupy yet -- one round trip for them instead of
+        // one per pair behind the kept rows'.  Measured (profiles/r04_keep_last_ab.txt): +1.2 % examples/s (0.576 against 0.569 of the peak) and a
+        // hold-out loss 0.004-0.005 HIGHER from 4 M examples on (0.6297-0.6345 against 0.6244-0.6293 after 10 M, three runs each): the kept rows are
+        // then gathered ~10 us later, their w_gather - step overwrites less of what concurrent examples did, and that damping is what the loss rests
+        // on.  Not the default.  The field sums are accumulated in buffer order either way.
+#ifndef FW_KEEP_LAST
+#define FW_KEEP_LAST 0
+#endif
+#ifndef FW_UG_FIRST
+#define FW_UG_FIRST 8
+#endif
+        constexpr bool kKeepLast = FW_KEEP_LAST && FW_PIPE_UPD && WIN && NC == 1 && MAXR > 0;
+        const uint32_t nk = cnt < (uint32_t)MAXR ? cnt : (uint32_t)MAXR;  // rows kept
+        const uint32_t kb = kKeepLast ? hi - nk : lo;                      // the first of them (cnt == 0: lo == hi == 0)
         V rows[MAXR > 0 ? MAXR : 1];
+        if (!kKeepLast) {
 #pragma unroll
-        for (int sl = 0; sl < MAXR; ++sl) {
-            rows[sl] = Vec<VEC>::zero();
-            if ((uint32_t)sl < cnt) {
-                const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[lo + sl]);
-                rows[sl] = Vec<VEC>::template load<AUX_G>(make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
+            for (int sl = 0; sl < MAXR; ++sl) {
+                rows[sl] = Vec<VEC>::zero();
+                if ((uint32_t)sl < nk) {
+                    const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[kb + sl]);
+                    rows[sl] = Vec<VEC>::template load<AUX_G>(make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
+                }
             }
         }
         {
@@ -2408,15 +2433,41 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
             }                                                                                                 \
         }                                                                                                     \
     }
+            if (kKeepLast) {
+                // overflow rows [lo, kb) first: transient (they are re-read in the update phase)
+                constexpr int UGF = FW_UG_FIRST;
+                for (uint32_t i = lo; i < kb; i += UGF) {
+                    V r[UGF][NC];
+#pragma unroll
+                    for (int u = 0; u < UGF; ++u) {
+                        r[u][0] = Vec<VEC>::zero();
+                        if (i + u < kb) {
+                            const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[i + u]);
+                            r[u][0] = Vec<VEC>::template load<AUX_G>(make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < UGF; ++u)
+                        if (i + u < kb) FW_CONSUME(r[u], i + u)
+                }
+#pragma unroll
+                for (int sl = 0; sl < MAXR; ++sl) {
+                    rows[sl] = Vec<VEC>::zero();
+                    if ((uint32_t)sl < nk) {
+                        const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[kb + sl]);
+                        rows[sl] = Vec<VEC>::template load<AUX_G>(make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
+                    }
+                }
+            }
 #pragma unroll
             for (int sl = 0; sl < MAXR; ++sl)
-                if ((uint32_t)sl < cnt) {
+                if ((uint32_t)sl < nk) {
                     V one[NC];
                     one[0] = rows[sl];
-                    FW_CONSUME(one, lo + sl)
+                    FW_CONSUME(one, kb + sl)
                 }
             // overflow rows of this range: transient (they are re-read in the update phase)
-            for (uint32_t i = lo + MAXR; i < hi; i += UG) {
+            for (uint32_t i = kKeepLast ? hi : lo + MAXR; i < hi; i += UG) {
                 V r[UG][NC];
 #pragma unroll
                 for (int u = 0; u < UG; ++u) {
@@ -2550,27 +2601,21 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
 #ifndef FW_LR_KEEP_MIN
 #define FW_LR_KEEP_MIN 128
 #endif
-            if (lr_upd) lr_update<OPT, COH>(p, s, nl, g, nullptr, lut_lr, tid, bd, 0u, 0xffffffffu, nl >= FW_LR_KEEP_MIN ? &lr_kept : nullptr);
+            if (lr_upd) lr_update<OPT, COH>(p, s, nl, g, nullptr, lut_lr, tid, bd, 0u, 0xffffffffu, nl >= FW_LR_KEEP_MIN, lr_kept);
             FW_TICK(4);
             // phase A, resident rows: w comes from registers (read once, in the gather); only acc is loaded.
             // Chained duplicates (WIN): a row that is chained to an earlier one is applied by that row's owner, and an owner WITH a
             // chain applies it from the window path below (which walks the chain): neither is stepped here.
             constexpr uint32_t kResSkip = WIN ? (kRowDep | kRowChained | kRowHasChain) : kRowDep;
-// The kept rows' update as branch-free straight-line code with the NEXT row's accumulator load issued before this row's stores (round 4's last
-// kernel change: 5.80-5.87 M examples/s against 5.63-5.69 M on one box, `roofline.frac` 0.561-0.568, same loss; profiles/r04_pipelined_update_ab.txt.
-// The same form for the ~5 overflow rows of a wave -- 5 / 8 / 12 static slots with fresh w and acc -- measured 0.6 % SLOWER and is not kept).
-#ifndef FW_PIPE_UPD
-#define FW_PIPE_UPD 1
-#endif
             if (FW_PIPE_UPD && WIN && NC == 1 && MAXR > 0) {
                 // Every kept slot goes through the same instructions; a slot without a row (beyond the wave's range, or a row the window path
                 // applies) gets descriptors of zero length: its loads return 0, its stores are dropped.  With no branch between them the compiler
                 // counts the memory operations exactly (s_waitcnt vmcnt(n) instead of vmcnt(0)): waiting for row sl + 1's accumulators does not
                 // wait for the acknowledgement of row sl's stores any more.
                 auto slot = [&](int sl, uint32_t &h, uint32_t &f, bool &ok) {
-                    const uint32_t i = lo + (uint32_t)sl;
+                    const uint32_t i = kb + (uint32_t)sl;
                     const uint32_t fb = __builtin_amdgcn_readfirstlane(s.e_fld[i]);
-                    ok = (uint32_t)sl < cnt && !(fb & kResSkip);
+                    ok = (uint32_t)sl < nk && !(fb & kResSkip);
                     h = ok ? __builtin_amdgcn_readfirstlane(s.e_hash[i]) : 0u;
                     f = ok ? (fb & kFldMask) : 0u;
                 };
@@ -2587,7 +2632,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                         slot(sl + 1, h1, f1, ok1);
                         if (OPT != FWGPU_OPT_SGD) a_nxt = Vec<VEC>::template load<AUX_LA>(make_rsrc(p.ffm_acc + h1, ok1 ? R * 4 : 0), e0 * 4);
                     }
-                    const float v = s.e_val[lo + (uint32_t)sl];
+                    const float v = s.e_val[kb + (uint32_t)sl];
                     V wv = rows[sl];
                     V tv = Vec<VEC>::zero();
                     if (inb) tv = Vec<VEC>::lds_load(s.T + f0 * R + e0);
@@ -2613,13 +2658,13 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
             } else
 #pragma unroll
             for (int g0 = 0; g0 < MAXR; g0 += UA) {
-                if ((uint32_t)g0 < cnt) {
+                if ((uint32_t)g0 < nk) {
                     V av[UA];
 #pragma unroll
                     for (int u = 0; u < UA; ++u) {
                         av[u] = Vec<VEC>::zero();
-                        if (OPT != FWGPU_OPT_SGD && (uint32_t)(g0 + u) < cnt) {
-                            const uint32_t i = lo + g0 + u;
+                        if (OPT != FWGPU_OPT_SGD && (uint32_t)(g0 + u) < nk) {
+                            const uint32_t i = kb + g0 + u;
                             if (!(s.e_fld[i] & kResSkip)) {
                                 const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[i]);
                                 av[u] = Vec<VEC>::template load<AUX_LA>(make_rsrc(p.ffm_acc + h, R * 4), e0 * 4);
@@ -2628,8 +2673,8 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                     }
 #pragma unroll
                     for (int u = 0; u < UA; ++u) {
-                        if (g0 + u < MAXR && (uint32_t)(g0 + u) < cnt) {
-                            const uint32_t i = lo + g0 + u;
+                        if (g0 + u < MAXR && (uint32_t)(g0 + u) < nk) {
+                            const uint32_t i = kb + g0 + u;
                             const uint32_t fb = s.e_fld[i];
                             if (!(fb & kResSkip)) {
                                 const uint32_t f = __builtin_amdgcn_readfirstlane(fb & kFldMask);
@@ -2670,7 +2715,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                     const uint32_t i = i0 + u;
                     idx[u] = (i < hi && !(s.e_fld[i] & (kRowDep | kRowChained))) ? i : 0xffffffffu;
                     // (the first MAXR rows of the range were stepped from registers, unless they own a chain)
-                    if (WIN && MAXR > 0 && i < lo + MAXR && i < hi && !(s.e_fld[i] & kRowHasChain)) idx[u] = 0xffffffffu;
+                    if (WIN && MAXR > 0 && i >= kb && i < kb + MAXR && i < hi && !(s.e_fld[i] & kRowHasChain)) idx[u] = 0xffffffffu;
                 }
                 if (WIN)
                     update_rows_win<OPT, AUX, UO, (NC > FW_WIN_NCH ? NC : FW_WIN_NCH), AUX_SW, AUX_SA>(p, s, idx, g, lane, nf);
