@@ -125,6 +125,7 @@ struct KernelParams {
                                         // device-scope write-through, 1 = weights write-back through the XCD's L2, 2 = both tables write-back
     uint32_t wb_flush_every;            // policies 1 / 2: a workgroup writes its XCD's dirty L2 lines back (buffer_wbl2 sc1) every this many of its examples (0: never)
     int32_t tr_lds;                     // record batches on the v2 kernel: the translator's tables are read from an LDS copy (kernels.hip TrLds)
+    uint32_t lds_keep, lds_keep_words;  // config-C-shaped kernel: rows per wave BEYOND the register-kept ones whose gather-time w stays in LDS for the update (0..FW_LDS_KEEP_MAX), and the region's size (rows x waves x R floats)
     int32_t prefetch;                   // record batches on the v2 kernel: example n+1's record is copied to LDS while example n is in its dot / update phases
     uint32_t *work;                     // next example to process (zeroed before every launch)
     uint32_t host_cus, host_wgs_cap, host_grid_cap;    // host side only: persistent grid = occupancy x CUs (capped), when launched with grid 0
@@ -192,6 +193,7 @@ struct LaunchConfig {
     uint32_t hot_lr_every = 1;       // debug option 4: hot LR entry route (0 off, 1 atomics per example, n>1 weight deltas pending n examples)
     int32_t store_policy = -1;       // debug option 5: FFM row store policy of hogwild launches (-1: the build's default, kDefaultStorePolicy)
     int32_t wb_flush_every = -1;     // debug option 6: write-back interval of policies 1 / 2 in examples per workgroup (-1: default, 0: never)
+    int32_t lds_keep = -1;           // debug option 8: rows per wave kept in LDS beyond the register-kept ones (-1: as many as leave two workgroups per CU)
     int32_t prefetch = 1;            // debug option 7: next-record prefetch of the v2 kernel (A/B runs)
     bool threads_set = false;
     uint32_t max_in_flight = 0;  // cap on the persistent grid = examples processed concurrently (0: what the device holds)  // fwgpu_set_launch chose the workgroup size: no automatic choice

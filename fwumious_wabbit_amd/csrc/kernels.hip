@@ -170,6 +170,7 @@ struct Lds {
     uint32_t *l_combo;        // combo slot of each LR entry (deep head only)
     float *nn;                // deep-head scratch: x[X], xg[X], h[sum_width], m[sum_width], l_prod[max_lr]
     uint32_t *ctr;            // 8 counters, then 3 floats: the hot LR entry's acc snapshot, pending weight delta, pending acc delta; [16..] see kCtr*
+    float *keep;              // v2 kernel: [wave][lds_keep][R] gather-time w of the rows a wave keeps in LDS (beyond its register-kept ones)
     uint32_t *rec_next;       // v2 kernel, record batches: the NEXT example's record, copied from HBM while this example is in its dot / update phases
 };
 // ctr[] slots of the v2 kernel's prefetch and write-back bookkeeping
@@ -313,8 +314,8 @@ __device__ __forceinline__ float2 lr_forward_pair(const KernelParams &p, const L
 }
 
 __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t max_ffm, uint32_t max_lr, uint32_t n_luts,
-                                             uint32_t max_rec, uint32_t tr_items, uint32_t nn_floats, bool chain, size_t *off /*[24]*/,
-                                             uint32_t pf_words = 0, uint32_t tr_words = 0) {
+                                             uint32_t max_rec, uint32_t tr_items, uint32_t nn_floats, bool chain, size_t *off /*[25]*/,
+                                             uint32_t pf_words = 0, uint32_t tr_words = 0, uint32_t keep_words = 0) {
     size_t o = 0;
     size_t R = (size_t)F * k;
     off[0] = o; o = align16(o + 4 * F * R);
@@ -353,6 +354,7 @@ __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t ma
     off[18] = o; o = align16(o + 4 * (size_t)nn_floats);
     off[22] = o; o = align16(o + 4 * (size_t)pf_words);  // rec_next (outside T's region: it is written while T is alive)
     off[23] = o; o = align16(o + 4 * (size_t)tr_words);  // v2 kernel: the translator's tables (TrLds)
+    off[24] = o; o = align16(o + 4 * (size_t)keep_words);  // v2 kernel: gather-time w of the rows kept in LDS (Lds::keep)
     return o;
 }
 
@@ -764,11 +766,11 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
 
 #ifndef FW_PHASE_TU  // (host functions live in ONE of the two translation units of this file: see the Makefile)
 size_t example_kernel_lds_bytes(const KernelParams &p, int optimizer) {
-    size_t off[24];
+    size_t off[25];
     // (lut_lds_forced: the v2 kernel's single-chunk instantiations ALWAYS keep the AdaGrad LUT in LDS -- kLdsLut -- whatever option 1 says)
     return lds_layout(p.F, p.k, p.max_ffm, p.max_lr, (optimizer == FWGPU_OPT_ADAGRAD_LUT && p.update && (!p.lut_global || p.lut_lds_forced)) ? 1 : 0,
                       p.records ? p.max_rec : 0, p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off,
-                      (p.records && p.prefetch) ? p.max_rec : 0, (p.records && p.tr_lds) ? tr_lds_words(p.tr) : 0);
+                      (p.records && p.prefetch) ? p.max_rec : 0, (p.records && p.tr_lds) ? tr_lds_words(p.tr) : 0, p.lds_keep_words);
 }
 #endif
 
@@ -1413,10 +1415,10 @@ uint32_t split_record_len(uint32_t F, uint32_t R, uint32_t nlr) { return split_l
 
 // LDS carve-up of the example kernels (lds_layout), the overlap pre-filter's geometry and the LDS copy of the translator's tables
 __device__ __forceinline__ void bind_lds(const KernelParams &p, unsigned char *smem, bool use_lut, Lds &s, SetGeom &geom, TrLds &trl) {
-    size_t off[24];
+    size_t off[25];
     lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut ? 1 : 0, p.records ? p.max_rec : 0,
                p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off, (p.records && p.prefetch) ? p.max_rec : 0,
-               (p.records && p.tr_lds) ? tr_lds_words(p.tr) : 0);
+               (p.records && p.tr_lds) ? tr_lds_words(p.tr) : 0, p.lds_keep_words);
     s.T = reinterpret_cast<float *>(smem + off[0]);
     s.selfw = reinterpret_cast<float *>(smem + off[1]);
     s.lut = reinterpret_cast<float *>(smem + off[2]);
@@ -1439,6 +1441,7 @@ __device__ __forceinline__ void bind_lds(const KernelParams &p, unsigned char *s
     s.l_combo = reinterpret_cast<uint32_t *>(smem + off[17]);
     s.nn = reinterpret_cast<float *>(smem + off[18]);
     s.rec_next = reinterpret_cast<uint32_t *>(smem + off[22]);
+    s.keep = reinterpret_cast<float *>(smem + off[24]);
     geom.setf_n = set_size(p.max_ffm);
     geom.setl_n = set_size(p.max_lr);
     geom.setf_shift = 32 - log2u(geom.setf_n);
@@ -2018,6 +2021,7 @@ hipError_t launch_example_phase(const KernelParams &p_in, int optimizer, int pha
     KernelParams p = p_in;
     p.window = 0;  // (the generic kernel's update path)
     p.prefetch = p.tr_lds = p.lut_lds_forced = 0;  // (v2-only LDS regions / choices)
+    p.lds_keep = p.lds_keep_words = 0;
     p.update = phase == 3 ? 1 : 0;
     p.chain = p.update && !p.no_chain;
     size_t lds = example_kernel_lds_bytes(p, optimizer);
@@ -2195,6 +2199,16 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // The same form for the ~5 overflow rows of a wave -- 5 / 8 / 12 static slots with fresh w and acc -- measured 0.6 % SLOWER and is not kept).
 #ifndef FW_PIPE_UPD
 #define FW_PIPE_UPD 1
+#endif
+// Rows of a wave's range BEYOND the FW_MAXR_WIN register-kept ones whose gather-time w is parked in LDS (Lds::keep) instead of being re-read by the
+// update phase: at most this many per wave; the host grants as many as leave two workgroups on a CU (regressor.cpp prepare_launch, KernelParams::lds_keep).
+// Config C: 55 KB + 3 x 7.7 KB per workgroup -> 3 rows, 23 of ~25 rows per wave written back as w_gather - step; +0.7 % examples/s and 0.002 of hold-out
+// loss after 10 M examples (profiles/r04_parked_rows_ab.txt); a fourth slot that stays empty costs 0.15 %.
+#ifndef FW_LDS_KEEP_MAX
+#define FW_LDS_KEEP_MAX 3
+#endif
+#ifndef FW_PIPE_DEPTH
+#define FW_PIPE_DEPTH 3  // rows the accumulator loads of the pipelined kept-row update run ahead, at most
 #endif
 #ifndef FW_UG_WIN
 #define FW_UG_WIN 2
@@ -2381,6 +2395,10 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
 #endif
         constexpr bool kKeepLast = FW_KEEP_LAST && FW_PIPE_UPD && WIN && NC == 1 && MAXR > 0;
         const uint32_t nk = cnt < (uint32_t)MAXR ? cnt : (uint32_t)MAXR;  // rows kept
+        constexpr bool kLdsKeep = FW_LDS_KEEP_MAX > 0 && !kKeepLast && FW_PIPE_UPD && WIN && NC == 1 && MAXR > 0;
+        constexpr int LKM = kLdsKeep ? FW_LDS_KEEP_MAX : 0;
+        const uint32_t lk = kLdsKeep ? p.lds_keep : 0u;                                          // rows of this launch kept in LDS per wave
+        const uint32_t nk2 = cnt < (uint32_t)MAXR + lk ? cnt : (uint32_t)MAXR + lk;              // rows kept, registers + LDS
         const uint32_t kb = kKeepLast ? hi - nk : lo;                      // the first of them (cnt == 0: lo == hi == 0)
         V rows[MAXR > 0 ? MAXR : 1];
         if (!kKeepLast) {
@@ -2483,7 +2501,12 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                 }
 #pragma unroll
                 for (int u = 0; u < UG; ++u)
-                    if (i + u < hi) FW_CONSUME(r[u], i + u)
+                    if (i + u < hi) {
+                        FW_CONSUME(r[u], i + u)
+                        // the first lds_keep of them stay in LDS for the update phase (as read HERE, like a register-kept row)
+                        if (kLdsKeep && inb && i + u - (lo + MAXR) < lk)
+                            Vec<VEC>::lds_store(s.keep + ((uint32_t)wave * lk + (i + u - (lo + MAXR))) * R + e0, r[u][0]);
+                    }
             }
             if (cur != 0xffffffffu) {
 #pragma unroll
@@ -2615,25 +2638,41 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                 auto slot = [&](int sl, uint32_t &h, uint32_t &f, bool &ok) {
                     const uint32_t i = kb + (uint32_t)sl;
                     const uint32_t fb = __builtin_amdgcn_readfirstlane(s.e_fld[i]);
-                    ok = (uint32_t)sl < nk && !(fb & kResSkip);
+                    ok = (uint32_t)sl < nk2 && !(fb & kResSkip);
                     h = ok ? __builtin_amdgcn_readfirstlane(s.e_hash[i]) : 0u;
                     f = ok ? (fb & kFldMask) : 0u;
                 };
-                uint32_t h0, f0;
-                bool ok0;
-                slot(0, h0, f0, ok0);
-                V a_cur = OPT != FWGPU_OPT_SGD ? Vec<VEC>::template load<AUX_LA>(make_rsrc(p.ffm_acc + h0, ok0 ? R * 4 : 0), e0 * 4) : Vec<VEC>::zero();
+                // The accumulator loads run AHEAD of the row being stepped by a distance that grows as the kept rows' registers are released:
+                // 1 row at slot 0 (20 rows + 2 accumulator rows alive), one more per slot up to FW_PIPE_DEPTH -- the register peak stays where it was.
+                // vmcnt counts in issue order, so waiting for row sl's accumulators also waits for every store issued before their load: at distance
+                // 1 that is row sl - 2's write-through accumulator store, at distance D row sl - 1 - D's.
+                constexpr int NS = MAXR + LKM, DMAX = FW_PIPE_DEPTH;
+                V av[NS > 0 ? NS : 1];
+                auto issue = [&](int j) {
+                    uint32_t h, f;
+                    bool ok;
+                    slot(j, h, f, ok);
+                    av[j] = OPT != FWGPU_OPT_SGD ? Vec<VEC>::template load<AUX_LA>(make_rsrc(p.ffm_acc + h, ok ? R * 4 : 0), e0 * 4) : Vec<VEC>::zero();
+                };
 #pragma unroll
-                for (int sl = 0; sl < MAXR; ++sl) {
-                    uint32_t h1 = 0, f1 = 0;
-                    bool ok1 = false;
-                    V a_nxt = Vec<VEC>::zero();
-                    if (sl + 1 < MAXR) {
-                        slot(sl + 1, h1, f1, ok1);
-                        if (OPT != FWGPU_OPT_SGD) a_nxt = Vec<VEC>::template load<AUX_LA>(make_rsrc(p.ffm_acc + h1, ok1 ? R * 4 : 0), e0 * 4);
-                    }
+                for (int sl = 0; sl < NS; ++sl) {
+                    const int d_prev = sl < DMAX ? sl : DMAX, d_now = sl + 1 < DMAX ? sl + 1 : DMAX;
+                    const int first = sl == 0 ? 0 : sl - 1 + d_prev + 1, last = sl + d_now;
+#pragma unroll
+                    for (int j = first; j <= last; ++j)
+                        if (j < NS) issue(j);
+                    uint32_t h0, f0;
+                    bool ok0;
+                    slot(sl, h0, f0, ok0);
+                    V a_cur = av[sl];
                     const float v = s.e_val[kb + (uint32_t)sl];
-                    V wv = rows[sl];
+                    V wv;
+                    if (sl < MAXR) {
+                        wv = rows[sl < MAXR ? sl : 0];
+                    } else {  // a row parked in LDS by the gather
+                        wv = Vec<VEC>::zero();
+                        if (inb && ok0) wv = Vec<VEC>::lds_load(s.keep + ((uint32_t)wave * lk + (uint32_t)(sl - MAXR)) * R + e0);
+                    }
                     V tv = Vec<VEC>::zero();
                     if (inb) tv = Vec<VEC>::lds_load(s.T + f0 * R + e0);
                     const bool self = (z == f0);
@@ -2650,10 +2689,6 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                     }
                     Vec<VEC>::template store<AUX_SW>(wv, make_rsrc(p.ffm_w + h0, ok0 ? R * 4 : 0), e0 * 4);
                     if (OPT != FWGPU_OPT_SGD) Vec<VEC>::template store<AUX_SA>(a_cur, make_rsrc(p.ffm_acc + h0, ok0 ? R * 4 : 0), e0 * 4);
-                    a_cur = a_nxt;
-                    h0 = h1;
-                    f0 = f1;
-                    ok0 = ok1;
                 }
             } else
 #pragma unroll
@@ -2715,7 +2750,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                     const uint32_t i = i0 + u;
                     idx[u] = (i < hi && !(s.e_fld[i] & (kRowDep | kRowChained))) ? i : 0xffffffffu;
                     // (the first MAXR rows of the range were stepped from registers, unless they own a chain)
-                    if (WIN && MAXR > 0 && i >= kb && i < kb + MAXR && i < hi && !(s.e_fld[i] & kRowHasChain)) idx[u] = 0xffffffffu;
+                    if (WIN && MAXR > 0 && i >= kb && i < kb + nk2 && !(s.e_fld[i] & kRowHasChain)) idx[u] = 0xffffffffu;
                 }
                 if (WIN)
                     update_rows_win<OPT, AUX, UO, (NC > FW_WIN_NCH ? NC : FW_WIN_NCH), AUX_SW, AUX_SA>(p, s, idx, g, lane, nf);
@@ -2827,6 +2862,10 @@ void resolve_row_mode(KernelParams &p, uint32_t threads) {
     // The v2 kernel's single-chunk updating instantiations keep the LUT in LDS as a compile-time fact (kLdsLut): settled HERE, so that the host's
     // LDS size -- the occupancy choice and the 160 KiB check of prepare_launch -- is the size the launch really uses (debug option 1 does not apply to them).
     p.lut_lds_forced = (uses_resident_kernel(p, threads) && p.R <= 64 * 4 && p.update) ? 1 : 0;
+    // rows kept in LDS beyond the register-kept ones: the chained-update instantiation of single-chunk rows only (fw_example_kernel_r, FW_LDS_KEEP_MAX)
+    if (!(p.lut_lds_forced && p.window) || FW_KEEP_LAST) p.lds_keep = 0;
+    if (p.lds_keep > FW_LDS_KEEP_MAX) p.lds_keep = FW_LDS_KEEP_MAX;
+    p.lds_keep_words = p.lds_keep * (threads / 64) * p.R;
 }
 
 hipError_t launch_example_kernel(const KernelParams &p_in, int optimizer, bool coherent, uint32_t grid, uint32_t threads,

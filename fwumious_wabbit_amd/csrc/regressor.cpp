@@ -397,6 +397,10 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
         p.store_policy = r->launch.store_policy >= 0 ? r->launch.store_policy : (env_pol ? atoi(env_pol) : -1);
         p.wb_flush_every = r->launch.wb_flush_every >= 0 ? (uint32_t)r->launch.wb_flush_every : (env_wb ? (uint32_t)atoi(env_wb) : 0xffffffffu);
         p.prefetch = (r->launch.prefetch && !(env_pf && env_pf[0] == '0')) ? 1 : 0;
+        static const char *env_lk = getenv("FWGPU_LDS_KEEP");
+        // rows per wave kept in LDS beyond the register-kept ones: the wish (clamped to the kernel's maximum by resolve_row_mode, to what leaves two
+        // workgroups on a CU by prepare_launch)
+        p.lds_keep = r->launch.lds_keep >= 0 ? (uint32_t)r->launch.lds_keep : (env_lk ? (uint32_t)atoi(env_lk) : 255u);
     }
     p.work = b->work;
     p.host_cus = r->num_cus;
@@ -421,6 +425,12 @@ static int prepare_launch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int upda
         return fail(FWGPU_ERR_RANGE, "an example has more than 4096 FFM features");
     resolve_row_mode(p, threads);
     size_t lds = example_kernel_lds_bytes(p, r->cfg.optimizer);
+    // rows parked in LDS by the gather (KernelParams::lds_keep): as many per wave as still let a second workgroup live on the CU
+    while (p.lds_keep > 0 && 2 * lds > r->lds_per_cu) {
+        p.lds_keep--;
+        resolve_row_mode(p, threads);
+        lds = example_kernel_lds_bytes(p, r->cfg.optimizer);
+    }
     // When the LDS footprint lets only ONE workgroup live on a CU (k = 16 rows: T alone is 57.6 KB), the CU's waves have
     // to come from that workgroup: 1024 threads (measured at k = 16: 1.53 -> 1.82 M examples/s; with the deep head 0.67 -> 0.79).
     if (!r->launch.threads_set && mode == FWGPU_MODE_HOGWILD && 2 * lds > r->lds_per_cu) {
@@ -434,6 +444,7 @@ static int prepare_launch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int upda
             lds = lds_nolut;
         } else {
             threads = 1024;
+            p.lds_keep = 0;
             resolve_row_mode(p, threads);
             lds = example_kernel_lds_bytes(p, r->cfg.optimizer);
         }
@@ -827,6 +838,7 @@ int fwgpu_debug_set_option(fwgpu_regressor *r, int option, int value) {
         if (value < -1 || value > 65536) return fail(FWGPU_ERR_INVALID, "write-back interval option: -1 .. 65536 examples");
         r->launch.wb_flush_every = value;
         return FWGPU_OK;
+    case 8: r->launch.lds_keep = value; return FWGPU_OK;  // rows per wave kept in LDS beyond the register-kept ones (-1: automatic)
     case 7: r->launch.prefetch = value ? 1 : 0; return FWGPU_OK;  // next-record prefetch of the v2 kernel's updating launches
     case 2:  // whole-line FFM row updates: 0 off, 1 auto (tables larger than the Infinity Cache; default), 2 always, 3 chained path always with float-granular accesses
         if (value < 0 || value > 3) return fail(FWGPU_ERR_INVALID, "window option: 0, 1, 2 or 3");

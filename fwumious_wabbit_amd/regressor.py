@@ -401,6 +401,11 @@ class Regressor:
         """updating launches copy the next example's record to LDS during the current example (fwgpu_debug_set_option 7; default on)"""
         check(self.L.fwgpu_debug_set_option(self.h, 7, int(bool(on))))
 
+    def set_lds_keep(self, rows):
+        """rows per wave beyond the register-kept ones whose gather-time weights stay in LDS for the update (fwgpu_debug_set_option 8;
+        -1 = automatic, the default)"""
+        check(self.L.fwgpu_debug_set_option(self.h, 8, int(rows)))
+
     def set_hot_lr_entry(self, every):
         """HOGWILD launches (fwgpu_debug_set_option 4): the constant feature's LR entry is stepped with atomics -- the step size
         always from the GLOBAL accumulator (returning atomic add of g^2), the weight delta by a fire-and-forget atomic, sent at

@@ -438,6 +438,8 @@ int fwgpu_debug_set_kernel_version(fwgpu_regressor *r, int version);
  *   build's default: 128) -- the bound on how long a popular row can stay private to one XCD (DESIGN.md 4.2,
  *   tests/test_gpu_conservation.py).  SEQUENTIAL launches are exact under every policy.
  * option 7: value 0 = the updating launches do not prefetch the next example's record (A/B runs; default 1).
+ * option 8: rows per wave, beyond the 20 kept in registers, whose gather-time weights are parked in LDS for the update phase instead of
+ *   being re-read (config-C-shaped rows on the chained path): 0..3, -1 (default) = as many as still let two workgroups share a CU.
  * (The update path of option 2 = 1 / 2 keeps the first 20 rows of every wave's share of an example from the gather and writes
  *   them back as w_gather - step in HOGWILD launches: what the concurrent mode's hold-out loss rests on) */
 int fwgpu_debug_set_option(fwgpu_regressor *r, int option, int value);

@@ -3,7 +3,7 @@
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "fwumious_wabbit_amd", "csrc")
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", f"-I{ROOT}/include", "-I.",
+cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", f"-I{ROOT}/include", "-I.", "-mllvm", "-pragma-unroll-threshold=131072",
        "-Rpass-analysis=kernel-resource-usage", "-c", "kernels.hip", "-o", "/tmp/kernels_ru.o"]
 out = subprocess.run(cmd, cwd=src, capture_output=True, text=True).stderr
 # (kernels.hip is two translation units: the phase kernels -- FWD / UPD / MID -- are the second, see the Makefile)

@@ -114,10 +114,11 @@ class Rig:
     def close(self):
         self.re.close()
 
-    def run(self, n, hot_field, policy, flush_every, mode=capi.MODE_HOGWILD, seed=5):
+    def run(self, n, hot_field, policy, flush_every, mode=capi.MODE_HOGWILD, seed=5, lds_keep=-1):
         """one launch of n crafted examples; per hot row (mean, min, max surviving fraction over the row's floats, share of examples)"""
         re = self.re
         re.set_store_policy(policy, flush_every)
+        re.set_lds_keep(lds_keep)  # (-1: the shipped choice; 0: rows beyond the register-kept ones are re-read by the update)
         re.table_fill(capi.TABLE_FFM_ACC, self.acc0)
         for hh in _hot_hashes():
             re.table_write(capi.TABLE_FFM_W, np.full(R, W_HOT0, dtype=np.float32), hh)
@@ -160,6 +161,7 @@ def test_in_order_launch_applies_every_step_under_every_policy():
 # workgroup every 128 examples); the asserts are about it, the others are measured next to it and printed
 SHIPPED = (-1, -1)
 MEASURED = [(0, 0), (1, 0), (2, 0), (2, 64)]
+REREAD = "-1,-1 L0"
 
 # Measured on MI355X (profiles/r04c_conservation.txt, r04b_conservation.txt; rows in a third of all examples, ~170 concurrent holders):
 #   weights, SGD      write-through 0.014-0.036 (row kept from the gather) / 0.22-0.46 (row re-read in the update); write-back 0.010-0.027 / 0.083-0.114,
@@ -182,16 +184,18 @@ def test_hot_ffm_rows_keep_a_bounded_share_of_their_steps(opt, ffm_bits, capsys)
             for pol in [SHIPPED] + MEASURED:
                 fr = rig.run(n, hot_field, pol[0], pol[1])
                 table[(n, hot_field, pol)] = float(np.mean([f[0] for f in fr]))
+            # the shipped policy with no row parked in LDS: the last feature of the last wave is then a row the update RE-READS
+            table[(n, hot_field, REREAD)] = float(np.mean([f[0] for f in rig.run(n, hot_field, -1, -1, lds_keep=0)]))
     rig.close()
     with capsys.disabled():
         print(f"\nsurviving fraction of hot FFM rows' steps, {opt}, {ffm_bits}-bit table (mean over {H_HOT} rows, each in 1/{H_HOT} of the examples)")
-        print("  launch  hot_field " + " ".join(f"{str(p):>9}" for p in [SHIPPED] + MEASURED))
+        print("  launch  hot_field " + " ".join(f"{str(p):>9}" for p in [SHIPPED] + MEASURED + [REREAD]))
         for n in sizes:
             for hot_field in (0, 29):
-                print(f"  {n:6d}  {hot_field:9d} " + " ".join(f"{table[(n, hot_field, p)]:9.4f}" for p in [SHIPPED] + MEASURED))
+                print(f"  {n:6d}  {hot_field:9d} " + " ".join(f"{table[(n, hot_field, p)]:9.4f}" for p in [SHIPPED] + MEASURED + [REREAD]))
     for n in sizes:
-        if opt == "sgd":  # one of the two positions is a row kept from the gather, the other a row re-read in the update (which is which is the kernel's choice)
-            assert max(table[(n, 0, SHIPPED)], table[(n, 29, SHIPPED)]) >= FLOOR_W_REREAD, (n, table[(n, 0, SHIPPED)], table[(n, 29, SHIPPED)])
+        if opt == "sgd":  # with no row parked in LDS one of the two positions is a row kept from the gather, the other a row re-read in the update (which is which is the kernel's choice)
+            assert max(table[(n, 0, REREAD)], table[(n, 29, REREAD)]) >= FLOOR_W_REREAD, (n, table[(n, 0, REREAD)], table[(n, 29, REREAD)])
         for hot_field in (0, 29):
             shipped, wt = table[(n, hot_field, SHIPPED)], table[(n, hot_field, (0, 0))]
             if opt == "sgd":

@@ -53,7 +53,7 @@ def test_smoke_entry():
 
 # ------------------------------------------------------------------ streams: sequential mode == reference single thread
 def _stream_parity(n_ns, k, bits, ffm_bits, optimizer, n, mean_extra, p_weighted, ids, seed, interactions=(),
-                   weight_tol=2e-5, whole_lines=None, **kw):
+                   weight_tol=2e-5, whole_lines=None, lds_keep=None, **kw):
     mi, ocfg, ots = make_pair(n_ns, k, bits, ffm_bits, optimizer, interactions=interactions, **kw)
     recs, off = fw.synth_records(n_ns, mean_extra, 1.1, ids, p_weighted, seed, 0, n)
     y = record_labels(recs, off)
@@ -65,6 +65,8 @@ def _stream_parity(n_ns, k, bits, ffm_bits, optimizer, n, mean_extra, p_weighted
         re = fw.Regressor(mi)
         if whole_lines is not None:
             re.set_whole_line_updates(whole_lines)
+        if lds_keep is not None:
+            re.set_lds_keep(lds_keep)
         fbt = fw.FeatureBufferTranslator(mi)
         b = re.batch_from_records(fbt, recs, off) if kind == "entries" else re.record_batch(fbt, recs, off)
         re.learn_batch(b, capi.MODE_SEQUENTIAL, True)
@@ -102,6 +104,25 @@ def test_sequential_stream_config_c_like():
     # 30 fields, k=8, ~200 nnz per example, weighted features, LR interactions
     _stream_parity(30, 8, 18, 18, fw.Optimizer.AdagradLUT, n=300, mean_extra=5.67, p_weighted=0.1, ids=100000, seed=2,
                    interactions=[(0, 1), (3, 7)])
+
+
+_PARKED_CASES = {
+    "lut_lines": dict(args=(30, 8, 18, 18, fw.Optimizer.AdagradLUT), kw=dict(n=200, mean_extra=5.67, p_weighted=0.1, ids=100000, seed=61, whole_lines=2)),
+    "lut_collisions": dict(args=(30, 8, 16, 16, fw.Optimizer.AdagradLUT), kw=dict(n=150, mean_extra=5.67, p_weighted=0.1, ids=3000, seed=62, whole_lines=3)),
+    "flex": dict(args=(30, 8, 16, 16, fw.Optimizer.AdagradFlex),
+                 kw=dict(n=150, mean_extra=6.5, p_weighted=0.2, ids=20000, seed=63, init_acc=1.0, ffm_init_acc=1.0, weight_tol=5e-5, whole_lines=2)),
+    "sgd": dict(args=(30, 8, 16, 16, fw.Optimizer.SGD), kw=dict(n=150, mean_extra=6.5, p_weighted=0.2, ids=20000, seed=64, lr=0.05, ffm_lr=0.05, whole_lines=3)),
+}
+
+
+@pytest.mark.parametrize("case", list(_PARKED_CASES))
+@pytest.mark.parametrize("rows", [0, 1, 3])
+def test_rows_parked_in_lds_for_the_update_are_exact_in_order(rows, case):
+    """Rows of a wave's share beyond the 20 register-kept ones keep their gather-time weights in LDS (option 8) instead of being re-read by the
+    update phase.  ~200 features per example = ~25 rows per wave: with 0 / 1 / 3 parked rows per wave the in-order mode must stay the
+    reference's single thread, with repeated and overlapping rows (small tables) taking the chained path as before, for the three optimizers."""
+    c = _PARKED_CASES[case]
+    _stream_parity(*c["args"], lds_keep=rows, **c["kw"])
 
 
 @pytest.mark.parametrize("whole_lines", [0, 2])
