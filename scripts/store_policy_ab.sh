@@ -1,6 +1,6 @@
 #!/bin/bash
 # Interleaved A/B of the FFM row store policy, its write-back interval, the record prefetch and library variants through bench.py
-# (one process per run; env switches FWGPU_STORE_POLICY / FWGPU_WB_FLUSH_EVERY / FWGPU_PREFETCH / FWGPU_LIBRARY).  Round 4's tables
+# (one process per run; env switches FWGPU_STORE_POLICY / FWGPU_WB_FLUSH_EVERY / FWGPU_PREFETCH / FWGPU_LDS_KEEP / FWGPU_LIBRARY).  Round 4's tables
 # (profiles/r04a_policy_ab.txt, r04b_*, r04c_*) were produced by lists of this form.
 # usage: scripts/store_policy_ab.sh [passes=2] [steps=20] -- "name|ENV=val ENV=val" ...
 #   e.g. scripts/store_policy_ab.sh 2 20 -- "p1_f128|" "p2_f128|FWGPU_STORE_POLICY=2" "p1_f0|FWGPU_WB_FLUSH_EVERY=0" "m16|FWGPU_LIBRARY=$PWD/build/variants/libfwgpu_m16.so"
