@@ -2207,6 +2207,9 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #ifndef FW_LDS_KEEP_MAX
 #define FW_LDS_KEEP_MAX 3
 #endif
+#ifndef FW_PARK_DIRECT
+#define FW_PARK_DIRECT 1  // the parked rows are loaded with LDS-direct loads in the gather's first burst (0: through registers, two at a time, behind the kept rows)
+#endif
 #ifndef FW_PIPE_DEPTH
 #define FW_PIPE_DEPTH 3  // rows the accumulator loads of the pipelined kept-row update run ahead, at most
 #endif
@@ -2410,6 +2413,21 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                     rows[sl] = Vec<VEC>::template load<AUX_G>(make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
                 }
             }
+            // ... and the rows parked in LDS go there DIRECTLY (LDS-direct loads: no register in between), issued in the same burst as the register
+            // rows' loads instead of two at a time behind them: destination = wave-uniform slot base + lane * 16
+            if (kLdsKeep && FW_PARK_DIRECT) {
+#pragma unroll
+                for (int j = 0; j < LKM; ++j) {
+                    if ((uint32_t)(MAXR + j) < nk2) {
+                        const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[lo + MAXR + j]);
+                        const float *src = p.ffm_w + h + e0;
+                        float *dst = s.keep + ((uint32_t)wave * lk + (uint32_t)j) * R;
+                        if (inb)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                             (__attribute__((address_space(3))) void *)dst, 16, 0, AUX_G);
+                    }
+                }
+            }
         }
         {
             V acc[NC];
@@ -2484,8 +2502,21 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                     one[0] = rows[sl];
                     FW_CONSUME(one, kb + sl)
                 }
+            if (kLdsKeep && FW_PARK_DIRECT) {
+                // rows parked in LDS: their loads were issued right behind the register rows', which have all been consumed by now (vmcnt counts in
+                // order: nothing else of this wave is in flight)
+                if (nk2 > (uint32_t)MAXR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < LKM; ++j)
+                    if ((uint32_t)(MAXR + j) < nk2) {
+                        V one[NC];
+                        one[0] = Vec<VEC>::zero();
+                        if (inb) one[0] = Vec<VEC>::lds_load(s.keep + ((uint32_t)wave * lk + (uint32_t)j) * R + e0);
+                        FW_CONSUME(one, lo + MAXR + j)
+                    }
+            }
             // overflow rows of this range: transient (they are re-read in the update phase)
-            for (uint32_t i = kKeepLast ? hi : lo + MAXR; i < hi; i += UG) {
+            for (uint32_t i = kKeepLast ? hi : ((kLdsKeep && FW_PARK_DIRECT) ? lo + nk2 + (nk2 < (uint32_t)MAXR ? (uint32_t)MAXR - nk2 : 0u) : lo + MAXR); i < hi; i += UG) {
                 V r[UG][NC];
 #pragma unroll
                 for (int u = 0; u < UG; ++u) {
@@ -2504,7 +2535,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                     if (i + u < hi) {
                         FW_CONSUME(r[u], i + u)
                         // the first lds_keep of them stay in LDS for the update phase (as read HERE, like a register-kept row)
-                        if (kLdsKeep && inb && i + u - (lo + MAXR) < lk)
+                        if (kLdsKeep && !FW_PARK_DIRECT && inb && i + u - (lo + MAXR) < lk)
                             Vec<VEC>::lds_store(s.keep + ((uint32_t)wave * lk + (i + u - (lo + MAXR))) * R + e0, r[u][0]);
                     }
             }

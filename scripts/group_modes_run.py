@@ -20,17 +20,19 @@ args = A()
 args.fields, args.k, args.bits, args.ffm_bits = 30, 8, 28, 28
 args.nn_layers, args.nn_width = 0, 256
 args.mean_extra, args.zipf, args.ids, args.p_weighted, args.seed = 5.67, 1.05, 10_000_000, 0.1, 20240612
-GLOBAL = {"sparse": 8192, "sharded": int(os.environ.get("SHARDED_BATCH", 1024))}
+GLOBAL = {"sparse": 8192, "sharded": int(os.environ.get("SHARDED_BATCH", 1024)), "owner": int(os.environ.get("OWNER_BATCH", 8192))}
 TOTAL = int(os.environ.get("TOTAL", 262144))
 mi = bench.build_model_instance(fw, args, 0)
 recs, off = bench.gen_records(fw, args, 0, TOTAL)
 hrecs, hoff = bench.gen_records(fw, args, 1_000_000_000, 16384)
 hy = hrecs[hoff[:-1].astype(np.int64) + 1].astype(np.float32)
-for mode in ("sparse", "sharded"):
+for mode in os.environ.get("MODES", "sparse,sharded,owner").split(","):
     for n in (1, 2, 4):
         regs = [fw.Regressor(mi) for _ in range(n)]
         fbt = fw.FeatureBufferTranslator(mi)
         g = DistGroup(regs)
+        if mode == "owner":  # owner-side apply: hogwild kernels push gradient rows to the rows' owners, every owner applies concurrently
+            g.set_mode(capi.MODE_HOGWILD)
         gb = GLOBAL[mode]
         per = gb // n
         steps = TOTAL // gb
@@ -41,9 +43,9 @@ for mode in ("sparse", "sharded"):
                 a, b = s * gb + j * per, s * gb + (j + 1) * per
                 rr.append(recs[int(off[a]):int(off[b])])
                 oo.append(off[a:b + 1] - off[a])
-            (g.learn_sparse if mode == "sparse" else g.learn_sharded)(fbt, rr, oo)
+            {"sparse": g.learn_sparse, "sharded": g.learn_sharded, "owner": g.learn_owner}[mode](fbt, rr, oo)
         dt = time.perf_counter() - t0
-        if mode == "sharded":
+        if mode in ("sharded", "owner"):
             g.gather_tables()
         hb = regs[0].record_batch(fbt, hrecs, hoff)
         regs[0].learn_batch(hb, capi.MODE_HOGWILD, False)
