@@ -663,7 +663,7 @@ def main():
                 "kernel": ("fw_example_kernel<4, AdagradLUT, coherent, peer-sharded> (generic kernel with the owner lookup, system-scope row accesses)" if peer_main else
                            "FWD / MID / " + ("head GEMMs (v_mfma_f32_32x32x2_f32) / " if args.nn_layers else "") + "UPD kernels of the synchronous micro-batch (generic row kernel)"
                            if sync_steps or sharded_main else
-                           "fw_example_kernel_r<AdagradLUT, coherent, MAXR=20, duplicate-row chains> (2 workgroups x 512 threads per CU at 128 VGPRs; 20 rows per wave kept from the gather and written back as w_gather - step; whole-line row accesses only when w and acc contend for one memory region)"
+                           "fw_example_kernel_r<AdagradLUT, coherent, MAXR=20, duplicate-row chains> (2 workgroups x 512 threads per CU at 128 VGPRs; 20 rows per wave kept from the gather in registers + 3 in LDS and written back as w_gather - step by a pipelined update; whole-line row accesses only when w and acc contend for one memory region)"
                            if args.k % 4 == 0 and args.fields * args.k <= 256 and not args.nn_layers else
                            "fw_example_kernel_r<AdagradLUT, coherent, MAXR=0, duplicate-row chains, NC=2> (two 16-byte chunks per lane and row; 2 workgroups x 512 threads per CU)"
                            if args.k % 4 == 0 and args.fields * args.k <= 512 and 256 % args.k == 0 and not args.nn_layers else

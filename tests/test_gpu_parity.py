@@ -115,6 +115,13 @@ _PARKED_CASES = {
 }
 
 
+def test_parked_rows_at_every_share_size_around_the_register_capacity():
+    """~150 ... ~260 features per example over 8 waves = 18 ... 33 rows per wave: shares that end below, at and beyond the 20 register slots and the
+    parked slots, with repeated hashes (ids = 2000 on a 17-bit table) falling on kept, parked and re-read positions alike."""
+    for i, mean_extra in enumerate((4.0, 4.6, 5.0, 5.4, 6.0, 6.6, 7.6)):
+        _stream_parity(30, 8, 17, 17, fw.Optimizer.AdagradLUT, n=60, mean_extra=mean_extra, p_weighted=0.1, ids=2000, seed=70 + i, whole_lines=3 if i % 2 else 2)
+
+
 @pytest.mark.parametrize("case", list(_PARKED_CASES))
 @pytest.mark.parametrize("rows", [0, 1, 3])
 def test_rows_parked_in_lds_for_the_update_are_exact_in_order(rows, case):

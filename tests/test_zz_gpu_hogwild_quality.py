@@ -8,6 +8,8 @@ log-loss of a short stream (benchmark/calc_loss.py:5-25), never with another GPU
 Every scenario is a function returning (gpu hold-out loss, sequential oracle's hold-out loss); the tests assert on the gap and
 `scripts/holdout_spread.py` runs the same functions repeatedly to measure the spread the tolerance rests on.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -176,7 +178,7 @@ def scenario_zipf13_noise(k8_win, hot_lr=None):
     the labels flipped.  `k8_win`: 20 fields, k = 8, ~40 features per example, weighted features, bench.py's hyper-parameters, and the
     update path of config C's large tables forced onto the 20-bit table (rows kept from the gather, duplicate-row chains, the shipped
     store policy) -- the kernel the headline number comes from, here against the sequential oracle."""
-    n_train, n_hold = 65536, 8192
+    n_train, n_hold = (int(os.environ.get("Z13_K8_TRAIN", 65536)) if k8_win else 65536), 8192
     if k8_win:
         mi, ocfg, ots = make_pair(20, 8, 20, 20, fw.Optimizer.AdagradLUT, lr=0.025, ffm_lr=0.025, power_t=0.38, ffm_power_t=0.38)
         recs, off = fw.synth_records(20, 1.0, 1.3, 100000, 0.1, 4242, 0, n_train + n_hold)
@@ -185,7 +187,7 @@ def scenario_zipf13_noise(k8_win, hot_lr=None):
         recs, off = fw.synth_records(10, 0.0, 1.3, 100000, 0.0, 4242, 0, n_train + n_hold)
     recs = _flip_labels(recs, off, 0.05, 99)
     y = record_labels(recs, off)
-    ref_hold, _ = _holdout_loss_oracle(ocfg, ots, recs, off, n_train, key=("z13", k8_win))
+    ref_hold, _ = _holdout_loss_oracle(ocfg, ots, recs, off, n_train, key=("z13", k8_win, n_train))
     re = fw.Regressor(mi)
     if k8_win:
         re.set_whole_line_updates(3)
