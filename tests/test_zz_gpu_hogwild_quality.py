@@ -29,8 +29,8 @@ pytestmark = [pytest.mark.gpu, pytest.mark.statistical]
 # Stream families: Zipf(1.1) ids with a teacher FFM (synth_records), the same at Zipf(1.3) with another teacher and 5 % of the labels
 # flipped (noisy: the loss floor is well above zero), and the reference's own example data (examples/ffm, config A).
 TOL = {
-    "short_fused": 0.0070, "short_sync": 0.0055, "hogwild_96k": 0.0075, "config_b": 0.0125, "two_chunk_wl1": 0.0145, "two_chunk_wl2": 0.0186,
-    "trainer": 0.0050, "zipf13_noise": 0.0100, "zipf13_noise_k8_win": 0.0265, "config_a_hogwild": 0.0550,
+    "short_fused": 0.0070, "short_sync": 0.0055, "hogwild_96k": 0.0075, "config_b": 0.0140, "two_chunk_wl1": 0.0145, "two_chunk_wl2": 0.0186,
+    "trainer": 0.0050, "zipf13_noise": 0.0100, "zipf13_noise_k8_win": 0.0160, "config_a_hogwild": 0.0550,
 }
 LN2 = 0.6931
 
@@ -178,7 +178,7 @@ def scenario_zipf13_noise(k8_win, hot_lr=None):
     the labels flipped.  `k8_win`: 20 fields, k = 8, ~40 features per example, weighted features, bench.py's hyper-parameters, and the
     update path of config C's large tables forced onto the 20-bit table (rows kept from the gather, duplicate-row chains, the shipped
     store policy) -- the kernel the headline number comes from, here against the sequential oracle."""
-    n_train, n_hold = (int(os.environ.get("Z13_K8_TRAIN", 65536)) if k8_win else 65536), 8192
+    n_train, n_hold = (int(os.environ.get("Z13_K8_TRAIN", 98304)) if k8_win else 65536), 8192
     if k8_win:
         mi, ocfg, ots = make_pair(20, 8, 20, 20, fw.Optimizer.AdagradLUT, lr=0.025, ffm_lr=0.025, power_t=0.38, ffm_power_t=0.38)
         recs, off = fw.synth_records(20, 1.0, 1.3, 100000, 0.1, 4242, 0, n_train + n_hold)
