@@ -1344,14 +1344,6 @@ int fwgpu_dist_group_learn_sparse(fwgpu_dist_group *g, const fwgpu_translator_co
         if (preds && preds[j] && d->B) FWGPU_HIP(hipMemcpyAsync(preds[j], d->cur->pred, (size_t)d->B * 4, hipMemcpyDeviceToHost, d->stream));
         FWGPU_HIP(hipStreamSynchronize(d->stream));
     }
-#ifdef FW_DBG_KERNARG_CHECK
-    {
-        unsigned checked[3] = {0, 0, 0};
-        const unsigned changed = dbg_kernarg_changed_read(checked);
-        std::fprintf(stderr, "[kernarg] of %u workgroups checked so far: argument block changed in memory while they ran: %u; arguments as LOADED BY THE KERNEL differ from the block in memory: %u (FWD), %u (MID workgroups)\n",
-                     checked[0], changed, checked[1], checked[2]);
-    }
-#endif
     return FWGPU_OK;
 }
 

@@ -208,10 +208,7 @@ hipError_t launch_example_kernel(const KernelParams &p, int optimizer, bool cohe
 // records and the gradients); the MID step (records -> logit -> prediction, general gradient / deep-head input) is its own kernel
 hipError_t launch_example_phase(const KernelParams &p, int optimizer, int phase, uint32_t grid, uint32_t threads, hipStream_t stream);
 hipError_t launch_split_mid(const KernelParams &p, uint32_t n_examples, hipStream_t stream);
-uint32_t dbg_canary_read();
-#ifdef FW_DBG_KERNARG_CHECK
-unsigned dbg_kernarg_changed_read(unsigned *checked);
-#endif  // debug: LDS canary words found changed so far (phase launches under FWGPU_DBG_LDS_CANARY)
+uint32_t dbg_canary_read();  // debug: LDS canary words found changed so far (phase launches under FWGPU_DBG_LDS_CANARY)
 uint32_t split_record_len(uint32_t F, uint32_t R, uint32_t nlr);
 // row-sparse gradient buckets (sparse.hip)
 struct SparseReduceArgs {

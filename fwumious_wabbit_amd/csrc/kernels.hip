@@ -494,11 +494,7 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
         o.imp = p.importance[ex];
     }
     o.do_update = p.update && (o.imp != 0.0f);  // regressor.rs:366
-#ifdef FW_ABL_NO_SETS
-    const bool do_update = false;
-#else
     const bool do_update = o.do_update;
-#endif
 
     for (uint32_t i = tid; i < F; i += bd) {
         s.fstart[i] = 0;
@@ -1057,10 +1053,7 @@ __device__ __forceinline__ void nn_layer_backward_vec(const DevNN &n, uint32_t l
                     w[u][c] = w[u][c] - upd;
                     a[u][c] = acc;
                 }
-#ifndef FW_NN_WB_W  // A/B build: the dense WEIGHT stores of hogwild launches write-back through the XCD's L2 (the FFM rows' policy 1 applied to the head)
-#define FW_NN_WB_W 0
-#endif
-                Vec<4>::store<(FW_NN_WB_W ? kAuxPlain : kAuxSc1)>(w[u], rw, bo);
+                Vec<4>::store<kAuxSc1>(w[u], rw, bo);
                 if (OPT != FWGPU_OPT_SGD) Vec<4>::store<kAuxSc1>(a[u], ra, bo);
             }
         }
@@ -1290,15 +1283,6 @@ template <int OPT, int AUX, int U, int NCH, int AUX_SW = AUX, int AUX_SA = AUX>
 __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds &s, const uint32_t (&idx)[U], float g,
                                                 int lane, uint32_t nf, const float *gpair = nullptr) {
     const uint32_t R = p.R, k = p.k, ksh = p.k_log2;
-#ifdef FW_PROF_UPD  // debug build only: where does an update iteration spend its time (thread 0 of every workgroup)
-    const bool prof = p.ticks != nullptr && threadIdx.x == 0;
-    unsigned long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0;
-    if (p.ticks) {
-        pt0 = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // earlier stores acknowledged
-        pt1 = __builtin_amdgcn_s_memtime();
-    }
-#endif
     // NCH 1 KiB chunks per row, all loaded before anything is computed (one memory round trip per batch of U rows).
     // A k = 8 row that starts 96 B into a line spans 9 lines: its second chunk is the one extra line (8 lanes).
     f4 wv[U][NCH], av[U][NCH];
@@ -1327,13 +1311,6 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
             }
         }
     }
-#ifdef FW_PROF_UPD
-    if (p.ticks) {
-        pt2 = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this batch's loads have landed
-        pt3 = __builtin_amdgcn_s_memtime();
-    }
-#endif
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         if (nb[u] == 0) continue;
@@ -1386,25 +1363,10 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
                 an = av[u][c];
             }
             const uint32_t fl = hh[u] - (sb[u] >> 2);
-#ifdef FW_ABL_NO_STORE
-            if (wn[0] == 123.456f && an[1] == 654.321f)
-#endif
             Vec<4>::template store<AUX_SW>(wn, make_rsrc(p.ffm_w + fl, nb[u]), c * 1024 + lane * 16);
-#ifdef FW_ABL_NO_STORE
-            if (wn[0] == 123.456f && an[1] == 654.321f)
-#endif
             if (OPT != FWGPU_OPT_SGD) Vec<4>::template store<AUX_SA>(an, make_rsrc(p.ffm_acc + fl, nb[u]), c * 1024 + lane * 16);
         }
     }
-#ifdef FW_PROF_UPD
-    if (prof) {
-        const unsigned long long pt4 = __builtin_amdgcn_s_memtime();
-        atomicAdd(p.ticks + 12, pt1 - pt0);  // draining the previous batch's stores
-        atomicAdd(p.ticks + 13, pt3 - pt2);  // load latency (issue done -> data)
-        atomicAdd(p.ticks + 14, (pt2 - pt1) + (pt4 - pt3));  // issue + compute + store issue
-        atomicAdd(p.ticks + 15, 1ull);
-    }
-#endif
 }
 
 // split record of one example (floats): T[F*R] | dcf[F] | LR sums[nlr] | feature count per field[F] | label | importance | pad
@@ -1471,31 +1433,6 @@ __device__ __forceinline__ const KernelParams &kp_fresh() {
 //   FWD : stage, gather the rows this rank OWNS (all of them on one GPU), write T / dcf / LR sums to the example's split record
 //   (exchange: records summed over the ranks; MID kernel: logit, prediction, general gradient; or the mini-batched deep head)
 //   UPD : stage, T and the entries' own slots back from the records, AdaGrad on the owned rows and LR entries
-#ifdef FW_DBG_KERNARG_CHECK  // debug build (scripts/kp_size_exp.sh): does a running kernel's argument block change under it?
-__device__ unsigned g_dbg_kernarg_changed[4];  // [0] workgroups whose kernarg checksum differed between entry and exit, [1] workgroups checked,
-                                               // [2] workgroups whose arguments, as loaded by the kernel, differ from the argument block in memory; [3] the same for the MID kernel
-#ifdef FW_PHASE_TU
-unsigned dbg_kernarg_changed_read(unsigned *checked) {
-    unsigned v[4] = {0, 0, 0, 0};
-    (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(g_dbg_kernarg_changed), sizeof(v));
-    if (checked) {
-        checked[0] = v[1];
-        checked[1] = v[2];
-        checked[2] = v[3];
-    }
-    return v[0];
-}
-#endif
-__device__ __forceinline__ unsigned dbg_kernarg_sum() {
-    // (read through the flat address of the segment with device-scope loads: not the scalar cache's copy)
-    unsigned long long a = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("; kernarg address laundered" : "+v"(a));  // (the constant address space must not follow the pointer)
-    const unsigned *ka = reinterpret_cast<const unsigned *>(a);
-    unsigned x = 0;
-    for (unsigned i = 0; i < sizeof(KernelParams) / 4; i++) x = x * 31u + __hip_atomic_load(ka + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    return x;
-}
-#endif
 template <int VEC, int OPT, bool COH, int PH = 0, bool NN = true, bool SH = false>
 __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* read through kp_fresh() */) {
     const KernelParams &p = kp_fresh();
@@ -1548,17 +1485,6 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
         hot_lr_init<COH>(p, s, PH == 0);
         s.ctr[kCtrWbCount] = blockIdx.x & 15u;
     }
-#ifdef FW_DBG_KERNARG_CHECK
-    unsigned ka_sum0 = 0;
-    if (tid == 0) {
-        ka_sum0 = dbg_kernarg_sum();
-        // the same sum over the arguments AS THE KERNEL SEES THEM (scalar loads from the kernarg segment, through the scalar cache / L2)
-        const unsigned *q = reinterpret_cast<const unsigned *>(&p);
-        unsigned xs = 0;
-        for (unsigned i = 0; i < sizeof(KernelParams) / 4; i++) xs = xs * 31u + q[i];
-        if (xs != ka_sum0) atomicAdd(&g_dbg_kernarg_changed[2], 1u);
-    }
-#endif
 #ifndef FW_KP_NO_CANARY
     if (p.dbg_canary)  // debug: 256 words behind this kernel's own LDS layout; nobody may write there
         for (uint32_t i = tid; i < 256; i += bd) reinterpret_cast<uint32_t *>(smem + p.dbg_canary_off)[i] = 0xC0FFEE00u + i;
@@ -1900,21 +1826,8 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
             FW_TICK(5);
         }
         if (tid == 0) s.ctr[6] = next_ticket;  // published by the loop-top barrier
-#if FW_NN_WB_W
-        if (COH && NN && gridDim.x > 1 && tid == bd - 1) {  // (A/B build) bound on the dense weights' dirty window: one L2 write-back per 16 examples of a workgroup
-            const uint32_t c = s.ctr[kCtrWbCount] + 1;
-            s.ctr[kCtrWbCount] = c & 15u;
-            if ((c & 15u) == 0) asm volatile("buffer_wbl2 sc1" ::: "memory");
-        }
-#endif
     }
     if (COH && tid == 0 && s.ctr[13]) hot_lr_flush<SH>(p, s);  // (every thread's steps are in: the loop ends on a barrier)
-#ifdef FW_DBG_KERNARG_CHECK
-    if (tid == 0) {
-        atomicAdd(&g_dbg_kernarg_changed[1], 1u);
-        if (dbg_kernarg_sum() != ka_sum0) atomicAdd(&g_dbg_kernarg_changed[0], 1u);
-    }
-#endif
 #ifndef FW_KP_NO_CANARY
     if (p.dbg_canary)
         for (uint32_t i = tid; i < 256; i += bd)
@@ -2056,22 +1969,9 @@ uint32_t dbg_canary_read() {
 // (LR sum + 0.5 * (sum_e T[e] * T[perm(e)] - sum_f dcf[f])), sigmoid / log-loss (block_loss_functions.rs:105-153) -> prediction and
 // general gradient; or, with a mini-batched deep head, the head's input x = [LR combo sums, triangle of the pair outputs]
 // (block_misc.rs:864-883; a field holding at most one feature has a diagonal of exactly 0, as in the reference's own form).
-#ifdef FW_DBG_MID_PAD  // debug build: two more by-value words lift this kernel's argument segment over the size class of the fault
-__global__ void __launch_bounds__(256) split_mid_kernel(const KernelParams p, uint32_t n, unsigned long long pad0, unsigned long long pad1) {
-#else
 __global__ void __launch_bounds__(256) split_mid_kernel(const KernelParams p, uint32_t n) {
-#endif
     __shared__ float red[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#ifdef FW_DBG_KERNARG_CHECK
-    if (tid == 0) {  // this kernel's arguments as it loads them against the argument block in memory
-        const unsigned mem = dbg_kernarg_sum();
-        const unsigned *q = reinterpret_cast<const unsigned *>(&p);
-        unsigned xs = 0;
-        for (unsigned i = 0; i < sizeof(KernelParams) / 4; i++) xs = xs * 31u + q[i];
-        if (xs != mem) atomicAdd(&g_dbg_kernarg_changed[3], 1u);
-    }
-#endif
     const uint32_t F = p.F, k = p.k, R = p.R, C = p.split_nlr;
     for (uint32_t ex = blockIdx.x; ex < n; ex += gridDim.x) {
         const float *rec = p.split + (size_t)ex * p.split_len;
@@ -2135,11 +2035,7 @@ __global__ void __launch_bounds__(256) split_mid_kernel(const KernelParams p, ui
 
 hipError_t launch_split_mid(const KernelParams &p, uint32_t n, hipStream_t stream) {
     if (!n) return hipSuccess;
-#ifdef FW_DBG_MID_PAD
-    hipLaunchKernelGGL(split_mid_kernel, dim3(n < 4096 ? n : 4096), dim3(256), 0, stream, p, n, 0ull, 0ull);
-#else
     hipLaunchKernelGGL(split_mid_kernel, dim3(n < 4096 ? n : 4096), dim3(256), 0, stream, p, n);
-#endif
     return hipGetLastError();
 }
 
@@ -2639,16 +2535,8 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         if (tid == 0) p.pred[ex] = pr;
         FW_TICK(3);
 
-#ifdef FW_ABL_SKIP_UPDATE
-        if (do_update && g == 123.456f) {
-#else
         if (do_update && g != 0.0f) {
-#endif
-#ifdef FW_ABL_NO_LR_UPD
-            const bool lr_upd = false;
-#else
             const bool lr_upd = p.has_lr;
-#endif
             // The pair kept from the forward pass saves the update's load round trip: +1.8 % examples/s at config C at the same loss.  Only for
             // examples of at least FW_LR_KEEP_MIN LR entries: on streams of small examples (10-40 entries, ~15 us per example) the longer
             // read-modify-write window of the hot LR entries costs 0.005-0.01 of hold-out loss (profiles/r04_lr_pair_kept_ab.txt; round 2 saw the same).
@@ -2770,11 +2658,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                 }
             }
             // phase A, overflow rows of this range: the v1 route (fresh read of w)
-#ifdef FW_ABL_NO_FFM_UPD
-            for (uint32_t i0 = hi; i0 < hi; i0 += UO) {
-#else
             for (uint32_t i0 = (WIN && MAXR > 0) ? lo : lo + MAXR; i0 < hi; i0 += UO) {
-#endif
                 uint32_t idx[UO];
 #pragma unroll
                 for (int u = 0; u < UO; ++u) {
