@@ -103,10 +103,113 @@ __global__ void __launch_bounds__(256) head_gemm(const float *__restrict__ A, co
     }
 }
 
+// The same product for the shapes the head really has (a batch of ~1024 rows against 256 ... 496 columns): the 64 x 64 tiles above make 32-64 workgroups
+// of them, i.e. most of the 256 CUs idle (2-3 TFLOP/s).  Here a workgroup owns ONE 32 x 32 tile of C and its eight waves split K: every wave feeds the
+// matrix core straight from global memory (the operands, a few MB, live in L2: no LDS staging, no barrier in the K loop), the loads of the next three groups of eight k
+// in flight while the current eight are multiplied; the partial tiles meet in LDS and are summed in wave order (deterministic).
+//   k of MFMA t of group u: 8 u + 4 (lane >> 5) + t -- so that a lane's four k are CONTIGUOUS: one 16-byte load where k is the fast dimension.
+// Needs K % 8 == 0, lda / ldb % 4 == 0 and 16-byte aligned operands where k is their fast dimension (head_step checks; otherwise head_gemm above).
+constexpr int kSplitK = 8;  // waves of a workgroup = shares of K
+template <bool TA, bool TB, int EPI>
+__global__ void __launch_bounds__(64 * kSplitK) head_gemm_splitk(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int M,
+                                                        int N, int K, int lda, int ldb, int ldc, const float *__restrict__ bias,
+                                                        float *__restrict__ aux, int relu) {
+    __shared__ float part[kSplitK][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, ij = lane & 31;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int gm = m0 + ij, gn = n0 + ij;
+    const bool mok = gm < M, nok = gn < N;
+    const int U = K >> 3, u0 = (U * wave) / kSplitK, u1 = (U * (wave + 1)) / kSplitK;
+    f16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    auto load_a = [&](int u) -> f4v {
+        f4v v = {0, 0, 0, 0};
+        const int kb = 8 * u + 4 * half;
+        if (mok) {
+            if (TA) {  // A[k * lda + m]: four rows of the k-major operand, each coalesced across the 32 lanes of a half
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = A[(size_t)(kb + t) * lda + gm];
+            } else {
+                v = *reinterpret_cast<const f4v *>(A + (size_t)gm * lda + kb);
+            }
+        }
+        return v;
+    };
+    auto load_b = [&](int u) -> f4v {
+        f4v v = {0, 0, 0, 0};
+        const int kb = 8 * u + 4 * half;
+        if (nok) {
+            if (TB) {
+                v = *reinterpret_cast<const f4v *>(B + (size_t)gn * ldb + kb);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = B[(size_t)(kb + t) * ldb + gn];
+            }
+        }
+        return v;
+    };
+    // three groups of eight k in flight ahead of the one being multiplied (rotating registers: no indexed arrays)
+    const f4v z4 = {0, 0, 0, 0};
+    f4v a0 = u0 < u1 ? load_a(u0) : z4, b0 = u0 < u1 ? load_b(u0) : z4;
+    f4v a1 = u0 + 1 < u1 ? load_a(u0 + 1) : z4, b1 = u0 + 1 < u1 ? load_b(u0 + 1) : z4;
+    f4v a2 = u0 + 2 < u1 ? load_a(u0 + 2) : z4, b2 = u0 + 2 < u1 ? load_b(u0 + 2) : z4;
+    for (int u = u0; u < u1; ++u) {
+        f4v a3 = z4, b3 = z4;
+        if (u + 3 < u1) {
+            a3 = load_a(u + 3);
+            b3 = load_b(u + 3);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc, 0, 0, 0);
+        a0 = a1; b0 = b1;
+        a1 = a2; b1 = b2;
+        a2 = a3; b2 = b3;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wave][r][lane] = acc[r];
+    __syncthreads();
+    // wave w finishes registers (16 / kSplitK) w ... of the tile: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int col = n0 + ij;
+    if (col < N) {
+        const float bj = (EPI == 1 && bias) ? bias[col] : 0.0f;
+        constexpr int RPW = 16 / kSplitK;
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            const int r = RPW * wave + q;
+            const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row < M) {
+                float v = 0.0f;
+#pragma unroll
+                for (int w = 0; w < kSplitK; ++w) v += part[w][r][lane];  // wave order: deterministic
+                const size_t ix = (size_t)row * ldc + col;
+                if (EPI == 1) {
+                    v += bj;
+                    const bool neg = relu && v < 0.0f;
+                    aux[ix] = neg ? 0.0f : 1.0f;
+                    C[ix] = neg ? 0.0f : v;
+                } else if (EPI == 2) {
+                    C[ix] = v * aux[ix];
+                } else if (EPI == 3) {
+                    C[ix] += v;
+                } else {
+                    C[ix] = v;
+                }
+            }
+        }
+    }
+}
+
 template <bool TA, bool TB, int EPI>
 static hipError_t gemm(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb, int ldc, const float *bias,
                        float *aux, int relu, hipStream_t s) {
     if (M <= 0 || N <= 0) return hipSuccess;
+    static const bool old_only = std::getenv("FWGPU_HEAD_GEMM_TILED") != nullptr;  // (A/B runs: the LDS-tiled 64 x 64 kernel for every shape)
+    const bool a_vec = TA || (lda % 4 == 0 && ((uintptr_t)A & 15u) == 0), b_vec = !TB || (ldb % 4 == 0 && ((uintptr_t)B & 15u) == 0);
+    if (!old_only && K >= 8 * kSplitK && K % 8 == 0 && a_vec && b_vec) {
+        dim3 grid((N + 31) / 32, (M + 31) / 32);
+        hipLaunchKernelGGL((head_gemm_splitk<TA, TB, EPI>), grid, dim3(64 * kSplitK), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias, aux, relu);
+        return hipGetLastError();
+    }
     dim3 grid((N + kTN - 1) / kTN, (M + kTM - 1) / kTM);
     hipLaunchKernelGGL((head_gemm<TA, TB, EPI>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias, aux, relu);
     return hipGetLastError();
@@ -156,14 +259,16 @@ __global__ void __launch_bounds__(256) head_final_kernel(const float *__restrict
 }
 
 // out[c] = sum_e scale[e] * Mat[e, c]  (scale == NULL: plain column sums): the bias gradients and the final neuron's weight
-// gradients.  Workgroup = 64 columns x 4 row groups; every group walks its quarter of the examples in order, the four partial
-// sums are added in a fixed order: deterministic, coalesced (64 consecutive columns per wave load).
-__global__ void __launch_bounds__(256) head_colsum_kernel(const float *__restrict__ mat, const float *__restrict__ scale, float *__restrict__ out, int n,
-                                                          int cols, int ld) {
-    __shared__ float part[4][64];
+// gradients.  Workgroup = 64 columns x 16 row groups (1024 threads: 256 ... 496 columns make only 4 ... 8 workgroups, so the rows have to be spread inside
+// them); every group walks its sixteenth of the examples in order, the partial sums are added in a fixed order: deterministic, coalesced (64
+// consecutive columns per wave load).
+constexpr int kColsumGroups = 16;
+__global__ void __launch_bounds__(64 * kColsumGroups) head_colsum_kernel(const float *__restrict__ mat, const float *__restrict__ scale, float *__restrict__ out,
+                                                                         int n, int cols, int ld) {
+    __shared__ float part[kColsumGroups][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    const int per = (n + 3) / 4, e0 = grp * per, e1 = min(n, e0 + per);
+    const int per = (n + kColsumGroups - 1) / kColsumGroups, e0 = grp * per, e1 = min(n, e0 + per);
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
     if (c < cols) {
         int e = e0;
@@ -177,7 +282,12 @@ __global__ void __launch_bounds__(256) head_colsum_kernel(const float *__restric
     }
     part[grp][lane] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (grp == 0 && c < cols) out[c] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (grp == 0 && c < cols) {
+        float t = 0.0f;
+#pragma unroll
+        for (int g = 0; g < kColsumGroups; ++g) t += part[g][lane];
+        out[c] = t;
+    }
 }
 __global__ void __launch_bounds__(256) head_sum_kernel(const float *__restrict__ v, float *__restrict__ out, int n) {
     __shared__ float part[256];
@@ -282,9 +392,9 @@ int head_step(fwgpu_regressor *r, fwgpu_split *sp, uint32_t first, uint32_t n, f
     // final neuron's weight gradients: sum_e g_e * [h_last | x]_e, bias: sum_e g_e
     {
         float *dwf = dW + nn.off[L];
-        hipLaunchKernelGGL(head_colsum_kernel, dim3((wl + 63) / 64), dim3(256), 0, stream, hs.h[L - 1], hs.gvec, dwf, (int)n, (int)wl, (int)wl);
+        hipLaunchKernelGGL(head_colsum_kernel, dim3((wl + 63) / 64), dim3(64 * kColsumGroups), 0, stream, hs.h[L - 1], hs.gvec, dwf, (int)n, (int)wl, (int)wl);
         if (nn.topology == 1)
-            hipLaunchKernelGGL(head_colsum_kernel, dim3((X + 63) / 64), dim3(256), 0, stream, x, hs.gvec, dwf + wl, (int)n, (int)X, (int)X);
+            hipLaunchKernelGGL(head_colsum_kernel, dim3((X + 63) / 64), dim3(64 * kColsumGroups), 0, stream, x, hs.gvec, dwf + wl, (int)n, (int)X, (int)X);
         hipLaunchKernelGGL(head_sum_kernel, dim3(1), dim3(256), 0, stream, hs.gvec, dwf + nn.in[L], (int)n);
         FWGPU_HIP(hipGetLastError());
     }
@@ -295,7 +405,7 @@ int head_step(fwgpu_regressor *r, fwgpu_split *sp, uint32_t first, uint32_t n, f
         const float *lin = l == 0 ? x : hs.h[l - 1];
         // dW_l[j, i] = sum_e dz[e, j] * in[e, i]
         FWGPU_HIP((gemm<true, false, 0>(hs.dz[l], lin, dW + nn.off[l], (int)out, (int)inw, (int)n, (int)out, (int)inw, (int)inw, nullptr, nullptr, 0, stream)));
-        hipLaunchKernelGGL(head_colsum_kernel, dim3((out + 63) / 64), dim3(256), 0, stream, hs.dz[l], (const float *)nullptr,
+        hipLaunchKernelGGL(head_colsum_kernel, dim3((out + 63) / 64), dim3(64 * kColsumGroups), 0, stream, hs.dz[l], (const float *)nullptr,
                            dW + nn.off[l] + (size_t)inw * out, (int)n, (int)out, (int)out);
         FWGPU_HIP(hipGetLastError());
         if (l > 0) {  // d in = dz . W, then through the previous layer's ReLU mask
