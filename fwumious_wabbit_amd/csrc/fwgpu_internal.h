@@ -120,6 +120,7 @@ struct KernelParams {
     float lr_rate, lr_minus_power_t;    // SGD / AdagradFlex parameters of the LR block
     float ffm_rate, ffm_minus_power_t;  // ... of the FFM block
     int32_t lut_global;                 // 1: AdaGrad LUT read from global memory (through L1) instead of an LDS copy
+    int32_t t_global;                   // phase kernels (FWD / UPD of the synchronous pipeline): the field sums T are written to / read from the example's split record in HBM directly, not staged in LDS (launch_example_phase)
     int32_t lut_lds_forced;             // ... unless the launch runs a kernel that keeps it in LDS as a compile-time fact (resolve_row_mode)
     int32_t store_policy;               // hogwild launches of the v2 window kernel: how FFM row stores reach memory (kernels.hip "store policy"): 0 = both tables
                                         // device-scope write-through, 1 = weights write-back through the XCD's L2, 2 = both tables write-back

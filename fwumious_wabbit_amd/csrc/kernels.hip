@@ -315,10 +315,11 @@ __device__ __forceinline__ float2 lr_forward_pair(const KernelParams &p, const L
 
 __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t max_ffm, uint32_t max_lr, uint32_t n_luts,
                                              uint32_t max_rec, uint32_t tr_items, uint32_t nn_floats, bool chain, size_t *off /*[25]*/,
-                                             uint32_t pf_words = 0, uint32_t tr_words = 0, uint32_t keep_words = 0) {
+                                             uint32_t pf_words = 0, uint32_t tr_words = 0, uint32_t keep_words = 0, bool t_in_lds = true) {
     size_t o = 0;
     size_t R = (size_t)F * k;
-    off[0] = o; o = align16(o + 4 * F * R);
+    const size_t t_bytes = t_in_lds ? 4 * F * R : 0;  // (phase kernels keep T in the split record: KernelParams::t_global)
+    off[0] = o; o = align16(o + t_bytes);
     off[1] = o; o = align16(o + 4 * (size_t)max_ffm * k);
     off[2] = o; o = align16(o + 4 * (size_t)kLutSize * n_luts);
     off[3] = o; o = align16(o + 4 * (size_t)max_ffm);
@@ -336,7 +337,7 @@ __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t ma
     {
         const size_t a13 = 0, a14 = align16(a13 + 4 * (size_t)set_size(max_ffm)), a15 = align16(a14 + 4 * (size_t)set_size(max_lr)),
                      a20 = align16(a15 + 4 * (size_t)max_rec), aend = align16(a20 + (chain ? 4 * (size_t)set_size(max_ffm) : 0));
-        if (aend <= 4 * F * R) {
+        if (aend <= t_bytes) {
             off[13] = a13;
             off[14] = a14;
             off[15] = a15;
@@ -709,6 +710,8 @@ __device__ __forceinline__ StageOut stage_example(const KernelParams &p, const L
     // the gather: it writes the columns of the non-empty fields only, and a barrier follows it.
     if (p.k) {
         const uint32_t per = R / (p.k % 4 == 0 ? 4 : 1), vecw = p.k % 4 == 0 ? 4 : 1;
+        // (UPD phase with T in the split record: the record IS the example's T -- for a chunk of an oversize example, the whole example's -- and is left alone)
+        if (!(p.t_global && p.update))
         for (uint32_t idx = tid; idx < F * per; idx += bd) {
             const uint32_t f = idx / per, q = idx - f * per;
             if (s.fstart[f] == s.fend[f]) {  // (with a context cache: the cached features' sums stand alone)
@@ -766,7 +769,7 @@ size_t example_kernel_lds_bytes(const KernelParams &p, int optimizer) {
     // (lut_lds_forced: the v2 kernel's single-chunk instantiations ALWAYS keep the AdaGrad LUT in LDS -- kLdsLut -- whatever option 1 says)
     return lds_layout(p.F, p.k, p.max_ffm, p.max_lr, (optimizer == FWGPU_OPT_ADAGRAD_LUT && p.update && (!p.lut_global || p.lut_lds_forced)) ? 1 : 0,
                       p.records ? p.max_rec : 0, p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off,
-                      (p.records && p.prefetch) ? p.max_rec : 0, (p.records && p.tr_lds) ? tr_lds_words(p.tr) : 0, p.lds_keep_words);
+                      (p.records && p.prefetch) ? p.max_rec : 0, (p.records && p.tr_lds) ? tr_lds_words(p.tr) : 0, p.lds_keep_words, !p.t_global);
 }
 #endif
 
@@ -1380,7 +1383,7 @@ __device__ __forceinline__ void bind_lds(const KernelParams &p, unsigned char *s
     size_t off[25];
     lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut ? 1 : 0, p.records ? p.max_rec : 0,
                p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off, (p.records && p.prefetch) ? p.max_rec : 0,
-               (p.records && p.tr_lds) ? tr_lds_words(p.tr) : 0, p.lds_keep_words);
+               (p.records && p.tr_lds) ? tr_lds_words(p.tr) : 0, p.lds_keep_words, !p.t_global);
     s.T = reinterpret_cast<float *>(smem + off[0]);
     s.selfw = reinterpret_cast<float *>(smem + off[1]);
     s.lut = reinterpret_cast<float *>(smem + off[2]);
@@ -1511,6 +1514,9 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
         if (ex >= p.n_examples) break;
         FW_TICK(6);
         if (timing) tk[7] += 1;
+        // Phase kernels: T lives in the example's split record (FWD writes the field sums there as they are finished, UPD reads them from there):
+        // without the F * R floats of LDS two to four workgroups share a CU instead of one, i.e. as many examples of a micro-batch run concurrently
+        if (PH != 0 && p.t_global) s.T = p.split + (size_t)ex * p.split_len;
         const StageOut so = stage_example<kCtx>(p, s, geom, ex, tid, bd, TrGlobal{p.tr});
         uint32_t next_ticket = 0;  // (every thread is past its read of ctr[6]: the stage phase has barriers)
         if (tid == 0) next_ticket = atomicAdd(p.work, 1u);
@@ -1590,7 +1596,8 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
             // ---------------- FWD: this rank's share of the example goes to its split record
             float *rec = p.split + (size_t)ex * p.split_len;
             const bool home = ex >= p.home_lo && ex < p.home_hi;
-            for (uint32_t i = tid; i < F * R; i += bd) rec[i] = s.T[i];
+            if (!p.t_global)
+                for (uint32_t i = tid; i < F * R; i += bd) rec[i] = s.T[i];
             for (uint32_t f = tid; f < F; f += bd) {
                 rec[F * R + f] = s.dcf[f];
                 rec[F * R + F + p.split_nlr + f] = home ? (float)(s.fend[f] - s.fstart[f]) : 0.0f;
@@ -1651,7 +1658,8 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
         if (PH == 3) {
             // ---------------- UPD: the batch-start field sums and own slots come back from the records
             const float *rec = p.split + (size_t)ex * p.split_len;
-            for (uint32_t i = tid; i < F * R; i += bd) s.T[i] = rec[i];
+            if (!p.t_global)
+                for (uint32_t i = tid; i < F * R; i += bd) s.T[i] = rec[i];
             for (uint32_t i = tid; i < nf * k; i += bd) s.selfw[i] = p.split_selfw[(size_t)ex * p.selfw_stride + i];
             g_split = p.gbuf[ex];
             __syncthreads();
@@ -1937,6 +1945,18 @@ hipError_t launch_example_phase(const KernelParams &p_in, int optimizer, int pha
     p.lds_keep = p.lds_keep_words = 0;
     p.update = phase == 3 ? 1 : 0;
     p.chain = p.update && !p.no_chain;
+    {
+        // T in the split record, not in LDS (FWGPU_PHASE_T_LDS=1: the staged form, A/B runs).  The workgroup size the caller chose was sized for the
+        // FUSED kernel's LDS (1024 threads where that lets one workgroup per CU live): the phases get 512-thread workgroups then, two per CU (256- and
+        // 384-thread ones measured slower: profiles/r04_phase_t_in_record.txt).
+        static const bool staged = std::getenv("FWGPU_PHASE_T_LDS") != nullptr;
+        // ... where the staged form leaves room for ONE workgroup per CU only (k = 16 at 30 fields: T = 57.6 KB).  Where two or three fit anyway (config C),
+        // the record's latency in the update costs 3 % and nothing is gained.
+        p.t_global = 0;
+        const size_t lds_staged = example_kernel_lds_bytes(p, optimizer);
+        p.t_global = (!staged && p.k != 0 && p.split != nullptr && 2 * lds_staged > 160 * 1024) ? 1 : 0;
+        if (p.t_global && threads == 1024 && (uint64_t)p.max_ffm <= 4ull * 512 && grid != 1) threads = 512;
+    }
     size_t lds = example_kernel_lds_bytes(p, optimizer);
     static const bool canary = std::getenv("FWGPU_DBG_LDS_CANARY") != nullptr;
     static uint32_t *d_canary = nullptr;

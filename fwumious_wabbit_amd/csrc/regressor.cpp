@@ -885,12 +885,19 @@ static int one_prediction(fwgpu_regressor *r, float *prediction) {
 //         overlap across chunks included (a later chunk re-reads what an earlier one wrote), exactly the reference's update loop (block_ffm.rs:265-288).
 // Only the order of the field sums' additions differs from the reference (chunk subtotals): ~1e-7 relative.  Models with a deep head are not covered.
 constexpr uint32_t kMaxStagedEntries = 4096;  // what one workgroup of the fused kernel stages (prepare_launch)
-constexpr uint32_t kChunkEntries = 2048;
+constexpr uint32_t kChunkEntriesMax = 2048;
+// entries per chunk: what the pipeline's workgroups stage beside the field sums (k floats of own-field weights and ~9 words per entry), a power of two
+static uint32_t chunk_entries(const fwgpu_regressor *r) {
+    const size_t k = r->cfg.ffm_k, F = k ? r->cfg.ffm_num_fields : 0, fixed = 4 * F * F * k + 12288;
+    uint32_t n = kChunkEntriesMax;
+    while (n > 64 && fixed + (size_t)n * (4 * k + 36) > r->lds_per_cu) n >>= 1;
+    return n;
+}
 
 static int learn_one_chunked(fwgpu_regressor *r, const HostBatch &hb, uint32_t e, int update, float *prediction) {
     if (r->nn.n_layers) return fail(FWGPU_ERR_RANGE, "an example has more than 4096 FFM features or LR entries: not covered for models with a deep head");
     const uint32_t f0 = hb.ffm_off[e], f1 = hb.ffm_off[e + 1], l0 = hb.lr_off[e], l1 = hb.lr_off[e + 1];
-    const uint32_t nf = f1 - f0, nl = l1 - l0;
+    const uint32_t nf = f1 - f0, nl = l1 - l0, kChunkEntries = chunk_entries(r);
     const uint32_t m = std::max<uint32_t>(1, std::max((nf + kChunkEntries - 1) / kChunkEntries, (nl + kChunkEntries - 1) / kChunkEntries));
     HostBatch hc;
     hc.clear();

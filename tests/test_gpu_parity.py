@@ -473,6 +473,9 @@ def test_sync_micro_batch_matches_oracle_micro_batch_mode():
     _sync_parity(2, 10, 13, 13, fw.Optimizer.AdagradLUT, n=600, mb=100, seed=53, mean_extra=0.0, ids=300, p_weighted=0.0,
                  interactions=[(0, 1)], power_t=0.0, ffm_power_t=0.0)
     _sync_parity(6, 8, 12, 12, fw.Optimizer.AdagradFlex, n=512, mb=64, seed=54, init_acc=1.0, ffm_init_acc=1.0, weight_tol=5e-5)
+    # 30 fields x k = 16: the phase kernels keep T in the split record instead of LDS (launch_example_phase, KernelParams::t_global)
+    _sync_parity(30, 16, 20, 20, fw.Optimizer.AdagradLUT, n=128, mb=64, seed=55, mean_extra=5.67, ids=100000, p_weighted=0.1, lr=0.025, ffm_lr=0.025,
+                 power_t=0.38, ffm_power_t=0.38)
     _sync_parity(6, 4, 12, 12, fw.Optimizer.SGD, n=512, mb=64, seed=55, lr=0.05, ffm_lr=0.05)
     _sync_parity(8, 0, 14, 14, fw.Optimizer.AdagradLUT, n=600, mb=50, seed=56, interactions=[(0, 1)])
     _sync_parity(30, 16, 16, 18, fw.Optimizer.AdagradLUT, n=96, mb=32, seed=57, ids=20000, p_weighted=0.1)
@@ -976,14 +979,11 @@ def test_table_placement_search_is_transparent(monkeypatch):
     small.close()
 
 
-# ------------------------------------------------------------------ examples beyond what a workgroup stages (block_ffm.rs:294-312)
-@pytest.mark.parametrize("n_feat,opt", [(6000, fw.Optimizer.AdagradLUT), (20000, fw.Optimizer.AdagradFlex), (20000, fw.Optimizer.SGD)])
-def test_examples_beyond_4096_features_take_the_chunked_path(n_feat, opt):
+def _chunked_path_parity(n_feat, opt, F=8, k=4, bits=16, ffm_bits=16):
     """The reference takes an example of any size (its gradient cache moves to the heap beyond 170 393 floats, block_ffm.rs:294-312).  The fused
     kernel stages at most 4096 entries; larger examples go through the synchronous pipeline chunk by chunk (regressor.cpp learn_one_chunked).
     Against the oracle: predict, three learn calls on three different huge examples -- rows repeated across chunks, rows that overlap rows of
     other chunks, LR hashes repeated across chunks included -- then an ordinary small example, per-call predictions and the final tables."""
-    F, k, bits, ffm_bits = 8, 4, 16, 16
     mi, ocfg, _ = make_pair(F, k, bits, ffm_bits, opt, lr=0.01, ffm_lr=0.01)
     om = fwo.Model(ocfg)
     re = fw.Regressor(mi)
@@ -992,9 +992,9 @@ def test_examples_beyond_4096_features_take_the_chunked_path(n_feat, opt):
 
     def example(n):
         fld = np.sort(rng.integers(0, F, size=n))
-        h = (rng.integers(0, (1 << ffm_bits) // 4, size=n) * 4).astype(np.int64)
+        h = (rng.integers(0, (1 << ffm_bits) // k, size=n) * k).astype(np.int64)  # (k = 4 or 16: a power of two, the row grid)
         h[n // 2] = h[7]                    # the same row 3000+ entries apart (another chunk) ...
-        h[n - 5] = h[11] + 4                # ... and a row that overlaps a row of an early chunk
+        h[n - 5] = h[11] + k                # ... and a row that overlaps a row of an early chunk
         v = rng.uniform(0.002, 0.02, size=n)
         ffm = [(int(h[i]), float(v[i]), int(fld[i]) * k) for i in range(n)]
         lh = rng.integers(0, 1 << bits, size=n)
@@ -1028,6 +1028,19 @@ def test_examples_beyond_4096_features_take_the_chunked_path(n_feat, opt):
     assert np.abs(b.predictions() - np.array(want, dtype=np.float32)).max() < 2e-5
     b.close()
     re.close()
+
+
+# ------------------------------------------------------------------ examples beyond what a workgroup stages (block_ffm.rs:294-312)
+@pytest.mark.parametrize("n_feat,opt", [(6000, fw.Optimizer.AdagradLUT), (20000, fw.Optimizer.AdagradFlex), (20000, fw.Optimizer.SGD)])
+def test_examples_beyond_4096_features_take_the_chunked_path(n_feat, opt):
+    _chunked_path_parity(n_feat, opt)
+
+
+def test_chunked_path_where_the_phase_kernels_keep_t_in_the_split_record():
+    """30 fields x k = 16: the staged T (57.6 KB) would leave one workgroup per CU, so the phase kernels write / read the field sums in the example's split
+    record directly (kernels.hip launch_example_phase, KernelParams::t_global).  An oversize example's chunks hold different fields each: the update of
+    a chunk must see the WHOLE example's sums, the fields that are empty in the chunk included."""
+    _chunked_path_parity(6000, fw.Optimizer.AdagradLUT, F=30, k=16, bits=18, ffm_bits=22)
 
 
 def test_oversize_records_through_record_batches_and_the_trainer():
