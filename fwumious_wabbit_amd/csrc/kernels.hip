@@ -1734,7 +1734,13 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
             // deep head: unwind it first; afterwards every LR slot and every FFM pair has its own general gradient
             const float *gx = nullptr, *gpair = nullptr;
             if (head_split) {
-                gx = p.dxbuf + (size_t)ex * p.nn.X;
+                // the example's slot gradients (X floats, written by the head kernels) come into LDS once: every row chunk of the update looks its pair's
+                // gradient up there instead of in global memory
+                float *xl = nn_buf(p, s).xg;
+                const float *src = p.dxbuf + (size_t)ex * p.nn.X;
+                for (uint32_t i = tid; i < p.nn.X; i += bd) xl[i] = src[i];
+                __syncthreads();
+                gx = xl;
                 gpair = gx + p.num_combos;
             } else if (NN && p.nn.n_layers) {
                 nn_backward<OPT, COH>(p, s, g, tid, bd);
