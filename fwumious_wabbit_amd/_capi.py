@@ -189,6 +189,7 @@ def lib():
         "fwgpu_debug_set_kernel_version": [vp, i32],
         "fwgpu_debug_set_option": [vp, i32, i32],
         "fwgpu_debug_coherence_probe": [i32, i32, u32, P(u32), P(u32)],
+        "fwgpu_debug_head_gemm": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp],
         "fwgpu_synth_records": [P(SynthConfig), u64, u32, vp, u64, vp, P(u64)],
         "fwgpu_debug_format_f32": [f32, C.c_char_p, u32],
         "fwgpu_vwmap_from_csv": [C.c_char_p, u64, P(vp)],

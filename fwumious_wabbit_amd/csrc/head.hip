@@ -109,6 +109,7 @@ __global__ void __launch_bounds__(256) head_gemm(const float *__restrict__ A, co
 // in flight while the current eight are multiplied; the partial tiles meet in LDS and are summed in wave order (deterministic).
 //   k of MFMA t of group u: 8 u + 4 (lane >> 5) + t -- so that a lane's four k are CONTIGUOUS: one 16-byte load where k is the fast dimension.
 // Needs K % 8 == 0, lda / ldb % 4 == 0 and 16-byte aligned operands where k is their fast dimension (head_step checks; otherwise head_gemm above).
+static bool g_force_tiled = false;  // (fwgpu_debug_head_gemm: tests run both kernels on one shape)
 constexpr int kSplitK = 8;  // waves of a workgroup = shares of K
 template <bool TA, bool TB, int EPI>
 __global__ void __launch_bounds__(64 * kSplitK) head_gemm_splitk(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int M,
@@ -203,7 +204,8 @@ template <bool TA, bool TB, int EPI>
 static hipError_t gemm(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb, int ldc, const float *bias,
                        float *aux, int relu, hipStream_t s) {
     if (M <= 0 || N <= 0) return hipSuccess;
-    static const bool old_only = std::getenv("FWGPU_HEAD_GEMM_TILED") != nullptr;  // (A/B runs: the LDS-tiled 64 x 64 kernel for every shape)
+    static const bool env_tiled = std::getenv("FWGPU_HEAD_GEMM_TILED") != nullptr;  // (A/B runs: the LDS-tiled 64 x 64 kernel for every shape)
+    const bool old_only = env_tiled || g_force_tiled;
     const bool a_vec = TA || (lda % 4 == 0 && ((uintptr_t)A & 15u) == 0), b_vec = !TB || (ldb % 4 == 0 && ((uintptr_t)B & 15u) == 0);
     if (!old_only && K >= 8 * kSplitK && K % 8 == 0 && a_vec && b_vec) {
         dim3 grid((N + 31) / 32, (M + 31) / 32);
@@ -422,3 +424,21 @@ int head_step(fwgpu_regressor *r, fwgpu_split *sp, uint32_t first, uint32_t n, f
 }
 
 }  // namespace fwgpu
+
+extern "C" int fwgpu_debug_head_gemm(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb, int ldc, int ta, int tb, int epilogue,
+                                     const float *bias, float *aux, int relu, int tiled, void *stream) {
+    using namespace fwgpu;
+    hipStream_t st = (hipStream_t)stream;
+    g_force_tiled = tiled != 0;
+    hipError_t e = hipErrorInvalidValue;
+    const int combo = (ta ? 2 : 0) | (tb ? 1 : 0);
+#define FW_HG(TA, TB, EPI) e = gemm<TA, TB, EPI>(A, B, C, M, N, K, lda, ldb, ldc, bias, aux, relu, st)
+    if (combo == 1 && epilogue == 1) FW_HG(false, true, 1);
+    else if (combo == 2 && epilogue == 0) FW_HG(true, false, 0);
+    else if (combo == 0 && epilogue == 2) FW_HG(false, false, 2);
+    else if (combo == 0 && epilogue == 3) FW_HG(false, false, 3);
+#undef FW_HG
+    g_force_tiled = false;
+    if (e != hipSuccess) return fail(FWGPU_ERR_INVALID, "head_gemm: not one of the head's products ((ta, tb, epilogue) = (0,1,1), (1,0,0), (0,0,2), (0,0,3)) or a launch error");
+    return FWGPU_OK;
+}

@@ -446,6 +446,12 @@ int fwgpu_debug_set_option(fwgpu_regressor *r, int option, int value);
 /* an f32 as serde_json / ryu prints it in the embedded JSON documents ("0.1", "1.0", "1e-7"); NUL-terminated */
 int fwgpu_debug_format_f32(float v, char *buf, uint32_t cap);
 int fwgpu_debug_coherence_probe(int device, int use_sc1, uint32_t iters, uint32_t *stale_words, uint32_t *timeouts);
+/* One product of the mini-batched head (head.hip) on device pointers, for tests against a plain f32 reference:
+ * C[M, N] = op(A) . op(B) with A(m, k) = ta ? A[k * lda + m] : A[m * lda + k], B(k, n) = tb ? B[n * ldb + k] : B[k * ldb + n]; epilogue 0: C = acc,
+ * 1: C = relu(acc + bias[n]) with the 0 / 1 mask in aux, 2: C = acc * aux[m, n], 3: C += acc.  tiled != 0 forces the LDS-tiled 64 x 64 kernel;
+ * otherwise the split-K kernel runs where K % 8 == 0 and the operands allow 16-byte loads.  The three (ta, tb) pairs the head uses: (0, 1), (1, 0), (0, 0). */
+int fwgpu_debug_head_gemm(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb, int ldc, int ta, int tb, int epilogue,
+                          const float *bias, float *aux, int relu, int tiled, void *stream);
 
 /* ---------------------------------------------------------------- feed path: namespace map, VW text parser, input cache
  * (SURVEY.md 8 f1/f3).  Host-side code; none of it needs a device.

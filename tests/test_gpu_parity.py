@@ -802,6 +802,52 @@ def test_full_size_config_c_properties():
 
 
 # ------------------------------------------------------------------ multi-GPU bookkeeping kernels
+@pytest.mark.parametrize("tiled", [0, 1])
+def test_head_products_match_a_torch_f32_reference(tiled):
+    """The mini-batched head's products (head.hip) against plain torch f32 matmuls: the split-K MFMA kernel (one 32 x 32 tile per workgroup, eight waves
+    over K) and the LDS-tiled one, for the three operand layouts the head uses, with ragged M / N, every epilogue, and shapes the split-K kernel must
+    refuse (K % 8 != 0, odd leading dimensions: the tiled kernel takes them).  f32 products summed in another order: tolerance 2e-5 relative to |A||B| row sums."""
+    import torch
+
+    L = capi.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cpu").manual_seed(7)
+
+    def rnd(*shape):
+        return torch.randn(*shape, generator=g).cuda()
+
+    def check(got, want, A2, B2):
+        bound = 2e-5 * (A2.abs() @ B2.abs()) + 1e-6
+        assert bool(((got - want).abs() <= bound).all()), float((got - want).abs().max())
+
+    for M, N, K in ((1024, 256, 496), (100, 70, 64), (33, 31, 72), (64, 496, 256), (50, 40, 20), (37, 29, 13)):
+        # forward: h = relu(x . W^T + b), mask        A[M, K] row-major, B = W[N, K] row-major (tb), epilogue 1
+        x, W, b = rnd(M, K), rnd(N, K), rnd(N)
+        h, mask = torch.full((M, N), 7.0, device="cuda"), torch.full((M, N), 7.0, device="cuda")
+        capi.check(L.fwgpu_debug_head_gemm(x.data_ptr(), W.data_ptr(), h.data_ptr(), M, N, K, K, K, N, 0, 1, 1, b.data_ptr(), mask.data_ptr(), 1, tiled, st))
+        z = x @ W.t() + b
+        check(h, torch.relu(z), x, W.t())
+        sure = z.abs() > 1e-3  # (a pre-activation within rounding of 0 may fall on either side)
+        assert bool((mask[sure] == (z[sure] >= 0).float()).all())
+        # weight gradients: dW[N2, K2] = dz^T . in      A = dz[Kb, M2] (ta: the batch is the slow dimension of both operands), epilogue 0
+        Kb, M2, N2 = M, N, K
+        dz, inp = rnd(Kb, M2), rnd(Kb, N2)
+        dW = torch.full((M2, N2), 7.0, device="cuda")
+        # (the split-K kernel needs Kb % 8 == 0; other batch sizes run on the tiled kernel: same call)
+        capi.check(L.fwgpu_debug_head_gemm(dz.data_ptr(), inp.data_ptr(), dW.data_ptr(), M2, N2, Kb, M2, N2, N2, 1, 0, 0, None, None, 0, tiled, st))
+        check(dW, dz.t() @ inp, dz.t(), inp)
+        # input gradients: d_in = (dz . W) * mask (epilogue 2), and accumulated into an existing buffer (epilogue 3)
+        dzz, W2, m2 = rnd(M, N), rnd(N, K), (rnd(M, K) > 0).float()
+        din = torch.full((M, K), 7.0, device="cuda")
+        capi.check(L.fwgpu_debug_head_gemm(dzz.data_ptr(), W2.data_ptr(), din.data_ptr(), M, K, N, N, K, K, 0, 0, 2, None, m2.data_ptr(), 0, tiled, st))
+        check(din, (dzz @ W2) * m2, dzz, W2)
+        base = rnd(M, K)
+        acc = base.clone()
+        capi.check(L.fwgpu_debug_head_gemm(dzz.data_ptr(), W2.data_ptr(), acc.data_ptr(), M, K, N, N, K, K, 0, 0, 3, None, None, 0, tiled, st))
+        check(acc - base, dzz @ W2, dzz, W2)
+    torch.cuda.synchronize()
+
+
 def test_delta_kernels_match_torch_reference():
     import torch
 
