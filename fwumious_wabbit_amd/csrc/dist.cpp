@@ -101,7 +101,7 @@ RcclApi g_rccl;
 
 struct fwgpu_dist;
 // Failure model of the collective steps (one rank per process).
-//  * A failure BEFORE the step's first exchange (bad records, a batch of another regressor, out of memory while sizing the buffers) is
+//  * A failure BEFORE the step's first exchange (bad records, a batch of another regressor, an example the kernels cannot stage) is
 //    what a job actually meets: the failing rank still takes part in the first collective -- the all-gather of the batch shapes -- with
 //    a poisoned shape (kShapePoison in word 3), every rank sees it, and every rank returns from the step without having exchanged or applied
 //    anything: the failing rank with its own error, the others with FWGPU_ERR_PEER.  The job stays usable.
@@ -110,6 +110,8 @@ struct fwgpu_dist;
 //    for this rank.  They get out through wait_stream(): every wait behind a collective polls the stream and the communicator's
 //    asynchronous error state (ncclCommGetAsyncError, where the library has it) and, after FWGPU_DIST_TIMEOUT_MS (default 0 = wait for
 //    ever, as RCCL itself does), aborts the own communicator and returns FWGPU_ERR_PEER.  A job that wants to survive a dead rank sets it.
+//    That FWGPU_ERR_PEER is TERMINAL for the rank (no communicator left), unlike the pre-exchange one.  Out of memory while the step's buffers are
+//    sized (step_upload / sparse_local run AFTER the shape exchange) is a failure of this second kind: the rank aborts, its peers need the time-out.
 constexpr uint32_t kShapePoison = 0xffffffffu;
 static int abort_on_failure(fwgpu_dist *d, int rc);
 
@@ -182,9 +184,27 @@ struct fwgpu_dist {
     std::vector<void *> ipc_open;    // ... what to close again
     hipEvent_t dbg_ev[3] = {nullptr, nullptr, nullptr};  // debug (scripts/group_bisect.sh): recorded behind FWD / MID / the FFM reduction of sparse_local
     uint32_t last_rows[2] = {0, 0};  // bucket rows {ffm, lr} this rank sent in its last sparse step
+    // shapes / counts read back behind a collective land HERE (pinned, owned by the rank, alive until fwgpu_dist_free): a copy into pageable memory
+    // blocks the host until the stream drains -- with a dead peer it would never reach wait_stream()'s polling -- and a copy into a function-local
+    // buffer could land after the function has given up (wait_stream's time-out path)
+    uint32_t *h_pin = nullptr;
+    size_t h_pin_words = 0;
+    int pinned(size_t words, uint32_t **out) {
+        if (words > h_pin_words) {
+            if (h_pin) (void)hipHostFree(h_pin);
+            h_pin = nullptr;
+            h_pin_words = 0;
+            const size_t cap = std::max<size_t>(words, 1024);
+            if (hipHostMalloc((void **)&h_pin, cap * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return FWGPU_ERR_OOM;
+            h_pin_words = cap;
+        }
+        *out = h_pin;
+        return FWGPU_OK;
+    }
     ~fwgpu_dist() {
         sf.release();
         sl.release();
+        if (h_pin) (void)hipHostFree(h_pin);
         if (sp_tmp) (void)hipFree(sp_tmp);
         if (d_counts) (void)hipFree(d_counts);
         if (ob) fwgpu_batch_free(ob);
@@ -342,10 +362,10 @@ int phase_mid(fwgpu_dist *d) {
 }
 int phase_upd(fwgpu_dist *d) { return split_update(d->r, d->gb, d->sp, d->mode, d->rg, false, d->stream); }
 
+int wait_stream_fwd(fwgpu_dist *d);
 int finish(fwgpu_dist *d, float *preds) {
-    if (preds && d->B)
-        FWGPU_HIP(hipMemcpyAsync(preds, d->gb->pred + (size_t)d->B * d->rank, (size_t)d->B * 4, hipMemcpyDeviceToHost, d->stream));
-    FWGPU_HIP(hipStreamSynchronize(d->stream));
+    if (int rc = wait_stream_fwd(d)) return rc;  // polled where a time-out is set (RCCL ranks); the caller's pageable buffer is filled after the wait
+    if (preds && d->B) FWGPU_HIP(hipMemcpy(preds, d->gb->pred + (size_t)d->B * d->rank, (size_t)d->B * 4, hipMemcpyDeviceToHost));
     return FWGPU_OK;
 }
 
@@ -691,12 +711,22 @@ static int wait_stream(fwgpu_dist *d) {
         if (async_err || late) {
             if (g_rccl.CommAbort) (void)g_rccl.CommAbort(d->comm);
             d->comm = nullptr;
-            return fail(FWGPU_ERR_PEER, async_err ? "a collective reported an asynchronous RCCL error: communicator aborted"
-                                                  : "a collective did not complete within FWGPU_DIST_TIMEOUT_MS (a peer rank is gone?): communicator aborted");
+            // the aborted collective's kernel leaves the stream; what was queued behind it (read-backs into d->h_pin, owned by the rank) drains.
+            // Bounded: a stream that does not come back is left to fwgpu_dist_free.  TERMINAL for this rank: it has no communicator any more,
+            // every later collective call of it returns FWGPU_ERR_INVALID; only the pre-exchange failures (poisoned shape) let a job go on.
+            for (int i = 0; i < 40000 && hipStreamQuery(d->stream) == hipErrorNotReady; i++) std::this_thread::sleep_for(std::chrono::microseconds(50));
+            return fail(FWGPU_ERR_PEER, async_err ? "a collective reported an asynchronous RCCL error: communicator aborted, this rank cannot take part in further collective steps"
+                                                  : "a collective did not complete within FWGPU_DIST_TIMEOUT_MS (a peer rank is gone?): communicator aborted, this rank cannot take part in further collective steps");
         }
         std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
 }
+
+}  // extern "C"
+namespace {
+int wait_stream_fwd(fwgpu_dist *d) { return wait_stream(d); }
+}  // namespace
+extern "C" {
 
 // after the all-gather of the batch shapes: did any rank poison its shape (a failure before the exchange)?
 static int check_shapes(fwgpu_dist *d, const std::vector<uint32_t> &shapes, bool same_n) {
@@ -792,8 +822,11 @@ static int rccl_step(fwgpu_dist *d, const uint32_t *records, const uint64_t *rec
     FWGPU_HIP(hipMemcpyAsync(d->d_shape + 4 * d->rank, shape, 4 * sizeof(uint32_t), hipMemcpyHostToDevice, d->stream));
     FWGPU_NCCL(g_rccl.AllGather(d->d_shape + 4 * d->rank, d->d_shape, 4, ncclUint32, d->comm, d->stream));
     std::vector<uint32_t> shapes((size_t)d->n * 4);
-    FWGPU_HIP(hipMemcpyAsync(shapes.data(), d->d_shape, shapes.size() * 4, hipMemcpyDeviceToHost, d->stream));
+    uint32_t *pin_shapes = nullptr;
+    if ((rc = d->pinned(shapes.size(), &pin_shapes))) return fail(rc, "dist step: no pinned host memory for the read-back");
+    FWGPU_HIP(hipMemcpyAsync(pin_shapes, d->d_shape, shapes.size() * 4, hipMemcpyDeviceToHost, d->stream));
     if ((rc = wait_stream(d))) return rc;
+    std::memcpy(shapes.data(), pin_shapes, shapes.size() * 4);
     if ((rc = check_shapes(d, shapes, true))) return rc;
     rc = step_upload(d, records, rec_off, shapes.data());
     if (rc) return rc;
@@ -1013,8 +1046,11 @@ static int rccl_sparse_step(fwgpu_dist *d, uint32_t shape[4], float *preds) {
     FWGPU_HIP(hipMemcpyAsync(d->d_shape + 4 * d->rank, shape, 4 * sizeof(uint32_t), hipMemcpyHostToDevice, d->stream));
     if (N > 1) FWGPU_NCCL(g_rccl.AllGather(d->d_shape + 4 * d->rank, d->d_shape, 4, ncclUint32, d->comm, d->stream));
     std::vector<uint32_t> shapes((size_t)N * 4);
-    FWGPU_HIP(hipMemcpyAsync(shapes.data(), d->d_shape, shapes.size() * 4, hipMemcpyDeviceToHost, d->stream));
+    uint32_t *pin_shapes = nullptr;
+    if ((rc = d->pinned(shapes.size(), &pin_shapes))) return fail(rc, "dist step: no pinned host memory for the read-back");
+    FWGPU_HIP(hipMemcpyAsync(pin_shapes, d->d_shape, shapes.size() * 4, hipMemcpyDeviceToHost, d->stream));
     if ((rc = wait_stream(d))) return rc;
+    std::memcpy(shapes.data(), pin_shapes, shapes.size() * 4);
     if ((rc = check_shapes(d, shapes, false))) return rc;
     rc = sparse_local(d, shapes.data());
     if (rc) return rc;
@@ -1025,8 +1061,11 @@ static int rccl_sparse_step(fwgpu_dist *d, uint32_t shape[4], float *preds) {
     else
         FWGPU_HIP(hipMemcpyAsync(all_counts, d->d_counts, 8, hipMemcpyDeviceToDevice, d->stream));
     std::vector<uint32_t> counts((size_t)2 * N);
-    FWGPU_HIP(hipMemcpyAsync(counts.data(), all_counts, counts.size() * 4, hipMemcpyDeviceToHost, d->stream));
+    uint32_t *pin_counts = nullptr;
+    if ((rc = d->pinned(counts.size(), &pin_counts))) return fail(rc, "dist step: no pinned host memory for the read-back");
+    FWGPU_HIP(hipMemcpyAsync(pin_counts, all_counts, counts.size() * 4, hipMemcpyDeviceToHost, d->stream));
     if ((rc = wait_stream(d))) return rc;
+    std::memcpy(counts.data(), pin_counts, counts.size() * 4);
     d->last_rows[0] = counts[2 * d->rank];
     d->last_rows[1] = counts[2 * d->rank + 1];
     for (int side = 0; side < 2; side++) {
@@ -1057,8 +1096,9 @@ static int rccl_sparse_step(fwgpu_dist *d, uint32_t shape[4], float *preds) {
         rc = sparse_apply_side(d, s, side == 0, keys, rows, s.flags, (uint32_t)N, stride);
         if (rc) return rc;
     }
-    if (preds && d->B) FWGPU_HIP(hipMemcpyAsync(preds, d->cur->pred, (size_t)d->B * 4, hipMemcpyDeviceToHost, d->stream));
-    return wait_stream(d);
+    if ((rc = wait_stream(d))) return rc;  // (polled; the caller's buffer is pageable: its copy comes after, not in front of the wait)
+    if (preds && d->B) FWGPU_HIP(hipMemcpy(preds, d->cur->pred, (size_t)d->B * 4, hipMemcpyDeviceToHost));
+    return FWGPU_OK;
 }
 
 int fwgpu_dist_learn_sparse(fwgpu_dist *d, const fwgpu_translator_config *t, const uint32_t *records, const uint64_t *rec_off,
@@ -1524,8 +1564,10 @@ int fwgpu_dist_group_learn_owner(fwgpu_dist_group *g, const fwgpu_translator_con
     uint32_t need_ffm = 64, need_lr = 64;
     for (uint32_t j = 0; j < N; j++) {
         if ((rc = sparse_begin(g->ranks[j].get(), t, records[j], rec_off[j], n[j], nullptr, &shapes[4 * j]))) return rc;  // (uploads the rank's records)
-        need_lr = std::max(need_lr, shapes[4 * j + 0] * shapes[4 * j + 3]);
-        need_ffm = std::max(need_ffm, shapes[4 * j + 1] * shapes[4 * j + 3]);
+        const uint64_t nl = (uint64_t)shapes[4 * j + 0] * shapes[4 * j + 3], nf = (uint64_t)shapes[4 * j + 1] * shapes[4 * j + 3];
+        if (nl > 0x7fffffffull || nf > 0x7fffffffull) return fail(FWGPU_ERR_RANGE, "owner-side apply: the step's gradient rows do not fit 31-bit ring positions; use smaller steps");
+        need_lr = std::max(need_lr, (uint32_t)nl);
+        need_ffm = std::max(need_ffm, (uint32_t)nf);
     }
     for (uint32_t j = 0; j < N; j++)
         if ((rc = rings_reserve(g->ranks[j].get(), N, need_ffm, need_lr))) return rc;
@@ -1667,8 +1709,11 @@ int fwgpu_dist_learn_owner(fwgpu_dist *d, const fwgpu_translator_config *t, cons
         FWGPU_HIP(hipMemcpyAsync(all, d->d_push_cnt, W * 4, hipMemcpyDeviceToDevice, d->stream));
     }
     std::vector<uint32_t> counts((size_t)N * W);
-    FWGPU_HIP(hipMemcpyAsync(counts.data(), all, counts.size() * 4, hipMemcpyDeviceToHost, d->stream));
+    uint32_t *pin_counts = nullptr;
+    if ((rc = d->pinned(counts.size(), &pin_counts))) return fail(rc, "dist step: no pinned host memory for the read-back");
+    FWGPU_HIP(hipMemcpyAsync(pin_counts, all, counts.size() * 4, hipMemcpyDeviceToHost, d->stream));
     if ((rc = wait_stream(d))) return rc;
+    std::memcpy(counts.data(), pin_counts, counts.size() * 4);
     for (uint32_t j = 0; j < N; j++)
         if (counts[(size_t)j * W] == kShapePoison) {
             d->ring_parity ^= 1;  // (every rank flips: the ranks stay in step)
@@ -1685,8 +1730,17 @@ int fwgpu_dist_learn_owner(fwgpu_dist *d, const fwgpu_translator_config *t, cons
                                      counts[(size_t)s * W + d->rank], ring_lr(d->own_rings, geom, d->ring_parity, s), counts[(size_t)s * W + N + d->rank],
                                      d->mode == FWGPU_MODE_SEQUENTIAL, d->stream));
     d->ring_parity ^= 1;
-    if (preds && d->B) FWGPU_HIP(hipMemcpyAsync(preds, d->cur->pred, (size_t)d->B * 4, hipMemcpyDeviceToHost, d->stream));
-    return wait_stream(d);
+    if (d->mode == FWGPU_MODE_SEQUENTIAL && N > 1) {
+        // the in-order form is the sequential reference: step t + 1's fetches (any rank's) must see step t's applies (every owner's).  A rank waits
+        // only for its OWN apply below; what orders the other owners' applies in front of its next push kernel is this one-word all-reduce queued
+        // behind the apply on every rank (the concurrent form tolerates the one-step staleness and does not pay for it)
+        FWGPU_HIP(hipMemsetAsync(d->d_shape, 0, 4, d->stream));
+        rc = g_rccl.AllReduce(d->d_shape, d->d_shape, 1, ncclFloat, ncclSum, d->comm, d->stream) == ncclSuccess ? FWGPU_OK : fail(FWGPU_ERR_DEVICE, "owner-side apply: closing all-reduce failed");
+        if (rc) return abort_on_failure(d, rc);
+    }
+    if ((rc = wait_stream(d))) return rc;  // (polled; the caller's buffer is pageable: its copy comes after, not in front of the wait)
+    if (preds && d->B) FWGPU_HIP(hipMemcpy(preds, d->cur->pred, (size_t)d->B * 4, hipMemcpyDeviceToHost));
+    return FWGPU_OK;
 }
 
 int fwgpu_dist_group_gather_tables(fwgpu_dist_group *g) {

@@ -54,6 +54,7 @@ struct DevNN {
     uint32_t X;          // length of x = LR slots + triangle
     uint32_t sum_width;  // sum of the hidden widths
     uint32_t max_in;     // largest layer input (LDS scratch)
+    uint32_t max_out;    // widest layer (LDS scratch: the active-neuron list of the dense backward)
     float rate, minus_power_t;
     float *w, *acc;      // all layers back to back: per layer W[j*in+i] then the biases (block_neural.rs:86-88)
     const float *lut;

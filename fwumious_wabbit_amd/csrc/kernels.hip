@@ -185,7 +185,7 @@ __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t
 // input gradient, and one product per LR entry
 __host__ __device__ inline uint32_t nn_lds_floats(const KernelParams &p) {
     if (!p.nn.n_layers) return 0;
-    return 2 * p.nn.X + 2 * p.nn.sum_width + p.nn.max_in + p.max_lr + 16;
+    return 2 * p.nn.X + 2 * p.nn.sum_width + p.nn.max_in + p.max_lr + p.nn.max_out + 1 + 16;
 }
 
 // size of the open-addressing sets: power of two >= 2*n (load factor <= 0.5)
@@ -782,6 +782,7 @@ struct NnBuf {
     float *m;    // [sum_width] ReLU 0/1 masks, then the layers' output gradients
     float *fg;   // [max_in] final neuron's input gradient / per-layer scratch
     float *prod; // [max_lr] w*v of every LR entry
+    uint32_t *act;  // [max_out + 1] indices of a layer's neurons with a nonzero output gradient, then their count (nn_layer_backward_vec)
 };
 __device__ __forceinline__ NnBuf nn_buf(const KernelParams &p, const Lds &s) {
     NnBuf b;
@@ -791,6 +792,7 @@ __device__ __forceinline__ NnBuf nn_buf(const KernelParams &p, const Lds &s) {
     b.m = b.h + p.nn.sum_width;
     b.fg = b.m + p.nn.sum_width;
     b.prod = b.fg + p.nn.max_in;
+    b.act = reinterpret_cast<uint32_t *>(b.prod + p.max_lr);
     return b;
 }
 template <bool COH>
@@ -876,16 +878,20 @@ __device__ __forceinline__ float nn_forward(const KernelParams &p, const Lds &s,
         const float *W = n.w + n.off[l];
         // a wave computes JU neurons per pass so that JU * ceil(in / 64) weight loads are in flight per lane
 #ifndef FW_NN_FJU
-#define FW_NN_FJU 4
+#define FW_NN_FJU 8
 #endif
         constexpr int JU = FW_NN_FJU;
         // hogwild launches: the same dot products from 16-byte device-scope loads (4-byte ones run at a third of the rate);
         // the order of the sum differs, which only the in-order mode promises
         const bool vec16 = COH && gridDim.x > 1 && (in & 3u) == 0 && (n.off[l] & 3u) == 0 && ((uintptr_t)in_vec & 15u) == 0;
         for (uint32_t j0 = wave * JU; j0 < out; j0 += nw * JU) {
-            float dot[JU];
+            float dot[JU], bias[JU];
 #pragma unroll
-            for (int u = 0; u < JU; ++u) dot[u] = 0.0f;
+            for (int u = 0; u < JU; ++u) {
+                dot[u] = 0.0f;
+                // (issued in front of the weights: loaded behind the reduction, the bias was a second round trip per pass)
+                bias[u] = j0 + u < out ? nn_ld<COH>(W + (size_t)in * out + j0 + u) : 0.0f;
+            }
             if (vec16) {
                 const __amdgpu_buffer_rsrc_t rw = make_rsrc(W, in * out * 4);
                 for (uint32_t q = lane; q < (in >> 2); q += 64) {
@@ -911,7 +917,7 @@ __device__ __forceinline__ float nn_forward(const KernelParams &p, const Lds &s,
                 const uint32_t j = j0 + u;
                 const float d = wave_sum(dot[u]);
                 if (j < out) {
-                    const float pre = nn_ld<COH>(W + (size_t)in * out + j) + d;
+                    const float pre = bias[u] + d;
                     if (n.relu[l]) {
                         b.h[hoff + j] = pre < 0.0f ? 0.0f : pre;
                         b.m[hoff + j] = pre < 0.0f ? 0.0f : 1.0f;
@@ -1011,15 +1017,39 @@ __device__ __forceinline__ void nn_layer_backward(const DevNN &n, uint32_t l, co
 template <int OPT>
 __device__ __forceinline__ void nn_layer_backward_vec(const DevNN &n, uint32_t l, const float *og, const float *in_a,
                                                       uint32_t split, const float *in_b, float *grad_a, float *grad_b,
-                                                      int tid, int bd) {
+                                                      uint32_t *act, int tid, int bd) {
     const uint32_t in = n.in[l], out = n.out[l], nq = in >> 2;
     float *W = n.w + n.off[l], *A = n.acc + n.off[l];
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(W, in * out * 4), ra = make_rsrc(A, in * out * 4);
+    // The neurons that take a step: those with a nonzero output gradient (block_neural.rs:275-277) -- behind a ReLU about half of a layer.  Their indices
+    // are compacted into LDS first, so that the groups below share the ACTIVE neurons evenly and a pass never holds slots of dead ones (round 4 walked
+    // all `out` neurons in passes of FW_NN_VJU and skipped the dead ones inside a pass: every pass still paid its memory round trip).
+    if (tid < 64) {
+        uint32_t cnt = 0;
+        for (uint32_t base = 0; base < out; base += 64) {
+            const uint32_t j = base + (uint32_t)tid;
+            const bool on = j < out && og[j] != 0.0f;
+            const unsigned long long m = __ballot(on);
+            if (on) act[cnt + (uint32_t)__popcll(m & ((1ull << tid) - 1ull))] = j;
+            cnt += (uint32_t)__popcll(m);
+        }
+        if (tid == 0) act[out] = cnt;
+    }
+    // bias terms (block_neural.rs:296-306): their loads are issued here, in front of the weight passes, and stepped behind them
+    const bool has_bias = (uint32_t)tid < out && og[(uint32_t)tid < out ? tid : 0] != 0.0f;
+    float bw = 0.0f, bacc = 0.0f;
+    if (has_bias) {
+        const size_t ix = (size_t)in * out + tid;
+        bw = nn_ld<true>(W + ix);
+        if (OPT != FWGPU_OPT_SGD) bacc = nn_ld<true>(A + ix);
+    }
+    __syncthreads();
+    const uint32_t n_act = act[out];
     uint32_t G = (uint32_t)bd / nq;
-    G = G > out ? out : G;
+    G = G > n_act ? (n_act ? n_act : 1u) : G;
     const uint32_t q = (uint32_t)tid % nq, grp = (uint32_t)tid / nq;
     const bool active = grp < G;
-    const uint32_t jn = (out + G - 1) / G, jlo = grp * jn, jhi = jlo + jn < out ? jlo + jn : out;
+    const uint32_t jn = (n_act + G - 1) / G, jlo = grp * jn, jhi = jlo + jn < n_act ? jlo + jn : n_act;
     f4 xi = Vec<4>::zero(), oe = Vec<4>::zero();
     if (active) {
 #pragma unroll
@@ -1029,25 +1059,26 @@ __device__ __forceinline__ void nn_layer_backward_vec(const DevNN &n, uint32_t l
         }
         constexpr int JU = FW_NN_VJU;  // neurons in flight per thread: 2 x JU x 16 bytes (8 in flight, and loading the next batch
                                        // while this one is stepped, both measured slower: registers)
-        for (uint32_t j0 = jlo; j0 < jhi; j0 += JU) {
+        for (uint32_t a0 = jlo; a0 < jhi; a0 += JU) {
             f4 w[JU], a[JU];
             float gg[JU];
+            uint32_t bo[JU];
 #pragma unroll
             for (int u = 0; u < JU; ++u) {
-                const uint32_t j = j0 + u;
-                gg[u] = j < jhi ? og[j] : 0.0f;
+                const bool on = a0 + u < jhi;
+                const uint32_t j = on ? act[a0 + u] : 0u;
+                gg[u] = on ? og[j] : 0.0f;
+                bo[u] = (j * in + 4 * q) * 4;
                 w[u] = Vec<4>::zero();
                 a[u] = Vec<4>::zero();
-                if (gg[u] != 0.0f) {  // block_neural.rs:275-277
-                    const uint32_t bo = (j * in + 4 * q) * 4;
-                    w[u] = Vec<4>::load<kAuxSc1>(rw, bo);
-                    if (OPT != FWGPU_OPT_SGD) a[u] = Vec<4>::load<kAuxSc1>(ra, bo);
+                if (on) {
+                    w[u] = Vec<4>::load<kAuxSc1>(rw, bo[u]);
+                    if (OPT != FWGPU_OPT_SGD) a[u] = Vec<4>::load<kAuxSc1>(ra, bo[u]);
                 }
             }
 #pragma unroll
             for (int u = 0; u < JU; ++u) {
-                if (gg[u] == 0.0f) continue;
-                const uint32_t bo = ((j0 + u) * in + 4 * q) * 4;
+                if (a0 + u >= jhi) continue;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float acc = a[u][c];
@@ -1056,13 +1087,13 @@ __device__ __forceinline__ void nn_layer_backward_vec(const DevNN &n, uint32_t l
                     w[u][c] = w[u][c] - upd;
                     a[u][c] = acc;
                 }
-                Vec<4>::store<kAuxSc1>(w[u], rw, bo);
-                if (OPT != FWGPU_OPT_SGD) Vec<4>::store<kAuxSc1>(a[u], ra, bo);
+                Vec<4>::store<kAuxSc1>(w[u], rw, bo[u]);
+                if (OPT != FWGPU_OPT_SGD) Vec<4>::store<kAuxSc1>(a[u], ra, bo[u]);
             }
         }
     }
     __syncthreads();  // every thread has read its inputs: the gradients may overwrite them (in_vals and in_grad alias)
-    if (active && grp == 0) {
+    if (grp == 0) {   // (nq <= workgroup size: group 0 always exists; with no active neuron its sums are the zeros the caller needs)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const uint32_t i = 4 * q + c;
@@ -1078,16 +1109,12 @@ __device__ __forceinline__ void nn_layer_backward_vec(const DevNN &n, uint32_t l
             atomicAdd(i < split ? &grad_a[i] : &grad_b[i - split], oe[c]);
         }
     }
-    for (uint32_t j = tid; j < out; j += bd) {  // bias terms (block_neural.rs:296-306)
-        const float gg = og[j];
-        if (gg != 0.0f) {
-            const size_t ix = (size_t)in * out + j;
-            const float w = nn_ld<true>(W + ix);
-            float acc = OPT == FWGPU_OPT_SGD ? 0.0f : nn_ld<true>(A + ix);
-            const float upd = opt_step<OPT>(gg, acc, n.rate, n.minus_power_t, n.lut);
-            nn_st<true>(W + ix, w - upd);
-            if (OPT != FWGPU_OPT_SGD) nn_st<true>(A + ix, acc);
-        }
+    if (has_bias) {
+        const size_t ix = (size_t)in * out + tid;
+        const float gg = og[tid];
+        const float upd = opt_step<OPT>(gg, bacc, n.rate, n.minus_power_t, n.lut);
+        nn_st<true>(W + ix, bw - upd);
+        if (OPT != FWGPU_OPT_SGD) nn_st<true>(A + ix, bacc);
     }
 }
 
@@ -1095,10 +1122,10 @@ __device__ __forceinline__ void nn_layer_backward_vec(const DevNN &n, uint32_t l
 template <int OPT, bool COH>
 __device__ __forceinline__ void nn_layer_backward_any(const DevNN &n, uint32_t l, const float *og, const float *in_a,
                                                       uint32_t split, const float *in_b, float *grad_a, float *grad_b,
-                                                      int tid, int bd) {
+                                                      uint32_t *act, int tid, int bd) {
     const uint32_t in = n.in[l];
-    if (COH && gridDim.x > 1 && in >= 4 && (in & 3u) == 0 && (n.off[l] & 3u) == 0 && (in >> 2) <= (uint32_t)bd)
-        nn_layer_backward_vec<OPT>(n, l, og, in_a, split, in_b, grad_a, grad_b, tid, bd);
+    if (COH && gridDim.x > 1 && in >= 4 && (in & 3u) == 0 && (n.off[l] & 3u) == 0 && (in >> 2) <= (uint32_t)bd && n.out[l] <= (uint32_t)bd && bd >= 64)
+        nn_layer_backward_vec<OPT>(n, l, og, in_a, split, in_b, grad_a, grad_b, act, tid, bd);
     else
         nn_layer_backward<OPT, COH>(n, l, og, in_a, split, in_b, grad_a, grad_b, tid, bd);
 }
@@ -1114,7 +1141,7 @@ __device__ __forceinline__ void nn_backward(const KernelParams &p, const Lds &s,
     if (tid == 0) b.fg[0] = g;  // og of the single final neuron
     __syncthreads();
     // final neuron: inputs [h_last | x], input gradients -> [h_last (in place) | xg]
-    nn_layer_backward_any<OPT, COH>(n, L, b.fg, b.h + hoff_last, wl, b.x, b.h + hoff_last, b.xg, tid, bd);
+    nn_layer_backward_any<OPT, COH>(n, L, b.fg, b.h + hoff_last, wl, b.x, b.h + hoff_last, b.xg, b.act, tid, bd);
     if (n.topology != 1)
         for (uint32_t i = tid; i < X; i += bd) b.xg[i] = 0.0f;
     __syncthreads();
@@ -1127,11 +1154,11 @@ __device__ __forceinline__ void nn_backward(const KernelParams &p, const Lds &s,
         if (l > 0) {
             const uint32_t pin = n.out[l - 1];
             nn_layer_backward_any<OPT, COH>(n, l, b.m + hoff, b.h + hoff - pin, pin, b.h + hoff - pin, b.h + hoff - pin,
-                                            b.h + hoff - pin, tid, bd);
+                                            b.h + hoff - pin, b.act, tid, bd);
             hoff -= pin;
         } else {
             // first layer: inputs x; its input gradient is ADDED to the copy branch (BlockCopy, block_misc.rs:456-475)
-            nn_layer_backward_any<OPT, COH>(n, 0, b.m + hoff, b.x, X, b.x, b.fg, b.fg, tid, bd);
+            nn_layer_backward_any<OPT, COH>(n, 0, b.m + hoff, b.x, X, b.x, b.fg, b.fg, b.act, tid, bd);
             __syncthreads();
             for (uint32_t i = tid; i < X; i += bd) b.xg[i] = b.fg[i] + b.xg[i];
         }
@@ -1193,77 +1220,92 @@ __device__ __forceinline__ void lr_update(const KernelParams &p, const Lds &s, u
 
 // Update of one FFM feature row by one wave (block_ffm.rs:269-286), U rows at a time for memory-level
 // parallelism.  idx[u] == 0xffffffff marks an unused slot.
-template <int VEC, int OPT, int AUX, int U, bool SH = false>
+// Chunks of a row (64 lanes x VEC floats each) whose loads are issued together: rows of up to FW_UPD_CG chunks -- 512 floats at 16 bytes per lane, i.e. config
+// E's 480 -- take ONE memory round trip per batch of U rows instead of one per chunk (round 5: the generic kernel walked the chunks one after the other,
+// 12.5 round trips per wave and example at config E where 6.25 do).
+#ifndef FW_UPD_CG
+#define FW_UPD_CG 2
+#endif
+template <int VEC, int OPT, int AUX, int U, bool SH = false, int CG = FW_UPD_CG>
 __device__ __forceinline__ void update_rows(const KernelParams &p, const Lds &s, const uint32_t (&idx)[U], float g,
                                             int lane, const float *gpair = nullptr, uint32_t nf = 0) {
     typedef typename Vec<VEC>::type V;
     const uint32_t R = p.R, k = p.k;
     const uint32_t nchunk = (R + 64 * VEC - 1) / (64 * VEC);
-    for (uint32_t c = 0; c < nchunk; ++c) {
-        const uint32_t e0 = (c * 64 + lane) * VEC;
-        const bool inb = e0 < R;
-        const uint32_t z = inb ? e0 / k : 0;
-        V wv[U], av[U];
+    for (uint32_t c0 = 0; c0 < nchunk; c0 += CG) {
+        V wv[U][CG], av[U][CG];
         __amdgpu_buffer_rsrc_t rw[U], ra[U];
         uint32_t fld[U], hsh[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            wv[u] = Vec<VEC>::zero();
-            av[u] = Vec<VEC>::zero();
             fld[u] = hsh[u] = 0;
-            if (idx[u] != 0xffffffffu) {
+            const bool on = idx[u] != 0xffffffffu;
+            if (on) {
                 const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[idx[u]]);
                 hsh[u] = h;
                 fld[u] = __builtin_amdgcn_readfirstlane(s.e_fld[idx[u]]);
                 rw[u] = make_rsrc(ffm_w_base<SH>(p, h) + h, R * 4);
-                wv[u] = Vec<VEC>::template load<AUX>(rw[u], e0 * 4);
-                if (OPT != FWGPU_OPT_SGD) {
-                    ra[u] = make_rsrc(ffm_acc_base<SH>(p, h) + h, R * 4);
-                    av[u] = Vec<VEC>::template load<AUX>(ra[u], e0 * 4);
+                if (OPT != FWGPU_OPT_SGD) ra[u] = make_rsrc(ffm_acc_base<SH>(p, h) + h, R * 4);
+            }
+#pragma unroll
+            for (int cc = 0; cc < CG; ++cc) {
+                wv[u][cc] = Vec<VEC>::zero();
+                av[u][cc] = Vec<VEC>::zero();
+                if (on && c0 + cc < nchunk) {  // (lanes beyond the row read 0: the descriptor ends at the row's end)
+                    const uint32_t e0 = ((c0 + cc) * 64 + lane) * VEC;
+                    wv[u][cc] = Vec<VEC>::template load<AUX>(rw[u], e0 * 4);
+                    if (OPT != FWGPU_OPT_SGD) av[u][cc] = Vec<VEC>::template load<AUX>(ra[u], e0 * 4);
                 }
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (idx[u] == 0xffffffffu) continue;
-            // one occurrence of the row (entry i of field f): gradient from the pre-update weights (T, selfw), optimizer step on
-            // the running register copy
-            auto apply = [&](uint32_t i, uint32_t f) {
-                const float v = s.e_val[i];
-                V tv = Vec<VEC>::zero(), sw = Vec<VEC>::zero();
-                const bool self = inb && (z == f);
-                if (inb) tv = Vec<VEC>::lds_load(s.T + f * R + e0);
-                if (self) sw = Vec<VEC>::lds_load(s.selfw + i * k + (e0 - z * k));
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) {
-                    float t = Vec<VEC>::get(tv, j);
-                    if (self) t = __fsub_rn(t, __fmul_rn(Vec<VEC>::get(sw, j), v));  // contra - w*v  block_ffm.rs:238
-                    const float G = __fmul_rn(v, t);             // gradient cache      block_ffm.rs:239, 249
-                    // general gradient of output (f, z): uniform g, or -- deep head -- the mirrored triangle gradient
-                    // (block_misc.rs:822-832)
-                    const float gz = gpair ? gpair[tri_index(f, VEC == 1 ? (inb ? e0 / k : 0) : z)] : g;
-                    const float grad = __fmul_rn(gz, G);          // block_ffm.rs:278
-                    float acc = Vec<VEC>::get(av[u], j);
-                    const float upd = opt_step<OPT>(grad, acc, p.ffm_rate, p.ffm_minus_power_t, s.lut);
-                    Vec<VEC>::set(av[u], j, acc);
-                    Vec<VEC>::set(wv[u], j, Vec<VEC>::get(wv[u], j) - upd);  // block_ffm.rs:282
-                }
-            };
-            apply(idx[u], fld[u] & kFldMask);
-            if (fld[u] & kRowHasChain) {  // later entries of the same hash, in buffer order (see update_rows_win)
-                for (uint32_t base = idx[u] + 1; base < nf; base += 64) {
-                    const uint32_t j = base + lane;
-                    unsigned long long m = __ballot(j < nf && s.e_hash[j] == hsh[u] && (s.e_fld[j] & kRowChained));
-                    while (m) {
-                        const uint32_t b = (uint32_t)__builtin_ctzll(m);
-                        m &= m - 1;
-                        const uint32_t jj = base + b;
-                        apply(jj, __builtin_amdgcn_readfirstlane(s.e_fld[jj]) & kFldMask);
+            for (int cc = 0; cc < CG; ++cc) {
+                if (c0 + cc >= nchunk) continue;
+                const uint32_t e0 = ((c0 + cc) * 64 + lane) * VEC;
+                const bool inb = e0 < R;
+                const uint32_t z = inb ? e0 / k : 0;
+                // one occurrence of the row (entry i of field f): gradient from the pre-update weights (T, selfw), optimizer step on
+                // the running register copy
+                auto apply = [&](uint32_t i, uint32_t f) {
+                    const float v = s.e_val[i];
+                    V tv = Vec<VEC>::zero(), sw = Vec<VEC>::zero();
+                    const bool self = inb && (z == f);
+                    if (inb) tv = Vec<VEC>::lds_load(s.T + f * R + e0);
+                    if (self) sw = Vec<VEC>::lds_load(s.selfw + i * k + (e0 - z * k));
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        float t = Vec<VEC>::get(tv, j);
+                        if (self) t = __fsub_rn(t, __fmul_rn(Vec<VEC>::get(sw, j), v));  // contra - w*v  block_ffm.rs:238
+                        const float G = __fmul_rn(v, t);             // gradient cache      block_ffm.rs:239, 249
+                        // general gradient of output (f, z): uniform g, or -- deep head -- the mirrored triangle gradient
+                        // (block_misc.rs:822-832)
+                        const float gz = gpair ? gpair[tri_index(f, VEC == 1 ? (inb ? e0 / k : 0) : z)] : g;
+                        const float grad = __fmul_rn(gz, G);          // block_ffm.rs:278
+                        float acc = Vec<VEC>::get(av[u][cc], j);
+                        const float upd = opt_step<OPT>(grad, acc, p.ffm_rate, p.ffm_minus_power_t, s.lut);
+                        Vec<VEC>::set(av[u][cc], j, acc);
+                        Vec<VEC>::set(wv[u][cc], j, Vec<VEC>::get(wv[u][cc], j) - upd);  // block_ffm.rs:282
+                    }
+                };
+                apply(idx[u], fld[u] & kFldMask);
+                if (fld[u] & kRowHasChain) {  // later entries of the same hash, in buffer order (see update_rows_win)
+                    for (uint32_t base = idx[u] + 1; base < nf; base += 64) {
+                        const uint32_t j = base + lane;
+                        unsigned long long m = __ballot(j < nf && s.e_hash[j] == hsh[u] && (s.e_fld[j] & kRowChained));
+                        while (m) {
+                            const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                            m &= m - 1;
+                            const uint32_t jj = base + b;
+                            apply(jj, __builtin_amdgcn_readfirstlane(s.e_fld[jj]) & kFldMask);
+                        }
                     }
                 }
+                Vec<VEC>::template store<AUX>(wv[u][cc], rw[u], e0 * 4);
+                if (OPT != FWGPU_OPT_SGD) Vec<VEC>::template store<AUX>(av[u][cc], ra[u], e0 * 4);
             }
-            Vec<VEC>::template store<AUX>(wv[u], rw[u], e0 * 4);
-            if (OPT != FWGPU_OPT_SGD) Vec<VEC>::template store<AUX>(av[u], ra[u], e0 * 4);
         }
     }
 }
@@ -2696,7 +2738,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                 if (WIN)
                     update_rows_win<OPT, AUX, UO, (NC > FW_WIN_NCH ? NC : FW_WIN_NCH), AUX_SW, AUX_SA>(p, s, idx, g, lane, nf);
                 else
-                    update_rows<VEC, OPT, AUX, UO>(p, s, idx, g, lane);
+                    update_rows<VEC, OPT, AUX, UO, false, NC>(p, s, idx, g, lane);
             }
             // phase B: rows overlapping an earlier row of this example, strictly in buffer order on one wave
             if (s.ctr[1]) {
@@ -2709,7 +2751,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                             if (WIN)
                                 update_rows_win<OPT, AUX, 1, (NC > FW_WIN_NCH ? NC : FW_WIN_NCH), AUX_SW, AUX_SA>(p, s, idx, g, lane, nf);
                             else
-                                update_rows<VEC, OPT, AUX, 1>(p, s, idx, g, lane);
+                                update_rows<VEC, OPT, AUX, 1, false, NC>(p, s, idx, g, lane);
                             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                             __builtin_amdgcn_s_waitcnt(0);
                         }

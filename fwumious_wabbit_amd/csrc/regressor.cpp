@@ -735,6 +735,7 @@ int fwgpu_set_nn(fwgpu_regressor *r, const fwgpu_nn_config *nn) {
         d.relu[l] = nn->relu[l] ? 1 : 0;
         off += (in + 1) * nn->width[l];  // +1: bias term (block_neural.rs:86)
         d.sum_width += nn->width[l];
+        d.max_out = std::max(d.max_out, nn->width[l]);
         in = nn->width[l];
         d.max_in = std::max(d.max_in, in);
     }
@@ -838,7 +839,10 @@ int fwgpu_debug_set_option(fwgpu_regressor *r, int option, int value) {
         if (value < -1 || value > 65536) return fail(FWGPU_ERR_INVALID, "write-back interval option: -1 .. 65536 examples");
         r->launch.wb_flush_every = value;
         return FWGPU_OK;
-    case 8: r->launch.lds_keep = value; return FWGPU_OK;  // rows per wave kept in LDS beyond the register-kept ones (-1: automatic)
+    case 8:  // rows per wave kept in LDS beyond the register-kept ones (-1: automatic)
+        if (value < -1 || value > 3) return fail(FWGPU_ERR_INVALID, "LDS-kept rows option: 0 .. 3, or -1 (automatic)");
+        r->launch.lds_keep = value;
+        return FWGPU_OK;
     case 7: r->launch.prefetch = value ? 1 : 0; return FWGPU_OK;  // next-record prefetch of the v2 kernel's updating launches
     case 2:  // whole-line FFM row updates: 0 off, 1 auto (tables larger than the Infinity Cache; default), 2 always, 3 chained path always with float-granular accesses
         if (value < 0 || value > 3) return fail(FWGPU_ERR_INVALID, "window option: 0, 1, 2 or 3");

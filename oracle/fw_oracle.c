@@ -1035,6 +1035,49 @@ double fwo_run_stream(fwo_model *m, const fwo_translator *t, const uint32_t *rec
     return dt;
 }
 
+/* read-only pass (update = false, main.rs:238-241) over n examples on nthreads threads: predictions do not depend on the order,
+ * so the result equals the single-threaded tail of fwo_run_stream; the threads only shorten the hold-out passes of the long curves */
+typedef struct {
+    fwo_model *m;
+    const fwo_translator *t;
+    const uint32_t *records;
+    const uint64_t *rec_off;
+    uint64_t lo, hi;
+    float *preds;
+} pred_args;
+
+static void *pred_worker(void *p) {
+    pred_args *a = (pred_args *)p;
+    fwo_scratch s;
+    scratch_init(&s, &a->m->cfg);
+    fwo_lr_entry *lr = (fwo_lr_entry *)malloc(sizeof(fwo_lr_entry) * FWO_EX_CAP);
+    fwo_ffm_entry *ffm = (fwo_ffm_entry *)malloc(sizeof(fwo_ffm_entry) * FWO_EX_CAP);
+    for (uint64_t i = a->lo; i < a->hi; i++) {
+        uint32_t n_lr, n_ffm;
+        float label, imp;
+        fwo_translate(a->t, a->records + a->rec_off[i], lr, FWO_EX_CAP, &n_lr, ffm, FWO_EX_CAP, &n_ffm, &label, &imp);
+        a->preds[i] = learn_s(a->m, &s, lr, n_lr, ffm, n_ffm, label, imp, 0);
+    }
+    free(lr);
+    free(ffm);
+    scratch_free(&s);
+    return NULL;
+}
+
+void fwo_predict_stream(fwo_model *m, const fwo_translator *t, const uint32_t *records, const uint64_t *rec_off, uint64_t n,
+                        int nthreads, float *preds) {
+    if (nthreads < 1) nthreads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    pred_args *a = (pred_args *)malloc(sizeof(pred_args) * (size_t)nthreads);
+    for (int i = 0; i < nthreads; i++) {
+        a[i] = (pred_args){m, t, records, rec_off, n * (uint64_t)i / (uint64_t)nthreads, n * (uint64_t)(i + 1) / (uint64_t)nthreads, preds};
+        pthread_create(&th[i], NULL, pred_worker, &a[i]);
+    }
+    for (int i = 0; i < nthreads; i++) pthread_join(th[i], NULL);
+    free(a);
+    free(th);
+}
+
 /* ------------------------------------------------------------------ synchronous micro-batch (see fw_oracle.h) */
 typedef struct {
     fwo_lr_entry *lr;

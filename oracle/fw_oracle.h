@@ -162,6 +162,10 @@ int fwo_translate(const fwo_translator *t, const uint32_t *record, fwo_lr_entry 
 double fwo_run_stream(fwo_model *m, const fwo_translator *t, const uint32_t *records, const uint64_t *rec_off,
                       uint64_t n, uint64_t holdout_after, int nthreads, float *preds);
 
+/* read-only pass (update = false) over n examples on nthreads threads; same predictions as the hold-out tail of fwo_run_stream */
+void fwo_predict_stream(fwo_model *m, const fwo_translator *t, const uint32_t *records, const uint64_t *rec_off, uint64_t n,
+                        int nthreads, float *preds);
+
 /* ---- synchronous micro-batch: the checker of the library's fwgpu_learn_batch_sync / sharded multi-GPU step ----
  * NOT a mode of the reference (which updates after every example): it is what N hogwild threads do when they all read the
  * weights at the same moment.  All n examples are scored with the weights as they are (forward passes of

@@ -153,6 +153,8 @@ def lib(native=False):
     L.fwo_learn_sparse.argtypes = [vp, C.POINTER(Translator), vp, vp, C.c_uint64, vp, C.c_uint32, vp]
     L.fwo_run_stream.restype = C.c_double
     L.fwo_run_stream.argtypes = [vp, C.POINTER(Translator), vp, vp, C.c_uint64, C.c_uint64, C.c_int, vp]
+    L.fwo_predict_stream.restype = None
+    L.fwo_predict_stream.argtypes = [vp, C.POINTER(Translator), vp, vp, C.c_uint64, C.c_int, vp]
     _lib_cache[native] = L
     return L
 
@@ -335,3 +337,12 @@ class Model:
         dt = self.L.fwo_run_stream(self.h, C.byref(tspec.c), _ptr(records), _ptr(rec_off), n, holdout_after,
                                    nthreads, _ptr(preds) if preds is not None else None)
         return dt, preds
+
+    def predict_stream(self, tspec, records, rec_off, nthreads=1):
+        """update=false pass over every record (main.rs:238-241) on nthreads threads; order-independent."""
+        records = np.ascontiguousarray(records, dtype=np.uint32)
+        rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
+        n = len(rec_off) - 1
+        preds = np.zeros(n, dtype=np.float32)
+        self.L.fwo_predict_stream(self.h, C.byref(tspec.c), _ptr(records), _ptr(rec_off), n, nthreads, _ptr(preds))
+        return preds

@@ -1,6 +1,6 @@
 """Interleaved A/B of launch options on config-C learn launches (one process, same batches, N rounds).
 usage: python3 scripts/ab_probe.py "name:opt=val,opt=val;name2:..."   options: window, lutg, threads, wgs, kv (kernel version)
-env: B (examples per launch, default 16384), ROUNDS (default 5), FIELDS, K, PREDICT=1 adds a predict-only timing."""
+env: B (examples per launch, default 16384), ROUNDS (default 5), FIELDS, K, ZIPF (id skew, default 1.05), PREDICT=1 adds a predict-only timing."""
 import sys, os, time, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,7 +17,7 @@ class A:
 args = A()
 args.fields, args.k, args.bits, args.ffm_bits = int(os.environ.get("FIELDS", 30)), int(os.environ.get("K", 8)), 28, 28
 args.nn_layers, args.nn_width = 0, 256
-args.mean_extra, args.zipf, args.ids, args.p_weighted, args.seed = 5.67, 1.05, 10_000_000, 0.1, 20240612
+args.mean_extra, args.zipf, args.ids, args.p_weighted, args.seed = 5.67, float(os.environ.get("ZIPF", 1.05)), 10_000_000, 0.1, 20240612
 B = int(os.environ.get("B", 16384))
 NB = 3
 ROUNDS = int(os.environ.get("ROUNDS", 5))

@@ -1,8 +1,16 @@
 #!/usr/bin/env python3
-"""Hold-out log-loss of the SEQUENTIAL CPU oracle (the reference's single-thread algorithm, oracle/fw_oracle.c) on bench.py's fixed-seed
-config-C stream, after every 65 536 examples: the reference point bench.py prints next to the GPU's hogwild loss (`oracle_logloss_after_examples`).
-Writes tests/golden/bench_oracle_curve.json (data; bench.py reads the numbers, never the oracle).  ~15 minutes on one core.
-usage: python scripts/make_bench_oracle_curve.py [n_steps=52]"""
+"""Hold-out log-loss of the CPU oracle (oracle/fw_oracle.c, the reference's algorithm) on bench.py's fixed-seed config-C stream at SURVEY 8d's
+protocol length: 16 Mi training examples (256 steps of 65 536), hold-out = 262 144 examples of the same stream's tail that are predicted and
+never learned (main.rs:184-185, 238-241; loss as benchmark/calc_loss.py:5-25).
+
+  python scripts/make_bench_oracle_curve.py seq            the reference's single thread (main.rs:213-270): deterministic
+  python scripts/make_bench_oracle_curve.py hog16 <run>    the reference's hogwild mode, 16 threads (main.rs:189-194, hogwild.rs:89-103);
+                                                           racy by definition: <run> only names the output, every run interleaves differently
+
+Checkpoints: after every step up to 52 (bench.py's default and driver shapes end at 25 / 52 steps), then every 4 steps up to 256.
+Writes tests/golden/bench_oracle_curve_<mode>[_r<run>].json (data: bench.py and the tests read the numbers, never the oracle).
+The 8 192-example prefix of the hold-out (round 1-4's yardstick) is kept beside the 262 144-example loss.
+Sequential: ~1 h on one core (+ the hold-out passes on `--pred-threads` threads)."""
 import json
 import os
 import sys
@@ -16,18 +24,24 @@ import bench  # noqa: E402  (hyper-parameters and the stream generator are bench
 import fwumious_wabbit_amd as fw  # noqa: E402
 from oracle import fwo  # noqa: E402
 
-n_steps = int(sys.argv[1]) if len(sys.argv) > 1 else 52
+mode = sys.argv[1] if len(sys.argv) > 1 else "seq"
+run = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+n_steps = int(os.environ.get("CURVE_STEPS", "256"))
+pred_threads = int(os.environ.get("CURVE_PRED_THREADS", "4"))
+gen_threads = int(os.environ.get("CURVE_GEN_THREADS", "2"))
 B = 65536
+HOLDOUT = 262144
 sys.argv = [sys.argv[0]]
 
 
 class A:  # bench.py's defaults for config C
     fields, k, bits, ffm_bits = 30, 8, 28, 28
-    mean_extra, zipf, ids, p_weighted, seed, holdout = 5.67, 1.05, 10_000_000, 0.1, 20240612, 8192
+    mean_extra, zipf, ids, p_weighted, seed, holdout = 5.67, 1.05, 10_000_000, 0.1, 20240612, HOLDOUT
 
 
 args = A()
 F = args.fields
+nthreads = {"seq": 1, "hog16": 16}[mode]
 ocfg = fwo.make_config(optimizer=fwo.OPT_ADAGRAD_LUT, learning_rate=bench.LR, ffm_learning_rate=bench.LR, power_t=bench.POWER_T,
                        ffm_power_t=bench.POWER_T, init_acc_gradient=bench.INIT_ACC, ffm_init_acc_gradient=bench.INIT_ACC,
                        bit_precision=args.bits, num_combos=F + 1, ffm_k=args.k, ffm_bit_precision=args.ffm_bits, ffm_num_fields=F)
@@ -36,18 +50,28 @@ try:
     om = fwo.Model(ocfg, native=True)
 except Exception:
     om = fwo.Model(ocfg, native=False)
-hrecs, hoff = bench.gen_records(fw, args, 1_000_000_000, args.holdout)
+hrecs, hoff = bench.gen_records(fw, args, 1_000_000_000, HOLDOUT, threads=gen_threads)
 hy = hrecs[hoff[:-1].astype(np.int64) + 1].astype(np.float32)
-out = {"what": "sequential CPU oracle, hold-out log-loss after N training examples of bench.py's default stream",
+name = f"bench_oracle_curve_{mode}" + (f"_r{run}" if mode != "seq" else "") + ".json"
+path = os.path.join(ROOT, "tests", "golden", name)
+out = {"what": ("CPU oracle, the reference's single thread (main.rs:213-270)" if mode == "seq" else
+                f"CPU oracle in the reference's hogwild mode, {nthreads} threads on {os.cpu_count()} host cores (hogwild.rs:89-103), run {run}")
+               + ": hold-out log-loss after N training examples of bench.py's default stream",
        "config": {k: getattr(args, k) for k in ("fields", "k", "bits", "ffm_bits", "mean_extra", "zipf", "ids", "p_weighted", "seed", "holdout")},
-       "hyper": {"lr": bench.LR, "power_t": bench.POWER_T, "init_acc": bench.INIT_ACC}, "examples": [], "logloss": []}
+       "hyper": {"lr": bench.LR, "power_t": bench.POWER_T, "init_acc": bench.INIT_ACC}, "threads": nthreads,
+       "holdout_prior_logloss": bench.logloss(np.full(len(hy), float(np.mean(hy == 1))), hy),
+       "examples": [], "logloss": [], "logloss_first_8192": [], "train_seconds": 0.0}
 t0 = time.time()
 for s in range(n_steps):
-    recs, off = bench.gen_records(fw, args, s * B, B)
-    om.run_stream(ots, recs, off, holdout_after=0, nthreads=1, want_preds=False)
-    _, p = om.run_stream(ots, hrecs, hoff, holdout_after=1, nthreads=1)
-    out["examples"].append((s + 1) * B)
-    out["logloss"].append(round(bench.logloss(p, hy), 6))
-    print(s + 1, out["logloss"][-1], f"{time.time() - t0:.0f}s", flush=True)
-    with open(os.path.join(ROOT, "tests", "golden", "bench_oracle_curve.json"), "w") as f:
-        json.dump(out, f, indent=1)
+    recs, off = bench.gen_records(fw, args, s * B, B, threads=gen_threads)
+    dt, _ = om.run_stream(ots, recs, off, holdout_after=0, nthreads=nthreads, want_preds=False)
+    out["train_seconds"] += dt
+    if s + 1 <= 52 or (s + 1) % 4 == 0 or s + 1 == n_steps:
+        p = om.predict_stream(ots, hrecs, hoff, nthreads=pred_threads)
+        out["examples"].append((s + 1) * B)
+        out["logloss"].append(round(bench.logloss(p, hy), 6))
+        out["logloss_first_8192"].append(round(bench.logloss(p[:8192], hy[:8192]), 6))
+        print(s + 1, out["logloss"][-1], out["logloss_first_8192"][-1], f"{time.time() - t0:.0f}s", flush=True)
+        with open(path + ".tmp", "w") as f:
+            json.dump(out, f, indent=1)
+        os.replace(path + ".tmp", path)

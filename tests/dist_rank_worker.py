@@ -53,6 +53,27 @@ def main():
     preds = []
     pos = 0
     codes = []
+    if mode == "sparse_timeout":
+        # A rank that is GONE (not failed-and-reporting: gone) in the middle of a job: after one good step the last rank exits without a word; the others'
+        # next step finds nobody at the first collective.  With FWGPU_DIST_TIMEOUT_MS set (and FWGPU_FAKERCCL_ASYNC=1, so that the collective sits on
+        # the stream like RCCL's would) the polled wait gives up, aborts the communicator and returns FWGPU_ERR_PEER -- terminal for the rank: its next
+        # collective call is refused with FWGPU_ERR_INVALID (no communicator), it does not hang and does not touch freed memory.
+        a = int(parts[0, :rank].sum())
+        b = a + int(parts[0, rank])
+        sub, so = recs[int(off[a]):int(off[b])], off[a:b + 1] - off[a]
+        d.learn_sparse(fbt, sub, so)
+        if rank == n_ranks - 1:
+            os._exit(0)
+        t0 = time.time()
+        for _ in range(2):
+            try:
+                d.learn_sparse(fbt, sub, so)
+                codes.append(0)
+            except capi.FwgpuError as e:
+                codes.append(e.code)
+        np.savez(sys.argv[3], codes=np.asarray(codes, dtype=np.int64), seconds=np.float64(time.time() - t0))
+        re.close()  # (the rank object is left to the process exit: its communicator is gone)
+        return
     if mode in ("sharded_fail", "sparse_fail"):
         # Failure model of the collective steps (dist.cpp): a rank whose LOCAL preparation fails still joins the shape exchange with a
         # poisoned shape; every rank returns from the step -- the culprit with its own error, the others with FWGPU_ERR_PEER -- nothing is

@@ -8,6 +8,10 @@
 //   same bits on every rank), host -> device, barrier.  Large messages go through in slot-sized chunks.
 // Semantics follow nccl.h: AllGather(send, recv, sendcount), ReduceScatter(send, recv, recvcount), AllReduce(send, recv, count),
 // in-place forms included.
+// FWGPU_FAKERCCL_ASYNC=1: ncclAllGather behaves like the real thing towards the CALLER -- it returns at once and leaves a kernel on the stream that
+// ends when the exchange has happened (a helper thread does the copies and the barriers); with a dead peer that kernel stays on the stream until
+// ncclCommAbort, which is what the library's polled waits (FWGPU_DIST_TIMEOUT_MS, dist.cpp wait_stream) exist for and what a host-synchronous
+// stand-in cannot exercise.
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
@@ -18,6 +22,7 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -40,6 +45,12 @@ struct Header {
 
 struct FakeComm {
     int rank = 0, n = 1;
+    int device = 0;
+    std::atomic<int> pending{0};          // asynchronous collectives whose helper thread is still running
+    std::atomic<int> async_error{0};      // ncclResult_t of the last failed asynchronous collective (ncclCommGetAsyncError)
+    unsigned *flags = nullptr;            // host-mapped completion flags of the asynchronous collectives (ring)
+    unsigned flag_next = 0;
+    hipStream_t helper_stream = nullptr;
     char name[128] = {0};
     Header *hdr = nullptr;
     unsigned char *slots = nullptr;
@@ -151,12 +162,16 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
     }
     c->hdr->attached.fetch_add(1);
     if (!c->barrier()) return ncclSystemError;
+    (void)hipGetDevice(&c->device);
     *out = c;
     return ncclSuccess;
 }
 
 ncclResult_t ncclCommDestroy(ncclComm_t c) {
     if (!c) return ncclSuccess;
+    while (c->pending.load(std::memory_order_acquire) > 0) std::this_thread::sleep_for(std::chrono::microseconds(100));  // helper threads use *c
+    if (c->flags) (void)hipHostFree(c->flags);
+    if (c->helper_stream) (void)hipStreamDestroy(c->helper_stream);
     const uint32_t left = c->hdr->attached.fetch_sub(1) - 1;
     munmap(reinterpret_cast<void *>(c->hdr), c->bytes);
     if (left == 0) shm_unlink(c->name);
@@ -179,8 +194,64 @@ ncclResult_t ncclCommAbort(ncclComm_t c) {
 
 #define HIPOK(x) do { if ((x) != hipSuccess) return ncclUnhandledCudaError; } while (0)
 
+ncclResult_t ncclCommGetAsyncError(ncclComm_t c, ncclResult_t *e) {
+    if (!c || !e) return ncclInvalidArgument;
+    *e = (ncclResult_t)c->async_error.load(std::memory_order_acquire);
+    return ncclSuccess;
+}
+
+// the kernel an asynchronous collective leaves on the caller's stream: it ends when the helper thread has finished (or given up on) the exchange
+__global__ void fake_rccl_wait_kernel(const unsigned *flag) {
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == 0) __builtin_amdgcn_s_sleep(64);
+}
+
+static ncclResult_t all_gather_body(const void *send, void *recv, size_t total, ncclComm_t c, hipStream_t copy_stream) {
+    for (size_t off = 0; off < total || (total == 0 && off == 0); off += kSlot) {
+        const size_t m = total - off < kSlot ? total - off : kSlot;
+        if (m) {
+            HIPOK(hipMemcpyAsync(c->slot(c->rank), (const char *)send + off, m, hipMemcpyDeviceToHost, copy_stream));
+            HIPOK(hipStreamSynchronize(copy_stream));
+        }
+        if (!c->barrier()) return ncclSystemError;
+        for (int r = 0; r < c->n && m; r++) HIPOK(hipMemcpyAsync((char *)recv + (size_t)r * total + off, c->slot(r), m, hipMemcpyHostToDevice, copy_stream));
+        HIPOK(hipStreamSynchronize(copy_stream));
+        if (!c->barrier()) return ncclSystemError;
+        if (total == 0) break;
+    }
+    return ncclSuccess;
+}
+
+static ncclResult_t all_gather_async(const void *send, void *recv, size_t total, ncclComm_t c, hipStream_t s) {
+    if (!c->flags) {
+        HIPOK(hipHostMalloc((void **)&c->flags, 1024 * sizeof(unsigned), hipHostMallocMapped));
+        memset(c->flags, 0, 1024 * sizeof(unsigned));
+        HIPOK(hipStreamCreateWithFlags(&c->helper_stream, hipStreamNonBlocking));
+    }
+    unsigned *flag = c->flags + (c->flag_next++ & 1023u);
+    __atomic_store_n(flag, 0u, __ATOMIC_RELEASE);
+    unsigned *dflag = nullptr;
+    HIPOK(hipHostGetDevicePointer((void **)&dflag, flag, 0));
+    hipEvent_t ready;
+    HIPOK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    HIPOK(hipEventRecord(ready, s));  // the send buffer is complete when this fires
+    hipLaunchKernelGGL(fake_rccl_wait_kernel, dim3(1), dim3(1), 0, s, dflag);
+    HIPOK(hipGetLastError());
+    c->pending.fetch_add(1, std::memory_order_acq_rel);
+    std::thread([=]() {
+        (void)hipSetDevice(c->device);
+        ncclResult_t e = hipEventSynchronize(ready) == hipSuccess ? all_gather_body(send, recv, total, c, c->helper_stream) : ncclUnhandledCudaError;
+        (void)hipEventDestroy(ready);
+        if (e != ncclSuccess) c->async_error.store((int)e, std::memory_order_release);
+        __atomic_store_n(flag, 1u, __ATOMIC_RELEASE);  // the stream goes on -- with the gathered data, or (failure / abort) without it
+        c->pending.fetch_sub(1, std::memory_order_acq_rel);
+    }).detach();
+    return ncclSuccess;
+}
+
 ncclResult_t ncclAllGather(const void *send, void *recv, size_t count, ncclDataType_t t, ncclComm_t c, hipStream_t s) {
     const size_t es = esize(t), total = count * es;
+    static const bool async = [] { const char *e = getenv("FWGPU_FAKERCCL_ASYNC"); return e && e[0] == '1'; }();
+    if (async) return all_gather_async(send, recv, total, c, s);
     HIPOK(hipStreamSynchronize(s));
     for (size_t off = 0; off < total || (total == 0 && off == 0); off += kSlot) {
         const size_t m = total - off < kSlot ? total - off : kSlot;

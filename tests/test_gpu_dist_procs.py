@@ -229,3 +229,30 @@ def test_process_per_rank_peer_sharded_hogwild_reaches_the_oracles_holdout_loss(
     re.close()
     print(f"process-per-rank peer-sharded hogwild: hold-out {gpu_hold:.4f}, sequential oracle {ref_hold:.4f}")
     assert gpu_hold < 0.6931 and abs(gpu_hold - ref_hold) < 0.02, (gpu_hold, ref_hold)
+
+
+def test_a_rank_that_is_gone_ends_the_others_step_through_the_timeout(tmp_path):
+    """dist.cpp wait_stream()'s FWGPU_DIST_TIMEOUT_MS path -- read-backs behind a collective go through pinned memory owned by the rank, the
+    caller's prediction buffer is filled after the polled wait, a timed-out rank is left without a communicator.  Three ranks; the last one exits after
+    the first step; the two others must come back from their next step with FWGPU_ERR_PEER within seconds and be refused (FWGPU_ERR_INVALID) afterwards."""
+    n_ns, k, bits, ffm_bits = 6, 4, 12, 12
+    n_ranks = 3
+    recs, off = fw.synth_records(n_ns, 1.0, 1.1, 500, 0.1, 77, 0, 96)
+    job = str(tmp_path / "job_timeout.npz")
+    np.savez(job, n_ranks=n_ranks, mode="sparse_timeout", n_ns=n_ns, k=k, bits=bits, ffm_bits=ffm_bits, optimizer=int(fw.Optimizer.AdagradLUT), lr=0.05, recs=recs,
+             off=off, parts=np.asarray([[32, 32, 32]], dtype=np.int64), id_file=str(tmp_path / "id_timeout"), allreduce=0)
+    env = dict(os.environ, FWGPU_RCCL_LIBRARY=FAKE, HSA_ENABLE_IPC_MODE_LEGACY="0", FWGPU_DIST_TIMEOUT_MS="1500", FWGPU_FAKERCCL_ASYNC="1")
+    procs = [subprocess.Popen([sys.executable, WORKER, job, str(r), str(tmp_path / f"out_timeout_{r}.npz")], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(n_ranks)]
+    for r, p in enumerate(procs):
+        try:
+            log, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, f"rank {r} failed:\n{log[-3000:]}"
+    for r in range(n_ranks - 1):
+        o = np.load(str(tmp_path / f"out_timeout_{r}.npz"))
+        assert list(o["codes"]) == [8, 1], (r, o["codes"])  # FWGPU_ERR_PEER, then FWGPU_ERR_INVALID (no communicator left)
+        assert float(o["seconds"]) < 60.0, float(o["seconds"])

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("shape", ["config_c_kernel", "generic_kernel"])
 def test_two_learners_on_two_streams_are_each_the_sequential_reference(shape):
-    if shape == "config_c_kernel":  # 30 fields, k = 8, the large-table update path forced onto small tables: fw_example_kernel_r<.., 14, true, 1, POL>
+    if shape == "config_c_kernel":  # 30 fields, k = 8, the large-table update path forced onto small tables: fw_example_kernel_r<.., 20, true, 1, POL>
         geo = dict(n_ns=30, k=8, bits=18, ffm_bits=20, mean_extra=5.67, p_weighted=0.1, ids=20000, lr=0.025, power_t=0.38)
         n = 700
     else:                            # k = 10: the generic kernel

@@ -7,6 +7,7 @@ workaround for hipIpcOpenMemHandle) all complete, and the line reports the commu
 import json
 import os
 import subprocess
+import sys
 
 import pytest
 
@@ -39,3 +40,55 @@ def test_eight_ranks_peer_sharded_mode():
     d = _launch(8, "--dp-mode", "peer", "--no-other-modes")
     assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8
     assert d["value"] > 0 and 0.3 < d["final_logloss"] < 0.70
+
+
+def _self_launch(n, *flags, timeout=900, env_extra=None):
+    """`python3 bench.py --gpus N ...` with NO launcher and no WORLD_SIZE around it: bench.py starts its own N ranks (bench.self_launch)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["FWGPU_RCCL_LIBRARY"] = os.path.join(ROOT, "tests", "fake_rccl", "libfwgpu_fakerccl.so")
+    env.update(env_extra or {})
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dist-backend", "gloo", "--same-device", "--library-comm", "--steps", "4",
+           "--warmup", "1", "--batch", "2048", "--bits", "20", "--ffm-bits", "20", "--holdout", "1024", "--no-cpu-baseline", "--no-traffic",
+           "--other-modes-timeout", "300", *flags]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_launches_its_own_eight_ranks_when_no_launcher_set_world_size():
+    p = _self_launch(8)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]  # rank 0's line, once
+    d = json.loads(lines[-1])
+    assert p.stdout.rstrip().splitlines()[-1] == lines[-1]  # and it is the last line of stdout
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8, (d["n_gpus"], d.get("rccl_ranks"))
+    assert d["value"] > 0 and 0.3 < d["final_logloss"] < 0.70
+    assert "error" not in d.get("dp_modes", {}), d.get("dp_modes")
+
+
+def test_self_launch_reports_a_failing_rank_and_ends_the_others():
+    # rank 3 of 4 dies before the rendezvous: the parent must come back non-zero, soon, with no rank left behind
+    p = _self_launch(4, "--no-other-modes", timeout=300, env_extra={"FWGPU_BENCH_FAIL_RANK": "3"})
+    assert p.returncode != 0
+    assert "rank 3 exited" in p.stderr, p.stderr[-2000:]
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_one_rank_through_the_dist_path_is_within_two_percent_of_the_plain_line():
+    """The replica-exchange machinery itself (snapshot, fused delta passes, the library's RCCL communicator with one rank) at config C's full size:
+    what it costs against the plain single-GPU line.  Best of two attempts each (clock ramp / placement differ from process to process)."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-traffic", "--no-config-e", "--holdout", "8192"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+
+    def rate(extra, env):
+        best = 0.0
+        for _ in range(2):
+            p = subprocess.run(base + extra, env=env, capture_output=True, text=True, timeout=600)
+            assert p.returncode == 0, p.stderr[-3000:]
+            d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+            best = max(best, d["value"])
+        return best, d
+
+    plain, _ = rate([], env)
+    one, d = rate(["--force-dist", "--no-other-modes"], dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29641"))
+    assert d["rccl_ranks"] == 1
+    assert one >= 0.98 * plain, (one, plain)
