@@ -93,7 +93,7 @@ def logloss(p, y):
     return float(np.mean(-np.where(y == 1, np.log(p), np.log(1 - p))))
 
 
-def oracle_reference_curves(args, world):
+def oracle_reference_curves(args, world, holdout=None):
     """Hold-out log-loss of the reference algorithm on this very stream and hold-out tail after N examples: numbers produced by
     scripts/make_bench_oracle_curve.py from the CPU oracle and committed as data (tests/golden/bench_oracle_curve_*.json) -- the reference's single
     thread ("seq", deterministic) and its 16-thread hogwild mode ("hog16", three runs: racy by definition).  Only for the default single-GPU stream
@@ -104,15 +104,17 @@ def oracle_reference_curves(args, world):
     out = {"seq": {}, "hog16": []}
     if world != 1:
         return out
+    holdout = args.holdout if holdout is None else holdout
     for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "bench_oracle_curve_*.json"))):
         d = json.load(open(path))
-        if args.holdout == d["config"]["holdout"]:
+        if holdout == d["config"]["holdout"]:
             key = "logloss"
-        elif args.holdout == 8192 and "logloss_first_8192" in d:
+        elif holdout == 8192 and "logloss_first_8192" in d:
             key = "logloss_first_8192"
         else:
             continue
-        c = dict(d["config"], holdout=args.holdout)
+        c = dict(d["config"])
+        c.pop("holdout")
         c.setdefault("nn_layers", 0)
         if not c["nn_layers"]:
             c.pop("nn_width", None)
@@ -641,7 +643,9 @@ def main():
     # loss-vs-examples curve: hold-out passes between timed steps, each into a batch object of its own (predictions are read after the run)
     curve_every = args.curve_every or max(1, K // 5)
     curve_steps = [i for i in range(K) if (i + 1) % curve_every == 0 and i + 1 < K]
-    curve_batches = {i: re.record_batch(fbt, hrecs, hoff) for i in curve_steps}
+    # (checkpoints inside the timed wall time run on the first 8192 hold-out examples -- 0.3 ms each at config C; the FINAL loss is on the whole tail)
+    cn = min(8192, args.holdout)
+    curve_batches = {i: re.record_batch(fbt, hrecs[: int(hoff[cn])], hoff[: cn + 1]) for i in curve_steps}
     del recs
     prep_s = time.time() - t0
 
@@ -772,19 +776,21 @@ def main():
 
     # ---- final hold-out log-loss (main.rs:238-241 --holdout_after semantics: predicted, never learned)
     re.learn_batch(hbatch, capi.MODE_HOGWILD, False, sptr)
-    final_ll = logloss(hbatch.predictions(sptr), hy)
+    p_final = hbatch.predictions(sptr)
+    final_ll = logloss(p_final, hy)
+    final_ll_cn = logloss(p_final[:cn], hy[:cn])
     # time to quality (benchmark/calc_loss.py:5-25 on the hold-out tail): loss after n learned examples (warm-up steps learn too), and the
     # wall time this run needs to reach a stated target at its measured rate
     prior_ll = logloss(np.full(len(hy), float(np.mean(hy == 1)), dtype=np.float64), hy)
     curve = {}
     if not sharded_main:
         for i in curve_steps:
-            curve[(W + i + 1) * B * world] = logloss(curve_batches[i].predictions(sptr), hy)
-    curve[(W + K) * B * world] = final_ll
+            curve[(W + i + 1) * B * world] = logloss(curve_batches[i].predictions(sptr), hy[:cn])
+    curve[(W + K) * B * world] = final_ll_cn
     # progressive validation on the training stream itself (the prediction every example got BEFORE it was learned), per timed step
     progressive = [] if sharded_main else [round(logloss(batches[W + i].predictions(sptr), blabels[W + i]), 5) for i in range(K)]
     target_ll = args.target_logloss if args.target_logloss is not None else 0.985 * prior_ll
-    reached = [n for n, v in sorted(curve.items()) if v <= target_ll]
+    reached = [n for n, v in sorted(curve.items()) if v <= target_ll]  # (on the checkpoints' prefix of the hold-out)
     # guard: a saturated sigmoid (|logit| > 50, block_loss_functions.rs:125-133) skips the update; report how many of
     # the last timed step's examples were in that state (healthy training: 0)
     p_last = batches[W + K - 1].predictions(sptr)
@@ -870,9 +876,11 @@ def main():
     if rank == 0:
         oc = oracle_reference_curves(args, world) if not (sync_steps or use_dist) or (args.nn_layers and args.head == "exact" and not use_dist) else {"seq": {}, "hog16": []}
         oracle_curve = oc["seq"]
+        same_stream = not (sync_steps or use_dist) or (args.nn_layers and args.head == "exact" and not use_dist)
+        occ = oracle_reference_curves(args, world, cn) if same_stream else {"seq": {}, "hog16": []}  # ... on the checkpoints' prefix of the hold-out
 
-        def hog16_at(n):  # the 16-thread hogwild oracle's runs at n examples (None where not precomputed)
-            v = [c.get(n) for c in oc["hog16"] if c.get(n) is not None]
+        def hog16_at(n, which=None):  # the 16-thread hogwild oracle's runs at n examples (None where not precomputed)
+            v = [c.get(n) for c in (which or oc)["hog16"] if c.get(n) is not None]
             return v or None
         achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
         out = {
@@ -894,13 +902,15 @@ def main():
             "final_logloss": final_ll,
             # what "learned" means on this hold-out tail: the loss of always predicting its positive rate (the untrained model reads ln 2)
             "holdout_prior_logloss": prior_ll,
+            # hold-out checkpoints during the run: on the FIRST `curve_holdout_examples` examples of the hold-out tail (cheap enough to sit inside the timed wall time)
+            "curve_holdout_examples": cn,
             "logloss_after_examples": {str(n): v for n, v in sorted(curve.items())},
             # the sequential CPU oracle (= the reference's single-thread algorithm) on the same stream, same hold-out tail, same number of examples:
             # null where it was not precomputed (tests/golden/bench_oracle_curve_seq.json: every multiple of 65 536 up to 3.4 M, every 262 144 up to 16.8 M)
-            "oracle_logloss_after_examples": {str(n): oracle_curve.get(n) for n, v in sorted(curve.items())},
+            "oracle_logloss_after_examples": {str(n): occ["seq"].get(n) for n, v in sorted(curve.items())},
             "oracle_final_logloss": oracle_curve.get((W + K) * B * world),
             # ... and the oracle in the reference's 16-thread hogwild mode (hogwild.rs:89-103), every committed run
-            "oracle_hogwild16_logloss_after_examples": {str(n): hog16_at(n) for n, v in sorted(curve.items())},
+            "oracle_hogwild16_logloss_after_examples": {str(n): hog16_at(n, occ) for n, v in sorted(curve.items())},
             "oracle_hogwild16_final_logloss": hog16_at((W + K) * B * world),
             "progressive_logloss_per_step": progressive,
             "seconds_to_logloss": {"target": target_ll, "examples": reached[0] if reached else None,

@@ -177,6 +177,17 @@ struct fwgpu_dist {
     PushRings *d_push = nullptr;
     unsigned char *peer_rings[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // the owners' ring allocations as mapped here
     bool rings_attached = false;
+    // streaming form of the owner-side apply (fwgpu_dist_*_owner_stream): ONE allocation for both roles -- as owner, a circular region per source (tag
+    // words | gradient rows | LR words) and the final positions its consumer polls; as source, per owner the slots' free generations, the LR credits and
+    // the position counters (layout: StreamGeom)
+    unsigned char *st_mem = nullptr;
+    size_t st_bytes = 0;
+    uint32_t st_lg_ffm = 0, st_lg_lr = 0, st_n = 0;
+    uint32_t st_pos_ffm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_pos_lr[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // as OWNER: positions of source s's rings consumed so far
+    hipStream_t cstream = nullptr;     // the consumer kernel's stream
+    uint32_t *h_resident = nullptr;    // pinned + mapped: consumer workgroups of the current launch that are running
+    PushRings *d_push_st = nullptr;
+    unsigned char *st_peer[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // every rank's st_mem as reachable from here
     PeerShards *d_peers = nullptr;   // peer-sharded step: the owners' table bases, on this rank's device
     bool peers_attached = false;     // process-per-rank peer mode: the other ranks' tables are mapped (hipIpcOpenMemHandle)
     float *lr_shard = nullptr;       // ... this rank's OWNED range of the LR table in an allocation of its own while the mode is on: what the
@@ -213,6 +224,10 @@ struct fwgpu_dist {
         if (d_own) (void)hipFree(d_own);
         for (void *q : ipc_open) (void)hipIpcCloseMemHandle(q);
         if (lr_shard) (void)hipFree(lr_shard);
+        if (st_mem) (void)hipFree(st_mem);
+        if (d_push_st) (void)hipFree(d_push_st);
+        if (h_resident) (void)hipHostFree(h_resident);
+        if (cstream) (void)hipStreamDestroy(cstream);
         if (d_peers) (void)hipFree(d_peers);
         if (own_rings) (void)hipFree(own_rings);
         if (d_push_cnt) (void)hipFree(d_push_cnt);
@@ -1633,6 +1648,230 @@ int fwgpu_dist_group_learn_owner(fwgpu_dist_group *g, const fwgpu_translator_con
         FWGPU_HIP(hipSetDevice(d->r->device));
         if (preds && preds[j] && d->B) FWGPU_HIP(hipMemcpyAsync(preds[j], d->cur->pred, (size_t)d->B * 4, hipMemcpyDeviceToHost, d->stream));
         FWGPU_HIP(hipStreamSynchronize(d->stream));
+    }
+    return FWGPU_OK;
+}
+
+// ------------------------------------------------------------------ owner-side apply, STREAMING form
+// The step-synchronous form above applies a step's gradients when the step's kernels have ended: every gradient of the step was taken at the step's
+// first weights and every one of them lands, which bounds the step to ~1024 global examples.  Here the owners drain their regions WHILE the
+// sources' kernels fill them: a persistent consumer grid per owner (kernels.hip owner_stream_kernel), circular regions, flow control through words the
+// owner stores in the SOURCE's memory -- staleness = the examples in flight, like hogwild.rs:89-103, whatever the step's size.  Per step: consumers up
+// (the host waits until every consumer workgroup is running: a source that found the device full could otherwise wait for a consumer that never
+// starts), sources' kernels, their final positions to the owners, consumers drain and leave.  No collective in the data path, one small read-back.
+namespace {
+struct StreamGeom {
+    uint32_t N, R, lg_ffm, lg_lr;
+    size_t off_tag, off_rows, off_lr, off_fin, off_free, off_credit, off_cnt, bytes;
+};
+StreamGeom stream_geom(uint32_t N, uint32_t R, uint32_t lg_ffm, uint32_t lg_lr) {
+    StreamGeom g{N, R, lg_ffm, lg_lr, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t cf = (size_t)1 << lg_ffm, cl = (size_t)1 << lg_lr;
+    size_t o = 0;
+    g.off_tag = o; o = up(o + (size_t)N * cf * 8);             // owner role, per source
+    g.off_rows = o; o = up(o + (size_t)N * cf * R * 4);
+    g.off_lr = o; o = up(o + (size_t)N * cl * 8);
+    g.off_fin = o; o = up(o + (size_t)2 * N * 8);
+    g.off_free = o; o = up(o + (size_t)N * cf * 4);             // source role, per owner
+    g.off_credit = o; o = up(o + (size_t)N * 4);
+    g.off_cnt = o; o = up(o + (size_t)2 * N * 4);
+    g.bytes = o;
+    return g;
+}
+// first use, another size, or positions close to the 32-bit wrap (generations are compared modulo: a fresh start at a step boundary is simpler than proving the wrap)
+int stream_reserve(fwgpu_dist *d, uint32_t N, uint32_t lg_ffm, uint32_t lg_lr, bool *fresh) {
+    const uint32_t R = d->r->cfg.ffm_k ? d->r->cfg.ffm_k * d->r->cfg.ffm_num_fields : 0;
+    const StreamGeom g = stream_geom(N, R, lg_ffm, lg_lr);
+    FWGPU_HIP(hipSetDevice(d->r->device));
+    if (!d->cstream) FWGPU_HIP(hipStreamCreateWithFlags(&d->cstream, hipStreamNonBlocking));
+    if (!d->h_resident) FWGPU_HIP(hipHostMalloc((void **)&d->h_resident, 64, hipHostMallocMapped));
+    if (!d->d_push_st) FWGPU_HIP(hipMalloc((void **)&d->d_push_st, sizeof(PushRings)));
+    *fresh = false;
+    if (!d->st_mem || d->st_bytes != g.bytes || d->st_lg_ffm != lg_ffm || d->st_lg_lr != lg_lr || d->st_n != N) {
+        if (d->st_mem) (void)hipFree(d->st_mem);
+        d->st_mem = nullptr;
+        if (hipMalloc((void **)&d->st_mem, g.bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(FWGPU_ERR_OOM, "owner-side apply, streaming form: no memory for the regions (smaller log2 capacities?)");
+        }
+        d->st_bytes = g.bytes;
+        d->st_lg_ffm = lg_ffm;
+        d->st_lg_lr = lg_lr;
+        d->st_n = N;
+        *fresh = true;
+    }
+    return FWGPU_OK;
+}
+int stream_reset(fwgpu_dist *d) {  // everything back to position 0 (tags, free generations, credits, counters)
+    const uint32_t R = d->r->cfg.ffm_k ? d->r->cfg.ffm_k * d->r->cfg.ffm_num_fields : 0;
+    const StreamGeom g = stream_geom(d->st_n, R, d->st_lg_ffm, d->st_lg_lr);
+    FWGPU_HIP(hipSetDevice(d->r->device));
+    FWGPU_HIP(hipMemsetAsync(d->st_mem + g.off_tag, 0, g.off_rows - g.off_tag, d->stream));
+    FWGPU_HIP(hipMemsetAsync(d->st_mem + g.off_lr, 0, g.bytes - g.off_lr, d->stream));
+    FWGPU_HIP(hipStreamSynchronize(d->stream));
+    for (int s = 0; s < 8; s++) d->st_pos_ffm[s] = d->st_pos_lr[s] = 0;
+    return FWGPU_OK;
+}
+}  // namespace
+
+// In-process group form of the streaming step.  batches[j] (may be NULL): rank j's micro-batch already in HBM (a record batch of its regressor);
+// otherwise records[j] / rec_off[j] / n[j].  HOGWILD only (the in-order reference is fwgpu_dist_group_learn_owner in FWGPU_MODE_SEQUENTIAL).
+// log2_rows / log2_lr: capacity of one (owner, source) region in gradient rows / LR gradients (0: 2^15 / 2^16).
+int fwgpu_dist_group_learn_owner_stream(fwgpu_dist_group *g, const fwgpu_translator_config *t, const uint32_t *const *records, const uint64_t *const *rec_off,
+                                        const uint32_t *n, fwgpu_batch *const *batches, float *const *preds, int update, uint32_t log2_rows, uint32_t log2_lr,
+                                        uint32_t consumer_workgroups) {
+    if (!g || !t || (!batches && (!records || !rec_off || !n))) return fail(FWGPU_ERR_INVALID, "NULL argument");
+    const uint32_t N = (uint32_t)g->ranks.size();
+    if (N > 8 || (N & (N - 1))) return fail(FWGPU_ERR_INVALID, "owner-side apply: 1, 2, 4 or 8 ranks");
+    fwgpu_regressor *r0 = g->ranks[0]->r;
+    if (r0->nn.n_layers) return fail(FWGPU_ERR_INVALID, "owner-side apply: models with a deep head are not covered");
+    if (r0->cfg.bit_precision > 30) return fail(FWGPU_ERR_INVALID, "owner-side apply, streaming form: LR hashes of more than 30 bits are not covered (the region's words keep 2 bits)");
+    int lg = 0;
+    while ((1u << lg) < N) lg++;
+    if ((r0->cfg.ffm_k && (int)r0->cfg.ffm_bit_precision < lg) || (int)r0->cfg.bit_precision < lg)
+        return fail(FWGPU_ERR_INVALID, "owner-side apply: fewer table entries than ranks");
+    const uint32_t lgf = log2_rows ? log2_rows : 15, lgl = log2_lr ? log2_lr : 16;
+    if (lgf < 6 || lgf > 24 || lgl < 6 || lgl > 24) return fail(FWGPU_ERR_INVALID, "owner-side apply, streaming form: log2 capacities of 6 .. 24");
+    uint32_t G = consumer_workgroups ? consumer_workgroups : 48;
+    G = std::max<uint32_t>(G, 2 * N);
+    G = N + ((G - N + N - 1) / N) * N;  // LR workgroups + a multiple of N row workgroups (4 waves each: waves divide evenly over the sources)
+    const uint32_t R = r0->cfg.ffm_k ? r0->cfg.ffm_k * r0->cfg.ffm_num_fields : 0;
+    PeerShards ps{};
+    ps.n = N;
+    ps.shift_ffm = r0->cfg.ffm_k ? r0->cfg.ffm_bit_precision - lg : 31;
+    ps.shift_lr = r0->cfg.bit_precision - lg;
+    for (uint32_t j = 0; j < N; j++) {
+        ps.ffm_w[j] = g->ranks[j]->r->d_ffm_w;
+        ps.ffm_acc[j] = g->ranks[j]->r->d_ffm_acc;
+        ps.lr[j] = g->ranks[j]->r->d_lr;
+    }
+    for (uint32_t i = 0; i < N; i++)
+        for (uint32_t j = 0; j < N; j++) {
+            const int di = g->ranks[i]->r->device, dj = g->ranks[j]->r->device;
+            if (di == dj) continue;
+            FWGPU_HIP(hipSetDevice(di));
+            hipError_t e = hipDeviceEnablePeerAccess(dj, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(FWGPU_ERR_DEVICE, "hipDeviceEnablePeerAccess failed");
+            (void)hipGetLastError();
+        }
+    int rc;
+    bool any_fresh = false, near_wrap = false;
+    for (uint32_t j = 0; j < N; j++) {
+        bool fresh = false;
+        if ((rc = stream_reserve(g->ranks[j].get(), N, lgf, lgl, &fresh))) return rc;
+        any_fresh |= fresh;
+        for (uint32_t s = 0; s < N; s++) near_wrap |= g->ranks[j]->st_pos_ffm[s] > 0x60000000u || g->ranks[j]->st_pos_lr[s] > 0x60000000u;
+    }
+    if (any_fresh || near_wrap)
+        for (uint32_t j = 0; j < N; j++)
+            if ((rc = stream_reset(g->ranks[j].get()))) return rc;
+    const StreamGeom geo = stream_geom(N, R, lgf, lgl);
+    const size_t cf = (size_t)1 << lgf, cl = (size_t)1 << lgl;
+    std::vector<uint32_t> shapes((size_t)N * 4);
+    for (uint32_t j = 0; j < N; j++) {
+        fwgpu_batch *bj = batches ? batches[j] : nullptr;
+        if ((rc = sparse_begin(g->ranks[j].get(), t, bj ? nullptr : records[j], bj ? nullptr : rec_off[j], bj ? bj->n : n[j], bj, &shapes[4 * j]))) return rc;
+    }
+    // ---- consumers up (only when something will be pushed)
+    if (update) {
+        for (uint32_t o = 0; o < N; o++) {
+            fwgpu_dist *od = g->ranks[o].get();
+            FWGPU_HIP(hipSetDevice(od->r->device));
+            OwnerStream os{};
+            os.n = N;
+            os.R = R;
+            os.log2cap_ffm = lgf;
+            os.log2cap_lr = lgl;
+            for (uint32_t s = 0; s < N; s++) {
+                unsigned char *src = g->ranks[s]->st_mem;
+                os.ffm_tag[s] = reinterpret_cast<const unsigned long long *>(od->st_mem + geo.off_tag) + (size_t)s * cf;
+                os.ffm_rows[s] = reinterpret_cast<const float *>(od->st_mem + geo.off_rows) + (size_t)s * cf * R;
+                os.lr_word[s] = reinterpret_cast<const unsigned long long *>(od->st_mem + geo.off_lr) + (size_t)s * cl;
+                os.ffm_free[s] = reinterpret_cast<uint32_t *>(src + geo.off_free) + (size_t)o * cf;
+                os.lr_credit[s] = reinterpret_cast<uint32_t *>(src + geo.off_credit) + o;
+                os.start_ffm[s] = od->st_pos_ffm[s];
+                os.start_lr[s] = od->st_pos_lr[s];
+            }
+            os.fin = reinterpret_cast<const unsigned long long *>(od->st_mem + geo.off_fin);
+            FWGPU_HIP(hipMemsetAsync(od->st_mem + geo.off_fin, 0, (size_t)2 * N * 8, od->cstream));
+            *od->h_resident = 0;
+            uint32_t *dres = nullptr;
+            FWGPU_HIP(hipHostGetDevicePointer((void **)&dres, od->h_resident, 0));
+            os.resident = dres;
+            os.w = od->r->d_ffm_w;
+            os.acc = od->r->d_ffm_acc;
+            os.lr = od->r->d_lr;
+            os.ffm_rate = od->r->cfg.ffm_learning_rate;
+            os.ffm_mpt = -od->r->cfg.ffm_power_t;
+            os.lr_rate = od->r->cfg.learning_rate;
+            os.lr_mpt = -od->r->cfg.power_t;
+            os.lut_ffm = od->r->d_lut_ffm;
+            os.lut_lr = od->r->d_lut_lr;
+            FWGPU_HIP(launch_owner_stream(os, od->r->cfg.optimizer, G, od->cstream));
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t o = 0; o < N; o++)
+            while (__atomic_load_n(g->ranks[o]->h_resident, __ATOMIC_ACQUIRE) < G) {
+                if (std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t0).count() > 20)
+                    return fail(FWGPU_ERR_DEVICE, "owner-side apply, streaming form: the consumer workgroups did not all start (device full?)");
+                std::this_thread::yield();
+            }
+    }
+    // ---- the sources' kernels
+    for (uint32_t j = 0; j < N; j++) {
+        fwgpu_dist *d = g->ranks[j].get();
+        FWGPU_HIP(hipSetDevice(d->r->device));
+        if (!d->d_peers) FWGPU_HIP(hipMalloc((void **)&d->d_peers, sizeof(PeerShards)));
+        FWGPU_HIP(hipMemcpyAsync(d->d_peers, &ps, sizeof(PeerShards), hipMemcpyHostToDevice, d->stream));
+        PushRings pr{};
+        pr.n = N;
+        pr.stream = 1;
+        pr.log2cap_ffm = lgf;
+        pr.log2cap_lr = lgl;
+        pr.cnt = reinterpret_cast<uint32_t *>(d->st_mem + geo.off_cnt);
+        pr.lr_credit = reinterpret_cast<const uint32_t *>(d->st_mem + geo.off_credit);
+        for (uint32_t o = 0; o < N; o++) {
+            unsigned char *ob = g->ranks[o]->st_mem;
+            pr.ffm_tag[o] = reinterpret_cast<unsigned long long *>(ob + geo.off_tag) + (size_t)j * cf;
+            pr.ffm_rows[o] = reinterpret_cast<float *>(ob + geo.off_rows) + (size_t)j * cf * R;
+            pr.lr_word[o] = reinterpret_cast<unsigned long long *>(ob + geo.off_lr) + (size_t)j * cl;
+            pr.ffm_free[o] = reinterpret_cast<const uint32_t *>(d->st_mem + geo.off_free) + (size_t)o * cf;
+        }
+        FWGPU_HIP(hipMemcpyAsync(d->d_push_st, &pr, sizeof(pr), hipMemcpyHostToDevice, d->stream));
+        FWGPU_HIP(hipStreamSynchronize(d->stream));  // (ps / pr are locals)
+        if ((rc = run_batch_peer(d->r, d->cur, FWGPU_MODE_HOGWILD, update, d->d_peers, d->stream, d->d_push_st))) return rc;
+    }
+    // ---- final positions to the owners; the consumers drain and leave
+    std::vector<uint32_t> cnt((size_t)N * 2 * N, 0);
+    for (uint32_t j = 0; j < N; j++) {
+        fwgpu_dist *d = g->ranks[j].get();
+        FWGPU_HIP(hipSetDevice(d->r->device));
+        FWGPU_HIP(hipStreamSynchronize(d->stream));
+        FWGPU_HIP(hipMemcpy(&cnt[(size_t)j * 2 * N], d->st_mem + geo.off_cnt, (size_t)2 * N * 4, hipMemcpyDeviceToHost));
+    }
+    if (update) {
+        for (uint32_t o = 0; o < N; o++) {
+            fwgpu_dist *od = g->ranks[o].get();
+            FWGPU_HIP(hipSetDevice(od->r->device));
+            std::vector<unsigned long long> fin((size_t)2 * N);
+            for (uint32_t s = 0; s < N; s++) {
+                fin[s] = (1ull << 32) | cnt[(size_t)s * 2 * N + o];
+                fin[N + s] = (1ull << 32) | cnt[(size_t)s * 2 * N + N + o];
+                od->st_pos_ffm[s] = cnt[(size_t)s * 2 * N + o];
+                od->st_pos_lr[s] = cnt[(size_t)s * 2 * N + N + o];
+            }
+            FWGPU_HIP(hipMemcpy(od->st_mem + geo.off_fin, fin.data(), fin.size() * 8, hipMemcpyHostToDevice));
+        }
+        for (uint32_t o = 0; o < N; o++) {
+            FWGPU_HIP(hipSetDevice(g->ranks[o]->r->device));
+            FWGPU_HIP(hipStreamSynchronize(g->ranks[o]->cstream));
+        }
+    }
+    for (uint32_t j = 0; j < N; j++) {
+        fwgpu_dist *d = g->ranks[j].get();
+        FWGPU_HIP(hipSetDevice(d->r->device));
+        if (preds && preds[j] && d->B) FWGPU_HIP(hipMemcpy(preds[j], d->cur->pred, (size_t)d->B * 4, hipMemcpyDeviceToHost));
     }
     return FWGPU_OK;
 }

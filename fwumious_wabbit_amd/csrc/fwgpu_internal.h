@@ -74,6 +74,31 @@ struct PushRings {
     uint32_t *ffm_key[8];  // per owner: row hash of every pushed gradient row ...
     float *ffm_rows[8];    // ... and its R floats (block_ffm.rs:278: general gradient x gradient cache)
     uint2 *lr_ent[8];      // per owner: {hash, gradient bits} of every pushed LR entry (block_lr.rs:140-147)
+    // ---- streaming form (fwgpu_dist_*_owner_stream): the regions are CIRCULAR and the owners drain them while this kernel runs.  Positions (cnt) run on
+    // from step to step; position q lives in slot q & (cap - 1) for generation q >> log2cap.  A gradient row is complete when its tag word -- hash |
+    // (generation + 1) << 32, stored AFTER the row's floats have been acknowledged -- says so; a slot may be written for generation g when the owner has
+    // said so in THIS rank's memory (ffm_free: per-slot generation; LR: a consumed-prefix credit): no read-modify-write and no poll ever crosses a link.
+    uint32_t stream, log2cap_ffm, log2cap_lr, pad2_;
+    unsigned long long *ffm_tag[8];  // per owner: [cap_ffm] tag words of this source's ring in the owner's memory
+    unsigned long long *lr_word[8];  // per owner: [cap_lr] {hash (30 bits) | ((generation % 3) + 1) << 30, gradient bits << 32}
+    const uint32_t *ffm_free[8];     // source-local, per owner: [cap_ffm] the generation slot q may be written for (the owner's consumer stores it)
+    const uint32_t *lr_credit;       // source-local [n]: LR positions of this source the owner o has consumed (a prefix)
+};
+
+// the owner's side of the streaming form: what its consumer kernel drains (kernels.hip owner_stream_kernel)
+struct OwnerStream {
+    uint32_t n, R, log2cap_ffm, log2cap_lr;
+    const unsigned long long *ffm_tag[8];  // per source: this owner's ring of that source (owner-local memory, written by the source)
+    const float *ffm_rows[8];
+    const unsigned long long *lr_word[8];
+    uint32_t *ffm_free[8];                  // per source: slot -> generation, in the SOURCE's memory
+    uint32_t *lr_credit[8];                 // per source: this owner's word of the source's credit array
+    uint32_t start_ffm[8], start_lr[8];     // first position of this step, per source
+    const unsigned long long *fin;          // owner-local [2n]: {1 << 32 | final position} once the source's kernel has ended (FFM, then LR); 0 before
+    uint32_t *resident;                     // host-visible counter: workgroups of this launch that are running
+    float *w, *acc, *lr;
+    float ffm_rate, ffm_mpt, lr_rate, lr_mpt;
+    const float *lut_ffm, *lut_lr;
 };
 
 // Everything the example kernel needs, passed by value.
@@ -158,6 +183,8 @@ struct KernelParams {
     uint32_t selfw_stride;
     float *gbuf;                        // [n] general gradient of every example (MID -> UPD)
     float *xbuf, *dxbuf;                // deep head, mini-batched: x and d logit/d x per example [n * nn.X]
+    int32_t emit_x;                     // read-only launch of a model with a deep head on the v2 kernel: the example's head input x goes to xbuf, {label, importance} to gbuf,
+                                        // and the layers run afterwards for the whole batch on the matrix cores (regressor.cpp run_batch, head.hip head_step)
 #if defined(FW_KP_PAD_POS) && FW_KP_PAD_POS == 2  // debug builds (scripts/kp_pos_exp.sh): 16 bytes HERE
     unsigned char kp_pos_pad[16];
 #endif
@@ -337,6 +364,8 @@ struct fwgpu_regressor {
     float *d_nn_w = nullptr, *d_nn_acc = nullptr, *d_lut_nn = nullptr;
     uint64_t nn_len = 0;
     void *head_scratch = nullptr;  // mini-batched head (head.hip): activations, masks, gradients of the current batch
+    float *pred_x = nullptr, *pred_yi = nullptr;  // predict-only batches of a model with a deep head: x [n * X] and {label, importance} [2n] of the batch in flight
+    uint32_t pred_cap = 0;
     // scratch for single-example calls
     fwgpu_batch *one = nullptr;
     void *pinned = nullptr;
@@ -493,6 +522,7 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
 int run_batch_peer(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, const PeerShards *d_shards, hipStream_t stream,
                    const PushRings *d_push = nullptr);
 // owner-side apply: the optimizer steps of `n_rows` pushed gradient rows / `n_lr` pushed LR gradients on this regressor's own tables
+hipError_t launch_owner_stream(const OwnerStream &os, int optimizer, uint32_t workgroups, hipStream_t stream);
 hipError_t launch_owner_apply(const fwgpu_regressor *r, float *lr_base, const uint32_t *keys, const float *rows, uint32_t n_rows, const uint2 *lr_ent,
                               uint32_t n_lr, bool in_order, hipStream_t stream);
 struct SplitRanges {  // what a rank owns (sharded tables) and which examples of the launch are its own

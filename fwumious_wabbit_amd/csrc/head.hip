@@ -207,7 +207,10 @@ static hipError_t gemm(const float *A, const float *B, float *C, int M, int N, i
     static const bool env_tiled = std::getenv("FWGPU_HEAD_GEMM_TILED") != nullptr;  // (A/B runs: the LDS-tiled 64 x 64 kernel for every shape)
     const bool old_only = env_tiled || g_force_tiled;
     const bool a_vec = TA || (lda % 4 == 0 && ((uintptr_t)A & 15u) == 0), b_vec = !TB || (ldb % 4 == 0 && ((uintptr_t)B & 15u) == 0);
-    if (!old_only && K >= 8 * kSplitK && K % 8 == 0 && a_vec && b_vec) {
+    // (the split-K kernel is for the small products of a micro-batch -- every 32 x 32 tile of C a workgroup of its own; a predict-only slab of tens of
+    // thousands of rows fills the device with 64 x 64 tiles and re-uses each staged operand 64 times)
+    static const int splitk_max_m = [] { const char *e = std::getenv("FWGPU_HEAD_GEMM_SPLITK_MAX_M"); return e ? std::atoi(e) : 4096; }();
+    if (!old_only && M <= splitk_max_m && K >= 8 * kSplitK && K % 8 == 0 && a_vec && b_vec) {
         dim3 grid((N + 31) / 32, (M + 31) / 32);
         hipLaunchKernelGGL((head_gemm_splitk<TA, TB, EPI>), grid, dim3(64 * kSplitK), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias, aux, relu);
         return hipGetLastError();
@@ -256,6 +259,7 @@ __global__ void __launch_bounds__(256) head_final_kernel(const float *__restrict
         pred[ex] = p;
         gvec[ex] = g;
     }
+    if (!update) return;  // (a predict-only batch has no gradient buffers)
     for (int i = lane; i < wl; i += 64) dz_last[(size_t)ex * wl + i] = g * wf[i] * mask_last[(size_t)ex * wl + i];
     for (int i = lane; i < X; i += 64) dx[(size_t)ex * X + i] = topo_one ? g * wf[wl + i] : 0.0f;
 }

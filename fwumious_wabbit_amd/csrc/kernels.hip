@@ -185,6 +185,7 @@ __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t
 // input gradient, and one product per LR entry
 __host__ __device__ inline uint32_t nn_lds_floats(const KernelParams &p) {
     if (!p.nn.n_layers) return 0;
+    if (p.emit_x) return p.max_lr + 16;  // (the v2 kernel only forms the head's input: one product per LR entry)
     return 2 * p.nn.X + 2 * p.nn.sum_width + p.nn.max_in + p.max_lr + p.nn.max_out + 1 + 16;
 }
 
@@ -1797,6 +1798,78 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
                 // owner's sequence of steps is the reference's (block_ffm.rs:269-286, block_lr.rs:140-150).
                 const PushRings &pr = *p.push;
                 const bool in_order = gridDim.x == 1;
+                if (pr.stream) {
+                    // ---------------- streaming form: circular regions drained by the owners WHILE this kernel runs (owner_stream_kernel)
+                    if (p.has_lr) {
+                        const uint32_t lg = pr.log2cap_lr, capl = 1u << lg;
+                        for (uint32_t t = tid; t < nl; t += bd) {
+                            const uint32_t h = s.l_hash[t], o = h >> p.shards->shift_lr;
+                            const uint32_t pos = atomicAdd(&pr.cnt[pr.n + o], 1u);
+                            // flow control: the owner has consumed every position below credit[o]; `pos` may be written when pos - credit < cap
+                            while ((int32_t)(pos - (__hip_atomic_load(pr.lr_credit + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + capl)) >= 0) __builtin_amdgcn_s_sleep(8);
+                            const float grad = g * s.l_val[t];  // block_lr.rs:143
+                            const unsigned long long word = (unsigned long long)(h | ((((pos >> lg) % 3u) + 1u) << 30)) | ((unsigned long long)__float_as_uint(grad) << 32);
+                            __hip_atomic_store(pr.lr_word[o] + (pos & (capl - 1u)), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                    }
+                    if (k) {
+                        constexpr int PU = 4;  // gradient rows a wave has under way at once
+                        const uint32_t lg = pr.log2cap_ffm, capf = 1u << lg, gmask = lg ? (0xffffffffu >> lg) : 0xffffffffu;
+                        for (uint32_t i0 = (uint32_t)wave * PU; i0 < nf; i0 += (uint32_t)nw * PU) {
+                            uint32_t h_[PU], o_[PU], pos_[PU];
+#pragma unroll
+                            for (int u = 0; u < PU; ++u) {
+                                const uint32_t i = i0 + u;
+                                h_[u] = o_[u] = pos_[u] = 0;
+                                if (i < nf) {
+                                    h_[u] = __builtin_amdgcn_readfirstlane(s.e_hash[i]);
+                                    o_[u] = h_[u] >> p.shards->shift_ffm;
+                                    uint32_t q = 0;
+                                    if (lane == 0) q = atomicAdd(&pr.cnt[o_[u]], 1u);
+                                    pos_[u] = __builtin_amdgcn_readfirstlane(q);
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < PU; ++u) {
+                                const uint32_t i = i0 + u;
+                                if (i >= nf) continue;
+                                const uint32_t slot = pos_[u] & (capf - 1u), gen = (pos_[u] >> lg) & gmask;
+                                // the slot's previous generation has been consumed: the owner says so in this rank's own memory
+                                for (;;) {
+                                    const uint32_t fr = __builtin_amdgcn_readfirstlane(__hip_atomic_load(pr.ffm_free[o_[u]] + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+                                    if ((fr & gmask) == gen) break;
+                                    __builtin_amdgcn_s_sleep(8);
+                                }
+                                const uint32_t f = __builtin_amdgcn_readfirstlane(s.e_fld[i]) & kFldMask;
+                                const __amdgpu_buffer_rsrc_t rr = make_rsrc(pr.ffm_rows[o_[u]] + (size_t)slot * R, R * 4);
+                                const float v = s.e_val[i];
+                                for (uint32_t c = 0; c < nchunk; ++c) {
+                                    const uint32_t e0 = (c * 64 + lane) * VEC;
+                                    if (e0 >= R) continue;
+                                    const uint32_t z = e0 / k;
+                                    V tv = Vec<VEC>::lds_load(s.T + f * R + e0), sw = Vec<VEC>::zero(), gv = Vec<VEC>::zero();
+                                    const bool self = z == f;
+                                    if (self) sw = Vec<VEC>::lds_load(s.selfw + i * k + (e0 - z * k));
+#pragma unroll
+                                    for (int j = 0; j < VEC; ++j) {
+                                        float t_ = Vec<VEC>::get(tv, j);
+                                        if (self) t_ = __fsub_rn(t_, __fmul_rn(Vec<VEC>::get(sw, j), v));  // contra - w*v   block_ffm.rs:238
+                                        Vec<VEC>::set(gv, j, __fmul_rn(g, __fmul_rn(v, t_)));               // block_ffm.rs:239, 278
+                                    }
+                                    Vec<VEC>::template store<kAuxSys>(gv, rr, e0 * 4);
+                                }
+                            }
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows' floats are at their owners: now the words that say so
+#pragma unroll
+                            for (int u = 0; u < PU; ++u) {
+                                if (i0 + u >= nf || lane != 0) continue;
+                                const uint32_t slot = pos_[u] & (capf - 1u), gen = (pos_[u] >> lg) & gmask;
+                                __hip_atomic_store(pr.ffm_tag[o_[u]] + slot, (unsigned long long)h_[u] | ((unsigned long long)((gen + 1u) & gmask) << 32), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_SYSTEM);
+                            }
+                        }
+                    }
+                } else {
                 auto push_lr = [&](uint32_t t) {
                     const uint32_t h = s.l_hash[t], o = h >> p.shards->shift_lr;
                     const uint32_t pos = atomicAdd(&pr.cnt[pr.n + o], 1u);
@@ -1848,6 +1921,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
                         }
                     }
                 }
+                }  // (step-synchronous regions)
             } else {
             if (p.has_lr) lr_update<OPT, COH, SH>(p, s, nl, g, gx, lut_lr, tid, bd, PH == 3 ? p.own_lo_lr : 0u, PH == 3 ? p.own_hi_lr : 0xffffffffu);
             FW_TICK(4);
@@ -2559,11 +2633,16 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         }
         float lrs = 0.0f;
         float2 lr_kept = float2{0.0f, 0.0f};  // this thread's first LR entry as the forward pass read it (lr_update `kept`)
+        const bool emit_x = !COH && p.emit_x;  // (read-only instantiations only)
         if (p.has_lr)
             for (uint32_t i = tid; i < nl; i += bd) {
                 const float2 wa = lr_forward_pair<COH>(p, s, s.l_hash[i]);
                 if (i == (uint32_t)tid) lr_kept = wa;
                 lrs += wa.x * s.l_val[i];
+                if (emit_x) {  // the head's input keeps one sum per combo slot (block_lr.rs:36-45): the products wait in LDS
+                    s.nn[i] = wa.x * s.l_val[i];
+                    if (i + 1 < nl && s.l_combo[i] > s.l_combo[i + 1]) s.ctr[14] = 1;  // (zeroed by the stage phase)
+                }
             }
         dot = wave_sum(dot);
         lrs = wave_sum(lrs);
@@ -2576,6 +2655,57 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
             if (tid == 0) s.ctr[kCtrPfLen] = pf_len;
         }
         __syncthreads();
+        if (emit_x) {
+            // ---------------- deep head, read-only launch: x = [per-combo LR sums | triangle of the FFM pair outputs] (block_misc.rs:864-883, the diagonal in
+            // the reference's per-feature form, as nn_forward) goes to the batch's x buffer; the layers run afterwards for all examples at once (head.hip)
+            float *x = p.xbuf + (size_t)ex * p.nn.X;
+            const uint32_t C = p.num_combos;
+            const bool by_combo = s.ctr[14] == 0;
+            for (uint32_t c = tid; c < C; c += bd) {
+                float acc = 0.0f;
+                if (by_combo) {
+                    uint32_t lo_ = 0, hi_ = nl;  // first entry with l_combo >= c
+                    while (lo_ < hi_) {
+                        const uint32_t mid = (lo_ + hi_) >> 1;
+                        if (s.l_combo[mid] < c) lo_ = mid + 1;
+                        else hi_ = mid;
+                    }
+                    for (uint32_t i = lo_; i < nl && s.l_combo[i] == c; ++i) acc += s.nn[i];
+                } else {
+                    for (uint32_t i = 0; i < nl; ++i)
+                        if (s.l_combo[i] == c) acc += s.nn[i];
+                }
+                x[c] = acc;
+            }
+            const uint32_t NT = F * (F + 1) / 2;
+            for (uint32_t t = tid; t < NT; t += bd) {
+                uint32_t i = (uint32_t)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+                while ((i + 1) * (i + 2) / 2 <= t) ++i;
+                while (i * (i + 1) / 2 > t) --i;
+                const uint32_t j = t - i * (i + 1) / 2;
+                float d = 0.0f;
+                if (i != j) {
+                    for (uint32_t kk = 0; kk < k; ++kk) d += s.T[i * R + j * k + kk] * s.T[j * R + i * k + kk];
+                } else {
+                    for (uint32_t e = s.fstart[i]; e < s.fend[i]; ++e) {
+                        const float v = s.e_val[e];
+                        float corr = 0.0f;
+                        for (uint32_t kk = 0; kk < k; ++kk) {
+                            const float w = s.selfw[e * k + kk];
+                            corr += w * (v * (s.T[i * R + i * k + kk] - w * v));
+                        }
+                        d += corr * 0.5f;
+                    }
+                }
+                x[C + t] = d;
+            }
+            if (tid == 0) {
+                p.gbuf[2 * (size_t)ex] = label;
+                p.gbuf[2 * (size_t)ex + 1] = imp;
+                s.ctr[6] = next_ticket;
+            }
+            continue;
+        }
         float dot_t = 0.0f, dc_t = 0.0f, lr_t = 0.0f;
         for (int w = 0; w < nw; ++w) {
             dot_t += s.red[w];
@@ -2828,7 +2958,7 @@ static hipError_t launch_resident(const KernelParams &p, int optimizer, bool coh
 static bool uses_resident_kernel(const KernelParams &p, uint32_t threads) {
     // rows of up to 256 floats (one 16-byte chunk per lane) or up to 512 (two chunks; a field slot must not straddle the chunks)
     const bool fits = p.R <= 64 * 4 || (p.R <= 64 * 4 * 2 && p.k != 0 && 256 % p.k == 0);
-    return p.k % 4 == 0 && p.aligned4 && fits && p.kernel_version != 1 && p.nn.n_layers == 0 && threads <= FW_LB_THREADS;
+    return p.k % 4 == 0 && p.aligned4 && fits && p.kernel_version != 1 && (p.nn.n_layers == 0 || (p.emit_x && !p.update)) && threads <= FW_LB_THREADS;
 }
 // Whole-line updates and duplicate-row chains exist in the v2 kernel's update path only, and only updating launches need them.
 void resolve_row_mode(KernelParams &p, uint32_t threads) {
@@ -2917,6 +3047,143 @@ __global__ void __launch_bounds__(256) owner_apply_kernel(float *w, float *acc, 
         wa.x -= opt_step<OPT>(grad, wa.y, lr_rate, lr_mpt, lut_lr);  // block_lr.rs:145-147
         lr_store<true>(lr, h, wa);
     }
+}
+
+// The owner's consumer of the STREAMING form: a small persistent grid that drains this owner's circular regions while the sources' kernels fill them
+// (staleness = the examples in flight, not the step: hogwild.rs:89-103 -- a consumer never waits for a step to end).  Workgroups 0 .. n-1: one wave each, the LR
+// ring of source s IN ORDER, 64 positions at a time, publishing a consumed-prefix credit in the source's memory.  The other workgroups' waves: source
+// s = wave % n, positions start + j, start + j + J, ... of that source's row ring; a slot is handed back (ffm_free, in the source's memory) as soon as
+// its gradient row is in registers.  A wave leaves a ring when the ring's final position is known (fin: the source's kernel has ended) and reached.
+template <int OPT>
+__global__ void __launch_bounds__(256) owner_stream_kernel(const OwnerStream os) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, N = os.n;
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(os.resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    auto fin_of = [&](uint32_t idx, uint32_t &fin) -> bool {  // final position of ring idx (FFM: s, LR: n + s), once known
+        const unsigned long long v = __hip_atomic_load(os.fin + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        fin = (uint32_t)v;
+        return (v >> 32) != 0;
+    };
+    if (blockIdx.x < N) {
+        if (wave != 0) return;
+        const uint32_t s = blockIdx.x, lg = os.log2cap_lr, mask = (1u << lg) - 1u;
+        uint32_t base = os.start_lr[s];
+        for (;;) {
+            const uint32_t pq = base + lane;
+            unsigned long long word = 0;
+            bool have = false, past = false;
+            uint32_t fin = 0;
+            for (;;) {  // this lane's position: produced, or never going to be
+                word = __hip_atomic_load(os.lr_word[s] + (pq & mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                have = (((uint32_t)word >> 30) & 3u) == ((pq >> lg) % 3u) + 1u;
+                if (have) break;
+                if (fin_of(N + s, fin) && (int32_t)(pq - fin) >= 0) {
+                    past = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (have) {
+                const uint32_t h = (uint32_t)word & 0x3fffffffu;
+                const float grad = __uint_as_float((uint32_t)(word >> 32));
+                float2 wa = lr_load<true>(os.lr, h);
+                wa.x -= opt_step<OPT>(grad, wa.y, os.lr_rate, os.lr_mpt, os.lut_lr);  // block_lr.rs:145-147
+                lr_store<true>(os.lr, h, wa);
+            }
+            const unsigned long long pm = __ballot(past);
+            const uint32_t done = pm ? (uint32_t)__builtin_ctzll(pm) : 64u;  // positions are consecutive: the first lane beyond the end
+            base += done;
+            if (lane == 0) __hip_atomic_store(os.lr_credit[s], base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (pm) break;
+        }
+        return;
+    }
+    const uint32_t W = (gridDim.x - N) * 4u, gw = (blockIdx.x - N) * 4u + wave;
+    const uint32_t s = gw % N, j = gw / N, J = W / N;
+    if (j >= J) return;
+    const uint32_t lg = os.log2cap_ffm, mask = (1u << lg) - 1u, gmask = lg ? (0xffffffffu >> lg) : 0xffffffffu, R = os.R;
+    for (uint32_t pq = os.start_ffm[s] + j;; pq += J) {
+        const uint32_t slot = pq & mask, gen = (pq >> lg) & gmask;
+        unsigned long long word;
+        bool past = false;
+        for (;;) {
+            unsigned long long wv = 0;
+            if (lane == 0) wv = __hip_atomic_load(os.ffm_tag[s] + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            word = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(wv >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wv);
+            if ((uint32_t)(word >> 32) == ((gen + 1u) & gmask)) break;
+            uint32_t fin = 0;
+            const bool known = fin_of(s, fin);
+            if (known && (int32_t)(pq - fin) >= 0) {
+                past = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (past) break;
+        const uint32_t h = (uint32_t)word;
+        if (((R | h) & 3u) == 0) {
+            const __amdgpu_buffer_rsrc_t rg = make_rsrc(os.ffm_rows[s] + (size_t)slot * R, R * 4), rw = make_rsrc(os.w + h, R * 4), ra = make_rsrc(os.acc + h, R * 4);
+            // (rows of up to 512 floats: both chunks' loads before anything is stepped)
+            f4 gv[2], wv[2], av[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const uint32_t e0 = (c * 64 + lane) * 4;
+                gv[c] = Vec<4>::load<kAuxSys>(rg, e0 * 4);
+                wv[c] = Vec<4>::load<kAuxSc1>(rw, e0 * 4);
+                av[c] = OPT == FWGPU_OPT_SGD ? Vec<4>::zero() : Vec<4>::load<kAuxSc1>(ra, e0 * 4);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (R <= 512 && lane == 0)  // the gradient row is in registers: its slot may be written for the next generation
+                __hip_atomic_store(os.ffm_free[s] + slot, (gen + 1u) & gmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const uint32_t e0 = (c * 64 + lane) * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float a = av[c][q];
+                    wv[c][q] = wv[c][q] - opt_step<OPT>(gv[c][q], a, os.ffm_rate, os.ffm_mpt, os.lut_ffm);  // block_ffm.rs:279-282
+                    av[c][q] = a;
+                }
+                Vec<4>::store<kAuxSc1>(wv[c], rw, e0 * 4);
+                if (OPT != FWGPU_OPT_SGD) Vec<4>::store<kAuxSc1>(av[c], ra, e0 * 4);
+            }
+            for (uint32_t e0 = 512 + lane * 4; e0 < R; e0 += 256) {  // longer rows: the rest chunk by chunk
+                const f4 g2 = Vec<4>::load<kAuxSys>(rg, e0 * 4);
+                f4 w2 = Vec<4>::load<kAuxSc1>(rw, e0 * 4), a2 = OPT == FWGPU_OPT_SGD ? Vec<4>::zero() : Vec<4>::load<kAuxSc1>(ra, e0 * 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float a = a2[q];
+                    w2[q] = w2[q] - opt_step<OPT>(g2[q], a, os.ffm_rate, os.ffm_mpt, os.lut_ffm);
+                    a2[q] = a;
+                }
+                Vec<4>::store<kAuxSc1>(w2, rw, e0 * 4);
+                if (OPT != FWGPU_OPT_SGD) Vec<4>::store<kAuxSc1>(a2, ra, e0 * 4);
+            }
+            if (R > 512) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(os.ffm_free[s] + slot, (gen + 1u) & gmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        } else {
+            for (uint32_t e = lane; e < R; e += 64) {
+                const float grad = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(os.ffm_rows[s] + (size_t)slot * R + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+                float a = OPT == FWGPU_OPT_SGD ? 0.0f : __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned *>(os.acc + h + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                float wv = __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned *>(os.w + h + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                wv -= opt_step<OPT>(grad, a, os.ffm_rate, os.ffm_mpt, os.lut_ffm);
+                __hip_atomic_store(reinterpret_cast<unsigned *>(os.w + h + e), __float_as_uint(wv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (OPT != FWGPU_OPT_SGD) __hip_atomic_store(reinterpret_cast<unsigned *>(os.acc + h + e), __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(os.ffm_free[s] + slot, (gen + 1u) & gmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+hipError_t launch_owner_stream(const OwnerStream &os, int optimizer, uint32_t workgroups, hipStream_t stream) {
+    switch (optimizer) {
+    case FWGPU_OPT_SGD: hipLaunchKernelGGL(owner_stream_kernel<FWGPU_OPT_SGD>, dim3(workgroups), dim3(256), 0, stream, os); break;
+    case FWGPU_OPT_ADAGRAD_FLEX: hipLaunchKernelGGL(owner_stream_kernel<FWGPU_OPT_ADAGRAD_FLEX>, dim3(workgroups), dim3(256), 0, stream, os); break;
+    default: hipLaunchKernelGGL(owner_stream_kernel<FWGPU_OPT_ADAGRAD_LUT>, dim3(workgroups), dim3(256), 0, stream, os); break;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_owner_apply(const fwgpu_regressor *r, float *lr_base, const uint32_t *keys, const float *rows, uint32_t n_rows, const uint2 *lr_ent,

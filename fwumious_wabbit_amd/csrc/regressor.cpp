@@ -455,9 +455,15 @@ static int prepare_launch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int upda
 }
 
 static int run_batch_by_example(fwgpu_regressor *r, fwgpu_batch *b, int update, hipStream_t stream);
+static bool head_predict_batched(const fwgpu_regressor *r, const fwgpu_batch *b, int mode, int update);
+static int run_batch_head_predict(fwgpu_regressor *r, fwgpu_batch *b, hipStream_t stream);
 static int run_batch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, hipStream_t stream) {
     if (b->n == 0) return FWGPU_OK;
     if (b->host_copy) return run_batch_by_example(r, b, update, stream);  // (an example beyond what the fused kernel stages: see learn_one_chunked)
+    if (head_predict_batched(r, b, mode, update)) {
+        const int rcb = run_batch_head_predict(r, b, stream);
+        if (rcb != FWGPU_ERR_RANGE) return rcb;  // (a shape the v2 kernel cannot stage: the per-example forward below)
+    }
     KernelParams p;
     uint32_t threads = 0;
     int rc = prepare_launch(r, b, mode, update, p, threads);
@@ -472,6 +478,63 @@ static int run_batch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, h
     }
     // An updating launch always uses device-scope (sc1) accesses; read-only launches use cached loads.
     FWGPU_HIP(launch_example_kernel(p, r->cfg.optimizer, update != 0, grid, threads, stream));
+    return FWGPU_OK;
+}
+
+// Predict-only batches of a model with a deep head (hold-out passes, serving): the weights are frozen, so nothing orders the examples and the head need
+// not run per example.  The FFM / LR part runs on the v2 kernel (two workgroups per CU, no dense traffic) and leaves every example's head input x
+// (regressor.rs:185-189: LR combo sums | triangle) in a batch buffer; the layers then take the batch through v_mfma_f32_32x32x2_f32 GEMMs, slab by slab
+// (head.hip head_step, update = false) -- the dense weights are read once per slab instead of once per example (block_neural.rs:196-222 per example:
+// 0.77 MB of weights for 1.2 MFLOP).  Same numbers as the per-example forward up to the order of the f32 sums.
+static constexpr uint32_t kHeadPredictSlab = 32768;
+static bool head_predict_batched(const fwgpu_regressor *r, const fwgpu_batch *b, int mode, int update) {
+    static const bool off = getenv("FWGPU_HEAD_PREDICT_PER_EXAMPLE") != nullptr;  // A/B runs and tests: the per-example forward for every launch
+    if (off || update || !r->nn.n_layers || mode != FWGPU_MODE_HOGWILD || b->n < 256 || b->cache || b->emit_T) return false;
+    const uint32_t k = r->cfg.ffm_k, R = k * r->cfg.ffm_num_fields;
+    return k && k % 4 == 0 && b->aligned4 && (R <= 256 || (R <= 512 && 256 % k == 0)) && r->launch.kernel_version != 1;
+}
+static int run_batch_head_predict(fwgpu_regressor *r, fwgpu_batch *b, hipStream_t stream) {
+    const uint32_t X = r->nn.X;
+    if (r->pred_cap < b->n) {
+        FWGPU_HIP(hipStreamSynchronize(stream));
+        if (r->pred_x) (void)hipFree(r->pred_x);
+        if (r->pred_yi) (void)hipFree(r->pred_yi);
+        r->pred_x = r->pred_yi = nullptr;
+        r->pred_cap = 0;
+        if (hipMalloc((void **)&r->pred_x, (size_t)b->n * X * sizeof(float)) != hipSuccess || hipMalloc((void **)&r->pred_yi, (size_t)b->n * 2 * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(FWGPU_ERR_OOM, "predict batch with a deep head: no memory for the head's inputs");
+        }
+        r->pred_cap = b->n;
+    }
+    KernelParams p;
+    uint32_t threads = 0;
+    {   // (prepare_launch with the head's per-example LDS taken out of the picture)
+        p = make_params(r, b, 0);
+        p.emit_x = 1;
+        p.xbuf = r->pred_x;
+        p.gbuf = r->pred_yi;
+        threads = std::min<uint32_t>(r->launch.threads, 512);
+        if ((uint64_t)p.max_ffm > 4ull * threads) return fail(FWGPU_ERR_RANGE, "an example has more than 2048 FFM features");  // (the caller falls back)
+        resolve_row_mode(p, threads);
+        if (example_kernel_lds_bytes(p, r->cfg.optimizer) > r->lds_per_cu) return fail(FWGPU_ERR_RANGE, "example does not fit the LDS");
+    }
+    if (b->work_ring) {
+        int rc = mapped_batch_next_counter(b, stream);
+        if (rc) return rc;
+        p.work = b->work;
+    } else {
+        FWGPU_HIP(hipMemsetAsync(b->work, 0, sizeof(uint32_t), stream));
+    }
+    FWGPU_HIP(launch_example_kernel(p, r->cfg.optimizer, false, 0, threads, stream));
+    fwgpu_split view;
+    view.owner = r;
+    view.d_x = r->pred_x;
+    view.d_g = r->pred_yi;
+    for (uint32_t first = 0; first < b->n; first += kHeadPredictSlab) {
+        int rc = head_step(r, &view, first, std::min(kHeadPredictSlab, b->n - first), b->pred + first, /*update=*/false, stream);
+        if (rc) return rc;
+    }
     return FWGPU_OK;
 }
 
@@ -678,6 +741,8 @@ int fwgpu_free(fwgpu_regressor *r) {
     (void)hipSetDevice(r->device);
     if (r->one) fwgpu_batch_free(r->one);
     head_scratch_free(r);
+    if (r->pred_x) (void)hipFree(r->pred_x);
+    if (r->pred_yi) (void)hipFree(r->pred_yi);
     (void)hipFree(r->d_lr);
     (void)hipFree(r->d_ffm_w);
     (void)hipFree(r->d_ffm_acc);
@@ -899,7 +964,11 @@ static uint32_t chunk_entries(const fwgpu_regressor *r) {
 }
 
 static int learn_one_chunked(fwgpu_regressor *r, const HostBatch &hb, uint32_t e, int update, float *prediction) {
-    if (r->nn.n_layers) return fail(FWGPU_ERR_RANGE, "an example has more than 4096 FFM features or LR entries: not covered for models with a deep head");
+    // With a deep head (regressor.rs:191-323) the chunks' partial records still add up -- per-combo LR sums, field sums, corrections, counts -- so MID forms
+    // the head's input x from the TOTAL record once, the head runs once on it (a "mini-batch" of one example is the reference's per-example rule: one
+    // AdaGrad step per dense weight with this example's gradient, input gradients from the pre-step weights, block_neural.rs:252-340), and every chunk's
+    // update takes the example's per-slot gradients dx.
+    const bool head = r->nn.n_layers != 0;
     const uint32_t f0 = hb.ffm_off[e], f1 = hb.ffm_off[e + 1], l0 = hb.lr_off[e], l1 = hb.lr_off[e + 1];
     const uint32_t nf = f1 - f0, nl = l1 - l0, kChunkEntries = chunk_entries(r);
     const uint32_t m = std::max<uint32_t>(1, std::max((nf + kChunkEntries - 1) / kChunkEntries, (nl + kChunkEntries - 1) / kChunkEntries));
@@ -936,20 +1005,29 @@ static int learn_one_chunked(fwgpu_regressor *r, const HostBatch &hb, uint32_t e
     if (rc) return done(rc);
     SplitRanges rg;
     rg.home_lo = 0;
-    rg.home_hi = 1;  // the label and the importance enter the total once: chunk 0 contributes them
+    rg.home_hi = m;  // every chunk is "home": the features-per-field counts of the chunks add up like the sums (the head's diagonal needs the example's)
     if ((rc = split_forward(r, cb, sp, FWGPU_MODE_HOGWILD, rg, 0))) return done(rc);
     const size_t SL = sp->split_len;
     for (uint32_t j = 1; j < m; j++)
         if (launch_add(sp->d_split, sp->d_split + (size_t)j * SL, SL, 0) != hipSuccess) return done(fail(FWGPU_ERR_DEVICE, "chunked example: add failed"));
-    if ((rc = split_mid(r, sp, 0, 1, cb->pred, false, 0))) return done(rc);
+    {   // ... the label and the importance enter the total ONCE (every chunk carried them)
+        const uint32_t F = r->cfg.ffm_k ? r->cfg.ffm_num_fields : 0, R = F * r->cfg.ffm_k;
+        const float li[2] = {hb.label[e], hb.importance[e]};
+        if (hipMemcpyAsync(sp->d_split + (size_t)F * R + 2 * (size_t)F + sp->nlr, li, sizeof(li), hipMemcpyHostToDevice, 0) != hipSuccess || hipStreamSynchronize(0) != hipSuccess)
+            return done(fail(FWGPU_ERR_DEVICE, "chunked example: label write failed"));
+    }
+    if ((rc = split_mid(r, sp, 0, 1, cb->pred, head, 0))) return done(rc);
     const bool upd = update && hb.importance[e] != 0.0f;  // regressor.rs:366
+    if (head && (rc = head_step(r, sp, 0, 1, cb->pred, upd, 0))) return done(rc);
     if (upd) {
+        const size_t X = head ? r->nn.X : 0;
         for (uint32_t j = 1; j < m; j++) {
             if (hipMemcpyAsync(sp->d_split + (size_t)j * SL, sp->d_split, SL * 4, hipMemcpyDeviceToDevice, 0) != hipSuccess ||
-                hipMemcpyAsync(sp->d_g + j, sp->d_g, 4, hipMemcpyDeviceToDevice, 0) != hipSuccess)
+                (!head && hipMemcpyAsync(sp->d_g + j, sp->d_g, 4, hipMemcpyDeviceToDevice, 0) != hipSuccess) ||
+                (head && hipMemcpyAsync(sp->d_dx + (size_t)j * X, sp->d_dx, X * 4, hipMemcpyDeviceToDevice, 0) != hipSuccess))
                 return done(fail(FWGPU_ERR_DEVICE, "chunked example: copy failed"));
         }
-        if ((rc = split_update(r, cb, sp, FWGPU_MODE_SEQUENTIAL, rg, false, 0))) return done(rc);
+        if ((rc = split_update(r, cb, sp, FWGPU_MODE_SEQUENTIAL, rg, head, 0))) return done(rc);
     }
     if (hipMemcpyAsync(prediction, cb->pred, 4, hipMemcpyDeviceToHost, 0) != hipSuccess) return done(fail(FWGPU_ERR_DEVICE, "chunked example: read-back failed"));
     return done(FWGPU_OK);
@@ -978,7 +1056,7 @@ static int learn_host_example(fwgpu_regressor *r, const HostBatch &hb, uint32_t 
     if (rc) return rc;
     if ((rc = batch_upload(r->one, one, 0))) return rc;
     rc = run_batch(r, r->one, FWGPU_MODE_SEQUENTIAL, update, 0);
-    if (rc == FWGPU_ERR_RANGE && !r->nn.n_layers) return learn_one_chunked(r, hb, e, update, prediction);
+    if (rc == FWGPU_ERR_RANGE) return learn_one_chunked(r, hb, e, update, prediction);
     if (rc) return rc;
     return one_prediction(r, prediction);
 }
@@ -1013,7 +1091,7 @@ static int learn_one(fwgpu_regressor *r, const fwgpu_lr_entry *lr, uint32_t n_lr
     if (rc) return rc;
     rc = run_batch(r, r->one, FWGPU_MODE_SEQUENTIAL, update, 0);
     // (fewer than 4096 entries of each kind, but together more than the LDS holds: prepare_launch refuses before anything is launched)
-    if (rc == FWGPU_ERR_RANGE && !r->nn.n_layers) return learn_one_chunked(r, hb, 0, update, prediction);
+    if (rc == FWGPU_ERR_RANGE) return learn_one_chunked(r, hb, 0, update, prediction);
     if (rc) return rc;
     return one_prediction(r, prediction);
 }

@@ -181,6 +181,24 @@ class DistGroup:
         check(capi.lib().fwgpu_dist_group_learn_owner(self.h, C.byref(translator.c), recp, offp, ns.ctypes.data_as(C.c_void_p), outp, 1 if update else 0))
         return [o[:int(n)] for o, n in zip(outs, ns)]
 
+    def learn_owner_stream(self, translator, records_per_rank=None, rec_off_per_rank=None, batches=None, update=True, log2_rows=0, log2_lr=0, consumer_workgroups=0):
+        """one step of the STREAMING owner-side apply (fwgpu_dist_group_learn_owner_stream): the owners drain their regions while the sources' kernels
+        fill them.  Either host records per rank (-> predictions per rank) or `batches`: one device-resident record batch per rank (predictions land there)."""
+        if batches is not None:
+            bp = (C.c_void_p * self.n)(*[b.h for b in batches])
+            check(capi.lib().fwgpu_dist_group_learn_owner_stream(self.h, C.byref(translator.c), None, None, None, bp, None, 1 if update else 0, int(log2_rows), int(log2_lr),
+                                                                 int(consumer_workgroups)))
+            return None
+        rr = [_recs(a, b) for a, b in zip(records_per_rank, rec_off_per_rank)]
+        ns = np.array([len(b) - 1 for _, b in rr], dtype=np.uint32)
+        outs = [np.zeros(max(int(n), 1), dtype=np.float32) for n in ns]
+        recp = (C.c_void_p * self.n)(*[a.ctypes.data for a, _ in rr])
+        offp = (C.c_void_p * self.n)(*[b.ctypes.data for _, b in rr])
+        outp = (C.c_void_p * self.n)(*[o.ctypes.data for o in outs])
+        check(capi.lib().fwgpu_dist_group_learn_owner_stream(self.h, C.byref(translator.c), recp, offp, ns.ctypes.data_as(C.c_void_p), None, outp, 1 if update else 0,
+                                                             int(log2_rows), int(log2_lr), int(consumer_workgroups)))
+        return [o[:int(n)] for o, n in zip(outs, ns)]
+
     def gather_tables(self):
         check(capi.lib().fwgpu_dist_group_gather_tables(self.h))
 

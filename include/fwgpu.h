@@ -301,6 +301,15 @@ int fwgpu_dist_learn_owner(fwgpu_dist *d, const fwgpu_translator_config *t, cons
                            float *predictions, int update);
 int fwgpu_dist_group_learn_owner(fwgpu_dist_group *g, const fwgpu_translator_config *t, const uint32_t *const *records,
                                  const uint64_t *const *rec_off, const uint32_t *n, float *const *predictions, int update);
+/* STREAMING form of the owner-side apply: the owners drain their regions WHILE the sources' kernels fill them (a persistent consumer grid per owner,
+ * circular regions, flow control through words the owner stores in the source's memory: no read-modify-write and no poll crosses a link), so that the
+ * staleness of a gradient is the examples in flight -- as with hogwild.rs:89-103's threads -- whatever the step's size; the step-synchronous form above is
+ * bounded to ~1024 global examples per step by stability.  HOGWILD only.  batches (or NULL): rank j's micro-batch already in HBM (a record batch of
+ * its regressor; predictions land in the batch), else records / rec_off / n.  log2_rows / log2_lr: capacity of one (owner, source) region in gradient
+ * rows / LR gradients (0: 2^15 / 2^16); consumer_workgroups: size of an owner's consumer grid (0: 48). */
+int fwgpu_dist_group_learn_owner_stream(fwgpu_dist_group *g, const fwgpu_translator_config *t, const uint32_t *const *records, const uint64_t *const *rec_off,
+                                        const uint32_t *n, fwgpu_batch *const *batches, float *const *predictions, int update, uint32_t log2_rows,
+                                        uint32_t log2_lr, uint32_t consumer_workgroups);
 int fwgpu_dist_rank(const fwgpu_dist *d, int *rank, int *n_ranks);
 /* ranks of the job as the RCCL communicator itself counts them (ncclCommCount); 0 for a member of an in-process group */
 int fwgpu_dist_comm_count(const fwgpu_dist *d, int *count);

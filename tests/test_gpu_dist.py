@@ -475,6 +475,93 @@ def test_owner_side_apply_concurrent_reaches_the_sequential_oracles_holdout_loss
     assert gpu_hold < 0.6931 and abs(gpu_hold - ref_hold) < gap / 3, (gpu_hold, ref_hold)
 
 
+@pytest.mark.parametrize("n_ranks,log2_rows,log2_lr", [(1, 7, 7), (2, 6, 6), (4, 8, 9)])
+def test_owner_side_apply_streaming_form_delivers_every_gradient_exactly_once(n_ranks, log2_rows, log2_lr):
+    """The STREAMING owner-side apply (fwgpu_dist_group_learn_owner_stream): circular regions much smaller than a step (64 .. 256 slots for ~9000
+    gradient rows per source and step: dozens of generations, flow control on every slot), consumers draining while the sources push, positions running
+    on over two steps.  SGD steps ADD UP (w -= lr * grad) and, with no constant feature and ids drawn uniformly from 10^7, an example's prediction hangs
+    on rows hardly any other example touches -- so the tables the streaming form leaves must equal, entry for entry, what the step-synchronous form
+    (fwgpu_dist_group_learn_owner: nothing in flight when the owners apply) leaves on the same job.  A lost, repeated or torn slot is a wrong entry.
+    (Entries two concurrent consumers step at the same moment may lose a step in either form -- hogwild inside the owner: a handful are allowed.)"""
+    n_ns, k, bits, ffm_bits = 6, 4, 20, 20
+    combos = [fw.FeatureComboDesc([fw.NamespaceDescriptor(i)]) for i in range(n_ns)]
+    mi = fw.ModelInstance(learning_rate=0.01, ffm_learning_rate=0.01, bit_precision=bits, power_t=0.5, ffm_power_t=0.5, add_constant_feature=False,
+                          feature_combo_descs=combos, ffm_fields=[[fw.NamespaceDescriptor(i)] for i in range(n_ns)], ffm_k=k, ffm_bit_precision=ffm_bits,
+                          init_acc_gradient=1.0, ffm_init_acc_gradient=1.0, optimizer=fw.Optimizer.SGD)
+    fbt = fw.FeatureBufferTranslator(mi)
+    n_ex = 3000 - 3000 % n_ranks
+    recs, off = fw.synth_records(n_ns, 0.5, 0.0, 10_000_000, 0.3, 77, 0, 2 * n_ex)
+    per = n_ex // n_ranks
+    tabs = {}
+    for form in ("stream", "sync"):
+        regs = [fw.Regressor(mi) for _ in range(n_ranks)]
+        g = DistGroup(regs)
+        g.set_mode(capi.MODE_HOGWILD)
+        for step in range(2):
+            rr, oo = [], []
+            for j in range(n_ranks):
+                a_, b_ = step * n_ex + j * per, step * n_ex + (j + 1) * per
+                rr.append(recs[int(off[a_]):int(off[b_])])
+                oo.append(off[a_:b_ + 1] - off[a_])
+            if form == "stream":
+                g.learn_owner_stream(fbt, rr, oo, log2_rows=log2_rows, log2_lr=log2_lr, consumer_workgroups=5 * n_ranks)
+            else:
+                g.learn_owner(fbt, rr, oo)
+        g.gather_tables()
+        tabs[form] = [regs[0].table_read(t) for t in (capi.TABLE_LR, capi.TABLE_FFM_W)]
+        if form == "stream":
+            init = fw.Regressor(mi)
+            w0 = init.table_read(capi.TABLE_FFM_W)
+            init.close()
+        g.close()
+        for r in regs:
+            r.close()
+    for name, a_, b_ in (("LR", tabs["stream"][0], tabs["sync"][0]), ("FFM", tabs["stream"][1], tabs["sync"][1])):
+        bad = np.abs(a_ - b_) > 2e-6 + 1e-4 * np.abs(b_)
+        assert int(bad.sum()) <= max(8, int(0.002 * np.count_nonzero(b_ != 0))), (name, int(bad.sum()), float(np.abs(a_ - b_).max()))
+    assert np.count_nonzero(tabs["sync"][0]) > 5 * n_ex            # the LR entries did move (6+ per example, collisions aside) ...
+    assert np.count_nonzero(tabs["sync"][1] != w0) > 20 * n_ex      # ... and so did the rows
+
+
+@pytest.mark.statistical
+@pytest.mark.parametrize("n_ranks", [2, 4])
+def test_owner_side_apply_streaming_form_learns_at_steps_far_beyond_the_synchronous_forms_bound(n_ranks):
+    """Steps of 16 384 examples -- 16x what the step-synchronous form tolerates (it applies a whole step's gradients, all taken at the step's first
+    weights: stable to ~1024) -- through the streaming form: the owners apply while the sources run, the staleness of a gradient is the examples in
+    flight.  Hold-out loss of the gathered model against the sequential oracle's, same tolerance as the other concurrent paths."""
+    n_train, n_hold = 49152, 6000
+    mi, ocfg, ots = make_pair(10, 4, 18, 18, fw.Optimizer.AdagradLUT)
+    recs, off = fw.synth_records(10, 0.0, 1.1, 100000, 0.0, 20240611, 0, n_train + n_hold)
+    y = record_labels(recs, off)
+    om = fwo.Model(ocfg)
+    _, p = om.run_stream(ots, recs, off, holdout_after=n_train + 1, nthreads=1)
+    ref_hold = float(logloss(p[n_train:], y[n_train:]).mean())
+    regs = [fw.Regressor(mi) for _ in range(n_ranks)]
+    fbt = fw.FeatureBufferTranslator(mi)
+    g = DistGroup(regs)
+    g.set_mode(capi.MODE_HOGWILD)
+    step = 16384
+    per = step // n_ranks
+    for s0 in range(0, n_train - step + 1, step):
+        rr, oo = [], []
+        for j in range(n_ranks):
+            a, b = s0 + j * per, s0 + (j + 1) * per
+            rr.append(recs[int(off[a]):int(off[b])])
+            oo.append(off[a:b + 1] - off[a])
+        g.learn_owner_stream(fbt, rr, oo)
+    g.gather_tables()
+    hb = regs[0].record_batch(fbt, recs[int(off[n_train]):], off[n_train:] - off[n_train])
+    regs[0].learn_batch(hb, capi.MODE_HOGWILD, False)
+    gpu_hold = float(logloss(hb.predictions(), y[n_train:]).mean())
+    hb.close()
+    g.close()
+    for r in regs:
+        r.close()
+    gap = 0.6931 - ref_hold
+    print(f"owner-side apply, streaming form, {n_ranks} ranks, steps of {step}: hold-out {gpu_hold:.4f}, sequential oracle {ref_hold:.4f}, learnable gap {gap:.4f}")
+    assert gpu_hold < 0.6931 and abs(gpu_hold - ref_hold) < gap / 3, (gpu_hold, ref_hold)
+
+
 def test_group_sparse_step_is_reproducible_at_scale():
     """Regression test of the in-process group's schedule ("the concurrency fault"): the ranks' local phases are ordered
     ON THE DEVICE by events, no host synchronisation between them; at a size where unordered ranks were seen to go wrong (2048

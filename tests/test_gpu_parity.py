@@ -1089,6 +1089,56 @@ def test_chunked_path_where_the_phase_kernels_keep_t_in_the_split_record():
     _chunked_path_parity(6000, fw.Optimizer.AdagradLUT, F=30, k=16, bits=18, ffm_bits=22)
 
 
+def test_oversize_example_with_a_deep_head_takes_the_chunked_path():
+    """6 000 features + a 2 x 256 ReLU head.  The chunks' partial records add up (per-combo LR sums, field sums, corrections, counts),
+    MID forms the head's input from the total once, the head runs once on it (one example = the reference's per-example rule, block_neural.rs:252-340),
+    every chunk's update takes the per-slot gradients.  Against the oracle's per-example head: a predict, three learn calls on huge examples, an ordinary
+    example through the fused kernel; per-call predictions and the final NN / FFM / LR tables."""
+    F, k, bits, ffm_bits, n_feat = 8, 4, 16, 16, 6000
+    layers = [(256, "relu", "hu"), (256, "relu", "hu")]
+    mi, ocfg, _ = make_pair(F, k, bits, ffm_bits, fw.Optimizer.AdagradLUT, lr=0.01, ffm_lr=0.01)
+    mi.nn_layers = [dict(width=w, activation=a, init=i) for w, a, i in layers]
+    mi.nn_topology = "one"
+    mi.nn_learning_rate, mi.nn_power_t, mi.nn_init_acc_gradient = 0.01, 0.45, 1.0
+    om = fwo.Model(ocfg, nn=fwo.make_nn_config(layers, "one", 0.01, 0.45, 1.0))
+    re = fw.Regressor(mi)
+    L = len(layers)
+    re.table_write(capi.TABLE_NN_W, np.concatenate([om.nn_weights(l).copy() for l in range(L + 1)]))  # (Hu draws are implementation-defined: same ones)
+    rng = np.random.default_rng(4242)
+
+    def example(n):
+        fld = np.sort(rng.integers(0, F, size=n))
+        h = (rng.integers(0, (1 << ffm_bits) // k, size=n) * k).astype(np.int64)
+        h[n // 2] = h[7]
+        h[n - 5] = h[11] + k
+        v = rng.uniform(0.002, 0.02, size=n)
+        ffm = [(int(h[i]), float(v[i]), int(fld[i]) * k) for i in range(n)]
+        lh = rng.integers(0, 1 << bits, size=n)
+        lh[n - 3] = lh[2]
+        lr = [(int(lh[i]), float(v[i]), int(fld[i])) for i in range(n)] + [(11650396 & ((1 << bits) - 1), 1.0, F)]
+        return lr, ffm
+
+    worst = 0.0
+    for step in range(5):
+        lr, ffm = example(n_feat if step < 4 else 40)
+        label = float(step % 2)
+        fb = fw.lr_and_ffm_vec(lr, ffm, label=label)
+        if step == 0:
+            p_gpu, p_cpu = re.predict(fb), om.predict(fwo.lr_entries(lr), fwo.ffm_entries(ffm))
+        else:
+            p_gpu, p_cpu = re.learn(fb, None, True), om.learn(fwo.lr_entries(lr), fwo.ffm_entries(ffm), label, 1.0, True)
+        worst = max(worst, abs(p_gpu - p_cpu))
+    assert worst < 5e-5, worst
+    w1 = np.concatenate([om.nn_weights(l) for l in range(L + 1)])
+    a1 = np.concatenate([om.nn_acc(l) for l in range(L + 1)])
+    for which, ref in ((capi.TABLE_NN_W, w1), (capi.TABLE_NN_ACC, a1), (capi.TABLE_FFM_W, om.ffm_weights), (capi.TABLE_FFM_ACC, om.ffm_acc),
+                       (capi.TABLE_LR, om.lr_table)):
+        got, ref = re.table_read(which), np.asarray(ref).reshape(-1)
+        bad = np.abs(got - ref[:len(got)]) > 3e-5 + 1e-4 * np.abs(ref[:len(got)])
+        assert int(bad.sum()) <= 3, (which, int(bad.sum()), float(np.abs(got - ref[:len(got)]).max()))
+    re.close()
+
+
 def test_oversize_records_through_record_batches_and_the_trainer():
     """Records that translate to more entries than a workgroup stages (two namespaces of 3000 features each: 6006 FFM features, 6007 LR entries)
     between ordinary ones: a raw-record batch with such a record is translated on the host and walked in order, and so is the trainer's
