@@ -567,7 +567,7 @@ def main():
                          "the line carries final_logloss per pass, the spread and the CPU oracle's values (sequential and 16-thread hogwild) on the same stream")
     ap.add_argument("--long-steps", dest="long_steps", type=int, default=256)
     ap.add_argument("--long-passes", dest="long_passes", type=int, default=3)
-    ap.add_argument("--store-policy", dest="store_policy", type=int, default=None, choices=[0, 1, 2], help="A/B: FFM row store policy (kernels.hip top); default = the build's")
+    ap.add_argument("--store-policy", dest="store_policy", type=int, default=None, choices=[0, 1, 2, 3], help="A/B: FFM row store policy (kernels.hip top); default = the build's")
     ap.add_argument("--launch-timeout", dest="launch_timeout", type=float, default=1500.0,
                     help="self-launched N>1 run (no WORLD_SIZE in the environment): seconds after which the parent ends its ranks and exits non-zero")
     args = ap.parse_args()

@@ -150,6 +150,8 @@ def lib():
         "fwgpu_dist_learn_owner": [vp, P(TranslatorConfig), vp, vp, u32, vp, i32],
         "fwgpu_dist_group_learn_owner": [vp, P(TranslatorConfig), vp, vp, vp, vp, i32],
         "fwgpu_dist_group_learn_owner_stream": [vp, P(TranslatorConfig), vp, vp, vp, vp, vp, i32, u32, u32, u32],
+        "fwgpu_dist_owner_stream_attach": [vp, u32, u32],
+        "fwgpu_dist_learn_owner_stream": [vp, P(TranslatorConfig), vp, vp, u32, vp, i32, u32],
         "fwgpu_dist_learn_peer": [vp, P(TranslatorConfig), vp, vp, u32, vp, i32],
         "fwgpu_dist_learn_peer_batch": [vp, P(TranslatorConfig), vp, i32, vp],
         "fwgpu_dist_barrier": [vp],

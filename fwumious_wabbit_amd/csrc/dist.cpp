@@ -184,9 +184,8 @@ struct fwgpu_dist {
     size_t st_bytes = 0;
     uint32_t st_lg_ffm = 0, st_lg_lr = 0, st_n = 0;
     uint32_t st_pos_ffm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_pos_lr[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // as OWNER: positions of source s's rings consumed so far
-    hipStream_t cstream = nullptr;     // the consumer kernel's stream
-    uint32_t *h_resident = nullptr;    // pinned + mapped: consumer workgroups of the current launch that are running
-    PushRings *d_push_st = nullptr;
+    uint32_t st_share = 1;             // ranks of the job on this rank's device (their kernels must be resident together: each takes an equal share of the device)
+    uint32_t st_step = 0;              // streaming steps since the last reset (tags the final positions: a consumer only believes its own step's)
     unsigned char *st_peer[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // every rank's st_mem as reachable from here
     PeerShards *d_peers = nullptr;   // peer-sharded step: the owners' table bases, on this rank's device
     bool peers_attached = false;     // process-per-rank peer mode: the other ranks' tables are mapped (hipIpcOpenMemHandle)
@@ -225,9 +224,6 @@ struct fwgpu_dist {
         for (void *q : ipc_open) (void)hipIpcCloseMemHandle(q);
         if (lr_shard) (void)hipFree(lr_shard);
         if (st_mem) (void)hipFree(st_mem);
-        if (d_push_st) (void)hipFree(d_push_st);
-        if (h_resident) (void)hipHostFree(h_resident);
-        if (cstream) (void)hipStreamDestroy(cstream);
         if (d_peers) (void)hipFree(d_peers);
         if (own_rings) (void)hipFree(own_rings);
         if (d_push_cnt) (void)hipFree(d_push_cnt);
@@ -1655,17 +1651,18 @@ int fwgpu_dist_group_learn_owner(fwgpu_dist_group *g, const fwgpu_translator_con
 // ------------------------------------------------------------------ owner-side apply, STREAMING form
 // The step-synchronous form above applies a step's gradients when the step's kernels have ended: every gradient of the step was taken at the step's
 // first weights and every one of them lands, which bounds the step to ~1024 global examples.  Here the owners drain their regions WHILE the
-// sources' kernels fill them: a persistent consumer grid per owner (kernels.hip owner_stream_kernel), circular regions, flow control through words the
-// owner stores in the SOURCE's memory -- staleness = the examples in flight, like hogwild.rs:89-103, whatever the step's size.  Per step: consumers up
-// (the host waits until every consumer workgroup is running: a source that found the device full could otherwise wait for a consumer that never
-// starts), sources' kernels, their final positions to the owners, consumers drain and leave.  No collective in the data path, one small read-back.
+// sources fill them: the first workgroups of every rank's example kernel are that rank's consumers (kernels.hip owner_stream_consume), the regions are
+// circular, flow control goes through words the owner stores in the SOURCE's memory, and a source's last producer workgroup stores the regions' final
+// positions of the step into the owners' memory -- staleness = the examples in flight, like hogwild.rs:89-103, whatever the step's size; no collective,
+// no host round trip and no second stream inside a step.  What it needs is what hogwild needs: the ranks' kernels RUN AT THE SAME TIME (one process per
+// GPU: always; an in-process group sharing one device: one hardware queue per rank, i.e. up to four ranks).
 namespace {
 struct StreamGeom {
     uint32_t N, R, lg_ffm, lg_lr;
-    size_t off_tag, off_rows, off_lr, off_fin, off_free, off_credit, off_cnt, bytes;
+    size_t off_tag, off_rows, off_lr, off_fin, off_free, off_credit, off_cnt, off_done, off_own, off_push, bytes;
 };
 StreamGeom stream_geom(uint32_t N, uint32_t R, uint32_t lg_ffm, uint32_t lg_lr) {
-    StreamGeom g{N, R, lg_ffm, lg_lr, 0, 0, 0, 0, 0, 0, 0, 0};
+    StreamGeom g{N, R, lg_ffm, lg_lr, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t cf = (size_t)1 << lg_ffm, cl = (size_t)1 << lg_lr;
     size_t o = 0;
@@ -1676,17 +1673,16 @@ StreamGeom stream_geom(uint32_t N, uint32_t R, uint32_t lg_ffm, uint32_t lg_lr) 
     g.off_free = o; o = up(o + (size_t)N * cf * 4);             // source role, per owner
     g.off_credit = o; o = up(o + (size_t)N * 4);
     g.off_cnt = o; o = up(o + (size_t)2 * N * 4);
+    g.off_done = o; o = up(o + 4);
+    g.off_own = o; o = up(o + sizeof(OwnerStream));             // the two descriptors the kernel reads
+    g.off_push = o; o = up(o + sizeof(PushRings));
     g.bytes = o;
     return g;
 }
-// first use, another size, or positions close to the 32-bit wrap (generations are compared modulo: a fresh start at a step boundary is simpler than proving the wrap)
 int stream_reserve(fwgpu_dist *d, uint32_t N, uint32_t lg_ffm, uint32_t lg_lr, bool *fresh) {
     const uint32_t R = d->r->cfg.ffm_k ? d->r->cfg.ffm_k * d->r->cfg.ffm_num_fields : 0;
     const StreamGeom g = stream_geom(N, R, lg_ffm, lg_lr);
     FWGPU_HIP(hipSetDevice(d->r->device));
-    if (!d->cstream) FWGPU_HIP(hipStreamCreateWithFlags(&d->cstream, hipStreamNonBlocking));
-    if (!d->h_resident) FWGPU_HIP(hipHostMalloc((void **)&d->h_resident, 64, hipHostMallocMapped));
-    if (!d->d_push_st) FWGPU_HIP(hipMalloc((void **)&d->d_push_st, sizeof(PushRings)));
     *fresh = false;
     if (!d->st_mem || d->st_bytes != g.bytes || d->st_lg_ffm != lg_ffm || d->st_lg_lr != lg_lr || d->st_n != N) {
         if (d->st_mem) (void)hipFree(d->st_mem);
@@ -1703,7 +1699,9 @@ int stream_reserve(fwgpu_dist *d, uint32_t N, uint32_t lg_ffm, uint32_t lg_lr, b
     }
     return FWGPU_OK;
 }
-int stream_reset(fwgpu_dist *d) {  // everything back to position 0 (tags, free generations, credits, counters)
+// everything back to position 0 (tags, free generations, credits, counters, final positions): first use, and when positions come close to the 32-bit
+// wrap (generations are compared modulo: a fresh start at a step boundary is simpler than proving the wrap)
+int stream_reset(fwgpu_dist *d) {
     const uint32_t R = d->r->cfg.ffm_k ? d->r->cfg.ffm_k * d->r->cfg.ffm_num_fields : 0;
     const StreamGeom g = stream_geom(d->st_n, R, d->st_lg_ffm, d->st_lg_lr);
     FWGPU_HIP(hipSetDevice(d->r->device));
@@ -1711,13 +1709,95 @@ int stream_reset(fwgpu_dist *d) {  // everything back to position 0 (tags, free 
     FWGPU_HIP(hipMemsetAsync(d->st_mem + g.off_lr, 0, g.bytes - g.off_lr, d->stream));
     FWGPU_HIP(hipStreamSynchronize(d->stream));
     for (int s = 0; s < 8; s++) d->st_pos_ffm[s] = d->st_pos_lr[s] = 0;
+    d->st_step = 0;
+    return FWGPU_OK;
+}
+uint32_t stream_consumer_wgs(uint32_t N, uint32_t wish, uint32_t waves_per_wg) {
+    // consumer waves: n for the LR regions + a multiple of n for the row regions' stripes
+    uint32_t G = wish ? wish : 32;
+    while ((uint64_t)G * waves_per_wg < 2ull * N) G++;
+    return G;
+}
+// One rank's launch of a streaming step: the descriptors of both roles go to the rank's own allocation, then the example kernel with the consumers on top.
+// base[j] = rank j's allocation as reachable from this rank.
+int stream_launch(fwgpu_dist *d, const StreamGeom &geo, unsigned char *const base[8], float *lr_base, int update, uint32_t consumer_wgs) {
+    const uint32_t N = geo.N, R = geo.R, me = (uint32_t)d->rank;
+    const size_t cf = (size_t)1 << geo.lg_ffm, cl = (size_t)1 << geo.lg_lr;
+    FWGPU_HIP(hipSetDevice(d->r->device));
+    OwnerStream os{};
+    os.n = N;
+    os.R = R;
+    os.log2cap_ffm = geo.lg_ffm;
+    os.log2cap_lr = geo.lg_lr;
+    os.step = d->st_step;
+    for (uint32_t s = 0; s < N; s++) {
+        os.ffm_tag[s] = reinterpret_cast<const unsigned long long *>(d->st_mem + geo.off_tag) + (size_t)s * cf;
+        os.ffm_rows[s] = reinterpret_cast<const float *>(d->st_mem + geo.off_rows) + (size_t)s * cf * R;
+        os.lr_word[s] = reinterpret_cast<const unsigned long long *>(d->st_mem + geo.off_lr) + (size_t)s * cl;
+        os.ffm_free[s] = reinterpret_cast<uint32_t *>(base[s] + geo.off_free) + (size_t)me * cf;
+        os.lr_credit[s] = reinterpret_cast<uint32_t *>(base[s] + geo.off_credit) + me;
+        os.start_ffm[s] = d->st_pos_ffm[s];
+        os.start_lr[s] = d->st_pos_lr[s];
+    }
+    os.fin = reinterpret_cast<const unsigned long long *>(d->st_mem + geo.off_fin);
+    os.w = d->r->d_ffm_w;
+    os.acc = d->r->d_ffm_acc;
+    os.lr = lr_base;
+    os.ffm_rate = d->r->cfg.ffm_learning_rate;
+    os.ffm_mpt = -d->r->cfg.ffm_power_t;
+    os.lr_rate = d->r->cfg.learning_rate;
+    os.lr_mpt = -d->r->cfg.power_t;
+    os.lut_ffm = d->r->d_lut_ffm;
+    os.lut_lr = d->r->d_lut_lr;
+    PushRings pr{};
+    pr.n = N;
+    pr.stream = 1;
+    pr.log2cap_ffm = geo.lg_ffm;
+    pr.log2cap_lr = geo.lg_lr;
+    pr.cnt = reinterpret_cast<uint32_t *>(d->st_mem + geo.off_cnt);
+    pr.lr_credit = reinterpret_cast<const uint32_t *>(d->st_mem + geo.off_credit);
+    pr.consumers = update ? consumer_wgs : 0;  // (a read-only step pushes nothing: nobody has anything to drain)
+    pr.step = d->st_step;
+    pr.src = me;
+    pr.done = reinterpret_cast<uint32_t *>(d->st_mem + geo.off_done);
+    pr.own = reinterpret_cast<const OwnerStream *>(d->st_mem + geo.off_own);
+    for (uint32_t o = 0; o < N; o++) {
+        pr.ffm_tag[o] = reinterpret_cast<unsigned long long *>(base[o] + geo.off_tag) + (size_t)me * cf;
+        pr.ffm_rows[o] = reinterpret_cast<float *>(base[o] + geo.off_rows) + (size_t)me * cf * R;
+        pr.lr_word[o] = reinterpret_cast<unsigned long long *>(base[o] + geo.off_lr) + (size_t)me * cl;
+        pr.ffm_free[o] = reinterpret_cast<const uint32_t *>(d->st_mem + geo.off_free) + (size_t)o * cf;
+        pr.fin_remote[o] = reinterpret_cast<unsigned long long *>(base[o] + geo.off_fin);
+    }
+    FWGPU_HIP(hipMemcpyAsync(d->st_mem + geo.off_own, &os, sizeof(os), hipMemcpyHostToDevice, d->stream));
+    FWGPU_HIP(hipMemcpyAsync(d->st_mem + geo.off_push, &pr, sizeof(pr), hipMemcpyHostToDevice, d->stream));
+    FWGPU_HIP(hipMemsetAsync(d->st_mem + geo.off_done, 0, 4, d->stream));
+    FWGPU_HIP(hipStreamSynchronize(d->stream));  // (os / pr are locals)
+    return run_batch_peer(d->r, d->cur, FWGPU_MODE_HOGWILD, update, d->d_peers, d->stream, reinterpret_cast<const PushRings *>(d->st_mem + geo.off_push), pr.consumers,
+                          d->st_share);
+}
+// the launch has ended: where this rank's regions (as owner) stand now = where the next step's consumers start
+int stream_finish(fwgpu_dist *d, const StreamGeom &geo, int update, bool *near_wrap) {
+    FWGPU_HIP(hipSetDevice(d->r->device));
+    FWGPU_HIP(hipStreamSynchronize(d->stream));
+    if (update) {
+        std::vector<unsigned long long> fin((size_t)2 * geo.N);
+        FWGPU_HIP(hipMemcpy(fin.data(), d->st_mem + geo.off_fin, fin.size() * 8, hipMemcpyDeviceToHost));
+        for (uint32_t s = 0; s < geo.N; s++) {
+            if ((uint32_t)(fin[s] >> 32) != d->st_step || (uint32_t)(fin[geo.N + s] >> 32) != d->st_step)
+                return fail(FWGPU_ERR_DEVICE, "owner-side apply, streaming form: a source's final positions of the step never arrived");
+            d->st_pos_ffm[s] = (uint32_t)fin[s];
+            d->st_pos_lr[s] = (uint32_t)fin[geo.N + s];
+            *near_wrap |= d->st_pos_ffm[s] > 0x60000000u || d->st_pos_lr[s] > 0x60000000u;
+        }
+    }
     return FWGPU_OK;
 }
 }  // namespace
 
 // In-process group form of the streaming step.  batches[j] (may be NULL): rank j's micro-batch already in HBM (a record batch of its regressor);
 // otherwise records[j] / rec_off[j] / n[j].  HOGWILD only (the in-order reference is fwgpu_dist_group_learn_owner in FWGPU_MODE_SEQUENTIAL).
-// log2_rows / log2_lr: capacity of one (owner, source) region in gradient rows / LR gradients (0: 2^15 / 2^16).
+// log2_rows / log2_lr: capacity of one (owner, source) region in gradient rows / LR gradients (0: 2^15 / 2^16); consumer_workgroups: workgroups of a
+// rank's launch that drain its regions (0: 32).
 int fwgpu_dist_group_learn_owner_stream(fwgpu_dist_group *g, const fwgpu_translator_config *t, const uint32_t *const *records, const uint64_t *const *rec_off,
                                         const uint32_t *n, fwgpu_batch *const *batches, float *const *preds, int update, uint32_t log2_rows, uint32_t log2_lr,
                                         uint32_t consumer_workgroups) {
@@ -1727,15 +1807,22 @@ int fwgpu_dist_group_learn_owner_stream(fwgpu_dist_group *g, const fwgpu_transla
     fwgpu_regressor *r0 = g->ranks[0]->r;
     if (r0->nn.n_layers) return fail(FWGPU_ERR_INVALID, "owner-side apply: models with a deep head are not covered");
     if (r0->cfg.bit_precision > 30) return fail(FWGPU_ERR_INVALID, "owner-side apply, streaming form: LR hashes of more than 30 bits are not covered (the region's words keep 2 bits)");
+    {   // the ranks' kernels must run at the same time: ranks that share a device need a hardware queue each
+        uint32_t same = 0;
+        for (uint32_t j = 0; j < N; j++) same += g->ranks[j]->r->device == r0->device ? 1u : 0u;
+        for (uint32_t j = 0; j < N; j++) {
+            uint32_t sh = 0;
+            for (uint32_t i = 0; i < N; i++) sh += g->ranks[i]->r->device == g->ranks[j]->r->device ? 1u : 0u;
+            g->ranks[j]->st_share = sh;
+        }
+        if (same > 4) return fail(FWGPU_ERR_INVALID, "owner-side apply, streaming form: more than four in-process ranks on one device (their kernels would queue behind one another); one process per rank there");
+    }
     int lg = 0;
     while ((1u << lg) < N) lg++;
     if ((r0->cfg.ffm_k && (int)r0->cfg.ffm_bit_precision < lg) || (int)r0->cfg.bit_precision < lg)
         return fail(FWGPU_ERR_INVALID, "owner-side apply: fewer table entries than ranks");
     const uint32_t lgf = log2_rows ? log2_rows : 15, lgl = log2_lr ? log2_lr : 16;
     if (lgf < 6 || lgf > 24 || lgl < 6 || lgl > 24) return fail(FWGPU_ERR_INVALID, "owner-side apply, streaming form: log2 capacities of 6 .. 24");
-    uint32_t G = consumer_workgroups ? consumer_workgroups : 48;
-    G = std::max<uint32_t>(G, 2 * N);
-    G = N + ((G - N + N - 1) / N) * N;  // LR workgroups + a multiple of N row workgroups (4 waves each: waves divide evenly over the sources)
     const uint32_t R = r0->cfg.ffm_k ? r0->cfg.ffm_k * r0->cfg.ffm_num_fields : 0;
     PeerShards ps{};
     ps.n = N;
@@ -1756,118 +1843,39 @@ int fwgpu_dist_group_learn_owner_stream(fwgpu_dist_group *g, const fwgpu_transla
             (void)hipGetLastError();
         }
     int rc;
-    bool any_fresh = false, near_wrap = false;
+    bool any_fresh = false;
     for (uint32_t j = 0; j < N; j++) {
         bool fresh = false;
         if ((rc = stream_reserve(g->ranks[j].get(), N, lgf, lgl, &fresh))) return rc;
         any_fresh |= fresh;
-        for (uint32_t s = 0; s < N; s++) near_wrap |= g->ranks[j]->st_pos_ffm[s] > 0x60000000u || g->ranks[j]->st_pos_lr[s] > 0x60000000u;
     }
-    if (any_fresh || near_wrap)
+    if (any_fresh)
         for (uint32_t j = 0; j < N; j++)
             if ((rc = stream_reset(g->ranks[j].get()))) return rc;
     const StreamGeom geo = stream_geom(N, R, lgf, lgl);
-    const size_t cf = (size_t)1 << lgf, cl = (size_t)1 << lgl;
+    unsigned char *bases[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (uint32_t j = 0; j < N; j++) bases[j] = g->ranks[j]->st_mem;
     std::vector<uint32_t> shapes((size_t)N * 4);
     for (uint32_t j = 0; j < N; j++) {
-        fwgpu_batch *bj = batches ? batches[j] : nullptr;
-        if ((rc = sparse_begin(g->ranks[j].get(), t, bj ? nullptr : records[j], bj ? nullptr : rec_off[j], bj ? bj->n : n[j], bj, &shapes[4 * j]))) return rc;
-    }
-    // ---- consumers up (only when something will be pushed)
-    if (update) {
-        for (uint32_t o = 0; o < N; o++) {
-            fwgpu_dist *od = g->ranks[o].get();
-            FWGPU_HIP(hipSetDevice(od->r->device));
-            OwnerStream os{};
-            os.n = N;
-            os.R = R;
-            os.log2cap_ffm = lgf;
-            os.log2cap_lr = lgl;
-            for (uint32_t s = 0; s < N; s++) {
-                unsigned char *src = g->ranks[s]->st_mem;
-                os.ffm_tag[s] = reinterpret_cast<const unsigned long long *>(od->st_mem + geo.off_tag) + (size_t)s * cf;
-                os.ffm_rows[s] = reinterpret_cast<const float *>(od->st_mem + geo.off_rows) + (size_t)s * cf * R;
-                os.lr_word[s] = reinterpret_cast<const unsigned long long *>(od->st_mem + geo.off_lr) + (size_t)s * cl;
-                os.ffm_free[s] = reinterpret_cast<uint32_t *>(src + geo.off_free) + (size_t)o * cf;
-                os.lr_credit[s] = reinterpret_cast<uint32_t *>(src + geo.off_credit) + o;
-                os.start_ffm[s] = od->st_pos_ffm[s];
-                os.start_lr[s] = od->st_pos_lr[s];
-            }
-            os.fin = reinterpret_cast<const unsigned long long *>(od->st_mem + geo.off_fin);
-            FWGPU_HIP(hipMemsetAsync(od->st_mem + geo.off_fin, 0, (size_t)2 * N * 8, od->cstream));
-            *od->h_resident = 0;
-            uint32_t *dres = nullptr;
-            FWGPU_HIP(hipHostGetDevicePointer((void **)&dres, od->h_resident, 0));
-            os.resident = dres;
-            os.w = od->r->d_ffm_w;
-            os.acc = od->r->d_ffm_acc;
-            os.lr = od->r->d_lr;
-            os.ffm_rate = od->r->cfg.ffm_learning_rate;
-            os.ffm_mpt = -od->r->cfg.ffm_power_t;
-            os.lr_rate = od->r->cfg.learning_rate;
-            os.lr_mpt = -od->r->cfg.power_t;
-            os.lut_ffm = od->r->d_lut_ffm;
-            os.lut_lr = od->r->d_lut_lr;
-            FWGPU_HIP(launch_owner_stream(os, od->r->cfg.optimizer, G, od->cstream));
-        }
-        const auto t0 = std::chrono::steady_clock::now();
-        for (uint32_t o = 0; o < N; o++)
-            while (__atomic_load_n(g->ranks[o]->h_resident, __ATOMIC_ACQUIRE) < G) {
-                if (std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t0).count() > 20)
-                    return fail(FWGPU_ERR_DEVICE, "owner-side apply, streaming form: the consumer workgroups did not all start (device full?)");
-                std::this_thread::yield();
-            }
-    }
-    // ---- the sources' kernels
-    for (uint32_t j = 0; j < N; j++) {
         fwgpu_dist *d = g->ranks[j].get();
+        fwgpu_batch *bj = batches ? batches[j] : nullptr;
+        if ((rc = sparse_begin(d, t, bj ? nullptr : records[j], bj ? nullptr : rec_off[j], bj ? bj->n : n[j], bj, &shapes[4 * j]))) return rc;
         FWGPU_HIP(hipSetDevice(d->r->device));
         if (!d->d_peers) FWGPU_HIP(hipMalloc((void **)&d->d_peers, sizeof(PeerShards)));
         FWGPU_HIP(hipMemcpyAsync(d->d_peers, &ps, sizeof(PeerShards), hipMemcpyHostToDevice, d->stream));
-        PushRings pr{};
-        pr.n = N;
-        pr.stream = 1;
-        pr.log2cap_ffm = lgf;
-        pr.log2cap_lr = lgl;
-        pr.cnt = reinterpret_cast<uint32_t *>(d->st_mem + geo.off_cnt);
-        pr.lr_credit = reinterpret_cast<const uint32_t *>(d->st_mem + geo.off_credit);
-        for (uint32_t o = 0; o < N; o++) {
-            unsigned char *ob = g->ranks[o]->st_mem;
-            pr.ffm_tag[o] = reinterpret_cast<unsigned long long *>(ob + geo.off_tag) + (size_t)j * cf;
-            pr.ffm_rows[o] = reinterpret_cast<float *>(ob + geo.off_rows) + (size_t)j * cf * R;
-            pr.lr_word[o] = reinterpret_cast<unsigned long long *>(ob + geo.off_lr) + (size_t)j * cl;
-            pr.ffm_free[o] = reinterpret_cast<const uint32_t *>(d->st_mem + geo.off_free) + (size_t)o * cf;
-        }
-        FWGPU_HIP(hipMemcpyAsync(d->d_push_st, &pr, sizeof(pr), hipMemcpyHostToDevice, d->stream));
-        FWGPU_HIP(hipStreamSynchronize(d->stream));  // (ps / pr are locals)
-        if ((rc = run_batch_peer(d->r, d->cur, FWGPU_MODE_HOGWILD, update, d->d_peers, d->stream, d->d_push_st))) return rc;
+        FWGPU_HIP(hipStreamSynchronize(d->stream));  // (ps is a local)
+        d->st_step++;
     }
-    // ---- final positions to the owners; the consumers drain and leave
-    std::vector<uint32_t> cnt((size_t)N * 2 * N, 0);
-    for (uint32_t j = 0; j < N; j++) {
-        fwgpu_dist *d = g->ranks[j].get();
-        FWGPU_HIP(hipSetDevice(d->r->device));
-        FWGPU_HIP(hipStreamSynchronize(d->stream));
-        FWGPU_HIP(hipMemcpy(&cnt[(size_t)j * 2 * N], d->st_mem + geo.off_cnt, (size_t)2 * N * 4, hipMemcpyDeviceToHost));
-    }
-    if (update) {
-        for (uint32_t o = 0; o < N; o++) {
-            fwgpu_dist *od = g->ranks[o].get();
-            FWGPU_HIP(hipSetDevice(od->r->device));
-            std::vector<unsigned long long> fin((size_t)2 * N);
-            for (uint32_t s = 0; s < N; s++) {
-                fin[s] = (1ull << 32) | cnt[(size_t)s * 2 * N + o];
-                fin[N + s] = (1ull << 32) | cnt[(size_t)s * 2 * N + N + o];
-                od->st_pos_ffm[s] = cnt[(size_t)s * 2 * N + o];
-                od->st_pos_lr[s] = cnt[(size_t)s * 2 * N + N + o];
-            }
-            FWGPU_HIP(hipMemcpy(od->st_mem + geo.off_fin, fin.data(), fin.size() * 8, hipMemcpyHostToDevice));
-        }
-        for (uint32_t o = 0; o < N; o++) {
-            FWGPU_HIP(hipSetDevice(g->ranks[o]->r->device));
-            FWGPU_HIP(hipStreamSynchronize(g->ranks[o]->cstream));
-        }
-    }
+    const uint32_t waves = std::max<uint32_t>(1u, r0->launch.threads / 64u);
+    const uint32_t CW = stream_consumer_wgs(N, consumer_workgroups, waves);
+    for (uint32_t j = 0; j < N; j++)
+        if ((rc = stream_launch(g->ranks[j].get(), geo, bases, g->ranks[j]->r->d_lr, update, CW))) return rc;
+    bool near_wrap = false;
+    for (uint32_t j = 0; j < N; j++)
+        if ((rc = stream_finish(g->ranks[j].get(), geo, update, &near_wrap))) return rc;
+    if (near_wrap)
+        for (uint32_t j = 0; j < N; j++)
+            if ((rc = stream_reset(g->ranks[j].get()))) return rc;
     for (uint32_t j = 0; j < N; j++) {
         fwgpu_dist *d = g->ranks[j].get();
         FWGPU_HIP(hipSetDevice(d->r->device));
@@ -1980,6 +1988,111 @@ int fwgpu_dist_learn_owner(fwgpu_dist *d, const fwgpu_translator_config *t, cons
     if ((rc = wait_stream(d))) return rc;  // (polled; the caller's buffer is pageable: its copy comes after, not in front of the wait)
     if (preds && d->B) FWGPU_HIP(hipMemcpy(preds, d->cur->pred, (size_t)d->B * 4, hipMemcpyDeviceToHost));
     return FWGPU_OK;
+}
+
+// Process-per-rank form of the STREAMING step.  fwgpu_dist_owner_stream_attach (collective, once): tables and LR shards as fwgpu_dist_peer_attach maps
+// them, plus every rank's streaming allocation (one IPC handle per rank: its regions as owner AND the words the owners store for it as source).
+// fwgpu_dist_learn_owner_stream: one step of THIS rank -- its kernel (consumers + producers) and nothing else: no collective.  Every rank must call it the
+// same number of times (a rank's consumers leave a step when every source's final positions OF THAT STEP have arrived; n may be 0).  A rank whose
+// local preparation fails takes part with an empty batch and returns its own error; the peers are not told (there is no exchange to tell them through).
+// Every ~10^9 gradient rows the ranks start their positions over: that one step ends with two barriers.
+int fwgpu_dist_owner_stream_attach(fwgpu_dist *d, uint32_t log2_rows, uint32_t log2_lr) {
+    if (!d || !d->comm) return fail(FWGPU_ERR_INVALID, "not an RCCL rank (fwgpu_dist_init)");
+    if (d->r->cfg.bit_precision > 30) return fail(FWGPU_ERR_INVALID, "owner-side apply, streaming form: LR hashes of more than 30 bits are not covered (the region's words keep 2 bits)");
+    const uint32_t N = (uint32_t)d->n;
+    const uint32_t lgf = log2_rows ? log2_rows : 15, lgl = log2_lr ? log2_lr : 16;
+    if (lgf < 6 || lgf > 24 || lgl < 6 || lgl > 24) return fail(FWGPU_ERR_INVALID, "owner-side apply, streaming form: log2 capacities of 6 .. 24");
+    int rc = fwgpu_dist_peer_attach(d);
+    if (rc) return rc;
+    bool fresh = false;
+    if ((rc = stream_reserve(d, N, lgf, lgl, &fresh))) return rc;
+    if (d->st_bytes >= (1ull << 31)) return fail(FWGPU_ERR_RANGE, "owner-side apply, streaming form: regions of 2 GiB or more cannot be mapped by the peers; smaller log2 capacities");
+    if ((rc = stream_reset(d))) return rc;
+    FWGPU_HIP(hipSetDevice(d->r->device));
+    hipIpcMemHandle_t mine{};
+    FWGPU_HIP(hipIpcGetMemHandle(&mine, d->st_mem));
+    hipIpcMemHandle_t *d_all = nullptr;
+    FWGPU_HIP(hipMalloc((void **)&d_all, sizeof(hipIpcMemHandle_t) * (size_t)N));
+    struct FreeOnExit {
+        void *q;
+        ~FreeOnExit() { if (q) (void)hipFree(q); }
+    } guard{d_all};
+    FWGPU_HIP(hipMemcpyAsync(d_all + d->rank, &mine, sizeof(mine), hipMemcpyHostToDevice, d->stream));
+    FWGPU_HIP(hipStreamSynchronize(d->stream));
+    if (N > 1) FWGPU_NCCL(g_rccl.AllGather(d_all + d->rank, d_all, sizeof(mine) / 4, ncclUint32, d->comm, d->stream));
+    if ((rc = wait_stream(d))) return rc;
+    std::vector<hipIpcMemHandle_t> all((size_t)N);
+    FWGPU_HIP(hipMemcpy(all.data(), d_all, sizeof(mine) * (size_t)N, hipMemcpyDeviceToHost));
+    {   // which ranks share this rank's GPU?  (their kernels must be resident together: each takes an equal share of the device)
+        char bus[64] = {0};
+        FWGPU_HIP(hipDeviceGetPCIBusId(bus, sizeof(bus), d->r->device));
+        uint32_t hsh = 2166136261u;
+        for (const char *c = bus; *c; ++c) hsh = (hsh ^ (uint32_t)(unsigned char)*c) * 16777619u;
+        FWGPU_HIP(hipMemcpyAsync(d->d_shape + 4 * d->rank, &hsh, 4, hipMemcpyHostToDevice, d->stream));
+        FWGPU_HIP(hipStreamSynchronize(d->stream));
+        if (N > 1) FWGPU_NCCL(g_rccl.AllGather(d->d_shape + 4 * d->rank, d->d_shape, 4, ncclUint32, d->comm, d->stream));
+        if ((rc = wait_stream(d))) return rc;
+        std::vector<uint32_t> ids((size_t)N * 4);
+        FWGPU_HIP(hipMemcpy(ids.data(), d->d_shape, ids.size() * 4, hipMemcpyDeviceToHost));
+        d->st_share = 0;
+        for (uint32_t j = 0; j < N; j++) d->st_share += ids[4 * (size_t)j] == hsh ? 1u : 0u;
+    }
+    for (uint32_t j = 0; j < N; j++) {
+        if ((int)j == d->rank) {
+            d->st_peer[j] = d->st_mem;
+            continue;
+        }
+        void *q = nullptr;
+        FWGPU_HIP(hipIpcOpenMemHandle(&q, all[j], hipIpcMemLazyEnablePeerAccess));
+        d->ipc_open.push_back(q);
+        d->st_peer[j] = static_cast<unsigned char *>(q);
+    }
+    return fwgpu_dist_barrier(d);
+}
+
+int fwgpu_dist_learn_owner_stream(fwgpu_dist *d, const fwgpu_translator_config *t, const uint32_t *records, const uint64_t *rec_off, uint32_t n, float *preds,
+                                  int update, uint32_t consumer_workgroups) {
+    if (!d || !d->comm) return fail(FWGPU_ERR_INVALID, "not an RCCL rank (fwgpu_dist_init)");
+    if (!d->st_mem || !d->st_peer[d->rank]) return fail(FWGPU_ERR_INVALID, "fwgpu_dist_owner_stream_attach first");
+    if (d->mode != FWGPU_MODE_HOGWILD) return fail(FWGPU_ERR_INVALID, "owner-side apply, streaming form: FWGPU_MODE_HOGWILD only (the in-order reference is fwgpu_dist_learn_owner)");
+    const uint32_t N = (uint32_t)d->n;
+    const uint32_t R = d->r->cfg.ffm_k ? d->r->cfg.ffm_k * d->r->cfg.ffm_num_fields : 0;
+    const StreamGeom geo = stream_geom(N, R, d->st_lg_ffm, d->st_lg_lr);
+    uint32_t shape[4];
+    int own_rc = sparse_begin(d, t, records, rec_off, n, nullptr, shape);
+    if (own_rc) {  // this rank's records are unusable: an empty batch keeps the job's steps aligned (its consumers must serve the peers all the same)
+        const std::string msg = fwgpu_last_error();
+        uint32_t sh2[4];
+        const uint64_t zero_off[1] = {0};
+        int rc2 = sparse_begin(d, t, nullptr, zero_off, 0, nullptr, sh2);
+        if (rc2) return rc2;
+        set_error(msg + " (the rank took part in the step with an empty batch)");
+    }
+    FWGPU_HIP(hipSetDevice(d->r->device));
+    float *lr_base = d->lr_shard ? d->lr_shard - 2 * d->lr_shard_lo : d->r->d_lr;
+    d->st_step++;
+    const uint32_t waves = std::max<uint32_t>(1u, d->r->launch.threads / 64u);
+    int rc = stream_launch(d, geo, d->st_peer, lr_base, update, stream_consumer_wgs(N, consumer_workgroups, waves));
+    if (rc) return rc;
+    bool near_wrap = false;
+    if ((rc = stream_finish(d, geo, update, &near_wrap))) return rc;
+    if (N > 1 && (d->st_step & 1023u) == 0) {  // (every 1024 steps: does ANY rank come close to the wrap?  one word, all-reduced)
+        float flag = near_wrap ? 1.0f : 0.0f;
+        FWGPU_HIP(hipMemcpyAsync(d->d_shape, &flag, 4, hipMemcpyHostToDevice, d->stream));
+        FWGPU_HIP(hipStreamSynchronize(d->stream));
+        FWGPU_NCCL(g_rccl.AllReduce(d->d_shape, d->d_shape, 1, ncclFloat, ncclSum, d->comm, d->stream));
+        if ((rc = wait_stream(d))) return rc;
+        FWGPU_HIP(hipMemcpy(&flag, d->d_shape, 4, hipMemcpyDeviceToHost));
+        if (flag > 0.0f) {
+            if ((rc = fwgpu_dist_barrier(d))) return rc;
+            if ((rc = stream_reset(d))) return rc;
+            if ((rc = fwgpu_dist_barrier(d))) return rc;
+        }
+    } else if (N == 1 && near_wrap) {
+        if ((rc = stream_reset(d))) return rc;
+    }
+    if (preds && d->B) FWGPU_HIP(hipMemcpy(preds, d->cur->pred, (size_t)d->B * 4, hipMemcpyDeviceToHost));
+    return own_rc;
 }
 
 int fwgpu_dist_group_gather_tables(fwgpu_dist_group *g) {

@@ -83,6 +83,14 @@ struct PushRings {
     unsigned long long *lr_word[8];  // per owner: [cap_lr] {hash (30 bits) | ((generation % 3) + 1) << 30, gradient bits << 32}
     const uint32_t *ffm_free[8];     // source-local, per owner: [cap_ffm] the generation slot q may be written for (the owner's consumer stores it)
     const uint32_t *lr_credit;       // source-local [n]: LR positions of this source the owner o has consumed (a prefix)
+    // The rank's consumers run INSIDE its example kernel: the first `consumers` workgroups of the launch drain this rank's regions as owner (`own`), the
+    // others are the producers.  A producer workgroup that finds no more examples counts itself in `done`; the last one stores every region's final
+    // position -- tagged with the step -- into the OWNERS' memory (fin_remote[o] + this rank's index, then + n for the LR region): the owners' consumers
+    // leave when they have reached it.  No host round trip, no collective, no second stream.
+    uint32_t consumers, step, src, pad3_;
+    uint32_t *done;                          // source-local counter of finished producer workgroups (zeroed before the launch)
+    unsigned long long *fin_remote[8];       // per owner: its array of final positions [2n]: {step << 32 | position}
+    const struct OwnerStream *own;           // device memory: this rank's regions as owner
 };
 
 // the owner's side of the streaming form: what its consumer kernel drains (kernels.hip owner_stream_kernel)
@@ -94,8 +102,8 @@ struct OwnerStream {
     uint32_t *ffm_free[8];                  // per source: slot -> generation, in the SOURCE's memory
     uint32_t *lr_credit[8];                 // per source: this owner's word of the source's credit array
     uint32_t start_ffm[8], start_lr[8];     // first position of this step, per source
-    const unsigned long long *fin;          // owner-local [2n]: {1 << 32 | final position} once the source's kernel has ended (FFM, then LR); 0 before
-    uint32_t *resident;                     // host-visible counter: workgroups of this launch that are running
+    const unsigned long long *fin;          // owner-local [2n]: {step << 32 | final position}, stored by source s's last producer workgroup (FFM regions, then LR)
+    uint32_t step, pad_;                    // the step this launch belongs to (fin words of other steps are not this launch's)
     float *w, *acc, *lr;
     float ffm_rate, ffm_mpt, lr_rate, lr_mpt;
     const float *lut_ffm, *lut_lr;
@@ -150,12 +158,16 @@ struct KernelParams {
     int32_t lut_lds_forced;             // ... unless the launch runs a kernel that keeps it in LDS as a compile-time fact (resolve_row_mode)
     int32_t store_policy;               // hogwild launches of the v2 window kernel: how FFM row stores reach memory (kernels.hip "store policy"): 0 = both tables
                                         // device-scope write-through, 1 = weights write-back through the XCD's L2, 2 = both tables write-back
+    float acc_hot_theta;                // policy 3: a kept row whose accumulators exceed this is "hot": its accumulator row is stored for one example in
+    uint32_t acc_sample_log2;           // 2^acc_sample_log2 only, with that many times the example's g^2 (an unbiased, thinned write-through: kernels.hip "store policy")
     uint32_t wb_flush_every;            // policies 1 / 2: a workgroup writes its XCD's dirty L2 lines back (buffer_wbl2 sc1) every this many of its examples (0: never)
     int32_t tr_lds;                     // record batches on the v2 kernel: the translator's tables are read from an LDS copy (kernels.hip TrLds)
     uint32_t lds_keep, lds_keep_words;  // config-C-shaped kernel: rows per wave BEYOND the register-kept ones whose gather-time w stays in LDS for the update (0..FW_LDS_KEEP_MAX), and the region's size (rows x waves x R floats)
     int32_t prefetch;                   // record batches on the v2 kernel: example n+1's record is copied to LDS while example n is in its dot / update phases
     uint32_t *work;                     // next example to process (zeroed before every launch)
     uint32_t host_cus, host_wgs_cap, host_grid_cap;    // host side only: persistent grid = occupancy x CUs (capped), when launched with grid 0
+    uint32_t host_share;                               // host side only: ranks whose kernels must be RESIDENT TOGETHER on this device (streaming owner-side apply on a shared device): the persistent grid is an equal share of what the device holds (0 / 1: all of it)
+    uint32_t host_extra_wgs;                           // host side only: workgroups on top of the example workgroups (streaming owner-side apply: the consumers; at least one producer workgroup is kept)
     int32_t kernel_version;             // 0 = auto, 1 = force the v1 kernel, 2 = v2 where applicable
     unsigned long long *ticks;          // optional [8] per-phase shader-clock accumulators (debug), else NULL
 #ifndef FW_KP_NO_CANARY                 // (debug builds of scripts/kp_size_exp.sh drop the two fields: sizeof(KernelParams) 744 -> 728)
@@ -520,9 +532,8 @@ void lut_init(float *lut, float learning_rate, float power_t, float init_acc);
 KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int update);
 // the fused learn / predict launch of `b` with every row and LR entry reached in its owner's tables (generic kernel); d_shards: device copy
 int run_batch_peer(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, const PeerShards *d_shards, hipStream_t stream,
-                   const PushRings *d_push = nullptr);
+                   const PushRings *d_push = nullptr, uint32_t stream_consumers = 0, uint32_t device_share = 1);
 // owner-side apply: the optimizer steps of `n_rows` pushed gradient rows / `n_lr` pushed LR gradients on this regressor's own tables
-hipError_t launch_owner_stream(const OwnerStream &os, int optimizer, uint32_t workgroups, hipStream_t stream);
 hipError_t launch_owner_apply(const fwgpu_regressor *r, float *lr_base, const uint32_t *keys, const float *rows, uint32_t n_rows, const uint2 *lr_ent,
                               uint32_t n_lr, bool in_order, hipStream_t stream);
 struct SplitRanges {  // what a rank owns (sharded tables) and which examples of the launch are its own

@@ -36,6 +36,12 @@
 //   0  both tables device-scope write-through (buffer_store ... sc1): every 64 B request goes to the memory side and is acknowledged from there;
 //   1  WEIGHT rows write-back through the XCD's L2, accumulators write-through (round 3's shipped build: +9.5 % examples/s);
 //   2  BOTH tables write-back (the fastest: 0.555-0.56 of the HBM peak, profiles/r04b_policy_ab.txt).
+//   3  (round 5, experimental) policy 1 with THINNED accumulator stores on hot rows.  What skew costs under policy 1 is the write-through of the accumulator
+//      lines that many concurrent examples hold (profiles/r05_skew_x_store_policy.txt: uniform ids 0.639 of the peak under policies 1 and 2 alike; Zipf 1.3:
+//      0.547 against 0.659; L2 tag stalls 6.4x, profiles/r05_skew_pmc_counters.txt).  A kept row whose accumulators exceed KernelParams::acc_hot_theta stores
+//      its accumulator row for one example in 2^acc_sample_log2 only (a hash of the example's ticket and the row's slot decides), with 2^acc_sample_log2 times
+//      the example's g^2: the expectation of what reaches memory is what write-through sends, one coherent copy (policy 2's trouble is eight private ones),
+//      an m-th of the requests on exactly the lines that queue.  The STEP of every example still uses acc_read + its own g^2.
 // A write-back line is visible to the other seven XCDs when it leaves this XCD's L2.  Cold lines leave within microseconds (an XCD's 4 MB L2 turns
 // over every ~16 us at this kernel's write rate); a line that is re-touched before it is evicted -- the head rows of a Zipf field -- would stay
 // dirty for the whole launch, each XCD stepping a private copy.  KernelParams::wb_flush_every bounds that window: every that many examples a
@@ -1474,6 +1480,137 @@ __device__ __forceinline__ const KernelParams &kp_fresh() {
     asm volatile("; argument block address handed out" : "+s"(k));
     return *(const KernelParams *)k;  // (KernelParams is the kernels' first and only explicit argument: offset 0 of the segment)
 }
+// ------------------------------------------------------------------ owner-side apply, streaming form: the consumer side
+// The first PushRings::consumers workgroups of a streaming launch drain this rank's circular regions as OWNER while the other workgroups -- and the other
+// ranks' kernels -- fill them (staleness = the examples in flight, not the step: hogwild.rs:89-103 -- nobody waits for a step to end).  Consumer waves
+// 0 .. n-1: the LR region of source s IN ORDER, 64 positions at a time, publishing a consumed-prefix credit in the source's memory.  The other consumer
+// waves: source s = w % n, positions start + j, start + j + J, ... of that source's row region; a slot is handed back (ffm_free, in the source's memory)
+// as soon as its gradient row is in registers.  A wave leaves a region when the region's final position for THIS step is known (fin: stored by the
+// source's last producer workgroup) and reached.
+template <int OPT>
+__device__ __forceinline__ void owner_stream_consume(const OwnerStream &os, uint32_t cw, uint32_t CW, uint32_t lane) {
+    const uint32_t N = os.n;
+    auto fin_of = [&](uint32_t idx, uint32_t &fin) -> bool {  // final position of ring idx (FFM: s, LR: n + s), once known
+        const unsigned long long v = __hip_atomic_load(os.fin + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        fin = (uint32_t)v;
+        return (uint32_t)(v >> 32) == os.step;
+    };
+    if (cw < N) {
+        const uint32_t s = cw, lg = os.log2cap_lr, mask = (1u << lg) - 1u;
+        uint32_t base = os.start_lr[s];
+        for (;;) {
+            const uint32_t pq = base + lane;
+            unsigned long long word = 0;
+            bool have = false, past = false;
+            uint32_t fin = 0;
+            for (;;) {  // this lane's position: produced, or never going to be
+                word = __hip_atomic_load(os.lr_word[s] + (pq & mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                have = (((uint32_t)word >> 30) & 3u) == ((pq >> lg) % 3u) + 1u;
+                if (have) break;
+                if (fin_of(N + s, fin) && (int32_t)(pq - fin) >= 0) {
+                    past = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (have) {
+                const uint32_t h = (uint32_t)word & 0x3fffffffu;
+                const float grad = __uint_as_float((uint32_t)(word >> 32));
+                float2 wa = lr_load<true>(os.lr, h);
+                wa.x -= opt_step<OPT>(grad, wa.y, os.lr_rate, os.lr_mpt, os.lut_lr);  // block_lr.rs:145-147
+                lr_store<true>(os.lr, h, wa);
+            }
+            const unsigned long long pm = __ballot(past);
+            const uint32_t done = pm ? (uint32_t)__builtin_ctzll(pm) : 64u;  // positions are consecutive: the first lane beyond the end
+            base += done;
+            if (lane == 0) __hip_atomic_store(os.lr_credit[s], base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (pm) break;
+        }
+        return;
+    }
+    const uint32_t W = CW - N, gw = cw - N;
+    const uint32_t s = gw % N, j = gw / N, J = W / N;
+    if (j >= J) return;
+    const uint32_t lg = os.log2cap_ffm, mask = (1u << lg) - 1u, gmask = lg ? (0xffffffffu >> lg) : 0xffffffffu, R = os.R;
+    for (uint32_t pq = os.start_ffm[s] + j;; pq += J) {
+        const uint32_t slot = pq & mask, gen = (pq >> lg) & gmask;
+        unsigned long long word;
+        bool past = false;
+        for (;;) {
+            unsigned long long wv = 0;
+            if (lane == 0) wv = __hip_atomic_load(os.ffm_tag[s] + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            word = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(wv >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wv);
+            if ((uint32_t)(word >> 32) == ((gen + 1u) & gmask)) break;
+            uint32_t fin = 0, known = 0;
+            if (lane == 0) known = fin_of(s, fin) ? 1u : 0u;
+            known = __builtin_amdgcn_readfirstlane(known);
+            fin = __builtin_amdgcn_readfirstlane(fin);
+            if (known && (int32_t)(pq - fin) >= 0) {
+                past = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (past) break;
+        const uint32_t h = (uint32_t)word;
+        if (((R | h) & 3u) == 0) {
+            const __amdgpu_buffer_rsrc_t rg = make_rsrc(os.ffm_rows[s] + (size_t)slot * R, R * 4), rw = make_rsrc(os.w + h, R * 4), ra = make_rsrc(os.acc + h, R * 4);
+            // (rows of up to 512 floats: both chunks' loads before anything is stepped)
+            f4 gv[2], wv[2], av[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const uint32_t e0 = (c * 64 + lane) * 4;
+                gv[c] = Vec<4>::load<kAuxSys>(rg, e0 * 4);
+                wv[c] = Vec<4>::load<kAuxSc1>(rw, e0 * 4);
+                av[c] = OPT == FWGPU_OPT_SGD ? Vec<4>::zero() : Vec<4>::load<kAuxSc1>(ra, e0 * 4);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (R <= 512 && lane == 0)  // the gradient row is in registers: its slot may be written for the next generation
+                __hip_atomic_store(os.ffm_free[s] + slot, (gen + 1u) & gmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const uint32_t e0 = (c * 64 + lane) * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float a = av[c][q];
+                    wv[c][q] = wv[c][q] - opt_step<OPT>(gv[c][q], a, os.ffm_rate, os.ffm_mpt, os.lut_ffm);  // block_ffm.rs:279-282
+                    av[c][q] = a;
+                }
+                Vec<4>::store<kAuxSc1>(wv[c], rw, e0 * 4);
+                if (OPT != FWGPU_OPT_SGD) Vec<4>::store<kAuxSc1>(av[c], ra, e0 * 4);
+            }
+            for (uint32_t e0 = 512 + lane * 4; e0 < R; e0 += 256) {  // longer rows: the rest chunk by chunk
+                const f4 g2 = Vec<4>::load<kAuxSys>(rg, e0 * 4);
+                f4 w2 = Vec<4>::load<kAuxSc1>(rw, e0 * 4), a2 = OPT == FWGPU_OPT_SGD ? Vec<4>::zero() : Vec<4>::load<kAuxSc1>(ra, e0 * 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float a = a2[q];
+                    w2[q] = w2[q] - opt_step<OPT>(g2[q], a, os.ffm_rate, os.ffm_mpt, os.lut_ffm);
+                    a2[q] = a;
+                }
+                Vec<4>::store<kAuxSc1>(w2, rw, e0 * 4);
+                if (OPT != FWGPU_OPT_SGD) Vec<4>::store<kAuxSc1>(a2, ra, e0 * 4);
+            }
+            if (R > 512) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(os.ffm_free[s] + slot, (gen + 1u) & gmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        } else {
+            for (uint32_t e = lane; e < R; e += 64) {
+                const float grad = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(os.ffm_rows[s] + (size_t)slot * R + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+                float a = OPT == FWGPU_OPT_SGD ? 0.0f : __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned *>(os.acc + h + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                float wv = __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned *>(os.w + h + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                wv -= opt_step<OPT>(grad, a, os.ffm_rate, os.ffm_mpt, os.lut_ffm);
+                __hip_atomic_store(reinterpret_cast<unsigned *>(os.w + h + e), __float_as_uint(wv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (OPT != FWGPU_OPT_SGD) __hip_atomic_store(reinterpret_cast<unsigned *>(os.acc + h + e), __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(os.ffm_free[s] + slot, (gen + 1u) & gmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+
 // PH = 0: the fused learn / predict step.  PH = 1 (FWD) and PH = 3 (UPD): the two table-touching halves of the synchronous
 // micro-batch pipeline -- every example of the batch sees the weights of the batch start, updates are applied afterwards:
 //   FWD : stage, gather the rows this rank OWNS (all of them on one GPU), write T / dcf / LR sums to the example's split record
@@ -1526,6 +1663,11 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
     // kernel -- RCCL during a replica exchange -- holds its slot, or the grid was over-subscribed) finds the work already
     // done instead of running its whole share alone after everyone else has finished.  One workgroup gets 0, 1, 2, ...
     // (the in-order mode).  The next ticket is requested one example ahead, so its latency is never waited for.
+    if (SH && PH == 0 && p.push && p.push->stream && blockIdx.x < p.push->consumers) {
+        // streaming owner-side apply: this workgroup is one of the rank's CONSUMERS for the whole launch (owner_stream_consume)
+        owner_stream_consume<OPT>(*p.push->own, blockIdx.x * (uint32_t)nw + (uint32_t)wave, p.push->consumers * (uint32_t)nw, (uint32_t)lane);
+        return;
+    }
     if (tid == 0) {
         s.ctr[6] = atomicAdd(p.work, 1u);
         hot_lr_init<COH>(p, s, PH == 0);
@@ -1805,11 +1947,19 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
                         for (uint32_t t = tid; t < nl; t += bd) {
                             const uint32_t h = s.l_hash[t], o = h >> p.shards->shift_lr;
                             const uint32_t pos = atomicAdd(&pr.cnt[pr.n + o], 1u);
-                            // flow control: the owner has consumed every position below credit[o]; `pos` may be written when pos - credit < cap
-                            while ((int32_t)(pos - (__hip_atomic_load(pr.lr_credit + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + capl)) >= 0) __builtin_amdgcn_s_sleep(8);
                             const float grad = g * s.l_val[t];  // block_lr.rs:143
                             const unsigned long long word = (unsigned long long)(h | ((((pos >> lg) % 3u) + 1u) << 30)) | ((unsigned long long)__float_as_uint(grad) << 32);
-                            __hip_atomic_store(pr.lr_word[o] + (pos & (capl - 1u)), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            // flow control: the owner has consumed every position below credit[o]; `pos` may be written when pos - credit < cap.  The store sits
+                            // INSIDE the loop: a lane whose position is free must not wait (at the loop's end) for a lane of its wave whose position is not --
+                            // the consumer takes the region in order and would never get to that one.
+                            for (bool sent = false; !sent;) {
+                                if ((int32_t)(pos - (__hip_atomic_load(pr.lr_credit + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + capl)) < 0) {
+                                    __hip_atomic_store(pr.lr_word[o] + (pos & (capl - 1u)), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                    sent = true;
+                                } else {
+                                    __builtin_amdgcn_s_sleep(8);
+                                }
+                            }
                         }
                     }
                     if (k) {
@@ -1829,17 +1979,35 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
                                     pos_[u] = __builtin_amdgcn_readfirstlane(q);
                                 }
                             }
+                            auto announce = [&](uint32_t mask_) {  // tag words of the rows written so far: their floats are at the owners
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                                for (int u = 0; u < PU; ++u) {
+                                    if (!((mask_ >> u) & 1u) || lane != 0) continue;
+                                    const uint32_t slot = pos_[u] & (capf - 1u), gen = (pos_[u] >> lg) & gmask;
+                                    __hip_atomic_store(pr.ffm_tag[o_[u]] + slot, (unsigned long long)h_[u] | ((unsigned long long)((gen + 1u) & gmask) << 32), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_SYSTEM);
+                                }
+                            };
+                            uint32_t written = 0;
 #pragma unroll
                             for (int u = 0; u < PU; ++u) {
                                 const uint32_t i = i0 + u;
                                 if (i >= nf) continue;
                                 const uint32_t slot = pos_[u] & (capf - 1u), gen = (pos_[u] >> lg) & gmask;
-                                // the slot's previous generation has been consumed: the owner says so in this rank's own memory
+                                // the slot's previous generation has been consumed: the owner says so in this rank's own memory.  A wave never WAITS while it
+                                // holds written rows it has not announced (the consumers take a region's stripes in order: two waves waiting for each other's
+                                // unannounced rows would wait for ever).
                                 for (;;) {
                                     const uint32_t fr = __builtin_amdgcn_readfirstlane(__hip_atomic_load(pr.ffm_free[o_[u]] + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
                                     if ((fr & gmask) == gen) break;
+                                    if (written) {
+                                        announce(written);
+                                        written = 0;
+                                    }
                                     __builtin_amdgcn_s_sleep(8);
                                 }
+                                written |= 1u << u;
                                 const uint32_t f = __builtin_amdgcn_readfirstlane(s.e_fld[i]) & kFldMask;
                                 const __amdgpu_buffer_rsrc_t rr = make_rsrc(pr.ffm_rows[o_[u]] + (size_t)slot * R, R * 4);
                                 const float v = s.e_val[i];
@@ -1859,14 +2027,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
                                     Vec<VEC>::template store<kAuxSys>(gv, rr, e0 * 4);
                                 }
                             }
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows' floats are at their owners: now the words that say so
-#pragma unroll
-                            for (int u = 0; u < PU; ++u) {
-                                if (i0 + u >= nf || lane != 0) continue;
-                                const uint32_t slot = pos_[u] & (capf - 1u), gen = (pos_[u] >> lg) & gmask;
-                                __hip_atomic_store(pr.ffm_tag[o_[u]] + slot, (unsigned long long)h_[u] | ((unsigned long long)((gen + 1u) & gmask) << 32), __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_SYSTEM);
-                            }
+                            if (written) announce(written);
                         }
                     }
                 } else {
@@ -1958,6 +2119,26 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
         if (tid == 0) s.ctr[6] = next_ticket;  // published by the loop-top barrier
     }
     if (COH && tid == 0 && s.ctr[13]) hot_lr_flush<SH>(p, s);  // (every thread's steps are in: the loop ends on a barrier)
+    if (SH && PH == 0 && p.push && p.push->stream) {
+        // streaming owner-side apply: this producer workgroup is through.  Its pushes have been acknowledged (rows: before their tag words; LR words: waited
+        // for here); the LAST producer workgroup of the launch tells every owner where this source's regions end for this step.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const PushRings &pr = *p.push;
+            const uint32_t producers = gridDim.x - pr.consumers;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (atomicAdd(pr.done, 1u) + 1u == producers) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                for (uint32_t o = 0; o < pr.n; ++o) {
+                    const uint32_t ff = __hip_atomic_load(pr.cnt + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t fl = __hip_atomic_load(pr.cnt + pr.n + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(pr.fin_remote[o] + pr.src, ((unsigned long long)pr.step << 32) | ff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(pr.fin_remote[o] + pr.n + pr.src, ((unsigned long long)pr.step << 32) | fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
+    }
 #ifndef FW_KP_NO_CANARY
     if (p.dbg_canary)
         for (uint32_t i = tid; i < 256; i += bd)
@@ -1994,9 +2175,14 @@ static hipError_t launch_persistent(K kern, const KernelParams &p, uint32_t grid
             c_per_cu = per_cu;
         }
         if (p.host_wgs_cap && (uint32_t)per_cu > p.host_wgs_cap) per_cu = (int)p.host_wgs_cap;
-        const uint64_t g = (uint64_t)per_cu * (p.host_cus ? p.host_cus : 1);
+        uint64_t g = (uint64_t)per_cu * (p.host_cus ? p.host_cus : 1);
+        if (p.host_share > 1) g = std::max<uint64_t>(2, g / p.host_share);  // kernels of several ranks resident together on this device
         grid = (uint32_t)(g < p.n_examples ? g : p.n_examples);
         if (p.host_grid_cap && grid > p.host_grid_cap) grid = p.host_grid_cap;
+        if (p.host_extra_wgs) {  // streaming owner-side apply: the consumers come on top of the example workgroups, all of them resident together
+            const uint32_t room = g > p.host_extra_wgs ? (uint32_t)g - p.host_extra_wgs : 1u;
+            grid = std::max<uint32_t>(1u, std::min(grid, room)) + p.host_extra_wgs;
+        }
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, p);
     return hipGetLastError();
@@ -2295,8 +2481,9 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
 #endif
     // (nt on the device-scope LOADS was measured and rejected: gather -2 %, accumulator loads -4 %, profiles/r04_nt_loads_and_flush256_ab.txt)
     constexpr int AUX_G = AUX, AUX_LA = AUX;
-    constexpr int AUX_SW = (COH && POL < 1) ? kAuxSc1 : (COH ? FW_WB_AUX_W : kAuxPlain);  // weight-row stores (store policy: top of this file)
-    constexpr int AUX_SA = (COH && POL < 2) ? kAuxSc1 : (COH ? FW_WB_AUX_A : kAuxPlain);  // accumulator-row stores
+    constexpr int AUX_SW = (COH && POL < 1) ? kAuxSc1 : (COH ? FW_WB_AUX_W : kAuxPlain);  // weight-row stores (store policy: top of this file; 3 = 1 here)
+    constexpr int AUX_SA = (COH && (POL < 2 || POL == 3)) ? kAuxSc1 : (COH ? FW_WB_AUX_A : kAuxPlain);  // accumulator-row stores
+    constexpr bool kThin = COH && POL == 3;  // thinned accumulator stores on hot rows (store policy 3)
     constexpr int UA = (WIN && NC == 1) ? FW_UA_WIN : FW_UA;  // accumulator rows in flight per wave in the update phase
     constexpr int UG = (WIN && NC == 1) ? FW_UG_WIN : FW_UG;  // overflow rows in flight per wave in the gather
     constexpr int UO = FW_UO;  // overflow rows (w + acc) in flight per wave
@@ -2782,6 +2969,18 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                     bool ok0;
                     slot(sl, h0, f0, ok0);
                     V a_cur = av[sl];
+                    // store policy 3: is this a hot row (wave-uniform: any lane's accumulator beyond theta), and is this example the one in m that stores it?
+                    float g2_scale = 0.0f;
+                    bool acc_store = ok0;
+                    if (kThin && gridDim.x > 1) {
+                        const bool hot = __ballot(a_cur[0] > p.acc_hot_theta || a_cur[1] > p.acc_hot_theta || a_cur[2] > p.acc_hot_theta || a_cur[3] > p.acc_hot_theta) != 0ull;
+                        if (hot) {
+                            const uint32_t m = 1u << p.acc_sample_log2;
+                            const uint32_t draw = ((ex * 2654435761u) ^ ((kb + (uint32_t)sl) * 40503u + (uint32_t)wave * 9973u)) >> 9;
+                            acc_store = ok0 && (draw & (m - 1u)) == 0u;
+                            g2_scale = (float)(m - 1u);
+                        }
+                    }
                     const float v = s.e_val[kb + (uint32_t)sl];
                     V wv;
                     if (sl < MAXR) {
@@ -2801,11 +3000,11 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                         const float grad = __fmul_rn(g, G);
                         float acc = a_cur[j];
                         const float upd = opt_step<OPT>(grad, acc, p.ffm_rate, p.ffm_minus_power_t, s.lut);
-                        a_cur[j] = acc;
+                        a_cur[j] = kThin ? acc + g2_scale * (grad * grad) : acc;  // (what is STORED for a thinned row: m x this example's g^2 on top of what it read)
                         wv[j] = wv[j] - upd;  // block_ffm.rs:282
                     }
                     Vec<VEC>::template store<AUX_SW>(wv, make_rsrc(p.ffm_w + h0, ok0 ? R * 4 : 0), e0 * 4);
-                    if (OPT != FWGPU_OPT_SGD) Vec<VEC>::template store<AUX_SA>(a_cur, make_rsrc(p.ffm_acc + h0, ok0 ? R * 4 : 0), e0 * 4);
+                    if (OPT != FWGPU_OPT_SGD) Vec<VEC>::template store<AUX_SA>(a_cur, make_rsrc(p.ffm_acc + h0, (kThin ? acc_store : ok0) ? R * 4 : 0), e0 * 4);
                 }
             } else
 #pragma unroll
@@ -2933,6 +3132,7 @@ static hipError_t launch_r(const KernelParams &p, uint32_t grid, uint32_t thread
         // the config-C kernel: its store policy is a launch parameter (instantiations of their own, so that the shipped policy pays nothing for the others)
         if (COH && p.store_policy == 0) return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR_WIN, true, 1, COH ? 0 : FW_DEFAULT_STORE_POLICY>, p, grid, threads, lds, stream);
         if (COH && p.store_policy == 2) return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR_WIN, true, 1, COH ? 2 : FW_DEFAULT_STORE_POLICY>, p, grid, threads, lds, stream);
+        if (COH && p.store_policy == 3) return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR_WIN, true, 1, COH ? 3 : FW_DEFAULT_STORE_POLICY>, p, grid, threads, lds, stream);
         return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR_WIN, true, 1, COH ? 1 : FW_DEFAULT_STORE_POLICY>, p, grid, threads, lds, stream);
     }
     return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR, false>, p, grid, threads, lds, stream);
@@ -2983,7 +3183,7 @@ void resolve_row_mode(KernelParams &p, uint32_t threads) {
 
 hipError_t launch_example_kernel(const KernelParams &p_in, int optimizer, bool coherent, uint32_t grid, uint32_t threads,
                                  hipStream_t stream) {
-    if (p_in.n_examples == 0) return hipSuccess;
+    if (p_in.n_examples == 0 && !p_in.host_extra_wgs) return hipSuccess;
     KernelParams p = p_in;
     const bool v2 = uses_resident_kernel(p, threads);
     resolve_row_mode(p, threads);  // (idempotent: run_batch has normally done it already, to size the LDS)
@@ -3047,143 +3247,6 @@ __global__ void __launch_bounds__(256) owner_apply_kernel(float *w, float *acc, 
         wa.x -= opt_step<OPT>(grad, wa.y, lr_rate, lr_mpt, lut_lr);  // block_lr.rs:145-147
         lr_store<true>(lr, h, wa);
     }
-}
-
-// The owner's consumer of the STREAMING form: a small persistent grid that drains this owner's circular regions while the sources' kernels fill them
-// (staleness = the examples in flight, not the step: hogwild.rs:89-103 -- a consumer never waits for a step to end).  Workgroups 0 .. n-1: one wave each, the LR
-// ring of source s IN ORDER, 64 positions at a time, publishing a consumed-prefix credit in the source's memory.  The other workgroups' waves: source
-// s = wave % n, positions start + j, start + j + J, ... of that source's row ring; a slot is handed back (ffm_free, in the source's memory) as soon as
-// its gradient row is in registers.  A wave leaves a ring when the ring's final position is known (fin: the source's kernel has ended) and reached.
-template <int OPT>
-__global__ void __launch_bounds__(256) owner_stream_kernel(const OwnerStream os) {
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, N = os.n;
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(os.resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    auto fin_of = [&](uint32_t idx, uint32_t &fin) -> bool {  // final position of ring idx (FFM: s, LR: n + s), once known
-        const unsigned long long v = __hip_atomic_load(os.fin + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        fin = (uint32_t)v;
-        return (v >> 32) != 0;
-    };
-    if (blockIdx.x < N) {
-        if (wave != 0) return;
-        const uint32_t s = blockIdx.x, lg = os.log2cap_lr, mask = (1u << lg) - 1u;
-        uint32_t base = os.start_lr[s];
-        for (;;) {
-            const uint32_t pq = base + lane;
-            unsigned long long word = 0;
-            bool have = false, past = false;
-            uint32_t fin = 0;
-            for (;;) {  // this lane's position: produced, or never going to be
-                word = __hip_atomic_load(os.lr_word[s] + (pq & mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                have = (((uint32_t)word >> 30) & 3u) == ((pq >> lg) % 3u) + 1u;
-                if (have) break;
-                if (fin_of(N + s, fin) && (int32_t)(pq - fin) >= 0) {
-                    past = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(8);
-            }
-            if (have) {
-                const uint32_t h = (uint32_t)word & 0x3fffffffu;
-                const float grad = __uint_as_float((uint32_t)(word >> 32));
-                float2 wa = lr_load<true>(os.lr, h);
-                wa.x -= opt_step<OPT>(grad, wa.y, os.lr_rate, os.lr_mpt, os.lut_lr);  // block_lr.rs:145-147
-                lr_store<true>(os.lr, h, wa);
-            }
-            const unsigned long long pm = __ballot(past);
-            const uint32_t done = pm ? (uint32_t)__builtin_ctzll(pm) : 64u;  // positions are consecutive: the first lane beyond the end
-            base += done;
-            if (lane == 0) __hip_atomic_store(os.lr_credit[s], base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (pm) break;
-        }
-        return;
-    }
-    const uint32_t W = (gridDim.x - N) * 4u, gw = (blockIdx.x - N) * 4u + wave;
-    const uint32_t s = gw % N, j = gw / N, J = W / N;
-    if (j >= J) return;
-    const uint32_t lg = os.log2cap_ffm, mask = (1u << lg) - 1u, gmask = lg ? (0xffffffffu >> lg) : 0xffffffffu, R = os.R;
-    for (uint32_t pq = os.start_ffm[s] + j;; pq += J) {
-        const uint32_t slot = pq & mask, gen = (pq >> lg) & gmask;
-        unsigned long long word;
-        bool past = false;
-        for (;;) {
-            unsigned long long wv = 0;
-            if (lane == 0) wv = __hip_atomic_load(os.ffm_tag[s] + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            word = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(wv >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wv);
-            if ((uint32_t)(word >> 32) == ((gen + 1u) & gmask)) break;
-            uint32_t fin = 0;
-            const bool known = fin_of(s, fin);
-            if (known && (int32_t)(pq - fin) >= 0) {
-                past = true;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(8);
-        }
-        if (past) break;
-        const uint32_t h = (uint32_t)word;
-        if (((R | h) & 3u) == 0) {
-            const __amdgpu_buffer_rsrc_t rg = make_rsrc(os.ffm_rows[s] + (size_t)slot * R, R * 4), rw = make_rsrc(os.w + h, R * 4), ra = make_rsrc(os.acc + h, R * 4);
-            // (rows of up to 512 floats: both chunks' loads before anything is stepped)
-            f4 gv[2], wv[2], av[2];
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const uint32_t e0 = (c * 64 + lane) * 4;
-                gv[c] = Vec<4>::load<kAuxSys>(rg, e0 * 4);
-                wv[c] = Vec<4>::load<kAuxSc1>(rw, e0 * 4);
-                av[c] = OPT == FWGPU_OPT_SGD ? Vec<4>::zero() : Vec<4>::load<kAuxSc1>(ra, e0 * 4);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (R <= 512 && lane == 0)  // the gradient row is in registers: its slot may be written for the next generation
-                __hip_atomic_store(os.ffm_free[s] + slot, (gen + 1u) & gmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const uint32_t e0 = (c * 64 + lane) * 4;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float a = av[c][q];
-                    wv[c][q] = wv[c][q] - opt_step<OPT>(gv[c][q], a, os.ffm_rate, os.ffm_mpt, os.lut_ffm);  // block_ffm.rs:279-282
-                    av[c][q] = a;
-                }
-                Vec<4>::store<kAuxSc1>(wv[c], rw, e0 * 4);
-                if (OPT != FWGPU_OPT_SGD) Vec<4>::store<kAuxSc1>(av[c], ra, e0 * 4);
-            }
-            for (uint32_t e0 = 512 + lane * 4; e0 < R; e0 += 256) {  // longer rows: the rest chunk by chunk
-                const f4 g2 = Vec<4>::load<kAuxSys>(rg, e0 * 4);
-                f4 w2 = Vec<4>::load<kAuxSc1>(rw, e0 * 4), a2 = OPT == FWGPU_OPT_SGD ? Vec<4>::zero() : Vec<4>::load<kAuxSc1>(ra, e0 * 4);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float a = a2[q];
-                    w2[q] = w2[q] - opt_step<OPT>(g2[q], a, os.ffm_rate, os.ffm_mpt, os.lut_ffm);
-                    a2[q] = a;
-                }
-                Vec<4>::store<kAuxSc1>(w2, rw, e0 * 4);
-                if (OPT != FWGPU_OPT_SGD) Vec<4>::store<kAuxSc1>(a2, ra, e0 * 4);
-            }
-            if (R > 512) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(os.ffm_free[s] + slot, (gen + 1u) & gmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        } else {
-            for (uint32_t e = lane; e < R; e += 64) {
-                const float grad = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(os.ffm_rows[s] + (size_t)slot * R + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-                float a = OPT == FWGPU_OPT_SGD ? 0.0f : __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned *>(os.acc + h + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                float wv = __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned *>(os.w + h + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                wv -= opt_step<OPT>(grad, a, os.ffm_rate, os.ffm_mpt, os.lut_ffm);
-                __hip_atomic_store(reinterpret_cast<unsigned *>(os.w + h + e), __float_as_uint(wv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (OPT != FWGPU_OPT_SGD) __hip_atomic_store(reinterpret_cast<unsigned *>(os.acc + h + e), __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(os.ffm_free[s] + slot, (gen + 1u) & gmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-}
-
-hipError_t launch_owner_stream(const OwnerStream &os, int optimizer, uint32_t workgroups, hipStream_t stream) {
-    switch (optimizer) {
-    case FWGPU_OPT_SGD: hipLaunchKernelGGL(owner_stream_kernel<FWGPU_OPT_SGD>, dim3(workgroups), dim3(256), 0, stream, os); break;
-    case FWGPU_OPT_ADAGRAD_FLEX: hipLaunchKernelGGL(owner_stream_kernel<FWGPU_OPT_ADAGRAD_FLEX>, dim3(workgroups), dim3(256), 0, stream, os); break;
-    default: hipLaunchKernelGGL(owner_stream_kernel<FWGPU_OPT_ADAGRAD_LUT>, dim3(workgroups), dim3(256), 0, stream, os); break;
-    }
-    return hipGetLastError();
 }
 
 hipError_t launch_owner_apply(const fwgpu_regressor *r, float *lr_base, const uint32_t *keys, const float *rows, uint32_t n_rows, const uint2 *lr_ent,

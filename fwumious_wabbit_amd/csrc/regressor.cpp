@@ -395,6 +395,9 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
     {   // FFM row store policy of hogwild launches and its write-back interval (kernels.hip, "store policy"); -1 / ~0 = the kernels' build default
         static const char *env_pol = getenv("FWGPU_STORE_POLICY"), *env_wb = getenv("FWGPU_WB_FLUSH_EVERY"), *env_pf = getenv("FWGPU_PREFETCH");
         p.store_policy = r->launch.store_policy >= 0 ? r->launch.store_policy : (env_pol ? atoi(env_pol) : -1);
+        static const char *env_th = getenv("FWGPU_ACC_HOT_THETA"), *env_sm = getenv("FWGPU_ACC_SAMPLE_LOG2");  // policy 3's two knobs (A/B runs)
+        p.acc_hot_theta = env_th ? (float)atof(env_th) : 4.0f;
+        p.acc_sample_log2 = env_sm ? (uint32_t)atoi(env_sm) : 3u;
         p.wb_flush_every = r->launch.wb_flush_every >= 0 ? (uint32_t)r->launch.wb_flush_every : (env_wb ? (uint32_t)atoi(env_wb) : 0xffffffffu);
         p.prefetch = (r->launch.prefetch && !(env_pf && env_pf[0] == '0')) ? 1 : 0;
         static const char *env_lk = getenv("FWGPU_LDS_KEEP");
@@ -539,8 +542,8 @@ static int run_batch_head_predict(fwgpu_regressor *r, fwgpu_batch *b, hipStream_
 }
 
 int run_batch_peer(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, const PeerShards *d_shards, hipStream_t stream,
-                   const PushRings *d_push) {
-    if (b->n == 0) return FWGPU_OK;
+                   const PushRings *d_push, uint32_t stream_consumers, uint32_t device_share) {
+    if (b->n == 0 && !stream_consumers) return FWGPU_OK;  // (a streaming step launches for an empty batch too: the rank's consumers serve the peers)
     if (r->nn.n_layers) return fail(FWGPU_ERR_INVALID, "peer-sharded tables: models with a deep head are not covered");
     KernelParams p;
     uint32_t threads = 0;
@@ -552,6 +555,8 @@ int run_batch_peer(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, con
     p.shards = d_shards;
     p.push = d_push;
     if (d_push) p.hot_lr_every = 0;  // (owner-side apply: every LR gradient travels to its owner, the constant feature's included)
+    p.host_extra_wgs = stream_consumers;
+    p.host_share = device_share;
     const uint32_t grid = pick_grid(r, p, mode, threads);
     FWGPU_HIP(hipMemsetAsync(b->work, 0, sizeof(uint32_t), stream));
     FWGPU_HIP(launch_example_kernel(p, r->cfg.optimizer, update != 0, grid, threads, stream));
@@ -897,7 +902,7 @@ int fwgpu_debug_set_option(fwgpu_regressor *r, int option, int value) {
         r->launch.hot_lr_every = (uint32_t)value;
         return FWGPU_OK;
     case 5:  // FFM row store policy of hogwild launches: 0 write-through, 1 weights write-back, 2 both tables write-back, -1 the build's default
-        if (value < -1 || value > 2) return fail(FWGPU_ERR_INVALID, "store policy option: -1, 0, 1 or 2");
+        if (value < -1 || value > 3) return fail(FWGPU_ERR_INVALID, "store policy option: -1, 0, 1, 2 or 3");
         r->launch.store_policy = value;
         return FWGPU_OK;
     case 6:  // write-back interval of policies 1 / 2: a workgroup issues buffer_wbl2 every `value` of its examples (0 never, -1 the build's default)

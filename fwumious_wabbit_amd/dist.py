@@ -66,6 +66,19 @@ class DistRank:
     def learn_sparse_batch(self, translator, batch):
         check(capi.lib().fwgpu_dist_learn_sparse_batch(self.h, C.byref(translator.c), batch.h))
 
+    def owner_stream_attach(self, log2_rows=0, log2_lr=0):
+        """collective, once: tables + the streaming regions of every rank (fwgpu_dist_owner_stream_attach)"""
+        check(capi.lib().fwgpu_dist_owner_stream_attach(self.h, int(log2_rows), int(log2_lr)))
+
+    def learn_owner_stream(self, translator, records, rec_off, update=True, consumer_workgroups=0) -> np.ndarray:
+        """one COLLECTIVE step of the streaming owner-side apply: this rank's records (may be none) -> their predictions"""
+        records, rec_off = _recs(records, rec_off)
+        n = len(rec_off) - 1
+        out = np.zeros(max(n, 1), dtype=np.float32)
+        check(capi.lib().fwgpu_dist_learn_owner_stream(self.h, C.byref(translator.c), ptr(records) if n else None, rec_off.ctypes.data_as(C.c_void_p), n, ptr(out),
+                                                       1 if update else 0, int(consumer_workgroups)))
+        return out[:n]
+
     def sparse_last_rows(self):
         """(FFM bucket rows, LR bucket entries) this rank sent in its last sparse step"""
         a, b = C.c_uint32(), C.c_uint32()

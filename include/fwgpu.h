@@ -310,6 +310,11 @@ int fwgpu_dist_group_learn_owner(fwgpu_dist_group *g, const fwgpu_translator_con
 int fwgpu_dist_group_learn_owner_stream(fwgpu_dist_group *g, const fwgpu_translator_config *t, const uint32_t *const *records, const uint64_t *const *rec_off,
                                         const uint32_t *n, fwgpu_batch *const *batches, float *const *predictions, int update, uint32_t log2_rows,
                                         uint32_t log2_lr, uint32_t consumer_workgroups);
+/* ... and its process-per-rank form: fwgpu_dist_owner_stream_attach (collective, once) maps tables and the streaming regions of every rank;
+ * fwgpu_dist_learn_owner_stream is ONE COLLECTIVE STEP (every rank calls it; n may be 0) with two small collectives (shapes, final positions). */
+int fwgpu_dist_owner_stream_attach(fwgpu_dist *d, uint32_t log2_rows, uint32_t log2_lr);
+int fwgpu_dist_learn_owner_stream(fwgpu_dist *d, const fwgpu_translator_config *t, const uint32_t *records, const uint64_t *rec_off, uint32_t n,
+                                  float *predictions, int update, uint32_t consumer_workgroups);
 int fwgpu_dist_rank(const fwgpu_dist *d, int *rank, int *n_ranks);
 /* ranks of the job as the RCCL communicator itself counts them (ncclCommCount); 0 for a member of an in-process group */
 int fwgpu_dist_comm_count(const fwgpu_dist *d, int *count);

@@ -23,7 +23,7 @@ args.mean_extra, args.zipf, args.ids, args.p_weighted, args.seed = 5.67, 1.05, 1
 N = int(os.environ.get("RANKS", 4))
 B = int(os.environ.get("B", 65536))
 K = int(os.environ.get("STEPS", 12))
-lgr, lgl, cwg = int(os.environ.get("LG_ROWS", 15)), int(os.environ.get("LG_LR", 16)), int(os.environ.get("CWG", 48))
+lgr, lgl, cwg = int(os.environ.get("LG_ROWS", 15)), int(os.environ.get("LG_LR", 16)), int(os.environ.get("CWG", 0))
 mi = bench.build_model_instance(fw, args, 0)
 regs = [fw.Regressor(mi) for _ in range(N)]
 fbt = fw.FeatureBufferTranslator(mi)

@@ -25,6 +25,8 @@ def main():
     mode = str(job["mode"])
     n_ns, k, bits, ffm_bits, opt = (int(job[x]) for x in ("n_ns", "k", "bits", "ffm_bits", "optimizer"))
     mi, _, _ = make_pair(n_ns, k, bits, ffm_bits, opt, lr=float(job["lr"]), ffm_lr=float(job["lr"]))
+    if "no_constant" in job.files and int(job["no_constant"]):
+        mi.add_constant_feature = False
     recs, off = job["recs"], job["off"]
     parts = job["parts"]  # [steps, n_ranks] records per rank and step
     id_file = str(job["id_file"])
@@ -50,6 +52,10 @@ def main():
     if mode == "owner_seq":
         d.set_mode(capi.MODE_SEQUENTIAL)
         d.owner_attach(4096, 4096)
+    if mode == "owner_sync":   # the step-synchronous form, hogwild: every rank's micro-batch pushed, counts exchanged, owners apply
+        d.owner_attach(65536, 65536)
+    if mode == "owner_stream":  # the streaming form with regions far smaller than a step
+        d.owner_stream_attach(int(job["log2_rows"]), int(job["log2_lr"]))
     preds = []
     pos = 0
     codes = []
@@ -116,6 +122,10 @@ def main():
             preds.append(d.learn_sparse(fbt, sub, so))
         elif mode == "peer":  # hogwild across the ranks: everybody at its own pace
             preds.append(d.learn_peer(fbt, sub, so))
+        elif mode == "owner_sync":
+            preds.append(d.learn_owner(fbt, sub, so))
+        elif mode == "owner_stream":
+            preds.append(d.learn_owner_stream(fbt, sub, so, consumer_workgroups=5 * n_ranks))
         elif mode == "owner_seq":
             # owner-side apply, one example per COLLECTIVE step, the ranks taking turns in rank order: the sequential reference.  Every rank calls
             # every step; the ranks whose turn it is not pass no record.
@@ -136,7 +146,7 @@ def main():
             raise SystemExit("unknown mode " + mode)
         pos += int(parts[s].sum())
     ranges = np.array(d.ranges(), dtype=np.uint64)
-    if mode in ("sharded", "peer", "peer_seq", "owner_seq"):
+    if mode in ("sharded", "peer", "peer_seq", "owner_seq", "owner_sync", "owner_stream"):
         d.gather_tables()
     tabs = [np.asarray(re.table_read(tt)) for tt in (capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC)]
     # the replica mode's exchange: all-reduce (sum) of a device buffer through the same communicator -- here the rank's FFM

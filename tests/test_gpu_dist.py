@@ -475,6 +475,7 @@ def test_owner_side_apply_concurrent_reaches_the_sequential_oracles_holdout_loss
     assert gpu_hold < 0.6931 and abs(gpu_hold - ref_hold) < gap / 3, (gpu_hold, ref_hold)
 
 
+@pytest.mark.timeout(300)
 @pytest.mark.parametrize("n_ranks,log2_rows,log2_lr", [(1, 7, 7), (2, 6, 6), (4, 8, 9)])
 def test_owner_side_apply_streaming_form_delivers_every_gradient_exactly_once(n_ranks, log2_rows, log2_lr):
     """The STREAMING owner-side apply (fwgpu_dist_group_learn_owner_stream): circular regions much smaller than a step (64 .. 256 slots for ~9000
@@ -523,6 +524,7 @@ def test_owner_side_apply_streaming_form_delivers_every_gradient_exactly_once(n_
     assert np.count_nonzero(tabs["sync"][1] != w0) > 20 * n_ex      # ... and so did the rows
 
 
+@pytest.mark.timeout(300)
 @pytest.mark.statistical
 @pytest.mark.parametrize("n_ranks", [2, 4])
 def test_owner_side_apply_streaming_form_learns_at_steps_far_beyond_the_synchronous_forms_bound(n_ranks):

@@ -30,11 +30,11 @@ def _fake_rccl_built():
     assert os.path.exists(FAKE)
 
 
-def _run_job(tmp_path, mode, n_ranks, cfg, recs, off, parts, allreduce=0):
+def _run_job(tmp_path, mode, n_ranks, cfg, recs, off, parts, allreduce=0, **extra):
     n_ns, k, bits, ffm_bits, opt, lr = cfg
     job = str(tmp_path / f"job_{mode}_{n_ranks}.npz")
     np.savez(job, n_ranks=n_ranks, mode=mode, n_ns=n_ns, k=k, bits=bits, ffm_bits=ffm_bits, optimizer=int(opt), lr=lr, recs=recs, off=off,
-             parts=np.asarray(parts, dtype=np.int64), id_file=str(tmp_path / f"id_{mode}_{n_ranks}"), allreduce=allreduce)
+             parts=np.asarray(parts, dtype=np.int64), id_file=str(tmp_path / f"id_{mode}_{n_ranks}"), allreduce=allreduce, **extra)
     env = dict(os.environ, FWGPU_RCCL_LIBRARY=FAKE, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, WORKER, job, str(r), str(tmp_path / f"out_{mode}_{n_ranks}_{r}.npz")], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(n_ranks)]
@@ -256,3 +256,26 @@ def test_a_rank_that_is_gone_ends_the_others_step_through_the_timeout(tmp_path):
         o = np.load(str(tmp_path / f"out_timeout_{r}.npz"))
         assert list(o["codes"]) == [8, 1], (r, o["codes"])  # FWGPU_ERR_PEER, then FWGPU_ERR_INVALID (no communicator left)
         assert float(o["seconds"]) < 60.0, float(o["seconds"])
+
+
+@pytest.mark.timeout(420)
+@pytest.mark.parametrize("n_ranks", [2, 4])
+def test_process_per_rank_streaming_owner_apply_delivers_every_gradient(tmp_path, n_ranks):
+    """The STREAMING owner-side apply with one process per rank (fwgpu_dist_owner_stream_attach / fwgpu_dist_learn_owner_stream): the regions and the
+    flow-control words of every rank reached through IPC mappings, circular regions of 128 slots for ~4000 gradient rows per source and step, two steps.
+    SGD steps add up, no constant feature, ids drawn uniformly from 10^7: the gathered tables must equal, entry for entry, what the step-synchronous
+    process-per-rank form leaves on the same job (see tests/test_gpu_dist.py, same check for the in-process group)."""
+    n_ns, k, bits, ffm_bits = 6, 4, 20, 20
+    cfg = (n_ns, k, bits, ffm_bits, fw.Optimizer.SGD, 0.01)
+    per, steps = 1200 // n_ranks, 2
+    recs, off = fw.synth_records(n_ns, 0.5, 0.0, 10_000_000, 0.3, 78, 0, steps * per * n_ranks)
+    parts = [[per] * n_ranks for _ in range(steps)]
+    a = _run_job(tmp_path, "owner_stream", n_ranks, cfg, recs, off, parts, no_constant=1, log2_rows=7, log2_lr=7)
+    b = _run_job(tmp_path, "owner_sync", n_ranks, cfg, recs, off, parts, no_constant=1)
+    for name in ("lr", "ffm_w"):
+        x, y = a[0][name], b[0][name]
+        bad = np.abs(x - y) > 2e-6 + 1e-4 * np.abs(y)
+        assert int(bad.sum()) <= 8, (name, int(bad.sum()), float(np.abs(x - y).max()))
+    for r in range(1, n_ranks):  # every rank gathered the same model
+        assert np.array_equal(a[r]["ffm_w"], a[0]["ffm_w"]) and np.array_equal(a[r]["lr"], a[0]["lr"])
+    assert np.abs(np.concatenate([o["preds"] for o in a]) - np.concatenate([o["preds"] for o in b])).max() < 1e-5
