@@ -652,6 +652,31 @@ def main():
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
 
+    def measured_copy_rate():
+        """What this device's memory delivers to the plainest kernel there is, measured in this run: a 1 GiB device-to-device copy (read + write bytes over
+        the time of 8 copies, HIP events).  The figure SURVEY 8d asks for next to the 8 TB/s spec: `roofline.peak_measured`."""
+        try:
+            n = 1 << 30
+            a = torch.empty(n, dtype=torch.uint8, device="cuda")
+            b = torch.empty(n, dtype=torch.uint8, device="cuda")
+            a.zero_()
+            for _ in range(3):
+                b.copy_(a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(8):
+                b.copy_(a)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 8
+            del a, b
+            torch.cuda.empty_cache()
+            return 2.0 * n / (ms * 1e-3) / 1e9
+        except Exception:  # a side measurement
+            return None
+
+    peak_measured = measured_copy_rate() if (rank == 0 and not use_dist) else None
+
     # ---- N>1: replicas + delta all-reduce (local SGD: the agreed model moves by the mean of the replicas' deltas)
     # Cadence: one exchange per 32 steps (0.5 M examples per GPU, ~150 ms of training); a shorter run still times one
     # whole exchange, started at its midpoint.  Every exchange started in the timed region also lands inside it.
@@ -954,6 +979,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                # (frac is against the 8 TB/s spec; this is what a 1 GiB device-to-device copy reaches on this very device in this run, read + write bytes)
+                "peak_measured": peak_measured,
+                "frac_of_peak_measured": (achieved / peak_measured) if peak_measured else None,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "pattern_ceiling_note": "profiles/r02_rowceil.txt (tools/rowceil.hip, raw output): random 960 B rows read 6.4 TB/s; written 3.2-3.5 TB/s as they lie (32 B aligned: "

@@ -1669,7 +1669,7 @@ StreamGeom stream_geom(uint32_t N, uint32_t R, uint32_t lg_ffm, uint32_t lg_lr) 
     g.off_tag = o; o = up(o + (size_t)N * cf * 8);             // owner role, per source
     g.off_rows = o; o = up(o + (size_t)N * cf * R * 4);
     g.off_lr = o; o = up(o + (size_t)N * cl * 8);
-    g.off_fin = o; o = up(o + (size_t)2 * N * 8);
+    g.off_fin = o; o = up(o + (size_t)2 * 2 * N * 8);           // two halves, by step parity (see stream_launch)
     g.off_free = o; o = up(o + (size_t)N * cf * 4);             // source role, per owner
     g.off_credit = o; o = up(o + (size_t)N * 4);
     g.off_cnt = o; o = up(o + (size_t)2 * N * 4);
@@ -1713,8 +1713,9 @@ int stream_reset(fwgpu_dist *d) {
     return FWGPU_OK;
 }
 uint32_t stream_consumer_wgs(uint32_t N, uint32_t wish, uint32_t waves_per_wg) {
-    // consumer waves: n for the LR regions + a multiple of n for the row regions' stripes
-    uint32_t G = wish ? wish : 32;
+    // consumer waves: n for the LR regions + the row regions' stripes.  0 = a share of the grid, chosen at launch (kernels.hip launch_persistent)
+    if (!wish) return 0xffffffffu;
+    uint32_t G = wish;
     while ((uint64_t)G * waves_per_wg < 2ull * N) G++;
     return G;
 }
@@ -1739,7 +1740,11 @@ int stream_launch(fwgpu_dist *d, const StreamGeom &geo, unsigned char *const bas
         os.start_ffm[s] = d->st_pos_ffm[s];
         os.start_lr[s] = d->st_pos_lr[s];
     }
-    os.fin = reinterpret_cast<const unsigned long long *>(d->st_mem + geo.off_fin);
+    // Final positions are kept per step PARITY: with no collective in a step, source A may be a whole step ahead of owner B (its producers need only room in
+    // B's regions) and store step t + 1's positions while B's consumers of step t still run -- into the other half.  It cannot be two steps ahead: its kernel
+    // t + 1 ends only when its own consumers have B's positions of step t + 1, i.e. after B's kernel t.
+    const size_t fin_half = (size_t)(d->st_step & 1u) * 2 * N;
+    os.fin = reinterpret_cast<const unsigned long long *>(d->st_mem + geo.off_fin) + fin_half;
     os.w = d->r->d_ffm_w;
     os.acc = d->r->d_ffm_acc;
     os.lr = lr_base;
@@ -1766,14 +1771,17 @@ int stream_launch(fwgpu_dist *d, const StreamGeom &geo, unsigned char *const bas
         pr.ffm_rows[o] = reinterpret_cast<float *>(base[o] + geo.off_rows) + (size_t)me * cf * R;
         pr.lr_word[o] = reinterpret_cast<unsigned long long *>(base[o] + geo.off_lr) + (size_t)me * cl;
         pr.ffm_free[o] = reinterpret_cast<const uint32_t *>(d->st_mem + geo.off_free) + (size_t)o * cf;
-        pr.fin_remote[o] = reinterpret_cast<unsigned long long *>(base[o] + geo.off_fin);
+        pr.fin_remote[o] = reinterpret_cast<unsigned long long *>(base[o] + geo.off_fin) + fin_half;
     }
     FWGPU_HIP(hipMemcpyAsync(d->st_mem + geo.off_own, &os, sizeof(os), hipMemcpyHostToDevice, d->stream));
     FWGPU_HIP(hipMemcpyAsync(d->st_mem + geo.off_push, &pr, sizeof(pr), hipMemcpyHostToDevice, d->stream));
     FWGPU_HIP(hipMemsetAsync(d->st_mem + geo.off_done, 0, 4, d->stream));
     FWGPU_HIP(hipStreamSynchronize(d->stream));  // (os / pr are locals)
+    // (a stripe's stride -- consumer waves per source -- stays below a quarter of a region's capacity: kernels.hip owner_stream_consume takes two positions of a
+    // stripe per round and the producers' flow control must never wait for a row such a round holds)
+    const uint32_t max_waves = (uint32_t)std::min<uint64_t>(0x7fffffffull, ((uint64_t)1 << geo.lg_ffm) / 4 * N + N);
     return run_batch_peer(d->r, d->cur, FWGPU_MODE_HOGWILD, update, d->d_peers, d->stream, reinterpret_cast<const PushRings *>(d->st_mem + geo.off_push), pr.consumers,
-                          d->st_share);
+                          d->st_share, max_waves);
 }
 // the launch has ended: where this rank's regions (as owner) stand now = where the next step's consumers start
 int stream_finish(fwgpu_dist *d, const StreamGeom &geo, int update, bool *near_wrap) {
@@ -1781,7 +1789,7 @@ int stream_finish(fwgpu_dist *d, const StreamGeom &geo, int update, bool *near_w
     FWGPU_HIP(hipStreamSynchronize(d->stream));
     if (update) {
         std::vector<unsigned long long> fin((size_t)2 * geo.N);
-        FWGPU_HIP(hipMemcpy(fin.data(), d->st_mem + geo.off_fin, fin.size() * 8, hipMemcpyDeviceToHost));
+        FWGPU_HIP(hipMemcpy(fin.data(), d->st_mem + geo.off_fin + (size_t)(d->st_step & 1u) * 2 * geo.N * 8, fin.size() * 8, hipMemcpyDeviceToHost));
         for (uint32_t s = 0; s < geo.N; s++) {
             if ((uint32_t)(fin[s] >> 32) != d->st_step || (uint32_t)(fin[geo.N + s] >> 32) != d->st_step)
                 return fail(FWGPU_ERR_DEVICE, "owner-side apply, streaming form: a source's final positions of the step never arrived");

@@ -167,7 +167,9 @@ struct KernelParams {
     uint32_t *work;                     // next example to process (zeroed before every launch)
     uint32_t host_cus, host_wgs_cap, host_grid_cap;    // host side only: persistent grid = occupancy x CUs (capped), when launched with grid 0
     uint32_t host_share;                               // host side only: ranks whose kernels must be RESIDENT TOGETHER on this device (streaming owner-side apply on a shared device): the persistent grid is an equal share of what the device holds (0 / 1: all of it)
-    uint32_t host_extra_wgs;                           // host side only: workgroups on top of the example workgroups (streaming owner-side apply: the consumers; at least one producer workgroup is kept)
+    uint32_t host_stream_max_consumer_waves;           // host side only: bound on the consumer waves of a streaming launch (a stripe's stride must stay well below a region's capacity)
+    uint32_t host_extra_wgs;                           // host side only: (0xffffffff: a share of the grid chosen at launch, written to PushRings::consumers before the kernel starts)
+                                                       // host side only: workgroups on top of the example workgroups (streaming owner-side apply: the consumers; at least one producer workgroup is kept)
     int32_t kernel_version;             // 0 = auto, 1 = force the v1 kernel, 2 = v2 where applicable
     unsigned long long *ticks;          // optional [8] per-phase shader-clock accumulators (debug), else NULL
 #ifndef FW_KP_NO_CANARY                 // (debug builds of scripts/kp_size_exp.sh drop the two fields: sizeof(KernelParams) 744 -> 728)
@@ -532,7 +534,7 @@ void lut_init(float *lut, float learning_rate, float power_t, float init_acc);
 KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int update);
 // the fused learn / predict launch of `b` with every row and LR entry reached in its owner's tables (generic kernel); d_shards: device copy
 int run_batch_peer(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, const PeerShards *d_shards, hipStream_t stream,
-                   const PushRings *d_push = nullptr, uint32_t stream_consumers = 0, uint32_t device_share = 1);
+                   const PushRings *d_push = nullptr, uint32_t stream_consumers = 0, uint32_t device_share = 1, uint32_t stream_max_consumer_waves = 0);
 // owner-side apply: the optimizer steps of `n_rows` pushed gradient rows / `n_lr` pushed LR gradients on this regressor's own tables
 hipError_t launch_owner_apply(const fwgpu_regressor *r, float *lr_base, const uint32_t *keys, const float *rows, uint32_t n_rows, const uint2 *lr_ent,
                               uint32_t n_lr, bool in_order, hipStream_t stream);

@@ -29,6 +29,8 @@
 #include "fwgpu_internal.h"
 #include "fwgpu_device.h"
 #include <cstdlib>
+#include <cstddef>
+#include <algorithm>
 
 // Store policy of the v2 kernel's FFM row traffic in HOGWILD launches (template argument POL of fw_example_kernel_r, chosen per launch from
 // KernelParams::store_policy; fwgpu_debug_set_option(r, 5, policy) / FWGPU_STORE_POLICY select it at run time, tests/test_gpu_conservation.py
@@ -1532,84 +1534,112 @@ __device__ __forceinline__ void owner_stream_consume(const OwnerStream &os, uint
     const uint32_t s = gw % N, j = gw / N, J = W / N;
     if (j >= J) return;
     const uint32_t lg = os.log2cap_ffm, mask = (1u << lg) - 1u, gmask = lg ? (0xffffffffu >> lg) : 0xffffffffu, R = os.R;
-    for (uint32_t pq = os.start_ffm[s] + j;; pq += J) {
-        const uint32_t slot = pq & mask, gen = (pq >> lg) & gmask;
-        unsigned long long word;
-        bool past = false;
+    // KR positions of the stripe per round: their tag words are polled together (lane u loads tag u: one round trip), the rows of those that are there are
+    // loaded together (one more), then stepped.  A round waits until each of its positions is either there or beyond the region's final position.
+    constexpr int KR = 2;
+    for (uint32_t p0 = os.start_ffm[s] + j;; p0 += KR * J) {
+        uint32_t hh[KR];
+        bool on[KR];
+        uint32_t n_past = 0;
         for (;;) {
             unsigned long long wv = 0;
-            if (lane == 0) wv = __hip_atomic_load(os.ffm_tag[s] + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            word = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(wv >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wv);
-            if ((uint32_t)(word >> 32) == ((gen + 1u) & gmask)) break;
-            uint32_t fin = 0, known = 0;
-            if (lane == 0) known = fin_of(s, fin) ? 1u : 0u;
-            known = __builtin_amdgcn_readfirstlane(known);
-            fin = __builtin_amdgcn_readfirstlane(fin);
-            if (known && (int32_t)(pq - fin) >= 0) {
-                past = true;
-                break;
+            if (lane < (uint32_t)KR) {
+                const uint32_t pq = p0 + lane * J;
+                wv = __hip_atomic_load(os.ffm_tag[s] + (pq & mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
+            uint32_t fin = 0, known = 0;
+            bool all = true;
+            n_past = 0;
+#pragma unroll
+            for (int u = 0; u < KR; ++u) {
+                const uint32_t pq = p0 + (uint32_t)u * J, gen = (pq >> lg) & gmask;
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wv >> 32), u), lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wv, u);
+                on[u] = hi == ((gen + 1u) & gmask);
+                hh[u] = lo;
+                if (!on[u]) {
+                    if (!known) {  // (one look at the final position per poll)
+                        uint32_t k_ = 0, f_ = 0;
+                        if (lane == 0) k_ = fin_of(s, f_) ? 1u : 0u;
+                        known = __builtin_amdgcn_readfirstlane(k_) ? 1u : 2u;
+                        fin = __builtin_amdgcn_readfirstlane(f_);
+                    }
+                    if (known == 1u && (int32_t)(pq - fin) >= 0) n_past++;
+                    else all = false;
+                }
+            }
+            if (all) break;
             __builtin_amdgcn_s_sleep(8);
         }
-        if (past) break;
-        const uint32_t h = (uint32_t)word;
-        if (((R | h) & 3u) == 0) {
-            const __amdgpu_buffer_rsrc_t rg = make_rsrc(os.ffm_rows[s] + (size_t)slot * R, R * 4), rw = make_rsrc(os.w + h, R * 4), ra = make_rsrc(os.acc + h, R * 4);
-            // (rows of up to 512 floats: both chunks' loads before anything is stepped)
-            f4 gv[2], wv[2], av[2];
+        // (positions of a stripe are consumed in order: once one is beyond the end, the later ones are too)
+        f4 gv[KR][2], wv2[KR][2], av[KR][2];
+        bool vec[KR];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
+        for (int u = 0; u < KR; ++u) {
+            vec[u] = on[u] && ((R | hh[u]) & 3u) == 0;
+            const uint32_t slot = (p0 + (uint32_t)u * J) & mask;
+            const __amdgpu_buffer_rsrc_t rg = make_rsrc(os.ffm_rows[s] + (size_t)slot * R, vec[u] ? R * 4 : 0), rw = make_rsrc(os.w + hh[u], vec[u] ? R * 4 : 0),
+                                         ra = make_rsrc(os.acc + hh[u], vec[u] ? R * 4 : 0);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {  // (rows of up to 512 floats: both chunks' loads before anything is stepped; a slot that is not there has zero-length descriptors)
                 const uint32_t e0 = (c * 64 + lane) * 4;
-                gv[c] = Vec<4>::load<kAuxSys>(rg, e0 * 4);
-                wv[c] = Vec<4>::load<kAuxSc1>(rw, e0 * 4);
-                av[c] = OPT == FWGPU_OPT_SGD ? Vec<4>::zero() : Vec<4>::load<kAuxSc1>(ra, e0 * 4);
+                gv[u][c] = Vec<4>::load<kAuxSys>(rg, e0 * 4);
+                wv2[u][c] = Vec<4>::load<kAuxSc1>(rw, e0 * 4);
+                av[u][c] = OPT == FWGPU_OPT_SGD ? Vec<4>::zero() : Vec<4>::load<kAuxSc1>(ra, e0 * 4);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (R <= 512 && lane == 0)  // the gradient row is in registers: its slot may be written for the next generation
-                __hip_atomic_store(os.ffm_free[s] + slot, (gen + 1u) & gmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const uint32_t e0 = (c * 64 + lane) * 4;
+        for (int u = 0; u < KR; ++u) {
+            if (!on[u]) continue;
+            const uint32_t pq = p0 + (uint32_t)u * J, slot = pq & mask, gen = (pq >> lg) & gmask, h = hh[u];
+            if (vec[u]) {
+                if (R <= 512 && lane == 0)  // the gradient row is in registers: its slot may be written for the next generation
+                    __hip_atomic_store(os.ffm_free[s] + slot, (gen + 1u) & gmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const __amdgpu_buffer_rsrc_t rg = make_rsrc(os.ffm_rows[s] + (size_t)slot * R, R * 4), rw = make_rsrc(os.w + h, R * 4), ra = make_rsrc(os.acc + h, R * 4);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float a = av[c][q];
-                    wv[c][q] = wv[c][q] - opt_step<OPT>(gv[c][q], a, os.ffm_rate, os.ffm_mpt, os.lut_ffm);  // block_ffm.rs:279-282
-                    av[c][q] = a;
+                for (int c = 0; c < 2; ++c) {
+                    const uint32_t e0 = (c * 64 + lane) * 4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float a = av[u][c][q];
+                        wv2[u][c][q] = wv2[u][c][q] - opt_step<OPT>(gv[u][c][q], a, os.ffm_rate, os.ffm_mpt, os.lut_ffm);  // block_ffm.rs:279-282
+                        av[u][c][q] = a;
+                    }
+                    Vec<4>::store<kAuxSc1>(wv2[u][c], rw, e0 * 4);
+                    if (OPT != FWGPU_OPT_SGD) Vec<4>::store<kAuxSc1>(av[u][c], ra, e0 * 4);
                 }
-                Vec<4>::store<kAuxSc1>(wv[c], rw, e0 * 4);
-                if (OPT != FWGPU_OPT_SGD) Vec<4>::store<kAuxSc1>(av[c], ra, e0 * 4);
-            }
-            for (uint32_t e0 = 512 + lane * 4; e0 < R; e0 += 256) {  // longer rows: the rest chunk by chunk
-                const f4 g2 = Vec<4>::load<kAuxSys>(rg, e0 * 4);
-                f4 w2 = Vec<4>::load<kAuxSc1>(rw, e0 * 4), a2 = OPT == FWGPU_OPT_SGD ? Vec<4>::zero() : Vec<4>::load<kAuxSc1>(ra, e0 * 4);
+                for (uint32_t e0 = 512 + lane * 4; e0 < R; e0 += 256) {  // longer rows: the rest chunk by chunk
+                    const f4 g2 = Vec<4>::load<kAuxSys>(rg, e0 * 4);
+                    f4 w2 = Vec<4>::load<kAuxSc1>(rw, e0 * 4), a2 = OPT == FWGPU_OPT_SGD ? Vec<4>::zero() : Vec<4>::load<kAuxSc1>(ra, e0 * 4);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float a = a2[q];
-                    w2[q] = w2[q] - opt_step<OPT>(g2[q], a, os.ffm_rate, os.ffm_mpt, os.lut_ffm);
-                    a2[q] = a;
+                    for (int q = 0; q < 4; ++q) {
+                        float a = a2[q];
+                        w2[q] = w2[q] - opt_step<OPT>(g2[q], a, os.ffm_rate, os.ffm_mpt, os.lut_ffm);
+                        a2[q] = a;
+                    }
+                    Vec<4>::store<kAuxSc1>(w2, rw, e0 * 4);
+                    if (OPT != FWGPU_OPT_SGD) Vec<4>::store<kAuxSc1>(a2, ra, e0 * 4);
                 }
-                Vec<4>::store<kAuxSc1>(w2, rw, e0 * 4);
-                if (OPT != FWGPU_OPT_SGD) Vec<4>::store<kAuxSc1>(a2, ra, e0 * 4);
-            }
-            if (R > 512) {
+                if (R > 512) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(os.ffm_free[s] + slot, (gen + 1u) & gmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            } else {
+                for (uint32_t e = lane; e < R; e += 64) {
+                    const float grad = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(os.ffm_rows[s] + (size_t)slot * R + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+                    float a = OPT == FWGPU_OPT_SGD ? 0.0f : __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned *>(os.acc + h + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    float wv = __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned *>(os.w + h + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    wv -= opt_step<OPT>(grad, a, os.ffm_rate, os.ffm_mpt, os.lut_ffm);
+                    __hip_atomic_store(reinterpret_cast<unsigned *>(os.w + h + e), __float_as_uint(wv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (OPT != FWGPU_OPT_SGD) __hip_atomic_store(reinterpret_cast<unsigned *>(os.acc + h + e), __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) __hip_atomic_store(os.ffm_free[s] + slot, (gen + 1u) & gmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
-        } else {
-            for (uint32_t e = lane; e < R; e += 64) {
-                const float grad = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(os.ffm_rows[s] + (size_t)slot * R + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-                float a = OPT == FWGPU_OPT_SGD ? 0.0f : __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned *>(os.acc + h + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                float wv = __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned *>(os.w + h + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                wv -= opt_step<OPT>(grad, a, os.ffm_rate, os.ffm_mpt, os.lut_ffm);
-                __hip_atomic_store(reinterpret_cast<unsigned *>(os.w + h + e), __float_as_uint(wv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (OPT != FWGPU_OPT_SGD) __hip_atomic_store(reinterpret_cast<unsigned *>(os.acc + h + e), __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(os.ffm_free[s] + slot, (gen + 1u) & gmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+        if (n_past) break;
     }
 }
-
 
 // PH = 0: the fused learn / predict step.  PH = 1 (FWD) and PH = 3 (UPD): the two table-touching halves of the synchronous
 // micro-batch pipeline -- every example of the batch sees the weights of the batch start, updates are applied afterwards:
@@ -2180,8 +2210,23 @@ static hipError_t launch_persistent(K kern, const KernelParams &p, uint32_t grid
         grid = (uint32_t)(g < p.n_examples ? g : p.n_examples);
         if (p.host_grid_cap && grid > p.host_grid_cap) grid = p.host_grid_cap;
         if (p.host_extra_wgs) {  // streaming owner-side apply: the consumers come on top of the example workgroups, all of them resident together
-            const uint32_t room = g > p.host_extra_wgs ? (uint32_t)g - p.host_extra_wgs : 1u;
-            grid = std::max<uint32_t>(1u, std::min(grid, room)) + p.host_extra_wgs;
+            uint32_t extra = p.host_extra_wgs;
+            if (extra == 0xffffffffu) {
+                // A share of the grid.  The consumers do the larger part of an example's memory work (gradient row in, w and acc read-modify-written: 960 B of
+                // traffic against the producers' 384 B per 240-float row): five eighths by default (FWGPU_STREAM_CONSUMER_EIGHTHS, A/B runs).
+                static const uint32_t eighths = [] { const char *e = std::getenv("FWGPU_STREAM_CONSUMER_EIGHTHS"); const int v = e ? std::atoi(e) : 5; return (uint32_t)(v < 1 ? 1 : v > 7 ? 7 : v); }();
+                extra = std::max<uint32_t>(1u, (uint32_t)(g * eighths / 8));
+                const uint32_t waves = threads / 64u;
+                if (p.host_stream_max_consumer_waves && extra * waves > p.host_stream_max_consumer_waves) extra = std::max<uint32_t>(1u, p.host_stream_max_consumer_waves / waves);
+                static thread_local uint32_t slot[64];
+                static thread_local uint32_t next = 0;
+                uint32_t *v = &slot[next++ & 63u];
+                *v = extra;
+                e = hipMemcpyAsync(const_cast<char *>(reinterpret_cast<const char *>(p.push)) + offsetof(PushRings, consumers), v, 4, hipMemcpyHostToDevice, stream);
+                if (e != hipSuccess) return e;
+            }
+            const uint32_t room = g > extra ? (uint32_t)g - extra : 1u;
+            grid = std::max<uint32_t>(1u, std::min(grid, room)) + extra;
         }
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, p);

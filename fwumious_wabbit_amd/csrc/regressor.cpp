@@ -542,7 +542,7 @@ static int run_batch_head_predict(fwgpu_regressor *r, fwgpu_batch *b, hipStream_
 }
 
 int run_batch_peer(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, const PeerShards *d_shards, hipStream_t stream,
-                   const PushRings *d_push, uint32_t stream_consumers, uint32_t device_share) {
+                   const PushRings *d_push, uint32_t stream_consumers, uint32_t device_share, uint32_t stream_max_consumer_waves) {
     if (b->n == 0 && !stream_consumers) return FWGPU_OK;  // (a streaming step launches for an empty batch too: the rank's consumers serve the peers)
     if (r->nn.n_layers) return fail(FWGPU_ERR_INVALID, "peer-sharded tables: models with a deep head are not covered");
     KernelParams p;
@@ -557,6 +557,7 @@ int run_batch_peer(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, con
     if (d_push) p.hot_lr_every = 0;  // (owner-side apply: every LR gradient travels to its owner, the constant feature's included)
     p.host_extra_wgs = stream_consumers;
     p.host_share = device_share;
+    p.host_stream_max_consumer_waves = stream_max_consumer_waves;
     const uint32_t grid = pick_grid(r, p, mode, threads);
     FWGPU_HIP(hipMemsetAsync(b->work, 0, sizeof(uint32_t), stream));
     FWGPU_HIP(launch_example_kernel(p, r->cfg.optimizer, update != 0, grid, threads, stream));

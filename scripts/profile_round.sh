@@ -6,10 +6,14 @@ TAG=${1:-r01}
 R=$PWD
 OUT=$R/gpurun_out
 mkdir -p $OUT
-timeout 600 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+timeout 900 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 tail -c 600 $OUT/${TAG}_bench.json
+# the driver's shape, and the protocol at its stated length (16 Mi examples, three passes)
+timeout 900 python3 bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_driver_shape.json 2> $OUT/${TAG}_bench_driver_shape.err
+timeout 900 python3 bench.py --long > $OUT/${TAG}_bench_long.json 2> $OUT/${TAG}_bench_long.err
+tail -c 400 $OUT/${TAG}_bench_long.json
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-traffic"
+CMD="python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-traffic --no-config-e --no-config-b"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o trace -- $CMD > $OUT/${TAG}_trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --pmc FETCH_SIZE -d $OUT/${TAG}_fetch -o fetch -- $CMD > $OUT/${TAG}_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --pmc WRITE_SIZE -d $OUT/${TAG}_write -o write -- $CMD > $OUT/${TAG}_write.log 2>&1
@@ -24,3 +28,12 @@ tail -c 700 $OUT/${TAG}_bench_dist1_replica.json; echo; tail -c 400 $OUT/${TAG}_
 timeout 600 python3 bench.py --k 16 --nn-layers 2 --batch 8192 --steps 24 --warmup 2 > $OUT/${TAG}_configE_exact.json 2> $OUT/${TAG}_configE_exact.err
 timeout 600 python3 bench.py --k 16 --nn-layers 2 --head minibatch --batch 1024 --steps 192 --warmup 4 --no-cpu-baseline > $OUT/${TAG}_configE_minibatch.json 2> $OUT/${TAG}_configE_minibatch.err
 tail -c 500 $OUT/${TAG}_configE_exact.json | head -c 300; echo
+# config E under the profiler: kernel trace + the two PMC passes of the exact-head run, and the predict-only (batched head) launches
+cd /tmp
+ECMD="python3 $R/bench.py --k 16 --nn-layers 2 --batch 8192 --steps 12 --warmup 2 --holdout 65536 --no-cpu-baseline --no-traffic --no-config-e --no-config-b"
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_E_trace -o trace -- $ECMD > $OUT/${TAG}_E_trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --pmc FETCH_SIZE -d $OUT/${TAG}_E_fetch -o fetch -- $ECMD > $OUT/${TAG}_E_fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --pmc WRITE_SIZE -d $OUT/${TAG}_E_write -o write -- $ECMD > $OUT/${TAG}_E_write.log 2>&1
+cd $R
+python3 scripts/rocprof_summary.py $(find $OUT/${TAG}_E_trace $OUT/${TAG}_E_fetch $OUT/${TAG}_E_write -name "*.db" | sort) > $OUT/${TAG}_configE_rocprofv3.txt 2>&1
+head -12 $OUT/${TAG}_configE_rocprofv3.txt

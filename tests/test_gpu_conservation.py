@@ -160,7 +160,7 @@ def test_in_order_launch_applies_every_step_under_every_policy():
 # (policy, write-back interval): (-1, -1) = what the build ships (policy 1: weight rows write-back, accumulators write-through; one buffer_wbl2 per
 # workgroup every 128 examples); the asserts are about it, the others are measured next to it and printed
 SHIPPED = (-1, -1)
-MEASURED = [(0, 0), (1, 0), (2, 0), (2, 64)]
+MEASURED = [(0, 0), (1, 0), (2, 0), (2, 64), (3, 0)]  # (3: round 5, thinned accumulator stores on hot rows)
 REREAD = "-1,-1 L0"
 
 # Measured on MI355X (profiles/r04c_conservation.txt, r04b_conservation.txt; rows in a third of all examples, ~170 concurrent holders):

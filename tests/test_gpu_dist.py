@@ -493,7 +493,7 @@ def test_owner_side_apply_streaming_form_delivers_every_gradient_exactly_once(n_
     n_ex = 3000 - 3000 % n_ranks
     recs, off = fw.synth_records(n_ns, 0.5, 0.0, 10_000_000, 0.3, 77, 0, 2 * n_ex)
     per = n_ex // n_ranks
-    tabs = {}
+    tabs, preds_of = {}, {}
     for form in ("stream", "sync"):
         regs = [fw.Regressor(mi) for _ in range(n_ranks)]
         g = DistGroup(regs)
@@ -505,9 +505,10 @@ def test_owner_side_apply_streaming_form_delivers_every_gradient_exactly_once(n_
                 rr.append(recs[int(off[a_]):int(off[b_])])
                 oo.append(off[a_:b_ + 1] - off[a_])
             if form == "stream":
-                g.learn_owner_stream(fbt, rr, oo, log2_rows=log2_rows, log2_lr=log2_lr, consumer_workgroups=5 * n_ranks)
+                outs = g.learn_owner_stream(fbt, rr, oo, log2_rows=log2_rows, log2_lr=log2_lr, consumer_workgroups=5 * n_ranks)
             else:
-                g.learn_owner(fbt, rr, oo)
+                outs = g.learn_owner(fbt, rr, oo)
+            preds_of.setdefault(form, []).extend(outs)
         g.gather_tables()
         tabs[form] = [regs[0].table_read(t) for t in (capi.TABLE_LR, capi.TABLE_FFM_W)]
         if form == "stream":
@@ -517,6 +518,18 @@ def test_owner_side_apply_streaming_form_delivers_every_gradient_exactly_once(n_
         g.close()
         for r in regs:
             r.close()
+    # the LR side in closed form: entry h must end at -lr * sum over its occurrences of g * v, g = p - y from the form's OWN predictions (block_lr.rs:143-147)
+    y = recs[off[:-1].astype(np.int64) + 1].astype(np.float64)
+    for form in ("stream", "sync"):
+        p_ = np.concatenate(preds_of[form]).astype(np.float64)
+        want = np.zeros(1 << bits, dtype=np.float64)
+        for e in range(2 * n_ex):
+            lrb = np.asarray(fbt.translate(recs[int(off[e]):int(off[e + 1])]).lr_buffer)
+            np.add.at(want, lrb["hash"].astype(np.int64), -0.01 * (p_[e] - y[e]) * lrb["value"].astype(np.float64))
+        got = tabs[form][0]
+        got = got[0::2] if got.size == 2 << bits else got
+        bad = np.abs(got - want) > 2e-6 + 2e-4 * np.abs(want)
+        assert int(bad.sum()) <= 8, (form, "LR entries that are not the sum of their gradients", int(bad.sum()), float(np.abs(got - want).max()))
     for name, a_, b_ in (("LR", tabs["stream"][0], tabs["sync"][0]), ("FFM", tabs["stream"][1], tabs["sync"][1])):
         bad = np.abs(a_ - b_) > 2e-6 + 1e-4 * np.abs(b_)
         assert int(bad.sum()) <= max(8, int(0.002 * np.count_nonzero(b_ != 0))), (name, int(bad.sum()), float(np.abs(a_ - b_).max()))
