@@ -1671,7 +1671,7 @@ StreamGeom stream_geom(uint32_t N, uint32_t R, uint32_t lg_ffm, uint32_t lg_lr) 
     g.off_lr = o; o = up(o + (size_t)N * cl * 8);
     g.off_fin = o; o = up(o + (size_t)2 * 2 * N * 8);           // two halves, by step parity (see stream_launch)
     g.off_free = o; o = up(o + (size_t)N * cf * 4);             // source role, per owner
-    g.off_credit = o; o = up(o + (size_t)N * 4);
+    g.off_credit = o; o = up(o + (size_t)N * cl * 4);           // (per owner: the LR slots' free generations)
     g.off_cnt = o; o = up(o + (size_t)2 * N * 4);
     g.off_done = o; o = up(o + 4);
     g.off_own = o; o = up(o + sizeof(OwnerStream));             // the two descriptors the kernel reads
@@ -1736,7 +1736,7 @@ int stream_launch(fwgpu_dist *d, const StreamGeom &geo, unsigned char *const bas
         os.ffm_rows[s] = reinterpret_cast<const float *>(d->st_mem + geo.off_rows) + (size_t)s * cf * R;
         os.lr_word[s] = reinterpret_cast<const unsigned long long *>(d->st_mem + geo.off_lr) + (size_t)s * cl;
         os.ffm_free[s] = reinterpret_cast<uint32_t *>(base[s] + geo.off_free) + (size_t)me * cf;
-        os.lr_credit[s] = reinterpret_cast<uint32_t *>(base[s] + geo.off_credit) + me;
+        os.lr_free[s] = reinterpret_cast<uint32_t *>(base[s] + geo.off_credit) + (size_t)me * cl;
         os.start_ffm[s] = d->st_pos_ffm[s];
         os.start_lr[s] = d->st_pos_lr[s];
     }
@@ -1760,7 +1760,6 @@ int stream_launch(fwgpu_dist *d, const StreamGeom &geo, unsigned char *const bas
     pr.log2cap_ffm = geo.lg_ffm;
     pr.log2cap_lr = geo.lg_lr;
     pr.cnt = reinterpret_cast<uint32_t *>(d->st_mem + geo.off_cnt);
-    pr.lr_credit = reinterpret_cast<const uint32_t *>(d->st_mem + geo.off_credit);
     pr.consumers = update ? consumer_wgs : 0;  // (a read-only step pushes nothing: nobody has anything to drain)
     pr.step = d->st_step;
     pr.src = me;
@@ -1771,6 +1770,7 @@ int stream_launch(fwgpu_dist *d, const StreamGeom &geo, unsigned char *const bas
         pr.ffm_rows[o] = reinterpret_cast<float *>(base[o] + geo.off_rows) + (size_t)me * cf * R;
         pr.lr_word[o] = reinterpret_cast<unsigned long long *>(base[o] + geo.off_lr) + (size_t)me * cl;
         pr.ffm_free[o] = reinterpret_cast<const uint32_t *>(d->st_mem + geo.off_free) + (size_t)o * cf;
+        pr.lr_free[o] = reinterpret_cast<const uint32_t *>(d->st_mem + geo.off_credit) + (size_t)o * cl;
         pr.fin_remote[o] = reinterpret_cast<unsigned long long *>(base[o] + geo.off_fin) + fin_half;
     }
     FWGPU_HIP(hipMemcpyAsync(d->st_mem + geo.off_own, &os, sizeof(os), hipMemcpyHostToDevice, d->stream));

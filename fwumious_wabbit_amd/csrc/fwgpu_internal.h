@@ -82,7 +82,8 @@ struct PushRings {
     unsigned long long *ffm_tag[8];  // per owner: [cap_ffm] tag words of this source's ring in the owner's memory
     unsigned long long *lr_word[8];  // per owner: [cap_lr] {hash (30 bits) | ((generation % 3) + 1) << 30, gradient bits << 32}
     const uint32_t *ffm_free[8];     // source-local, per owner: [cap_ffm] the generation slot q may be written for (the owner's consumer stores it)
-    const uint32_t *lr_credit;       // source-local [n]: LR positions of this source the owner o has consumed (a prefix)
+    const uint32_t *lr_credit;       // (unused since the LR regions got per-slot free generations like the rows)
+    const uint32_t *lr_free[8];      // source-local, per owner: [cap_lr] the generation LR slot q may be written for
     // The rank's consumers run INSIDE its example kernel: the first `consumers` workgroups of the launch drain this rank's regions as owner (`own`), the
     // others are the producers.  A producer workgroup that finds no more examples counts itself in `done`; the last one stores every region's final
     // position -- tagged with the step -- into the OWNERS' memory (fin_remote[o] + this rank's index, then + n for the LR region): the owners' consumers
@@ -100,7 +101,8 @@ struct OwnerStream {
     const float *ffm_rows[8];
     const unsigned long long *lr_word[8];
     uint32_t *ffm_free[8];                  // per source: slot -> generation, in the SOURCE's memory
-    uint32_t *lr_credit[8];                 // per source: this owner's word of the source's credit array
+    uint32_t *lr_credit[8];                 // (unused)
+    uint32_t *lr_free[8];                   // per source: LR slot -> generation, in the SOURCE's memory
     uint32_t start_ffm[8], start_lr[8];     // first position of this step, per source
     const unsigned long long *fin;          // owner-local [2n]: {step << 32 | final position}, stored by source s's last producer workgroup (FFM regions, then LR)
     uint32_t step, pad_;                    // the step this launch belongs to (fin words of other steps are not this launch's)
@@ -197,6 +199,7 @@ struct KernelParams {
     uint32_t selfw_stride;
     float *gbuf;                        // [n] general gradient of every example (MID -> UPD)
     float *xbuf, *dxbuf;                // deep head, mini-batched: x and d logit/d x per example [n * nn.X]
+    int32_t no_selfw;                   // read-only launch on the v2 kernel: the entries' own slots (Lds::selfw) are not kept -- only the update and the generic kernel's head read them (resolve_row_mode)
     int32_t emit_x;                     // read-only launch of a model with a deep head on the v2 kernel: the example's head input x goes to xbuf, {label, importance} to gbuf,
                                         // and the layers run afterwards for the whole batch on the matrix cores (regressor.cpp run_batch, head.hip head_step)
 #if defined(FW_KP_PAD_POS) && FW_KP_PAD_POS == 2  // debug builds (scripts/kp_pos_exp.sh): 16 bytes HERE

@@ -324,12 +324,12 @@ __device__ __forceinline__ float2 lr_forward_pair(const KernelParams &p, const L
 
 __host__ __device__ inline size_t lds_layout(uint32_t F, uint32_t k, uint32_t max_ffm, uint32_t max_lr, uint32_t n_luts,
                                              uint32_t max_rec, uint32_t tr_items, uint32_t nn_floats, bool chain, size_t *off /*[25]*/,
-                                             uint32_t pf_words = 0, uint32_t tr_words = 0, uint32_t keep_words = 0, bool t_in_lds = true) {
+                                             uint32_t pf_words = 0, uint32_t tr_words = 0, uint32_t keep_words = 0, bool t_in_lds = true, bool selfw_on = true) {
     size_t o = 0;
     size_t R = (size_t)F * k;
     const size_t t_bytes = t_in_lds ? 4 * F * R : 0;  // (phase kernels keep T in the split record: KernelParams::t_global)
     off[0] = o; o = align16(o + t_bytes);
-    off[1] = o; o = align16(o + 4 * (size_t)max_ffm * k);
+    off[1] = o; o = align16(o + (selfw_on ? 4 * (size_t)max_ffm * k : 0));
     off[2] = o; o = align16(o + 4 * (size_t)kLutSize * n_luts);
     off[3] = o; o = align16(o + 4 * (size_t)max_ffm);
     off[4] = o; o = align16(o + 4 * (size_t)max_ffm);
@@ -778,7 +778,7 @@ size_t example_kernel_lds_bytes(const KernelParams &p, int optimizer) {
     // (lut_lds_forced: the v2 kernel's single-chunk instantiations ALWAYS keep the AdaGrad LUT in LDS -- kLdsLut -- whatever option 1 says)
     return lds_layout(p.F, p.k, p.max_ffm, p.max_lr, (optimizer == FWGPU_OPT_ADAGRAD_LUT && p.update && (!p.lut_global || p.lut_lds_forced)) ? 1 : 0,
                       p.records ? p.max_rec : 0, p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off,
-                      (p.records && p.prefetch) ? p.max_rec : 0, (p.records && p.tr_lds) ? tr_lds_words(p.tr) : 0, p.lds_keep_words, !p.t_global);
+                      (p.records && p.prefetch) ? p.max_rec : 0, (p.records && p.tr_lds) ? tr_lds_words(p.tr) : 0, p.lds_keep_words, !p.t_global, !p.no_selfw);
 }
 #endif
 
@@ -1434,7 +1434,7 @@ __device__ __forceinline__ void bind_lds(const KernelParams &p, unsigned char *s
     size_t off[25];
     lds_layout(p.F, p.k, p.max_ffm, p.max_lr, use_lut ? 1 : 0, p.records ? p.max_rec : 0,
                p.records ? p.tr.n_pairs + p.tr.n_combos + 2 : 0, nn_lds_floats(p), p.chain != 0, off, (p.records && p.prefetch) ? p.max_rec : 0,
-               (p.records && p.tr_lds) ? tr_lds_words(p.tr) : 0, p.lds_keep_words, !p.t_global);
+               (p.records && p.tr_lds) ? tr_lds_words(p.tr) : 0, p.lds_keep_words, !p.t_global, !p.no_selfw);
     s.T = reinterpret_cast<float *>(smem + off[0]);
     s.selfw = reinterpret_cast<float *>(smem + off[1]);
     s.lut = reinterpret_cast<float *>(smem + off[2]);
@@ -1484,10 +1484,9 @@ __device__ __forceinline__ const KernelParams &kp_fresh() {
 }
 // ------------------------------------------------------------------ owner-side apply, streaming form: the consumer side
 // The first PushRings::consumers workgroups of a streaming launch drain this rank's circular regions as OWNER while the other workgroups -- and the other
-// ranks' kernels -- fill them (staleness = the examples in flight, not the step: hogwild.rs:89-103 -- nobody waits for a step to end).  Consumer waves
-// 0 .. n-1: the LR region of source s IN ORDER, 64 positions at a time, publishing a consumed-prefix credit in the source's memory.  The other consumer
-// waves: source s = w % n, positions start + j, start + j + J, ... of that source's row region; a slot is handed back (ffm_free, in the source's memory)
-// as soon as its gradient row is in registers.  A wave leaves a region when the region's final position for THIS step is known (fin: stored by the
+// ranks' kernels -- fill them (staleness = the examples in flight, not the step: hogwild.rs:89-103 -- nobody waits for a step to end).  An eighth of the
+// consumer waves take the LR regions (blocks of 64 positions, a lane per word), the others stripes of the row regions: source s = w % n, positions
+// start + j, start + j + J, ...; a slot is handed back (lr_free / ffm_free, in the source's memory) as soon as its word / gradient row is in registers.  A wave leaves a region when the region's final position for THIS step is known (fin: stored by the
 // source's last producer workgroup) and reached.
 template <int OPT>
 __device__ __forceinline__ void owner_stream_consume(const OwnerStream &os, uint32_t cw, uint32_t CW, uint32_t lane) {
@@ -1497,10 +1496,12 @@ __device__ __forceinline__ void owner_stream_consume(const OwnerStream &os, uint
         fin = (uint32_t)v;
         return (uint32_t)(v >> 32) == os.step;
     };
-    if (cw < N) {
-        const uint32_t s = cw, lg = os.log2cap_lr, mask = (1u << lg) - 1u;
-        uint32_t base = os.start_lr[s];
-        for (;;) {
+    // consumer waves [0, NL): the LR regions.  Wave w: source w % n, blocks of 64 positions b = w / n, b + BL, ... of that source's region (BL waves per
+    // source); a lane takes one word, steps its entry and hands the slot back.  NL = n x max(1, CW / (8 n)).
+    const uint32_t BL = CW / (8u * N) > 1u ? CW / (8u * N) : 1u, NL = N * BL;
+    if (cw < NL) {
+        const uint32_t s = cw % N, lg = os.log2cap_lr, mask = (1u << lg) - 1u, gmask = lg ? (0xffffffffu >> lg) : 0xffffffffu;
+        for (uint32_t base = os.start_lr[s] + (cw / N) * 64u;; base += BL * 64u) {
             const uint32_t pq = base + lane;
             unsigned long long word = 0;
             bool have = false, past = false;
@@ -1516,21 +1517,18 @@ __device__ __forceinline__ void owner_stream_consume(const OwnerStream &os, uint
                 __builtin_amdgcn_s_sleep(8);
             }
             if (have) {
+                __hip_atomic_store(os.lr_free[s] + (pq & mask), ((pq >> lg) + 1u) & gmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (the word is in a register)
                 const uint32_t h = (uint32_t)word & 0x3fffffffu;
                 const float grad = __uint_as_float((uint32_t)(word >> 32));
                 float2 wa = lr_load<true>(os.lr, h);
                 wa.x -= opt_step<OPT>(grad, wa.y, os.lr_rate, os.lr_mpt, os.lut_lr);  // block_lr.rs:145-147
                 lr_store<true>(os.lr, h, wa);
             }
-            const unsigned long long pm = __ballot(past);
-            const uint32_t done = pm ? (uint32_t)__builtin_ctzll(pm) : 64u;  // positions are consecutive: the first lane beyond the end
-            base += done;
-            if (lane == 0) __hip_atomic_store(os.lr_credit[s], base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (pm) break;
+            if (__ballot(past)) break;  // (positions are consecutive: every later block of this wave lies beyond the end as well)
         }
         return;
     }
-    const uint32_t W = CW - N, gw = cw - N;
+    const uint32_t W = CW - NL, gw = cw - NL;
     const uint32_t s = gw % N, j = gw / N, J = W / N;
     if (j >= J) return;
     const uint32_t lg = os.log2cap_ffm, mask = (1u << lg) - 1u, gmask = lg ? (0xffffffffu >> lg) : 0xffffffffu, R = os.R;
@@ -1979,12 +1977,13 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
                             const uint32_t pos = atomicAdd(&pr.cnt[pr.n + o], 1u);
                             const float grad = g * s.l_val[t];  // block_lr.rs:143
                             const unsigned long long word = (unsigned long long)(h | ((((pos >> lg) % 3u) + 1u) << 30)) | ((unsigned long long)__float_as_uint(grad) << 32);
-                            // flow control: the owner has consumed every position below credit[o]; `pos` may be written when pos - credit < cap.  The store sits
+                            // flow control: slot q may be written for generation g when the owner has said so (lr_free, in this rank's memory).  The store sits
                             // INSIDE the loop: a lane whose position is free must not wait (at the loop's end) for a lane of its wave whose position is not --
-                            // the consumer takes the region in order and would never get to that one.
+                            // the consumers take a region's blocks in order and might never get to that one.
+                            const uint32_t lslot = pos & (capl - 1u), lgen = (pos >> lg) & (lg ? (0xffffffffu >> lg) : 0xffffffffu);
                             for (bool sent = false; !sent;) {
-                                if ((int32_t)(pos - (__hip_atomic_load(pr.lr_credit + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + capl)) < 0) {
-                                    __hip_atomic_store(pr.lr_word[o] + (pos & (capl - 1u)), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                if ((__hip_atomic_load(pr.lr_free[o] + lslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) & (lg ? (0xffffffffu >> lg) : 0xffffffffu)) == lgen) {
+                                    __hip_atomic_store(pr.lr_word[o] + lslot, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                                     sent = true;
                                 } else {
                                     __builtin_amdgcn_s_sleep(8);
@@ -2735,7 +2734,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
             }                                                                                                 \
             if (zc[c] == f_) {                                                                                \
                 dc += ss_ * v_ * v_;                                                                          \
-                Vec<VEC>::lds_store(s.selfw + (IDX)*k + kkc[c], (ROW)[c]);                                     \
+                if (COH || !p.no_selfw) Vec<VEC>::lds_store(s.selfw + (IDX)*k + kkc[c], (ROW)[c]);             \
             }                                                                                                 \
         }                                                                                                     \
     }
@@ -2916,19 +2915,10 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                 while (i * (i + 1) / 2 > t) --i;
                 const uint32_t j = t - i * (i + 1) / 2;
                 float d = 0.0f;
-                if (i != j) {
-                    for (uint32_t kk = 0; kk < k; ++kk) d += s.T[i * R + j * k + kk] * s.T[j * R + i * k + kk];
-                } else {
-                    for (uint32_t e = s.fstart[i]; e < s.fend[i]; ++e) {
-                        const float v = s.e_val[e];
-                        float corr = 0.0f;
-                        for (uint32_t kk = 0; kk < k; ++kk) {
-                            const float w = s.selfw[e * k + kk];
-                            corr += w * (v * (s.T[i * R + i * k + kk] - w * v));
-                        }
-                        d += corr * 0.5f;
-                    }
-                }
+                for (uint32_t kk = 0; kk < k; ++kk) d += s.T[i * R + j * k + kk] * s.T[j * R + i * k + kk];
+                // the diagonal as split_mid_kernel forms it: exactly 0 for a field of at most one feature, 0.5 (|field sum|^2 - sum of the features' own squares) otherwise
+                // (the per-feature form of the training forward needs the entries' own slots in LDS, which a read-only launch does not keep)
+                if (i == j) d = (s.fend[i] - s.fstart[i]) <= 1u ? 0.0f : 0.5f * (d - s.dcf[i]);
                 x[C + t] = d;
             }
             if (tid == 0) {
@@ -3220,6 +3210,7 @@ void resolve_row_mode(KernelParams &p, uint32_t threads) {
     // The v2 kernel's single-chunk updating instantiations keep the LUT in LDS as a compile-time fact (kLdsLut): settled HERE, so that the host's
     // LDS size -- the occupancy choice and the 160 KiB check of prepare_launch -- is the size the launch really uses (debug option 1 does not apply to them).
     p.lut_lds_forced = (uses_resident_kernel(p, threads) && p.R <= 64 * 4 && p.update) ? 1 : 0;
+    p.no_selfw = (!p.update && uses_resident_kernel(p, threads)) ? 1 : 0;  // (only the update and the generic kernel's head read the entries' own slots)
     // rows kept in LDS beyond the register-kept ones: the chained-update instantiation of single-chunk rows only (fw_example_kernel_r, FW_LDS_KEEP_MAX)
     if (!(p.lut_lds_forced && p.window) || FW_KEEP_LAST) p.lds_keep = 0;
     if (p.lds_keep > FW_LDS_KEEP_MAX) p.lds_keep = FW_LDS_KEEP_MAX;

@@ -520,19 +520,24 @@ def test_owner_side_apply_streaming_form_delivers_every_gradient_exactly_once(n_
             r.close()
     # the LR side in closed form: entry h must end at -lr * sum over its occurrences of g * v, g = p - y from the form's OWN predictions (block_lr.rs:143-147)
     y = recs[off[:-1].astype(np.int64) + 1].astype(np.float64)
+    lr_entries = [np.asarray(fbt.translate(recs[int(off[e]):int(off[e + 1])]).lr_buffer) for e in range(2 * n_ex)]
+    hits = np.zeros(1 << bits, dtype=np.int64)
+    for lrb in lr_entries:
+        np.add.at(hits, lrb["hash"].astype(np.int64), 1)
+    shared = int(np.count_nonzero(hits > 1))  # entries two examples hold (hash collisions): steps on those may race inside the owner, in either form
     for form in ("stream", "sync"):
         p_ = np.concatenate(preds_of[form]).astype(np.float64)
         want = np.zeros(1 << bits, dtype=np.float64)
-        for e in range(2 * n_ex):
-            lrb = np.asarray(fbt.translate(recs[int(off[e]):int(off[e + 1])]).lr_buffer)
+        for e, lrb in enumerate(lr_entries):
             np.add.at(want, lrb["hash"].astype(np.int64), -0.01 * (p_[e] - y[e]) * lrb["value"].astype(np.float64))
         got = tabs[form][0]
         got = got[0::2] if got.size == 2 << bits else got
         bad = np.abs(got - want) > 2e-6 + 2e-4 * np.abs(want)
-        assert int(bad.sum()) <= 8, (form, "LR entries that are not the sum of their gradients", int(bad.sum()), float(np.abs(got - want).max()))
+        assert not np.any(bad & (hits <= 1)), (form, "an LR entry ONE example holds is not -lr * g * v", int((bad & (hits <= 1)).sum()), float(np.abs(got - want).max()))
+        assert int(bad.sum()) <= shared, (form, int(bad.sum()), shared)
     for name, a_, b_ in (("LR", tabs["stream"][0], tabs["sync"][0]), ("FFM", tabs["stream"][1], tabs["sync"][1])):
         bad = np.abs(a_ - b_) > 2e-6 + 1e-4 * np.abs(b_)
-        assert int(bad.sum()) <= max(8, int(0.002 * np.count_nonzero(b_ != 0))), (name, int(bad.sum()), float(np.abs(a_ - b_).max()))
+        assert int(bad.sum()) <= 2 * shared + max(8, int(0.01 * np.count_nonzero(b_ != 0))), (name, int(bad.sum()), float(np.abs(a_ - b_).max()))
     assert np.count_nonzero(tabs["sync"][0]) > 5 * n_ex            # the LR entries did move (6+ per example, collisions aside) ...
     assert np.count_nonzero(tabs["sync"][1] != w0) > 20 * n_ex      # ... and so did the rows
 
