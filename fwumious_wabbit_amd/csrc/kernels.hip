@@ -1498,7 +1498,14 @@ __device__ __forceinline__ void owner_stream_consume(const OwnerStream &os, uint
     };
     // consumer waves [0, NL): the LR regions.  Wave w: source w % n, blocks of 64 positions b = w / n, b + BL, ... of that source's region (BL waves per
     // source); a lane takes one word, steps its entry and hands the slot back.  NL = n x max(1, CW / (8 n)).
-    const uint32_t BL = CW / (8u * N) > 1u ? CW / (8u * N) : 1u, NL = N * BL;
+    // (at most 16 waves per source: 64 words a round each is ~300 M words/s, beyond what the producers send, and every waiting lane polls memory; and never more
+    // blocks under way than HALF a region holds: the words' 2-bit generation tags tell a generation from its two neighbours, not from the third)
+    uint32_t BL = CW / (8u * N);
+    BL = BL > 16u ? 16u : BL;
+    const uint32_t half_blocks = (1u << os.log2cap_lr) / 128u;
+    BL = BL > half_blocks ? half_blocks : BL;
+    BL = BL < 1u ? 1u : BL;
+    const uint32_t NL = N * BL;
     if (cw < NL) {
         const uint32_t s = cw % N, lg = os.log2cap_lr, mask = (1u << lg) - 1u, gmask = lg ? (0xffffffffu >> lg) : 0xffffffffu;
         for (uint32_t base = os.start_lr[s] + (cw / N) * 64u;; base += BL * 64u) {
@@ -1514,7 +1521,7 @@ __device__ __forceinline__ void owner_stream_consume(const OwnerStream &os, uint
                     past = true;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(64);  // (~1 us: a waiting lane's poll is a memory request)
             }
             if (have) {
                 __hip_atomic_store(os.lr_free[s] + (pq & mask), ((pq >> lg) + 1u) & gmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (the word is in a register)
@@ -1566,7 +1573,7 @@ __device__ __forceinline__ void owner_stream_consume(const OwnerStream &os, uint
                 }
             }
             if (all) break;
-            __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_s_sleep(32);
         }
         // (positions of a stripe are consumed in order: once one is beyond the end, the later ones are too)
         f4 gv[KR][2], wv2[KR][2], av[KR][2];
