@@ -1979,9 +1979,21 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
                     // ---------------- streaming form: circular regions drained by the owners WHILE this kernel runs (owner_stream_kernel)
                     if (p.has_lr) {
                         const uint32_t lg = pr.log2cap_lr, capl = 1u << lg;
-                        for (uint32_t t = tid; t < nl; t += bd) {
-                            const uint32_t h = s.l_hash[t], o = h >> p.shards->shift_lr;
-                            const uint32_t pos = atomicAdd(&pr.cnt[pr.n + o], 1u);
+                        for (uint32_t t0 = 0; t0 < nl; t0 += bd) {  // (uniform trip count: the position allocation below is a wave-wide step)
+                            const uint32_t t = t0 + (uint32_t)tid;
+                            const bool act_ = t < nl;
+                            const uint32_t h = act_ ? s.l_hash[t] : 0u, o = act_ ? h >> p.shards->shift_lr : 0xffffffffu;
+                            // positions: ONE atomic per wave and owner (the counters are single addresses: a per-word atomic serialises 13 M of them per step)
+                            uint32_t pos = 0;
+                            for (uint32_t oo = 0; oo < pr.n; ++oo) {
+                                const unsigned long long m_ = __ballot(o == oo);
+                                if (!m_) continue;
+                                uint32_t base_ = 0;
+                                if ((uint32_t)lane == (uint32_t)__builtin_ctzll(m_)) base_ = atomicAdd(&pr.cnt[pr.n + oo], (uint32_t)__popcll(m_));
+                                base_ = (uint32_t)__shfl((int)base_, (int)__builtin_ctzll(m_), 64);
+                                if (o == oo) pos = base_ + (uint32_t)__popcll(m_ & ((1ull << lane) - 1ull));
+                            }
+                            if (!act_) continue;
                             const float grad = g * s.l_val[t];  // block_lr.rs:143
                             const unsigned long long word = (unsigned long long)(h | ((((pos >> lg) % 3u) + 1u) << 30)) | ((unsigned long long)__float_as_uint(grad) << 32);
                             // flow control: slot q may be written for generation g when the owner has said so (lr_free, in this rank's memory).  The store sits
@@ -2001,18 +2013,30 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
                     if (k) {
                         constexpr int PU = 4;  // gradient rows a wave has under way at once
                         const uint32_t lg = pr.log2cap_ffm, capf = 1u << lg, gmask = lg ? (0xffffffffu >> lg) : 0xffffffffu;
-                        for (uint32_t i0 = (uint32_t)wave * PU; i0 < nf; i0 += (uint32_t)nw * PU) {
-                            uint32_t h_[PU], o_[PU], pos_[PU];
+                        // This wave's rows: i = wave, wave + nw, ...  Taken OWNER BY OWNER, so that the wave draws all its positions of an owner's region with one
+                        // atomic (the counters are single addresses: one atomic per row serialises 13 M of them per step), then PU rows at a time.
+                        for (uint32_t ow = 0; ow < pr.n; ++ow) {
+                        uint32_t mine = 0;
+                        for (uint32_t i = (uint32_t)wave; i < nf; i += (uint32_t)nw)
+                            mine += (__builtin_amdgcn_readfirstlane(s.e_hash[i]) >> p.shards->shift_ffm) == ow ? 1u : 0u;
+                        if (!mine) continue;
+                        uint32_t next_pos = 0;
+                        if (lane == 0) next_pos = atomicAdd(&pr.cnt[ow], mine);
+                        next_pos = __builtin_amdgcn_readfirstlane(next_pos);
+                        for (uint32_t iw = (uint32_t)wave, left = mine; left;) {
+                            uint32_t h_[PU], o_[PU], pos_[PU], row_[PU];
 #pragma unroll
                             for (int u = 0; u < PU; ++u) {
-                                const uint32_t i = i0 + u;
-                                h_[u] = o_[u] = pos_[u] = 0;
-                                if (i < nf) {
-                                    h_[u] = __builtin_amdgcn_readfirstlane(s.e_hash[i]);
-                                    o_[u] = h_[u] >> p.shards->shift_ffm;
-                                    uint32_t q = 0;
-                                    if (lane == 0) q = atomicAdd(&pr.cnt[o_[u]], 1u);
-                                    pos_[u] = __builtin_amdgcn_readfirstlane(q);
+                                h_[u] = pos_[u] = 0;
+                                o_[u] = ow;
+                                row_[u] = 0xffffffffu;
+                                if (left) {
+                                    while ((__builtin_amdgcn_readfirstlane(s.e_hash[iw]) >> p.shards->shift_ffm) != ow) iw += (uint32_t)nw;  // (`left` rows of this owner remain)
+                                    row_[u] = iw;
+                                    h_[u] = __builtin_amdgcn_readfirstlane(s.e_hash[iw]);
+                                    pos_[u] = next_pos++;
+                                    iw += (uint32_t)nw;
+                                    left--;
                                 }
                             }
                             auto announce = [&](uint32_t mask_) {  // tag words of the rows written so far: their floats are at the owners
@@ -2028,8 +2052,8 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
                             uint32_t written = 0;
 #pragma unroll
                             for (int u = 0; u < PU; ++u) {
-                                const uint32_t i = i0 + u;
-                                if (i >= nf) continue;
+                                const uint32_t i = row_[u];
+                                if (i == 0xffffffffu) continue;
                                 const uint32_t slot = pos_[u] & (capf - 1u), gen = (pos_[u] >> lg) & gmask;
                                 // the slot's previous generation has been consumed: the owner says so in this rank's own memory.  A wave never WAITS while it
                                 // holds written rows it has not announced (the consumers take a region's stripes in order: two waves waiting for each other's
@@ -2065,6 +2089,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
                             }
                             if (written) announce(written);
                         }
+                        }  // (owner by owner)
                     }
                 } else {
                 auto push_lr = [&](uint32_t t) {
