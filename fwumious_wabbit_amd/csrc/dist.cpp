@@ -1656,6 +1656,12 @@ int fwgpu_dist_group_learn_owner(fwgpu_dist_group *g, const fwgpu_translator_con
 // positions of the step into the owners' memory -- staleness = the examples in flight, like hogwild.rs:89-103, whatever the step's size; no collective,
 // no host round trip and no second stream inside a step.  What it needs is what hogwild needs: the ranks' kernels RUN AT THE SAME TIME (one process per
 // GPU: always; an in-process group sharing one device: one hardware queue per rank, i.e. up to four ranks).
+// The streaming form needs the kernels of ranks that share a device to RUN AT THE SAME TIME.  Streams of one process map onto a handful of hardware queues
+// (ROCclr: GPU_MAX_HW_QUEUES, default 4, handed out round robin), and two streams on one queue run their kernels one after the other -- with four
+// in-process ranks plus the default stream that is a rank waiting for a peer whose kernel sits behind its own.  The library asks for eight queues before
+// the runtime initialises (no effect when the variable is set already, or when HIP was initialised before the library was loaded).
+__attribute__((constructor)) static void fwgpu_ask_for_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 namespace {
 struct StreamGeom {
     uint32_t N, R, lg_ffm, lg_lr;
