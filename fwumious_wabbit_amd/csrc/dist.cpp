@@ -184,6 +184,7 @@ struct fwgpu_dist {
     size_t st_bytes = 0;
     uint32_t st_lg_ffm = 0, st_lg_lr = 0, st_n = 0;
     uint32_t st_pos_ffm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_pos_lr[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // as OWNER: positions of source s's rings consumed so far
+    bool st_probed = false;            // in-process group: the concurrency probe of the ranks sharing a device has passed
     uint32_t st_share = 1;             // ranks of the job on this rank's device (their kernels must be resident together: each takes an equal share of the device)
     uint32_t st_step = 0;              // streaming steps since the last reset (tags the final positions: a consumer only believes its own step's)
     unsigned char *st_peer[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // every rank's st_mem as reachable from here
@@ -1659,7 +1660,9 @@ int fwgpu_dist_group_learn_owner(fwgpu_dist_group *g, const fwgpu_translator_con
 // The streaming form needs the kernels of ranks that share a device to RUN AT THE SAME TIME.  Streams of one process map onto a handful of hardware queues
 // (ROCclr: GPU_MAX_HW_QUEUES, default 4, handed out round robin), and two streams on one queue run their kernels one after the other -- with four
 // in-process ranks plus the default stream that is a rank waiting for a peer whose kernel sits behind its own.  The library asks for eight queues before
-// the runtime initialises (no effect when the variable is set already, or when HIP was initialised before the library was loaded).
+// the runtime initialises (no effect when the variable is set already, or when HIP was initialised before the library was loaded -- and measured: none either
+// once torch has been imported into the process, whichever came first).  So the group form PROBES before its first streaming step (stream_concurrent below) and
+// refuses loudly instead of hanging; one process per rank has its own queues and needs none of this.
 __attribute__((constructor)) static void fwgpu_ask_for_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 namespace {
@@ -1716,6 +1719,21 @@ int stream_reset(fwgpu_dist *d) {
     FWGPU_HIP(hipStreamSynchronize(d->stream));
     for (int s = 0; s < 8; s++) d->st_pos_ffm[s] = d->st_pos_lr[s] = 0;
     d->st_step = 0;
+    return FWGPU_OK;
+}
+// do the kernels of these ranks (which share device `dev`) run at the same time?  (kernels.hip rendezvous_kernel)
+int stream_concurrent(const std::vector<fwgpu_dist *> &ranks, int dev, bool *ok) {
+    FWGPU_HIP(hipSetDevice(dev));
+    uint32_t *d = nullptr;
+    FWGPU_HIP(hipMalloc((void **)&d, 8));
+    FWGPU_HIP(hipMemset(d, 0, 8));
+    for (fwgpu_dist *r : ranks) FWGPU_HIP(hipStreamSynchronize(r->stream));
+    for (fwgpu_dist *r : ranks) FWGPU_HIP(launch_rendezvous(d, (uint32_t)ranks.size(), d + 1, r->stream));
+    for (fwgpu_dist *r : ranks) FWGPU_HIP(hipStreamSynchronize(r->stream));
+    uint32_t h[2] = {0, 0};
+    FWGPU_HIP(hipMemcpy(h, d, 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    *ok = h[1] == (uint32_t)ranks.size();
     return FWGPU_OK;
 }
 uint32_t stream_consumer_wgs(uint32_t N, uint32_t wish, uint32_t waves_per_wg) {
@@ -1830,6 +1848,22 @@ int fwgpu_dist_group_learn_owner_stream(fwgpu_dist_group *g, const fwgpu_transla
             g->ranks[j]->st_share = sh;
         }
         if (same > 4) return fail(FWGPU_ERR_INVALID, "owner-side apply, streaming form: more than four in-process ranks on one device (their kernels would queue behind one another); one process per rank there");
+        if (!g->ranks[0]->st_probed) {  // once per group: can the ranks that share a device run their kernels at the same time?
+            for (uint32_t j = 0; j < N; j++) {
+                std::vector<fwgpu_dist *> on_dev;
+                for (uint32_t i = 0; i < N; i++)
+                    if (g->ranks[i]->r->device == g->ranks[j]->r->device) on_dev.push_back(g->ranks[i].get());
+                if (on_dev.size() < 2 || on_dev[0] != g->ranks[j].get()) continue;  // (each device once)
+                bool ok = false;
+                int rcp = stream_concurrent(on_dev, g->ranks[j]->r->device, &ok);
+                if (rcp) return rcp;
+                if (!ok)
+                    return fail(FWGPU_ERR_DEVICE, "owner-side apply, streaming form: the kernels of the " + std::to_string(on_dev.size()) + " in-process ranks on device " +
+                                                      std::to_string(g->ranks[j]->r->device) + " do not run at the same time (their streams share hardware queues: GPU_MAX_HW_QUEUES, "
+                                                      "default 4 and fixed once the HIP runtime -- or torch -- is up); fewer ranks per device, or one process per rank");
+            }
+            for (uint32_t j = 0; j < N; j++) g->ranks[j]->st_probed = true;
+        }
     }
     int lg = 0;
     while ((1u << lg) < N) lg++;

@@ -539,6 +539,7 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
 int run_batch_peer(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, const PeerShards *d_shards, hipStream_t stream,
                    const PushRings *d_push = nullptr, uint32_t stream_consumers = 0, uint32_t device_share = 1, uint32_t stream_max_consumer_waves = 0);
 // owner-side apply: the optimizer steps of `n_rows` pushed gradient rows / `n_lr` pushed LR gradients on this regressor's own tables
+hipError_t launch_rendezvous(uint32_t *counter, uint32_t n, uint32_t *met, hipStream_t stream);
 hipError_t launch_owner_apply(const fwgpu_regressor *r, float *lr_base, const uint32_t *keys, const float *rows, uint32_t n_rows, const uint2 *lr_ent,
                               uint32_t n_lr, bool in_order, hipStream_t stream);
 struct SplitRanges {  // what a rank owns (sharded tables) and which examples of the launch are its own

@@ -2237,7 +2237,9 @@ static hipError_t launch_persistent(K kern, const KernelParams &p, uint32_t grid
         }
         if (p.host_wgs_cap && (uint32_t)per_cu > p.host_wgs_cap) per_cu = (int)p.host_wgs_cap;
         uint64_t g = (uint64_t)per_cu * (p.host_cus ? p.host_cus : 1);
-        if (p.host_share > 1) g = std::max<uint64_t>(2, g / p.host_share);  // kernels of several ranks resident together on this device
+        // kernels of several ranks resident together on this device: an equal share each, less a quarter (what the occupancy query promises for ONE kernel
+        // alone is not what four kernels with their own scratch and wave slots get: a rank whose consumers do not become resident stalls everybody)
+        if (p.host_share > 1) g = std::max<uint64_t>(2, g * 3 / (4 * p.host_share));
         grid = (uint32_t)(g < p.n_examples ? g : p.n_examples);
         if (p.host_grid_cap && grid > p.host_grid_cap) grid = p.host_grid_cap;
         if (p.host_extra_wgs) {  // streaming owner-side apply: the consumers come on top of the example workgroups, all of them resident together
@@ -3315,6 +3317,27 @@ __global__ void __launch_bounds__(256) owner_apply_kernel(float *w, float *acc, 
         wa.x -= opt_step<OPT>(grad, wa.y, lr_rate, lr_mpt, lut_lr);  // block_lr.rs:145-147
         lr_store<true>(lr, h, wa);
     }
+}
+
+// Can kernels launched on these streams RUN AT THE SAME TIME?  One single-wave kernel per stream: count yourself, then wait (bounded: tens of milliseconds) until all n have
+// counted.  Streams that share a hardware queue run their kernels one after the other: the first one's wait runs out.  (dist.cpp: the streaming
+// owner-side apply of an in-process group needs this of the ranks that share a device, and nothing the library can set guarantees it.)
+__global__ void rendezvous_kernel(uint32_t *counter, uint32_t n, uint32_t *met) {
+    if (threadIdx.x != 0) return;
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (;;) {
+        if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= n) {
+            __hip_atomic_fetch_add(met, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        if (__builtin_amdgcn_s_memtime() - t0 > 40000000ull) return;  // (20 ms at the shader clock, 0.4 s should s_memtime count at 100 MHz)
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+hipError_t launch_rendezvous(uint32_t *counter, uint32_t n, uint32_t *met, hipStream_t stream) {
+    hipLaunchKernelGGL(rendezvous_kernel, dim3(1), dim3(64), 0, stream, counter, n, met);
+    return hipGetLastError();
 }
 
 hipError_t launch_owner_apply(const fwgpu_regressor *r, float *lr_base, const uint32_t *keys, const float *rows, uint32_t n_rows, const uint2 *lr_ent,
