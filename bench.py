@@ -951,7 +951,8 @@ def main():
                 "examples_per_step_per_gpu": B,
                 "global_batch": B * world,
                 "mode": ("synchronous micro-batches (every example sees the batch-start weights; FWD / MID / head on MFMA / UPD kernels)" if sync_steps
-                         else "hogwild (device-wide concurrent examples, racy RMW; device-scope loads and accumulator stores, weight rows stored write-back through L2)"),
+                         else "hogwild (device-wide concurrent examples, racy RMW; device-scope loads and accumulator stores, weight rows stored write-back through L2; store policy "
+                              + (str(args.store_policy) if args.store_policy is not None else "3 (thinned accumulator stores on hot kept rows)") + ")"),
                 "parallelism": ("1 GPU" if not use_dist else
                                 f"dp{world} peer: tables sharded by owner, every rank's fused hogwild kernel reaches each row in its owner's memory (IPC-mapped tables over xGMI), "
                                 f"no collective per step, {world} x {B} examples per step" if peer_main else

@@ -52,7 +52,7 @@
 // the L2 or, for lines another XCD has written through, by the memory side).
 // In-order launches (one workgroup = one XCD) are exact under every policy; the launch's end writes everything back.
 #ifndef FW_DEFAULT_STORE_POLICY
-#define FW_DEFAULT_STORE_POLICY 1
+#define FW_DEFAULT_STORE_POLICY 3
 #endif
 #ifndef FW_DEFAULT_WB_FLUSH_EVERY
 #define FW_DEFAULT_WB_FLUSH_EVERY 128
@@ -3041,7 +3041,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                     // store policy 3: is this a hot row (wave-uniform: any lane's accumulator beyond theta), and is this example the one in m that stores it?
                     float g2_scale = 0.0f;
                     bool acc_store = ok0;
-                    if (kThin && gridDim.x > 1) {
+                    if (kThin && sl < MAXR && gridDim.x > 1) {  // (rows kept in registers only: a thinned store on a row parked in LDS -- stepped last, behind the longest window -- loses its race more often, tests/test_gpu_conservation.py)
                         const bool hot = __ballot(a_cur[0] > p.acc_hot_theta || a_cur[1] > p.acc_hot_theta || a_cur[2] > p.acc_hot_theta || a_cur[3] > p.acc_hot_theta) != 0ull;
                         if (hot) {
                             const uint32_t m = 1u << p.acc_sample_log2;
