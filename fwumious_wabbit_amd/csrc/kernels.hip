@@ -2327,7 +2327,7 @@ hipError_t launch_example_phase(const KernelParams &p_in, int optimizer, int pha
     if (p_in.n_examples == 0) return hipSuccess;
     KernelParams p = p_in;
     p.window = 0;  // (the generic kernel's update path)
-    p.prefetch = p.tr_lds = p.lut_lds_forced = 0;  // (v2-only LDS regions / choices)
+    p.prefetch = p.tr_lds = p.lut_lds_forced = p.no_selfw = 0;  // (v2-only LDS regions / choices: the phases are the generic kernel, whose gather keeps the entries' own slots)
     p.lds_keep = p.lds_keep_words = 0;
     p.update = phase == 3 ? 1 : 0;
     p.chain = p.update && !p.no_chain;
