@@ -2278,16 +2278,13 @@ template <int VEC>
 static hipError_t launch_v(const KernelParams &p, int optimizer, bool coherent, uint32_t grid, uint32_t threads,
                            size_t lds, hipStream_t stream) {
     if (!p.update) return launch_t<VEC, FWGPU_OPT_SGD, false>(p, grid, threads, lds, stream);
+    // An updating launch is a coherent one (device-scope accesses), in order or not: every caller passes coherent = update.  The <AdaGrad, non-coherent>
+    // instantiations this switch used to name were never launched -- and the deep head's spilled 650 .. 1600 vector registers (profiles/r04_kernel_resource_usage.txt).
+    if (!coherent) return hipErrorInvalidValue;
     switch (optimizer) {
-    case FWGPU_OPT_SGD:
-        return coherent ? launch_t<VEC, FWGPU_OPT_SGD, true>(p, grid, threads, lds, stream)
-                        : launch_t<VEC, FWGPU_OPT_SGD, false>(p, grid, threads, lds, stream);
-    case FWGPU_OPT_ADAGRAD_FLEX:
-        return coherent ? launch_t<VEC, FWGPU_OPT_ADAGRAD_FLEX, true>(p, grid, threads, lds, stream)
-                        : launch_t<VEC, FWGPU_OPT_ADAGRAD_FLEX, false>(p, grid, threads, lds, stream);
-    default:
-        return coherent ? launch_t<VEC, FWGPU_OPT_ADAGRAD_LUT, true>(p, grid, threads, lds, stream)
-                        : launch_t<VEC, FWGPU_OPT_ADAGRAD_LUT, false>(p, grid, threads, lds, stream);
+    case FWGPU_OPT_SGD: return launch_t<VEC, FWGPU_OPT_SGD, true>(p, grid, threads, lds, stream);
+    case FWGPU_OPT_ADAGRAD_FLEX: return launch_t<VEC, FWGPU_OPT_ADAGRAD_FLEX, true>(p, grid, threads, lds, stream);
+    default: return launch_t<VEC, FWGPU_OPT_ADAGRAD_LUT, true>(p, grid, threads, lds, stream);
     }
 }
 
@@ -3210,16 +3207,11 @@ static hipError_t launch_r(const KernelParams &p, uint32_t grid, uint32_t thread
 static hipError_t launch_resident(const KernelParams &p, int optimizer, bool coherent, uint32_t grid, uint32_t threads,
                                   size_t lds, hipStream_t stream) {
     if (!p.update) return launch_r<FWGPU_OPT_SGD, false>(p, grid, threads, lds, stream);
+    if (!coherent) return hipErrorInvalidValue;  // (an updating launch is a coherent one: see launch_v)
     switch (optimizer) {
-    case FWGPU_OPT_SGD:
-        return coherent ? launch_r<FWGPU_OPT_SGD, true>(p, grid, threads, lds, stream)
-                        : launch_r<FWGPU_OPT_SGD, false>(p, grid, threads, lds, stream);
-    case FWGPU_OPT_ADAGRAD_FLEX:
-        return coherent ? launch_r<FWGPU_OPT_ADAGRAD_FLEX, true>(p, grid, threads, lds, stream)
-                        : launch_r<FWGPU_OPT_ADAGRAD_FLEX, false>(p, grid, threads, lds, stream);
-    default:
-        return coherent ? launch_r<FWGPU_OPT_ADAGRAD_LUT, true>(p, grid, threads, lds, stream)
-                        : launch_r<FWGPU_OPT_ADAGRAD_LUT, false>(p, grid, threads, lds, stream);
+    case FWGPU_OPT_SGD: return launch_r<FWGPU_OPT_SGD, true>(p, grid, threads, lds, stream);
+    case FWGPU_OPT_ADAGRAD_FLEX: return launch_r<FWGPU_OPT_ADAGRAD_FLEX, true>(p, grid, threads, lds, stream);
+    default: return launch_r<FWGPU_OPT_ADAGRAD_LUT, true>(p, grid, threads, lds, stream);
     }
 }
 

@@ -565,14 +565,26 @@ int run_batch_peer(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, con
 }
 
 // a batch with an example beyond what the fused kernel stages keeps its entries on the host: it is walked example by example (run_batch)
+// does the batch's largest example fit what a workgroup of the fused kernel stages?  (fewer than 4096 entries of each kind can still be more than the
+// LDS holds: at k = 8 x 30 fields about 2.5 k features, at k = 16 far fewer -- ADVICE r4)
+static bool batch_fits_fused_kernel(fwgpu_batch *b) {
+    if (b->max_ffm > 4096 || b->max_lr > 4096) return false;
+    if (!b->owner) return true;
+    KernelParams p;
+    uint32_t threads = 0;
+    const std::string keep = fwgpu_last_error();
+    const int rc = prepare_launch(b->owner, b, FWGPU_MODE_HOGWILD, 1, p, threads);
+    if (rc == FWGPU_ERR_RANGE) set_error(keep);  // (not an error of the caller's: the batch takes the example-by-example path)
+    return rc != FWGPU_ERR_RANGE;
+}
 void keep_host_copy_if_oversize(fwgpu_batch *b, HostBatch &&hb) {
-    if (hb.max_ffm > 4096 || hb.max_lr > 4096) b->host_copy.reset(new HostBatch(std::move(hb)));
+    if (hb.max_ffm > 4096 || hb.max_lr > 4096 || !batch_fits_fused_kernel(b)) b->host_copy.reset(new HostBatch(std::move(hb)));
 }
 // ... a RECORD batch (just uploaded: max_ffm / max_lr are known) with a record that translates to more entries than that: translated on the host
 int record_batch_host_copy_if_oversize(fwgpu_regressor *r, const fwgpu_translator_config *t, fwgpu_batch *b, const uint32_t *records,
                                        const uint64_t *rec_off, uint32_t n) {
     b->host_copy.reset();
-    if (b->max_ffm <= 4096 && b->max_lr <= 4096) return FWGPU_OK;
+    if (batch_fits_fused_kernel(b)) return FWGPU_OK;
     HostBatch hb;
     hb.clear();
     std::vector<fwgpu_lr_entry> lr;

@@ -391,7 +391,7 @@ class Regressor:
 
     def set_store_policy(self, policy, flush_every=-1):
         """HOGWILD launches of the large-table update path (fwgpu_debug_set_option 5 / 6): how FFM row stores reach memory -- 0 both
-        tables device-scope write-through, 1 weight rows write-back through the XCD's L2 (the default), 2 both tables write-back,
+        tables device-scope write-through, 1 weight rows write-back through the XCD's L2, 2 both tables write-back, 3 (the default) = 1 with thinned accumulator stores on hot kept rows,
         -1 the build's default; with 1 / 2 a workgroup writes its XCD's dirty L2 lines back every `flush_every` of its examples (0 = only when the
         launch ends, -1 = the build's default).  kernels.hip "store policy", tests/test_gpu_conservation.py"""
         check(self.L.fwgpu_debug_set_option(self.h, 5, int(policy)))

@@ -1082,6 +1082,13 @@ def test_examples_beyond_4096_features_take_the_chunked_path(n_feat, opt):
     _chunked_path_parity(n_feat, opt)
 
 
+def test_batch_with_an_example_below_4096_entries_that_does_not_fit_the_lds():
+    """3 500 features at 30 fields x k = 8 are fewer than the 4096 entries a workgroup indexes but more than the LDS holds (own slots alone: 112 KB).  A batch
+    that holds such an example used to come back with FWGPU_ERR_RANGE from the launch; the batch's host copy is now decided by the kernel's own LDS check, and the example
+    takes the chunked path inside the batch like any oversize one."""
+    _chunked_path_parity(3500, fw.Optimizer.AdagradLUT, F=30, k=8, bits=16, ffm_bits=20)
+
+
 def test_chunked_path_where_the_phase_kernels_keep_t_in_the_split_record():
     """30 fields x k = 16: the staged T (57.6 KB) would leave one workgroup per CU, so the phase kernels write / read the field sums in the example's split
     record directly (kernels.hip launch_example_phase, KernelParams::t_global).  An oversize example's chunks hold different fields each: the update of
