@@ -985,8 +985,9 @@ def main():
                 "frac_of_peak_measured": (achieved / peak_measured) if peak_measured else None,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "pattern_ceiling_note": "profiles/r02_rowceil.txt (tools/rowceil.hip, raw output): random 960 B rows read 6.4 TB/s; written 3.2-3.5 TB/s as they lie (32 B aligned: "
-                                        "partial 128 B lines cost 4-5 whole lines), 6.8 TB/s as whole lines; read w+acc and write both back as whole lines: 5.0 TB/s of row bytes = 0.62 of the 8 TB/s peak",
+                "pattern_ceiling_note": "profiles/r02_rowceil.txt (tools/rowceil.hip): read w+acc rows and write both back as whole lines = 0.62 of the 8 TB/s peak; this kernel on UNIFORM ids "
+                                        "(every access a miss of every cache): 0.64 (profiles/r05_skew_sweep.txt) -- what is lost on the bench's Zipf stream is write-through serialisation on "
+                                        "hot accumulator lines (L2 tag stalls 6.4x, profiles/r05_skew_pmc_counters.txt), which store policy 3 thins",
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": avg_kernel_ms,
                 "launch_ms_min_median_max": [float(np.min(kernel_ms)), float(np.median(kernel_ms)), float(np.max(kernel_ms))],

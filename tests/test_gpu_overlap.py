@@ -15,9 +15,14 @@ from oracle import fwo
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("shape", ["config_c_kernel", "generic_kernel"])
+@pytest.mark.parametrize("shape", ["config_c_kernel", "generic_kernel", "deep_head_kernel"])
 def test_two_learners_on_two_streams_are_each_the_sequential_reference(shape):
-    if shape == "config_c_kernel":  # 30 fields, k = 8, the large-table update path forced onto small tables: fw_example_kernel_r<.., 20, true, 1, POL>
+    nn_layers = None
+    if shape == "deep_head_kernel":  # k = 16 rows (two chunks) + a 2 x 64 ReLU head: fw_example_kernel<4, AdagradLUT, true, 0, true, false>, the instantiation with the most lane-spilled scalars
+        geo = dict(n_ns=12, k=16, bits=16, ffm_bits=18, mean_extra=2.0, p_weighted=0.1, ids=5000, lr=0.025, power_t=0.38)
+        n = 600
+        nn_layers = [(64, "relu", "hu"), (64, "relu", "hu")]
+    elif shape == "config_c_kernel":  # 30 fields, k = 8, the large-table update path forced onto small tables: fw_example_kernel_r<.., 20, true, 1, POL>
         geo = dict(n_ns=30, k=8, bits=18, ffm_bits=20, mean_extra=5.67, p_weighted=0.1, ids=20000, lr=0.025, power_t=0.38)
         n = 700
     else:                            # k = 10: the generic kernel
@@ -29,7 +34,19 @@ def test_two_learners_on_two_streams_are_each_the_sequential_reference(shape):
         mi, ocfg, ots = make_pair(geo["n_ns"], geo["k"], geo["bits"], geo["ffm_bits"], fw.Optimizer.AdagradLUT, lr=geo["lr"], ffm_lr=geo["lr"],
                                   power_t=geo["power_t"], ffm_power_t=geo["power_t"])
         recs, off = fw.synth_records(geo["n_ns"], geo["mean_extra"], 1.1, geo["ids"], geo["p_weighted"], seed, 0, n)
+        nn = None
+        if nn_layers:
+            mi.nn_layers = [dict(width=w, activation=a, init=i) for w, a, i in nn_layers]
+            mi.nn_topology = "one"
+            mi.nn_learning_rate, mi.nn_power_t, mi.nn_init_acc_gradient = 0.025, 0.38, 1.0
+            nn = fwo.make_nn_config(nn_layers, "one", 0.025, 0.38, 1.0)
         re = fw.Regressor(mi)
+        if nn_layers:  # (Hu draws are implementation-defined: the oracle model below starts from the same ones)
+            om0 = fwo.Model(ocfg, nn=nn)
+            w0 = np.concatenate([om0.nn_weights(l).copy() for l in range(len(nn_layers) + 1)])
+            om0.close()
+            re.table_write(capi.TABLE_NN_W, w0)
+            ocfg = (ocfg, nn)
         if shape == "config_c_kernel":
             re.set_whole_line_updates(3)
         fbt = fw.FeatureBufferTranslator(mi)
@@ -49,7 +66,7 @@ def test_two_learners_on_two_streams_are_each_the_sequential_reference(shape):
     torch.cuda.synchronize()
     for mi, ocfg, ots, recs, off, re, batches in tenants:
         y = record_labels(recs, off)
-        om = fwo.Model(ocfg)
+        om = fwo.Model(ocfg[0], nn=ocfg[1]) if isinstance(ocfg, tuple) else fwo.Model(ocfg)
         _, p_ref = om.run_stream(ots, recs, off, holdout_after=0, nthreads=1)
         p_gpu = np.concatenate([b.predictions() for b in batches])
         assert np.abs(logloss(p_gpu, y) - logloss(p_ref, y)).max() < 1e-4
