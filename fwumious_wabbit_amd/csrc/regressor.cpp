@@ -396,7 +396,7 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
         static const char *env_pol = getenv("FWGPU_STORE_POLICY"), *env_wb = getenv("FWGPU_WB_FLUSH_EVERY"), *env_pf = getenv("FWGPU_PREFETCH");
         p.store_policy = r->launch.store_policy >= 0 ? r->launch.store_policy : (env_pol ? atoi(env_pol) : -1);
         static const char *env_th = getenv("FWGPU_ACC_HOT_THETA"), *env_sm = getenv("FWGPU_ACC_SAMPLE_LOG2");  // policy 3's two knobs (A/B runs)
-        p.acc_hot_theta = env_th ? (float)atof(env_th) : 2.0f;
+        p.acc_hot_theta = env_th ? (float)atof(env_th) : 0.5f;
         p.acc_sample_log2 = env_sm ? (uint32_t)atoi(env_sm) : 3u;
         p.wb_flush_every = r->launch.wb_flush_every >= 0 ? (uint32_t)r->launch.wb_flush_every : (env_wb ? (uint32_t)atoi(env_wb) : 0xffffffffu);
         p.prefetch = (r->launch.prefetch && !(env_pf && env_pf[0] == '0')) ? 1 : 0;
