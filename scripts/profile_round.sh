@@ -13,7 +13,7 @@ timeout 900 python3 bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_driver_sh
 timeout 900 python3 bench.py --long > $OUT/${TAG}_bench_long.json 2> $OUT/${TAG}_bench_long.err
 tail -c 400 $OUT/${TAG}_bench_long.json
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-traffic --no-config-e --no-config-b"
+CMD="python3 $R/bench.py --no-cpu-baseline --no-traffic --no-config-e --no-config-b"  # (the default shape: 4 + 48 steps -- the kernel gets faster over the first steps as rows turn hot, store policy 3)
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o trace -- $CMD > $OUT/${TAG}_trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --pmc FETCH_SIZE -d $OUT/${TAG}_fetch -o fetch -- $CMD > $OUT/${TAG}_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --pmc WRITE_SIZE -d $OUT/${TAG}_write -o write -- $CMD > $OUT/${TAG}_write.log 2>&1
