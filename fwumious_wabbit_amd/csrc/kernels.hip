@@ -1541,7 +1541,10 @@ __device__ __forceinline__ void owner_stream_consume(const OwnerStream &os, uint
     const uint32_t lg = os.log2cap_ffm, mask = (1u << lg) - 1u, gmask = lg ? (0xffffffffu >> lg) : 0xffffffffu, R = os.R;
     // KR positions of the stripe per round: their tag words are polled together (lane u loads tag u: one round trip), the rows of those that are there are
     // loaded together (one more), then stepped.  A round waits until each of its positions is either there or beyond the region's final position.
-    constexpr int KR = 2;
+#ifndef FW_STREAM_KR
+#define FW_STREAM_KR 2
+#endif
+    constexpr int KR = FW_STREAM_KR;
     for (uint32_t p0 = os.start_ffm[s] + j;; p0 += KR * J) {
         uint32_t hh[KR];
         bool on[KR];
@@ -2011,7 +2014,10 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
                         }
                     }
                     if (k) {
-                        constexpr int PU = 4;  // gradient rows a wave has under way at once
+#ifndef FW_STREAM_PU
+#define FW_STREAM_PU 4
+#endif
+                        constexpr int PU = FW_STREAM_PU;  // gradient rows a wave has under way at once
                         const uint32_t lg = pr.log2cap_ffm, capf = 1u << lg, gmask = lg ? (0xffffffffu >> lg) : 0xffffffffu;
                         // This wave's rows: i = wave, wave + nw, ...  Taken OWNER BY OWNER, so that the wave draws all its positions of an owner's region with one
                         // atomic (the counters are single addresses: one atomic per row serialises 13 M of them per step), then PU rows at a time.
