@@ -168,6 +168,7 @@ struct KernelParams {
     int32_t prefetch;                   // record batches on the v2 kernel: example n+1's record is copied to LDS while example n is in its dot / update phases
     uint32_t *work;                     // next example to process (zeroed before every launch)
     uint32_t host_cus, host_wgs_cap, host_grid_cap;    // host side only: persistent grid = occupancy x CUs (capped), when launched with grid 0
+    uint32_t grid_wgs;                                 // workgroups of THIS launch, filled in by launch_persistent: the example kernels read it here where they need it (gridDim.x, an implicit argument, is loaded once in the prologue and then lives in a scalar register across the whole example loop)
     uint32_t host_share;                               // host side only: ranks whose kernels must be RESIDENT TOGETHER on this device (streaming owner-side apply on a shared device): the persistent grid is an equal share of what the device holds (0 / 1: all of it)
     uint32_t host_stream_max_consumer_waves;           // host side only: bound on the consumer waves of a streaming launch (a stripe's stride must stay well below a region's capacity)
     uint32_t host_extra_wgs;                           // host side only: (0xffffffff: a share of the grid chosen at launch, written to PushRings::consumers before the kernel starts)

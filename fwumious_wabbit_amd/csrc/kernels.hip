@@ -280,7 +280,7 @@ __device__ __forceinline__ float *hot_lr_state(const Lds &s) { return reinterpre
 __device__ __forceinline__ bool hot_lr_is(const Lds &s, uint32_t h) { return s.ctr[13] != 0 && h == s.ctr[12]; }
 template <bool COH>
 __device__ __forceinline__ void hot_lr_init(const KernelParams &p, const Lds &s, bool fused) {  // thread 0, before the example loop
-    const bool on = fused && COH && p.hot_lr_every != 0 && p.has_lr && p.update && gridDim.x > 1;
+    const bool on = fused && COH && p.hot_lr_every != 0 && p.has_lr && p.update && p.grid_wgs > 1;
     s.ctr[13] = on ? p.hot_lr_every : 0;
     s.ctr[12] = p.hot_lr_hash;
     s.ctr[7] = 0;
@@ -418,7 +418,12 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, int lane) {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t t = (uint32_t)__shfl_up((int)v, d, 64);
-        if (lane >= d) v += t;
+        // (`lane >= d` as arithmetic -- all ones when d - 1 - lane is negative: as six compares the lane masks of a scan are twelve scalar registers,
+        // computed ahead of the scan, in the stage phase where the example kernels' scalar pressure peaks)
+        // (through an asm statement: written in C++ the compiler turns it back into the compare)
+        int m;
+        asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m) : "v"(d - 1 - lane));
+        v += t & (uint32_t)m;
     }
     return v;
 }
@@ -892,7 +897,7 @@ __device__ __forceinline__ float nn_forward(const KernelParams &p, const Lds &s,
         constexpr int JU = FW_NN_FJU;
         // hogwild launches: the same dot products from 16-byte device-scope loads (4-byte ones run at a third of the rate);
         // the order of the sum differs, which only the in-order mode promises
-        const bool vec16 = COH && gridDim.x > 1 && (in & 3u) == 0 && (n.off[l] & 3u) == 0 && ((uintptr_t)in_vec & 15u) == 0;
+        const bool vec16 = COH && p.grid_wgs > 1 && (in & 3u) == 0 && (n.off[l] & 3u) == 0 && ((uintptr_t)in_vec & 15u) == 0;
         for (uint32_t j0 = wave * JU; j0 < out; j0 += nw * JU) {
             float dot[JU], bias[JU];
 #pragma unroll
@@ -974,22 +979,30 @@ __device__ __forceinline__ void nn_layer_backward(const DevNN &n, uint32_t l, co
         constexpr int JU = FW_NN_BJU;  // weights (and accumulators) of JU neurons in flight per thread
         for (uint32_t j0 = 0; j0 < out; j0 += JU) {
             float w[JU], a[JU], gg[JU];
+            // (a neuron's output gradient is the same LDS word for every thread: "is it zero" is decided on its bits in a scalar register -- +-0 shifted left
+            // is 0, a NaN is not, as in the float compare -- and kept as one bit of one scalar register: JU neurons in flight are then scalar branches on ONE
+            // register, not JU 64-bit lane masks)
+            uint32_t live = 0;  // bit u: neuron j0 + u takes a step
 #pragma unroll
             for (int u = 0; u < JU; ++u) {
                 const uint32_t j = j0 + u;
                 gg[u] = j < out ? og[j] : 0.0f;
+                const uint32_t gbits = __builtin_amdgcn_readfirstlane(__float_as_uint(gg[u])) << 1;
                 w[u] = 0.0f;
                 a[u] = 0.0f;
-                if (gg[u] != 0.0f) {  // block_neural.rs:275-277
+                if (gbits != 0u) {  // block_neural.rs:275-277
+                    live |= 1u << u;
                     const size_t ix = (size_t)j * in + i;
                     w[u] = nn_ld<COH>(W + ix);
                     if (OPT != FWGPU_OPT_SGD) a[u] = nn_ld<COH>(A + ix);
                 }
             }
+            uint32_t j0s = j0;
+            asm volatile("" : "+s"(j0s), "+s"(live));  // (tested afresh -- the first loop's test results, kept for here, are lane masks again -- and the neuron indices formed afresh instead of living in JU scalars from the first loop on)
 #pragma unroll
             for (int u = 0; u < JU; ++u) {
-                if (gg[u] == 0.0f) continue;
-                const size_t ix = (size_t)(j0 + u) * in + i;
+                if (!((live >> u) & 1u)) continue;
+                const size_t ix = (size_t)(j0s + u) * in + i;
                 const float upd = opt_step<OPT>(gg[u] * xi, a[u], n.rate, n.minus_power_t, n.lut);
                 oe += w[u] * gg[u];
                 nn_st<COH>(W + ix, w[u] - upd);
@@ -1072,22 +1085,19 @@ __device__ __forceinline__ void nn_layer_backward_vec(const DevNN &n, uint32_t l
             f4 w[JU], a[JU];
             float gg[JU];
             uint32_t bo[JU];
+            // (a slot beyond the thread's share works on an offset outside the layer: the buffer loads return 0 there and the stores are dropped, its gradient
+            // is 0 -- every slot runs the same instructions, no lane mask per slot is kept from the loads to the stores)
 #pragma unroll
             for (int u = 0; u < JU; ++u) {
                 const bool on = a0 + u < jhi;
                 const uint32_t j = on ? act[a0 + u] : 0u;
                 gg[u] = on ? og[j] : 0.0f;
-                bo[u] = (j * in + 4 * q) * 4;
-                w[u] = Vec<4>::zero();
-                a[u] = Vec<4>::zero();
-                if (on) {
-                    w[u] = Vec<4>::load<kAuxSc1>(rw, bo[u]);
-                    if (OPT != FWGPU_OPT_SGD) a[u] = Vec<4>::load<kAuxSc1>(ra, bo[u]);
-                }
+                bo[u] = on ? (j * in + 4 * q) * 4 : 0xfffffff0u;
+                w[u] = Vec<4>::load<kAuxSc1>(rw, bo[u]);
+                a[u] = OPT != FWGPU_OPT_SGD ? Vec<4>::load<kAuxSc1>(ra, bo[u]) : Vec<4>::zero();
             }
 #pragma unroll
             for (int u = 0; u < JU; ++u) {
-                if (a0 + u >= jhi) continue;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float acc = a[u][c];
@@ -1131,9 +1141,9 @@ __device__ __forceinline__ void nn_layer_backward_vec(const DevNN &n, uint32_t l
 template <int OPT, bool COH>
 __device__ __forceinline__ void nn_layer_backward_any(const DevNN &n, uint32_t l, const float *og, const float *in_a,
                                                       uint32_t split, const float *in_b, float *grad_a, float *grad_b,
-                                                      uint32_t *act, int tid, int bd) {
+                                                      uint32_t *act, int tid, int bd, bool concurrent) {
     const uint32_t in = n.in[l];
-    if (COH && gridDim.x > 1 && in >= 4 && (in & 3u) == 0 && (n.off[l] & 3u) == 0 && (in >> 2) <= (uint32_t)bd && n.out[l] <= (uint32_t)bd && bd >= 64)
+    if (COH && concurrent && in >= 4 && (in & 3u) == 0 && (n.off[l] & 3u) == 0 && (in >> 2) <= (uint32_t)bd && n.out[l] <= (uint32_t)bd && bd >= 64)
         nn_layer_backward_vec<OPT>(n, l, og, in_a, split, in_b, grad_a, grad_b, act, tid, bd);
     else
         nn_layer_backward<OPT, COH>(n, l, og, in_a, split, in_b, grad_a, grad_b, tid, bd);
@@ -1150,7 +1160,7 @@ __device__ __forceinline__ void nn_backward(const KernelParams &p, const Lds &s,
     if (tid == 0) b.fg[0] = g;  // og of the single final neuron
     __syncthreads();
     // final neuron: inputs [h_last | x], input gradients -> [h_last (in place) | xg]
-    nn_layer_backward_any<OPT, COH>(n, L, b.fg, b.h + hoff_last, wl, b.x, b.h + hoff_last, b.xg, b.act, tid, bd);
+    nn_layer_backward_any<OPT, COH>(n, L, b.fg, b.h + hoff_last, wl, b.x, b.h + hoff_last, b.xg, b.act, tid, bd, p.grid_wgs > 1);
     if (n.topology != 1)
         for (uint32_t i = tid; i < X; i += bd) b.xg[i] = 0.0f;
     __syncthreads();
@@ -1163,11 +1173,11 @@ __device__ __forceinline__ void nn_backward(const KernelParams &p, const Lds &s,
         if (l > 0) {
             const uint32_t pin = n.out[l - 1];
             nn_layer_backward_any<OPT, COH>(n, l, b.m + hoff, b.h + hoff - pin, pin, b.h + hoff - pin, b.h + hoff - pin,
-                                            b.h + hoff - pin, b.act, tid, bd);
+                                            b.h + hoff - pin, b.act, tid, bd, p.grid_wgs > 1);
             hoff -= pin;
         } else {
             // first layer: inputs x; its input gradient is ADDED to the copy branch (BlockCopy, block_misc.rs:456-475)
-            nn_layer_backward_any<OPT, COH>(n, 0, b.m + hoff, b.x, X, b.x, b.fg, b.fg, b.act, tid, bd);
+            nn_layer_backward_any<OPT, COH>(n, 0, b.m + hoff, b.x, X, b.x, b.fg, b.fg, b.act, tid, bd, p.grid_wgs > 1);
             __syncthreads();
             for (uint32_t i = tid; i < X; i += bd) b.xg[i] = b.fg[i] + b.xg[i];
         }
@@ -1678,15 +1688,16 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
     bind_lds(p, smem, use_lut, s, geom, trl_unused);
 
     const int tid = threadIdx.x, bd = blockDim.x;
-    const int lane = tid & 63, wave = tid >> 6, nw = bd >> 6;
-    const uint32_t F = p.F, k = p.k, R = p.R;
-    const uint32_t nchunk = R ? (R + 64 * VEC - 1) / (64 * VEC) : 0;
+    const int lane = tid & 63, wave = tid >> 6, nw = bd >> 6;  // (the prologue's; every phase of the example loop derives its own)
+    (void)lane;
 
-    const float *lut_lr = p.lut_lr;  // 201 lookups per example: read through L1 (an LDS copy measured no faster)
     if (use_lut)
         for (int i = tid; i < kLutSize; i += bd) s.lut[i] = p.lut_ffm[i];
 
-    // debug phase timing (thread 0 of every workgroup; all stamps sit right after a barrier or at a phase end)
+    // debug phase timing (thread 0 of every workgroup; all stamps sit right after a barrier or at a phase end): -DFW_TICKS builds only, like the v2
+    // kernel's (scripts/perf_probe.py builds its own library) -- the eight sums and the stamp are 18 vector registers and a lane mask alive across the
+    // whole example loop, in a kernel that runs at its 128-register limit with the deep head
+#ifdef FW_TICKS
     unsigned long long tk_last = 0, tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool timing = p.ticks != nullptr && tid == 0;
 #define FW_TICK(slot)                                           \
@@ -1696,6 +1707,9 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
         tk_last = now_;                                         \
     }
     if (timing) tk_last = __builtin_amdgcn_s_memtime();
+#else
+#define FW_TICK(slot)
+#endif
 
     // Examples are handed out by a device counter, not by a static stride: a workgroup that becomes resident late (another
     // kernel -- RCCL during a replica exchange -- holds its slot, or the grid was over-subscribed) finds the work already
@@ -1716,31 +1730,52 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
         for (uint32_t i = tid; i < 256; i += bd) reinterpret_cast<uint32_t *>(smem + p.dbg_canary_off)[i] = 0xC0FFEE00u + i;
 #endif
     for (;;) {
-        const KernelParams &p = kp_fresh();  // (shadows the prologue's: this example's loads start here)
         // Previous example's LDS reads are done.  A workgroup-scope barrier does not drain vmcnt on this target,
         // so in the in-order (single workgroup) mode every wave first waits for its own table stores to be
         // acknowledged: the next example must read what this one wrote.  Concurrent (hogwild) grids skip the
         // wait and let the stores drain under the next example's gather.
-        // (the thread index is made opaque once per example, so that the lane masks derived from it are recomputed where they are used instead of
-        // living in scalar-register pairs across the whole example loop: see fw_example_kernel_r)
+        // The stage phase and the rest of the example each take their own view of the argument block and of the LDS carve-up (see fw_example_kernel_r):
+        // what only the stage phase needs dies at its end instead of living in scalar registers through the gather and the update.
+        StageOut so;
+        uint32_t ex;
+        {
+            const KernelParams &p = kp_fresh();  // (shadows the prologue's: this example's loads start here)
+            // (the thread index is made opaque once per example, so that the lane masks derived from it are recomputed where they are used instead of
+            // living in scalar-register pairs across the whole example loop: see fw_example_kernel_r)
+            int tid_now = threadIdx.x, bd_now = blockDim.x;
+            uint32_t grid_now = p.grid_wgs;
+            asm volatile("; thread index, workgroup and grid size handed out" : "+v"(tid_now), "+s"(bd_now), "+s"(grid_now));
+            const int tid = tid_now, bd = bd_now;
+            Lds s;
+            SetGeom geom;
+            TrLds trl_unused;
+            bind_lds(p, smem, (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global, s, geom, trl_unused);
+            if (grid_now == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            ex = s.ctr[6];
+            if (ex >= p.n_examples) break;
+            FW_TICK(6);
+#ifdef FW_TICKS
+            if (timing) tk[7] += 1;
+#endif
+            // Phase kernels: T lives in the example's split record (FWD writes the field sums there as they are finished, UPD reads them from there):
+            // without the F * R floats of LDS two to four workgroups share a CU instead of one, i.e. as many examples of a micro-batch run concurrently
+            if (PH != 0 && p.t_global) s.T = p.split + (size_t)ex * p.split_len;
+            so = stage_example<kCtx>(p, s, geom, ex, tid, bd, TrGlobal{p.tr});
+        }
+        const KernelParams &p = kp_fresh();
         int tid_now = threadIdx.x, bd_now = blockDim.x;
-        uint32_t grid_now = gridDim.x;
-        asm volatile("; thread index, workgroup and grid size handed out" : "+v"(tid_now), "+s"(bd_now), "+s"(grid_now));
+        asm volatile("; thread index and workgroup size handed out" : "+v"(tid_now), "+s"(bd_now));
         const int tid = tid_now, lane = tid & 63, wave = tid >> 6, bd = bd_now, nw = bd >> 6;
         Lds s;
-        SetGeom geom;
-        TrLds trl_unused;
-        bind_lds(p, smem, use_lut, s, geom, trl_unused);
-        if (grid_now == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const uint32_t ex = s.ctr[6];
-        if (ex >= p.n_examples) break;
-        FW_TICK(6);
-        if (timing) tk[7] += 1;
-        // Phase kernels: T lives in the example's split record (FWD writes the field sums there as they are finished, UPD reads them from there):
-        // without the F * R floats of LDS two to four workgroups share a CU instead of one, i.e. as many examples of a micro-batch run concurrently
+        {
+            SetGeom geom_unused;
+            TrLds trl_unused;
+            bind_lds(p, smem, (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global, s, geom_unused, trl_unused);
+        }
         if (PH != 0 && p.t_global) s.T = p.split + (size_t)ex * p.split_len;
-        const StageOut so = stage_example<kCtx>(p, s, geom, ex, tid, bd, TrGlobal{p.tr});
+        const uint32_t F = p.F, k = p.k, R = p.R;  // (shadow the prologue's, like everything else the example works with)
+        const uint32_t nchunk = R ? (R + 64 * VEC - 1) / (64 * VEC) : 0;
         uint32_t next_ticket = 0;  // (every thread is past its read of ctr[6]: the stage phase has barriers)
         if (tid == 0) next_ticket = atomicAdd(p.work, 1u);
         const uint32_t nf = so.nf, nl = so.nl;
@@ -1772,22 +1807,28 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
                     for (uint32_t i = fs; i < fe; i += UG) {
                         V r[UG];
                         float v[UG];
-                        bool on[UG];
+                        // (which of the UG rows exist: bits of ONE scalar register, tested afresh in the second loop -- as UG booleans every test result
+                        // of the first loop was kept for the second as a 64-bit lane mask)
+                        uint32_t onm = 0;
 #pragma unroll
                         for (int u = 0; u < UG; ++u) {
                             r[u] = Vec<VEC>::zero();
                             v[u] = 0.0f;
-                            on[u] = i + u < fe;
-                            if (on[u]) {
+                            if (i + u < fe) {
                                 const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[i + u]);
-                                if (PH == 1) on[u] = h >= p.own_lo_ffm && h < p.own_hi_ffm;  // sharded tables: owned rows only
+                                bool on = true;
+                                if (PH == 1) on = h >= p.own_lo_ffm && h < p.own_hi_ffm;  // sharded tables: owned rows only
                                 v[u] = s.e_val[i + u];
-                                if (on[u]) r[u] = Vec<VEC>::template load<AUX>(make_rsrc(ffm_w_base<SH>(p, h) + h, R * 4), e0 * 4);
+                                if (on) {
+                                    onm |= 1u << u;
+                                    r[u] = Vec<VEC>::template load<AUX>(make_rsrc(ffm_w_base<SH>(p, h) + h, R * 4), e0 * 4);
+                                }
                             }
                         }
+                        asm volatile("" : "+s"(onm));
 #pragma unroll
                         for (int u = 0; u < UG; ++u) {
-                            if (on[u]) {
+                            if ((onm >> u) & 1u) {
                                 float ss = 0.0f;
 #pragma unroll
                                 for (int j = 0; j < VEC; ++j) {
@@ -1953,20 +1994,53 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
         // ---------------- update.  g == 0 leaves every weight and accumulator unchanged in all three
         // optimizers (acc += 0, w -= 0), so the whole phase is skipped.
         const bool head_split = NN && PH == 3 && p.dxbuf != nullptr;  // mini-batched deep head: per-slot gradients come from the head kernels
-        if (do_update && (g != 0.0f || head_split)) {
+        // ("does this example update" is formed again from the argument block and the importance, regressor.rs:366: as the stage phase's own boolean it is
+        // a lane mask alive from the stage phase through the gather and the head's forward pass)
+        const bool do_update_now = kp_fresh().update && imp != 0.0f;
+        (void)do_update;
+        if (do_update_now && (g != 0.0f || head_split)) {
+            // The head's unwinding and the table update each take a view of their own, like the stage phase: the LDS offsets and table addresses they need are
+            // formed where they start, not carried in scalar registers from the top of the example through the gather and the head's forward pass.
             // deep head: unwind it first; afterwards every LR slot and every FFM pair has its own general gradient
+            if (NN && (head_split || p.nn.n_layers)) {
+                const KernelParams &p = kp_fresh();
+                int tid_h = threadIdx.x, bd_h = blockDim.x;
+                asm volatile("; thread index and workgroup size handed out" : "+v"(tid_h), "+s"(bd_h));
+                const int tid = tid_h, bd = bd_h;
+                Lds s;
+                {
+                    SetGeom geom_unused;
+                    TrLds trl_unused;
+                    bind_lds(p, smem, (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global, s, geom_unused, trl_unused);
+                }
+                if (head_split) {
+                    // the example's slot gradients (X floats, written by the head kernels) come into LDS once: every row chunk of the update looks its pair's
+                    // gradient up there instead of in global memory
+                    float *xl = nn_buf(p, s).xg;
+                    const float *src = p.dxbuf + (size_t)ex * p.nn.X;
+                    for (uint32_t i = tid; i < p.nn.X; i += bd) xl[i] = src[i];
+                    __syncthreads();
+                } else {
+                    nn_backward<OPT, COH>(p, s, g, tid, bd);
+                }
+            }
+            const KernelParams &p = kp_fresh();
+            int tid_u = threadIdx.x, bd_u = blockDim.x;
+            asm volatile("; thread index and workgroup size handed out" : "+v"(tid_u), "+s"(bd_u));
+            const int tid = tid_u, lane = tid & 63, wave = tid >> 6, bd = bd_u, nw = bd >> 6;
+            Lds s;
+            {
+                SetGeom geom_unused;
+                TrLds trl_unused;
+                bind_lds(p, smem, (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global, s, geom_unused, trl_unused);
+            }
+            if (PH != 0 && p.t_global) s.T = p.split + (size_t)ex * p.split_len;
+            const uint32_t F = p.F, k = p.k, R = p.R;
+            const uint32_t nchunk = R ? (R + 64 * VEC - 1) / (64 * VEC) : 0;
+            const float *lut_lr = p.lut_lr;
+            (void)F; (void)k; (void)nchunk; (void)lane; (void)wave; (void)nw; (void)lut_lr;
             const float *gx = nullptr, *gpair = nullptr;
-            if (head_split) {
-                // the example's slot gradients (X floats, written by the head kernels) come into LDS once: every row chunk of the update looks its pair's
-                // gradient up there instead of in global memory
-                float *xl = nn_buf(p, s).xg;
-                const float *src = p.dxbuf + (size_t)ex * p.nn.X;
-                for (uint32_t i = tid; i < p.nn.X; i += bd) xl[i] = src[i];
-                __syncthreads();
-                gx = xl;
-                gpair = gx + p.num_combos;
-            } else if (NN && p.nn.n_layers) {
-                nn_backward<OPT, COH>(p, s, g, tid, bd);
+            if (NN && (head_split || p.nn.n_layers)) {
                 gx = nn_buf(p, s).xg;
                 gpair = gx + p.num_combos;
             }
@@ -1977,7 +2051,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
                 // applies what it receives one after the other.  In-order launches push in buffer order from one wave / one thread, so that the
                 // owner's sequence of steps is the reference's (block_ffm.rs:269-286, block_lr.rs:140-150).
                 const PushRings &pr = *p.push;
-                const bool in_order = gridDim.x == 1;
+                const bool in_order = p.grid_wgs == 1;
                 if (pr.stream) {
                     // ---------------- streaming form: circular regions drained by the owners WHILE this kernel runs (owner_stream_kernel)
                     if (p.has_lr) {
@@ -2183,17 +2257,42 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
             }  // (not the owner-side-apply push)
             FW_TICK(5);
         }
-        if (tid == 0) s.ctr[6] = next_ticket;  // published by the loop-top barrier
+        // (the tail's lane test starts from a fresh thread index: `tid == 0` from the top of the example would be one more mask alive across the whole body)
+        int tid_tail = threadIdx.x;
+        asm volatile("; thread index handed out" : "+v"(tid_tail));
+        if (tid_tail == 0) {  // published by the loop-top barrier
+            // (through a view of its own: the counters' offset is formed here from the argument block, instead of its dozen inputs living in scalar
+            // registers from the post-stage view down to this line)
+            const KernelParams &pt = kp_fresh();
+            Lds st;
+            SetGeom geom_unused;
+            TrLds trl_unused;
+            bind_lds(pt, smem, (OPT == FWGPU_OPT_ADAGRAD_LUT) && pt.update && !pt.lut_global, st, geom_unused, trl_unused);
+            st.ctr[6] = next_ticket;
+        }
     }
-    if (COH && tid == 0 && s.ctr[13]) hot_lr_flush<SH>(p, s);  // (every thread's steps are in: the loop ends on a barrier)
-    if (SH && PH == 0 && p.push && p.push->stream) {
+    // (the epilogue takes a view of its own as well: through the prologue's, the argument block's address, the counters' LDS offset and the
+    // `tid == 0` mask stayed in scalar registers across the whole example loop)
+    const KernelParams &pe = kp_fresh();
+    int tid_e = threadIdx.x, bd_e = blockDim.x;
+    asm volatile("; thread index and workgroup size handed out" : "+v"(tid_e), "+s"(bd_e));
+    if (COH && tid_e == 0) {
+        Lds se;
+        SetGeom geom_unused;
+        TrLds trl_unused;
+        bind_lds(pe, smem, (OPT == FWGPU_OPT_ADAGRAD_LUT) && pe.update && !pe.lut_global, se, geom_unused, trl_unused);
+        if (se.ctr[13]) hot_lr_flush<SH>(pe, se);  // (every thread's steps are in: the loop ends on a barrier)
+    }
+    if (SH && PH == 0 && pe.push && pe.push->stream) {
+        const KernelParams &p = pe;
+        const int tid = tid_e;
         // streaming owner-side apply: this producer workgroup is through.  Its pushes have been acknowledged (rows: before their tag words; LR words: waited
         // for here); the LAST producer workgroup of the launch tells every owner where this source's regions end for this step.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
             const PushRings &pr = *p.push;
-            const uint32_t producers = gridDim.x - pr.consumers;
+            const uint32_t producers = p.grid_wgs - pr.consumers;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             if (atomicAdd(pr.done, 1u) + 1u == producers) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -2207,12 +2306,14 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
         }
     }
 #ifndef FW_KP_NO_CANARY
-    if (p.dbg_canary)
-        for (uint32_t i = tid; i < 256; i += bd)
-            if (reinterpret_cast<uint32_t *>(smem + p.dbg_canary_off)[i] != 0xC0FFEE00u + i) atomicAdd(p.dbg_canary, 1u);
+    if (pe.dbg_canary)
+        for (uint32_t i = tid_e; i < 256; i += bd_e)
+            if (reinterpret_cast<uint32_t *>(smem + pe.dbg_canary_off)[i] != 0xC0FFEE00u + i) atomicAdd(pe.dbg_canary, 1u);
 #endif
+#ifdef FW_TICKS
     if (timing)
         for (int i = 0; i < 8; ++i) atomicAdd(p.ticks + i, tk[i]);
+#endif
 #undef FW_TICK
 }
 
@@ -2268,7 +2369,9 @@ static hipError_t launch_persistent(K kern, const KernelParams &p, uint32_t grid
             grid = std::max<uint32_t>(1u, std::min(grid, room)) + extra;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, p);
+    KernelParams q = p;
+    q.grid_wgs = grid;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, q);
     return hipGetLastError();
 }
 
@@ -2580,10 +2683,8 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
     TrLds trl;
     bind_lds(p, smem, use_lut, s, geom, trl);
 
-    const int tid = threadIdx.x, bd = blockDim.x;
-    const int lane = tid & 63, wave = tid >> 6, nw = bd >> 6;
+    const int tid = threadIdx.x, bd = blockDim.x;  // (the prologue's; every phase of the example loop derives its own)
     constexpr int kPfMax = 2;  // words of the next record a thread carries through the dot phase (records of up to kPfMax * blockDim words are prefetched)
-    const uint32_t F = p.F, k = p.k, R = p.R;
 
     if (use_lut)
         for (int i = tid; i < kLutSize; i += bd) s.lut[i] = p.lut_ffm[i];
@@ -2620,27 +2721,56 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         hot_lr_init<COH>(p, s, true);
         s.ctr[kCtrPfLen] = 0;
         // write-back policies: this workgroup's turn to write its XCD's L2 back comes every wb_flush_every examples, staggered by workgroup
-        const uint32_t every = (COH && POL >= 1 && gridDim.x > 1) ? p.wb_flush_every : 0u;
+        const uint32_t every = (COH && POL >= 1 && p.grid_wgs > 1) ? p.wb_flush_every : 0u;
         s.ctr[kCtrWbEvery] = every;
         s.ctr[kCtrWbCount] = every ? blockIdx.x % every : 0u;
     }
     for (;;) {
-        const KernelParams &p = kp_fresh();  // (shadows the prologue's: this example's loads start here)
-        // The thread index is made opaque once per example, and everything that depends on it -- the lane's place in a row, and above all the
-        // dozen lane MASKS (tid == 0, tid < n, lane < 2 / 4 / ... of the wave scans) -- is derived inside the loop: left loop-invariant, every
-        // such mask is a pair of scalar registers that lives across the whole example loop, i.e. is spilled to a VGPR lane in the prologue
-        // and read back where it is used (~30 of the kernel's ~100 spilled scalars).
+        // The example's stage phase and the rest of it (gather / dot / update) each take their OWN view of the argument block and of the LDS carve-up:
+        // the two dozen LDS offsets, the translator's geometry and the launch flags the stage phase works with die at its end instead of living in scalar
+        // registers beside the ones the gather and the update need (the kernel's peak of live scalars is inside the stage phase).
+        StageOut so;
+        uint32_t ex;
+        {
+            const KernelParams &p = kp_fresh();  // (shadows the prologue's: this example's loads start here)
+            // The thread index is made opaque once per example, and everything that depends on it -- the lane's place in a row, and above all the
+            // dozen lane MASKS (tid == 0, tid < n, lane < 2 / 4 / ... of the wave scans) -- is derived inside the loop: left loop-invariant, every
+            // such mask is a pair of scalar registers that lives across the whole example loop, i.e. is spilled to a VGPR lane in the prologue
+            // and read back where it is used (~30 of the kernel's ~100 spilled scalars).
+            int tid_now = threadIdx.x, bd_now = blockDim.x;
+            uint32_t grid_now = p.grid_wgs;
+            asm volatile("; thread index, workgroup and grid size handed out" : "+v"(tid_now), "+s"(bd_now), "+s"(grid_now));
+            const int tid = tid_now, bd = bd_now;
+            // ... and so is the LDS carve-up: two dozen offsets that would otherwise live in scalar registers from the prologue on
+            Lds s;
+            SetGeom geom;
+            TrLds trl;
+            bind_lds(p, smem, use_lut, s, geom, trl);
+            if (grid_now == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in-order mode: see fw_example_kernel
+            __syncthreads();
+            ex = s.ctr[6];
+            if (ex >= p.n_examples) break;
+            FW_TICK(6);
+#ifdef FW_TICKS
+            if (timing) atomicAdd(p.ticks + 7, 1ull);
+            so = stage_example<!COH>(p, s, geom, ex, tid, bd, trl, timing ? p.ticks : nullptr, s.ctr[kCtrPfLen]);
+#else
+            so = stage_example<!COH>(p, s, geom, ex, tid, bd, trl, nullptr, s.ctr[kCtrPfLen]);
+#endif
+        }
+        const KernelParams &p = kp_fresh();
         int tid_now = threadIdx.x, bd_now = blockDim.x;
-        uint32_t grid_now = gridDim.x;
+        uint32_t grid_now = p.grid_wgs;
         asm volatile("; thread index, workgroup and grid size handed out" : "+v"(tid_now), "+s"(bd_now), "+s"(grid_now));
         const int tid = tid_now, lane = tid & 63, wave = tid >> 6, bd = bd_now, nw = bd >> 6;
         const uint32_t F = p.F, k = p.k, R = p.R;
         const float *lut_lr = p.lut_lr;  // 201 lookups per example: read through L1 (an LDS copy measured no faster)
-        // ... and so is the LDS carve-up: two dozen offsets that would otherwise live in scalar registers from the prologue on
         Lds s;
-        SetGeom geom;
-        TrLds trl;
-        bind_lds(p, smem, use_lut, s, geom, trl);
+        {
+            SetGeom geom_unused;
+            TrLds trl_unused;
+            bind_lds(p, smem, use_lut, s, geom_unused, trl_unused);
+        }
         // this lane's 4 floats of a row's chunk c: elements [e0, e0+4) = slot z, offset kk0
         uint32_t e0c[NC], zc[NC], kkc[NC];
         bool inbc[NC];
@@ -2653,17 +2783,6 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         }
         const uint32_t e0 = e0c[0], z = zc[0];  // (chunk 0: what the resident-row code, NC == 1 only, works on)
         const bool inb = inbc[0];
-        if (grid_now == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in-order mode: see fw_example_kernel
-        __syncthreads();
-        const uint32_t ex = s.ctr[6];
-        if (ex >= p.n_examples) break;
-        FW_TICK(6);
-#ifdef FW_TICKS
-        if (timing) atomicAdd(p.ticks + 7, 1ull);
-        const StageOut so = stage_example<!COH>(p, s, geom, ex, tid, bd, trl, timing ? p.ticks : nullptr, s.ctr[kCtrPfLen]);
-#else
-        const StageOut so = stage_example<!COH>(p, s, geom, ex, tid, bd, trl, nullptr, s.ctr[kCtrPfLen]);
-#endif
         uint32_t next_ticket = 0;
         if (tid == 0) next_ticket = atomicAdd(p.work, 1u);
         const uint32_t nf = so.nf, nl = so.nl;
@@ -2713,11 +2832,11 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         if (!kKeepLast) {
 #pragma unroll
             for (int sl = 0; sl < MAXR; ++sl) {
-                rows[sl] = Vec<VEC>::zero();
-                if ((uint32_t)sl < nk) {
-                    const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[kb + sl]);
-                    rows[sl] = Vec<VEC>::template load<AUX_G>(make_rsrc(p.ffm_w + h, R * 4), e0 * 4);
-                }
+                // (a slot beyond the range loads through a zero-length descriptor: zeros, no memory access -- as a branch around the load every
+                // slot's `sl < nk` became a lane mask that lived from here to the end of the burst, 40 scalar registers for 20 rows)
+                const bool on = (uint32_t)sl < nk;
+                const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[kb + sl]);  // (beyond the range: some word of the LDS, unused)
+                rows[sl] = Vec<VEC>::template load<AUX_G>(make_rsrc(p.ffm_w + h, on ? R * 4 : 0u), e0 * 4);
             }
             // ... and the rows parked in LDS go there DIRECTLY (LDS-direct loads: no register in between), issued in the same burst as the register
             // rows' loads instead of two at a time behind them: destination = wave-uniform slot base + lane * 16
@@ -2801,9 +2920,13 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                     }
                 }
             }
+            // (the count is handed out afresh: compared with the SAME value as in the burst above, every slot's `sl < nk` is computed once, up there,
+            // and kept as a 64-bit lane mask until its row is consumed -- two scalar registers per kept row)
+            uint32_t nk_c = __builtin_amdgcn_readfirstlane(nk);
+            asm volatile("; kept-row count handed out" : "+s"(nk_c));
 #pragma unroll
             for (int sl = 0; sl < MAXR; ++sl)
-                if ((uint32_t)sl < nk) {
+                if ((uint32_t)sl < nk_c) {
                     V one[NC];
                     one[0] = rows[sl];
                     FW_CONSUME(one, kb + sl)
@@ -3011,8 +3134,11 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                 // applies) gets descriptors of zero length: its loads return 0, its stores are dropped.  With no branch between them the compiler
                 // counts the memory operations exactly (s_waitcnt vmcnt(n) instead of vmcnt(0)): waiting for row sl + 1's accumulators does not
                 // wait for the acknowledgement of row sl's stores any more.
+                // (the range's first index is handed out afresh: as the gather's own `kb`, every slot's kb + sl stayed in a scalar register from the gather to here)
+                uint32_t kb_u = __builtin_amdgcn_readfirstlane(kb);
+                asm volatile("; first kept row handed out" : "+s"(kb_u));
                 auto slot = [&](int sl, uint32_t &h, uint32_t &f, bool &ok) {
-                    const uint32_t i = kb + (uint32_t)sl;
+                    const uint32_t i = kb_u + (uint32_t)sl;
                     const uint32_t fb = __builtin_amdgcn_readfirstlane(s.e_fld[i]);
                     ok = (uint32_t)sl < nk2 && !(fb & kResSkip);
                     h = ok ? __builtin_amdgcn_readfirstlane(s.e_hash[i]) : 0u;
@@ -3044,16 +3170,16 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                     // store policy 3: is this a hot row (wave-uniform: any lane's accumulator beyond theta), and is this example the one in m that stores it?
                     float g2_scale = 0.0f;
                     bool acc_store = ok0;
-                    if (kThin && sl < MAXR && gridDim.x > 1) {  // (rows kept in registers only: a thinned store on a row parked in LDS -- stepped last, behind the longest window -- loses its race more often, tests/test_gpu_conservation.py)
+                    if (kThin && sl < MAXR && p.grid_wgs > 1) {  // (rows kept in registers only: a thinned store on a row parked in LDS -- stepped last, behind the longest window -- loses its race more often, tests/test_gpu_conservation.py)
                         const bool hot = __ballot(a_cur[0] > p.acc_hot_theta || a_cur[1] > p.acc_hot_theta || a_cur[2] > p.acc_hot_theta || a_cur[3] > p.acc_hot_theta) != 0ull;
                         if (hot) {
                             const uint32_t m = 1u << p.acc_sample_log2;
-                            const uint32_t draw = ((ex * 2654435761u) ^ ((kb + (uint32_t)sl) * 40503u + (uint32_t)wave * 9973u)) >> 9;
+                            const uint32_t draw = ((ex * 2654435761u) ^ ((kb_u + (uint32_t)sl) * 40503u + (uint32_t)wave * 9973u)) >> 9;
                             acc_store = ok0 && (draw & (m - 1u)) == 0u;
                             g2_scale = (float)(m - 1u);
                         }
                     }
-                    const float v = s.e_val[kb + (uint32_t)sl];
+                    const float v = s.e_val[kb_u + (uint32_t)sl];
                     V wv;
                     if (sl < MAXR) {
                         wv = rows[sl < MAXR ? sl : 0];
@@ -3182,7 +3308,15 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
     {
         int tid_end = threadIdx.x;
         asm volatile("; thread index handed out" : "+v"(tid_end));
-        if (COH && tid_end == 0 && s.ctr[13]) hot_lr_flush(p, s);  // (every thread's steps are in: the loop ends on a barrier)
+        if (COH && tid_end == 0) {
+            // (a view of its own: through the prologue's, the counters' LDS offset stayed in a scalar register across the whole example loop)
+            const KernelParams &p = kp_fresh();
+            Lds s;
+            SetGeom geom_unused;
+            TrLds trl_unused;
+            bind_lds(p, smem, use_lut, s, geom_unused, trl_unused);
+            if (s.ctr[13]) hot_lr_flush(p, s);  // (every thread's steps are in: the loop ends on a barrier)
+        }
     }
 #undef FW_TICK
 }
