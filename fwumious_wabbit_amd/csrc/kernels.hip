@@ -3136,7 +3136,11 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                 // wait for the acknowledgement of row sl's stores any more.
                 // (the range's first index is handed out afresh: as the gather's own `kb`, every slot's kb + sl stayed in a scalar register from the gather to here)
                 uint32_t kb_u = __builtin_amdgcn_readfirstlane(kb);
-                asm volatile("; first kept row handed out" : "+s"(kb_u));
+                // (... and so is the per-wave count of rows parked in LDS: with the gather's own `lk` this lane's address in the parked rows' slots is computed
+                // once, up there, and kept in a vector register through the dot phase -- spilled in this 128-register kernel, and its reload from scratch HERE
+                // is an s_waitcnt vmcnt(0): every parked row's step then waited for the acknowledgement of every store of the rows before it)
+                uint32_t lk_u = __builtin_amdgcn_readfirstlane(lk);
+                asm volatile("; first kept row and parked-row count handed out" : "+s"(kb_u), "+s"(lk_u));
                 auto slot = [&](int sl, uint32_t &h, uint32_t &f, bool &ok) {
                     const uint32_t i = kb_u + (uint32_t)sl;
                     const uint32_t fb = __builtin_amdgcn_readfirstlane(s.e_fld[i]);
@@ -3185,7 +3189,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                         wv = rows[sl < MAXR ? sl : 0];
                     } else {  // a row parked in LDS by the gather
                         wv = Vec<VEC>::zero();
-                        if (inb && ok0) wv = Vec<VEC>::lds_load(s.keep + ((uint32_t)wave * lk + (uint32_t)(sl - MAXR)) * R + e0);
+                        if (inb && ok0) wv = Vec<VEC>::lds_load(s.keep + ((uint32_t)wave * lk_u + (uint32_t)(sl - MAXR)) * R + e0);
                     }
                     V tv = Vec<VEC>::zero();
                     if (inb) tv = Vec<VEC>::lds_load(s.T + f0 * R + e0);

@@ -3137,7 +3137,11 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                 // wait for the acknowledgement of row sl's stores any more.
                 // (the range's first index is handed out afresh: as the gather's own `kb`, every slot's kb + sl stayed in a scalar register from the gather to here)
                 uint32_t kb_u = __builtin_amdgcn_readfirstlane(kb);
-                asm volatile("; first kept row handed out" : "+s"(kb_u));
+                // (... and so is the per-wave count of rows parked in LDS: with the gather's own `lk` this lane's address in the parked rows' slots is computed
+                // once, up there, and kept in a vector register through the dot phase -- spilled in this 128-register kernel, and its reload from scratch HERE
+                // is an s_waitcnt vmcnt(0): every parked row's step then waited for the acknowledgement of every store of the rows before it)
+                uint32_t lk_u = __builtin_amdgcn_readfirstlane(lk);
+                asm volatile("; first kept row and parked-row count handed out" : "+s"(kb_u), "+s"(lk_u));
                 auto slot = [&](int sl, uint32_t &h, uint32_t &f, bool &ok) {
                     const uint32_t i = kb_u + (uint32_t)sl;
                     const uint32_t fb = __builtin_amdgcn_readfirstlane(s.e_fld[i]);
@@ -3186,7 +3190,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                         wv = rows[sl < MAXR ? sl : 0];
                     } else {  // a row parked in LDS by the gather
                         wv = Vec<VEC>::zero();
-                        if (inb && ok0) wv = Vec<VEC>::lds_load(s.keep + ((uint32_t)wave * lk + (uint32_t)(sl - MAXR)) * R + e0);
+                        if (inb && ok0) wv = Vec<VEC>::lds_load(s.keep + ((uint32_t)wave * lk_u + (uint32_t)(sl - MAXR)) * R + e0);
                     }
                     V tv = Vec<VEC>::zero();
                     if (inb) tv = Vec<VEC>::lds_load(s.T + f0 * R + e0);
@@ -3716,4 +3720,4 @@ hipError_t launch_coherence_probe(unsigned *scratch /* >= 256+1+64+2 words, zero
 #endif  // !FW_PHASE_TU
 }  // namespace fwgpu
 
-namespace fwgpu { hipError_t probe_launch(const KernelParams &p, hipStream_t st) { return launch_persistent(fw_example_kernel<4, 300, true, 0, true>, p, 1, 512, 0, st); } }
+namespace fwgpu { hipError_t probe_launch(const KernelParams &p, hipStream_t st) { return launch_persistent(fw_example_kernel_r<300, true, 20, true, 1, 3>, p, 1, 512, 0, st); } }
