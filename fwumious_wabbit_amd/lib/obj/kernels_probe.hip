@@ -186,6 +186,8 @@ constexpr int kCtrNext = 16;      // the next example's ticket, published to all
 constexpr int kCtrPfLen = 17;     // words of the next example's record that sit in rec_next (0: not prefetched)
 constexpr int kCtrWbCount = 18;   // examples of this workgroup since its last buffer_wbl2
 constexpr int kCtrWbEvery = 19;   // KernelParams::wb_flush_every, or 0 when this launch never writes back (in-order launches, policy 0)
+constexpr int kCtrLabel = 20;     // v2 kernel: the example's label and importance (float bits), left here by the stage phase for the loss: two vector registers less through the gather
+constexpr int kCtrImp = 21;
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
@@ -2685,6 +2687,11 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
     bind_lds(p, smem, use_lut, s, geom, trl);
 
     const int tid = threadIdx.x, bd = blockDim.x;  // (the prologue's; every phase of the example loop derives its own)
+    // The example loop forms the thread index from the wave's index -- one scalar register -- and the lane's number in the wave: threadIdx.x itself is a
+    // vector register alive across the whole loop, i.e. (128-register instantiation) spilled, and its reload from scratch at the end of every example was
+    // an s_waitcnt vmcnt(0) that drained the example's row stores before the next stage phase could start.
+    const uint32_t wave_s = __builtin_amdgcn_readfirstlane((uint32_t)threadIdx.x >> 6);
+#define FW_TID_FRESH() ((int)(wave_s * 64u + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))))
     constexpr int kPfMax = 2;  // words of the next record a thread carries through the dot phase (records of up to kPfMax * blockDim words are prefetched)
 
     if (use_lut)
@@ -2738,7 +2745,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
             // dozen lane MASKS (tid == 0, tid < n, lane < 2 / 4 / ... of the wave scans) -- is derived inside the loop: left loop-invariant, every
             // such mask is a pair of scalar registers that lives across the whole example loop, i.e. is spilled to a VGPR lane in the prologue
             // and read back where it is used (~30 of the kernel's ~100 spilled scalars).
-            int tid_now = threadIdx.x, bd_now = blockDim.x;
+            int tid_now = FW_TID_FRESH(), bd_now = blockDim.x;
             uint32_t grid_now = p.grid_wgs;
             asm volatile("; thread index, workgroup and grid size handed out" : "+v"(tid_now), "+s"(bd_now), "+s"(grid_now));
             const int tid = tid_now, bd = bd_now;
@@ -2752,15 +2759,25 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
             ex = s.ctr[6];
             if (ex >= p.n_examples) break;
             FW_TICK(6);
+            // The next example's ticket is requested HERE and parked in LDS at the end of the stage phase, with the label and the importance the loss needs:
+            // requested behind the stage phase, as until round 5, the returned ticket sat in a vector register until the gather's row loads had been
+            // issued -- at the kernel's register peak.
+            uint32_t next_ticket = 0;
+            if (tid == 0) next_ticket = atomicAdd(p.work, 1u);
 #ifdef FW_TICKS
             if (timing) atomicAdd(p.ticks + 7, 1ull);
             so = stage_example<!COH>(p, s, geom, ex, tid, bd, trl, timing ? p.ticks : nullptr, s.ctr[kCtrPfLen]);
 #else
             so = stage_example<!COH>(p, s, geom, ex, tid, bd, trl, nullptr, s.ctr[kCtrPfLen]);
 #endif
+            if (tid == 0) {  // (visible to everybody behind the gather's barrier)
+                s.ctr[kCtrNext] = next_ticket;
+                s.ctr[kCtrLabel] = __float_as_uint(so.label);
+                s.ctr[kCtrImp] = __float_as_uint(so.imp);
+            }
         }
         const KernelParams &p = kp_fresh();
-        int tid_now = threadIdx.x, bd_now = blockDim.x;
+        int tid_now = FW_TID_FRESH(), bd_now = blockDim.x;
         uint32_t grid_now = p.grid_wgs;
         asm volatile("; thread index, workgroup and grid size handed out" : "+v"(tid_now), "+s"(bd_now), "+s"(grid_now));
         const int tid = tid_now, lane = tid & 63, wave = tid >> 6, bd = bd_now, nw = bd >> 6;
@@ -2784,11 +2801,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         }
         const uint32_t e0 = e0c[0], z = zc[0];  // (chunk 0: what the resident-row code, NC == 1 only, works on)
         const bool inb = inbc[0];
-        uint32_t next_ticket = 0;
-        if (tid == 0) next_ticket = atomicAdd(p.work, 1u);
-        const uint32_t nf = so.nf, nl = so.nl;
-        const float label = so.label, imp = so.imp;
-        const bool do_update = so.do_update;
+        const uint32_t nf = __builtin_amdgcn_readfirstlane(so.nf), nl = __builtin_amdgcn_readfirstlane(so.nl);
         FW_TICK(1);
 
         // ---------------- this wave's feature range [lo, hi): the fields f with floor(fstart[f]*nw/nf) == wave
@@ -2979,7 +2992,6 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
             }
 #undef FW_CONSUME
         }
-        if (tid == 0) s.ctr[kCtrNext] = next_ticket;  // (its atomic was issued before this wave's row loads: it has returned)
         __syncthreads();
         FW_TICK(2);
         // ---------------- the NEXT example's record: HBM -> registers now, -> LDS after the dot phase.  Its stage phase then needs no memory
@@ -3083,9 +3095,9 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                 x[C + t] = d;
             }
             if (tid == 0) {
-                p.gbuf[2 * (size_t)ex] = label;
-                p.gbuf[2 * (size_t)ex + 1] = imp;
-                s.ctr[6] = next_ticket;
+                p.gbuf[2 * (size_t)ex] = __uint_as_float(s.ctr[kCtrLabel]);
+                p.gbuf[2 * (size_t)ex + 1] = __uint_as_float(s.ctr[kCtrImp]);
+                s.ctr[6] = s.ctr[kCtrNext];
             }
             continue;
         }
@@ -3099,6 +3111,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         if (p.has_lr) wsum += lr_t;
         wsum += 0.5f * (dot_t - dc_t);
 
+        const float label = __uint_as_float(s.ctr[kCtrLabel]), imp = __uint_as_float(s.ctr[kCtrImp]);  // (parked by the stage phase)
         float pr, g;
         if (isnan(wsum)) {
             pr = logistic(0.0f);
@@ -3116,6 +3129,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         if (tid == 0) p.pred[ex] = pr;
         FW_TICK(3);
 
+        const bool do_update = p.update && imp != 0.0f;  // regressor.rs:366 (as the stage phase's StageOut::do_update)
         if (do_update && g != 0.0f) {
             const bool lr_upd = p.has_lr;
             // The pair kept from the forward pass saves the update's load round trip: +1.8 % examples/s at config C at the same loss.  Only for
@@ -3293,9 +3307,9 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
             FW_TICK(5);
         }
         // (the tail's lane tests start from a fresh thread index: `tid == 0` from the top of the example would be one more mask alive across the whole body)
-        int tid_tail = threadIdx.x;
+        int tid_tail = FW_TID_FRESH();
         asm volatile("; thread index handed out" : "+v"(tid_tail));
-        if (tid_tail == 0) s.ctr[6] = next_ticket;  // published by the loop-top barrier
+        if (tid_tail == 0) s.ctr[6] = s.ctr[kCtrNext];  // published by the loop-top barrier
         if (COH && POL >= 1 && tid_tail == bd - 1) {
             // bounded staleness of the write-back policies: this workgroup's turn to write its XCD's dirty L2 lines back (one instruction, not
             // waited for here: it completes under the next example's stage phase)
@@ -3311,7 +3325,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         }
     }
     {
-        int tid_end = threadIdx.x;
+        int tid_end = FW_TID_FRESH();
         asm volatile("; thread index handed out" : "+v"(tid_end));
         if (COH && tid_end == 0) {
             // (a view of its own: through the prologue's, the counters' LDS offset stayed in a scalar register across the whole example loop)
@@ -3324,6 +3338,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         }
     }
 #undef FW_TICK
+#undef FW_TID_FRESH
 }
 
 #ifndef FW_MAXR
