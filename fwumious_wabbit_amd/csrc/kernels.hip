@@ -2842,7 +2842,45 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         const uint32_t nk2 = cnt < (uint32_t)MAXR + lk ? cnt : (uint32_t)MAXR + lk;              // rows kept, registers + LDS
         const uint32_t kb = kKeepLast ? hi - nk : lo;                      // the first of them (cnt == 0: lo == hi == 0)
         V rows[MAXR > 0 ? MAXR : 1];
+        // The rows parked in LDS go there DIRECTLY (LDS-direct loads: no register in between), issued in the same burst as the register rows' loads instead
+        // of two at a time behind them: destination = wave-uniform slot base + lane * 16.  -DFW_PARK_FIRST=1 issues them in FRONT of the register rows' loads.
+#ifndef FW_PARK_ASM
+#define FW_PARK_ASM 0
+#endif
+#ifndef FW_PARK_FIRST
+#define FW_PARK_FIRST FW_PARK_ASM
+#endif
+        auto park_rows = [&]() {
+            if (kLdsKeep && FW_PARK_DIRECT) {
+#pragma unroll
+                for (int j = 0; j < LKM; ++j) {
+                    if ((uint32_t)(MAXR + j) < nk2) {
+                        const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[lo + MAXR + j]);
+                        const float *src = p.ffm_w + h + e0;
+                        float *dst = s.keep + ((uint32_t)wave * lk + (uint32_t)j) * R;
+                        if (inb) {
+#if FW_PARK_ASM
+                            // (issued behind the compiler's back: it treats an LDS-direct load as a store to ANY LDS address, and waits for vmcnt(0) -- for all
+                            // the row loads of the burst -- before every LDS read of the consume steps below.  The parked rows' own readers wait explicitly.
+                            // Issued FIRST, the three loads the compiler does not count are the oldest: its vmcnt(n) waits for the register rows stay exact.)
+                            const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)dst);
+                            const uint32_t voff = e0 * 4u;
+                            const float *sbase = p.ffm_w + h;
+                            if (AUX_G == kAuxSc1)
+                                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1" ::"s"(lds_base), "v"(voff), "s"(sbase) : "m0", "memory");
+                            else
+                                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_base), "v"(voff), "s"(sbase) : "m0", "memory");
+#else
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                             (__attribute__((address_space(3))) void *)dst, 16, 0, AUX_G);
+#endif
+                        }
+                    }
+                }
+            }
+        };
         if (!kKeepLast) {
+            if (FW_PARK_FIRST) park_rows();
 #pragma unroll
             for (int sl = 0; sl < MAXR; ++sl) {
                 // (a slot beyond the range loads through a zero-length descriptor: zeros, no memory access -- as a branch around the load every
@@ -2851,21 +2889,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                 const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[kb + sl]);  // (beyond the range: some word of the LDS, unused)
                 rows[sl] = Vec<VEC>::template load<AUX_G>(make_rsrc(p.ffm_w + h, on ? R * 4 : 0u), e0 * 4);
             }
-            // ... and the rows parked in LDS go there DIRECTLY (LDS-direct loads: no register in between), issued in the same burst as the register
-            // rows' loads instead of two at a time behind them: destination = wave-uniform slot base + lane * 16
-            if (kLdsKeep && FW_PARK_DIRECT) {
-#pragma unroll
-                for (int j = 0; j < LKM; ++j) {
-                    if ((uint32_t)(MAXR + j) < nk2) {
-                        const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[lo + MAXR + j]);
-                        const float *src = p.ffm_w + h + e0;
-                        float *dst = s.keep + ((uint32_t)wave * lk + (uint32_t)j) * R;
-                        if (inb)
-                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                             (__attribute__((address_space(3))) void *)dst, 16, 0, AUX_G);
-                    }
-                }
-            }
+            if (!FW_PARK_FIRST) park_rows();
         }
         {
             V acc[NC];

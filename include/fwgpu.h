@@ -426,7 +426,8 @@ int fwgpu_delta_finish(void *table, void *snapshot, const void *local_delta, con
 /* Per-phase shader-clock accounting of the example kernel (debug): enable=1 allocates/zeroes 8 device counters that
  * every workgroup's thread 0 adds to: [0] stage entries, [1] field boundaries + overlap scan, [2] row gather,
  * [3] dot + LR forward + sigmoid, [4] LR update, [5] FFM update, [6] wait for the slowest wave, [7] examples.
- * out16 (may be NULL) receives the counters accumulated so far. */
+ * out16 (may be NULL) receives the counters accumulated so far.  The stamps are compiled into -DFW_TICKS builds of kernels.hip only
+ * (scripts/build_variant.sh ticks -DFW_TICKS; scripts/perf_probe.py): the shipped kernels add nothing, the counters stay 0. */
 int fwgpu_debug_phase_ticks(fwgpu_regressor *r, int enable, uint64_t *out16);
 /* How the FFM accumulator table was placed relative to the weight table (fwgpu_create tries a few candidate allocations for
  * tables beyond the Infinity Cache and times the update's access pattern on each pair; FWGPU_PLACEMENT=0 disables it):

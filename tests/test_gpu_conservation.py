@@ -206,7 +206,7 @@ def test_hot_ffm_rows_keep_a_bounded_share_of_their_steps(opt, ffm_bits, capsys)
             else:
                 assert shipped >= FLOOR_ACC, (n, hot_field, shipped)
                 # the accumulators must count what write-through stores count: a private accumulator makes the steps of exactly the most contended rows too large
-                # (round 5's shipped policy thins the stores of hot register-kept rows -- one example in eight stores eight times its g^2: measured 0.83-0.87 of
+                # (round 5's shipped policy thins the stores of hot register-kept rows -- one example in eight stores eight times its g^2: measured 0.83-0.88 of
                 # write-through on the rig's rows in 16 384- and 65 536-example launches, 0.77-0.86 in the 2048-example one, whose ~230 hits per row are the noisier)
                 assert shipped >= (0.8 if n > 2048 else 0.7) * wt, (n, hot_field, shipped, wt)
     # ... and nothing may get worse with the LENGTH of the launch (a row that stays private to an XCD until the launch ends would)
