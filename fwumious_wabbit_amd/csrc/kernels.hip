@@ -1484,6 +1484,16 @@ __device__ __forceinline__ void bind_lds(const KernelParams &p, unsigned char *s
     trl.cw = reinterpret_cast<const float *>(tw + p.tr.n_pairs + p.tr.n_combos + 1 + p.tr.n_members);
 }
 
+// The carve-up alone, for the views the example kernels take per phase (stage / gather + dot / head unwinding / table update / tail / epilogue): what a phase
+// does not use of it is dead code, what it uses is formed where the phase starts instead of living in scalar registers from an earlier phase on.
+__device__ __forceinline__ Lds lds_view(const KernelParams &p, unsigned char *smem, bool use_lut) {
+    Lds s;
+    SetGeom geom_unused;
+    TrLds trl_unused;
+    bind_lds(p, smem, use_lut, s, geom_unused, trl_unused);
+    return s;
+}
+
 // The kernels take their parameters by value (one argument block, scalar loads).  Left alone, the compiler loads every field once in the
 // prologue of the persistent kernel and keeps ~180 scalars alive across the example loop -- 200 of them spilled to VGPR lanes, which in turn
 // pushed 8 vector registers of the config-C learn kernel to scratch.  kp_fresh() hands out the argument block's address through an empty
@@ -1769,12 +1779,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
         int tid_now = threadIdx.x, bd_now = blockDim.x;
         asm volatile("; thread index and workgroup size handed out" : "+v"(tid_now), "+s"(bd_now));
         const int tid = tid_now, lane = tid & 63, wave = tid >> 6, bd = bd_now, nw = bd >> 6;
-        Lds s;
-        {
-            SetGeom geom_unused;
-            TrLds trl_unused;
-            bind_lds(p, smem, (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global, s, geom_unused, trl_unused);
-        }
+        Lds s = lds_view(p, smem, (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global);
         if (PH != 0 && p.t_global) s.T = p.split + (size_t)ex * p.split_len;
         const uint32_t F = p.F, k = p.k, R = p.R;  // (shadow the prologue's, like everything else the example works with)
         const uint32_t nchunk = R ? (R + 64 * VEC - 1) / (64 * VEC) : 0;
@@ -2009,12 +2014,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
                 int tid_h = threadIdx.x, bd_h = blockDim.x;
                 asm volatile("; thread index and workgroup size handed out" : "+v"(tid_h), "+s"(bd_h));
                 const int tid = tid_h, bd = bd_h;
-                Lds s;
-                {
-                    SetGeom geom_unused;
-                    TrLds trl_unused;
-                    bind_lds(p, smem, (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global, s, geom_unused, trl_unused);
-                }
+                Lds s = lds_view(p, smem, (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global);
                 if (head_split) {
                     // the example's slot gradients (X floats, written by the head kernels) come into LDS once: every row chunk of the update looks its pair's
                     // gradient up there instead of in global memory
@@ -2030,12 +2030,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
             int tid_u = threadIdx.x, bd_u = blockDim.x;
             asm volatile("; thread index and workgroup size handed out" : "+v"(tid_u), "+s"(bd_u));
             const int tid = tid_u, lane = tid & 63, wave = tid >> 6, bd = bd_u, nw = bd >> 6;
-            Lds s;
-            {
-                SetGeom geom_unused;
-                TrLds trl_unused;
-                bind_lds(p, smem, (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global, s, geom_unused, trl_unused);
-            }
+            Lds s = lds_view(p, smem, (OPT == FWGPU_OPT_ADAGRAD_LUT) && p.update && !p.lut_global);
             if (PH != 0 && p.t_global) s.T = p.split + (size_t)ex * p.split_len;
             const uint32_t F = p.F, k = p.k, R = p.R;
             const uint32_t nchunk = R ? (R + 64 * VEC - 1) / (64 * VEC) : 0;
@@ -2266,10 +2261,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
             // (through a view of its own: the counters' offset is formed here from the argument block, instead of its dozen inputs living in scalar
             // registers from the post-stage view down to this line)
             const KernelParams &pt = kp_fresh();
-            Lds st;
-            SetGeom geom_unused;
-            TrLds trl_unused;
-            bind_lds(pt, smem, (OPT == FWGPU_OPT_ADAGRAD_LUT) && pt.update && !pt.lut_global, st, geom_unused, trl_unused);
+            Lds st = lds_view(pt, smem, (OPT == FWGPU_OPT_ADAGRAD_LUT) && pt.update && !pt.lut_global);
             st.ctr[6] = next_ticket;
         }
     }
@@ -2279,10 +2271,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
     int tid_e = threadIdx.x, bd_e = blockDim.x;
     asm volatile("; thread index and workgroup size handed out" : "+v"(tid_e), "+s"(bd_e));
     if (COH && tid_e == 0) {
-        Lds se;
-        SetGeom geom_unused;
-        TrLds trl_unused;
-        bind_lds(pe, smem, (OPT == FWGPU_OPT_ADAGRAD_LUT) && pe.update && !pe.lut_global, se, geom_unused, trl_unused);
+        Lds se = lds_view(pe, smem, (OPT == FWGPU_OPT_ADAGRAD_LUT) && pe.update && !pe.lut_global);
         if (se.ctr[13]) hot_lr_flush<SH>(pe, se);  // (every thread's steps are in: the loop ends on a barrier)
     }
     if (SH && PH == 0 && pe.push && pe.push->stream) {
@@ -2782,12 +2771,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         const int tid = tid_now, lane = tid & 63, wave = tid >> 6, bd = bd_now, nw = bd >> 6;
         const uint32_t F = p.F, k = p.k, R = p.R;
         const float *lut_lr = p.lut_lr;  // 201 lookups per example: read through L1 (an LDS copy measured no faster)
-        Lds s;
-        {
-            SetGeom geom_unused;
-            TrLds trl_unused;
-            bind_lds(p, smem, use_lut, s, geom_unused, trl_unused);
-        }
+        Lds s = lds_view(p, smem, use_lut);
         // this lane's 4 floats of a row's chunk c: elements [e0, e0+4) = slot z, offset kk0
         uint32_t e0c[NC], zc[NC], kkc[NC];
         bool inbc[NC];
@@ -3353,10 +3337,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         if (COH && tid_end == 0) {
             // (a view of its own: through the prologue's, the counters' LDS offset stayed in a scalar register across the whole example loop)
             const KernelParams &p = kp_fresh();
-            Lds s;
-            SetGeom geom_unused;
-            TrLds trl_unused;
-            bind_lds(p, smem, use_lut, s, geom_unused, trl_unused);
+            Lds s = lds_view(p, smem, use_lut);
             if (s.ctr[13]) hot_lr_flush(p, s);  // (every thread's steps are in: the loop ends on a barrier)
         }
     }
