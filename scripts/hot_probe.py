@@ -17,11 +17,15 @@ s = s.replace("template <typename K>\nstatic hipError_t launch_persistent(", "st
               "template <typename K>\nstatic hipError_t launch_persistent(", 1)
 assert n >= 19 and "launch_none(const" in s, n
 s += f"\nnamespace fwgpu {{ hipError_t probe_launch(const KernelParams &p, hipStream_t st) {{ return launch_persistent({kern}, p, 1, 512, 0, st); }} }}\n"
-path = os.path.join(obj, "kernels_probe.hip")
+path = os.path.join(obj, f"kernels_probe_{os.getpid()}.hip")  # (per process: the register-budget tests may run in parallel)
+asm = f"/tmp/hot_probe_{os.getpid()}.s"
 open(path, "w").write(s)
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", f"-I{ROOT}/include", f"-I{src}", "-mllvm", "-pragma-unroll-threshold=131072",
-       "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage"] + (["-DFW_PHASE_TU"] if os.environ.get("PHASE") else []) + flags + ["-S", path, "-o", "/tmp/hot_probe.s"]
+       "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage"] + (["-DFW_PHASE_TU"] if os.environ.get("PHASE") else []) + flags + ["-S", path, "-o", asm]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
+os.remove(path)
+if os.path.exists(asm):
+    os.replace(asm, "/tmp/hot_probe.s")
 keep = False
 for line in out.splitlines():
     m = re.search(r"remark:\s+(.*?)(?: \[-Rpass)", line)

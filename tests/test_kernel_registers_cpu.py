@@ -1,0 +1,41 @@
+"""Register budget of the hot kernel instantiations, checked at compile time (no GPU): no scalar register spilled to a VGPR lane (DESIGN.md 4.7;
+VERDICT r4 item 7), and the vector-register spills where round 5 left them.  One device-only compile of a single instantiation per case
+(scripts/hot_probe.py: a few seconds each)."""
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+CASES = [
+    # instantiation, second translation unit (-DFW_PHASE_TU), most VGPR spills allowed
+    ("fw_example_kernel_r<300, true, 20, true, 1, 3>", False, 2),   # config C, store policy 3 (the shipped default)
+    ("fw_example_kernel_r<300, true, 20, true, 1, 1>", False, 4),   # config C, round 4's store policy
+    ("fw_example_kernel_r<300, true, 0, true, 2, 3>", False, 0),    # two-chunk rows (k = 16), updating
+    ("fw_example_kernel_r<100, false, 0, false, 2, 3>", False, 0),  # ... predict-only (config E's batched head path)
+    ("fw_example_kernel<4, 300, true, 0, true>", False, 0),         # config E: the generic kernel with the deep head
+    ("fw_example_kernel<4, 100, false, 1, false>", True, 0),        # FWD phase
+    ("fw_example_kernel<4, 300, true, 3, false>", True, 0),         # UPD phase
+    ("fw_example_kernel<4, 300, true, 3, true>", True, 0),          # UPD phase behind the mini-batched head
+]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+@pytest.mark.parametrize("kernel,phase_tu,max_vgpr_spills", CASES)
+def test_no_scalar_register_is_spilled_to_a_vgpr_lane(kernel, phase_tu, max_vgpr_spills, tmp_path):
+    env = dict(os.environ)
+    if phase_tu:
+        env["PHASE"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "hot_probe.py"), kernel], capture_output=True, text=True, env=env, timeout=600).stdout
+    sg = re.search(r"SGPRs Spill: (\d+)", out)
+    vg = re.search(r"VGPRs Spill: (\d+)", out)
+    vr = re.search(r"\bVGPRs: (\d+)", out)
+    assert sg and vg and vr, out
+    assert int(sg.group(1)) == 0, out
+    assert int(vg.group(1)) <= max_vgpr_spills, out
+    assert int(vr.group(1)) <= 128, out
