@@ -247,6 +247,7 @@ struct LaunchConfig {
 };
 
 size_t example_kernel_lds_bytes(const KernelParams &p, int optimizer);
+bool example_kernel_is_resident(const KernelParams &p, uint32_t threads);  // does a launch of this shape run on the v2 kernel (fw_example_kernel_r)?
 void resolve_row_mode(KernelParams &p, uint32_t threads);  // settles KernelParams::window / chain for this launch shape
 // Enqueue the example kernel.  grid==1 gives the sequential (in-order) semantics.
 hipError_t launch_example_kernel(const KernelParams &p, int optimizer, bool coherent, uint32_t grid,

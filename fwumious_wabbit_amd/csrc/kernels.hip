@@ -3385,6 +3385,7 @@ static bool uses_resident_kernel(const KernelParams &p, uint32_t threads) {
     const bool fits = p.R <= 64 * 4 || (p.R <= 64 * 4 * 2 && p.k != 0 && 256 % p.k == 0);
     return p.k % 4 == 0 && p.aligned4 && fits && p.kernel_version != 1 && (p.nn.n_layers == 0 || (p.emit_x && !p.update)) && threads <= FW_LB_THREADS;
 }
+bool example_kernel_is_resident(const KernelParams &p, uint32_t threads) { return uses_resident_kernel(p, threads); }
 // Whole-line updates and duplicate-row chains exist in the v2 kernel's update path only, and only updating launches need them.
 void resolve_row_mode(KernelParams &p, uint32_t threads) {
     p.window = (p.window && uses_resident_kernel(p, threads) && p.update && p.k_log2 != 0xffu) ? 1 : 0;

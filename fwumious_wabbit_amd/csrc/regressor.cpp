@@ -445,6 +445,10 @@ static int prepare_launch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int upda
         if (!p.lut_global && 2 * lds_nolut <= r->lds_per_cu) {
             p.lut_global = 1;
             lds = lds_nolut;
+        } else if (example_kernel_is_resident(p, threads)) {
+            // ... and unless the launch runs on the v2 kernel (models without a deep head): ONE 512-thread workgroup of it per CU beats one 1024-thread workgroup
+            // of the generic kernel on both axes -- headless k = 16, round 5: 2.62-2.63 M examples/s and hold-out 0.653-0.655 against 2.52-2.53 M and 0.673
+            // (profiles/r05_k16_threads_ab.txt)
         } else {
             threads = 1024;
             p.lds_keep = 0;
