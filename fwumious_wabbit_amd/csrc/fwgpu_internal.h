@@ -200,7 +200,8 @@ struct KernelParams {
     uint32_t selfw_stride;
     float *gbuf;                        // [n] general gradient of every example (MID -> UPD)
     float *xbuf, *dxbuf;                // deep head, mini-batched: x and d logit/d x per example [n * nn.X]
-    int32_t no_selfw;                   // read-only launch on the v2 kernel: the entries' own slots (Lds::selfw) are not kept -- only the update and the generic kernel's head read them (resolve_row_mode)
+    int32_t concurrent;                 // host side: a HOGWILD launch of more than one workgroup (prepare_launch); with it a whole-line updating launch of the v2 kernel does without Lds::selfw (resolve_row_mode)
+    int32_t no_selfw;                   // v2 kernel, read-only launch or concurrent whole-line update: the entries' own slots (Lds::selfw) are not kept (resolve_row_mode)
     int32_t emit_x;                     // read-only launch of a model with a deep head on the v2 kernel: the example's head input x goes to xbuf, {label, importance} to gbuf,
                                         // and the layers run afterwards for the whole batch on the matrix cores (regressor.cpp run_batch, head.hip head_step)
 #if defined(FW_KP_PAD_POS) && FW_KP_PAD_POS == 2  // debug builds (scripts/kp_pos_exp.sh): 16 bytes HERE

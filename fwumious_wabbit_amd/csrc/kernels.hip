@@ -1395,7 +1395,8 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
                 const bool self = z == f;
                 f4 tv = f4{0.f, 0.f, 0.f, 0.f}, sw = tv;
                 if (inb) tv = Vec<4>::lds_load(s.T + f * R + e);
-                if (self) sw = Vec<4>::lds_load(s.selfw + i * k + (e - (int)(z << ksh)));
+                // (the entry's own slot: the LDS copy the gather left, or -- concurrent launches, resolve_row_mode -- this lane's part of the row as just re-read, before any step of this example)
+                if (self) sw = (NCH > 1 && p.no_selfw) ? wv[u][c] : Vec<4>::lds_load(s.selfw + i * k + (e - (int)(z << ksh)));
                 const float gz = (gpair && inb) ? gpair[tri_index(f, z)] : g;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -2911,7 +2912,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
             }                                                                                                 \
             if (zc[c] == f_) {                                                                                \
                 dc += ss_ * v_ * v_;                                                                          \
-                if (COH || !p.no_selfw) Vec<VEC>::lds_store(s.selfw + (IDX)*k + kkc[c], (ROW)[c]);             \
+                if ((COH && NC == 1) || !p.no_selfw) Vec<VEC>::lds_store(s.selfw + (IDX)*k + kkc[c], (ROW)[c]);             \
             }                                                                                                 \
         }                                                                                                     \
     }
@@ -3401,7 +3402,13 @@ void resolve_row_mode(KernelParams &p, uint32_t threads) {
     // The v2 kernel's single-chunk updating instantiations keep the LUT in LDS as a compile-time fact (kLdsLut): settled HERE, so that the host's
     // LDS size -- the occupancy choice and the 160 KiB check of prepare_launch -- is the size the launch really uses (debug option 1 does not apply to them).
     p.lut_lds_forced = (uses_resident_kernel(p, threads) && p.R <= 64 * 4 && p.update) ? 1 : 0;
-    p.no_selfw = (!p.update && uses_resident_kernel(p, threads)) ? 1 : 0;  // (only the update and the generic kernel's head read the entries' own slots)
+    // The entries' own slots (Lds::selfw: every row's w[f_i * k ..] as the gather read it) are read by the update and by the generic kernel's head only.  Read-only launches of the
+    // v2 kernel do without them -- and so do its CONCURRENT whole-line updates (update_rows_win): the row the update has just re-read holds the same slot, as fresh as the rest of
+    // the row (between concurrent examples either is a value the weight had; in-order launches keep the LDS copy, which is what makes rows that overlap an earlier row of the
+    // example exact).  At k = 16 that is 16-19 KB of 89: what lets a SECOND workgroup live on a CU (+27 % examples/s where it fits, profiles/r05_k16_two_wgs_probe.txt).
+    static const bool selfw_lds_forced = [] { const char *e = std::getenv("FWGPU_SELFW_LDS"); return e && std::atoi(e) != 0; }();
+    // (two-chunk rows only: config C's kernel has the LDS to spare, and the choice costs its update two vector registers it does not have)
+    p.no_selfw = (uses_resident_kernel(p, threads) && (!p.update || (p.window && p.concurrent && p.R > 64 * 4 && !selfw_lds_forced))) ? 1 : 0;
     // rows kept in LDS beyond the register-kept ones: the chained-update instantiation of single-chunk rows only (fw_example_kernel_r, FW_LDS_KEEP_MAX)
     if (!(p.lut_lds_forced && p.window) || FW_KEEP_LAST) p.lds_keep = 0;
     if (p.lds_keep > FW_LDS_KEEP_MAX) p.lds_keep = FW_LDS_KEEP_MAX;

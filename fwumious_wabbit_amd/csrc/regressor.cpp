@@ -421,6 +421,7 @@ uint32_t pick_grid(const fwgpu_regressor *r, const KernelParams &p, int mode, ui
 // launch shape of a batch: workgroup size, LDS copy of the LUT or not (settles p.window / p.chain / p.lut_global)
 static int prepare_launch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, KernelParams &p, uint32_t &threads) {
     p = make_params(r, b, update);
+    p.concurrent = (mode == FWGPU_MODE_HOGWILD && p.host_grid_cap != 1 && b->n > 1) ? 1 : 0;  // (one workgroup -- in-order semantics -- otherwise)
     threads = r->launch.threads;
     if (mode == FWGPU_MODE_SEQUENTIAL) threads = std::max<uint32_t>(threads, 512);
     if ((uint64_t)p.max_ffm > 4ull * threads) threads = 1024;
