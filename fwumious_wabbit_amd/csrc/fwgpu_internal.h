@@ -161,6 +161,7 @@ struct KernelParams {
     int32_t store_policy;               // hogwild launches of the v2 window kernel: how FFM row stores reach memory (kernels.hip "store policy"): 0 = both tables
                                         // device-scope write-through, 1 = weights write-back through the XCD's L2, 2 = both tables write-back
     float acc_hot_theta;                // policy 3: a kept row whose accumulators exceed this is "hot": its accumulator row is stored for one example in
+    int32_t thin_reread;                // policy 3 also on the re-read rows of the two-chunk instantiations (update_rows_win): FWGPU_THIN_REREAD (default 1)
     uint32_t acc_sample_log2;           // 2^acc_sample_log2 only, with that many times the example's g^2 (an unbiased, thinned write-through: kernels.hip "store policy")
     uint32_t wb_flush_every;            // policies 1 / 2: a workgroup writes its XCD's dirty L2 lines back (buffer_wbl2 sc1) every this many of its examples (0: never)
     int32_t tr_lds;                     // record batches on the v2 kernel: the translator's tables are read from an LDS copy (kernels.hip TrLds)

@@ -1347,7 +1347,7 @@ __device__ __forceinline__ void update_rows(const KernelParams &p, const Lds &s,
 // this path keeps in both cases.
 template <int OPT, int AUX, int U, int NCH, int AUX_SW = AUX, int AUX_SA = AUX>
 __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds &s, const uint32_t (&idx)[U], float g,
-                                                int lane, uint32_t nf, const float *gpair = nullptr) {
+                                                int lane, uint32_t nf, const float *gpair = nullptr, uint32_t thin_seed = 0xffffffffu) {
     const uint32_t R = p.R, k = p.k, ksh = p.k_log2;
     // NCH 1 KiB chunks per row, all loaded before anything is computed (one memory round trip per batch of U rows).
     // A k = 8 row that starts 96 B into a line spans 9 lines: its second chunk is the one extra line (8 lanes).
@@ -1431,7 +1431,23 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
             }
             const uint32_t fl = hh[u] - (sb[u] >> 2);
             Vec<4>::template store<AUX_SW>(wn, make_rsrc(p.ffm_w + fl, nb[u]), c * 1024 + lane * 16);
-            if (OPT != FWGPU_OPT_SGD) Vec<4>::template store<AUX_SA>(an, make_rsrc(p.ffm_acc + fl, nb[u]), c * 1024 + lane * 16);
+            // Store policy 3 on two-chunk rows (thin_seed given): a row whose accumulators exceed acc_hot_theta stores them for one example in m only, with m times
+            // what this example added (av + m (an - av): unbiased; the step above was taken with the true running accumulator) -- the kept rows' rule of the config-C
+            // kernel, for rows that are re-read: the window between this load and this store is one round trip.
+            uint32_t acc_bytes = nb[u];
+            if (NCH > 1 && OPT != FWGPU_OPT_SGD && thin_seed != 0xffffffffu) {
+                const f4 a0 = av[u][c];
+                const bool hot = __ballot(inb && (a0[0] > p.acc_hot_theta || a0[1] > p.acc_hot_theta || a0[2] > p.acc_hot_theta || a0[3] > p.acc_hot_theta)) != 0ull;
+                if (hot) {
+                    const uint32_t m = 1u << p.acc_sample_log2;
+                    const uint32_t draw = ((thin_seed * 2654435761u) ^ (idx[u] * 40503u + (uint32_t)c * 9973u)) >> 9;
+                    if ((draw & (m - 1u)) != 0u) acc_bytes = 0;  // (not this example's turn: the store is dropped)
+                    const float ms = (float)(m - 1u);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) an[j] = an[j] + ms * (an[j] - a0[j]);
+                }
+            }
+            if (OPT != FWGPU_OPT_SGD) Vec<4>::template store<AUX_SA>(an, make_rsrc(p.ffm_acc + fl, acc_bytes), c * 1024 + lane * 16);
         }
     }
 }
@@ -3290,7 +3306,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                     if (WIN && MAXR > 0 && i >= kb && i < kb + nk2 && !(s.e_fld[i] & kRowHasChain)) idx[u] = 0xffffffffu;
                 }
                 if (WIN)
-                    update_rows_win<OPT, AUX, UO, (NC > FW_WIN_NCH ? NC : FW_WIN_NCH), AUX_SW, AUX_SA>(p, s, idx, g, lane, nf);
+                    update_rows_win<OPT, AUX, UO, (NC > FW_WIN_NCH ? NC : FW_WIN_NCH), AUX_SW, AUX_SA>(p, s, idx, g, lane, nf, nullptr, (kThin && NC > 1 && p.store_policy == 3 && p.grid_wgs > 1 && p.thin_reread) ? ex : 0xffffffffu);
                 else
                     update_rows<VEC, OPT, AUX, UO, false, NC>(p, s, idx, g, lane);
             }

@@ -398,6 +398,8 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
         static const char *env_th = getenv("FWGPU_ACC_HOT_THETA"), *env_sm = getenv("FWGPU_ACC_SAMPLE_LOG2");  // policy 3's two knobs (A/B runs)
         p.acc_hot_theta = env_th ? (float)atof(env_th) : 0.5f;
         p.acc_sample_log2 = env_sm ? (uint32_t)atoi(env_sm) : 3u;
+        static const char *env_tr = getenv("FWGPU_THIN_REREAD");
+        p.thin_reread = env_tr ? atoi(env_tr) : 1;
         p.wb_flush_every = r->launch.wb_flush_every >= 0 ? (uint32_t)r->launch.wb_flush_every : (env_wb ? (uint32_t)atoi(env_wb) : 0xffffffffu);
         p.prefetch = (r->launch.prefetch && !(env_pf && env_pf[0] == '0')) ? 1 : 0;
         static const char *env_lk = getenv("FWGPU_LDS_KEEP");
