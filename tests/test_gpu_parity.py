@@ -175,6 +175,44 @@ def test_sequential_stream_k16_two_chunk_rows(whole_lines):
                    ffm_init_acc=1.0, weight_tol=5e-5, whole_lines=whole_lines)
 
 
+def test_concurrent_two_chunk_rows_equal_the_in_order_result_on_disjoint_examples():
+    """Concurrent whole-line updates of two-chunk rows (k = 16 x 30 fields) keep no LDS copy of the entries' own slots: the self-pair correction
+    (block_ffm.rs:238) reads the slot from the row the update has just re-read -- its copy from before any step of the example, so a duplicate-row chain
+    sees the pre-update value like the reference's forward pass (resolve_row_mode: KernelParams::no_selfw).  On examples that share no row and no LR
+    entry the order of the examples cannot matter: the concurrent launch (two workgroups per CU, own slots from the re-read rows) must leave the SAME bits
+    as the in-order launch (one workgroup, own slots from the gather's LDS copy), duplicates and weighted features included.  Store policy 1: policy 3's
+    thinned accumulator stores are unbiased, not bit-equal."""
+    F, k, n = 30, 16, 96
+    mi, _, _ = make_pair(F, k, 16, 24, fw.Optimizer.AdagradLUT, lr=0.05, ffm_lr=0.05)
+    rng = np.random.default_rng(20241003)
+    fbs = []
+    for e in range(n):
+        feats = []
+        j = 0
+        for f in range(F):
+            for _ in range(int(rng.integers(1, 4))):
+                feats.append(((e * 128 + j) * 512, float(rng.choice([1.0, 0.5, 2.0])), f * k))
+                j += 1
+            if f % 7 == 3:  # the same feature again in the same field: a chained duplicate row
+                feats.append((feats[-1][0], 1.0, f * k))
+        assert j < 128
+        fbs.append(fw.lr_and_ffm_vec([((e * 4 + 1) * 8, 1.0, e % F)], feats, float(e & 1), 1.0 if e % 5 else 0.5))
+    out = []
+    for mode in (capi.MODE_SEQUENTIAL, capi.MODE_HOGWILD):
+        re = fw.Regressor(mi)
+        re.set_store_policy(1)
+        b = re.batch(fbs)
+        re.learn_batch(b, mode, True)
+        out.append((b.predictions().copy(), re.table_read(capi.TABLE_FFM_W), re.table_read(capi.TABLE_FFM_ACC), re.table_read(capi.TABLE_LR)))
+        b.close()
+        re.close()
+    for a, c in zip(out[0], out[1]):
+        assert np.array_equal(a, c)
+    fresh = fw.Regressor(mi)
+    assert not np.array_equal(out[0][1], fresh.table_read(capi.TABLE_FFM_W))  # (the batch did step the weights)
+    fresh.close()
+
+
 def test_lr_only_model():
     _stream_parity(8, 0, 14, 14, fw.Optimizer.AdagradLUT, n=1500, mean_extra=1.0, p_weighted=0.2, ids=2000, seed=7,
                    interactions=[(0, 1)])
