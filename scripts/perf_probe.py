@@ -1,4 +1,6 @@
-"""GPU perf exploration: config-C learn launches with per-phase shader-clock breakdown and launch-shape sweeps."""
+"""GPU perf exploration: config-C learn launches with per-phase shader-clock breakdown and launch-shape sweeps.
+The phase stamps exist in -DFW_TICKS builds of kernels.hip only (both example kernels, round 5): `scripts/build_variant.sh ticks -DFW_TICKS`, then
+`FWGPU_LIBRARY=build/variants/libfwgpu_ticks.so python3 scripts/perf_probe.py`; with the shipped library the breakdown reads zero."""
 import sys, os, time, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
