@@ -1345,6 +1345,9 @@ __device__ __forceinline__ void update_rows(const KernelParams &p, const Lds &s,
 // device memory; with acc placed away from w (regressor.cpp place_ffm_acc) the float-granular accesses of the same code path
 // (sb = 0, nb = 4R: exactly the row) are as fast, and the race stays at the float.  The duplicate-row chains below are what
 // this path keeps in both cases.
+#ifndef FW_THIN_OVERFLOW  // 1: store policy 3 also on the re-read (overflow) rows of the single-chunk instantiations -- config C's; not measured yet
+#define FW_THIN_OVERFLOW 0
+#endif
 template <int OPT, int AUX, int U, int NCH, int AUX_SW = AUX, int AUX_SA = AUX>
 __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds &s, const uint32_t (&idx)[U], float g,
                                                 int lane, uint32_t nf, const float *gpair = nullptr, uint32_t thin_seed = 0xffffffffu) {
@@ -1435,7 +1438,7 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
             // what this example added (av + m (an - av): unbiased; the step above was taken with the true running accumulator) -- the kept rows' rule of the config-C
             // kernel, for rows that are re-read: the window between this load and this store is one round trip.
             uint32_t acc_bytes = nb[u];
-            if (NCH > 1 && OPT != FWGPU_OPT_SGD && thin_seed != 0xffffffffu) {
+            if ((NCH > 1 || FW_THIN_OVERFLOW) && OPT != FWGPU_OPT_SGD && thin_seed != 0xffffffffu) {
                 const f4 a0 = av[u][c];
                 const bool hot = __ballot(inb && (a0[0] > p.acc_hot_theta || a0[1] > p.acc_hot_theta || a0[2] > p.acc_hot_theta || a0[3] > p.acc_hot_theta)) != 0ull;
                 if (hot) {
@@ -3306,7 +3309,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                     if (WIN && MAXR > 0 && i >= kb && i < kb + nk2 && !(s.e_fld[i] & kRowHasChain)) idx[u] = 0xffffffffu;
                 }
                 if (WIN)
-                    update_rows_win<OPT, AUX, UO, (NC > FW_WIN_NCH ? NC : FW_WIN_NCH), AUX_SW, AUX_SA>(p, s, idx, g, lane, nf, nullptr, (kThin && NC > 1 && p.store_policy == 3 && p.grid_wgs > 1 && p.thin_reread) ? ex : 0xffffffffu);
+                    update_rows_win<OPT, AUX, UO, (NC > FW_WIN_NCH ? NC : FW_WIN_NCH), AUX_SW, AUX_SA>(p, s, idx, g, lane, nf, nullptr, (kThin && (NC > 1 || FW_THIN_OVERFLOW) && p.store_policy == 3 && p.grid_wgs > 1 && p.thin_reread) ? ex : 0xffffffffu);
                 else
                     update_rows<VEC, OPT, AUX, UO, false, NC>(p, s, idx, g, lane);
             }
