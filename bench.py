@@ -55,6 +55,30 @@ def build_model_instance(fw, args, device):
         nn_topology="one", nn_learning_rate=NN_LR, nn_power_t=NN_POWER_T, nn_init_acc_gradient=NN_INIT_ACC)
 
 
+# The second stream family at config C's size (tests/test_zz_gpu_hogwild_quality.py's `zipf13_noise` recipe): another teacher
+# (the teacher's scores and the ids' streams both derive from the seed), a heavier head (Zipf 1.3: the hot rows are hotter), 5 % of the labels flipped
+# (a loss floor well above the teacher's entropy).  `--family 2`; oracle curves: tests/golden/bench_oracle_curve_fam2_*.json.
+FAMILY2 = {"seed": 4242, "zipf": 1.3, "label_flip": 0.05}
+
+
+def apply_family(args, family):
+    if family == 2:
+        for k_, v_ in FAMILY2.items():
+            setattr(args, k_, v_)
+
+
+def _flip_mask(seed, first, n, frac):
+    """label noise that does not depend on how the stream is cut into chunks: example number e is flipped iff splitmix64(seed, e) < frac * 2^64"""
+    with np.errstate(over="ignore"):
+        x = (np.arange(first, first + n, dtype=np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed) * np.uint64(0xD1342543DE82EF95)
+        x ^= x >> np.uint64(30)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27)
+        x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    return (x >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53)) < frac
+
+
 def gen_records(fw, args, first, n, threads=8):
     """Synthetic stream [first, first+n) in chunks on a thread pool (ctypes releases the GIL)."""
     chunk = 2048
@@ -71,7 +95,13 @@ def gen_records(fw, args, first, n, threads=8):
     for r, o in parts:
         offs.append(o[1:] + np.uint64(base))
         base += len(r)
-    return recs, np.concatenate(offs)
+    off = np.concatenate(offs)
+    flip = getattr(args, "label_flip", 0.0)
+    if flip:  # record word 1 = the label (parser.rs:57-60): 1 <-> 0
+        idx = off[:-1].astype(np.int64) + 1
+        f = _flip_mask(args.seed, first, n, flip)
+        recs[idx[f]] = 1 - recs[idx[f]]
+    return recs, off
 
 
 def algorithmic_bytes(args, batch, n_words):
@@ -116,9 +146,10 @@ def oracle_reference_curves(args, world, holdout=None):
         c = dict(d["config"])
         c.pop("holdout")
         c.setdefault("nn_layers", 0)
+        c.setdefault("label_flip", 0.0)
         if not c["nn_layers"]:
             c.pop("nn_width", None)
-        same = all(getattr(args, k) == v for k, v in c.items()) and d["hyper"] == {"lr": getattr(args, "lr", LR), "power_t": getattr(args, "power_t", POWER_T), "init_acc": INIT_ACC}
+        same = all(getattr(args, k, 0.0 if k == "label_flip" else None) == v for k, v in c.items()) and d["hyper"] == {"lr": getattr(args, "lr", LR), "power_t": getattr(args, "power_t", POWER_T), "init_acc": INIT_ACC}
         if not same:
             continue
         curve = dict(zip(d["examples"], d[key]))
@@ -503,6 +534,9 @@ def main():
     ap.add_argument("--ids", type=int, default=10_000_000)
     ap.add_argument("--p-weighted", dest="p_weighted", type=float, default=0.1)
     ap.add_argument("--seed", type=int, default=20240612)
+    ap.add_argument("--label-flip", dest="label_flip", type=float, default=0.0, help="fraction of the labels flipped (label noise; chunk-invariant)")
+    ap.add_argument("--family", type=int, default=1, choices=[1, 2],
+                    help="2: the second stream family at config C's size (another teacher seed, Zipf 1.3 ids, 5 %% label flips: FAMILY2)")
     ap.add_argument("--holdout", type=int, default=262144,
                     help="hold-out examples of the stream's tail, predicted and never learned (main.rs:238-241); 262 144: standard error of the mean log-loss ~0.0005. "
                          "(8192 = rounds 1-4's yardstick, the first 8192 of the same tail)")
@@ -567,10 +601,11 @@ def main():
                          "the line carries final_logloss per pass, the spread and the CPU oracle's values (sequential and 16-thread hogwild) on the same stream")
     ap.add_argument("--long-steps", dest="long_steps", type=int, default=256)
     ap.add_argument("--long-passes", dest="long_passes", type=int, default=3)
-    ap.add_argument("--store-policy", dest="store_policy", type=int, default=None, choices=[0, 1, 2, 3], help="A/B: FFM row store policy (kernels.hip top); default = the build's")
+    ap.add_argument("--store-policy", dest="store_policy", type=int, default=None, choices=[0, 1, 2, 3, 4], help="A/B: FFM row store policy (kernels.hip top); default = the build's")
     ap.add_argument("--launch-timeout", dest="launch_timeout", type=float, default=1500.0,
                     help="self-launched N>1 run (no WORLD_SIZE in the environment): seconds after which the parent ends its ranks and exits non-zero")
     args = ap.parse_args()
+    apply_family(args, args.family)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python3 bench.py --gpus N` as the driver types it for N = 1, with nothing else set: be the launcher
         raise SystemExit(self_launch(args))

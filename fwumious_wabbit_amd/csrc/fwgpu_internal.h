@@ -241,6 +241,8 @@ struct LaunchConfig {
     int32_t no_chain = 0;            // debug option 3
     uint32_t hot_lr_every = 1;       // debug option 4: hot LR entry route (0 off, 1 atomics per example, n>1 weight deltas pending n examples)
     int32_t store_policy = -1;       // debug option 5: FFM row store policy of hogwild launches (-1: the build's default, kDefaultStorePolicy)
+    float acc_hot_theta = -1.0f;     // debug option 9: policies 3 / 4, a row is hot once its accumulators have grown by this much (-1: FWGPU_ACC_HOT_THETA or 0.5)
+    int32_t acc_sample_log2 = -1;    // debug option 10: policies 3 / 4, one example in 2^this touches a hot row's accumulators (-1: FWGPU_ACC_SAMPLE_LOG2 or 3)
     int32_t wb_flush_every = -1;     // debug option 6: write-back interval of policies 1 / 2 in examples per workgroup (-1: default, 0: never)
     int32_t lds_keep = -1;           // debug option 8: rows per wave kept in LDS beyond the register-kept ones (-1: as many as leave two workgroups per CU)
     int32_t prefetch = 1;            // debug option 7: next-record prefetch of the v2 kernel (A/B runs)

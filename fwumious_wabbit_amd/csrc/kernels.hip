@@ -44,6 +44,12 @@
 //      its accumulator row for one example in 2^acc_sample_log2 only (a hash of the example's ticket and the row's slot decides), with 2^acc_sample_log2 times
 //      the example's g^2: the expectation of what reaches memory is what write-through sends, one coherent copy (policy 2's trouble is eight private ones),
 //      an m-th of the requests on exactly the lines that queue.  The STEP of every example still uses acc_read + its own g^2.
+//   4  (round 6) policy 3 with the thinned store replaced by a thinned ATOMIC ADD: the one example in m = 2^acc_sample_log2 whose turn it is adds m x its g^2 to the
+//      accumulator row with fire-and-forget device-scope float atomics (buffer_atomic_add_f32 ... sc1, four per lane), everybody else issues nothing.  A thinned
+//      STORE writes acc_read + m g^2: when it loses its race against another example's store, m examples' worth of g^2 are gone (tests/test_gpu_conservation.py:
+//      hot rows kept 0.15-0.29 of their true sum under policies 0, 1 and 3 alike).  An add cannot lose: what reaches memory is an unbiased estimate of the TRUE sum
+//      of g^2 over all concurrent examples -- what the reference's hogwild threads count (hogwild.rs:89-103: `acc += g*g` on coherent memory, optimizer.rs:147-149)
+//      -- at an m-th of the requests.  It applies to every row of a wave (kept in registers, parked in LDS, re-read), since there is no race to lose.
 // A write-back line is visible to the other seven XCDs when it leaves this XCD's L2.  Cold lines leave within microseconds (an XCD's 4 MB L2 turns
 // over every ~16 us at this kernel's write rate); a line that is re-touched before it is evicted -- the head rows of a Zipf field -- would stay
 // dirty for the whole launch, each XCD stepping a private copy.  KernelParams::wb_flush_every bounds that window: every that many examples a
@@ -1438,16 +1444,29 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
             // what this example added (av + m (an - av): unbiased; the step above was taken with the true running accumulator) -- the kept rows' rule of the config-C
             // kernel, for rows that are re-read: the window between this load and this store is one round trip.
             uint32_t acc_bytes = nb[u];
-            if ((NCH > 1 || FW_THIN_OVERFLOW) && OPT != FWGPU_OPT_SGD && thin_seed != 0xffffffffu) {
+            if (OPT != FWGPU_OPT_SGD && thin_seed != 0xffffffffu) {  // (the caller passes a seed only where the instantiation thins: two-chunk rows, FW_THIN_OVERFLOW builds, policy 4)
                 const f4 a0 = av[u][c];
                 const bool hot = __ballot(inb && (a0[0] > p.acc_hot_theta || a0[1] > p.acc_hot_theta || a0[2] > p.acc_hot_theta || a0[3] > p.acc_hot_theta)) != 0ull;
                 if (hot) {
                     const uint32_t m = 1u << p.acc_sample_log2;
                     const uint32_t draw = ((thin_seed * 2654435761u) ^ (idx[u] * 40503u + (uint32_t)c * 9973u)) >> 9;
-                    if ((draw & (m - 1u)) != 0u) acc_bytes = 0;  // (not this example's turn: the store is dropped)
-                    const float ms = (float)(m - 1u);
+                    const bool turn = (draw & (m - 1u)) == 0u;
+                    if (p.store_policy == 4) {
+                        // policy 4: the example whose turn it is ADDS m x what it (and its chained duplicates) added; nobody stores.  Lanes outside the row add 0.
+                        acc_bytes = 0;
+                        if (turn) {
+                            const float mf = (float)m;
+                            const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.ffm_acc + fl, nb[u]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) an[j] = an[j] + ms * (an[j] - a0[j]);
+                            for (int j = 0; j < 4; ++j)
+                                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(mf * (an[j] - a0[j]), ra, c * 1024 + lane * 16 + 4 * j, 0, kAuxSc1);
+                        }
+                    } else {
+                        if (!turn) acc_bytes = 0;  // (not this example's turn: the store is dropped)
+                        const float ms = (float)(m - 1u);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) an[j] = an[j] + ms * (an[j] - a0[j]);
+                    }
                 }
             }
             if (OPT != FWGPU_OPT_SGD) Vec<4>::template store<AUX_SA>(an, make_rsrc(p.ffm_acc + fl, acc_bytes), c * 1024 + lane * 16);
@@ -2677,8 +2696,9 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
     // (nt on the device-scope LOADS was measured and rejected: gather -2 %, accumulator loads -4 %, profiles/r04_nt_loads_and_flush256_ab.txt)
     constexpr int AUX_G = AUX, AUX_LA = AUX;
     constexpr int AUX_SW = (COH && POL < 1) ? kAuxSc1 : (COH ? FW_WB_AUX_W : kAuxPlain);  // weight-row stores (store policy: top of this file; 3 = 1 here)
-    constexpr int AUX_SA = (COH && (POL < 2 || POL == 3)) ? kAuxSc1 : (COH ? FW_WB_AUX_A : kAuxPlain);  // accumulator-row stores
-    constexpr bool kThin = COH && POL == 3;  // thinned accumulator stores on hot rows (store policy 3)
+    constexpr int AUX_SA = (COH && (POL < 2 || POL >= 3)) ? kAuxSc1 : (COH ? FW_WB_AUX_A : kAuxPlain);  // accumulator-row stores
+    constexpr bool kThin = COH && POL >= 3;  // thinned accumulator traffic on hot rows (store policies 3 and 4)
+    constexpr bool kAtom = COH && POL == 4;  // ... as atomic adds of m g^2 (policy 4) instead of stores of acc_read + m g^2 (policy 3)
     constexpr int UA = (WIN && NC == 1) ? FW_UA_WIN : FW_UA;  // accumulator rows in flight per wave in the update phase
     constexpr int UG = (WIN && NC == 1) ? FW_UG_WIN : FW_UG;  // overflow rows in flight per wave in the gather
     constexpr int UO = FW_UO;  // overflow rows (w + acc) in flight per wave
@@ -3215,14 +3235,17 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                     V a_cur = av[sl];
                     // store policy 3: is this a hot row (wave-uniform: any lane's accumulator beyond theta), and is this example the one in m that stores it?
                     float g2_scale = 0.0f;
-                    bool acc_store = ok0;
-                    if (kThin && sl < MAXR && p.grid_wgs > 1) {  // (rows kept in registers only: a thinned store on a row parked in LDS -- stepped last, behind the longest window -- loses its race more often, tests/test_gpu_conservation.py)
+                    bool acc_store = ok0, acc_add = false, hot_row = false;
+                    if (kThin && (kAtom || sl < MAXR) && p.grid_wgs > 1) {  // (policy 3: rows kept in registers only: a thinned STORE on a row parked in LDS -- stepped last, behind the longest window -- loses its race more often, tests/test_gpu_conservation.py; an atomic add has no race to lose)
                         const bool hot = __ballot(a_cur[0] > p.acc_hot_theta || a_cur[1] > p.acc_hot_theta || a_cur[2] > p.acc_hot_theta || a_cur[3] > p.acc_hot_theta) != 0ull;
                         if (hot) {
                             const uint32_t m = 1u << p.acc_sample_log2;
                             const uint32_t draw = ((ex * 2654435761u) ^ ((kb_u + (uint32_t)sl) * 40503u + (uint32_t)wave * 9973u)) >> 9;
-                            acc_store = ok0 && (draw & (m - 1u)) == 0u;
-                            g2_scale = (float)(m - 1u);
+                            const bool turn = ok0 && (draw & (m - 1u)) == 0u;
+                            acc_store = kAtom ? false : turn;
+                            acc_add = kAtom && turn;
+                            g2_scale = kAtom ? (float)m : (float)(m - 1u);
+                            hot_row = true;
                         }
                     }
                     const float v = s.e_val[kb_u + (uint32_t)sl];
@@ -3244,11 +3267,18 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                         const float grad = __fmul_rn(g, G);
                         float acc = a_cur[j];
                         const float upd = opt_step<OPT>(grad, acc, p.ffm_rate, p.ffm_minus_power_t, s.lut);
-                        a_cur[j] = kThin ? acc + g2_scale * (grad * grad) : acc;  // (what is STORED for a thinned row: m x this example's g^2 on top of what it read)
+                        // (what is STORED for a thinned row: m x this example's g^2 on top of what it read; policy 4: what is ADDED to a hot row, m x this example's g^2)
+                        a_cur[j] = kAtom ? (hot_row ? g2_scale * (grad * grad) : acc) : (kThin ? acc + g2_scale * (grad * grad) : acc);
                         wv[j] = wv[j] - upd;  // block_ffm.rs:282
                     }
                     Vec<VEC>::template store<AUX_SW>(wv, make_rsrc(p.ffm_w + h0, ok0 ? R * 4 : 0), e0 * 4);
                     if (OPT != FWGPU_OPT_SGD) Vec<VEC>::template store<AUX_SA>(a_cur, make_rsrc(p.ffm_acc + h0, (kThin ? acc_store : ok0) ? R * 4 : 0), e0 * 4);
+                    if (kAtom && OPT != FWGPU_OPT_SGD) {
+                        // fire-and-forget (no return value: nothing waits for them); a row that is not hot, or not this example's turn, adds through a zero-length descriptor: dropped
+                        const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.ffm_acc + h0, acc_add ? R * 4 : 0);
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(a_cur[j], ra, (int)(e0 * 4 + 4 * j), 0, kAuxSc1);
+                    }
                 }
             } else
 #pragma unroll
@@ -3309,7 +3339,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                     if (WIN && MAXR > 0 && i >= kb && i < kb + nk2 && !(s.e_fld[i] & kRowHasChain)) idx[u] = 0xffffffffu;
                 }
                 if (WIN)
-                    update_rows_win<OPT, AUX, UO, (NC > FW_WIN_NCH ? NC : FW_WIN_NCH), AUX_SW, AUX_SA>(p, s, idx, g, lane, nf, nullptr, (kThin && (NC > 1 || FW_THIN_OVERFLOW) && p.store_policy == 3 && p.grid_wgs > 1 && p.thin_reread) ? ex : 0xffffffffu);
+                    update_rows_win<OPT, AUX, UO, (NC > FW_WIN_NCH ? NC : FW_WIN_NCH), AUX_SW, AUX_SA>(p, s, idx, g, lane, nf, nullptr, (kThin && (NC > 1 || FW_THIN_OVERFLOW || kAtom) && p.store_policy >= 3 && p.grid_wgs > 1 && p.thin_reread) ? ex : 0xffffffffu);
                 else
                     update_rows<VEC, OPT, AUX, UO, false, NC>(p, s, idx, g, lane);
             }
@@ -3383,6 +3413,7 @@ static hipError_t launch_r(const KernelParams &p, uint32_t grid, uint32_t thread
         if (COH && p.store_policy == 0) return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR_WIN, true, 1, COH ? 0 : FW_DEFAULT_STORE_POLICY>, p, grid, threads, lds, stream);
         if (COH && p.store_policy == 2) return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR_WIN, true, 1, COH ? 2 : FW_DEFAULT_STORE_POLICY>, p, grid, threads, lds, stream);
         if (COH && p.store_policy == 3) return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR_WIN, true, 1, COH ? 3 : FW_DEFAULT_STORE_POLICY>, p, grid, threads, lds, stream);
+        if (COH && p.store_policy == 4) return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR_WIN, true, 1, COH ? 4 : FW_DEFAULT_STORE_POLICY>, p, grid, threads, lds, stream);
         return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR_WIN, true, 1, COH ? 1 : FW_DEFAULT_STORE_POLICY>, p, grid, threads, lds, stream);
     }
     return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR, false>, p, grid, threads, lds, stream);

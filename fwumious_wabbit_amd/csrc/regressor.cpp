@@ -396,8 +396,12 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
         static const char *env_pol = getenv("FWGPU_STORE_POLICY"), *env_wb = getenv("FWGPU_WB_FLUSH_EVERY"), *env_pf = getenv("FWGPU_PREFETCH");
         p.store_policy = r->launch.store_policy >= 0 ? r->launch.store_policy : (env_pol ? atoi(env_pol) : -1);
         static const char *env_th = getenv("FWGPU_ACC_HOT_THETA"), *env_sm = getenv("FWGPU_ACC_SAMPLE_LOG2");  // policy 3's two knobs (A/B runs)
-        p.acc_hot_theta = env_th ? (float)atof(env_th) : 0.5f;
-        p.acc_sample_log2 = env_sm ? (uint32_t)atoi(env_sm) : 3u;
+        // "hot" = the row has ACCUMULATED more than theta: measured from the accumulators' initial value (AdagradFlex starts them at ffm_init_acc_gradient,
+        // optimizer.rs:90-92; AdagradLUT at 0 with the initial value folded into its table, 158-161), so a row is never hot before it has been stepped
+        const float theta = r->launch.acc_hot_theta >= 0.0f ? r->launch.acc_hot_theta : (env_th ? (float)atof(env_th) : 0.5f);
+        p.acc_hot_theta = theta + initial_acc(r->cfg.optimizer, r->cfg.ffm_init_acc_gradient);
+        const int sm = r->launch.acc_sample_log2 >= 0 ? r->launch.acc_sample_log2 : (env_sm ? atoi(env_sm) : 3);
+        p.acc_sample_log2 = (uint32_t)std::min(std::max(sm, 0), 6);  // (1u << it in the kernels: one example in 1 .. 64)
         static const char *env_tr = getenv("FWGPU_THIN_REREAD");
         p.thin_reread = env_tr ? atoi(env_tr) : 1;
         p.wb_flush_every = r->launch.wb_flush_every >= 0 ? (uint32_t)r->launch.wb_flush_every : (env_wb ? (uint32_t)atoi(env_wb) : 0xffffffffu);
@@ -922,8 +926,16 @@ int fwgpu_debug_set_option(fwgpu_regressor *r, int option, int value) {
         r->launch.hot_lr_every = (uint32_t)value;
         return FWGPU_OK;
     case 5:  // FFM row store policy of hogwild launches: 0 write-through, 1 weights write-back, 2 both tables write-back, -1 the build's default
-        if (value < -1 || value > 3) return fail(FWGPU_ERR_INVALID, "store policy option: -1, 0, 1, 2 or 3");
+        if (value < -1 || value > 4) return fail(FWGPU_ERR_INVALID, "store policy option: -1, 0, 1, 2, 3 or 4");
         r->launch.store_policy = value;
+        return FWGPU_OK;
+    case 9:  // policies 3 / 4: a row counts as hot when its accumulators have grown by more than value / 1024 (-1: the default, 0.5)
+        if (value < -1 || value > (1 << 24)) return fail(FWGPU_ERR_INVALID, "hot-row threshold option: -1, or 0 .. 2^24 (in 1/1024)");
+        r->launch.acc_hot_theta = value < 0 ? -1.0f : (float)value / 1024.0f;
+        return FWGPU_OK;
+    case 10:  // policies 3 / 4: one example in 2^value touches a hot row's accumulators (-1: the default, 3)
+        if (value < -1 || value > 6) return fail(FWGPU_ERR_INVALID, "accumulator sampling option: -1, or 0 .. 6");
+        r->launch.acc_sample_log2 = value;
         return FWGPU_OK;
     case 6:  // write-back interval of policies 1 / 2: a workgroup issues buffer_wbl2 every `value` of its examples (0 never, -1 the build's default)
         if (value < -1 || value > 65536) return fail(FWGPU_ERR_INVALID, "write-back interval option: -1 .. 65536 examples");

@@ -392,10 +392,17 @@ class Regressor:
     def set_store_policy(self, policy, flush_every=-1):
         """HOGWILD launches of the large-table update path (fwgpu_debug_set_option 5 / 6): how FFM row stores reach memory -- 0 both
         tables device-scope write-through, 1 weight rows write-back through the XCD's L2, 2 both tables write-back, 3 (the default) = 1 with thinned accumulator stores on hot kept rows,
+        4 = 3 with the thinned store replaced by a thinned atomic add of m g^2 on every hot row (lossless in expectation),
         -1 the build's default; with 1 / 2 a workgroup writes its XCD's dirty L2 lines back every `flush_every` of its examples (0 = only when the
         launch ends, -1 = the build's default).  kernels.hip "store policy", tests/test_gpu_conservation.py"""
         check(self.L.fwgpu_debug_set_option(self.h, 5, int(policy)))
         check(self.L.fwgpu_debug_set_option(self.h, 6, int(flush_every)))
+
+    def set_hot_row_sampling(self, theta=-1.0, sample_log2=-1):
+        """store policies 3 / 4 (fwgpu_debug_set_option 9 / 10): a row is hot once its accumulators have grown by more than `theta` (default 0.5;
+        resolution 1/1024); one example in 2^sample_log2 (default 3) then touches its accumulator row, with that many times its g^2"""
+        check(self.L.fwgpu_debug_set_option(self.h, 9, -1 if theta < 0 else int(round(theta * 1024))))
+        check(self.L.fwgpu_debug_set_option(self.h, 10, int(sample_log2)))
 
     def set_prefetch(self, on):
         """updating launches copy the next example's record to LDS during the current example (fwgpu_debug_set_option 7; default on)"""

@@ -449,7 +449,10 @@ int fwgpu_debug_set_kernel_version(fwgpu_regressor *r, int version);
  *   SEQUENTIAL launches never use it.
  * option 5: store policy of the FFM row stores in HOGWILD launches of that update path: 0 = both tables device-scope write-through,
  *   1 = weight rows write-back through the XCD's L2, 2 = both tables write-back, 3 (the default since round 5) = 1 with thinned accumulator stores on hot
- *   register-kept rows (one example in eight stores eight times its g^2: DESIGN 4.2); -1 = the build's default.  option 6: with
+ *   register-kept rows (one example in eight stores eight times its g^2: DESIGN 4.2), 4 = 3 with the thinned store replaced by a thinned device-scope
+ *   atomic add (one example in eight adds eight times its g^2, on every hot row of the example: nothing is lost to a concurrent writer); -1 = the build's
+ *   default.  option 9: policies 3 / 4 call a row hot once its accumulators have grown by more than value / 1024 (-1 = default: 0.5); option 10: one example in
+ *   2^value touches a hot row's accumulators (0..6; -1 = default: 3).  option 6: with
  *   policy 1 / 2 a workgroup writes its XCD's dirty L2 lines back every `value` of its examples (0 = only when the launch ends; -1 = the
  *   build's default: 128) -- the bound on how long a popular row can stay private to one XCD (DESIGN.md 4.2,
  *   tests/test_gpu_conservation.py).  SEQUENTIAL launches are exact under every policy.

@@ -114,12 +114,15 @@ class Rig:
     def close(self):
         self.re.close()
 
-    def run(self, n, hot_field, policy, flush_every, mode=capi.MODE_HOGWILD, seed=5, lds_keep=-1):
-        """one launch of n crafted examples; per hot row (mean, min, max surviving fraction over the row's floats, share of examples)"""
+    def run(self, n, hot_field, policy, flush_every, mode=capi.MODE_HOGWILD, seed=5, lds_keep=-1, acc_start=None):
+        """one launch of n crafted examples; per hot row (mean, min, max surviving fraction over the row's floats, share of examples).
+        `acc_start`: the accumulators' value before the launch (default: the optimizer's initial value) -- above the hot-row threshold of
+        policies 3 / 4 the rig's rows are hot from the first example on"""
         re = self.re
         re.set_store_policy(policy, flush_every)
         re.set_lds_keep(lds_keep)  # (-1: the shipped choice; 0: rows beyond the register-kept ones are re-read by the update)
-        re.table_fill(capi.TABLE_FFM_ACC, self.acc0)
+        acc0 = self.acc0 if acc_start is None else float(acc_start)
+        re.table_fill(capi.TABLE_FFM_ACC, acc0)
         for hh in _hot_hashes():
             re.table_write(capi.TABLE_FFM_W, np.full(R, W_HOT0, dtype=np.float32), hh)
         recs, off, which = _records(n, hot_field, self.ffm_bits, seed)
@@ -140,7 +143,7 @@ class Rig:
                 frac = (w[sel] - W_HOT0) / (-self.lr * G_CONST * ge.sum())
             else:
                 a = re.table_read(capi.TABLE_FFM_ACC, hh, R).astype(np.float64)
-                frac = (a[sel] - self.acc0) / ((ge * G_CONST) ** 2).sum()
+                frac = (a[sel] - acc0) / ((ge * G_CONST) ** 2).sum()
             out.append((float(np.mean(frac)), float(np.min(frac)), float(np.max(frac)), float(len(ge)) / n))
         # the partners never moved: spot-check a row
         assert np.all(re.table_read(capi.TABLE_FFM_W, 20000, 64) == W_PARTNER)
@@ -151,7 +154,7 @@ def test_in_order_launch_applies_every_step_under_every_policy():
     """SEQUENTIAL launches are exact whatever the store policy: all steps arrive (fraction 1 up to f32 summation order)."""
     for opt in (fw.Optimizer.SGD, fw.Optimizer.AdagradLUT):
         rig = Rig(opt, 18)
-        for policy in (0, 1, 2):
+        for policy in (0, 1, 2, 3, 4):
             for mean, lo, hi, share in rig.run(600, 29, policy, 4, mode=capi.MODE_SEQUENTIAL, seed=3):
                 assert abs(lo - 1.0) < 2e-3 and abs(hi - 1.0) < 2e-3, (opt, policy, lo, hi)
         rig.close()
@@ -160,7 +163,7 @@ def test_in_order_launch_applies_every_step_under_every_policy():
 # (policy, write-back interval): (-1, -1) = what the build ships (round 5: policy 3 = policy 1 with thinned accumulator stores on hot register-kept rows; policy 1: weight rows write-back, accumulators write-through; one buffer_wbl2 per
 # workgroup every 128 examples); the asserts are about it, the others are measured next to it and printed
 SHIPPED = (-1, -1)
-MEASURED = [(0, 0), (1, 0), (2, 0), (2, 64), (3, 0)]  # (3: round 5, thinned accumulator stores on hot rows)
+MEASURED = [(0, 0), (1, 0), (2, 0), (2, 64), (3, 0), (4, 0)]  # (3: round 5, thinned accumulator stores on hot rows; 4: round 6, thinned atomic adds)
 REREAD = "-1,-1 L0"
 
 # Measured on MI355X (profiles/r04c_conservation.txt, r04b_conservation.txt; rows in a third of all examples, ~170 concurrent holders):
@@ -212,3 +215,31 @@ def test_hot_ffm_rows_keep_a_bounded_share_of_their_steps(opt, ffm_bits, capsys)
     # ... and nothing may get worse with the LENGTH of the launch (a row that stays private to an XCD until the launch ends would)
     for hot_field in (0, 29):
         assert table[(65536, hot_field, SHIPPED)] >= 0.5 * table[(2048, hot_field, SHIPPED)], table
+
+
+@pytest.mark.parametrize("ffm_bits", [18, 28])
+def test_thinned_atomic_adds_count_every_gradient_on_hot_rows(ffm_bits, capsys):
+    """Store policy 4 (round 6): on a row that is hot -- its accumulators beyond the threshold -- one example in eight ADDS eight times its g^2 with
+    device-scope float atomics and nobody stores.  An add cannot lose a race, so what reaches memory is an unbiased estimate of the TRUE sum of g^2 over
+    all concurrent examples, which is what the reference's hogwild threads count (`acc += g * g` on coherent memory, optimizer.rs:147-149) -- where the
+    store policies keep 0.15-0.45 of it (the table of the test above).  The rows start hot (accumulators at 2.0: beyond the default threshold of 0.5)."""
+    rig = Rig(fw.Optimizer.AdagradLUT, ffm_bits)
+    table = {}
+    sizes = (2048, 16384, 65536)
+    for n in sizes:
+        for hot_field in (0, 29):
+            for pol in (3, 4):
+                table[(n, hot_field, pol)] = float(np.mean([f[0] for f in rig.run(n, hot_field, pol, 0, acc_start=2.0)]))
+            table[(n, hot_field, "4 L0")] = float(np.mean([f[0] for f in rig.run(n, hot_field, 4, 0, acc_start=2.0, lds_keep=0)]))
+    rig.close()
+    with capsys.disabled():
+        print(f"\nshare of the true sum of g^2 that reaches a HOT row's accumulators, adagrad, {ffm_bits}-bit table (rows hot from the start)")
+        print("  launch  hot_field  policy 3  policy 4  policy 4, nothing parked in LDS")
+        for n in sizes:
+            for hot_field in (0, 29):
+                print(f"  {n:6d}  {hot_field:9d} {table[(n, hot_field, 3)]:9.4f} {table[(n, hot_field, 4)]:9.4f} {table[(n, hot_field, '4 L0')]:9.4f}")
+    for n in sizes:
+        tol = 0.1 if n > 2048 else 0.3  # (one example in eight is drawn: ~85 draws per row in the 2048-example launch)
+        for hot_field in (0, 29):
+            for key in (4, "4 L0"):
+                assert abs(table[(n, hot_field, key)] - 1.0) <= tol, (n, hot_field, key, table[(n, hot_field, key)])
