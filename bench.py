@@ -987,7 +987,7 @@ def main():
                 "global_batch": B * world,
                 "mode": ("synchronous micro-batches (every example sees the batch-start weights; FWD / MID / head on MFMA / UPD kernels)" if sync_steps
                          else "hogwild (device-wide concurrent examples, racy RMW; device-scope loads and accumulator stores, weight rows stored write-back through L2; store policy "
-                              + (str(args.store_policy) if args.store_policy is not None else "3 (thinned accumulator stores on hot kept rows)") + ")"),
+                              + (str(args.store_policy) if args.store_policy is not None else "4 (hot rows' accumulators: one example in eight adds eight times its g^2 with device-scope float atomics instead of every example storing the row)") + ")"),
                 "parallelism": ("1 GPU" if not use_dist else
                                 f"dp{world} peer: tables sharded by owner, every rank's fused hogwild kernel reaches each row in its owner's memory (IPC-mapped tables over xGMI), "
                                 f"no collective per step, {world} x {B} examples per step" if peer_main else
@@ -1022,7 +1022,7 @@ def main():
                 "traffic_source": traffic_src,
                 "pattern_ceiling_note": "profiles/r02_rowceil.txt (tools/rowceil.hip): read w+acc rows and write both back as whole lines = 0.62 of the 8 TB/s peak; this kernel on UNIFORM ids "
                                         "(every access a miss of every cache): 0.64 (profiles/r05_skew_sweep.txt) -- what is lost on the bench's Zipf stream is write-through serialisation on "
-                                        "hot accumulator lines (L2 tag stalls 6.4x, profiles/r05_skew_pmc_counters.txt), which store policy 3 thins",
+                                        "hot accumulator lines (L2 tag stalls 6.4x, profiles/r05_skew_pmc_counters.txt), which store policies 3 / 4 thin",
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": avg_kernel_ms,
                 "launch_ms_min_median_max": [float(np.min(kernel_ms)), float(np.median(kernel_ms)), float(np.max(kernel_ms))],

@@ -38,13 +38,13 @@
 //   0  both tables device-scope write-through (buffer_store ... sc1): every 64 B request goes to the memory side and is acknowledged from there;
 //   1  WEIGHT rows write-back through the XCD's L2, accumulators write-through (round 3's shipped build: +9.5 % examples/s);
 //   2  BOTH tables write-back (the fastest: 0.555-0.56 of the HBM peak, profiles/r04b_policy_ab.txt).
-//   3  (round 5, experimental) policy 1 with THINNED accumulator stores on hot rows.  What skew costs under policy 1 is the write-through of the accumulator
+//   3  (round 5's shipped policy) policy 1 with THINNED accumulator stores on hot rows.  What skew costs under policy 1 is the write-through of the accumulator
 //      lines that many concurrent examples hold (profiles/r05_skew_x_store_policy.txt: uniform ids 0.639 of the peak under policies 1 and 2 alike; Zipf 1.3:
 //      0.547 against 0.659; L2 tag stalls 6.4x, profiles/r05_skew_pmc_counters.txt).  A kept row whose accumulators exceed KernelParams::acc_hot_theta stores
 //      its accumulator row for one example in 2^acc_sample_log2 only (a hash of the example's ticket and the row's slot decides), with 2^acc_sample_log2 times
 //      the example's g^2: the expectation of what reaches memory is what write-through sends, one coherent copy (policy 2's trouble is eight private ones),
 //      an m-th of the requests on exactly the lines that queue.  The STEP of every example still uses acc_read + its own g^2.
-//   4  (round 6) policy 3 with the thinned store replaced by a thinned ATOMIC ADD: the one example in m = 2^acc_sample_log2 whose turn it is adds m x its g^2 to the
+//   4  (shipped since round 6) policy 3 with the thinned store replaced by a thinned ATOMIC ADD: the one example in m = 2^acc_sample_log2 whose turn it is adds m x its g^2 to the
 //      accumulator row with fire-and-forget device-scope float atomics (buffer_atomic_add_f32 ... sc1, four per lane), everybody else issues nothing.  A thinned
 //      STORE writes acc_read + m g^2: when it loses its race against another example's store, m examples' worth of g^2 are gone (tests/test_gpu_conservation.py:
 //      hot rows kept 0.15-0.29 of their true sum under policies 0, 1 and 3 alike).  An add cannot lose: what reaches memory is an unbiased estimate of the TRUE sum
@@ -58,7 +58,7 @@
 // the L2 or, for lines another XCD has written through, by the memory side).
 // In-order launches (one workgroup = one XCD) are exact under every policy; the launch's end writes everything back.
 #ifndef FW_DEFAULT_STORE_POLICY
-#define FW_DEFAULT_STORE_POLICY 3
+#define FW_DEFAULT_STORE_POLICY 4
 #endif
 #ifndef FW_DEFAULT_WB_FLUSH_EVERY
 #define FW_DEFAULT_WB_FLUSH_EVERY 128
@@ -2638,6 +2638,9 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #ifndef FW_PIPE_UPD
 #define FW_PIPE_UPD 1
 #endif
+#ifndef FW_ATOM_COALESCED  // store policy 4: the thinned adds in a layout of their own (256 contiguous bytes per instruction), behind a wave-uniform branch
+#define FW_ATOM_COALESCED 1
+#endif
 // Rows of a wave's range BEYOND the FW_MAXR_WIN register-kept ones whose gather-time w is parked in LDS (Lds::keep) instead of being re-read by the
 // update phase: at most this many per wave; the host grants as many as leave two workgroups on a CU (regressor.cpp prepare_launch, KernelParams::lds_keep).
 // Config C: 55 KB + 3 x 7.7 KB per workgroup -> 3 rows, 23 of ~25 rows per wave written back as w_gather - step; +0.7 % examples/s and 0.002 of hold-out
@@ -3222,6 +3225,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                     slot(j, h, f, ok);
                     av[j] = OPT != FWGPU_OPT_SGD ? Vec<VEC>::template load<AUX_LA>(make_rsrc(p.ffm_acc + h, ok ? R * 4 : 0), e0 * 4) : Vec<VEC>::zero();
                 };
+                uint32_t add_mask = 0;  // policy 4: the slots whose hot row this example adds its (m-fold) g^2 to
 #pragma unroll
                 for (int sl = 0; sl < NS; ++sl) {
                     const int d_prev = sl < DMAX ? sl : DMAX, d_now = sl + 1 < DMAX ? sl + 1 : DMAX;
@@ -3267,17 +3271,50 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                         const float grad = __fmul_rn(g, G);
                         float acc = a_cur[j];
                         const float upd = opt_step<OPT>(grad, acc, p.ffm_rate, p.ffm_minus_power_t, s.lut);
-                        // (what is STORED for a thinned row: m x this example's g^2 on top of what it read; policy 4: what is ADDED to a hot row, m x this example's g^2)
-                        a_cur[j] = kAtom ? (hot_row ? g2_scale * (grad * grad) : acc) : (kThin ? acc + g2_scale * (grad * grad) : acc);
+                        // (what is STORED for a thinned row: m x this example's g^2 on top of what it read; policy 4, strided form: what is ADDED to a hot row, m x this example's g^2)
+                        a_cur[j] = kAtom ? ((!FW_ATOM_COALESCED && hot_row) ? g2_scale * (grad * grad) : acc) : (kThin ? acc + g2_scale * (grad * grad) : acc);
                         wv[j] = wv[j] - upd;  // block_ffm.rs:282
                     }
                     Vec<VEC>::template store<AUX_SW>(wv, make_rsrc(p.ffm_w + h0, ok0 ? R * 4 : 0), e0 * 4);
                     if (OPT != FWGPU_OPT_SGD) Vec<VEC>::template store<AUX_SA>(a_cur, make_rsrc(p.ffm_acc + h0, (kThin ? acc_store : ok0) ? R * 4 : 0), e0 * 4);
                     if (kAtom && OPT != FWGPU_OPT_SGD) {
+#if FW_ATOM_COALESCED
+                        add_mask |= (acc_add ? 1u : 0u) << sl;  // (the adds themselves: behind the loop, where no row is alive in registers any more)
+#else
                         // fire-and-forget (no return value: nothing waits for them); a row that is not hot, or not this example's turn, adds through a zero-length descriptor: dropped
                         const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.ffm_acc + h0, acc_add ? R * 4 : 0);
 #pragma unroll
                         for (int j = 0; j < VEC; ++j) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(a_cur[j], ra, (int)(e0 * 4 + 4 * j), 0, kAuxSc1);
+#endif
+                    }
+                }
+                if (kAtom && FW_ATOM_COALESCED && OPT != FWGPU_OPT_SGD) {
+                    // Store policy 4's adds: fire-and-forget (no return value: nothing waits for them) and COALESCED -- lane l adds to floats l, 64 + l, 128 + l,
+                    // 192 + l of the row, so one instruction covers 256 contiguous bytes = four 64-byte requests of 16 floats each (in the step's own layout, 4
+                    // consecutive floats per lane, an instruction touches sixteen 64-byte segments with 4 floats each: four times the requests at the memory
+                    // side; measured in round 6, profiles/r06_store_policy4_*.txt).  The gradient is formed again in that layout from what the step used: T and
+                    // the entry's own slot as the gather read it, both in LDS.  A plain loop over the few slots whose turn it is: no row is alive in registers here.
+                    uint32_t am = __builtin_amdgcn_readfirstlane(add_mask);
+                    const uint32_t ksh = p.k_log2;
+                    const float mf = (float)(1u << p.acc_sample_log2);
+                    while (am) {
+                        const uint32_t sl = (uint32_t)__builtin_ctz(am);
+                        am &= am - 1u;
+                        const uint32_t i = kb_u + sl;
+                        const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[i]);
+                        const uint32_t f = __builtin_amdgcn_readfirstlane(s.e_fld[i]) & kFldMask;
+                        const float v = s.e_val[i];
+                        const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.ffm_acc + h, R * 4);  // (floats beyond the row: dropped by the descriptor)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t e = (uint32_t)lane + 64u * (uint32_t)j;
+                            const uint32_t ec = e < R ? e : R - 1u;
+                            float t = s.T[f * R + ec];
+                            const float sw = s.selfw[i * k + (ec & (k - 1u))];
+                            t = ((ec >> ksh) == f) ? __fsub_rn(t, __fmul_rn(sw, v)) : t;  // contra - w*v  block_ffm.rs:238
+                            const float grad = __fmul_rn(g, __fmul_rn(v, t));
+                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(mf * (grad * grad), ra, (int)(e * 4u), 0, kAuxSc1);
+                        }
                     }
                 }
             } else
