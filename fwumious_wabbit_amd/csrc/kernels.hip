@@ -202,7 +202,9 @@ __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t
 __host__ __device__ inline uint32_t nn_lds_floats(const KernelParams &p) {
     if (!p.nn.n_layers) return 0;
     if (p.emit_x) return p.max_lr + 16;  // (the v2 kernel only forms the head's input: one product per LR entry)
-    return 2 * p.nn.X + 2 * p.nn.sum_width + p.nn.max_in + p.max_lr + p.nn.max_out + 1 + 16;
+    // (fg takes a layer's input gradient only for the first layer -- X floats; the later layers' land in place -- and the LR products of the forward pass
+    // are dead long before the unwinding writes it: one region for both)
+    return 2 * p.nn.X + 2 * p.nn.sum_width + (p.nn.X > p.max_lr ? p.nn.X : p.max_lr) + p.nn.max_out + 1 + 16;
 }
 
 // size of the open-addressing sets: power of two >= 2*n (load factor <= 0.5)
@@ -802,8 +804,8 @@ struct NnBuf {
     float *xg;   // [X]  d logit / d x : through the layers + (topology "one") the final neuron's direct part
     float *h;    // [sum_width] post-activation outputs of the hidden layers
     float *m;    // [sum_width] ReLU 0/1 masks, then the layers' output gradients
-    float *fg;   // [max_in] final neuron's input gradient / per-layer scratch
-    float *prod; // [max_lr] w*v of every LR entry
+    float *fg;   // [max(X, max_lr)] the final neuron's output gradient, then the first layer's input gradient (nn_backward) ...
+    float *prod; // ... and, before that, w*v of every LR entry (nn_forward): the same region
     uint32_t *act;  // [max_out + 1] indices of a layer's neurons with a nonzero output gradient, then their count (nn_layer_backward_vec)
 };
 __device__ __forceinline__ NnBuf nn_buf(const KernelParams &p, const Lds &s) {
@@ -813,8 +815,8 @@ __device__ __forceinline__ NnBuf nn_buf(const KernelParams &p, const Lds &s) {
     b.h = b.xg + p.nn.X;
     b.m = b.h + p.nn.sum_width;
     b.fg = b.m + p.nn.sum_width;
-    b.prod = b.fg + p.nn.max_in;
-    b.act = reinterpret_cast<uint32_t *>(b.prod + p.max_lr);
+    b.prod = b.fg;
+    b.act = reinterpret_cast<uint32_t *>(b.fg + (p.nn.X > p.max_lr ? p.nn.X : p.max_lr));
     return b;
 }
 template <bool COH>
@@ -842,6 +844,17 @@ __device__ __forceinline__ float nn_forward(const KernelParams &p, const Lds &s,
     const NnBuf b = nn_buf(p, s);
     const DevNN &n = p.nn;
     const uint32_t F = p.F, k = p.k, R = p.R, C = p.num_combos;
+#ifdef FW_TICKS  // sub-phase stamps of the head (slots 8..14 of fwgpu_debug_phase_ticks; -DFW_TICKS builds only)
+    unsigned long long nn_last = __builtin_amdgcn_s_memtime();
+#define FW_NN_TICK(slot)                                                   \
+    if (tid == 0 && p.ticks) {                                             \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();      \
+        atomicAdd(p.ticks + (slot), now_ - nn_last);                       \
+        nn_last = now_;                                                    \
+    }
+#else
+#define FW_NN_TICK(slot)
+#endif
     for (uint32_t i = tid; i < nl; i += bd) {
         b.prod[i] = lr_forward_weight<COH>(p, s, s.l_hash[i]) * s.l_val[i];
         if (i + 1 < nl && s.l_combo[i] > s.l_combo[i + 1]) s.ctr[14] = 1;  // (zeroed by the stage phase)
@@ -876,6 +889,11 @@ __device__ __forceinline__ float nn_forward(const KernelParams &p, const Lds &s,
         float dot = 0.0f;
         if (i != j) {
             for (uint32_t kk = 0; kk < k; ++kk) dot += s.T[i * R + j * k + kk] * s.T[j * R + i * k + kk];
+        } else if (p.no_selfw) {
+            // (launches that keep no LDS copy of the entries' own slots -- the v2 kernel's concurrent two-chunk launches: the diagonal as split_mid_kernel and
+            // the batched predict-only head form it: exactly 0 for a field of at most one feature, 0.5 (|field sum|^2 - sum of the features' own squares) otherwise)
+            for (uint32_t kk = 0; kk < k; ++kk) dot += s.T[i * R + i * k + kk] * s.T[i * R + i * k + kk];
+            dot = (s.fend[i] - s.fstart[i]) <= 1u ? 0.0f : 0.5f * (dot - s.dcf[i]);
         } else {
             // Diagonal in the reference's own form (block_ffm.rs:231-243): per feature, sum_k w * v * (contra - w * v).
             // A field with one feature gives EXACTLY 0 this way; "0.5 * (dot - dcf)" leaves a 1e-10 residue there and the
@@ -893,6 +911,7 @@ __device__ __forceinline__ float nn_forward(const KernelParams &p, const Lds &s,
         b.x[C + t] = dot;  // triangle (block_misc.rs:864-883): 2 * (0.5 * dot) off the diagonal
     }
     __syncthreads();
+    FW_NN_TICK(8);
     const float *in_vec = b.x;
     uint32_t hoff = 0;
     for (uint32_t l = 0; l < n.n_layers; ++l) {
@@ -908,11 +927,17 @@ __device__ __forceinline__ float nn_forward(const KernelParams &p, const Lds &s,
         const bool vec16 = COH && p.grid_wgs > 1 && (in & 3u) == 0 && (n.off[l] & 3u) == 0 && ((uintptr_t)in_vec & 15u) == 0;
         for (uint32_t j0 = wave * JU; j0 < out; j0 += nw * JU) {
             float dot[JU], bias[JU];
+            // (hogwild launches: the biases through the same kind of device-scope buffer load as the weights -- as atomic loads, nn_ld, the compiler issued the
+            // JU of a pass one at a time, each waited for before the next: 8 dependent round trips per pass in front of the weights' one; round 6)
+            const __amdgpu_buffer_rsrc_t rwb = make_rsrc(W, (in * out + out) * 4);
 #pragma unroll
             for (int u = 0; u < JU; ++u) {
                 dot[u] = 0.0f;
                 // (issued in front of the weights: loaded behind the reduction, the bias was a second round trip per pass)
-                bias[u] = j0 + u < out ? nn_ld<COH>(W + (size_t)in * out + j0 + u) : 0.0f;
+                if (vec16)
+                    bias[u] = Vec<1>::load<kAuxSc1>(rwb, j0 + u < out ? (in * out + j0 + u) * 4 : 0xfffffff0u);
+                else
+                    bias[u] = j0 + u < out ? nn_ld<COH>(W + (size_t)in * out + j0 + u) : 0.0f;
             }
             if (vec16) {
                 const __amdgpu_buffer_rsrc_t rw = make_rsrc(W, in * out * 4);
@@ -951,6 +976,7 @@ __device__ __forceinline__ float nn_forward(const KernelParams &p, const Lds &s,
             }
         }
         __syncthreads();
+        FW_NN_TICK(9 + (l ? 1 : 0));
         in_vec = b.h + hoff;
         hoff += out;
     }
@@ -958,6 +984,18 @@ __device__ __forceinline__ float nn_forward(const KernelParams &p, const Lds &s,
     const uint32_t L = n.n_layers, fin = n.in[L], wl = n.out[L - 1];
     const float *Wf = n.w + n.off[L];
     float dot = 0.0f;
+    if (COH && p.grid_wgs > 1) {  // (hogwild launches: buffer loads, issued together; the order of the sum is the in-order mode's promise only)
+        const __amdgpu_buffer_rsrc_t rf = make_rsrc(Wf, fin * 4);
+        float wf[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wf[u] = Vec<1>::load<kAuxSc1>(rf, ((uint32_t)tid + (uint32_t)u * (uint32_t)bd) * 4u);  // (beyond the neuron's inputs: 0)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = (uint32_t)tid + (uint32_t)u * (uint32_t)bd;
+            if (i < fin) dot += wf[u] * (i < wl ? in_vec[i] : b.x[i - wl]);
+        }
+        for (uint32_t i = tid + 4 * bd; i < fin; i += bd) dot += nn_ld<COH>(Wf + i) * (i < wl ? in_vec[i] : b.x[i - wl]);
+    } else
     for (uint32_t i = tid; i < fin; i += bd) dot += nn_ld<COH>(Wf + i) * (i < wl ? in_vec[i] : b.x[i - wl]);
     dot = wave_sum(dot);
     if (lane == 0) s.red[wave] = dot;
@@ -966,6 +1004,7 @@ __device__ __forceinline__ float nn_forward(const KernelParams &p, const Lds &s,
     for (int w = 0; w < nw; ++w) z += s.red[w];
     z = nn_ld<COH>(Wf + fin) + z;
     __syncthreads();
+    FW_NN_TICK(11);
     return z;
 }
 
@@ -1044,6 +1083,9 @@ __device__ __forceinline__ void nn_layer_backward(const DevNN &n, uint32_t l, co
 #ifndef FW_NN_VJU
 #define FW_NN_VJU 4
 #endif
+#ifndef FW_NN_ROT
+#define FW_NN_ROT 0
+#endif
 template <int OPT>
 __device__ __forceinline__ void nn_layer_backward_vec(const DevNN &n, uint32_t l, const float *og, const float *in_a,
                                                       uint32_t split, const float *in_b, float *grad_a, float *grad_b,
@@ -1089,6 +1131,44 @@ __device__ __forceinline__ void nn_layer_backward_vec(const DevNN &n, uint32_t l
         }
         constexpr int JU = FW_NN_VJU;  // neurons in flight per thread: 2 x JU x 16 bytes (8 in flight, and loading the next batch
                                        // while this one is stepped, both measured slower: registers)
+#if FW_NN_ROT
+        // Rotating form (round 6): the JU slots are loaded once up front; a slot is stepped, stored, and RE-LOADED with its neuron of the next pass at once,
+        // in the registers the store has just read.  vmcnt counts in issue order: waiting for a pass's loads used to wait for the previous pass's write-through
+        // stores as well (issued in front of them) -- a store acknowledgement PLUS a load round trip per pass; here a slot's reload is waited for a whole
+        // rotation later, when its store in front of it has long been acknowledged: one round trip per pass.
+        {
+            f4 w[JU], a[JU];
+            float gg[JU];
+            uint32_t bo[JU];
+            auto fetch = [&](int u, uint32_t a0) {
+                const bool on = a0 + u < jhi;
+                const uint32_t j = on ? act[a0 + u] : 0u;
+                gg[u] = on ? og[j] : 0.0f;
+                bo[u] = on ? (j * in + 4 * q) * 4 : 0xfffffff0u;  // (beyond the thread's share: an offset outside the layer -- the loads return 0, the stores are dropped)
+                w[u] = Vec<4>::load<kAuxSc1>(rw, bo[u]);
+                a[u] = OPT != FWGPU_OPT_SGD ? Vec<4>::load<kAuxSc1>(ra, bo[u]) : Vec<4>::zero();
+            };
+#pragma unroll
+            for (int u = 0; u < JU; ++u) fetch(u, jlo);
+            for (uint32_t a0 = jlo; a0 < jhi; a0 += JU) {
+#pragma unroll
+                for (int u = 0; u < JU; ++u) {
+                    f4 wn = w[u], an = a[u];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float acc = an[c];
+                        const float upd = opt_step<OPT>(gg[u] * xi[c], acc, n.rate, n.minus_power_t, n.lut);
+                        oe[c] += wn[c] * gg[u];
+                        wn[c] = wn[c] - upd;
+                        an[c] = acc;
+                    }
+                    Vec<4>::store<kAuxSc1>(wn, rw, bo[u]);
+                    if (OPT != FWGPU_OPT_SGD) Vec<4>::store<kAuxSc1>(an, ra, bo[u]);
+                    fetch(u, a0 + JU);  // (the last pass fetches beyond the share: zero-length accesses)
+                }
+            }
+        }
+#else
         for (uint32_t a0 = jlo; a0 < jhi; a0 += JU) {
             f4 w[JU], a[JU];
             float gg[JU];
@@ -1104,6 +1184,31 @@ __device__ __forceinline__ void nn_layer_backward_vec(const DevNN &n, uint32_t l
                 w[u] = Vec<4>::load<kAuxSc1>(rw, bo[u]);
                 a[u] = OPT != FWGPU_OPT_SGD ? Vec<4>::load<kAuxSc1>(ra, bo[u]) : Vec<4>::zero();
             }
+            if (OPT == FWGPU_OPT_ADAGRAD_LUT) {
+                // AdagradLUT: the pass's 4 JU table lookups (optimizer.rs:147-156; the head's table is read through L1) are issued TOGETHER, in front of the pass's
+                // first store -- left inside the per-weight step, each lookup was a round trip of its own behind the previous neuron's write-through stores
+                // (vmcnt counts in issue order): 16 dependent round trips per pass where one does (round 6)
+                f4 lv[JU];
+#pragma unroll
+                for (int u = 0; u < JU; ++u)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float grad = gg[u] * xi[c];
+                        const float na = __fadd_rn(a[u][c], __fmul_rn(grad, grad));
+                        a[u][c] = na;
+                        lv[u][c] = n.lut[(__float_as_uint(na) >> (31 - kLutBits)) & (uint32_t)(kLutSize - 1)];
+                    }
+#pragma unroll
+                for (int u = 0; u < JU; ++u) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        oe[c] += w[u][c] * gg[u];
+                        w[u][c] = w[u][c] - __fmul_rn(gg[u] * xi[c], lv[u][c]);
+                    }
+                    Vec<4>::store<kAuxSc1>(w[u], rw, bo[u]);
+                    Vec<4>::store<kAuxSc1>(a[u], ra, bo[u]);
+                }
+            } else
 #pragma unroll
             for (int u = 0; u < JU; ++u) {
 #pragma unroll
@@ -1118,6 +1223,7 @@ __device__ __forceinline__ void nn_layer_backward_vec(const DevNN &n, uint32_t l
                 if (OPT != FWGPU_OPT_SGD) Vec<4>::store<kAuxSc1>(a[u], ra, bo[u]);
             }
         }
+#endif
     }
     __syncthreads();  // every thread has read its inputs: the gradients may overwrite them (in_vals and in_grad alias)
     if (grp == 0) {   // (nq <= workgroup size: group 0 always exists; with no active neuron its sums are the zeros the caller needs)
@@ -1165,6 +1271,9 @@ __device__ __forceinline__ void nn_backward(const KernelParams &p, const Lds &s,
     const DevNN &n = p.nn;
     const uint32_t L = n.n_layers, X = n.X, wl = n.out[L - 1];
     uint32_t hoff_last = n.sum_width - wl;
+#ifdef FW_TICKS
+    unsigned long long nn_last = __builtin_amdgcn_s_memtime();
+#endif
     if (tid == 0) b.fg[0] = g;  // og of the single final neuron
     __syncthreads();
     // final neuron: inputs [h_last | x], input gradients -> [h_last (in place) | xg]
@@ -1172,6 +1281,7 @@ __device__ __forceinline__ void nn_backward(const KernelParams &p, const Lds &s,
     if (n.topology != 1)
         for (uint32_t i = tid; i < X; i += bd) b.xg[i] = 0.0f;
     __syncthreads();
+    FW_NN_TICK(12);
     uint32_t hoff = hoff_last;
     for (int l = (int)L - 1; l >= 0; --l) {
         const uint32_t out = n.out[l];
@@ -1190,6 +1300,7 @@ __device__ __forceinline__ void nn_backward(const KernelParams &p, const Lds &s,
             for (uint32_t i = tid; i < X; i += bd) b.xg[i] = b.fg[i] + b.xg[i];
         }
         __syncthreads();
+        FW_NN_TICK(13 + (l ? 0 : 1));
     }
 }
 
@@ -1390,8 +1501,13 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
     for (int u = 0; u < U; ++u) {
         if (nb[u] == 0) continue;
         const uint32_t fbits = __builtin_amdgcn_readfirstlane(s.e_fld[idx[u]]);
+        // (every chunk of the row is stepped before any chunk is stored: the second chunk's LUT lookups -- through L1 in the two-chunk launches -- are then not
+        // waited for behind the acknowledgement of the first chunk's write-through stores; vmcnt counts in issue order)
+        f4 wn_c[NCH], an_c[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
+            wn_c[c] = wv[u][c];
+            an_c[c] = av[u][c];
             if (nb[u] <= (uint32_t)c * 1024u) continue;
             const int e = c * 256 + lane * 4 - (int)(sb[u] >> 2);    // this lane's first element of the row
             const bool inb = e >= 0 && e < (int)R;
@@ -1438,6 +1554,15 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
                 wn = wv[u][c];
                 an = av[u][c];
             }
+            wn_c[c] = wn;
+            an_c[c] = an;
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (nb[u] <= (uint32_t)c * 1024u) continue;
+            const int e = c * 256 + lane * 4 - (int)(sb[u] >> 2);
+            const bool inb = e >= 0 && e < (int)R;
+            f4 wn = wn_c[c], an = an_c[c];
             const uint32_t fl = hh[u] - (sb[u] >> 2);
             Vec<4>::template store<AUX_SW>(wn, make_rsrc(p.ffm_w + fl, nb[u]), c * 1024 + lane * 16);
             // Store policy 3 on two-chunk rows (thin_seed given): a row whose accumulators exceed acc_hot_theta stores them for one example in m only, with m times
@@ -2676,13 +2801,17 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #endif
 // NC = 16-byte chunks per lane and row: 1 for rows of up to 256 floats (config C: 240), 2 for rows of up to 512 floats (k = 16 with 30
 // fields: 480).  Two-chunk rows keep T alone at 57.6 KB of LDS, so two workgroups share a CU and the register budget is 128 VGPRs.
-template <int OPT, bool COH, int MAXR, bool WIN, int NC = 1, int POL = FW_DEFAULT_STORE_POLICY>
+// NN: the deep head (a18) as a phase of the two-chunk instantiation -- config E's CONCURRENT launches: nn_forward between the gather and the sigmoid, nn_backward in front
+// of the table update, every FFM pair and every LR combo slot stepping with its own general gradient.  Two 512-thread workgroups per CU where the generic kernel
+// (which keeps the in-order launches: the parity mode) runs one of 1024 (round 6).
+template <int OPT, bool COH, int MAXR, bool WIN, int NC = 1, int POL = FW_DEFAULT_STORE_POLICY, bool NN = false>
 #ifndef FW_LB_WAVES_WIN  // the window path (config C's updating launches): FOUR waves per SIMD = two workgroups per CU, 128 registers -- room for
 #define FW_LB_WAVES_WIN 4  // 14 (round 4: 20) kept rows per wave; faster AND better than three workgroups with 8 kept rows
 #endif
 __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WIN : FW_LB_WAVES) : 4) fw_example_kernel_r(const KernelParams /* read through kp_fresh() */) {
     const KernelParams &p = kp_fresh();
     static_assert(NC == 1 || MAXR == 0, "resident rows are a single-chunk feature");
+    static_assert(!NN || (NC == 2 && WIN && COH), "the head is a phase of the concurrent two-chunk instantiation only");
     typedef f4 V;
     constexpr int VEC = 4;
     constexpr int AUX = COH ? kAuxSc1 : kAuxPlain;
@@ -2704,7 +2833,12 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
     constexpr bool kAtom = COH && POL == 4;  // ... as atomic adds of m g^2 (policy 4) instead of stores of acc_read + m g^2 (policy 3)
     constexpr int UA = (WIN && NC == 1) ? FW_UA_WIN : FW_UA;  // accumulator rows in flight per wave in the update phase
     constexpr int UG = (WIN && NC == 1) ? FW_UG_WIN : FW_UG;  // overflow rows in flight per wave in the gather
-    constexpr int UO = FW_UO;  // overflow rows (w + acc) in flight per wave
+#ifndef FW_UO_NN
+#define FW_UO_NN FW_UO
+#endif
+    // overflow rows (w + acc) in flight per wave.  (With the deep head, FW_UO_NN: 2, 4 and 5 rows per round trip were measured against 1 in round 6 -- 1.31-1.34 / 1.26 / 1.28-1.30 M
+    // examples/s against 1.33-1.39 M: the update's share of an example's lifetime does not shrink with the rows in flight, profiles/r06_configE_v2_head.txt.)
+    constexpr int UO = NN ? FW_UO_NN : FW_UO;
     extern __shared__ __align__(16) unsigned char smem[];
     // Single-chunk rows (configs B / C): the AdaGrad LUT is ALWAYS the LDS copy, decided at compile time -- s.lut is then an LDS pointer the
     // compiler can see through (ds_read_b32).  As a run-time choice between the LDS copy and the global table the pointer was generic: every
@@ -3071,9 +3205,17 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
             for (uint32_t f = tid; f < F; f += bd) p.emit_dcf[f] = s.dcf[f];
         }
 
+        float wsum_nn = 0.0f;
+        if (NN) {  // x = [LR combo sums | triangle] -> layers -> final neuron (block_neural.rs:196-222); its own barriers, and a view of its own
+            const KernelParams &p = kp_fresh();
+            int tid_h = FW_TID_FRESH(), bd_h = blockDim.x;
+            asm volatile("; thread index and workgroup size handed out" : "+v"(tid_h), "+s"(bd_h));
+            const Lds s = lds_view(p, smem, use_lut);
+            wsum_nn = nn_forward<VEC, COH>(p, s, __builtin_amdgcn_readfirstlane(so.nl), tid_h, bd_h);
+        }
         // ---------------- all-pairs dot from LDS + LR forward (identical to fw_example_kernel)
         float dot = 0.0f;
-        {
+        if (!NN) {
             const uint32_t nq = F * R / VEC;
             for (uint32_t q = tid; q < nq; q += bd) {
                 const uint32_t ee = q * VEC;
@@ -3088,7 +3230,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         float lrs = 0.0f;
         float2 lr_kept = float2{0.0f, 0.0f};  // this thread's first LR entry as the forward pass read it (lr_update `kept`)
         const bool emit_x = !COH && p.emit_x;  // (read-only instantiations only)
-        if (p.has_lr)
+        if (!NN && p.has_lr)
             for (uint32_t i = tid; i < nl; i += bd) {
                 const float2 wa = lr_forward_pair<COH>(p, s, s.l_hash[i]);
                 if (i == (uint32_t)tid) lr_kept = wa;
@@ -3160,6 +3302,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         float wsum = 0.0f;
         if (p.has_lr) wsum += lr_t;
         wsum += 0.5f * (dot_t - dc_t);
+        if (NN) wsum = wsum_nn;  // deep head: the sigmoid sees the final neuron's output (regressor.rs:191-323)
 
         const float label = __uint_as_float(s.ctr[kCtrLabel]), imp = __uint_as_float(s.ctr[kCtrImp]);  // (parked by the stage phase)
         float pr, g;
@@ -3182,13 +3325,25 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         const bool do_update = p.update && imp != 0.0f;  // regressor.rs:366 (as the stage phase's StageOut::do_update)
         if (do_update && g != 0.0f) {
             const bool lr_upd = p.has_lr;
+            const float *gx = nullptr, *gpair = nullptr;
+            if (NN) {  // deep head: unwind it first; afterwards every LR combo slot and every FFM pair has its own general gradient (block_neural.rs:252-340, block_misc.rs:822-832)
+                {
+                    const KernelParams &p = kp_fresh();
+                    int tid_h = FW_TID_FRESH(), bd_h = blockDim.x;
+                    asm volatile("; thread index and workgroup size handed out" : "+v"(tid_h), "+s"(bd_h));
+                    const Lds s = lds_view(p, smem, use_lut);
+                    nn_backward<OPT, COH>(p, s, g, tid_h, bd_h);
+                }
+                gx = nn_buf(p, s).xg;
+                gpair = gx + p.num_combos;
+            }
             // The pair kept from the forward pass saves the update's load round trip: +1.8 % examples/s at config C at the same loss.  Only for
             // examples of at least FW_LR_KEEP_MIN LR entries: on streams of small examples (10-40 entries, ~15 us per example) the longer
             // read-modify-write window of the hot LR entries costs 0.005-0.01 of hold-out loss (profiles/r04_lr_pair_kept_ab.txt; round 2 saw the same).
 #ifndef FW_LR_KEEP_MIN
 #define FW_LR_KEEP_MIN 128
 #endif
-            if (lr_upd) lr_update<OPT, COH>(p, s, nl, g, nullptr, lut_lr, tid, bd, 0u, 0xffffffffu, nl >= FW_LR_KEEP_MIN, lr_kept);
+            if (lr_upd) lr_update<OPT, COH>(p, s, nl, g, gx, lut_lr, tid, bd, 0u, 0xffffffffu, !NN && nl >= FW_LR_KEEP_MIN, lr_kept);
             FW_TICK(4);
             // phase A, resident rows: w comes from registers (read once, in the gather); only acc is loaded.
             // Chained duplicates (WIN): a row that is chained to an earlier one is applied by that row's owner, and an owner WITH a
@@ -3376,7 +3531,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                     if (WIN && MAXR > 0 && i >= kb && i < kb + nk2 && !(s.e_fld[i] & kRowHasChain)) idx[u] = 0xffffffffu;
                 }
                 if (WIN)
-                    update_rows_win<OPT, AUX, UO, (NC > FW_WIN_NCH ? NC : FW_WIN_NCH), AUX_SW, AUX_SA>(p, s, idx, g, lane, nf, nullptr, (kThin && (NC > 1 || FW_THIN_OVERFLOW || kAtom) && p.store_policy >= 3 && p.grid_wgs > 1 && p.thin_reread) ? ex : 0xffffffffu);
+                    update_rows_win<OPT, AUX, UO, (NC > FW_WIN_NCH ? NC : FW_WIN_NCH), AUX_SW, AUX_SA>(p, s, idx, g, lane, nf, gpair, (kThin && (NC > 1 || FW_THIN_OVERFLOW || kAtom) && p.store_policy >= 3 && p.grid_wgs > 1 && p.thin_reread) ? ex : 0xffffffffu);
                 else
                     update_rows<VEC, OPT, AUX, UO, false, NC>(p, s, idx, g, lane);
             }
@@ -3389,7 +3544,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                         if (s.e_fld[i] & kRowDep) {
                             uint32_t idx[1] = {i};
                             if (WIN)
-                                update_rows_win<OPT, AUX, 1, (NC > FW_WIN_NCH ? NC : FW_WIN_NCH), AUX_SW, AUX_SA>(p, s, idx, g, lane, nf);
+                                update_rows_win<OPT, AUX, 1, (NC > FW_WIN_NCH ? NC : FW_WIN_NCH), AUX_SW, AUX_SA>(p, s, idx, g, lane, nf, gpair);
                             else
                                 update_rows<VEC, OPT, AUX, 1, false, NC>(p, s, idx, g, lane);
                             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -3442,6 +3597,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
 template <int OPT, bool COH>
 static hipError_t launch_r(const KernelParams &p, uint32_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
     if (p.R > 64 * 4) {  // two-chunk rows (k = 16 at config E's 30 fields): no resident rows
+        if (COH && p.nn_v2) return launch_persistent(fw_example_kernel_r<OPT, COH, 0, true, 2, FW_DEFAULT_STORE_POLICY, COH>, p, grid, threads, lds, stream);  // ... with the deep head as a phase
         if (p.window) return launch_persistent(fw_example_kernel_r<OPT, COH, 0, true, 2>, p, grid, threads, lds, stream);
         return launch_persistent(fw_example_kernel_r<OPT, COH, 0, false, 2>, p, grid, threads, lds, stream);
     }
@@ -3471,7 +3627,9 @@ static hipError_t launch_resident(const KernelParams &p, int optimizer, bool coh
 static bool uses_resident_kernel(const KernelParams &p, uint32_t threads) {
     // rows of up to 256 floats (one 16-byte chunk per lane) or up to 512 (two chunks; a field slot must not straddle the chunks)
     const bool fits = p.R <= 64 * 4 || (p.R <= 64 * 4 * 2 && p.k != 0 && 256 % p.k == 0);
-    return p.k % 4 == 0 && p.aligned4 && fits && p.kernel_version != 1 && (p.nn.n_layers == 0 || (p.emit_x && !p.update)) && threads <= FW_LB_THREADS;
+    // a deep head: read-only launches that only form its input (emit_x), and -- nn_v2, chosen by prepare_launch where two workgroups fit a CU -- config E's concurrent updating launches
+    const bool head_ok = p.nn.n_layers == 0 || (p.emit_x && !p.update) || (p.nn_v2 && p.update && p.R > 64 * 4);
+    return p.k % 4 == 0 && p.aligned4 && fits && p.kernel_version != 1 && head_ok && threads <= FW_LB_THREADS;
 }
 bool example_kernel_is_resident(const KernelParams &p, uint32_t threads) { return uses_resident_kernel(p, threads); }
 // Whole-line updates and duplicate-row chains exist in the v2 kernel's update path only, and only updating launches need them.

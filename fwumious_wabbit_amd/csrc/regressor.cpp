@@ -433,6 +433,26 @@ static int prepare_launch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int upda
     if ((uint64_t)p.max_ffm > 4ull * threads) threads = 1024;
     if ((uint64_t)p.max_ffm > 4ull * threads)
         return fail(FWGPU_ERR_RANGE, "an example has more than 4096 FFM features");
+    // Config E's concurrent launches: the deep head as a phase of the v2 kernel's two-chunk instantiation (kernels.hip fw_example_kernel_r<..., NN = true>) where TWO of its
+    // 512-thread workgroups fit a CU -- the AdaGrad LUT read through L1, no record prefetch, no LDS copy of the entries' own slots -- instead of one 1024-thread workgroup
+    // of the generic kernel.  In-order launches (the parity mode) and shapes that do not fit stay on the generic kernel.  fwgpu_debug_set_option(r, 11, 0) / FWGPU_NN_V2=0: off.
+    {
+        static const char *env_nn = getenv("FWGPU_NN_V2");
+        const bool wish = r->launch.nn_v2 >= 0 ? r->launch.nn_v2 != 0 : !(env_nn && env_nn[0] == '0');
+        const bool forced = r->launch.nn_v2 == 2;  // (tests: in-order launches too, whatever fits -- the head's wiring in that kernel against the oracle, per example)
+        if (wish && p.nn.n_layers && update && (p.concurrent || forced) && p.window && p.k_log2 != 0xffu && p.R > 64 * 4 && (!r->launch.threads_set || r->launch.threads == 512) && r->launch.kernel_version != 1 && (uint64_t)p.max_ffm <= 4ull * 512) {
+            KernelParams q = p;
+            q.nn_v2 = 1;
+            q.lut_global = 1;
+            q.prefetch = 0;
+            resolve_row_mode(q, 512);
+            const size_t lds_q = example_kernel_lds_bytes(q, r->cfg.optimizer);
+            if (example_kernel_is_resident(q, 512) && q.window && (forced ? lds_q <= r->lds_per_cu : 2 * lds_q <= r->lds_per_cu)) {
+                p = q;
+                threads = 512;
+            }
+        }
+    }
     resolve_row_mode(p, threads);
     size_t lds = example_kernel_lds_bytes(p, r->cfg.optimizer);
     // rows parked in LDS by the gather (KernelParams::lds_keep): as many per wave as still let a second workgroup live on the CU
@@ -928,6 +948,10 @@ int fwgpu_debug_set_option(fwgpu_regressor *r, int option, int value) {
     case 5:  // FFM row store policy of hogwild launches: 0 write-through, 1 weights write-back, 2 both tables write-back, -1 the build's default
         if (value < -1 || value > 4) return fail(FWGPU_ERR_INVALID, "store policy option: -1, 0, 1, 2, 3 or 4");
         r->launch.store_policy = value;
+        return FWGPU_OK;
+    case 11:  // the deep head of concurrent two-chunk launches as a phase of the v2 kernel (1, default where two workgroups fit a CU) or always on the generic kernel (0); -1 = default
+        if (value < -1 || value > 2) return fail(FWGPU_ERR_INVALID, "deep-head kernel option: -1, 0, 1 or 2");
+        r->launch.nn_v2 = value;
         return FWGPU_OK;
     case 9:  // policies 3 / 4: a row counts as hot when its accumulators have grown by more than value / 1024 (-1: the default, 0.5)
         if (value < -1 || value > (1 << 24)) return fail(FWGPU_ERR_INVALID, "hot-row threshold option: -1, or 0 .. 2^24 (in 1/1024)");

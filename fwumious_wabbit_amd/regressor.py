@@ -404,6 +404,11 @@ class Regressor:
         check(self.L.fwgpu_debug_set_option(self.h, 9, -1 if theta < 0 else int(round(theta * 1024))))
         check(self.L.fwgpu_debug_set_option(self.h, 10, int(sample_log2)))
 
+    def set_head_kernel(self, v2):
+        """deep head of HOGWILD launches with two-chunk rows (config E): as a phase of the large-table kernel (1; default -1 = where two workgroups fit a CU)
+        or on the generic kernel (0) -- fwgpu_debug_set_option 11"""
+        check(self.L.fwgpu_debug_set_option(self.h, 11, int(v2)))
+
     def set_prefetch(self, on):
         """updating launches copy the next example's record to LDS during the current example (fwgpu_debug_set_option 7; default on)"""
         check(self.L.fwgpu_debug_set_option(self.h, 7, int(bool(on))))

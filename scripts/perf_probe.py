@@ -43,6 +43,8 @@ def run(threads, wgs, update=True, reps=6, label=""):
     sub = " ".join(f"s{j}={100*t[8+j]/tot:.1f}%" for j in range(4) if t[8+j])
     if t[15]:
         sub += f" | per update batch: store-drain {t[12]/t[15]:.0f} load-wait {t[13]/t[15]:.0f} issue+compute {t[14]/t[15]:.0f} ticks, {t[15]/max(t[7],1):.1f} batches/example"
+    if args.nn_layers:
+        sub = "head: " + " ".join(f"{nm}={100*t[8+j]/tot:.1f}%" for j, nm in enumerate(["x", "fwd_l0", "fwd_l1", "fwd_final", "bwd_final", "bwd_l1", "bwd_l0"]))
     print(f"{label} threads={threads} wgs/cu={wgs or 'auto'} update={update}: {dt*1e3:.3f} ms/launch {B/dt/1e6:.2f} Mex/s | ticks/example={per_ex:.0f} | {br} | stage parts: {sub}", flush=True)
 
 use_records = os.environ.get("RECORDS", "1") == "1"

@@ -220,7 +220,7 @@ def test_lr_only_model():
 
 # ------------------------------------------------------------------ deep head (SURVEY a18, config E shape)
 def _nn_stream_parity(n_ns, k, bits, ffm_bits, optimizer, layers, topology, n, seed, mean_extra=1.0, ids=3000,
-                      interactions=(), nn_lr=0.02, nn_power_t=0.45, nn_init_acc=0.0, weight_tol=2e-5, **kw):
+                      interactions=(), nn_lr=0.02, nn_power_t=0.45, nn_init_acc=0.0, weight_tol=2e-5, setup=None, **kw):
     mi, ocfg, ots = make_pair(n_ns, k, bits, ffm_bits, optimizer, interactions=interactions, **kw)
     mi.nn_layers = [dict(width=w, activation=a, init=i) for w, a, i in layers]
     mi.nn_topology = topology
@@ -238,6 +238,8 @@ def _nn_stream_parity(n_ns, k, bits, ffm_bits, optimizer, layers, topology, n, s
     outs = []
     for kind in ("entries", "records"):
         re = fw.Regressor(mi)
+        if setup:
+            setup(re)
         assert re.table_len(capi.TABLE_NN_W) == w0.size
         re.table_write(capi.TABLE_NN_W, w0)  # Hu / Xavier draws are implementation-defined: load the same ones
         fbt = fw.FeatureBufferTranslator(mi)
@@ -323,6 +325,21 @@ def test_config_e_real_geometry_sequential_parity():
     _nn_stream_parity(30, 16, 20, 20, fw.Optimizer.AdagradLUT, [(256, "relu", "hu"), (256, "relu", "hu")], "one", n=96,
                       seed=31, mean_extra=5.67, ids=100000, lr=0.025, ffm_lr=0.025, power_t=0.38, ffm_power_t=0.38,
                       nn_lr=0.025, nn_power_t=0.38, nn_init_acc=1.0)
+
+
+def test_config_e_real_geometry_sequential_parity_on_the_large_table_kernel():
+    """The same stream through the kernel that runs config E's CONCURRENT launches since round 6 -- the head as a phase of the large-table kernel's two-chunk
+    instantiation (fw_example_kernel_r<..., NN = true>; fwgpu_debug_set_option 11 = 2 forces in-order launches onto it, option 2 = 3 its update path onto a
+    20-bit table): per-example parity with the oracle and the final NN / FFM / LR tables, as above."""
+    def setup(re):
+        re.set_whole_line_updates(3)
+        re.set_head_kernel(2)
+
+    _nn_stream_parity(30, 16, 20, 20, fw.Optimizer.AdagradLUT, [(256, "relu", "hu"), (256, "relu", "hu")], "one", n=96,
+                      seed=31, mean_extra=5.67, ids=100000, lr=0.025, ffm_lr=0.025, power_t=0.38, ffm_power_t=0.38,
+                      nn_lr=0.025, nn_power_t=0.38, nn_init_acc=1.0, setup=setup)
+    _nn_stream_parity(30, 16, 20, 20, fw.Optimizer.SGD, [(256, "relu", "hu"), (256, "relu", "hu")], "one", n=48,
+                      seed=33, mean_extra=5.67, ids=100000, lr=0.025, ffm_lr=0.025, nn_lr=0.025, setup=setup)
 
 
 def test_config_e_real_geometry_hogwild_1024_thread_workgroups():
