@@ -175,6 +175,7 @@ def link_bytes_per_example(args, world, n_ffm, n_lr, rec_words, sync_every, tabl
         "sharded": 4 * rec_words * (N - 1) + 2 * SL4 * f + (SL4 + 4) * (N - 1),               # records all-gathered, field sums reduce-scattered, records + gradients all-gathered
         "peer": (5 * rows + 4 * n_lr * 8) * f,                                                 # gather w; read w, acc; write w, acc -- all in the owner's memory
         "owner_apply": (2 * rows + n_ffm * 8 + 2 * n_lr * 8) * f,                               # fetch w from the owner, push the gradient row to the owner (fwgpu_dist_*_owner)
+        "owner_stream": (2 * rows + n_ffm * 12 + 2 * n_lr * 12) * f,                            # the same rows, streaming form: + a tag word per row and a free-generation word back (dp_modes.owner_stream)
         "what": "bytes per example on one rank's links (sent + received), (N-1)/N of the rows being remote",
     }
 
@@ -241,7 +242,9 @@ def measure_traffic(args):
 
     if not shutil.which("rocprofv3"):
         return None, "rocprofv3 not on PATH"
-    fwd = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-traffic", "--batch", str(args.batch), "--fields", str(args.fields),
+    # (20 + 4 launches, as the driver's shape: the counters of the launches from the 16th on are the figure -- by then the stream's hot rows ARE hot, and store policy 4
+    # issues an eighth of their accumulator traffic; the first three launches are kept beside it)
+    fwd = ["--steps", "20", "--warmup", "4", "--no-cpu-baseline", "--no-traffic", "--no-config-e", "--no-config-b", "--batch", str(args.batch), "--fields", str(args.fields),
            "--k", str(args.k), "--bits", str(args.bits), "--ffm-bits", str(args.ffm_bits), "--mean-extra", str(args.mean_extra),
            "--zipf", str(args.zipf), "--ids", str(args.ids), "--p-weighted", str(args.p_weighted), "--seed", str(args.seed),
            "--holdout", "256", "--nn-layers", str(args.nn_layers), "--nn-width", str(args.nn_width), "--head", args.head]
@@ -251,7 +254,7 @@ def measure_traffic(args):
         fwd += ["--threads", str(args.threads)]
     if args.wgs:
         fwd += ["--wgs-per-cu", str(args.wgs)]
-    kb = {}
+    kb, kb_first = {}, {}
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = tempfile.mkdtemp(prefix="fwbench_pmc_", dir="/tmp")
@@ -263,9 +266,17 @@ def measure_traffic(args):
                 vals = []
                 for db in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
                     con = sqlite3.connect(db)
-                    rows = list(con.execute("select kernel_name, value from counters_collection where counter_name = ? and "
-                                            "kernel_name like '%fw_example_kernel%'", (ctr,)))
+                    rows = None
+                    for order in ("dispatch_id", "start", "rowid"):  # (the dispatches in launch order, whatever this rocprofv3's view calls it)
+                        try:
+                            rows = list(con.execute(f"select kernel_name, value from counters_collection where counter_name = ? and "
+                                                    f"kernel_name like '%fw_example_kernel%' order by {order}", (ctr,)))
+                            break
+                        except sqlite3.Error:
+                            continue
                     con.close()
+                    if rows is None:
+                        continue
                     # the updating launches are the coherent (sc1) instantiations: template argument COH, the 2nd of
                     # fw_example_kernel_r<OPT, COH, MAXR, WIN> and the 3rd of fw_example_kernel<VEC, OPT, COH, PHASE, NN>
                     for name, v in rows:
@@ -275,15 +286,19 @@ def measure_traffic(args):
                             vals.append(v)
                 if not vals:
                     return None, f"rocprofv3 --pmc {ctr}: no dispatch of the learn kernel found"
-                # every timed dispatch of the child has the same shape: take the median
-                kb[ctr] = float(np.median(vals))
+                # every dispatch of the child has the same shape; what store policy 4 sends depends on how hot the rows are by then: the late launches are the figure
+                late = vals[15:] if len(vals) > 18 else vals
+                kb[ctr] = float(np.median(late))
+                kb_first[ctr] = float(np.median(vals[:3]))
             finally:
                 shutil.rmtree(d, ignore_errors=True)
     except Exception as e:  # a side measurement: never lose the bench line over it
         return None, f"traffic measurement failed: {e!r}"
     total = (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0
+    first = (2.0 * kb_first["FETCH_SIZE"] + kb_first["WRITE_SIZE"]) * 1024.0
     return total, (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE on child runs of the same command "
-                   f"(3 steps; median per learn dispatch: FETCH_SIZE {kb['FETCH_SIZE']:.0f} KB x2 (gfx950 16 B/lane correction) + WRITE_SIZE {kb['WRITE_SIZE']:.0f} KB)")
+                   f"(24 launches; median over the learn dispatches from the 16th on: FETCH_SIZE {kb['FETCH_SIZE']:.0f} KB x2 (gfx950 16 B/lane correction) + WRITE_SIZE {kb['WRITE_SIZE']:.0f} KB; "
+                   f"the first three launches, where few rows are hot yet: {first / 1e9:.2f} GB = FETCH_SIZE {kb_first['FETCH_SIZE']:.0f} KB x2 + WRITE_SIZE {kb_first['WRITE_SIZE']:.0f} KB)")
 
 
 def _child_leg(cmd, timeout=420):
@@ -329,6 +344,21 @@ def config_b_leg(args):
         return {"value": None, "error": repr(e)}
 
 
+LONG_TOLERANCE = 0.003  # |GPU final hold-out - reference's concurrent mode's| at the end of the long protocol (stated before measuring, round 6)
+
+
+def two_sided_verdict(finals, merged, seq_final, hog_final, spread):
+    gpu = float(np.mean(finals))
+    ref = float(np.mean(hog_final)) if hog_final else seq_final
+    curve = {n: float(np.mean(v)) for n, v in merged.items()} if merged else {}
+    lo_n = min(curve, key=curve.get) if curve else None
+    rise = (gpu - curve[lo_n]) if curve else None
+    return {"two_sided": True, "tolerance": LONG_TOLERANCE, "gpu_mean_final": gpu, "reference": "oracle, 16-thread hogwild" if hog_final else "oracle, single thread",
+            "reference_final": ref, "oracle_single_thread_final": seq_final, "abs_diff": abs(gpu - ref), "within": bool(abs(gpu - ref) <= LONG_TOLERANCE),
+            "minimum": curve.get(lo_n) if curve else None, "minimum_at_examples": lo_n, "rise_after_minimum": rise,
+            "non_increasing_after_minimum": (bool(rise <= max(spread, 0.001)) if rise is not None else None)}
+
+
 def long_protocol(args):
     """`bench.py --long`: SURVEY 8d's protocol at its stated length on one GPU -- 16 Mi training examples (256 steps of 65 536) of the config-C stream, hold-out
     = 262 144 examples of the stream's tail that are predicted and never learned (main.rs:184-185, 238-241; loss as benchmark/calc_loss.py:5-25) -- in
@@ -343,7 +373,8 @@ def long_protocol(args):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path)")
     torch.cuda.set_device(0)
-    K, B, P = args.long_steps, args.batch or 65536, max(1, args.long_passes)
+    B, P = args.batch or 65536, max(1, args.long_passes)
+    K = (args.examples // B) if args.examples else args.long_steps
     mi = build_model_instance(fw, args, 0)
     re = fw.Regressor(mi)
     if args.max_in_flight:
@@ -420,9 +451,10 @@ def long_protocol(args):
         "examples_per_sec_passes": rates,
         "oracle_final_logloss": seq_final,
         "oracle_hogwild16_final_logloss": hog_final or None,
-        # the bar of VERDICT r4 item 1: the concurrent mode's final loss against the better of the reference's two execution modes, within the run-to-run spread
-        "final_logloss_vs_oracle": ({"gpu_worst_pass": max(finals), "oracle_best": min(refs), "allowance": 1.3 * spread,
-                                     "within": bool(max(finals) <= min(refs) + 1.3 * spread)} if refs else None),
+        # The bar of VERDICT r5 item 1c, stated BEFORE the 64 Mi-example runs were made: TWO-sided -- the concurrent mode's final hold-out loss within LONG_TOLERANCE of the
+        # reference's own concurrent mode (16-thread hogwild; its single thread where no hogwild curve of this length is committed) -- and, beside it, whether the GPU's
+        # curve is non-increasing after its minimum (within the larger of the run-to-run spread and 0.001): reported as measured, both of them.
+        "final_logloss_vs_oracle": (two_sided_verdict(finals, merged, seq_final, hog_final, spread) if refs else None),
         "holdout_prior_logloss": logloss(np.full(len(hy), float(np.mean(hy == 1)), dtype=np.float64), hy),
         "logloss_after_examples": {str(n): v for n, v in sorted(merged.items())},
         "oracle_logloss_after_examples": {str(n): oc["seq"].get(n) for n in sorted(merged)},
@@ -600,9 +632,10 @@ def main():
                     help="SURVEY 8d's protocol at its stated length: 16 Mi training examples + the 262 144-example hold-out, --long-passes passes from fresh weights; "
                          "the line carries final_logloss per pass, the spread and the CPU oracle's values (sequential and 16-thread hogwild) on the same stream")
     ap.add_argument("--long-steps", dest="long_steps", type=int, default=256)
+    ap.add_argument("--examples", type=int, default=0, help="--long: training examples (a multiple of the batch; 67108864 = round 6's 64 Mi protocol); overrides --long-steps")
     ap.add_argument("--long-passes", dest="long_passes", type=int, default=3)
     ap.add_argument("--store-policy", dest="store_policy", type=int, default=None, choices=[0, 1, 2, 3, 4], help="A/B: FFM row store policy (kernels.hip top); default = the build's")
-    ap.add_argument("--launch-timeout", dest="launch_timeout", type=float, default=1500.0,
+    ap.add_argument("--launch-timeout", dest="launch_timeout", type=float, default=900.0,
                     help="self-launched N>1 run (no WORLD_SIZE in the environment): seconds after which the parent ends its ranks and exits non-zero")
     args = ap.parse_args()
     apply_family(args, args.family)
@@ -882,6 +915,8 @@ def main():
     # them as dp_modes; the owner-sharded step leaves every rank with only its own range current, so it comes last).  They have
     # never run on more than one GPU: a watchdog prints the line without them if they do not come back.
     def run_other_modes():
+        if os.environ.get("FWGPU_BENCH_HANG_OTHER_MODES"):  # (tests: a leg that never comes back -- the watchdog's business)
+            time.sleep(10 ** 6)
         Kp, Bp = min(K, 16), max(256, 8192 // world)  # global micro-batch of 8192 examples: the summed-gradient rule's stable range
         precs_, poff_ = gen_records(fw, args, 2_500_000_000 + rank * Kp * Bp, Kp * Bp)
         pb = [re.record_batch(fbt, precs_[int(poff_[j * Bp]):int(poff_[(j + 1) * Bp])], poff_[j * Bp:(j + 1) * Bp + 1] - poff_[j * Bp]) for j in range(Kp)]
@@ -914,7 +949,33 @@ def main():
         dist.all_reduce(tsh, op=dist.ReduceOp.MAX)
         for x in sb:
             x.close()
-        return {"replica": "the timed mode of this line",
+        # The streaming owner-side apply (owner-sharded tables, every rank's fused kernel pushes gradient rows to the rows' owners, whose consumer workgroups run
+        # the optimizer while the sources push; no collective inside a step) -- the one mode designed to SCALE: global steps of 65 536 examples from host records.
+        # Last: it maps the peers' tables and regions (IPC) and leaves every rank with its own range current.
+        owner_stream = None
+        try:
+            Ko, Bo = min(K, 8), max(1024, 65536 // world)
+            orecs, ooff = gen_records(fw, args, 3_000_000_000 + rank * (Ko + 1) * Bo, (Ko + 1) * Bo)
+            dist_rank.set_mode(capi.MODE_HOGWILD)
+            dist_rank.owner_stream_attach()
+            cut = lambda j: (orecs[int(ooff[j * Bo]):int(ooff[(j + 1) * Bo])], ooff[j * Bo:(j + 1) * Bo + 1] - ooff[j * Bo])  # noqa: E731
+            dist_rank.learn_owner_stream(fbt, *cut(0))  # warm-up
+            torch.cuda.synchronize()
+            dist.barrier()
+            ts = time.perf_counter()
+            for j in range(1, Ko + 1):
+                dist_rank.learn_owner_stream(fbt, *cut(j))
+            torch.cuda.synchronize()
+            dist.barrier()
+            tos = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tos, op=dist.ReduceOp.MAX)
+            owner_stream = {"value": world * Ko * Bo / float(tos.item()), "unit": "examples/sec", "steps": Ko, "examples_per_step_per_gpu": Bo,
+                            "ms_per_step": 1e3 * float(tos.item()) / Ko,
+                            "what": "owner-sharded tables, streaming owner-side apply (fwgpu_dist_learn_owner_stream): hogwild across the GPUs -- gradient rows pushed into circular "
+                                    "regions in the owner's memory and applied there while the sources run; no collective inside a step; records come from host memory (PCIe-inclusive)"}
+        except Exception as e:  # (a side leg: a collective that hangs instead is the watchdog's business)
+            owner_stream = {"value": None, "error": repr(e)[:300]}
+        return {"replica": "the timed mode of this line", "owner_stream": owner_stream,
                 "sparse": {"value": world * Kp * Bp / float(tsp.item()), "unit": "examples/sec", "steps": Kp,
                            "examples_per_step_per_gpu": Bp, "ms_per_step": 1e3 * float(tsp.item()) / Kp,
                            "bucket_rows_last_step": {"ffm": sp_rows[0], "lr": sp_rows[1]},
@@ -1006,10 +1067,12 @@ def main():
                 "kernel": ("fw_example_kernel<4, AdagradLUT, coherent, peer-sharded> (generic kernel with the owner lookup, system-scope row accesses)" if peer_main else
                            "FWD / MID / " + ("head GEMMs (v_mfma_f32_32x32x2_f32) / " if args.nn_layers else "") + "UPD kernels of the synchronous micro-batch (generic row kernel)"
                            if sync_steps or sharded_main else
-                           "fw_example_kernel_r<AdagradLUT, coherent, MAXR=20, duplicate-row chains> (2 workgroups x 512 threads per CU at 128 VGPRs; 20 rows per wave kept from the gather in registers + 3 in LDS and written back as w_gather - step by a pipelined update; whole-line row accesses only when w and acc contend for one memory region)"
+                           "fw_example_kernel_r<AdagradLUT, coherent, MAXR=20, duplicate-row chains, store policy 4> (2 workgroups x 512 threads per CU at 128 VGPRs; 20 rows per wave kept from the gather in registers + 3 in LDS and written back as w_gather - step by a pipelined update; accumulators of hot rows: one example in eight ADDS eight times its g^2 with device-scope float atomics instead of every example storing the row -- fewer accumulator writes than `frac`'s algorithmic count, see frac_traffic; whole-line row accesses only when w and acc contend for one memory region)"
                            if args.k % 4 == 0 and args.fields * args.k <= 256 and not args.nn_layers else
                            "fw_example_kernel_r<AdagradLUT, coherent, MAXR=0, duplicate-row chains, NC=2> (two 16-byte chunks per lane and row; 2 workgroups x 512 threads per CU)"
                            if args.k % 4 == 0 and args.fields * args.k <= 512 and 256 % args.k == 0 and not args.nn_layers else
+                           "fw_example_kernel_r<AdagradLUT, coherent, MAXR=0, duplicate-row chains, NC=2, NN> (the per-example deep head as a phase of the large-table kernel: 2 workgroups x 512 threads per CU; FWGPU_NN_V2=0: the generic kernel, one 1024-thread workgroup per CU)"
+                           if args.nn_layers and args.k % 4 == 0 and 256 < args.fields * args.k <= 512 and 256 % args.k == 0 and args.head == "exact" and os.environ.get("FWGPU_NN_V2", "1") != "0" else
                            "fw_example_kernel<VEC=4, AdagradLUT, coherent> (generic rows, duplicate-row chains" + (" + per-example deep head)" if args.nn_layers else ")")),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -1020,6 +1083,11 @@ def main():
                 "frac_of_peak_measured": (achieved / peak_measured) if peak_measured else None,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                # what the memory system did: measured bytes (FETCH x 2 + WRITE of the launches from the 16th on) / this run's average launch time / peak.  `frac` counts
+                # ALGORITHMIC bytes (every row's w and acc read and written once per occurrence); store policy 4 issues fewer accumulator writes than that on
+                # hot rows (one example in eight adds eight times its g^2), so the two differ by what thinning skips -- plus what the caches absorb on the head rows.
+                "frac_traffic": (traffic / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
                 "pattern_ceiling_note": "profiles/r02_rowceil.txt (tools/rowceil.hip): read w+acc rows and write both back as whole lines = 0.62 of the 8 TB/s peak; this kernel on UNIFORM ids "
                                         "(every access a miss of every cache): 0.64 (profiles/r05_skew_sweep.txt) -- what is lost on the bench's Zipf stream is write-through serialisation on "
                                         "hot accumulator lines (L2 tag stalls 6.4x, profiles/r05_skew_pmc_counters.txt), which store policies 3 / 4 thin",

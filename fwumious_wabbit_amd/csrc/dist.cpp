@@ -187,6 +187,9 @@ struct fwgpu_dist {
     bool st_probed = false;            // in-process group: the concurrency probe of the ranks sharing a device has passed
     uint32_t st_share = 1;             // ranks of the job on this rank's device (their kernels must be resident together: each takes an equal share of the device)
     uint32_t st_step = 0;              // streaming steps since the last reset (tags the final positions: a consumer only believes its own step's)
+    uint32_t *st_abort = nullptr;      // pinned host word every wait loop of a streaming launch looks at (kernels.hip PushRings::abort): set by stream_finish when a step
+                                       // outlives its deadline -- written by a plain host store, so that giving a step up needs no queue of a device whose CUs the step holds
+    bool st_void = false;              // a step was given up: positions, tags and free generations no longer agree between the ranks (terminal for the streaming form of this rank)
     unsigned char *st_peer[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // every rank's st_mem as reachable from here
     PeerShards *d_peers = nullptr;   // peer-sharded step: the owners' table bases, on this rank's device
     bool peers_attached = false;     // process-per-rank peer mode: the other ranks' tables are mapped (hipIpcOpenMemHandle)
@@ -225,6 +228,7 @@ struct fwgpu_dist {
         for (void *q : ipc_open) (void)hipIpcCloseMemHandle(q);
         if (lr_shard) (void)hipFree(lr_shard);
         if (st_mem) (void)hipFree(st_mem);
+        if (st_abort) (void)hipHostFree(st_abort);
         if (d_peers) (void)hipFree(d_peers);
         if (own_rings) (void)hipFree(own_rings);
         if (d_push_cnt) (void)hipFree(d_push_cnt);
@@ -1688,7 +1692,7 @@ StreamGeom stream_geom(uint32_t N, uint32_t R, uint32_t lg_ffm, uint32_t lg_lr) 
     g.bytes = o;
     return g;
 }
-int stream_reserve(fwgpu_dist *d, uint32_t N, uint32_t lg_ffm, uint32_t lg_lr, bool *fresh) {
+int stream_reserve(fwgpu_dist *d, uint32_t N, uint32_t lg_ffm, uint32_t lg_lr, bool *fresh, bool allow_fine = true) {
     const uint32_t R = d->r->cfg.ffm_k ? d->r->cfg.ffm_k * d->r->cfg.ffm_num_fields : 0;
     const StreamGeom g = stream_geom(N, R, lg_ffm, lg_lr);
     FWGPU_HIP(hipSetDevice(d->r->device));
@@ -1696,9 +1700,28 @@ int stream_reserve(fwgpu_dist *d, uint32_t N, uint32_t lg_ffm, uint32_t lg_lr, b
     if (!d->st_mem || d->st_bytes != g.bytes || d->st_lg_ffm != lg_ffm || d->st_lg_lr != lg_lr || d->st_n != N) {
         if (d->st_mem) (void)hipFree(d->st_mem);
         d->st_mem = nullptr;
-        if (hipMalloc((void **)&d->st_mem, g.bytes) != hipSuccess) {
+        // The regions are polled and written by OTHER ranks' kernels while this rank's kernel runs: fine-grained device memory where the runtime grants it
+        // (coarse-grained memory promises cross-agent visibility at kernel boundaries only; every access of the protocol is system-scope -- sc0 sc1 -- on top).
+        // FWGPU_STREAM_FINEGRAINED=0: plain hipMalloc (what every round-5 test ran on; ranks that share one device need no more).
+        static const bool fine = [] { const char *e = std::getenv("FWGPU_STREAM_FINEGRAINED"); return !(e && e[0] == '0'); }();
+        bool got = false;
+        if (fine && allow_fine) {
+            got = hipExtMallocWithFlags((void **)&d->st_mem, g.bytes, hipDeviceMallocFinegrained) == hipSuccess;
+            if (!got) {
+                (void)hipGetLastError();
+                d->st_mem = nullptr;
+            }
+        }
+        if (!got && hipMalloc((void **)&d->st_mem, g.bytes) != hipSuccess) {
             (void)hipGetLastError();
             return fail(FWGPU_ERR_OOM, "owner-side apply, streaming form: no memory for the regions (smaller log2 capacities?)");
+        }
+        if (!d->st_abort) {
+            if (hipHostMalloc((void **)&d->st_abort, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(FWGPU_ERR_OOM, "owner-side apply, streaming form: no pinned host memory for the abort word");
+            }
+            *d->st_abort = 0u;
         }
         d->st_bytes = g.bytes;
         d->st_lg_ffm = lg_ffm;
@@ -1746,6 +1769,7 @@ uint32_t stream_consumer_wgs(uint32_t N, uint32_t wish, uint32_t waves_per_wg) {
 // One rank's launch of a streaming step: the descriptors of both roles go to the rank's own allocation, then the example kernel with the consumers on top.
 // base[j] = rank j's allocation as reachable from this rank.
 int stream_launch(fwgpu_dist *d, const StreamGeom &geo, unsigned char *const base[8], float *lr_base, int update, uint32_t consumer_wgs) {
+    if (d->st_void) return fail(FWGPU_ERR_PEER, "owner-side apply, streaming form: an earlier step of this rank was given up (time-out): the regions' state is void, the rank cannot take part in further streaming steps");
     const uint32_t N = geo.N, R = geo.R, me = (uint32_t)d->rank;
     const size_t cf = (size_t)1 << geo.lg_ffm, cl = (size_t)1 << geo.lg_lr;
     FWGPU_HIP(hipSetDevice(d->r->device));
@@ -1778,9 +1802,11 @@ int stream_launch(fwgpu_dist *d, const StreamGeom &geo, unsigned char *const bas
     os.lr_mpt = -d->r->cfg.power_t;
     os.lut_ffm = d->r->d_lut_ffm;
     os.lut_lr = d->r->d_lut_lr;
+    os.abort = d->st_abort;
     PushRings pr{};
     pr.n = N;
     pr.stream = 1;
+    pr.abort = d->st_abort;
     pr.log2cap_ffm = geo.lg_ffm;
     pr.log2cap_lr = geo.lg_lr;
     pr.cnt = reinterpret_cast<uint32_t *>(d->st_mem + geo.off_cnt);
@@ -1808,9 +1834,35 @@ int stream_launch(fwgpu_dist *d, const StreamGeom &geo, unsigned char *const bas
                           d->st_share, max_waves);
 }
 // the launch has ended: where this rank's regions (as owner) stand now = where the next step's consumers start
+// A streaming launch waits INSIDE the kernel for its peers (consumers for tags and final positions, producers for free slots): a peer that never launches --
+// gone, or returned early with an error of its own -- would hold this rank's GPU for ever.  The wait is therefore polled against a deadline
+// (FWGPU_DIST_TIMEOUT_MS where set, ten minutes otherwise); past it the host sets the abort word, every wait loop of the kernel leaves, the step is reported
+// as failed and the rank's streaming state as void.
+int stream_wait(fwgpu_dist *d) {
+    static const long timeout_ms = [] {
+        const char *e = std::getenv("FWGPU_DIST_TIMEOUT_MS");
+        const long v = e ? std::atol(e) : 0L;
+        return v > 0 ? v : 600000L;
+    }();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t it = 0;; it++) {
+        const hipError_t q = hipStreamQuery(d->stream);
+        if (q == hipSuccess) return FWGPU_OK;
+        if (q != hipErrorNotReady) return fail(FWGPU_ERR_DEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+        if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_ms) {
+            __atomic_store_n(d->st_abort, 1u, __ATOMIC_SEQ_CST);
+            d->st_void = true;
+            for (int i = 0; i < 200000 && hipStreamQuery(d->stream) == hipErrorNotReady; i++) std::this_thread::sleep_for(std::chrono::microseconds(50));
+            return fail(FWGPU_ERR_PEER, "owner-side apply, streaming form: the step did not complete within its deadline (FWGPU_DIST_TIMEOUT_MS; a peer rank is gone or never launched): "
+                                        "the launch was told to give up, this rank's streaming state is void");
+        }
+        if (it < 2000) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+}
 int stream_finish(fwgpu_dist *d, const StreamGeom &geo, int update, bool *near_wrap) {
     FWGPU_HIP(hipSetDevice(d->r->device));
-    FWGPU_HIP(hipStreamSynchronize(d->stream));
+    if (int rcw = stream_wait(d)) return rcw;
     if (update) {
         std::vector<unsigned long long> fin((size_t)2 * geo.N);
         FWGPU_HIP(hipMemcpy(fin.data(), d->st_mem + geo.off_fin + (size_t)(d->st_step & 1u) * 2 * geo.N * 8, fin.size() * 8, hipMemcpyDeviceToHost));
@@ -1904,6 +1956,9 @@ int fwgpu_dist_group_learn_owner_stream(fwgpu_dist_group *g, const fwgpu_transla
     unsigned char *bases[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     for (uint32_t j = 0; j < N; j++) bases[j] = g->ranks[j]->st_mem;
     std::vector<uint32_t> shapes((size_t)N * 4);
+    // Every rank's preparation first: an input error of ANY rank (unusable records, a batch of another regressor) returns here, before one step counter has
+    // moved and before one kernel has been launched -- the group's ranks stay at the same step (their step tags, the final positions' parity halves and
+    // the regions' positions all hang on it: a rank one step ahead of its peers would wait for final positions that never come).
     for (uint32_t j = 0; j < N; j++) {
         fwgpu_dist *d = g->ranks[j].get();
         fwgpu_batch *bj = batches ? batches[j] : nullptr;
@@ -1912,15 +1967,45 @@ int fwgpu_dist_group_learn_owner_stream(fwgpu_dist_group *g, const fwgpu_transla
         if (!d->d_peers) FWGPU_HIP(hipMalloc((void **)&d->d_peers, sizeof(PeerShards)));
         FWGPU_HIP(hipMemcpyAsync(d->d_peers, &ps, sizeof(PeerShards), hipMemcpyHostToDevice, d->stream));
         FWGPU_HIP(hipStreamSynchronize(d->stream));  // (ps is a local)
-        d->st_step++;
     }
+    for (uint32_t j = 0; j < N; j++) g->ranks[j]->st_step++;
     const uint32_t waves = std::max<uint32_t>(1u, r0->launch.threads / 64u);
     const uint32_t CW = stream_consumer_wgs(N, consumer_workgroups, waves);
-    for (uint32_t j = 0; j < N; j++)
-        if ((rc = stream_launch(g->ranks[j].get(), geo, bases, g->ranks[j]->r->d_lr, update, CW))) return rc;
+    // From here on every rank MUST launch: the peers' kernels wait for its final positions and for its consumers.  A rank whose launch fails (the launch shape
+    // does not fit, no memory) takes part with an EMPTY batch instead -- its producers publish the final positions at once, its consumers serve the peers --
+    // and its error is what the call returns once every rank's kernel has ended.
+    int first_rc = FWGPU_OK;
+    std::string first_msg;
+    for (uint32_t j = 0; j < N; j++) {
+        fwgpu_dist *d = g->ranks[j].get();
+        rc = stream_launch(d, geo, bases, d->r->d_lr, update, CW);
+        if (rc) {
+            if (!first_rc) {
+                first_rc = rc;
+                first_msg = fwgpu_last_error();
+            }
+            uint32_t sh2[4];
+            const uint64_t zero_off[1] = {0};
+            int rc2 = sparse_begin(d, t, nullptr, zero_off, 0, nullptr, sh2);
+            if (!rc2) rc2 = stream_launch(d, geo, bases, d->r->d_lr, update, CW);
+            if (rc2) {  // not even an empty launch: the peers are told to give up (they would wait for this rank for ever)
+                for (uint32_t i = 0; i < N; i++) {
+                    if (g->ranks[i]->st_abort) __atomic_store_n(g->ranks[i]->st_abort, 1u, __ATOMIC_SEQ_CST);
+                    g->ranks[i]->st_void = true;
+                }
+            }
+        }
+    }
     bool near_wrap = false;
     for (uint32_t j = 0; j < N; j++)
-        if ((rc = stream_finish(g->ranks[j].get(), geo, update, &near_wrap))) return rc;
+        if ((rc = stream_finish(g->ranks[j].get(), geo, update, &near_wrap)) && !first_rc) {
+            first_rc = rc;
+            first_msg = fwgpu_last_error();
+        }
+    if (first_rc) {
+        set_error(first_msg + " (rank-level failure inside a streaming step: the other ranks' kernels were served by an empty launch)");
+        return first_rc;
+    }
     if (near_wrap)
         for (uint32_t j = 0; j < N; j++)
             if ((rc = stream_reset(g->ranks[j].get()))) return rc;
@@ -2058,7 +2143,15 @@ int fwgpu_dist_owner_stream_attach(fwgpu_dist *d, uint32_t log2_rows, uint32_t l
     if ((rc = stream_reset(d))) return rc;
     FWGPU_HIP(hipSetDevice(d->r->device));
     hipIpcMemHandle_t mine{};
-    FWGPU_HIP(hipIpcGetMemHandle(&mine, d->st_mem));
+    if (hipIpcGetMemHandle(&mine, d->st_mem) != hipSuccess) {
+        // (a runtime that does not export fine-grained allocations: the regions as plain device memory, as in round 5)
+        (void)hipGetLastError();
+        (void)hipFree(d->st_mem);
+        d->st_mem = nullptr;
+        if ((rc = stream_reserve(d, N, lgf, lgl, &fresh, /*allow_fine=*/false))) return rc;
+        if ((rc = stream_reset(d))) return rc;
+        FWGPU_HIP(hipIpcGetMemHandle(&mine, d->st_mem));
+    }
     hipIpcMemHandle_t *d_all = nullptr;
     FWGPU_HIP(hipMalloc((void **)&d_all, sizeof(hipIpcMemHandle_t) * (size_t)N));
     struct FreeOnExit {
@@ -2121,6 +2214,20 @@ int fwgpu_dist_learn_owner_stream(fwgpu_dist *d, const fwgpu_translator_config *
     d->st_step++;
     const uint32_t waves = std::max<uint32_t>(1u, d->r->launch.threads / 64u);
     int rc = stream_launch(d, geo, d->st_peer, lr_base, update, stream_consumer_wgs(N, consumer_workgroups, waves));
+    if (rc && !d->st_void) {  // the launch shape does not fit, no memory, ...: the peers' kernels wait for this rank's final positions and consumers all the same -- an empty launch serves them
+        own_rc = rc;
+        const std::string msg = fwgpu_last_error();
+        uint32_t sh2[4];
+        const uint64_t zero_off[1] = {0};
+        int rc2 = sparse_begin(d, t, nullptr, zero_off, 0, nullptr, sh2);
+        if (!rc2) rc2 = stream_launch(d, geo, d->st_peer, lr_base, update, stream_consumer_wgs(N, consumer_workgroups, waves));
+        if (rc2) {
+            d->st_void = true;
+            return rc2;
+        }
+        set_error(msg + " (the rank took part in the step with an empty batch)");
+        rc = FWGPU_OK;
+    }
     if (rc) return rc;
     bool near_wrap = false;
     if ((rc = stream_finish(d, geo, update, &near_wrap))) return rc;

@@ -82,7 +82,8 @@ struct PushRings {
     unsigned long long *ffm_tag[8];  // per owner: [cap_ffm] tag words of this source's ring in the owner's memory
     unsigned long long *lr_word[8];  // per owner: [cap_lr] {hash (30 bits) | ((generation % 3) + 1) << 30, gradient bits << 32}
     const uint32_t *ffm_free[8];     // source-local, per owner: [cap_ffm] the generation slot q may be written for (the owner's consumer stores it)
-    const uint32_t *lr_credit;       // (unused since the LR regions got per-slot free generations like the rows)
+    const uint32_t *abort;           // a word the HOST sets when a step outlives its deadline (a peer rank is gone, or never launched): every wait loop of the streaming
+                                     // form -- producers waiting for a free slot, consumers waiting for a tag or a final position -- looks at it and leaves (dist.cpp stream_finish)
     const uint32_t *lr_free[8];      // source-local, per owner: [cap_lr] the generation LR slot q may be written for
     // The rank's consumers run INSIDE its example kernel: the first `consumers` workgroups of the launch drain this rank's regions as owner (`own`), the
     // others are the producers.  A producer workgroup that finds no more examples counts itself in `done`; the last one stores every region's final
@@ -106,6 +107,7 @@ struct OwnerStream {
     uint32_t start_ffm[8], start_lr[8];     // first position of this step, per source
     const unsigned long long *fin;          // owner-local [2n]: {step << 32 | final position}, stored by source s's last producer workgroup (FFM regions, then LR)
     uint32_t step, pad_;                    // the step this launch belongs to (fin words of other steps are not this launch's)
+    const uint32_t *abort;                  // as PushRings::abort
     float *w, *acc, *lr;
     float ffm_rate, ffm_mpt, lr_rate, lr_mpt;
     const float *lut_ffm, *lut_lr;

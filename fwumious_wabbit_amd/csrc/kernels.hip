@@ -927,17 +927,11 @@ __device__ __forceinline__ float nn_forward(const KernelParams &p, const Lds &s,
         const bool vec16 = COH && p.grid_wgs > 1 && (in & 3u) == 0 && (n.off[l] & 3u) == 0 && ((uintptr_t)in_vec & 15u) == 0;
         for (uint32_t j0 = wave * JU; j0 < out; j0 += nw * JU) {
             float dot[JU], bias[JU];
-            // (hogwild launches: the biases through the same kind of device-scope buffer load as the weights -- as atomic loads, nn_ld, the compiler issued the
-            // JU of a pass one at a time, each waited for before the next: 8 dependent round trips per pass in front of the weights' one; round 6)
-            const __amdgpu_buffer_rsrc_t rwb = make_rsrc(W, (in * out + out) * 4);
 #pragma unroll
             for (int u = 0; u < JU; ++u) {
                 dot[u] = 0.0f;
                 // (issued in front of the weights: loaded behind the reduction, the bias was a second round trip per pass)
-                if (vec16)
-                    bias[u] = Vec<1>::load<kAuxSc1>(rwb, j0 + u < out ? (in * out + j0 + u) * 4 : 0xfffffff0u);
-                else
-                    bias[u] = j0 + u < out ? nn_ld<COH>(W + (size_t)in * out + j0 + u) : 0.0f;
+                bias[u] = j0 + u < out ? nn_ld<COH>(W + (size_t)in * out + j0 + u) : 0.0f;
             }
             if (vec16) {
                 const __amdgpu_buffer_rsrc_t rw = make_rsrc(W, in * out * 4);
@@ -984,18 +978,6 @@ __device__ __forceinline__ float nn_forward(const KernelParams &p, const Lds &s,
     const uint32_t L = n.n_layers, fin = n.in[L], wl = n.out[L - 1];
     const float *Wf = n.w + n.off[L];
     float dot = 0.0f;
-    if (COH && p.grid_wgs > 1) {  // (hogwild launches: buffer loads, issued together; the order of the sum is the in-order mode's promise only)
-        const __amdgpu_buffer_rsrc_t rf = make_rsrc(Wf, fin * 4);
-        float wf[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) wf[u] = Vec<1>::load<kAuxSc1>(rf, ((uint32_t)tid + (uint32_t)u * (uint32_t)bd) * 4u);  // (beyond the neuron's inputs: 0)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t i = (uint32_t)tid + (uint32_t)u * (uint32_t)bd;
-            if (i < fin) dot += wf[u] * (i < wl ? in_vec[i] : b.x[i - wl]);
-        }
-        for (uint32_t i = tid + 4 * bd; i < fin; i += bd) dot += nn_ld<COH>(Wf + i) * (i < wl ? in_vec[i] : b.x[i - wl]);
-    } else
     for (uint32_t i = tid; i < fin; i += bd) dot += nn_ld<COH>(Wf + i) * (i < wl ? in_vec[i] : b.x[i - wl]);
     dot = wave_sum(dot);
     if (lane == 0) s.red[wave] = dot;
@@ -1083,9 +1065,6 @@ __device__ __forceinline__ void nn_layer_backward(const DevNN &n, uint32_t l, co
 #ifndef FW_NN_VJU
 #define FW_NN_VJU 4
 #endif
-#ifndef FW_NN_ROT
-#define FW_NN_ROT 0
-#endif
 template <int OPT>
 __device__ __forceinline__ void nn_layer_backward_vec(const DevNN &n, uint32_t l, const float *og, const float *in_a,
                                                       uint32_t split, const float *in_b, float *grad_a, float *grad_b,
@@ -1131,44 +1110,6 @@ __device__ __forceinline__ void nn_layer_backward_vec(const DevNN &n, uint32_t l
         }
         constexpr int JU = FW_NN_VJU;  // neurons in flight per thread: 2 x JU x 16 bytes (8 in flight, and loading the next batch
                                        // while this one is stepped, both measured slower: registers)
-#if FW_NN_ROT
-        // Rotating form (round 6): the JU slots are loaded once up front; a slot is stepped, stored, and RE-LOADED with its neuron of the next pass at once,
-        // in the registers the store has just read.  vmcnt counts in issue order: waiting for a pass's loads used to wait for the previous pass's write-through
-        // stores as well (issued in front of them) -- a store acknowledgement PLUS a load round trip per pass; here a slot's reload is waited for a whole
-        // rotation later, when its store in front of it has long been acknowledged: one round trip per pass.
-        {
-            f4 w[JU], a[JU];
-            float gg[JU];
-            uint32_t bo[JU];
-            auto fetch = [&](int u, uint32_t a0) {
-                const bool on = a0 + u < jhi;
-                const uint32_t j = on ? act[a0 + u] : 0u;
-                gg[u] = on ? og[j] : 0.0f;
-                bo[u] = on ? (j * in + 4 * q) * 4 : 0xfffffff0u;  // (beyond the thread's share: an offset outside the layer -- the loads return 0, the stores are dropped)
-                w[u] = Vec<4>::load<kAuxSc1>(rw, bo[u]);
-                a[u] = OPT != FWGPU_OPT_SGD ? Vec<4>::load<kAuxSc1>(ra, bo[u]) : Vec<4>::zero();
-            };
-#pragma unroll
-            for (int u = 0; u < JU; ++u) fetch(u, jlo);
-            for (uint32_t a0 = jlo; a0 < jhi; a0 += JU) {
-#pragma unroll
-                for (int u = 0; u < JU; ++u) {
-                    f4 wn = w[u], an = a[u];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        float acc = an[c];
-                        const float upd = opt_step<OPT>(gg[u] * xi[c], acc, n.rate, n.minus_power_t, n.lut);
-                        oe[c] += wn[c] * gg[u];
-                        wn[c] = wn[c] - upd;
-                        an[c] = acc;
-                    }
-                    Vec<4>::store<kAuxSc1>(wn, rw, bo[u]);
-                    if (OPT != FWGPU_OPT_SGD) Vec<4>::store<kAuxSc1>(an, ra, bo[u]);
-                    fetch(u, a0 + JU);  // (the last pass fetches beyond the share: zero-length accesses)
-                }
-            }
-        }
-#else
         for (uint32_t a0 = jlo; a0 < jhi; a0 += JU) {
             f4 w[JU], a[JU];
             float gg[JU];
@@ -1184,31 +1125,6 @@ __device__ __forceinline__ void nn_layer_backward_vec(const DevNN &n, uint32_t l
                 w[u] = Vec<4>::load<kAuxSc1>(rw, bo[u]);
                 a[u] = OPT != FWGPU_OPT_SGD ? Vec<4>::load<kAuxSc1>(ra, bo[u]) : Vec<4>::zero();
             }
-            if (OPT == FWGPU_OPT_ADAGRAD_LUT) {
-                // AdagradLUT: the pass's 4 JU table lookups (optimizer.rs:147-156; the head's table is read through L1) are issued TOGETHER, in front of the pass's
-                // first store -- left inside the per-weight step, each lookup was a round trip of its own behind the previous neuron's write-through stores
-                // (vmcnt counts in issue order): 16 dependent round trips per pass where one does (round 6)
-                f4 lv[JU];
-#pragma unroll
-                for (int u = 0; u < JU; ++u)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float grad = gg[u] * xi[c];
-                        const float na = __fadd_rn(a[u][c], __fmul_rn(grad, grad));
-                        a[u][c] = na;
-                        lv[u][c] = n.lut[(__float_as_uint(na) >> (31 - kLutBits)) & (uint32_t)(kLutSize - 1)];
-                    }
-#pragma unroll
-                for (int u = 0; u < JU; ++u) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        oe[c] += w[u][c] * gg[u];
-                        w[u][c] = w[u][c] - __fmul_rn(gg[u] * xi[c], lv[u][c]);
-                    }
-                    Vec<4>::store<kAuxSc1>(w[u], rw, bo[u]);
-                    Vec<4>::store<kAuxSc1>(a[u], ra, bo[u]);
-                }
-            } else
 #pragma unroll
             for (int u = 0; u < JU; ++u) {
 #pragma unroll
@@ -1223,7 +1139,6 @@ __device__ __forceinline__ void nn_layer_backward_vec(const DevNN &n, uint32_t l
                 if (OPT != FWGPU_OPT_SGD) Vec<4>::store<kAuxSc1>(a[u], ra, bo[u]);
             }
         }
-#endif
     }
     __syncthreads();  // every thread has read its inputs: the gradients may overwrite them (in_vals and in_grad alias)
     if (grp == 0) {   // (nq <= workgroup size: group 0 always exists; with no active neuron its sums are the zeros the caller needs)
@@ -1501,13 +1416,8 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
     for (int u = 0; u < U; ++u) {
         if (nb[u] == 0) continue;
         const uint32_t fbits = __builtin_amdgcn_readfirstlane(s.e_fld[idx[u]]);
-        // (every chunk of the row is stepped before any chunk is stored: the second chunk's LUT lookups -- through L1 in the two-chunk launches -- are then not
-        // waited for behind the acknowledgement of the first chunk's write-through stores; vmcnt counts in issue order)
-        f4 wn_c[NCH], an_c[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            wn_c[c] = wv[u][c];
-            an_c[c] = av[u][c];
             if (nb[u] <= (uint32_t)c * 1024u) continue;
             const int e = c * 256 + lane * 4 - (int)(sb[u] >> 2);    // this lane's first element of the row
             const bool inb = e >= 0 && e < (int)R;
@@ -1554,15 +1464,6 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
                 wn = wv[u][c];
                 an = av[u][c];
             }
-            wn_c[c] = wn;
-            an_c[c] = an;
-        }
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            if (nb[u] <= (uint32_t)c * 1024u) continue;
-            const int e = c * 256 + lane * 4 - (int)(sb[u] >> 2);
-            const bool inb = e >= 0 && e < (int)R;
-            f4 wn = wn_c[c], an = an_c[c];
             const uint32_t fl = hh[u] - (sb[u] >> 2);
             Vec<4>::template store<AUX_SW>(wn, make_rsrc(p.ffm_w + fl, nb[u]), c * 1024 + lane * 16);
             // Store policy 3 on two-chunk rows (thin_seed given): a row whose accumulators exceed acc_hot_theta stores them for one example in m only, with m times
@@ -1677,6 +1578,10 @@ __device__ __forceinline__ const KernelParams &kp_fresh() {
 template <int OPT>
 __device__ __forceinline__ void owner_stream_consume(const OwnerStream &os, uint32_t cw, uint32_t CW, uint32_t lane) {
     const uint32_t N = os.n;
+    // (the host's way out of a step whose peer never arrives: dist.cpp stream_finish sets the word when the step outlives its deadline)
+    // (the word lives in pinned host memory -- a write to it needs no queue of the device, whose CUs a waiting step holds -- so it is looked at once per 1024 polls of a wait loop)
+    uint32_t polls = 0;
+    auto aborted = [&]() -> bool { return (++polls & 1023u) == 0u && __hip_atomic_load(os.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u; };
     auto fin_of = [&](uint32_t idx, uint32_t &fin) -> bool {  // final position of ring idx (FFM: s, LR: n + s), once known
         const unsigned long long v = __hip_atomic_load(os.fin + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         fin = (uint32_t)v;
@@ -1703,7 +1608,7 @@ __device__ __forceinline__ void owner_stream_consume(const OwnerStream &os, uint
                 word = __hip_atomic_load(os.lr_word[s] + (pq & mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 have = (((uint32_t)word >> 30) & 3u) == ((pq >> lg) % 3u) + 1u;
                 if (have) break;
-                if (fin_of(N + s, fin) && (int32_t)(pq - fin) >= 0) {
+                if ((fin_of(N + s, fin) && (int32_t)(pq - fin) >= 0) || aborted()) {
                     past = true;
                     break;
                 }
@@ -1762,6 +1667,10 @@ __device__ __forceinline__ void owner_stream_consume(const OwnerStream &os, uint
                 }
             }
             if (all) break;
+            if (__builtin_amdgcn_readfirstlane(aborted() ? 1u : 0u)) {  // (the step is void: leave with what is there)
+                n_past = 1;
+                break;
+            }
             __builtin_amdgcn_s_sleep(32);
         }
         // (positions of a stripe are consumed in order: once one is beyond the end, the later ones are too)
@@ -2238,10 +2147,13 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
                             // INSIDE the loop: a lane whose position is free must not wait (at the loop's end) for a lane of its wave whose position is not --
                             // the consumers take a region's blocks in order and might never get to that one.
                             const uint32_t lslot = pos & (capl - 1u), lgen = (pos >> lg) & (lg ? (0xffffffffu >> lg) : 0xffffffffu);
+                            uint32_t lr_polls = 0;
                             for (bool sent = false; !sent;) {
                                 if ((__hip_atomic_load(pr.lr_free[o] + lslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) & (lg ? (0xffffffffu >> lg) : 0xffffffffu)) == lgen) {
                                     __hip_atomic_store(pr.lr_word[o] + lslot, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                                     sent = true;
+                                } else if ((++lr_polls & 1023u) == 0u && __hip_atomic_load(pr.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+                                    sent = true;  // (the host gave the step up: PushRings::abort, looked at once per 1024 polls)
                                 } else {
                                     __builtin_amdgcn_s_sleep(8);
                                 }
@@ -2290,7 +2202,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
                                                        __HIP_MEMORY_SCOPE_SYSTEM);
                                 }
                             };
-                            uint32_t written = 0;
+                            uint32_t written = 0, row_polls = 0;
 #pragma unroll
                             for (int u = 0; u < PU; ++u) {
                                 const uint32_t i = row_[u];
@@ -2302,6 +2214,7 @@ __global__ void __launch_bounds__(1024) fw_example_kernel(const KernelParams /* 
                                 for (;;) {
                                     const uint32_t fr = __builtin_amdgcn_readfirstlane(__hip_atomic_load(pr.ffm_free[o_[u]] + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
                                     if ((fr & gmask) == gen) break;
+                                    if ((++row_polls & 1023u) == 0u && __builtin_amdgcn_readfirstlane(__hip_atomic_load(pr.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != 0u) break;  // (the host gave the step up)
                                     if (written) {
                                         announce(written);
                                         written = 0;

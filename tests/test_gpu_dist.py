@@ -508,6 +508,25 @@ def _sgd_expectations(fbt, recs, off, first, n, preds, w0, lr, k, n_ns, bits):
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("n_ranks,log2_rows,log2_lr", [(1, 7, 7), (2, 6, 6), (4, 8, 9)])
 def test_owner_side_apply_streaming_form_delivers_every_gradient_exactly_once(n_ranks, log2_rows, log2_lr):
+    """(body: _streaming_exactly_once below.)  Four in-process ranks on one GPU need a hardware queue each: streams of one process map onto GPU_MAX_HW_QUEUES
+    queues, and once torch is in the process (conftest imports it) the runtime gives four in all, default stream included -- the library's probe then refuses
+    instead of hanging.  The library's own request for eight queues works in a process that loads it FIRST, so the four-rank case runs in a fresh child process
+    that imports neither torch nor pytest's plugins (it used to skip here)."""
+    if n_ranks <= 2:
+        _streaming_exactly_once(n_ranks, log2_rows, log2_lr)
+        return
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = os.pathsep.join([root, os.path.dirname(os.path.abspath(__file__))] + ([env["PYTHONPATH"]] if env.get("PYTHONPATH") else []))
+    env.pop("GPU_MAX_HW_QUEUES", None)  # (the library asks for eight itself, fwgpu_ask_for_hw_queues)
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), "streaming_exactly_once", str(n_ranks), str(log2_rows), str(log2_lr)], env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0 and "streaming_exactly_once ok" in p.stdout, (p.returncode, p.stdout[-1500:], p.stderr[-3000:])
+
+
+def _streaming_exactly_once(n_ranks, log2_rows, log2_lr):
     """The STREAMING owner-side apply (fwgpu_dist_group_learn_owner_stream): circular regions much smaller than a step (64 .. 256 slots for ~9000 gradient rows
     and as many LR words per source and step: dozens of generations, flow control on every slot), consumers draining while the sources push, positions running on
     over two steps.  SGD steps ADD UP (w -= lr * grad), so what every table entry must hold afterwards is computable from the launch's own predictions: a lost,
@@ -533,14 +552,7 @@ def test_owner_side_apply_streaming_form_delivers_every_gradient_exactly_once(n_
             a_, b_ = step * n_ex + j * per, step * n_ex + (j + 1) * per
             rr.append(recs[int(off[a_]):int(off[b_])])
             oo.append(off[a_:b_ + 1] - off[a_])
-        try:
-            preds = np.concatenate(g.learn_owner_stream(fbt, rr, oo, log2_rows=log2_rows, log2_lr=log2_lr, consumer_workgroups=5 * n_ranks))
-        except capi.FwgpuError as e:
-            # four in-process ranks on one GPU need a hardware queue each; with torch in the process (conftest imports it) the runtime gives four in all and the
-            # library's probe refuses instead of hanging.  Four ranks are covered as four PROCESSES (tests/test_gpu_dist_procs.py).
-            if n_ranks > 2 and "do not run at the same time" in str(e):
-                pytest.skip(str(e))
-            raise
+        preds = np.concatenate(g.learn_owner_stream(fbt, rr, oo, log2_rows=log2_rows, log2_lr=log2_lr, consumer_workgroups=5 * n_ranks))
         g.gather_tables()
         d_lr, d_ffm, hits_lr, hits_ffm = _sgd_expectations(fbt, recs, off, step * n_ex, n_ex, preds, w_prev, lr, k, n_ns, bits)
         lrt = regs[0].table_read(capi.TABLE_LR)
@@ -640,3 +652,11 @@ def test_group_sparse_step_is_reproducible_at_scale():
         for r in regs:
             r.close()
     assert sums[0] == sums[1] == sums[2], sums
+
+
+if __name__ == "__main__":  # the torch-free child of the four-rank exactly-once test
+    import sys
+    if len(sys.argv) == 5 and sys.argv[1] == "streaming_exactly_once":
+        assert "torch" not in sys.modules
+        _streaming_exactly_once(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
+        print("streaming_exactly_once ok")

@@ -46,7 +46,11 @@ def _self_launch(n, *flags, timeout=900, env_extra=None):
     """`python3 bench.py --gpus N ...` with NO launcher and no WORLD_SIZE around it: bench.py starts its own N ranks (bench.self_launch)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     env["FWGPU_RCCL_LIBRARY"] = os.path.join(ROOT, "tests", "fake_rccl", "libfwgpu_fakerccl.so")
-    env.update(env_extra or {})
+    for k_, v_ in (env_extra or {}).items():  # (None: unset)
+        if v_ is None:
+            env.pop(k_, None)
+        else:
+            env[k_] = v_
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dist-backend", "gloo", "--same-device", "--library-comm", "--steps", "4",
            "--warmup", "1", "--batch", "2048", "--bits", "20", "--ffm-bits", "20", "--holdout", "1024", "--no-cpu-baseline", "--no-traffic",
            "--other-modes-timeout", "300", *flags]
@@ -71,6 +75,33 @@ def test_self_launch_reports_a_failing_rank_and_ends_the_others():
     assert p.returncode != 0
     assert "rank 3 exited" in p.stderr, p.stderr[-2000:]
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_two_ranks_on_one_device_over_the_real_rccl_fail_fast_and_loudly():
+    """First contact of the REAL library path with N > 1 as far as one GPU allows: two self-launched ranks on cuda:0 with FWGPU_RCCL_LIBRARY
+    unset, i.e. the library's communicator comes from the real librccl -- which refuses two ranks on one device.  What must happen: every rank comes back with an
+    error, the launcher returns non-zero well inside a minute or two, one clear message, no JSON line, nobody left hanging."""
+    import time
+    env = {"FWGPU_RCCL_LIBRARY": None}  # unset: the real librccl
+    t0 = time.time()
+    p = _self_launch(2, "--no-other-modes", "--launch-timeout", "240", timeout=400, env_extra=env)
+    assert p.returncode != 0, (p.stdout[-1000:], p.stderr[-2000:])
+    assert time.time() - t0 < 300
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    err = p.stderr.lower()
+    assert "exited" in err and ("nccl" in err or "rccl" in err or "communicator" in err), p.stderr[-3000:]
+
+
+def test_the_line_carries_dp_modes_when_a_side_leg_hangs():
+    """A side leg that never comes back (a collective that does not complete on a first multi-GPU run) must not cost the line: the watchdog prints rank 0's line with
+    dp_modes.error and the run ends non-zero (FWGPU_BENCH_HANG_OTHER_MODES makes the legs sleep instead of running)."""
+    p = _self_launch(2, "--other-modes-timeout", "20", timeout=600, env_extra={"FWGPU_BENCH_HANG_OTHER_MODES": "1"})
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert lines, (p.stdout[-1000:], p.stderr[-3000:])
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d.get("rccl_ranks") == 2
+    assert "error" in d["dp_modes"] and "did not finish" in d["dp_modes"]["error"], d["dp_modes"]
+    assert p.returncode != 0
 
 
 def test_one_rank_through_the_dist_path_is_within_three_percent_of_the_plain_line():
