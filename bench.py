@@ -780,6 +780,13 @@ def main():
                     if dist_rank is not None:
                         dist_rank.close()
                     dist_rank = None
+                    if args.library_comm:
+                        # --library-comm ASKED for the library's communicator: failing to get it is the run's failure, said once and at once (every rank leaves here,
+                        # after the all-reduce above: nobody waits for anybody)
+                        if rank == 0:
+                            print("[bench] --library-comm: the library's RCCL communicator could not be created on every rank (see the ranks' messages above): no line", file=sys.stderr)
+                        sys.stderr.flush()
+                        os._exit(4)
         tabs = [capi.TABLE_LR, capi.TABLE_FFM_W, capi.TABLE_FFM_ACC]
         if args.nn_layers:  # the dense head is part of the replica (config E)
             tabs += [capi.TABLE_NN_W, capi.TABLE_NN_ACC]

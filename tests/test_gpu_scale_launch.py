@@ -89,7 +89,7 @@ def test_two_ranks_on_one_device_over_the_real_rccl_fail_fast_and_loudly():
     assert time.time() - t0 < 300
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     err = p.stderr.lower()
-    assert "exited" in err and ("nccl" in err or "rccl" in err or "communicator" in err), p.stderr[-3000:]
+    assert "exited" in err and "ncclcomminitrank" in err and "communicator could not be created" in err, p.stderr[-3000:]
 
 
 def test_the_line_carries_dp_modes_when_a_side_leg_hangs():
