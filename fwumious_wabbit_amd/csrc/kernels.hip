@@ -1377,9 +1377,6 @@ __device__ __forceinline__ void update_rows(const KernelParams &p, const Lds &s,
 // device memory; with acc placed away from w (regressor.cpp place_ffm_acc) the float-granular accesses of the same code path
 // (sb = 0, nb = 4R: exactly the row) are as fast, and the race stays at the float.  The duplicate-row chains below are what
 // this path keeps in both cases.
-#ifndef FW_THIN_OVERFLOW  // 1: store policy 3 also on the re-read (overflow) rows of the single-chunk instantiations -- config C's; not measured yet
-#define FW_THIN_OVERFLOW 0
-#endif
 template <int OPT, int AUX, int U, int NCH, int AUX_SW = AUX, int AUX_SA = AUX>
 __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds &s, const uint32_t (&idx)[U], float g,
                                                 int lane, uint32_t nf, const float *gpair = nullptr, uint32_t thin_seed = 0xffffffffu) {
@@ -1470,7 +1467,7 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
             // what this example added (av + m (an - av): unbiased; the step above was taken with the true running accumulator) -- the kept rows' rule of the config-C
             // kernel, for rows that are re-read: the window between this load and this store is one round trip.
             uint32_t acc_bytes = nb[u];
-            if (OPT != FWGPU_OPT_SGD && thin_seed != 0xffffffffu) {  // (the caller passes a seed only where the instantiation thins: two-chunk rows, FW_THIN_OVERFLOW builds, policy 4)
+            if (OPT != FWGPU_OPT_SGD && thin_seed != 0xffffffffu) {  // (the caller passes a seed only where the instantiation thins: two-chunk rows under policy 3, every re-read row under policy 4)
                 const f4 a0 = av[u][c];
                 const bool hot = __ballot(inb && (a0[0] > p.acc_hot_theta || a0[1] > p.acc_hot_theta || a0[2] > p.acc_hot_theta || a0[3] > p.acc_hot_theta)) != 0ull;
                 if (hot) {
@@ -2919,7 +2916,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
         // The rows parked in LDS go there DIRECTLY (LDS-direct loads: no register in between), issued in the same burst as the register rows' loads instead
         // of two at a time behind them: destination = wave-uniform slot base + lane * 16.  -DFW_PARK_FIRST=1 issues them in FRONT of the register rows' loads.
 #ifndef FW_PARK_ASM
-#define FW_PARK_ASM 0
+#define FW_PARK_ASM 1  // (default since round 6: +0.5-1.2 % in three of three interleaved pairs, profiles/r06_park_asm_ab.txt; 0 = the compiler-issued LDS-direct loads)
 #endif
 #ifndef FW_PARK_FIRST
 #define FW_PARK_FIRST FW_PARK_ASM
@@ -3444,7 +3441,7 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                     if (WIN && MAXR > 0 && i >= kb && i < kb + nk2 && !(s.e_fld[i] & kRowHasChain)) idx[u] = 0xffffffffu;
                 }
                 if (WIN)
-                    update_rows_win<OPT, AUX, UO, (NC > FW_WIN_NCH ? NC : FW_WIN_NCH), AUX_SW, AUX_SA>(p, s, idx, g, lane, nf, gpair, (kThin && (NC > 1 || FW_THIN_OVERFLOW || kAtom) && p.store_policy >= 3 && p.grid_wgs > 1 && p.thin_reread) ? ex : 0xffffffffu);
+                    update_rows_win<OPT, AUX, UO, (NC > FW_WIN_NCH ? NC : FW_WIN_NCH), AUX_SW, AUX_SA>(p, s, idx, g, lane, nf, gpair, (kThin && (NC > 1 || kAtom) && p.store_policy >= 3 && p.grid_wgs > 1 && p.thin_reread) ? ex : 0xffffffffu);
                 else
                     update_rows<VEC, OPT, AUX, UO, false, NC>(p, s, idx, g, lane);
             }

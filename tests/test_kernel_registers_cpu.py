@@ -15,7 +15,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 CASES = [
     # instantiation, second translation unit (-DFW_PHASE_TU), most VGPR spills allowed
     ("fw_example_kernel_r<300, true, 20, true, 1, 4>", False, 1),   # config C, store policy 4 (the shipped default since round 6)
-    ("fw_example_kernel_r<300, true, 20, true, 1, 3>", False, 2),   # config C, store policy 3 (round 5's)
+    ("fw_example_kernel_r<300, true, 20, true, 1, 3>", False, 5),   # config C, store policy 3 (round 5's; an A/B policy since round 6: 5 spilled vector registers with the asm-issued parked rows, FW_PARK_ASM)
     ("fw_example_kernel_r<300, true, 20, true, 1, 1>", False, 4),   # config C, round 4's store policy
     ("fw_example_kernel_r<300, true, 0, true, 2, 4>", False, 0),    # two-chunk rows (k = 16), updating
     ("fw_example_kernel_r<100, false, 0, false, 2, 4>", False, 0),  # ... predict-only (config E's batched head path)
