@@ -433,6 +433,16 @@ static int prepare_launch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int upda
     if ((uint64_t)p.max_ffm > 4ull * threads) threads = 1024;
     if ((uint64_t)p.max_ffm > 4ull * threads)
         return fail(FWGPU_ERR_RANGE, "an example has more than 4096 FFM features");
+    // Small examples (BASELINE configs[1]: 10 features, 11 LR entries): a 512-thread workgroup has eight waves for ten rows, and the rate of such a launch is (examples in
+    // flight) / (an example's latency) with MORE than ~512 in flight costing both rate and loss (the hot LR entries' lines).  Two waves per example and two workgroups per CU:
+    // 13.8 M examples/s at hold-out 0.59431 against 11.9 M at 0.59419 for the 512-thread shape (profiles/r06_configB_time_to_loss_table.txt).  FWGPU_SMALL_SHAPE=0: the old shape.
+    {
+        static const char *env_ss = getenv("FWGPU_SMALL_SHAPE");
+        if (!(env_ss && env_ss[0] == '0') && p.concurrent && update && !r->launch.threads_set && !p.nn.n_layers && p.max_ffm <= 32 && p.max_lr <= 64) {
+            threads = 128;
+            if (!p.host_grid_cap) p.host_grid_cap = 2 * r->num_cus;
+        }
+    }
     // Config E's concurrent launches: the deep head as a phase of the v2 kernel's two-chunk instantiation (kernels.hip fw_example_kernel_r<..., NN = true>) where TWO of its
     // 512-thread workgroups fit a CU -- the AdaGrad LUT read through L1, no record prefetch, no LDS copy of the entries' own slots -- instead of one 1024-thread workgroup
     // of the generic kernel.  In-order launches (the parity mode) and shapes that do not fit stay on the generic kernel.  fwgpu_debug_set_option(r, 11, 0) / FWGPU_NN_V2=0: off.
