@@ -1831,7 +1831,7 @@ int stream_launch(fwgpu_dist *d, const StreamGeom &geo, unsigned char *const bas
     // stripe per round and the producers' flow control must never wait for a row such a round holds)
     const uint32_t max_waves = (uint32_t)std::min<uint64_t>(0x7fffffffull, ((uint64_t)1 << geo.lg_ffm) / 4 * N + N);
     return run_batch_peer(d->r, d->cur, FWGPU_MODE_HOGWILD, update, d->d_peers, d->stream, reinterpret_cast<const PushRings *>(d->st_mem + geo.off_push), pr.consumers,
-                          d->st_share, max_waves);
+                          d->st_share, max_waves, N);
 }
 // the launch has ended: where this rank's regions (as owner) stand now = where the next step's consumers start
 // A streaming launch waits INSIDE the kernel for its peers (consumers for tags and final positions, producers for free slots): a peer that never launches --

@@ -174,6 +174,7 @@ struct KernelParams {
     uint32_t host_cus, host_wgs_cap, host_grid_cap;    // host side only: persistent grid = occupancy x CUs (capped), when launched with grid 0
     uint32_t grid_wgs;                                 // workgroups of THIS launch, filled in by launch_persistent: the example kernels read it here where they need it (gridDim.x, an implicit argument, is loaded once in the prologue and then lives in a scalar register across the whole example loop)
     uint32_t host_share;                               // host side only: ranks whose kernels must be RESIDENT TOGETHER on this device (streaming owner-side apply on a shared device): the persistent grid is an equal share of what the device holds (0 / 1: all of it)
+    uint32_t host_stream_min_consumer_waves;           // host side only: floor of the automatic consumer count (two waves per source)
     uint32_t host_stream_max_consumer_waves;           // host side only: bound on the consumer waves of a streaming launch (a stripe's stride must stay well below a region's capacity)
     uint32_t host_extra_wgs;                           // host side only: (0xffffffff: a share of the grid chosen at launch, written to PushRings::consumers before the kernel starts)
                                                        // host side only: workgroups on top of the example workgroups (streaming owner-side apply: the consumers; at least one producer workgroup is kept)
@@ -547,7 +548,7 @@ void lut_init(float *lut, float learning_rate, float power_t, float init_acc);
 KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int update);
 // the fused learn / predict launch of `b` with every row and LR entry reached in its owner's tables (generic kernel); d_shards: device copy
 int run_batch_peer(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, const PeerShards *d_shards, hipStream_t stream,
-                   const PushRings *d_push = nullptr, uint32_t stream_consumers = 0, uint32_t device_share = 1, uint32_t stream_max_consumer_waves = 0);
+                   const PushRings *d_push = nullptr, uint32_t stream_consumers = 0, uint32_t device_share = 1, uint32_t stream_max_consumer_waves = 0, uint32_t n_ranks = 0);
 // owner-side apply: the optimizer steps of `n_rows` pushed gradient rows / `n_lr` pushed LR gradients on this regressor's own tables
 hipError_t launch_rendezvous(uint32_t *counter, uint32_t n, uint32_t *met, hipStream_t stream);
 hipError_t launch_owner_apply(const fwgpu_regressor *r, float *lr_base, const uint32_t *keys, const float *rows, uint32_t n_rows, const uint2 *lr_ent,

@@ -2423,6 +2423,10 @@ static hipError_t launch_persistent(K kern, const KernelParams &p, uint32_t grid
                 extra = std::max<uint32_t>(1u, (uint32_t)(g * eighths / 8));
                 const uint32_t waves = threads / 64u;
                 if (p.host_stream_max_consumer_waves && extra * waves > p.host_stream_max_consumer_waves) extra = std::max<uint32_t>(1u, p.host_stream_max_consumer_waves / waves);
+                // ... and never fewer consumer waves than two per source (one for its LR region, one for its row region: dist.cpp stream_consumer_wgs keeps the same floor
+                // for an explicit count) -- a tiny grid's share would leave a source's regions undrained
+                if (p.host_stream_min_consumer_waves)
+                    while (extra * waves < p.host_stream_min_consumer_waves) extra++;
                 static thread_local uint32_t slot[64];
                 static thread_local uint32_t next = 0;
                 uint32_t *v = &slot[next++ & 63u];
@@ -2927,7 +2931,6 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                 for (int j = 0; j < LKM; ++j) {
                     if ((uint32_t)(MAXR + j) < nk2) {
                         const uint32_t h = __builtin_amdgcn_readfirstlane(s.e_hash[lo + MAXR + j]);
-                        const float *src = p.ffm_w + h + e0;
                         float *dst = s.keep + ((uint32_t)wave * lk + (uint32_t)j) * R;
                         if (inb) {
 #if FW_PARK_ASM
@@ -2937,11 +2940,14 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
                             const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)dst);
                             const uint32_t voff = e0 * 4u;
                             const float *sbase = p.ffm_w + h;
+                            // (m0 is a reserved register the compiler keeps for its own LDS-direct loads -- the record prefetch -- and does not accept as a clobber: saved and restored)
+                            uint32_t m0_saved;
                             if (AUX_G == kAuxSc1)
-                                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1" ::"s"(lds_base), "v"(voff), "s"(sbase) : "m0", "memory");
+                                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 sc1\n\ts_mov_b32 m0, %0" : "=&s"(m0_saved) : "s"(lds_base), "v"(voff), "s"(sbase) : "memory");
                             else
-                                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_base), "v"(voff), "s"(sbase) : "m0", "memory");
+                                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0" : "=&s"(m0_saved) : "s"(lds_base), "v"(voff), "s"(sbase) : "memory");
 #else
+                            const float *src = p.ffm_w + h + e0;
                             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                              (__attribute__((address_space(3))) void *)dst, 16, 0, AUX_G);
 #endif

@@ -438,7 +438,8 @@ static int prepare_launch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int upda
     // 13.8 M examples/s at hold-out 0.59431 against 11.9 M at 0.59419 for the 512-thread shape (profiles/r06_configB_time_to_loss_table.txt).  FWGPU_SMALL_SHAPE=0: the old shape.
     {
         static const char *env_ss = getenv("FWGPU_SMALL_SHAPE");
-        if (!(env_ss && env_ss[0] == '0') && p.concurrent && update && !r->launch.threads_set && !p.nn.n_layers && p.max_ffm <= 32 && p.max_lr <= 64) {
+        // (not the generic kernel forced by kernel_version 1: the peer-sharded and streaming launches size their consumer workgroups by the regressor's own workgroup size)
+        if (!(env_ss && env_ss[0] == '0') && p.concurrent && update && !r->launch.threads_set && r->launch.kernel_version != 1 && !p.nn.n_layers && p.max_ffm <= 32 && p.max_lr <= 64) {
             threads = 128;
             if (!p.host_grid_cap) p.host_grid_cap = 2 * r->num_cus;
         }
@@ -583,7 +584,7 @@ static int run_batch_head_predict(fwgpu_regressor *r, fwgpu_batch *b, hipStream_
 }
 
 int run_batch_peer(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, const PeerShards *d_shards, hipStream_t stream,
-                   const PushRings *d_push, uint32_t stream_consumers, uint32_t device_share, uint32_t stream_max_consumer_waves) {
+                   const PushRings *d_push, uint32_t stream_consumers, uint32_t device_share, uint32_t stream_max_consumer_waves, uint32_t n_ranks) {
     if (b->n == 0 && !stream_consumers) return FWGPU_OK;  // (a streaming step launches for an empty batch too: the rank's consumers serve the peers)
     if (r->nn.n_layers) return fail(FWGPU_ERR_INVALID, "peer-sharded tables: models with a deep head are not covered");
     KernelParams p;
@@ -599,6 +600,7 @@ int run_batch_peer(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, con
     p.host_extra_wgs = stream_consumers;
     p.host_share = device_share;
     p.host_stream_max_consumer_waves = stream_max_consumer_waves;
+    p.host_stream_min_consumer_waves = (d_push && stream_consumers) ? 2u * (n_ranks ? n_ranks : 1u) : 0u;
     const uint32_t grid = pick_grid(r, p, mode, threads);
     FWGPU_HIP(hipMemsetAsync(b->work, 0, sizeof(uint32_t), stream));
     FWGPU_HIP(launch_example_kernel(p, r->cfg.optimizer, update != 0, grid, threads, stream));
