@@ -189,6 +189,7 @@ struct fwgpu_dist {
     uint32_t st_step = 0;              // streaming steps since the last reset (tags the final positions: a consumer only believes its own step's)
     uint32_t *st_abort = nullptr;      // pinned host word every wait loop of a streaming launch looks at (kernels.hip PushRings::abort): set by stream_finish when a step
                                        // outlives its deadline -- written by a plain host store, so that giving a step up needs no queue of a device whose CUs the step holds
+    uint32_t st_next_check = 0;        // process-per-rank form: the step at which the ranks next agree on "is any region close to the 32-bit position wrap"
     bool st_void = false;              // a step was given up: positions, tags and free generations no longer agree between the ranks (terminal for the streaming form of this rank)
     unsigned char *st_peer[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // every rank's st_mem as reachable from here
     PeerShards *d_peers = nullptr;   // peer-sharded step: the owners' table bases, on this rank's device
@@ -1742,6 +1743,7 @@ int stream_reset(fwgpu_dist *d) {
     FWGPU_HIP(hipStreamSynchronize(d->stream));
     for (int s = 0; s < 8; s++) d->st_pos_ffm[s] = d->st_pos_lr[s] = 0;
     d->st_step = 0;
+    d->st_next_check = 0;
     return FWGPU_OK;
 }
 // do the kernels of these ranks (which share device `dev`) run at the same time?  (kernels.hip rendezvous_kernel)
@@ -2231,18 +2233,26 @@ int fwgpu_dist_learn_owner_stream(fwgpu_dist *d, const fwgpu_translator_config *
     if (rc) return rc;
     bool near_wrap = false;
     if ((rc = stream_finish(d, geo, update, &near_wrap))) return rc;
-    if (N > 1 && (d->st_step & 1023u) == 0) {  // (every 1024 steps: does ANY rank come close to the wrap?  one word, all-reduced)
-        float flag = near_wrap ? 1.0f : 0.0f;
-        FWGPU_HIP(hipMemcpyAsync(d->d_shape, &flag, 4, hipMemcpyHostToDevice, d->stream));
+    if (N > 1 && d->st_step >= d->st_next_check) {
+        // Does ANY rank come close to the positions' 32-bit wrap?  Two words, all-reduced: the flag, and this step's bound on the positions a region can advance by (examples x
+        // the longest example's entries, summed over the ranks: an upper bound for every (owner, source) region).  The NEXT check is due before 2^28 more positions can have
+        // passed at that pace -- the same step on every rank, since it is computed from the all-reduced value (round 5 checked every 1024 steps whatever the step's size:
+        // steps of 65 536 examples on two ranks advance a region by 6.5 M positions each and would have wrapped in between).
+        const uint64_t own_bound = (uint64_t)std::max(shape[0], shape[1]) * (uint64_t)shape[3];
+        float v2[2] = {near_wrap ? 1.0f : 0.0f, (float)own_bound};
+        FWGPU_HIP(hipMemcpyAsync(d->d_shape, v2, 8, hipMemcpyHostToDevice, d->stream));
         FWGPU_HIP(hipStreamSynchronize(d->stream));
-        FWGPU_NCCL(g_rccl.AllReduce(d->d_shape, d->d_shape, 1, ncclFloat, ncclSum, d->comm, d->stream));
+        FWGPU_NCCL(g_rccl.AllReduce(d->d_shape, d->d_shape, 2, ncclFloat, ncclSum, d->comm, d->stream));
         if ((rc = wait_stream(d))) return rc;
-        FWGPU_HIP(hipMemcpy(&flag, d->d_shape, 4, hipMemcpyDeviceToHost));
-        if (flag > 0.0f) {
+        FWGPU_HIP(hipMemcpy(v2, d->d_shape, 8, hipMemcpyDeviceToHost));
+        if (v2[0] > 0.0f) {
             if ((rc = fwgpu_dist_barrier(d))) return rc;
             if ((rc = stream_reset(d))) return rc;
             if ((rc = fwgpu_dist_barrier(d))) return rc;
         }
+        const double per_step = std::max(1.0, (double)v2[1]);
+        const double period = std::min(1024.0, std::max(1.0, std::floor(268435456.0 / per_step)));
+        d->st_next_check = d->st_step + (uint32_t)period;
     } else if (N == 1 && near_wrap) {
         if ((rc = stream_reset(d))) return rc;
     }
