@@ -383,7 +383,7 @@ def long_protocol(args):
         re.set_store_policy(args.store_policy)
     fbt = fw.FeatureBufferTranslator(mi)
     t0 = time.time()
-    gen_threads = min(64, os.cpu_count() or 8)
+    gen_threads = min(128, os.cpu_count() or 8)
     batches, words = [], []
     for s in range(K):  # generated and uploaded step by step: 29 GB of records end up in HBM, never in host memory at once
         recs, off = gen_records(fw, args, s * B, B, threads=gen_threads)

@@ -1409,6 +1409,11 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
             }
         }
     }
+    // Every row of the batch is stepped before any row is stored.  vmcnt counts in issue order: a row's AdaGrad-table lookups (through L1 in the two-chunk launches) and the
+    // next chunk's would otherwise wait behind the acknowledgement of the write-through stores just issued -- one drain per chunk; with U rows in flight that is what kept
+    // the batch from paying (round 6).  The stepped values replace the loaded ones in place (lanes outside the row keep theirs bit for bit); what the accumulator side of a
+    // chunk does -- store the new row, store nothing, add a delta -- is one bit each of two scalar registers.
+    uint32_t st_mask = 0, add_mask = 0;  // bit u * NCH + c: the chunk's accumulators are stored / added (store policy 4, a hot row on the example's turn: av then holds the delta)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         if (nb[u] == 0) continue;
@@ -1461,13 +1466,11 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
                 wn = wv[u][c];
                 an = av[u][c];
             }
-            const uint32_t fl = hh[u] - (sb[u] >> 2);
-            Vec<4>::template store<AUX_SW>(wn, make_rsrc(p.ffm_w + fl, nb[u]), c * 1024 + lane * 16);
-            // Store policy 3 on two-chunk rows (thin_seed given): a row whose accumulators exceed acc_hot_theta stores them for one example in m only, with m times
-            // what this example added (av + m (an - av): unbiased; the step above was taken with the true running accumulator) -- the kept rows' rule of the config-C
-            // kernel, for rows that are re-read: the window between this load and this store is one round trip.
-            uint32_t acc_bytes = nb[u];
-            if (OPT != FWGPU_OPT_SGD && thin_seed != 0xffffffffu) {  // (the caller passes a seed only where the instantiation thins: two-chunk rows under policy 3, every re-read row under policy 4)
+            // Store policies 3 / 4 on re-read rows (thin_seed given: two-chunk rows under policy 3, every re-read row under policy 4): a row whose accumulators exceed
+            // acc_hot_theta is touched by one example in m only.  Policy 3: that example stores av + m (an - av) (unbiased; the step above was taken with the true running
+            // accumulator); policy 4: it ADDS m (an - av) -- what it and its chained duplicates added, m-fold -- and nobody stores (lanes outside the row add 0).
+            bool st = OPT != FWGPU_OPT_SGD, ad = false;
+            if (OPT != FWGPU_OPT_SGD && thin_seed != 0xffffffffu) {
                 const f4 a0 = av[u][c];
                 const bool hot = __ballot(inb && (a0[0] > p.acc_hot_theta || a0[1] > p.acc_hot_theta || a0[2] > p.acc_hot_theta || a0[3] > p.acc_hot_theta)) != 0ull;
                 if (hot) {
@@ -1475,24 +1478,41 @@ __device__ __forceinline__ void update_rows_win(const KernelParams &p, const Lds
                     const uint32_t draw = ((thin_seed * 2654435761u) ^ (idx[u] * 40503u + (uint32_t)c * 9973u)) >> 9;
                     const bool turn = (draw & (m - 1u)) == 0u;
                     if (p.store_policy == 4) {
-                        // policy 4: the example whose turn it is ADDS m x what it (and its chained duplicates) added; nobody stores.  Lanes outside the row add 0.
-                        acc_bytes = 0;
-                        if (turn) {
-                            const float mf = (float)m;
-                            const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.ffm_acc + fl, nb[u]);
+                        st = false;
+                        ad = turn;
+                        const float mf = (float)m;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(mf * (an[j] - a0[j]), ra, c * 1024 + lane * 16 + 4 * j, 0, kAuxSc1);
-                        }
+                        for (int j = 0; j < 4; ++j) an[j] = mf * (an[j] - a0[j]);
                     } else {
-                        if (!turn) acc_bytes = 0;  // (not this example's turn: the store is dropped)
+                        st = turn;
                         const float ms = (float)(m - 1u);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) an[j] = an[j] + ms * (an[j] - a0[j]);
                     }
                 }
             }
-            if (OPT != FWGPU_OPT_SGD) Vec<4>::template store<AUX_SA>(an, make_rsrc(p.ffm_acc + fl, acc_bytes), c * 1024 + lane * 16);
+            wv[u][c] = wn;
+            av[u][c] = an;
+            st_mask |= (st ? 1u : 0u) << (u * NCH + c);
+            add_mask |= (ad ? 1u : 0u) << (u * NCH + c);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (nb[u] == 0) continue;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (nb[u] <= (uint32_t)c * 1024u) continue;
+            const uint32_t fl = hh[u] - (sb[u] >> 2);
+            Vec<4>::template store<AUX_SW>(wv[u][c], make_rsrc(p.ffm_w + fl, nb[u]), c * 1024 + lane * 16);
+            if (OPT != FWGPU_OPT_SGD) {
+                Vec<4>::template store<AUX_SA>(av[u][c], make_rsrc(p.ffm_acc + fl, ((st_mask >> (u * NCH + c)) & 1u) ? nb[u] : 0u), c * 1024 + lane * 16);
+                if ((add_mask >> (u * NCH + c)) & 1u) {  // (wave-uniform; fire-and-forget)
+                    const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.ffm_acc + fl, nb[u]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(av[u][c][j], ra, c * 1024 + lane * 16 + 4 * j, 0, kAuxSc1);
+                }
+            }
         }
     }
 }
@@ -2750,9 +2770,12 @@ __global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WI
 #ifndef FW_UO_NN
 #define FW_UO_NN FW_UO
 #endif
+#ifndef FW_UO_NC2  // ... of the headless two-chunk instantiations
+#define FW_UO_NC2 FW_UO
+#endif
     // overflow rows (w + acc) in flight per wave.  (With the deep head, FW_UO_NN: 2, 4 and 5 rows per round trip were measured against 1 in round 6 -- 1.31-1.34 / 1.26 / 1.28-1.30 M
     // examples/s against 1.33-1.39 M: the update's share of an example's lifetime does not shrink with the rows in flight, profiles/r06_configE_v2_head.txt.)
-    constexpr int UO = NN ? FW_UO_NN : FW_UO;
+    constexpr int UO = NN ? FW_UO_NN : (NC == 2 ? FW_UO_NC2 : FW_UO);
     extern __shared__ __align__(16) unsigned char smem[];
     // Single-chunk rows (configs B / C): the AdaGrad LUT is ALWAYS the LDS copy, decided at compile time -- s.lut is then an LDS pointer the
     // compiler can see through (ds_read_b32).  As a run-time choice between the LDS copy and the global table the pointer was generic: every
