@@ -72,3 +72,32 @@ def test_second_stream_family_at_config_c_size_two_sided():
     assert v["abs_diff"] <= FAM2_TOL, v
     assert v["non_increasing_after_minimum"], v
     assert d["final_logloss"] < d["holdout_prior_logloss"] - 0.05
+
+
+LONG64_TOL = 0.005  # 1.3 x the largest |GPU - oracle hogwild16| measured at 64 Mi examples (0.0023 / 0.0037 on two passes: profiles/r06_store_policy4_long64_b.txt against 0.6378)
+
+
+@pytest.mark.timeout(1500)
+def test_the_metrics_protocol_at_64_mi_examples_two_sided():
+    """The metric's own protocol run OUT: 64 Mi training examples of BASELINE configs[2]'s stream (116 GB of records resident in HBM), the 262 144-example hold-out,
+    two passes from freshly initialised weights -- `bench.py --long --examples 67108864` -- against the committed curve of the reference's own concurrent mode (the CPU oracle's
+    16-thread hogwild run on the same stream, tests/golden/bench_oracle_curve_hog16_r4_64mi.json: 0.6378 at the end, flat within 0.001 from 17 M examples on).
+    TWO-sided.  bench.py's own verdict uses the tolerance stated before the runs were made (0.003; the two passes measured read 0.0023 and 0.0037 BELOW the reference, so it can go
+    either way); this test's bound follows the suite's rule for statistical tests, 1.3 x the largest gap measured.  The curve's shape is asserted as it is: a minimum between 4 M and 10 M
+    examples 0.012-0.017 below the reference, then a rise to a plateau the last quarter of the run no longer leaves (|final - value at 48 Mi| <= 0.002)."""
+    import multiprocessing
+    if multiprocessing.cpu_count() < 32:
+        pytest.skip("generating 64 Mi examples of records needs the GPU box's host cores")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--long", "--examples", "67108864", "--long-passes", "2"], env=env, capture_output=True, text=True, timeout=1400)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    v = d["final_logloss_vs_oracle"]
+    assert v is not None and v["two_sided"] and v["reference"].startswith("oracle, 16-thread"), v
+    curve = {int(n): float(x[0]) for n, x in d["logloss_after_examples"].items()}
+    print(f"64 Mi examples: {d['value'] / 1e6:.2f} M examples/s, GPU final {d['final_logloss_passes']}, reference {v['reference_final']:.4f}, |diff| {v['abs_diff']:.4f} "
+          f"(bench.py's verdict at {v['tolerance']}: {v['within']}), minimum {v['minimum']:.4f} at {v['minimum_at_examples'] / 1e6:.1f} M, rise {v['rise_after_minimum']:.4f}")
+    assert v["abs_diff"] <= LONG64_TOL, v
+    assert 4e6 <= v["minimum_at_examples"] <= 10.5e6 and 0.010 <= v["reference_final"] - v["minimum"] <= 0.020, v
+    assert abs(curve[67108864] - curve[50331648]) <= 0.002, (curve[50331648], curve[67108864])
+    assert d["roofline"]["frac"] > 0.55
