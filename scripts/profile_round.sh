@@ -12,8 +12,11 @@ tail -c 600 $OUT/${TAG}_bench.json
 timeout 900 python3 bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_driver_shape.json 2> $OUT/${TAG}_bench_driver_shape.err
 timeout 900 python3 bench.py --long > $OUT/${TAG}_bench_long.json 2> $OUT/${TAG}_bench_long.err
 tail -c 400 $OUT/${TAG}_bench_long.json
+# ... run out: 64 Mi examples, two passes, against the 16-thread hogwild oracle's committed curve (round 6)
+timeout 1200 python3 bench.py --long --examples 67108864 --long-passes 2 > $OUT/${TAG}_bench_long64.json 2> $OUT/${TAG}_bench_long64.err
+tail -c 300 $OUT/${TAG}_bench_long64.json
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --no-cpu-baseline --no-traffic --no-config-e --no-config-b"  # (the default shape: 4 + 48 steps -- the kernel gets faster over the first steps as rows turn hot, store policy 3)
+CMD="python3 $R/bench.py --no-cpu-baseline --no-traffic --no-config-e --no-config-b"  # (the default shape: 4 + 48 steps -- the kernel gets faster over the first steps as rows turn hot, store policy 4)
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o trace -- $CMD > $OUT/${TAG}_trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --pmc FETCH_SIZE -d $OUT/${TAG}_fetch -o fetch -- $CMD > $OUT/${TAG}_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --pmc WRITE_SIZE -d $OUT/${TAG}_write -o write -- $CMD > $OUT/${TAG}_write.log 2>&1
