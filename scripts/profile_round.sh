@@ -23,6 +23,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --pmc WRITE_SIZE -d $OUT/${TAG}_wri
 cd $R
 python3 scripts/rocprof_summary.py $(find $OUT/${TAG}_trace $OUT/${TAG}_fetch $OUT/${TAG}_write -name "*.db" | sort) > $OUT/${TAG}_kernel_rocprofv3.txt 2>&1
 head -40 $OUT/${TAG}_kernel_rocprofv3.txt
+rm -rf $OUT/${TAG}_trace $OUT/${TAG}_fetch $OUT/${TAG}_write  # (the rocpd databases: tens of MB each; gpurun merges at most 64 MiB back -- round 6 lost a whole evidence run to them)
 # the multi-GPU code paths with ONE rank over RCCL (library communicator): replica exchange + sharded leg, then the sharded step as the timed mode
 MASTER_ADDR=127.0.0.1 MASTER_PORT=29544 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 600 python3 bench.py --force-dist --no-cpu-baseline --no-traffic > $OUT/${TAG}_bench_dist1_replica.json 2> $OUT/${TAG}_bench_dist1_replica.err
 MASTER_ADDR=127.0.0.1 MASTER_PORT=29545 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 600 python3 bench.py --force-dist --dp-mode sharded --steps 192 --no-cpu-baseline --no-traffic > $OUT/${TAG}_bench_dist1_sharded.json 2> $OUT/${TAG}_bench_dist1_sharded.err
@@ -40,3 +41,4 @@ timeout 600 rocprofv3 --kernel-trace --stats --pmc WRITE_SIZE -d $OUT/${TAG}_E_w
 cd $R
 python3 scripts/rocprof_summary.py $(find $OUT/${TAG}_E_trace $OUT/${TAG}_E_fetch $OUT/${TAG}_E_write -name "*.db" | sort) > $OUT/${TAG}_configE_rocprofv3.txt 2>&1
 head -12 $OUT/${TAG}_configE_rocprofv3.txt
+rm -rf $OUT/${TAG}_E_trace $OUT/${TAG}_E_fetch $OUT/${TAG}_E_write
