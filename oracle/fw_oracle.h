@@ -178,6 +178,10 @@ void fwo_learn_minibatch(fwo_model *m, const fwo_translator *t, const uint32_t *
 /* Row-sparse gradient buckets: update rule of the library's multi-GPU "sparse" mode (one optimizer step per table row and batch,
  * gradient summed over the row's occurrences; parts = the ranks' micro-batches, examples [part_end[p-1], part_end[p])).
  * Models without a deep head. */
+/* An emulation of the device's concurrent mode for analysis (windows of examples scored against the window's first tables; flags bit 0: FFM weights written back as
+ * start value - step, last writer wins; bit 1: accumulators likewise): NOT a reference code path, see fw_oracle.c */
+void fwo_learn_window_emulation(fwo_model *m, const fwo_translator *t, const uint32_t *records, const uint64_t *rec_off, uint64_t n, uint32_t window,
+                                uint32_t flags, float *preds);
 void fwo_learn_sparse(fwo_model *m, const fwo_translator *t, const uint32_t *records, const uint64_t *rec_off, uint64_t n,
                       const uint64_t *part_end, uint32_t n_parts, float *preds);
 

@@ -147,6 +147,8 @@ def lib(native=False):
     L.fwo_ffm_hash_mask.argtypes = [C.c_uint32, C.c_uint32]
     L.fwo_translate.restype = C.c_int
     L.fwo_translate.argtypes = [C.POINTER(Translator), vp, vp, C.c_uint32, u32p, vp, C.c_uint32, u32p, f32p, f32p]
+    L.fwo_learn_window_emulation.restype = None
+    L.fwo_learn_window_emulation.argtypes = [vp, C.POINTER(Translator), vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp]
     L.fwo_learn_minibatch.restype = None
     L.fwo_learn_minibatch.argtypes = [vp, C.POINTER(Translator), vp, vp, C.c_uint64, vp]
     L.fwo_learn_sparse.restype = None
@@ -315,6 +317,15 @@ class Model:
         n = len(rec_off) - 1
         preds = np.zeros(n, dtype=np.float32)
         self.L.fwo_learn_minibatch(self.h, C.byref(tspec.c), _ptr(records), _ptr(rec_off), n, _ptr(preds))
+        return preds
+
+    def learn_window_emulation(self, tspec, records, rec_off, window, flags, want_preds=False):
+        """emulation of the device's concurrent mode (fw_oracle.c fwo_learn_window_emulation): analysis only, not a reference code path"""
+        records = np.ascontiguousarray(records, dtype=np.uint32)
+        rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
+        n = len(rec_off) - 1
+        preds = np.zeros(n, dtype=np.float32) if want_preds else None
+        self.L.fwo_learn_window_emulation(self.h, C.byref(tspec.c), _ptr(records), _ptr(rec_off), n, int(window), int(flags), _ptr(preds) if want_preds else None)
         return preds
 
     def learn_sparse(self, tspec, records, rec_off, part_end=None):
