@@ -2742,7 +2742,13 @@ template <int OPT, bool COH, int MAXR, bool WIN, int NC = 1, int POL = FW_DEFAUL
 #ifndef FW_LB_WAVES_WIN  // the window path (config C's updating launches): FOUR waves per SIMD = two workgroups per CU, 128 registers -- room for
 #define FW_LB_WAVES_WIN 4  // 14 (round 4: 20) kept rows per wave; faster AND better than three workgroups with 8 kept rows
 #endif
-__global__ void __launch_bounds__(FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WIN : FW_LB_WAVES) : 4) fw_example_kernel_r(const KernelParams /* read through kp_fresh() */) {
+#ifndef FW_NN_THREADS  // workgroup size / waves per SIMD of the instantiation with the deep head as a phase (config E's concurrent launches)
+#define FW_NN_THREADS 512
+#endif
+#ifndef FW_NN_WAVES
+#define FW_NN_WAVES 4
+#endif
+__global__ void __launch_bounds__(NN ? FW_NN_THREADS : FW_LB_THREADS, NC == 1 ? (WIN ? FW_LB_WAVES_WIN : FW_LB_WAVES) : (NN ? FW_NN_WAVES : 4)) fw_example_kernel_r(const KernelParams /* read through kp_fresh() */) {
     const KernelParams &p = kp_fresh();
     static_assert(NC == 1 || MAXR == 0, "resident rows are a single-chunk feature");
     static_assert(!NN || (NC == 2 && WIN && COH), "the head is a phase of the concurrent two-chunk instantiation only");
@@ -3568,9 +3574,10 @@ static bool uses_resident_kernel(const KernelParams &p, uint32_t threads) {
     const bool fits = p.R <= 64 * 4 || (p.R <= 64 * 4 * 2 && p.k != 0 && 256 % p.k == 0);
     // a deep head: read-only launches that only form its input (emit_x), and -- nn_v2, chosen by prepare_launch where two workgroups fit a CU -- config E's concurrent updating launches
     const bool head_ok = p.nn.n_layers == 0 || (p.emit_x && !p.update) || (p.nn_v2 && p.update && p.R > 64 * 4);
-    return p.k % 4 == 0 && p.aligned4 && fits && p.kernel_version != 1 && head_ok && threads <= FW_LB_THREADS;
+    return p.k % 4 == 0 && p.aligned4 && fits && p.kernel_version != 1 && head_ok && threads <= ((p.nn_v2 && p.update) ? (FW_NN_THREADS > FW_LB_THREADS ? FW_NN_THREADS : FW_LB_THREADS) : FW_LB_THREADS);
 }
 bool example_kernel_is_resident(const KernelParams &p, uint32_t threads) { return uses_resident_kernel(p, threads); }
+uint32_t nn_v2_threads() { return FW_NN_THREADS; }
 // Whole-line updates and duplicate-row chains exist in the v2 kernel's update path only, and only updating launches need them.
 void resolve_row_mode(KernelParams &p, uint32_t threads) {
     p.window = (p.window && uses_resident_kernel(p, threads) && p.update && p.k_log2 != 0xffu) ? 1 : 0;

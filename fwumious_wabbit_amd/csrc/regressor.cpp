@@ -425,6 +425,7 @@ uint32_t pick_grid(const fwgpu_regressor *r, const KernelParams &p, int mode, ui
 }
 
 // launch shape of a batch: workgroup size, LDS copy of the LUT or not (settles p.window / p.chain / p.lut_global)
+uint32_t nn_v2_threads();  // (kernels.hip: the workgroup size the head-as-a-phase instantiation was built for)
 static int prepare_launch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int update, KernelParams &p, uint32_t &threads) {
     p = make_params(r, b, update);
     p.concurrent = (mode == FWGPU_MODE_HOGWILD && p.host_grid_cap != 1 && b->n > 1) ? 1 : 0;  // (one workgroup -- in-order semantics -- otherwise)
@@ -451,16 +452,17 @@ static int prepare_launch(fwgpu_regressor *r, fwgpu_batch *b, int mode, int upda
         static const char *env_nn = getenv("FWGPU_NN_V2");
         const bool wish = r->launch.nn_v2 >= 0 ? r->launch.nn_v2 != 0 : !(env_nn && env_nn[0] == '0');
         const bool forced = r->launch.nn_v2 == 2;  // (tests: in-order launches too, whatever fits -- the head's wiring in that kernel against the oracle, per example)
-        if (wish && p.nn.n_layers && update && (p.concurrent || forced) && p.window && p.k_log2 != 0xffu && p.R > 64 * 4 && (!r->launch.threads_set || r->launch.threads == 512) && r->launch.kernel_version != 1 && (uint64_t)p.max_ffm <= 4ull * 512) {
+        if (wish && p.nn.n_layers && update && (p.concurrent || forced) && p.window && p.k_log2 != 0xffu && p.R > 64 * 4 && (!r->launch.threads_set || r->launch.threads == nn_v2_threads()) && r->launch.kernel_version != 1 && (uint64_t)p.max_ffm <= 4ull * 512) {
             KernelParams q = p;
             q.nn_v2 = 1;
             q.lut_global = 1;
             q.prefetch = 0;
-            resolve_row_mode(q, 512);
+            const uint32_t th_q = nn_v2_threads();
+            resolve_row_mode(q, th_q);
             const size_t lds_q = example_kernel_lds_bytes(q, r->cfg.optimizer);
-            if (example_kernel_is_resident(q, 512) && q.window && (forced ? lds_q <= r->lds_per_cu : 2 * lds_q <= r->lds_per_cu)) {
+            if (example_kernel_is_resident(q, th_q) && q.window && (forced ? lds_q <= r->lds_per_cu : 2 * lds_q <= r->lds_per_cu)) {
                 p = q;
-                threads = 512;
+                threads = th_q;
             }
         }
     }
