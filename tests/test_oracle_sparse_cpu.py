@@ -73,3 +73,23 @@ def test_repeated_row_takes_one_step_with_the_sum():
     for e in lr:
         G = np.float32(np.float32(g * e["value"]) + np.float32(g * e["value"]))
         assert tab[e["hash"], 1] == np.float32(np.float32(1.0) + G * G)  # init_acc 1.0 + (summed gradient)^2
+
+
+def test_window_emulation_with_one_example_per_window_is_the_sequential_reference():
+    """oracle/fw_oracle.c fwo_learn_window_emulation (round 6: an emulation of the device's concurrent mode, analysis only) must BE the sequential reference when a window holds one
+    example and nothing is written back from the window's start -- bit for bit; with 64 examples per window and last-writer-wins weights it must differ, learn, and stay finite."""
+    import numpy as np
+    import fwumious_wabbit_amd as fw
+    from helpers import logloss, make_pair, record_labels
+    from oracle import fwo
+    mi, ocfg, ots = make_pair(10, 4, 16, 16, fw.Optimizer.AdagradLUT)
+    recs, off = fw.synth_records(10, 1.0, 1.1, 3000, 0.1, 5, 0, 4000)
+    y = record_labels(recs, off)
+    a, b, c = fwo.Model(ocfg), fwo.Model(ocfg), fwo.Model(ocfg)
+    _, p1 = a.run_stream(ots, recs, off, holdout_after=0, nthreads=1)
+    p2 = b.learn_window_emulation(ots, recs, off, 1, 0, want_preds=True)
+    assert np.array_equal(p1, p2) and np.array_equal(a.ffm_weights, b.ffm_weights) and np.array_equal(a.ffm_acc, b.ffm_acc) and np.array_equal(a.lr_table, b.lr_table)
+    p3 = c.learn_window_emulation(ots, recs, off, 64, 1, want_preds=True)
+    assert np.all(np.isfinite(p3)) and not np.array_equal(p1, p3)
+    ll = logloss(p3, y)
+    assert ll[-1000:].mean() < ll[:1000].mean()
