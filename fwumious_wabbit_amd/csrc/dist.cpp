@@ -1718,7 +1718,7 @@ int stream_reserve(fwgpu_dist *d, uint32_t N, uint32_t lg_ffm, uint32_t lg_lr, b
             return fail(FWGPU_ERR_OOM, "owner-side apply, streaming form: no memory for the regions (smaller log2 capacities?)");
         }
         if (!d->st_abort) {
-            if (hipHostMalloc((void **)&d->st_abort, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+            if (hipHostMalloc((void **)&d->st_abort, 64, hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) {
                 (void)hipGetLastError();
                 return fail(FWGPU_ERR_OOM, "owner-side apply, streaming form: no pinned host memory for the abort word");
             }
