@@ -80,6 +80,27 @@ def main():
         np.savez(sys.argv[3], codes=np.asarray(codes, dtype=np.int64), seconds=np.float64(time.time() - t0))
         re.close()  # (the rank object is left to the process exit: its communicator is gone)
         return
+    if mode == "owner_stream_timeout":
+        # The streaming owner-side apply with a peer that is GONE: after one good step the last rank exits without a word.  The others' next step launches a kernel whose
+        # consumers wait for that rank's final positions (and whose producers wait for slots it will never free): with FWGPU_DIST_TIMEOUT_MS set the host's polled wait
+        # sets the abort word, every wait loop of the kernel leaves, and the call returns FWGPU_ERR_PEER; the rank's streaming state is void afterwards (FWGPU_ERR_PEER again).
+        d.owner_stream_attach(int(job["log2_rows"]), int(job["log2_lr"]))
+        a = int(parts[0, :rank].sum())
+        b = a + int(parts[0, rank])
+        sub, so = recs[int(off[a]):int(off[b])], off[a:b + 1] - off[a]
+        d.learn_owner_stream(fbt, sub, so, consumer_workgroups=5 * n_ranks)
+        d.barrier()
+        if rank == n_ranks - 1:
+            os._exit(0)
+        t0 = time.time()
+        for _ in range(2):
+            try:
+                d.learn_owner_stream(fbt, sub, so, consumer_workgroups=5 * n_ranks)
+                codes.append(0)
+            except capi.FwgpuError as e:
+                codes.append(e.code)
+        np.savez(sys.argv[3], codes=np.asarray(codes, dtype=np.int64), seconds=np.float64(time.time() - t0))
+        os._exit(0)  # (the rank's mappings of the gone peer's memory are left to the process exit)
     if mode in ("sharded_fail", "sparse_fail"):
         # Failure model of the collective steps (dist.cpp): a rank whose LOCAL preparation fails still joins the shape exchange with a
         # poisoned shape; every rank returns from the step -- the culprit with its own error, the others with FWGPU_ERR_PEER -- nothing is

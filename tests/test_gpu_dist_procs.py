@@ -258,6 +258,33 @@ def test_a_rank_that_is_gone_ends_the_others_step_through_the_timeout(tmp_path):
         assert float(o["seconds"]) < 60.0, float(o["seconds"])
 
 
+@pytest.mark.timeout(300)
+def test_streaming_owner_apply_with_a_rank_that_is_gone_gives_the_step_up(tmp_path):
+    """the streaming step waits INSIDE the kernel for its peers -- a peer that is gone would hold the GPU for ever.  Two ranks; the second exits after the first
+    step; the first one's next step must come back with FWGPU_ERR_PEER within seconds of FWGPU_DIST_TIMEOUT_MS (the host sets the abort word every wait loop of the kernel
+    looks at) and its streaming state is void afterwards (FWGPU_ERR_PEER again, at once)."""
+    n_ns, k, bits, ffm_bits = 6, 4, 16, 16
+    n_ranks = 2
+    recs, off = fw.synth_records(n_ns, 0.5, 0.0, 10_000_000, 0.3, 79, 0, 800)
+    job = str(tmp_path / "job_stream_timeout.npz")
+    np.savez(job, n_ranks=n_ranks, mode="owner_stream_timeout", n_ns=n_ns, k=k, bits=bits, ffm_bits=ffm_bits, optimizer=int(fw.Optimizer.SGD), lr=0.01, recs=recs,
+             off=off, parts=np.asarray([[400, 400]], dtype=np.int64), id_file=str(tmp_path / "id_stream_timeout"), allreduce=0, no_constant=1, log2_rows=7, log2_lr=7)
+    env = dict(os.environ, FWGPU_RCCL_LIBRARY=FAKE, HSA_ENABLE_IPC_MODE_LEGACY="0", FWGPU_DIST_TIMEOUT_MS="3000")
+    procs = [subprocess.Popen([sys.executable, WORKER, job, str(r), str(tmp_path / f"out_stream_timeout_{r}.npz")], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(n_ranks)]
+    for r, p in enumerate(procs):
+        try:
+            log, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, f"rank {r} failed:\n{log[-3000:]}"
+    o = np.load(str(tmp_path / "out_stream_timeout_0.npz"))
+    assert list(o["codes"]) == [8, 8], o["codes"]  # FWGPU_ERR_PEER: the step was given up; then: the streaming state is void
+    assert 2.0 < float(o["seconds"]) < 60.0, float(o["seconds"])
+
+
 @pytest.mark.timeout(420)
 @pytest.mark.parametrize("n_ranks", [2, 4])
 def test_process_per_rank_streaming_owner_apply_delivers_every_gradient(tmp_path, n_ranks):
