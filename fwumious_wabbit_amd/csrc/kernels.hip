@@ -1230,7 +1230,7 @@ __device__ __forceinline__ void nn_backward(const KernelParams &p, const Lds &s,
 template <int OPT, bool COH, bool SH = false>
 __device__ __forceinline__ void lr_update(const KernelParams &p, const Lds &s, uint32_t nl, float g, const float *gx,
                                           const float *lut_lr, int tid, int bd, uint32_t lo = 0, uint32_t hi = 0xffffffffu, bool use_kept = false,
-                                          float2 kept = float2{0.0f, 0.0f}) {
+                                          float2 kept = float2{0.0f, 0.0f}, uint32_t thin_seed = 0xffffffffu) {
     for (uint32_t t = tid; t < nl; t += bd) {
         const uint32_t fl = s.l_flag[t];
         const uint32_t h = s.l_hash[t];
@@ -1257,6 +1257,7 @@ __device__ __forceinline__ void lr_update(const KernelParams &p, const Lds &s, u
         if (h < lo || h >= hi) continue;  // sharded tables: another rank's entry
         float2 wa = kept;  // (by value: a pointer to the caller's pair would put it in scratch memory)
         if (!(use_kept && t == (uint32_t)tid)) wa = lr_load<COH, SH>(lr_base<SH>(p, h), h);
+        const float acc_read = wa.y;
         {
             const float grad = (gx ? gx[s.l_combo[t]] : g) * s.l_val[t];
             wa.x -= opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, lut_lr);
@@ -1267,6 +1268,18 @@ __device__ __forceinline__ void lr_update(const KernelParams &p, const Lds &s, u
                     const float grad = (gx ? gx[s.l_combo[j]] : g) * s.l_val[j];
                     wa.x -= opt_step<OPT>(grad, wa.y, p.lr_rate, p.lr_minus_power_t, lut_lr);
                 }
+        // Store policy 4 on the LR block (thin_seed given: concurrent launches of the large-table kernel, KernelParams::lr_thin): an entry that is HOT -- its accumulator beyond
+        // lr_hot_theta: an id that thousands of examples have stepped -- is read-modify-written by every example in flight that holds it, and an 8-byte store of {w, acc} that
+        // loses its race loses that example's g^2 (the FFM rows' story, tests/test_gpu_conservation.py).  So the weight alone is stored (4 bytes), and one example in m ADDS m
+        // times what it added to the accumulator with a fire-and-forget float atomic: every g^2 is counted in expectation, as the reference's threads count it (optimizer.rs:147-149).
+        if (COH && !SH && OPT != FWGPU_OPT_SGD && thin_seed != 0xffffffffu && acc_read > p.lr_hot_theta) {
+            float *entry = lr_base<SH>(p, h) + 2 * (size_t)h;
+            __hip_atomic_store(reinterpret_cast<unsigned *>(entry), __float_as_uint(wa.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t m = 1u << p.acc_sample_log2;
+            if (((((thin_seed * 2654435761u) ^ (h * 40503u)) >> 9) & (m - 1u)) == 0u)
+                __hip_atomic_fetch_add(entry + 1, (float)m * (wa.y - acc_read), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
         lr_store<COH, SH>(lr_base<SH>(p, h), h, wa);
     }
 }
@@ -3288,7 +3301,8 @@ __global__ void __launch_bounds__(NN ? FW_NN_THREADS : FW_LB_THREADS, NC == 1 ? 
 #ifndef FW_LR_KEEP_MIN
 #define FW_LR_KEEP_MIN 128
 #endif
-            if (lr_upd) lr_update<OPT, COH>(p, s, nl, g, gx, lut_lr, tid, bd, 0u, 0xffffffffu, !NN && nl >= FW_LR_KEEP_MIN, lr_kept);
+            if (lr_upd) lr_update<OPT, COH>(p, s, nl, g, gx, lut_lr, tid, bd, 0u, 0xffffffffu, !NN && nl >= FW_LR_KEEP_MIN, lr_kept,
+                                            (kAtom || (NC == 2 && p.store_policy == 4)) && p.lr_thin && p.grid_wgs > 1 ? ex : 0xffffffffu);
             FW_TICK(4);
             // phase A, resident rows: w comes from registers (read once, in the gather); only acc is loaded.
             // Chained duplicates (WIN): a row that is chained to an earlier one is applied by that row's owner, and an owner WITH a

@@ -9,6 +9,9 @@
 
 #include "fwgpu_internal.h"
 
+#ifndef FWGPU_LR_THIN_DEFAULT  // store policy 4 also on hot LR entries (kernels.hip lr_update): measured in round 6 before it was decided, see DESIGN 4.2
+#define FWGPU_LR_THIN_DEFAULT 0
+#endif
 namespace fwgpu {
 
 static thread_local std::string g_last_error;
@@ -402,6 +405,9 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
         p.acc_hot_theta = theta + initial_acc(r->cfg.optimizer, r->cfg.ffm_init_acc_gradient);
         const int sm = r->launch.acc_sample_log2 >= 0 ? r->launch.acc_sample_log2 : (env_sm ? atoi(env_sm) : 3);
         p.acc_sample_log2 = (uint32_t)std::min(std::max(sm, 0), 6);  // (1u << it in the kernels: one example in 1 .. 64)
+        static const char *env_lt = getenv("FWGPU_LR_THIN");
+        p.lr_hot_theta = theta + initial_acc(r->cfg.optimizer, r->cfg.init_acc_gradient);
+        p.lr_thin = r->launch.lr_thin >= 0 ? r->launch.lr_thin : (env_lt ? atoi(env_lt) : FWGPU_LR_THIN_DEFAULT);
         static const char *env_tr = getenv("FWGPU_THIN_REREAD");
         p.thin_reread = env_tr ? atoi(env_tr) : 1;
         p.wb_flush_every = r->launch.wb_flush_every >= 0 ? (uint32_t)r->launch.wb_flush_every : (env_wb ? (uint32_t)atoi(env_wb) : 0xffffffffu);
@@ -962,6 +968,10 @@ int fwgpu_debug_set_option(fwgpu_regressor *r, int option, int value) {
     case 5:  // FFM row store policy of hogwild launches: 0 write-through, 1 weights write-back, 2 both tables write-back, -1 the build's default
         if (value < -1 || value > 4) return fail(FWGPU_ERR_INVALID, "store policy option: -1, 0, 1, 2, 3 or 4");
         r->launch.store_policy = value;
+        return FWGPU_OK;
+    case 12:  // store policy 4 also on hot LR entries (weight stored alone, accumulator by thinned atomic adds): 0 / 1, -1 = default
+        if (value < -1 || value > 1) return fail(FWGPU_ERR_INVALID, "LR thinning option: -1, 0 or 1");
+        r->launch.lr_thin = value;
         return FWGPU_OK;
     case 11:  // the deep head of concurrent two-chunk launches as a phase of the v2 kernel (1, default where two workgroups fit a CU) or always on the generic kernel (0); -1 = default
         if (value < -1 || value > 2) return fail(FWGPU_ERR_INVALID, "deep-head kernel option: -1, 0, 1 or 2");
