@@ -3302,7 +3302,7 @@ __global__ void __launch_bounds__(NN ? FW_NN_THREADS : FW_LB_THREADS, NC == 1 ? 
 #define FW_LR_KEEP_MIN 128
 #endif
             if (lr_upd) lr_update<OPT, COH>(p, s, nl, g, gx, lut_lr, tid, bd, 0u, 0xffffffffu, !NN && nl >= FW_LR_KEEP_MIN, lr_kept,
-                                            (kAtom || (NC == 2 && p.store_policy == 4)) && p.lr_thin && p.grid_wgs > 1 ? ex : 0xffffffffu);
+                                            (WIN && (kAtom || NC == 2) && p.store_policy == 4 && p.lr_thin && p.grid_wgs > 1) ? ex : 0xffffffffu);  // (the large-table path only)
             FW_TICK(4);
             // phase A, resident rows: w comes from registers (read once, in the gather); only acc is loaded.
             // Chained duplicates (WIN): a row that is chained to an earlier one is applied by that row's owner, and an owner WITH a

@@ -9,8 +9,8 @@
 
 #include "fwgpu_internal.h"
 
-#ifndef FWGPU_LR_THIN_DEFAULT  // store policy 4 also on hot LR entries (kernels.hip lr_update): measured in round 6 before it was decided, see DESIGN 4.2
-#define FWGPU_LR_THIN_DEFAULT 0
+#ifndef FWGPU_LR_THIN_DEFAULT  // store policy 4 also on hot LR entries of the large-table path (kernels.hip lr_update; DESIGN 4.2: shipped in round 6)
+#define FWGPU_LR_THIN_DEFAULT 1
 #endif
 namespace fwgpu {
 
@@ -406,7 +406,9 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
         const int sm = r->launch.acc_sample_log2 >= 0 ? r->launch.acc_sample_log2 : (env_sm ? atoi(env_sm) : 3);
         p.acc_sample_log2 = (uint32_t)std::min(std::max(sm, 0), 6);  // (1u << it in the kernels: one example in 1 .. 64)
         static const char *env_lt = getenv("FWGPU_LR_THIN");
-        p.lr_hot_theta = theta + initial_acc(r->cfg.optimizer, r->cfg.init_acc_gradient);
+        // (an LR entry's g^2 is (g v)^2 ~ 0.1-0.25 per hit where an FFM float's is ~1e-4: the same "stepped by more than a hundred examples" reads 64 x the FFM rows' threshold here)
+        static const char *env_ls = getenv("FWGPU_LR_HOT_SCALE");
+        p.lr_hot_theta = theta * (env_ls ? (float)atof(env_ls) : 64.0f) + initial_acc(r->cfg.optimizer, r->cfg.init_acc_gradient);
         p.lr_thin = r->launch.lr_thin >= 0 ? r->launch.lr_thin : (env_lt ? atoi(env_lt) : FWGPU_LR_THIN_DEFAULT);
         static const char *env_tr = getenv("FWGPU_THIN_REREAD");
         p.thin_reread = env_tr ? atoi(env_tr) : 1;

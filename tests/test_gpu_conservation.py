@@ -127,6 +127,7 @@ class Rig:
             re.table_write(capi.TABLE_FFM_W, np.full(R, W_HOT0, dtype=np.float32), hh)
         recs, off, which = _records(n, hot_field, self.ffm_bits, seed)
         b = re.record_batch(self.fbt, recs, off)
+        lr_acc0 = [float(re.table_read(capi.TABLE_LR, 2 * (hh & ((1 << 18) - 1)), 2)[1]) for hh in _hot_hashes()]  # (the hot feature's LR entries: {w, acc} pairs, 18-bit table)
         re.learn_batch(b, mode, True)
         p = b.predictions().astype(np.float64)
         b.close()
@@ -144,7 +145,10 @@ class Rig:
             else:
                 a = re.table_read(capi.TABLE_FFM_ACC, hh, R).astype(np.float64)
                 frac = (a[sel] - acc0) / ((ge * G_CONST) ** 2).sum()
-            out.append((float(np.mean(frac)), float(np.min(frac)), float(np.max(frac)), float(len(ge)) / n))
+            # the hot feature's LR entry (value 1, block_lr.rs:143-147): its accumulator must have grown by sum g_e^2 if every example's g^2 was counted
+            lr_acc1 = float(re.table_read(capi.TABLE_LR, 2 * (hh & ((1 << 18) - 1)), 2)[1])
+            lr_frac = (lr_acc1 - lr_acc0[q]) / float((ge ** 2).sum()) if self.opt != fw.Optimizer.SGD else float("nan")
+            out.append((float(np.mean(frac)), float(np.min(frac)), float(np.max(frac)), float(len(ge)) / n, lr_frac))
         # the partners never moved: spot-check a row
         assert np.all(re.table_read(capi.TABLE_FFM_W, 20000, 64) == W_PARTNER)
         return out
@@ -155,7 +159,7 @@ def test_in_order_launch_applies_every_step_under_every_policy():
     for opt in (fw.Optimizer.SGD, fw.Optimizer.AdagradLUT):
         rig = Rig(opt, 18)
         for policy in (0, 1, 2, 3, 4):
-            for mean, lo, hi, share in rig.run(600, 29, policy, 4, mode=capi.MODE_SEQUENTIAL, seed=3):
+            for mean, lo, hi, share, _lr in rig.run(600, 29, policy, 4, mode=capi.MODE_SEQUENTIAL, seed=3):
                 assert abs(lo - 1.0) < 2e-3 and abs(hi - 1.0) < 2e-3, (opt, policy, lo, hi)
         rig.close()
 
@@ -224,12 +228,14 @@ def test_thinned_atomic_adds_count_every_gradient_on_hot_rows(ffm_bits, capsys):
     all concurrent examples, which is what the reference's hogwild threads count (`acc += g * g` on coherent memory, optimizer.rs:147-149) -- where the
     store policies keep 0.15-0.45 of it (the table of the test above).  The rows start hot (accumulators at 2.0: beyond the default threshold of 0.5)."""
     rig = Rig(fw.Optimizer.AdagradLUT, ffm_bits)
-    table = {}
+    table, lr_table = {}, {}
     sizes = (2048, 16384, 65536)
     for n in sizes:
         for hot_field in (0, 29):
             for pol in (3, 4):
-                table[(n, hot_field, pol)] = float(np.mean([f[0] for f in rig.run(n, hot_field, pol, 0, acc_start=2.0)]))
+                fr = rig.run(n, hot_field, pol, 0, acc_start=2.0)
+                table[(n, hot_field, pol)] = float(np.mean([f[0] for f in fr]))
+                lr_table[(n, hot_field, pol)] = float(np.mean([f[4] for f in fr]))
             table[(n, hot_field, "4 L0")] = float(np.mean([f[0] for f in rig.run(n, hot_field, 4, 0, acc_start=2.0, lds_keep=0)]))
     rig.close()
     with capsys.disabled():
@@ -238,6 +244,14 @@ def test_thinned_atomic_adds_count_every_gradient_on_hot_rows(ffm_bits, capsys):
         for n in sizes:
             for hot_field in (0, 29):
                 print(f"  {n:6d}  {hot_field:9d} {table[(n, hot_field, 3)]:9.4f} {table[(n, hot_field, 4)]:9.4f} {table[(n, hot_field, '4 L0')]:9.4f}")
+    with capsys.disabled():
+        print("  the hot feature's LR entry (8-byte {w, acc} pair): share of sum g^2 its accumulator received -- policy 3: every holder stores the pair; policy 4: the weight alone is")
+        print("  stored and one example in eight adds eight times its g^2 once the entry is hot (accumulator > 32: after ~130 of its hits)")
+        for n in sizes:
+            print(f"  {n:6d}  " + "  ".join(f"field {hf}: policy 3 {lr_table[(n, hf, 3)]:.4f}, policy 4 {lr_table[(n, hf, 4)]:.4f}" for hf in (0, 29)))
+    for n in sizes[1:]:  # (the entry is hot from its ~130th hit on: 2 % of a 16 384-example launch's hits come before)
+        for hot_field in (0, 29):
+            assert lr_table[(n, hot_field, 4)] >= 0.9, (n, hot_field, lr_table[(n, hot_field, 4)])
     for n in sizes:
         tol = 0.1 if n > 2048 else 0.3  # (one example in eight is drawn: ~85 draws per row in the 2048-example launch)
         for hot_field in (0, 29):
