@@ -301,10 +301,10 @@ def measure_traffic(args):
                    f"the first three launches, where few rows are hot yet: {first / 1e9:.2f} GB = FETCH_SIZE {kb_first['FETCH_SIZE']:.0f} KB x2 + WRITE_SIZE {kb_first['WRITE_SIZE']:.0f} KB)")
 
 
-def _child_leg(cmd, timeout=420):
+def _child_leg(cmd, timeout=420, env=None):
     import subprocess
 
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, check=False)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, check=False, env=env)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     if p.returncode != 0 or not lines:
         raise RuntimeError((p.stderr or p.stdout)[-300:])
@@ -323,6 +323,21 @@ def config_e_leg(args):
         return {"value": d["value"], "unit": d["unit"], "final_logloss": d["final_logloss"], "oracle_final_logloss": d.get("oracle_final_logloss"),
                 "ms_per_step": d["ms_per_step"], "roofline_frac": d["roofline"]["frac"], "examples_learned": (d["steps"] + d["warmup"]) * 8192,
                 "holdout_examples": 65536, "workload": d["config"]["workload"], "kernel": d["roofline"]["kernel"]}
+    except Exception as e:  # a side measurement: never lose the bench line over it
+        return {"value": None, "error": repr(e)}
+
+
+def no_kept_rows_leg(args, steps, warmup):
+    """The same stream and the same number of launches with NO rows kept from the gather (fwgpu_debug_set_option 13 = 0 / FWGPU_KEPT_ROWS=0: every row re-read by the update, no
+    last-writer-wins over an example's lifetime): the concurrent mode whose hold-out curve on this stream IS the reference's (profiles/r06_kept_rows_long.txt) -- 14 % slower,
+    and on the second stream family 0.004 above the reference where the shipped mode is on it.  A reported side figure, never `value`."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-traffic", "--no-config-e", "--no-config-b",
+           "--fields", str(args.fields), "--k", str(args.k), "--bits", str(args.bits), "--ffm-bits", str(args.ffm_bits), "--holdout", str(args.holdout)]
+    try:
+        d = _child_leg(cmd, env=dict(os.environ, FWGPU_KEPT_ROWS="0"))
+        return {"value": d["value"], "unit": d["unit"], "final_logloss": d["final_logloss"], "oracle_final_logloss": d.get("oracle_final_logloss"),
+                "oracle_hogwild16_final_logloss": d.get("oracle_hogwild16_final_logloss"), "roofline_frac": d["roofline"]["frac"], "steps": d["steps"], "warmup": d["warmup"],
+                "what": "FWGPU_KEPT_ROWS=0: the large-table kernel re-reads every row in the update instead of writing 20 + 3 rows per wave back as w_gather - step"}
     except Exception as e:  # a side measurement: never lose the bench line over it
         return {"value": None, "error": repr(e)}
 
@@ -1152,6 +1167,7 @@ def main():
         out["config_e"] = config_e_leg(args)
         if args.config_b:
             out["config_b"] = config_b_leg(args)
+            out["no_kept_rows"] = no_kept_rows_leg(args, K, W)
     result_line = json.dumps(out) if out is not None else None
     if use_dist:
         dist.barrier()

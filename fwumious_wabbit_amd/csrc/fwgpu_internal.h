@@ -163,6 +163,7 @@ struct KernelParams {
     int32_t store_policy;               // hogwild launches of the v2 window kernel: how FFM row stores reach memory (kernels.hip "store policy"): 0 = both tables
                                         // device-scope write-through, 1 = weights write-back through the XCD's L2, 2 = both tables write-back
     float acc_hot_theta;                // policy 3: a kept row whose accumulators exceed this is "hot": its accumulator row is stored for one example in
+    int32_t no_kept_rows;               // the large-table kernel without rows kept from the gather (fwgpu_debug_set_option 13 / FWGPU_KEPT_ROWS=0): every row re-read by the update
     float lr_hot_theta;                 // store policy 4 on the LR block: an entry whose accumulator exceeds this is hot (its initial value + the FFM rows' theta)
     int32_t lr_thin;                    // ... on (1) / off (0): FWGPU_LR_THIN, fwgpu_debug_set_option 12
     int32_t nn_v2;                      // deep head as a phase of the v2 kernel's two-chunk instantiation (config E's concurrent launches; prepare_launch decides)
@@ -247,6 +248,7 @@ struct LaunchConfig {
     int32_t no_chain = 0;            // debug option 3
     uint32_t hot_lr_every = 1;       // debug option 4: hot LR entry route (0 off, 1 atomics per example, n>1 weight deltas pending n examples)
     int32_t store_policy = -1;       // debug option 5: FFM row store policy of hogwild launches (-1: the build's default, kDefaultStorePolicy)
+    int32_t kept_rows = -1;          // debug option 13: 0 = no rows kept from the gather in the large-table kernel (-1: FWGPU_KEPT_ROWS or kept)
     int32_t lr_thin = -1;            // debug option 12: store policy 4 also on hot LR entries (-1: FWGPU_LR_THIN or the build's default)
     int32_t nn_v2 = -1;              // debug option 11: deep head of concurrent two-chunk launches on the v2 kernel (-1: FWGPU_NN_V2 or on)
     float acc_hot_theta = -1.0f;     // debug option 9: policies 3 / 4, a row is hot once its accumulators have grown by this much (-1: FWGPU_ACC_HOT_THETA or 0.5)

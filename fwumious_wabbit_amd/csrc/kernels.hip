@@ -3565,6 +3565,8 @@ static hipError_t launch_r(const KernelParams &p, uint32_t grid, uint32_t thread
         if (COH && p.store_policy == 0) return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR_WIN, true, 1, COH ? 0 : FW_DEFAULT_STORE_POLICY>, p, grid, threads, lds, stream);
         if (COH && p.store_policy == 2) return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR_WIN, true, 1, COH ? 2 : FW_DEFAULT_STORE_POLICY>, p, grid, threads, lds, stream);
         if (COH && p.store_policy == 3) return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR_WIN, true, 1, COH ? 3 : FW_DEFAULT_STORE_POLICY>, p, grid, threads, lds, stream);
+        // (no rows kept from the gather -- every row re-read by the update: the concurrent mode without last-writer-wins over an example's lifetime; option 13, policy 4 only)
+        if (COH && p.store_policy == 4 && p.no_kept_rows) return launch_persistent(fw_example_kernel_r<OPT, COH, 0, true, 1, COH ? 4 : FW_DEFAULT_STORE_POLICY>, p, grid, threads, lds, stream);
         if (COH && p.store_policy == 4) return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR_WIN, true, 1, COH ? 4 : FW_DEFAULT_STORE_POLICY>, p, grid, threads, lds, stream);
         return launch_persistent(fw_example_kernel_r<OPT, COH, FW_MAXR_WIN, true, 1, COH ? 1 : FW_DEFAULT_STORE_POLICY>, p, grid, threads, lds, stream);
     }
@@ -3615,7 +3617,7 @@ void resolve_row_mode(KernelParams &p, uint32_t threads) {
     // (two-chunk rows only: config C's kernel has the LDS to spare, and the choice costs its update two vector registers it does not have)
     p.no_selfw = (uses_resident_kernel(p, threads) && (!p.update || (p.window && p.concurrent && p.R > 64 * 4 && !selfw_lds_forced))) ? 1 : 0;
     // rows kept in LDS beyond the register-kept ones: the chained-update instantiation of single-chunk rows only (fw_example_kernel_r, FW_LDS_KEEP_MAX)
-    if (!(p.lut_lds_forced && p.window) || FW_KEEP_LAST) p.lds_keep = 0;
+    if (!(p.lut_lds_forced && p.window) || FW_KEEP_LAST || p.no_kept_rows) p.lds_keep = 0;
     if (p.lds_keep > FW_LDS_KEEP_MAX) p.lds_keep = FW_LDS_KEEP_MAX;
     p.lds_keep_words = p.lds_keep * (threads / 64) * p.R;
 }

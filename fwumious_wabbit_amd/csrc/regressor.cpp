@@ -405,6 +405,8 @@ KernelParams make_params(const fwgpu_regressor *r, const fwgpu_batch *b, int upd
         p.acc_hot_theta = theta + initial_acc(r->cfg.optimizer, r->cfg.ffm_init_acc_gradient);
         const int sm = r->launch.acc_sample_log2 >= 0 ? r->launch.acc_sample_log2 : (env_sm ? atoi(env_sm) : 3);
         p.acc_sample_log2 = (uint32_t)std::min(std::max(sm, 0), 6);  // (1u << it in the kernels: one example in 1 .. 64)
+        static const char *env_kr = getenv("FWGPU_KEPT_ROWS");
+        p.no_kept_rows = (r->launch.kept_rows >= 0 ? r->launch.kept_rows == 0 : (env_kr && env_kr[0] == '0')) ? 1 : 0;
         static const char *env_lt = getenv("FWGPU_LR_THIN");
         // (an LR entry's g^2 is (g v)^2 ~ 0.1-0.25 per hit where an FFM float's is ~1e-4: the same "stepped by more than a hundred examples" reads 64 x the FFM rows' threshold here)
         static const char *env_ls = getenv("FWGPU_LR_HOT_SCALE");
@@ -970,6 +972,10 @@ int fwgpu_debug_set_option(fwgpu_regressor *r, int option, int value) {
     case 5:  // FFM row store policy of hogwild launches: 0 write-through, 1 weights write-back, 2 both tables write-back, -1 the build's default
         if (value < -1 || value > 4) return fail(FWGPU_ERR_INVALID, "store policy option: -1, 0, 1, 2, 3 or 4");
         r->launch.store_policy = value;
+        return FWGPU_OK;
+    case 13:  // rows kept from the gather in the large-table kernel: 0 = none (every row re-read by the update: no last-writer-wins over an example's lifetime), 1 / -1 = kept (default)
+        if (value < -1 || value > 1) return fail(FWGPU_ERR_INVALID, "kept-rows option: -1, 0 or 1");
+        r->launch.kept_rows = value;
         return FWGPU_OK;
     case 12:  // store policy 4 also on hot LR entries (weight stored alone, accumulator by thinned atomic adds): 0 / 1, -1 = default
         if (value < -1 || value > 1) return fail(FWGPU_ERR_INVALID, "LR thinning option: -1, 0 or 1");

@@ -404,6 +404,11 @@ class Regressor:
         check(self.L.fwgpu_debug_set_option(self.h, 9, -1 if theta < 0 else int(round(theta * 1024))))
         check(self.L.fwgpu_debug_set_option(self.h, 10, int(sample_log2)))
 
+    def set_kept_rows(self, on):
+        """HOGWILD launches of the large-table kernel keep 20 + 3 rows per wave from the gather and write them back as w_gather - step (1, default: the faster learner, damped on the rows
+        many examples hold) or re-read every row in the update (0: 14 % slower; on the bench's stream the reference's own curve) -- fwgpu_debug_set_option 13"""
+        check(self.L.fwgpu_debug_set_option(self.h, 13, int(on)))
+
     def set_head_kernel(self, v2):
         """deep head of HOGWILD launches with two-chunk rows (config E): as a phase of the large-table kernel (1; default -1 = where two workgroups fit a CU)
         or on the generic kernel (0) -- fwgpu_debug_set_option 11"""

@@ -456,6 +456,9 @@ int fwgpu_debug_set_kernel_version(fwgpu_regressor *r, int version);
  *   policy 1 / 2 a workgroup writes its XCD's dirty L2 lines back every `value` of its examples (0 = only when the launch ends; -1 = the
  *   build's default: 128) -- the bound on how long a popular row can stay private to one XCD (DESIGN.md 4.2,
  *   tests/test_gpu_conservation.py).  SEQUENTIAL launches are exact under every policy.
+ * option 13: rows the large-table kernel keeps from the gather (20 in registers + 3 in LDS per wave, written back as w_gather - step): 1 (default, -1) = kept; 0 = none, every row is
+ *   re-read by the update (14 % slower; without the damping of rows many concurrent examples hold -- on BASELINE configs[2]'s stream the reference's own hold-out curve).
+ * option 12: store policy 4 also on hot LR entries of that kernel (the weight stored alone, the accumulator by thinned atomic adds): 1 (default, -1) / 0.
  * option 11: HOGWILD launches of a model with a deep head and rows of 257..512 floats (BASELINE config E: k = 16 at 30 fields): 1 (default, -1) = the head runs
  *   as a phase of the large-table kernel, two 512-thread workgroups per CU, where they fit; 0 = always on the generic kernel (one 1024-thread workgroup per CU).
  *   SEQUENTIAL launches take the generic kernel (the parity mode) unless value 2 forces them onto the large-table kernel too (tests of that kernel's head phase).

@@ -7,7 +7,7 @@ initialised weights, learns the same batches, and is scored on the same hold-out
   python scripts/long_variants.py --steps 1024 --family 1 --out gpurun_out/x.json  "name:policy=4,theta=0.05,m=3,inflight=512"  "shipped:"  ...
 
 Variant keys: policy (store policy 0-4), theta / m (hot-row threshold, log2 of the sampling: options 9 / 10), inflight (fwgpu_set_max_in_flight),
-wb (write-back interval, option 6), keep (rows parked in LDS, option 8), lrthin (store policy 4 on hot LR entries, option 12), reps (passes of this variant, default 1), lib (path of a variant libfwgpu.so:
+wb (write-back interval, option 6), keep (rows parked in LDS, option 8), lrthin (store policy 4 on hot LR entries, option 12), kept (0: no rows kept from the gather, option 13), reps (passes of this variant, default 1), lib (path of a variant libfwgpu.so:
 run in a child process -- NOT supported here: use FWGPU_LIBRARY on the whole script).
 Prints one JSON document: per variant examples/s (wall clock around the training launches, checkpoints excluded by events) and the hold-out curve."""
 import argparse
@@ -80,6 +80,7 @@ def main():
         re.set_max_in_flight(int(opt.get("inflight", 0)))
         re.set_lds_keep(int(opt.get("keep", -1)))
         capi.check(capi.lib().fwgpu_debug_set_option(re.h, 12, int(opt.get("lrthin", -1))))
+        capi.check(capi.lib().fwgpu_debug_set_option(re.h, 13, int(opt.get("kept", -1))))
         for rep in range(reps):
             re.allocate_and_init_weights()
             torch.cuda.synchronize()

@@ -53,7 +53,7 @@ def test_smoke_entry():
 
 # ------------------------------------------------------------------ streams: sequential mode == reference single thread
 def _stream_parity(n_ns, k, bits, ffm_bits, optimizer, n, mean_extra, p_weighted, ids, seed, interactions=(),
-                   weight_tol=2e-5, whole_lines=None, lds_keep=None, **kw):
+                   weight_tol=2e-5, whole_lines=None, lds_keep=None, kept_rows=None, **kw):
     mi, ocfg, ots = make_pair(n_ns, k, bits, ffm_bits, optimizer, interactions=interactions, **kw)
     recs, off = fw.synth_records(n_ns, mean_extra, 1.1, ids, p_weighted, seed, 0, n)
     y = record_labels(recs, off)
@@ -67,6 +67,8 @@ def _stream_parity(n_ns, k, bits, ffm_bits, optimizer, n, mean_extra, p_weighted
             re.set_whole_line_updates(whole_lines)
         if lds_keep is not None:
             re.set_lds_keep(lds_keep)
+        if kept_rows is not None:
+            re.set_kept_rows(kept_rows)
         fbt = fw.FeatureBufferTranslator(mi)
         b = re.batch_from_records(fbt, recs, off) if kind == "entries" else re.record_batch(fbt, recs, off)
         re.learn_batch(b, capi.MODE_SEQUENTIAL, True)
@@ -113,6 +115,15 @@ _PARKED_CASES = {
                  kw=dict(n=150, mean_extra=6.5, p_weighted=0.2, ids=20000, seed=63, init_acc=1.0, ffm_init_acc=1.0, weight_tol=5e-5, whole_lines=2)),
     "sgd": dict(args=(30, 8, 16, 16, fw.Optimizer.SGD), kw=dict(n=150, mean_extra=6.5, p_weighted=0.2, ids=20000, seed=64, lr=0.05, ffm_lr=0.05, whole_lines=3)),
 }
+
+
+def test_large_table_kernel_without_kept_rows_in_order():
+    """fwgpu_debug_set_option 13 = 0 (round 6): the large-table kernel with NO rows kept from the gather -- its own instantiation, every row re-read by the update.  In order it is the
+    reference like every other path: per example and on the final tables, three optimizers, collisions and repeated hashes included."""
+    _stream_parity(30, 8, 16, 16, fw.Optimizer.AdagradLUT, n=150, mean_extra=5.67, p_weighted=0.1, ids=3000, seed=62, whole_lines=3, kept_rows=0)
+    _stream_parity(30, 8, 17, 17, fw.Optimizer.AdagradLUT, n=60, mean_extra=7.6, p_weighted=0.1, ids=2000, seed=76, whole_lines=2, kept_rows=0)
+    _stream_parity(30, 8, 16, 16, fw.Optimizer.AdagradFlex, n=100, mean_extra=6.5, p_weighted=0.2, ids=20000, seed=63, init_acc=1.0, ffm_init_acc=1.0, weight_tol=5e-5, whole_lines=3, kept_rows=0)
+    _stream_parity(30, 8, 16, 16, fw.Optimizer.SGD, n=100, mean_extra=6.5, p_weighted=0.2, ids=20000, seed=64, lr=0.05, ffm_lr=0.05, whole_lines=3, kept_rows=0)
 
 
 def test_parked_rows_at_every_share_size_around_the_register_capacity():
