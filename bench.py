@@ -445,6 +445,41 @@ def long_protocol(args):
     n_final = K * B
     seq_final = oc["seq"].get(n_final)
     hog_final = [c.get(n_final) for c in oc["hog16"] if c.get(n_final) is not None]
+    # One more pass WITHOUT rows kept from the gather (fwgpu_debug_set_option 13 = 0): every row re-read by the update, no last-writer-wins over an example's lifetime on the rows many
+    # examples hold -- the concurrent mode whose curve on BASELINE configs[2]'s stream is the reference's own.  Reported beside the shipped mode's passes.
+    no_kept = None
+    if not args.nn_layers and args.k % 4 == 0 and args.fields * args.k <= 256:
+        re.set_kept_rows(0)
+        re.allocate_and_init_weights()
+        torch.cuda.synchronize()
+        nk_curve = {}
+        t_start = time.perf_counter()
+        t_ckpt = 0.0
+        for i in range(K):
+            re.learn_batch(batches[i], capi.MODE_HOGWILD, True, sptr)
+            if (i + 1) % every == 0 or i + 1 == K:
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                re.learn_batch(hbatch, capi.MODE_HOGWILD, False, sptr)
+                nk_curve[(i + 1) * B] = logloss(hbatch.predictions(sptr), hy)
+                t_ckpt += time.perf_counter() - t1
+        nk_elapsed = time.perf_counter() - t_start - t_ckpt
+        re.set_kept_rows(-1)
+        ref_nk = float(np.mean(hog_final)) if hog_final else seq_final
+
+        def ref_at(n):  # the reference's concurrent mode at n examples (its single thread where no hogwild curve covers n)
+            v = [c.get(n) for c in oc["hog16"] if c.get(n) is not None]
+            return float(np.mean(v)) if v else oc["seq"].get(n)
+
+        gaps = {n: abs(v - ref_at(n)) for n, v in nk_curve.items() if ref_at(n) is not None}
+        lo_n = min(nk_curve, key=nk_curve.get)
+        no_kept = {"what": "one pass with fwgpu_debug_set_option(h, 13, 0) / FWGPU_KEPT_ROWS=0: every row re-read by the update", "examples_per_sec": K * B / nk_elapsed,
+                   "final_logloss": nk_curve[K * B], "abs_diff": (abs(nk_curve[K * B] - ref_nk) if ref_nk is not None else None),
+                   "within": (bool(abs(nk_curve[K * B] - ref_nk) <= LONG_TOLERANCE) if ref_nk is not None else None),
+                   "largest_abs_diff_at_any_checkpoint": (max(gaps.values()) if gaps else None),
+                   "largest_abs_diff_from_a_quarter_of_the_run_on": (max(v for n, v in gaps.items() if n >= K * B // 4) if gaps else None),
+                   "rise_after_minimum": nk_curve[K * B] - nk_curve[lo_n], "minimum_at_examples": lo_n,
+                   "logloss_after_examples": {str(n): v for n, v in sorted(nk_curve.items())}}
     spread = max(finals) - min(finals)
     refs = [v for v in [seq_final] + hog_final if v is not None]
     alg_bytes = float(np.mean([algorithmic_bytes(args, batches[i], words[i]) for i in range(K)]))
@@ -470,6 +505,7 @@ def long_protocol(args):
         # reference's own concurrent mode (16-thread hogwild; its single thread where no hogwild curve of this length is committed) -- and, beside it, whether the GPU's
         # curve is non-increasing after its minimum (within the larger of the run-to-run spread and 0.001): reported as measured, both of them.
         "final_logloss_vs_oracle": (two_sided_verdict(finals, merged, seq_final, hog_final, spread) if refs else None),
+        "no_kept_rows": no_kept,
         "holdout_prior_logloss": logloss(np.full(len(hy), float(np.mean(hy == 1)), dtype=np.float64), hy),
         "logloss_after_examples": {str(n): v for n, v in sorted(merged.items())},
         "oracle_logloss_after_examples": {str(n): oc["seq"].get(n) for n in sorted(merged)},
