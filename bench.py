@@ -154,7 +154,7 @@ def oracle_reference_curves(args, world, holdout=None):
             continue
         curve = dict(zip(d["examples"], d[key]))
         if d.get("threads", 1) == 1:
-            out["seq"] = curve
+            out["seq"].update(curve)  # (the sequential curve is deterministic: a longer run's file only adds checkpoints)
         else:
             out["hog16"].append(curve)
     return out
