@@ -74,7 +74,7 @@ def test_second_stream_family_at_config_c_size_two_sided():
     assert d["final_logloss"] < d["holdout_prior_logloss"] - 0.05
 
 
-LONG64_TOL = 0.005  # 1.3 x the largest |GPU - oracle hogwild16| measured at 64 Mi examples (0.0023 / 0.0037 on two passes: profiles/r06_store_policy4_long64_b.txt against 0.6378)
+LONG64_TOL = 0.006  # 1.3 x the largest |GPU - oracle hogwild16| measured at 64 Mi examples over twelve passes of the shipped build (0.0024 .. 0.0045 BELOW the reference's 0.6378: profiles/r06_bench_long64.json, r06_lr_thinning_ab.txt)
 
 
 @pytest.mark.timeout(1500)
@@ -82,7 +82,7 @@ def test_the_metrics_protocol_at_64_mi_examples_two_sided():
     """The metric's own protocol run OUT: 64 Mi training examples of BASELINE configs[2]'s stream (116 GB of records resident in HBM), the 262 144-example hold-out,
     two passes from freshly initialised weights -- `bench.py --long --examples 67108864` -- against the committed curve of the reference's own concurrent mode (the CPU oracle's
     16-thread hogwild run on the same stream, tests/golden/bench_oracle_curve_hog16_r4_64mi.json: 0.6378 at the end, flat within 0.001 from 17 M examples on).
-    TWO-sided.  bench.py's own verdict uses the tolerance stated before the runs were made (0.003; the two passes measured read 0.0023 and 0.0037 BELOW the reference, so it can go
+    TWO-sided.  bench.py's own verdict uses the tolerance stated before the runs were made (0.003; the shipped build's passes read 0.0024 .. 0.0045 BELOW the reference, so it goes
     either way); this test's bound follows the suite's rule for statistical tests, 1.3 x the largest gap measured.  The curve's shape is asserted as it is: a minimum between 4 M and 10 M
     examples 0.012-0.017 below the reference, then a rise to a plateau the last quarter of the run no longer leaves (|final - value at 48 Mi| <= 0.002)."""
     import multiprocessing
